@@ -1,0 +1,253 @@
+"""Generate golden vectors by executing the reference's OWN layer classes
+(unmodified, imported from /root/reference behind fake_tensorflow.py) and
+its own graph_structure.py / graph_topology.py.
+
+BUILD-CONTAINER ONLY.  Usage:
+    PYTHONDONTWRITEBYTECODE=1 python oracle/refshim/gen_golden.py
+
+Writes small .npz files (inputs + expected outputs, data only) into
+tests/golden/.  The reference source itself never leaves /root/reference.
+
+What each file pins (reference file:line):
+  lap_*.npz      graph_structure.py:22-55,85-130   degree_list, CSR indptr/indices/data (f64)
+  topo_*.npz     tf_modules/graph_topology.py:84-135  padded feeds + int32 slices
+  sgc_*.npz      layers/graphconv.py:85-252          SGC_LL fwd + TF-autodiff grads
+  reslap_*.npz   layers/graphconv_reslap.py:45-230   SGC_LL_Reslap (single layer and 2-layer chain)
+  gather_*.npz   layers/graphgather.py:40-77         GraphGatherMol fwd + grads
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import load_reference  # noqa: E402
+import agcn_oracle as orc  # noqa: E402  (only for the synthetic topology / feature generators)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _graphs(rs, ns, Fin, gs, atoms):
+    graphs = []
+    for n in ns:
+        adj = orc.synth_adj_lists(rs, int(n))
+        if atoms and Fin == 75:
+            x = orc.synth_atom_features(rs, int(n))
+        else:
+            x = np.maximum(rs.randn(int(n), Fin), 0).astype(np.float32)
+            if n >= 6:              # force duplicate rows (r_ij == 0 path)
+                x[3] = x[1]
+        graphs.append(gs.MolGraph(x, adj))
+    return graphs
+
+
+def _feed(ftf, topo_cls, graphs, Fin, B, max_atom):
+    topo = topo_cls(n_feat=Fin, batch_size=B, max_atom=max_atom)
+    fd = topo.batch_to_feed_dict(np.array(graphs, dtype=object))
+    X = [np.asarray(fd[p], dtype=np.float32) for p in topo.get_atom_features_placeholder()]
+    L = [np.asarray(fd[p], dtype=np.float32) for p in topo.get_laplacians_placeholder()]
+    ds = np.asarray(fd[topo.get_dataslice_placeholders()])
+    ls = np.asarray(fd[topo.get_lapslice_placeholders()])
+    assert ds.dtype == np.int32 and ls.dtype == np.int32
+    return X, L, ds, ls
+
+
+def _pad_sq(t_list, ns, max_atom):
+    out = np.zeros((len(ns), max_atom, max_atom), dtype=np.float32)
+    for b, (t, n) in enumerate(zip(t_list, ns)):
+        a = t.t.detach().numpy() if hasattr(t, "t") else np.asarray(t)
+        assert a.shape == (n, n), (a.shape, n)
+        out[b, :n, :n] = a
+    return out
+
+
+def _grad(v):
+    return None if v.t.grad is None else v.t.grad.detach().numpy().copy()
+
+
+def _param_overrides(rs, Fin, Fout, K, reslap, fancy):
+    """fancy => non-trivial bias/alpha/beta so that every term is exercised;
+    otherwise the reference's own initial values (bias 0, alpha = beta = 1)."""
+    ov = {}
+    if fancy:
+        ov["bias"] = (0.1 * rs.randn(Fout)).astype(np.float32)
+        ov["alpha"] = np.array([0.7], dtype=np.float32)
+        if reslap:
+            ov["beta"] = np.array([1.3], dtype=np.float32)
+    return ov
+
+
+def run_layer_case(ftf, layers, gs, topo_cls, name, variant, ns, Fin, Fout, K, seed, fancy,
+                   atoms=False, chain=False):
+    rs = np.random.RandomState(seed)
+    B = len(ns)
+    max_atom = int(max(ns)) + int(rs.randint(0, 4))
+    graphs = _graphs(rs, ns, Fin, gs, atoms)
+    Xn, Ln, ds, ls = _feed(ftf, topo_cls, graphs, Fin, B, max_atom)
+    X = [ftf.Tensor(torch.from_numpy(x.copy()).requires_grad_(True)) for x in Xn]
+    L = [ftf.Tensor(torch.from_numpy(l.copy())) for l in Ln]
+    dsT, lsT = ftf.constant(ds), ftf.constant(ls)
+    reslap = variant == "reslap"
+    save = dict(variant=np.array(1 if reslap else 0), ns=np.asarray(ns, np.int32), K=np.array(K),
+                Fin=np.array(Fin), Fout=np.array(Fout), max_atom=np.array(max_atom),
+                X=np.stack(Xn), L=np.stack(Ln), data_slice=ds, lap_slice=ls, chain=np.array(int(chain)))
+
+    ftf.reset_state(seed + 1000, _param_overrides(rs, Fin, Fout, K, reslap, fancy))
+    if not reslap:
+        l1 = layers.SGC_LL(Fout, Fin, B, activation="relu", K=K)
+        inp = {"node_features": X, "original_laplacian": L, "data_slice": dsT, "lap_slice": lsT}
+        out1 = l1(inp)
+        assert len(out1) == 3
+        Y, resL, resW = out1
+        Lsum = None
+    else:
+        l1 = layers.SGC_LL_Reslap(Fout, Fin, B, activation="relu", K=K, save_lap=True)
+        inp = {"node_features": X, "original_laplacian": L, "data_slice": dsT, "lap_slice": lsT,
+               "res_lap": [][-B:]}            # tf_graphs.py:184 on an empty stack
+        out1 = l1(inp)
+        assert len(out1) == 4
+        Y, resL, resW, Lsum = out1
+
+    def dump(prefix, layer, Yl, rL, rW, Ls):
+        for k, v in layer.vars.items():
+            save[prefix + "p_" + k] = v.t.detach().numpy().copy()
+        save[prefix + "Y"] = np.stack([y.t.detach().numpy() for y in Yl])
+        save[prefix + "res_L"] = _pad_sq(rL, ns, max_atom)
+        save[prefix + "res_W"] = _pad_sq(rW, ns, max_atom)
+        if Ls is not None:
+            save[prefix + "L_sum"] = _pad_sq(Ls, ns, max_atom)
+
+    dump("l1_", l1, Y, resL, resW, Lsum)
+    final = Y
+    if chain:
+        ftf.reset_state(seed + 2000, _param_overrides(rs, Fout, Fout, K, True, fancy))
+        l2 = layers.SGC_LL_Reslap(Fout, Fout, B, activation="relu", K=K)
+        inp2 = {"node_features": Y, "original_laplacian": L, "data_slice": dsT, "lap_slice": lsT,
+                "res_lap": list(Lsum)[-B:]}   # tf_graphs.py:184,193-194
+        Y2, resL2, resW2, Lsum2 = l2(inp2)
+        dump("l2_", l2, Y2, resL2, resW2, Lsum2)
+        final = Y2
+
+    G = rs.randn(B, max_atom, Fout).astype(np.float32)
+    save["G"] = G
+    loss = sum((y.t * torch.from_numpy(G[b])).sum() for b, y in enumerate(final))
+    loss.backward()
+    save["dX"] = np.stack([_grad(x) for x in X])
+    for prefix, layer in (("l1_", l1),) + ((("l2_", l2),) if chain else ()):
+        for k, v in layer.vars.items():
+            g = _grad(v)
+            save[prefix + "has_d_" + k] = np.array(int(g is not None))
+            save[prefix + "d_" + k] = g if g is not None else np.zeros_like(v.t.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print("wrote", name, "B=%d max_atom=%d" % (B, max_atom))
+
+
+def run_lap_cases(gs):
+    rs = np.random.RandomState(7)
+    cases = {
+        "ring6": [[(i - 1) % 6, (i + 1) % 6] for i in range(6)],
+        "path4": [[1], [0, 2], [1, 3], [2]],
+        "star5": [[1, 2, 3, 4], [0], [0], [0], [0]],
+        "asym5": [[1], [2], [3], [4], []],              # one-directional lists: symmetrised by networkx
+        "isolated6": [[1], [0], [], [4, 5], [3], [3]],  # node 2 has degree 0
+        "selfloop4": [[0, 1], [0, 2], [1, 3], [2]],     # explicit self reference
+        "tiny3": [[1], [0, 2], [1]],                    # n <= 3 -> no Laplacian
+    }
+    for n in (4, 5, 7, 18, 48, 132):
+        cases["tree%d" % n] = orc.synth_adj_lists(rs, n)
+    for name, adj in cases.items():
+        n = len(adj)
+        g = gs.MolGraph(np.zeros((n, 3), dtype=np.float32), adj)
+        save = dict(n=np.array(n), has_lap=np.array(int(g.has_Lap)),
+                    degree_list=g.degree_list,
+                    adj_flat=np.array([j for a in adj for j in a], dtype=np.int64),
+                    adj_ptr=np.cumsum([0] + [len(a) for a in adj]).astype(np.int64))
+        if g.has_Lap:
+            Lm = g.Laplacian
+            assert Lm.dtype == np.float64
+            Ls = Lm.copy()
+            Ls.sort_indices()
+            save.update(indptr=Lm.indptr, indices=Lm.indices, data=Lm.data,
+                        sorted_indices=Ls.indices, sorted_data=Ls.data,
+                        dense=np.asarray(Lm.todense()))
+        np.savez_compressed(os.path.join(OUT, "lap_%s.npz" % name), **save)
+    print("wrote %d lap cases" % len(cases))
+
+
+def run_topo_case(ftf, gs, topo_cls):
+    rs = np.random.RandomState(11)
+    ns = [4, 9, 5, 17]
+    graphs = _graphs(rs, ns, 75, gs, atoms=True)
+    X, L, ds, ls = _feed(ftf, topo_cls, graphs, 75, len(ns), 20)
+    np.savez_compressed(
+        os.path.join(OUT, "topo_tox4.npz"), ns=np.asarray(ns, np.int32), max_atom=np.array(20),
+        feat=np.concatenate([g.node_features for g in graphs]),
+        lap_dense=np.concatenate([np.asarray(g.Laplacian.todense()).reshape(-1) for g in graphs]),
+        X=np.stack(X), L=np.stack(L), data_slice=ds, lap_slice=ls)
+    print("wrote topo_tox4")
+
+
+def run_gather_case(ftf, layers):
+    rs = np.random.RandomState(13)
+    ns, F, max_atom = [4, 7, 5, 12, 6], 9, 14
+    Xn = np.zeros((len(ns), max_atom, F), dtype=np.float32)
+    for b, n in enumerate(ns):
+        Xn[b, :n] = rs.randn(n, F)
+        Xn[b, n:] = 5.0          # garbage in the pad rows must not reach the sum (DenseMol bias lands there)
+    X = [ftf.Tensor(torch.from_numpy(Xn[b].copy()).requires_grad_(True)) for b in range(len(ns))]
+    ds = np.asarray([[n, -1] for n in ns], dtype=np.int32)
+    for act in ("tanh", "relu"):
+        for x in X:
+            x.t.grad = None
+        layer = layers.GraphGatherMol(len(ns), activation=act)
+        out = layer({"node_features": X, "data_slice": ftf.constant(ds)})
+        G = rs.randn(len(ns), F).astype(np.float32)
+        (out.t * torch.from_numpy(G)).sum().backward()
+        np.savez_compressed(os.path.join(OUT, "gather_%s.npz" % act), ns=np.asarray(ns, np.int32),
+                            X=Xn, data_slice=ds, out=out.t.detach().numpy(), G=G,
+                            dX=np.stack([_grad(x) for x in X]))
+    print("wrote gather cases")
+
+
+def main():
+    assert load_reference.available(), "reference tree not found"
+    os.makedirs(OUT, exist_ok=True)
+    ftf, layers, gs = load_reference.load()
+    import importlib.util
+    # tf_modules/__init__.py drags in h5py/rdkit; load the one file directly instead
+    spec = importlib.util.spec_from_file_location(
+        "agcn_ref_graph_topology",
+        os.path.join(load_reference.REF_ROOT, "models", "tf_modules", "graph_topology.py"))
+    topo_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(topo_mod)
+    topo_cls = topo_mod.GraphTopologyMol
+
+    run_lap_cases(gs)
+    run_topo_case(ftf, gs, topo_cls)
+    run_gather_case(ftf, layers)
+
+    L = (ftf, layers, gs, topo_cls)
+    #                 name                 variant   ns                 Fin Fout K seed fancy
+    run_layer_case(*L, "sgc_small",        "sgc",    [4, 5, 7],          5,  4, 2, 1, False)
+    run_layer_case(*L, "sgc_small_fancy",  "sgc",    [4, 5, 7, 6],       5,  4, 2, 2, True)
+    run_layer_case(*L, "sgc_k1",           "sgc",    [5, 9],             6,  8, 1, 3, True)
+    run_layer_case(*L, "sgc_k3",           "sgc",    [6, 11, 4],         7,  5, 3, 4, True)
+    run_layer_case(*L, "sgc_tox_l1",       "sgc",    [18, 48, 7, 23],   75, 64, 2, 5, False, atoms=True)
+    run_layer_case(*L, "sgc_tox_l3",       "sgc",    [18, 33, 5],      128, 128, 2, 6, True)
+    run_layer_case(*L, "sgc_n132",         "sgc",    [132, 4],          75, 64, 2, 7, True, atoms=True)
+    run_layer_case(*L, "reslap_small",     "reslap", [4, 5, 7],          5,  4, 2, 8, False)
+    run_layer_case(*L, "reslap_fancy",     "reslap", [6, 9, 4, 13],      7,  6, 2, 9, True)
+    run_layer_case(*L, "reslap_k1",        "reslap", [5, 8],             6,  4, 1, 10, True)
+    run_layer_case(*L, "reslap_tox",       "reslap", [18, 48, 7],       75, 64, 2, 11, True, atoms=True)
+    run_layer_case(*L, "reslap_chain",     "reslap", [4, 9, 6, 12],      7,  6, 2, 12, True, chain=True)
+    run_layer_case(*L, "reslap_chain_tox", "reslap", [18, 30, 5],       75, 64, 2, 13, False, atoms=True,
+                   chain=True)
+
+
+if __name__ == "__main__":
+    main()
