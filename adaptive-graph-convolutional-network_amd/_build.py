@@ -1,0 +1,42 @@
+"""Builds csrc/ into lib/libagcn_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libagcn_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def _deps():
+    root = os.path.dirname(HERE)
+    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(root, "include", "agcn.h")]
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into one shared library (in-tree)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-o", LIB_PATH] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout)
+    return LIB_PATH

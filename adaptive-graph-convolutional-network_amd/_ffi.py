@@ -1,0 +1,117 @@
+"""ctypes binding of the C ABI in include/agcn.h.  No compute happens in Python: this module
+only marshals pointers.  The library is REQUIRED: there is no CPU or torch fallback, and
+loading fails loudly if lib/libagcn_hip.so is missing."""
+import ctypes as C
+import os
+
+from . import _build
+
+_lib = None
+
+
+class AgcnError(RuntimeError):
+    pass
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N1", C.c_int32), ("rows", C.c_int32), ("max_n", C.c_int32),
+                ("N2", C.c_int64), ("tile_elems", C.c_int64), ("plan_bytes", C.c_int64),
+                ("off_n", C.c_int64), ("off_row_off", C.c_int64), ("off_tile_off", C.c_int64),
+                ("off_order", C.c_int64), ("off_wtile_off", C.c_int64)]
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("Fin", C.c_int32), ("Fout", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32),
+                ("variant", C.c_int32), ("activation", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32)]
+
+
+class GraphBatch(C.Structure):
+    _fields_ = [("plan_host", C.c_void_p), ("plan_dev", C.c_void_p), ("X", C.c_void_p),
+                ("L0_dense", C.c_void_p), ("L0_ld", C.c_int32), ("reserved0", C.c_int32),
+                ("L0_rowptr", C.c_void_p), ("L0_col", C.c_void_p), ("L0_val", C.c_void_p),
+                ("L_prev", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("M_L", C.c_void_p),
+                ("alpha", C.c_void_p), ("beta", C.c_void_p)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("Y", C.c_void_p), ("res_L", C.c_void_p), ("res_W", C.c_void_p), ("L_sum", C.c_void_p)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("dX", C.c_void_p), ("dweight", C.c_void_p), ("dbias", C.c_void_p), ("dM_L", C.c_void_p),
+                ("dalpha", C.c_void_p), ("dbeta", C.c_void_p), ("dL_prev", C.c_void_p)]
+
+
+MODE = {"reference": 0, "paper": 1}
+VARIANT = {"SGC_LL": 0, "SGC_LL_Reslap": 1}
+ACT = {None: 0, "linear": 0, "relu": 1, "tanh": 2}
+
+# every symbol include/agcn.h declares (tests/test_abi.py checks the two lists agree)
+SYMBOLS = [
+    "agcn_plan_bytes", "agcn_plan_build", "agcn_plan_info",
+    "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
+    "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
+    "agcn_graph_gather_forward", "agcn_graph_gather_backward",
+    "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
+]
+
+
+def _declare(lib):
+    P, I32, SZ = C.c_void_p, C.c_int32, C.c_size_t
+    lib.agcn_plan_bytes.restype = SZ
+    lib.agcn_plan_bytes.argtypes = [I32]
+    lib.agcn_plan_build.restype = C.c_int
+    lib.agcn_plan_build.argtypes = [P, I32, I32, P, SZ]
+    lib.agcn_plan_info.restype = C.c_int
+    lib.agcn_plan_info.argtypes = [P, C.POINTER(PlanInfo)]
+    for name in ("agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes",
+                 "agcn_sgc_ll_backward_workspace_bytes"):
+        f = getattr(lib, name)
+        f.restype = SZ
+        f.argtypes = [C.POINTER(LayerDesc), P]
+    lib.agcn_sgc_ll_forward.restype = C.c_int
+    lib.agcn_sgc_ll_forward.argtypes = [C.POINTER(LayerDesc), C.POINTER(GraphBatch), C.POINTER(Params),
+                                        C.POINTER(Outputs), P, SZ, P, SZ, P]
+    for name in ("agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params"):
+        f = getattr(lib, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(LayerDesc), C.POINTER(GraphBatch), C.POINTER(Params),
+                      C.POINTER(Outputs), P, P, C.POINTER(Grads), P, SZ, P, SZ, P]
+    lib.agcn_graph_gather_forward.restype = C.c_int
+    lib.agcn_graph_gather_forward.argtypes = [P, P, P, I32, I32, I32, P, P]
+    lib.agcn_graph_gather_backward.restype = C.c_int
+    lib.agcn_graph_gather_backward.argtypes = [P, P, P, P, I32, I32, I32, P, P]
+    lib.agcn_version.restype = I32
+    lib.agcn_version.argtypes = []
+    lib.agcn_last_error.restype = C.c_char_p
+    lib.agcn_last_error.argtypes = []
+    lib.agcn_get_lds_limit.restype = I32
+    lib.agcn_get_lds_limit.argtypes = []
+    lib.agcn_set_lds_limit.restype = None
+    lib.agcn_set_lds_limit.argtypes = [I32]
+
+
+def lib():
+    """The loaded C-ABI library.  torch must be imported first so that the HIP runtime that
+    is already in the process (torch's libamdhip64.so.7) satisfies the library's dependency."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (loads libamdhip64 before our .so resolves it)
+        path = os.environ.get("AGCN_HIP_LIB", _build.LIB_PATH)
+        if not os.path.exists(path):
+            raise AgcnError(
+                "HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % path)
+        l = C.CDLL(path)
+        _declare(l)
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AgcnError("agcn error %d: %s" % (rc, lib().agcn_last_error().decode()))

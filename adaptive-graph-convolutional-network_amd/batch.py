@@ -1,0 +1,179 @@
+"""Ragged batches of graphs on the device.
+
+Replaces the reference's feed construction (`models/tf_modules/graph_topology.py:84-135`:
+every graph zero-padded to max_atom, the CSR Laplacian densified every step, int32
+data_slice / lap_slice tensors) by one packed layout that the kernels index directly:
+
+    rows   graph b owns rows [row_off[b], row_off[b+1]) of every node-feature matrix
+    tiles  graph b owns n_b x n_b floats at tile_off[b] of every per-graph square output
+    L0     the original Laplacians as one CSR over the row space (f32 values, local columns)
+
+The integer bookkeeping (the *plan*) is built by the C library on the host
+(`agcn_plan_build`) and uploaded once per batch.
+"""
+import ctypes as C
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+
+class Plan(object):
+    """Host + device copies of the plan blob, plus numpy views of its arrays."""
+
+    def __init__(self, n_nodes, row_stride=0, device=None):
+        lib = _ffi.lib()
+        n = np.ascontiguousarray(np.asarray(n_nodes, dtype=np.int32))
+        if n.ndim != 1 or n.size < 1:
+            raise ValueError("n_nodes must be a non-empty 1-D array")
+        B = int(n.size)
+        nbytes = lib.agcn_plan_bytes(B)
+        self.host = np.zeros(nbytes, dtype=np.uint8)
+        _ffi.check(lib.agcn_plan_build(n.ctypes.data, B, int(row_stride), self.host.ctypes.data, nbytes))
+        info = _ffi.PlanInfo()
+        _ffi.check(lib.agcn_plan_info(self.host.ctypes.data, C.byref(info)))
+        self.info = info
+        self.B, self.N1, self.rows, self.max_n = info.B, info.N1, info.rows, info.max_n
+        self.N2, self.tile_elems = info.N2, info.tile_elems
+        self.row_stride = int(row_stride)
+
+        def view(off, dtype, count):
+            return self.host[off:off + count * np.dtype(dtype).itemsize].view(dtype)
+
+        self.n = view(info.off_n, np.int32, B)
+        self.row_off = view(info.off_row_off, np.int32, B + 1)
+        self.tile_off = view(info.off_tile_off, np.int64, B + 1)
+        self.order = view(info.off_order, np.int32, B)
+        self.dev = None
+        self.device = None
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        device = torch.device(device)
+        if self.dev is None or self.device != device:
+            self.dev = torch.from_numpy(self.host).to(device)
+            self.device = device
+        return self
+
+    @property
+    def host_ptr(self):
+        return self.host.ctypes.data
+
+    @property
+    def dev_ptr(self):
+        return self.dev.data_ptr()
+
+
+class TileViews(Sequence):
+    """Lazy list of per-graph [n_b, n_b] views into a packed tile tensor (what the reference
+    returns as a Python list of B tensors: graphconv.py:252)."""
+
+    def __init__(self, data, plan):
+        self.data, self.plan = data, plan
+
+    def __len__(self):
+        return self.plan.B
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            idx = range(*i.indices(len(self)))
+            if len(idx) == len(self) and i.step in (None, 1):
+                return self
+            return [self[j] for j in idx]
+        if i < 0:
+            i += len(self)
+        n, off = int(self.plan.n[i]), int(self.plan.tile_off[i])
+        return self.data[off:off + n * n].view(n, n)
+
+
+class RowViews(Sequence):
+    """Lazy list of per-graph node-feature matrices.  With padded rows (row_stride > 0) item b
+    is the reference's [max_atom, F] tensor; with packed rows it is [n_b, F]."""
+
+    def __init__(self, data, plan):
+        self.data, self.plan = data, plan
+
+    def __len__(self):
+        return self.plan.B
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            idx = range(*i.indices(len(self)))
+            if len(idx) == len(self) and i.step in (None, 1):
+                return self
+            return [self[j] for j in idx]
+        if i < 0:
+            i += len(self)
+        return self.data[int(self.plan.row_off[i]):int(self.plan.row_off[i + 1])]
+
+
+class GraphBatch(object):
+    """A batch of graphs resident on the device in the packed layout."""
+
+    def __init__(self, plan, X, l0_rowptr=None, l0_col=None, l0_val=None, l0_dense=None, l0_ld=0):
+        self.plan = plan
+        self.X = X
+        self.l0_rowptr, self.l0_col, self.l0_val = l0_rowptr, l0_col, l0_val
+        self.l0_dense, self.l0_ld = l0_dense, int(l0_ld)
+
+    @property
+    def device(self):
+        return self.X.device
+
+    @classmethod
+    def from_graphs(cls, graphs, device, dtype=torch.float32):
+        """Packed batch from `Graph`/`MolGraph`-like objects (node_features [n,F] array and a
+        scipy CSR `Laplacian`).  This is the ingest that replaces pad_data2sparse /
+        pad_Lap2sparse / batch_to_feed_dict (graph_topology.py:84-135)."""
+        graphs = list(graphs)
+        n = np.array([g.node_features.shape[0] for g in graphs], dtype=np.int32)
+        for g in graphs:
+            if getattr(g, "Laplacian", None) is None:
+                raise ValueError("graph without a Laplacian (n <= 3 graphs are dropped by the reference loader)")
+        X = np.concatenate([np.asarray(g.node_features, dtype=np.float32) for g in graphs], axis=0)
+        csr = [(g.Laplacian.indptr, g.Laplacian.indices, g.Laplacian.data) for g in graphs]
+        return cls.from_arrays(n, X, csr, device)
+
+    @classmethod
+    def from_arrays(cls, n, X, csr_list, device):
+        """n int32 [B]; X float32 [N1, F] packed; csr_list = [(indptr, indices, data)] per graph."""
+        plan = Plan(n, 0, device)
+        nnz = np.array([len(c[1]) for c in csr_list], dtype=np.int64)
+        rowptr = np.zeros(plan.rows + 1, dtype=np.int32)
+        base = np.concatenate([[0], np.cumsum(nnz)])
+        for b, (ip, _, _) in enumerate(csr_list):
+            r0 = int(plan.row_off[b])
+            rowptr[r0 + 1:r0 + int(n[b]) + 1] = np.asarray(ip[1:], dtype=np.int64) + base[b]
+        col = np.concatenate([np.asarray(c[1], dtype=np.int32) for c in csr_list]) if len(csr_list) else np.zeros(0, np.int32)
+        val = np.concatenate([np.asarray(c[2]).astype(np.float32) for c in csr_list]) if len(csr_list) else np.zeros(0, np.float32)
+        dev = torch.device(device)
+        return cls(plan, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev),
+                   torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev))
+
+    @classmethod
+    def from_padded(cls, node_features, laplacians, data_slice, device=None):
+        """Batch in the REFERENCE's feed layout: node_features / laplacians are lists of B
+        [max_atom, F] / [max_atom, max_atom] tensors (or one 3-D tensor each), data_slice is the
+        int32 [B, 2] array with rows [n, -1] (graph_topology.py:90).  Rows stay padded
+        (row_stride = max_atom) so outputs alias the reference's per-graph tensors."""
+        X3 = node_features if torch.is_tensor(node_features) else torch.stack(list(node_features))
+        L3 = laplacians if torch.is_tensor(laplacians) else torch.stack(list(laplacians))
+        ds = data_slice.detach().cpu().numpy() if torch.is_tensor(data_slice) else np.asarray(data_slice)
+        n = np.ascontiguousarray(ds[:, 0], dtype=np.int32)
+        B, max_atom, F = X3.shape
+        if L3.shape != (B, max_atom, max_atom) or n.shape[0] != B:
+            raise ValueError("inconsistent padded batch shapes")
+        device = X3.device if device is None else torch.device(device)
+        plan = Plan(n, max_atom, device)
+        X = X3.to(device=device, dtype=torch.float32).reshape(B * max_atom, F)
+        L = L3.to(device=device, dtype=torch.float32).contiguous()
+        return cls(plan, X, l0_dense=L, l0_ld=max_atom)
+
+    def rows(self, data):
+        return RowViews(data, self.plan)
+
+    def tiles(self, data):
+        return TileViews(data, self.plan)

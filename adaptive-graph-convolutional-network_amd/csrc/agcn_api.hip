@@ -1,0 +1,303 @@
+// C ABI glue for the SGC_LL / SGC_LL_Reslap layer (include/agcn.h): argument validation,
+// reserve/workspace carving, LDS-vs-global tile scheduling and kernel launches.
+// No allocation, no synchronisation, everything on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include "sgc_kernels.h"
+
+namespace agcn {
+size_t sgc_lds_bytes_bwd(int32_t n, int32_t Fin);
+
+namespace {
+
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+  float* take(size_t floats) {
+    float* r = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += align256(floats * sizeof(float));
+    return r;
+  }
+};
+
+int check_desc(const AgcnLayerDesc* d, const char* who) {
+  if (!d) return fail(AGCN_EINVAL, "%s: null layer descriptor", who);
+  if (d->Fin < 1 || d->Fin > 1024 || d->Fout < 1 || d->Fout > 1024)
+    return fail(AGCN_EINVAL, "%s: Fin/Fout must be in [1, 1024] (got %d, %d)", who, d->Fin, d->Fout);
+  if (d->K < 1 || d->K > 64) return fail(AGCN_EINVAL, "%s: K must be in [1, 64] (got %d)", who, d->K);
+  if (d->mode != AGCN_MODE_REFERENCE && d->mode != AGCN_MODE_PAPER)
+    return fail(AGCN_EINVAL, "%s: unknown laplacian mode %d", who, d->mode);
+  if (d->variant != AGCN_SGC_LL && d->variant != AGCN_SGC_LL_RESLAP)
+    return fail(AGCN_EINVAL, "%s: unknown layer variant %d", who, d->variant);
+  if (d->activation != AGCN_ACT_LINEAR && d->activation != AGCN_ACT_RELU)
+    return fail(AGCN_EINVAL, "%s: unsupported activation %d (linear or relu)", who, d->activation);
+  if (d->ldx < d->Fin || d->ldy < d->Fout) return fail(AGCN_EINVAL, "%s: ldx/ldy smaller than Fin/Fout", who);
+  return AGCN_OK;
+}
+
+// Graphs are scheduled largest first; the leading ones whose on-chip image exceeds the LDS
+// limit run with their tile in global scratch.
+int count_global(const PlanView& host, int32_t Fin, bool bwd) {
+  const size_t limit = (size_t)agcn_get_lds_limit();
+  int g = 0;
+  for (int i = 0; i < host.info.B; ++i) {
+    const int32_t nb = host.n[host.order[i]];
+    const size_t need = bwd ? sgc_lds_bytes_bwd(nb, Fin) : sgc_lds_bytes(nb, Fin);
+    if (need > limit) ++g; else break;
+  }
+  return g;
+}
+
+struct ReserveLayout { size_t s, scal, X, Lpre, total; };
+ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
+  Carver c(nullptr);
+  ReserveLayout r;
+  r.s = c.off; c.take((size_t)pi.rows);
+  r.scal = c.off; c.take((size_t)4 * pi.B);
+  r.X = c.off; c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
+  r.Lpre = c.off; if (d->variant == AGCN_SGC_LL_RESLAP) c.take((size_t)pi.tile_elems);
+  r.total = c.off;
+  return r;
+}
+
+int n_chunks_for(int32_t rows) {
+  int c = (rows + 255) / 256;
+  if (c < 1) c = 1;
+  if (c > 128) c = 128;
+  return c;
+}
+
+void fill_common(SgcArgs& a, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnParams* p,
+                 const AgcnOutputs* o, const PlanView& dev) {
+  std::memset(&a, 0, sizeof(a));
+  a.n = dev.n; a.row_off = dev.row_off; a.tile_off = dev.tile_off; a.order = dev.order;
+  a.wtile_off = dev.wtile_off;
+  a.B = dev.info.B; a.rows = dev.info.rows;
+  a.Fin = d->Fin; a.Fout = d->Fout; a.K = d->K; a.mode = d->mode; a.variant = d->variant;
+  a.activation = d->activation; a.ldx = d->ldx; a.ldy = d->ldy;
+  a.X = g->X; a.L0_dense = g->L0_dense; a.L0_ld = g->L0_ld; a.L0_rowptr = g->L0_rowptr;
+  a.L0_col = g->L0_col; a.L0_val = g->L0_val;
+  a.L_prev = d->variant == AGCN_SGC_LL_RESLAP ? g->L_prev : nullptr;
+  a.weight = p->weight; a.bias = p->bias; a.M_L = p->M_L; a.alpha = p->alpha; a.beta = p->beta;
+  a.Y = o->Y; a.res_L = o->res_L; a.res_W = o->res_W; a.L_sum = o->L_sum;
+}
+
+int check_batch(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnParams* p, const char* who) {
+  if (!g || !p) return fail(AGCN_EINVAL, "%s: null batch/params", who);
+  if (!g->plan_host || !g->plan_dev || !g->X) return fail(AGCN_EINVAL, "%s: null plan or X", who);
+  if (g->L0_dense && g->L0_rowptr) return fail(AGCN_EINVAL, "%s: give the original Laplacian dense OR CSR, not both", who);
+  if (g->L0_rowptr && (!g->L0_col || !g->L0_val)) return fail(AGCN_EINVAL, "%s: incomplete CSR Laplacian", who);
+  if (g->L0_ld < 0) return fail(AGCN_EINVAL, "%s: negative L0_ld", who);
+  if (!p->weight || !p->bias || !p->M_L || !p->alpha) return fail(AGCN_EINVAL, "%s: null parameter", who);
+  if (d->variant == AGCN_SGC_LL_RESLAP && g->L_prev && !p->beta)
+    return fail(AGCN_EINVAL, "%s: L_prev given without beta", who);
+  return AGCN_OK;
+}
+
+}  // namespace
+}  // namespace agcn
+
+using namespace agcn;
+
+extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
+  AgcnPlanInfo pi;
+  if (check_desc(desc, "agcn_sgc_ll_reserve_bytes") != AGCN_OK || agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;
+  return reserve_layout(desc, pi).total + 256;
+}
+
+static size_t global_scratch_floats(const AgcnLayerDesc* d, const PlanView& host, bool bwd, Carver* c,
+                                    float** tile, float** buf) {
+  const int ng = count_global(host, d->Fin, bwd);
+  *tile = *buf = nullptr;
+  if (ng > 0) {
+    *tile = c->take((size_t)host.wtile_off[host.info.B]);
+    *buf = c->take((size_t)host.info.rows * (size_t)(d->Fin | 1));
+  }
+  return ng;
+}
+
+extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
+  PlanView host;
+  if (check_desc(desc, "agcn_sgc_ll_forward_workspace_bytes") != AGCN_OK ||
+      plan_view(plan_host, plan_host, &host) != AGCN_OK) return 0;
+  Carver c(nullptr);
+  float *t, *b;
+  global_scratch_floats(desc, host, false, &c, &t, &b);
+  return c.off + 256;
+}
+
+struct BwdWs { float *g, *dZ, *pg, *part, *tile, *buf; int n_chunks; int64_t part_stride; int n_glb; };
+
+static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
+  Carver c(ws);
+  const AgcnPlanInfo& pi = host.info;
+  const bool paper = d->mode == AGCN_MODE_PAPER;
+  w->g = c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
+  w->dZ = paper ? c.take((size_t)pi.rows * d->Fin) : nullptr;
+  w->pg = c.take((size_t)2 * pi.B);
+  w->n_chunks = n_chunks_for(pi.rows);
+  w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
+  w->part_stride = (w->part_stride + 3) / 4 * 4;
+  w->part = c.take((size_t)w->n_chunks * w->part_stride);
+  w->n_glb = (int)global_scratch_floats(d, host, true, &c, &w->tile, &w->buf);
+  return c.off;
+}
+
+extern "C" size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
+  PlanView host;
+  if (check_desc(desc, "agcn_sgc_ll_backward_workspace_bytes") != AGCN_OK ||
+      plan_view(plan_host, plan_host, &host) != AGCN_OK) return 0;
+  BwdWs w;
+  return carve_bwd(desc, host, nullptr, &w) + 256;
+}
+
+extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
+                                   const AgcnParams* params, const AgcnOutputs* out, void* reserve,
+                                   size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                   void* hip_stream) {
+  const char* who = "agcn_sgc_ll_forward";
+  int rc = check_desc(desc, who);
+  if (rc != AGCN_OK) return rc;
+  rc = check_batch(desc, batch, params, who);
+  if (rc != AGCN_OK) return rc;
+  if (!out || !out->Y || !out->res_L || !out->res_W) return fail(AGCN_EINVAL, "%s: null output", who);
+  const bool reslap = desc->variant == AGCN_SGC_LL_RESLAP;
+  if (reslap && !out->L_sum) return fail(AGCN_EINVAL, "%s: SGC_LL_Reslap needs the L_sum output", who);
+  PlanView host, dev;
+  rc = plan_view(batch->plan_host, batch->plan_host, &host);
+  if (rc != AGCN_OK) return rc;
+  plan_view(batch->plan_host, batch->plan_dev, &dev);
+  const ReserveLayout rl = reserve_layout(desc, host.info);
+  if (!reserve || reserve_bytes < rl.total) return fail(AGCN_ENOSPACE, "%s: reserve too small (%zu < %zu)", who, reserve_bytes, rl.total);
+
+  SgcArgs a;
+  fill_common(a, desc, batch, params, out, dev);
+  char* rb = static_cast<char*>(reserve);
+  a.sv_s = reinterpret_cast<float*>(rb + rl.s);
+  a.sv_scal = reinterpret_cast<float*>(rb + rl.scal);
+  a.sv_X = reinterpret_cast<float*>(rb + rl.X);
+  a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
+
+  Carver c(workspace);
+  const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
+  if (c.off > workspace_bytes || (n_glb > 0 && !workspace))
+    return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, c.off);
+
+  const int B = host.info.B;
+  if (n_glb > 0) {
+    const size_t lds = 4 * (32 + (size_t)((host.info.max_n + 3) & ~3));
+    rc = launch_sgc_forward(a, 0, n_glb, false, lds, hip_stream);
+    if (rc != AGCN_OK) return rc;
+  }
+  if (n_glb < B) {
+    const size_t lds = sgc_lds_bytes(host.n[host.order[n_glb]], desc->Fin);
+    rc = launch_sgc_forward(a, n_glb, B - n_glb, true, lds, hip_stream);
+    if (rc != AGCN_OK) return rc;
+  }
+  return AGCN_OK;
+}
+
+// stages: bit 0 = per-graph adjoints (dX, dL_prev, dZ, per-graph dalpha/dbeta partials),
+//         bit 1 = parameter gradients (dweight, dbias, dM_L, dalpha, dbeta)
+static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
+                         const AgcnParams* params, const AgcnOutputs* fwd, const float* dY,
+                         const float* dL_sum, const AgcnGrads* grads, const void* reserve,
+                         size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                         void* hip_stream, int stages, const char* who) {
+  int rc = check_desc(desc, who);
+  if (rc != AGCN_OK) return rc;
+  rc = check_batch(desc, batch, params, who);
+  if (rc != AGCN_OK) return rc;
+  if (!fwd || !fwd->Y || !fwd->res_L || !fwd->res_W || !dY) return fail(AGCN_EINVAL, "%s: null forward tensor / dY", who);
+  const bool reslap = desc->variant == AGCN_SGC_LL_RESLAP;
+  const bool paper = desc->mode == AGCN_MODE_PAPER;
+  if (reslap && !fwd->L_sum) return fail(AGCN_EINVAL, "%s: SGC_LL_Reslap needs L_sum", who);
+  if (!grads || !grads->dX || !grads->dweight || !grads->dbias || !grads->dalpha)
+    return fail(AGCN_EINVAL, "%s: null gradient output", who);
+  if (paper && !grads->dM_L) return fail(AGCN_EINVAL, "%s: paper mode needs dM_L", who);
+  const bool has_prev = reslap && batch->L_prev != nullptr;
+  if (has_prev && (!grads->dbeta || !grads->dL_prev)) return fail(AGCN_EINVAL, "%s: L_prev given but dbeta/dL_prev null", who);
+
+  PlanView host, dev;
+  rc = plan_view(batch->plan_host, batch->plan_host, &host);
+  if (rc != AGCN_OK) return rc;
+  plan_view(batch->plan_host, batch->plan_dev, &dev);
+  const ReserveLayout rl = reserve_layout(desc, host.info);
+  if (!reserve || reserve_bytes < rl.total) return fail(AGCN_ENOSPACE, "%s: reserve too small", who);
+  BwdWs w;
+  const size_t need = carve_bwd(desc, host, workspace, &w);
+  if (!workspace || workspace_bytes < need) return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, need);
+
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  SgcArgs a;
+  fill_common(a, desc, batch, params, fwd, dev);
+  char* rb = const_cast<char*>(static_cast<const char*>(reserve));
+  a.sv_s = reinterpret_cast<float*>(rb + rl.s);
+  a.sv_scal = reinterpret_cast<float*>(rb + rl.scal);
+  a.sv_X = reinterpret_cast<float*>(rb + rl.X);
+  a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
+  a.dY = dY; a.dL_sum = dL_sum; a.dX = grads->dX; a.dL_prev = has_prev ? grads->dL_prev : nullptr;
+  a.ws_g = w.g; a.ws_dZ = w.dZ; a.ws_pg = w.pg; a.ws_tile = w.tile; a.ws_buf = w.buf;
+
+  // Reslap with K == 1 and no incoming dL_sum: L never reaches Y, so dL_prev == 0
+  const bool need_dL = (reslap || paper) && (desc->K > 1 || dL_sum != nullptr);
+  if ((stages & 1) && has_prev && !need_dL) {
+    hipError_t e = hipMemsetAsync(grads->dL_prev, 0, (size_t)host.info.tile_elems * sizeof(float), s);
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
+  }
+
+  const int B = host.info.B;
+  if (stages & 1) {
+    if (w.n_glb > 0) {
+      const size_t lds = 4 * (32 + 2 * (size_t)((host.info.max_n + 3) & ~3));
+      rc = launch_sgc_backward(a, 0, w.n_glb, false, lds, hip_stream);
+      if (rc != AGCN_OK) return rc;
+    }
+    if (w.n_glb < B) {
+      const size_t lds = sgc_lds_bytes_bwd(host.n[host.order[w.n_glb]], desc->Fin);
+      rc = launch_sgc_backward(a, w.n_glb, B - w.n_glb, true, lds, hip_stream);
+      if (rc != AGCN_OK) return rc;
+    }
+  }
+  if (!(stages & 2)) return AGCN_OK;
+
+  ParamGradArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.rows = host.info.rows; pa.Fin = desc->Fin; pa.Fout = desc->Fout; pa.K = desc->K;
+  pa.activation = desc->activation; pa.ldx = desc->ldx; pa.ldy = desc->ldy; pa.paper = paper ? 1 : 0;
+  pa.n_chunks = w.n_chunks;
+  pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 3) / 4 * 4;
+  pa.B = B; pa.part_stride = w.part_stride;
+  pa.X = batch->X; pa.sv_X = a.sv_X; pa.Y = fwd->Y; pa.dY = dY; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
+  pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
+  pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
+  return launch_param_grads(pa, hip_stream);
+}
+
+extern "C" int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
+                                    const AgcnParams* params, const AgcnOutputs* fwd, const float* dY,
+                                    const float* dL_sum, const AgcnGrads* grads, const void* reserve,
+                                    size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                    void* hip_stream) {
+  return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
+                       workspace_bytes, hip_stream, 3, "agcn_sgc_ll_backward");
+}
+
+extern "C" int agcn_sgc_ll_backward_nodes(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
+                                          const AgcnParams* params, const AgcnOutputs* fwd, const float* dY,
+                                          const float* dL_sum, const AgcnGrads* grads, const void* reserve,
+                                          size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                          void* hip_stream) {
+  return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
+                       workspace_bytes, hip_stream, 1, "agcn_sgc_ll_backward_nodes");
+}
+
+extern "C" int agcn_sgc_ll_backward_params(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
+                                           const AgcnParams* params, const AgcnOutputs* fwd, const float* dY,
+                                           const float* dL_sum, const AgcnGrads* grads, const void* reserve,
+                                           size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                           void* hip_stream) {
+  return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
+                       workspace_bytes, hip_stream, 2, "agcn_sgc_ll_backward_params");
+}

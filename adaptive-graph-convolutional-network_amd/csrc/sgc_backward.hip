@@ -1,0 +1,383 @@
+// Backward of SGC_LL / SGC_LL_Reslap: one workgroup per graph for everything that is local
+// to a graph (dX, the chain through the learned Laplacian, dZ, dL_prev, per-graph dalpha /
+// dbeta); the parameter gradients that reduce over all rows (dweight, dbias, dM_L) are
+// formed by param_grads.hip.
+//
+// The reference gets these from TF autodiff (models/tf_modules/multitask_classifier.py:237)
+// of models/layers/graphconv.py:127-252 / graphconv_reslap.py:91-230; the analytic form is
+// SURVEY.md Appendix A.
+//
+//   Q1  g_k = (dY . act') . W_k^T                      k = 0..K-1      (MFMA f32)
+//   Q2  tile = L  (L_sum for Reslap, res_L + L_orig for SGC_LL)
+//   Q3  Chebyshev adjoint: g_{k-1} += c L^T g_k, g_{k-2} -= g_k       (MFMA f32)
+//   Q5  dL = sum_k c_k g_k X_{k-1}^T (+ dL_sum)                       (MFMA f32)
+//   Q6  chain: leaky-ReLU / clip adjoints, dalpha, dbeta, dL_prev; paper mode continues
+//       through R = I - s S s, S = exp(-r), r = ||Z_i - Z_j|| to dZ, dX += dZ M^T
+#include "agcn_device.h"
+#include "sgc_kernels.h"
+
+namespace agcn {
+
+template <bool LDS_TILE>
+__global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(SgcArgs a, int first) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int b = a.order[first + blockIdx.x];
+  const int n = a.n[b];
+  const int row0 = a.row_off[b];
+  const int nrows_owned = a.row_off[b + 1] - row0;
+  const int64_t toff = a.tile_off[b];
+  const int Fin = a.Fin, Fout = a.Fout, K = a.K;
+  const int ldt = n | 1, ldb = Fin | 1;
+  const int ldx = a.ldx, ldy = a.ldy;
+  const bool reslap = a.variant == AGCN_SGC_LL_RESLAP;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const bool relu = a.activation == AGCN_ACT_RELU;
+
+  float* red = smem;               // 32
+  float* s_vec = smem + 32;        // n   s_i
+  float* v1 = s_vec + round4(n);   // n   dd_j, later rowsum(c)_i
+  float* tile;
+  float* buf;
+  if (LDS_TILE) {
+    tile = v1 + round4(n);
+    buf = tile + round4(n * ldt);
+  } else {
+    tile = a.ws_tile + a.wtile_off[b];
+    buf = a.ws_buf + (int64_t)row0 * ldb;
+  }
+  const float* Xg = a.X + (int64_t)row0 * ldx;
+  const float* Yg = a.Y + (int64_t)row0 * ldy;
+  const float* dYg = a.dY + (int64_t)row0 * ldy;
+  float* dXg = a.dX + (int64_t)row0 * ldx;
+  const int64_t row_stride_F = (int64_t)a.rows * Fin;   // stride between k-planes of sv_X / ws_g
+  const FastDiv divn((uint32_t)n);
+  const int nn = n * n;
+  const float alpha = a.alpha[0];
+
+  auto gptr = [&](int k) -> float* {  // adjoint of X_k; g_0 lives in dX
+    return a.ws_g + (int64_t)(k - 1) * row_stride_F + (int64_t)row0 * Fin;
+  };
+  auto xptr = [&](int k) -> const float* { return a.sv_X + (int64_t)(k - 1) * row_stride_F + (int64_t)row0 * Fin; };
+
+  // ---- Q1: g_k = Gp . W_k^T ----------------------------------------------------------------
+  {
+    const float* Wt = a.weight;
+    for (int k = 0; k < K; ++k) {
+      float* gk = (k == 0) ? dXg : gptr(k);
+      const int ldg = (k == 0) ? ldx : Fin;
+      wg_gemm<2>(
+          n, Fin, Fout,
+          [&](int i, int c) {
+            if (i >= n || c >= Fout) return 0.f;
+            const float g = dYg[(int64_t)i * ldy + c];
+            return (!relu || Yg[(int64_t)i * ldy + c] > 0.f) ? g : 0.f;
+          },
+          [&](int c, int f) { return (c < Fout && f < Fin) ? Wt[(int64_t)(f * K + k) * Fout + c] : 0.f; },
+          [&](int i, int f, float v) { if (i < n && f < Fin) gk[(int64_t)i * ldg + f] = v; });
+    }
+  }
+  // paper mode: Z = X . M_L is needed again (r_ij and dZ); buf is otherwise unused here
+  if (paper) {
+    const float* M = a.M_L;
+    wg_gemm<2>(
+        n, Fin, Fin,
+        [&](int i, int k) { return (i < n && k < Fin) ? Xg[(int64_t)i * ldx + k] : 0.f; },
+        [&](int k, int c) { return (k < Fin && c < Fin) ? M[k * Fin + c] : 0.f; },
+        [&](int i, int c, float v) { if (i < n && c < Fin) buf[i * ldb + c] = v; });
+    for (int j = tid; j < n; j += nthr) s_vec[j] = a.sv_s[row0 + j];
+  }
+  __syncthreads();
+
+  const bool l0_dense = a.L0_dense != nullptr;
+  const bool l0_csr = a.L0_rowptr != nullptr;
+  const bool has_prev = reslap && a.L_prev != nullptr;
+
+  if (K > 1) {
+    // ---- Q2: tile = L ------------------------------------------------------------------------
+    if (reslap) {
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        tile[i * ldt + j] = a.L_sum[toff + idx];
+      }
+    } else {
+      const float* L0d = nullptr;
+      int l0ld = n;
+      if (l0_dense) {
+        if (a.L0_ld > 0) { L0d = a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld; l0ld = a.L0_ld; }
+        else { L0d = a.L0_dense + toff; }
+      }
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        float v = a.res_L[toff + idx];
+        if (l0_dense) v = v + L0d[(int64_t)i * l0ld + j];
+        tile[i * ldt + j] = v;
+      }
+      if (l0_csr) {
+        __syncthreads();
+        const int32_t* rp = a.L0_rowptr + row0;
+        for (int i = tid; i < n; i += nthr) {
+          const int p0 = rp[i], p1 = rp[i + 1];
+          for (int p = p0; p < p1; ++p) tile[i * ldt + a.L0_col[p]] += a.L0_val[p];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- Q3: adjoint of the Chebyshev recurrence, k = K-1 .. 1 ---------------------------------
+    for (int k = K - 1; k >= 1; --k) {
+      const float ck = (k >= 2) ? 2.0f : 1.0f;
+      const float* gk = gptr(k);
+      float* gkm1 = (k == 1) ? dXg : gptr(k - 1);
+      const int ldm1 = (k == 1) ? ldx : Fin;
+      wg_gemm<2>(
+          n, Fin, n,
+          [&](int i, int kk) { return (i < n && kk < n) ? tile[kk * ldt + i] : 0.f; },  // L^T
+          [&](int kk, int f) { return (kk < n && f < Fin) ? gk[(int64_t)kk * Fin + f] : 0.f; },
+          [&](int i, int f, float v) {
+            if (i < n && f < Fin) gkm1[(int64_t)i * ldm1 + f] += ck * v;
+          });
+      if (k >= 2) {
+        float* gkm2 = (k == 2) ? dXg : gptr(k - 2);
+        const int ldm2 = (k == 2) ? ldx : Fin;
+        const FastDiv divF((uint32_t)Fin);
+        for (int idx = tid; idx < n * Fin; idx += nthr) {
+          const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
+          gkm2[(int64_t)i * ldm2 + f] -= gk[(int64_t)i * Fin + f];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // dX pad rows carry no gradient
+  {
+    const int npad = (nrows_owned - n) * Fin;
+    const FastDiv divF((uint32_t)Fin);
+    for (int idx = tid; idx < npad; idx += nthr) {
+      const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
+      dXg[(int64_t)(n + i) * ldx + f] = 0.f;
+      if (paper) a.ws_dZ[(int64_t)(row0 + n + i) * Fin + f] = 0.f;
+    }
+  }
+
+  // Does anything consume dL?  SGC_LL in reference mode: R is a constant and min(R1, 0) == 0,
+  // so dalpha == 0 exactly and the whole chain is skipped.
+  const bool need_dL = (reslap || paper) && (K > 1 || a.dL_sum != nullptr);
+  float dalpha_part = 0.f, dbeta_part = 0.f;
+  if (need_dL) {
+    // ---- Q5: tile = dL = sum_k c_k g_k X_{k-1}^T (+ dL_sum) ---------------------------------------
+    wg_tiles<2>(
+        n, n,
+        [&](f32x4 (&acc)[2], int r0, int c0) {
+          for (int k = 1; k < K; ++k) {
+            const float ck = (k >= 2) ? 2.0f : 1.0f;
+            const float* gk = gptr(k);
+            const float* Xp = (k == 1) ? Xg : xptr(k - 1);
+            const int ldp = (k == 1) ? ldx : Fin;
+            mfma_acc<2>(
+                acc, r0, c0, Fin,
+                [&](int i, int f) { return (i < n && f < Fin) ? ck * gk[(int64_t)i * Fin + f] : 0.f; },
+                [&](int f, int j) { return (f < Fin && j < n) ? Xp[(int64_t)j * ldp + f] : 0.f; });
+          }
+        },
+        [&](int i, int j, float v) {
+          if (i < n && j < n) {
+            if (a.dL_sum) v = v + a.dL_sum[toff + (int64_t)i * n + j];
+            tile[i * ldt + j] = v;
+          }
+        });
+    __syncthreads();
+
+    // ---- Q6: chain -------------------------------------------------------------------------------
+    const float* sc = a.sv_scal + 4 * b;
+    if (reslap) {
+      const float ssL = sc[2], scL = sc[3];
+      const float invL = 1.0f / sqrtf(ssL);
+      const bool clipped = invL <= 1.0f;  // TF MinimumGrad: ties take the norm branch
+      float dot_part = 0.f;
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        const float Lpre = a.sv_Lpre[toff + idx];
+        const float Lc = Lpre * scL;
+        const float dLa = tile[i * ldt + j];
+        dalpha_part += dLa * fminf(Lc, 0.f);
+        const float dLc = dLa * lrelu_grad(Lc, alpha);
+        tile[i * ldt + j] = dLc;
+        dot_part += dLc * Lpre;
+      }
+      float dot = 0.f;
+      if (clipped) dot = block_sum(dot_part, red);
+      const float beta = has_prev ? a.beta[0] : 0.f;
+      const float k3 = dot * invL * invL * invL;
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        float d = tile[i * ldt + j];
+        if (clipped) d = d * invL - a.sv_Lpre[toff + idx] * k3;
+        tile[i * ldt + j] = d;  // dLpre == dR2
+        if (has_prev) {
+          dbeta_part += d * a.L_prev[toff + idx];
+          a.dL_prev[toff + idx] = d * beta;
+        }
+      }
+    }
+    if (paper) {
+      // tile = dR2.  R1 = scR * R, R = I - s S s (recomputed from res_W and s).
+      const float ssR = sc[0], scR = sc[1];
+      const float q = reslap ? 1.0f : (float)nn;
+      const float invR = 1.0f / sqrtf(ssR);
+      const bool clippedR = invR * q <= 1.0f;
+      const float* S = a.res_W + toff;
+      float dot_part = 0.f;
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        float R = (i == j) ? 1.f : 0.f;
+        R = R - (s_vec[i] * S[idx]) * s_vec[j];
+        const float R1 = R * scR;
+        const float dR2 = tile[i * ldt + j];
+        dalpha_part += dR2 * fminf(R1, 0.f);
+        const float dR1 = dR2 * lrelu_grad(R1, alpha);
+        tile[i * ldt + j] = dR1;
+        dot_part += dR1 * R;
+      }
+      float dotR = 0.f;
+      if (clippedR) dotR = block_sum(dot_part, red);
+      const float k3 = dotR * invR * invR * invR;
+      // tile = dA = -dR
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        float d = tile[i * ldt + j];
+        if (clippedR) {
+          float R = (i == j) ? 1.f : 0.f;
+          R = R - (s_vec[i] * S[idx]) * s_vec[j];
+          d = q * (d * invR - R * k3);
+        }
+        tile[i * ldt + j] = -d;
+      }
+      __syncthreads();
+      // ds_k = sum_j dA_kj S_kj s_j + sum_i dA_ik s_i S_ik ;  dd_k = -1/2 s_k^3 ds_k
+      for (int k = tid; k < n; k += nthr) {
+        float r1 = 0.f, r2 = 0.f;
+        for (int j = 0; j < n; ++j) r1 += (tile[k * ldt + j] * S[(int64_t)k * n + j]) * s_vec[j];
+        for (int i = 0; i < n; ++i) r2 += (tile[i * ldt + k] * S[(int64_t)i * n + k]) * s_vec[i];
+        const float sk = s_vec[k];
+        v1[k] = -0.5f * sk * sk * sk * (r1 + r2);
+      }
+      __syncthreads();
+      // dS_ij = dA_ij s_i s_j + dd_j ; dr_ij = -S_ij dS_ij   (S_ii = 0 kills the diagonal)
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        const float dS = tile[i * ldt + j] * s_vec[i] * s_vec[j] + v1[j];
+        tile[i * ldt + j] = -S[idx] * dS;
+      }
+      __syncthreads();
+      // c_ij = (dr_ij + dr_ji) / r_ij, defined 0 where r_ij == 0 (duplicate atoms) and on the diagonal
+      {
+        const int nb2 = (n + 1) >> 1;
+        const TriFold tri(nb2);
+        const FastDiv dW((uint32_t)tri.W);
+        for (int t = tid; t < tri.count(); t += nthr) {
+          int bi, bj;
+          if (!tri.get(t, dW, bi, bj)) continue;
+          const int i0 = 2 * bi, j0 = 2 * bj;
+          const int i1 = min(i0 + 1, n - 1), j1 = min(j0 + 1, n - 1);
+          const float* zi0 = buf + i0 * ldb;
+          const float* zi1 = buf + i1 * ldb;
+          const float* zj0 = buf + j0 * ldb;
+          const float* zj1 = buf + j1 * ldb;
+          float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+          for (int f = 0; f < Fin; ++f) {
+            const float u0 = zi0[f], u1 = zi1[f], w0 = zj0[f], w1 = zj1[f];
+            float d;
+            d = u0 - w0; a00 = fmaf(d, d, a00);
+            d = u0 - w1; a01 = fmaf(d, d, a01);
+            d = u1 - w0; a10 = fmaf(d, d, a10);
+            d = u1 - w1; a11 = fmaf(d, d, a11);
+          }
+          const float acc[2][2] = {{a00, a01}, {a10, a11}};
+#pragma unroll
+          for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+              const int i = i0 + di, j = j0 + dj;
+              if (i < n && j < n && i <= j) {
+                float c = 0.f;
+                if (i != j) {
+                  const float r = sqrtf(acc[di][dj]);
+                  const float num = tile[i * ldt + j] + tile[j * ldt + i];
+                  c = r > 0.f ? num / r : 0.f;
+                }
+                tile[i * ldt + j] = c;
+                tile[j * ldt + i] = c;
+              }
+            }
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += nthr) {
+        float r = 0.f;
+        for (int j = 0; j < n; ++j) r += tile[i * ldt + j];
+        v1[i] = r;
+      }
+      __syncthreads();
+      // dZ_i = rowsum(c)_i Z_i - (c Z)_i
+      float* dZg = a.ws_dZ + (int64_t)row0 * Fin;
+      wg_gemm<2>(
+          n, Fin, n,
+          [&](int i, int kk) { return (i < n && kk < n) ? tile[i * ldt + kk] : 0.f; },
+          [&](int kk, int f) { return (kk < n && f < Fin) ? buf[kk * ldb + f] : 0.f; },
+          [&](int i, int f, float v) {
+            if (i < n && f < Fin) dZg[(int64_t)i * Fin + f] = v1[i] * buf[i * ldb + f] - v;
+          });
+      __syncthreads();
+      // dX += dZ . M_L^T
+      const float* M = a.M_L;
+      wg_gemm<2>(
+          n, Fin, Fin,
+          [&](int i, int kk) { return (i < n && kk < Fin) ? dZg[(int64_t)i * Fin + kk] : 0.f; },
+          [&](int kk, int f) { return (kk < Fin && f < Fin) ? M[f * Fin + kk] : 0.f; },
+          [&](int i, int f, float v) { if (i < n && f < Fin) dXg[(int64_t)i * ldx + f] += v; });
+    }
+  } else if (paper) {
+    // K == 1 and no dL_sum: L never reaches Y, so dZ == 0
+    const FastDiv divF((uint32_t)Fin);
+    for (int idx = tid; idx < n * Fin; idx += nthr) {
+      const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
+      a.ws_dZ[(int64_t)(row0 + i) * Fin + f] = 0.f;
+    }
+  }
+  const float da = block_sum(dalpha_part, red);
+  const float db = block_sum(dbeta_part, red);
+  if (tid == 0) {
+    a.ws_pg[2 * b + 0] = da;
+    a.ws_pg[2 * b + 1] = db;
+  }
+}
+
+size_t sgc_lds_bytes_bwd(int32_t n, int32_t Fin) {
+  auto r4 = [](int64_t v) { return (v + 3) & ~int64_t(3); };
+  const int64_t ldt = n | 1, ldb = Fin | 1;
+  return (size_t)(4 * (32 + 2 * r4(n) + r4((int64_t)n * ldt) + r4((int64_t)n * ldb)));
+}
+
+int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
+                        void* stream) {
+  if (count <= 0) return AGCN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (lds_tile) {
+    if (lds_bytes > 64 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sgc_backward_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(bwd): %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(sgc_backward_kernel<true>, dim3(count), dim3(256), lds_bytes, s, a, first);
+  } else {
+    hipLaunchKernelGGL(sgc_backward_kernel<false>, dim3(count), dim3(1024), lds_bytes, s, a, first);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "sgc_backward launch: %s", hipGetErrorString(e));
+  return AGCN_OK;
+}
+
+}  // namespace agcn

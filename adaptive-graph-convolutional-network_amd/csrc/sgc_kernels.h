@@ -1,0 +1,73 @@
+// Kernel argument blocks + launcher prototypes (host <-> .hip translation units).
+#ifndef AGCN_SGC_KERNELS_H_
+#define AGCN_SGC_KERNELS_H_
+
+#include "agcn_internal.h"
+
+namespace agcn {
+
+// Everything is a device pointer unless noted.
+struct SgcArgs {
+  // plan
+  const int32_t* n;
+  const int32_t* row_off;
+  const int64_t* tile_off;
+  const int32_t* order;
+  const int64_t* wtile_off;
+  int32_t B, rows;
+  // layer
+  int32_t Fin, Fout, K, mode, variant, activation, ldx, ldy;
+  // inputs
+  const float* X;
+  const float* L0_dense;
+  int32_t L0_ld;
+  const int32_t* L0_rowptr;
+  const int32_t* L0_col;
+  const float* L0_val;
+  const float* L_prev;
+  const float *weight, *bias, *M_L, *alpha, *beta;
+  // forward outputs (const in backward)
+  float *Y, *res_L, *res_W, *L_sum;
+  // reserve (forward writes, backward reads)
+  float* sv_s;     // [rows]       s_i = d_i^-1/2
+  float* sv_scal;  // [B][4]       ssR, scR, ssL, scL
+  float* sv_X;     // [K-1][rows][Fin]  Chebyshev terms X_1..X_{K-1}
+  float* sv_Lpre;  // [tile_elems] Reslap: L before the second clip
+  // global-tile mode scratch
+  float* ws_tile;  // [wtile_off[B]]
+  float* ws_buf;   // [rows][Fin|1]
+  // backward only
+  const float* dY;
+  const float* dL_sum;
+  float *dX, *dL_prev;
+  float* ws_g;     // [K-1][rows][Fin]  adjoints of X_1..X_{K-1}
+  float* ws_dZ;    // [rows][Fin]       (paper mode)
+  float* ws_pg;    // [B][2]            per-graph dalpha, dbeta
+};
+
+struct ParamGradArgs {
+  int32_t rows, Fin, Fout, K, activation, ldx, ldy, paper;
+  int32_t n_chunks, chunk_rows, B;
+  int64_t part_stride;  // floats per chunk in `part`
+  const float* X;
+  const float* sv_X;
+  const float* Y;
+  const float* dY;
+  const float* dZ;
+  float* part;          // [n_chunks][part_stride]
+  const float* pg;      // [B][2]
+  float *dweight, *dbias, *dM_L, *dalpha, *dbeta;
+};
+
+// LDS bytes one graph of n nodes needs in LDS-tile mode.
+size_t sgc_lds_bytes(int32_t n, int32_t Fin);
+
+// `first`/`count` select a slice of plan.order; lds_tile picks the kernel flavour.
+int launch_sgc_forward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
+                       void* stream);
+int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
+                        void* stream);
+int launch_param_grads(const ParamGradArgs& a, void* stream);
+
+}  // namespace agcn
+#endif

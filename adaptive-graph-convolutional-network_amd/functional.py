@@ -1,0 +1,161 @@
+"""torch.autograd bridge to the C ABI: one forward / one backward call per layer for the
+whole batch.  PyTorch is used for device memory, streams and autograd bookkeeping only --
+all arithmetic happens in the HIP library (there is no eager fallback)."""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise _ffi.AgcnError("%s must live on the GPU: the AGCN layer path has no CPU fallback" % what)
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32" % what)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Cfg(object):
+    __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation")
+
+    def __init__(self, Fin, Fout, K, mode, variant, activation):
+        self.Fin, self.Fout, self.K = int(Fin), int(Fout), int(K)
+        self.mode, self.variant, self.activation = mode, variant, activation
+
+
+def _desc(cfg, ldx, ldy):
+    return _ffi.LayerDesc(cfg.Fin, cfg.Fout, cfg.K, _ffi.MODE[cfg.mode], _ffi.VARIANT[cfg.variant],
+                          _ffi.ACT[cfg.activation], int(ldx), int(ldy))
+
+
+def _gbatch(batch, X, L_prev):
+    p = batch.plan
+    return _ffi.GraphBatch(p.host_ptr, p.dev_ptr, X.data_ptr(), _ptr(batch.l0_dense), batch.l0_ld, 0,
+                           _ptr(batch.l0_rowptr), _ptr(batch.l0_col), _ptr(batch.l0_val), _ptr(L_prev))
+
+
+class SgcLLFunction(torch.autograd.Function):
+    """(Y, res_L, res_W, L_sum) = SGC_LL[_Reslap](X; weight, bias, M_L, alpha, beta, L_prev)."""
+
+    @staticmethod
+    def forward(ctx, X, weight, bias, M_L, alpha, beta, L_prev, batch, cfg):
+        lib = _ffi.lib()
+        _require_gpu(X, "node features")
+        X = _f32c(X, "node features")
+        weight, bias, M_L, alpha = (_f32c(weight, "weight"), _f32c(bias, "bias"), _f32c(M_L, "M_L"),
+                                    _f32c(alpha, "alpha"))
+        plan = batch.plan
+        if X.dim() != 2 or X.shape[0] != plan.rows or X.shape[1] < cfg.Fin:
+            raise ValueError("node features must be [rows=%d, >=%d], got %s" % (plan.rows, cfg.Fin, tuple(X.shape)))
+        if tuple(weight.shape) != (cfg.Fin * cfg.K, cfg.Fout) or tuple(M_L.shape) != (cfg.Fin, cfg.Fin):
+            raise ValueError("parameter shapes do not match the layer")
+        reslap = cfg.variant == "SGC_LL_Reslap"
+        if L_prev is not None:
+            L_prev = _f32c(L_prev, "L_prev")
+            if L_prev.numel() != plan.tile_elems:
+                raise ValueError("L_prev must be a packed tile tensor of %d floats" % plan.tile_elems)
+            if beta is None:
+                raise ValueError("L_prev given without beta")
+            beta = _f32c(beta, "beta")
+        dev = X.device
+        ldx, ldy = X.shape[1], cfg.Fout
+        Y = torch.empty((plan.rows, ldy), dtype=torch.float32, device=dev)
+        res_L = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
+        res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
+        L_sum = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
+        desc = _desc(cfg, ldx, ldy)
+        rbytes = lib.agcn_sgc_ll_reserve_bytes(C.byref(desc), plan.host_ptr)
+        wbytes = lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(desc), plan.host_ptr)
+        reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        gb = _gbatch(batch, X, L_prev if reslap else None)
+        pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
+        out = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr())
+        _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(out),
+                                           reserve.data_ptr(), rbytes, ws.data_ptr(), wbytes, _stream(dev)))
+        ctx.batch, ctx.cfg, ctx.has_prev, ctx.has_beta = batch, cfg, (reslap and L_prev is not None), beta is not None
+        ctx.save_for_backward(X, weight, bias, M_L, alpha, beta, L_prev if reslap else None,
+                              Y, res_L, res_W, L_sum, reserve)
+        ctx.mark_non_differentiable(res_L, res_W)
+        return Y, res_L, res_W, L_sum
+
+    @staticmethod
+    def backward(ctx, dY, _dres_L, _dres_W, dL_sum):
+        lib = _ffi.lib()
+        X, weight, bias, M_L, alpha, beta, L_prev, Y, res_L, res_W, L_sum, reserve = ctx.saved_tensors
+        batch, cfg, plan = ctx.batch, ctx.cfg, ctx.batch.plan
+        dev = X.device
+        paper = cfg.mode == "paper"
+        if dY is None:
+            dY = torch.zeros_like(Y)
+        dY = _f32c(dY, "dY")
+        if dL_sum is not None:
+            dL_sum = _f32c(dL_sum, "dL_sum")
+        ldx, ldy = X.shape[1], cfg.Fout
+        desc = _desc(cfg, ldx, ldy)
+        dX = torch.empty_like(X)
+        if ldx > cfg.Fin:
+            dX.zero_()
+        dweight = torch.empty_like(weight)
+        dbias = torch.empty_like(bias)
+        dM = torch.empty_like(M_L) if paper else None
+        dalpha = torch.empty_like(alpha)
+        dbeta = torch.empty_like(beta) if ctx.has_prev else None
+        dLp = torch.empty_like(L_prev) if ctx.has_prev else None
+        wbytes = lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(desc), plan.host_ptr)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        gb = _gbatch(batch, X, L_prev)
+        pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
+        fw = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr())
+        gr = _ffi.Grads(dX.data_ptr(), dweight.data_ptr(), dbias.data_ptr(), _ptr(dM), dalpha.data_ptr(),
+                        _ptr(dbeta), _ptr(dLp))
+        _ffi.check(lib.agcn_sgc_ll_backward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(fw),
+                                            dY.data_ptr(), _ptr(dL_sum), C.byref(gr), reserve.data_ptr(),
+                                            reserve.numel(), ws.data_ptr(), wbytes, _stream(dev)))
+        if ctx.has_beta and dbeta is None:
+            dbeta = None   # beta unused (no L_prev): TF reports no gradient either
+        return dX, dweight, dbias, dM, dalpha, dbeta, dLp, None, None
+
+
+class GraphGatherFunction(torch.autograd.Function):
+    """out[b] = act(sum of graph b's real rows)   (graphgather.py:40-77)."""
+
+    @staticmethod
+    def forward(ctx, X, batch, activation):
+        lib = _ffi.lib()
+        _require_gpu(X, "node features")
+        X = _f32c(X, "node features")
+        plan = batch.plan
+        if X.dim() != 2 or X.shape[0] != plan.rows:
+            raise ValueError("node features must be [rows=%d, F]" % plan.rows)
+        F = X.shape[1]
+        out = torch.empty((plan.B, F), dtype=torch.float32, device=X.device)
+        _ffi.check(lib.agcn_graph_gather_forward(plan.host_ptr, plan.dev_ptr, X.data_ptr(), F, F,
+                                                 _ffi.ACT[activation], out.data_ptr(), _stream(X.device)))
+        ctx.batch, ctx.activation, ctx.F = batch, activation, F
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        lib = _ffi.lib()
+        (out,) = ctx.saved_tensors
+        plan = ctx.batch.plan
+        dOut = _f32c(dOut, "dOut")
+        dX = torch.empty((plan.rows, ctx.F), dtype=torch.float32, device=out.device)
+        _ffi.check(lib.agcn_graph_gather_backward(plan.host_ptr, plan.dev_ptr, out.data_ptr(), dOut.data_ptr(),
+                                                  ctx.F, ctx.F, _ffi.ACT[ctx.activation], dX.data_ptr(),
+                                                  _stream(out.device)))
+        return dX, None, None

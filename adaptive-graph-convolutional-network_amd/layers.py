@@ -1,0 +1,240 @@
+"""Host-side mirror of the reference's layer classes for the hot path.
+
+Class names, constructor arguments, the dict-in / tuple-of-lists-out call contract and the
+read-back attributes are those of `models/layers/graphconv.py` (SGC_LL),
+`graphconv_reslap.py` (SGC_LL_Reslap), `graphgather.py` (GraphGatherMol) and
+`basic_layer.py` (Layer), because the reference's containers dispatch on
+`type(layer).__name__` (models/tf_modules/tf_graphs.py:41,45,56,173,178).
+
+Two input forms are accepted for `x['node_features']`:
+  * the reference feed: a list of B [max_atom, Fin] tensors (+ 'original_laplacian' list of
+    [max_atom, max_atom], 'data_slice' [B,2] rows [n,-1], 'lap_slice' [B,2] rows [n,n]);
+  * the output of a previous layer of this package (a lazy `RowViews` over packed device
+    memory), which keeps the batch packed on the device between layers.
+Returned lists are lazy sequences of per-graph views (`RowViews` / `TileViews`).
+
+Extension over the reference: `laplacian_mode` ("reference" = what the repository computes,
+res_L == I and no gradient to M_L; "paper" = I - D^-1/2 W D^-1/2, differentiable).
+"""
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from .batch import GraphBatch, RowViews, TileViews
+from .functional import GraphGatherFunction, SgcLLFunction, _Cfg
+
+_UID_PREFIXES = defaultdict(int)
+
+
+def get_uid(prefix=""):
+    """models/operators/model_operatos.py:156-168."""
+    _UID_PREFIXES[prefix] += 1
+    return _UID_PREFIXES[prefix]
+
+
+class Layer(object):
+    """Base layer: naming + kwargs whitelist of models/layers/basic_layer.py:44-79."""
+
+    def __init__(self, **kwargs):
+        if not hasattr(self, "uses_learning_phase"):
+            self.uses_learning_phase = False
+        if not hasattr(self, "losses"):
+            self.losses = []
+        allowed_kwargs = {"input_shape", "batch_input_shape", "input_dtype", "name", "trainable"}
+        for kwarg in kwargs.keys():
+            if kwarg not in allowed_kwargs:
+                raise TypeError("Keyword argument not understood:", kwarg)
+        name = kwargs.get("name")
+        if not name:
+            prefix = self.__class__.__name__.lower()
+            name = prefix + "_" + str(get_uid(prefix))
+        self.name = name
+        self.trainable = kwargs.get("trainable", True)
+
+    def call(self, x):
+        return x
+
+    def __call__(self, x):
+        return self.call(x)
+
+
+def glorot(shape, generator=None, device=None):
+    """graphconv.py:19-23: U(-r, r), r = sqrt(6 / (fan_in + fan_out))."""
+    r = float(np.sqrt(6.0 / (shape[0] + shape[1])))
+    t = torch.empty(shape, dtype=torch.float32)
+    t.uniform_(-r, r, generator=generator)
+    return t.to(device) if device is not None else t
+
+
+def _resolve_batch(x):
+    """Returns (GraphBatch, X2d) for either input form."""
+    nf = x["node_features"]
+    gb = x.get("graph_batch")
+    if isinstance(nf, RowViews):
+        if gb is None:
+            gb = getattr(nf, "batch", None)
+        if gb is None:
+            raise ValueError("packed node_features need x['graph_batch']")
+        return gb, nf.data
+    if gb is not None and torch.is_tensor(nf) and nf.dim() == 2:
+        return gb, nf
+    # reference feed (lists of padded tensors)
+    gb = GraphBatch.from_padded(nf, x["original_laplacian"], x["data_slice"])
+    ls = x.get("lap_slice")
+    if ls is not None:
+        ls = ls.detach().cpu().numpy() if torch.is_tensor(ls) else np.asarray(ls)
+        if not (np.array_equal(ls[:, 0], gb.plan.n) and np.array_equal(ls[:, 1], gb.plan.n)):
+            raise ValueError("lap_slice does not agree with data_slice")
+    return gb, gb.X
+
+
+def _pack_tiles(res_lap, plan, device):
+    """res_lap (list of B [n,n] tensors, or TileViews) -> packed tile tensor or None."""
+    if res_lap is None or len(res_lap) == 0:     # `if early_Laps:` graphconv_reslap.py:188
+        return None
+    if isinstance(res_lap, TileViews) and res_lap.plan is plan:
+        return res_lap.data
+    if len(res_lap) != plan.B:
+        raise ValueError("res_lap must hold one Laplacian per graph")
+    out = torch.zeros(plan.tile_elems, dtype=torch.float32, device=device)
+    for b, t in enumerate(res_lap):
+        n, off = int(plan.n[b]), int(plan.tile_off[b])
+        out[off:off + n * n] = t.reshape(-1)
+    return out
+
+
+class SGC_LL(Layer):
+    """Spectral graph convolution with a learned residual Laplacian (graphconv.py:32-252).
+
+    SGC_LL(output_dim, input_dim, batch_size, activation='relu', dropout=None, K=2,
+           save_lap=False, save_output=False, **kwargs)
+    call(x) -> (activated_nodes, res_L_updated, res_W_updated)
+    """
+    _variant = "SGC_LL"
+
+    def __init__(self, output_dim, input_dim, batch_size, activation="relu", dropout=None, K=2,
+                 save_lap=False, save_output=False, laplacian_mode="reference", device=None,
+                 generator=None, **kwargs):
+        super(SGC_LL, self).__init__(**kwargs)
+        if dropout is not None:
+            raise NotImplementedError("dropout is never enabled by the reference networks")
+        if activation not in ("relu", "linear", None):
+            raise ValueError("Invalid activation function: %s" % (activation,))
+        if laplacian_mode not in ("reference", "paper"):
+            raise ValueError("laplacian_mode must be 'reference' or 'paper'")
+        self.dropout = dropout
+        self.activation = activation
+        self.batch_size = batch_size
+        self.nb_filter = output_dim
+        self.n_atom_feature = input_dim
+        self.vars = {}
+        self.bias = True
+        self.K = K
+        self.save_lap = save_lap
+        self.early_laps = None
+        self.save_output = save_output
+        self.laplacian_mode = laplacian_mode
+        self._device = device
+        self._generator = generator
+        self._built = False
+
+    def build(self, device=None):
+        """Creates the parameters once (the reference re-creates them on every call,
+        graphconv.py:66-83,92; same names in `.vars`)."""
+        if self._built:
+            return
+        device = self._device if self._device is not None else device
+        g = self._generator
+        req = bool(self.trainable)
+        Fin, K, Fout = self.n_atom_feature, self.K, self.nb_filter
+        self.vars["weight"] = glorot([Fin * K, Fout], g, device).requires_grad_(req)
+        self.vars["bias"] = torch.zeros([Fout], dtype=torch.float32, device=device).requires_grad_(req)
+        self.vars["M_L"] = glorot([Fin, Fin], g, device).requires_grad_(req)
+        self.vars["alpha"] = torch.ones((1,), dtype=torch.float32, device=device).requires_grad_(req)
+        if self._variant == "SGC_LL_Reslap":
+            self.vars["beta"] = torch.ones((1,), dtype=torch.float32, device=device).requires_grad_(req)
+        self._built = True
+
+    def parameters(self):
+        self.build()
+        return list(self.vars.values())
+
+    def load_vars(self, arrays):
+        """Set parameters from numpy arrays / tensors (same keys as `.vars`)."""
+        dev = self._device
+        for k, v in arrays.items():
+            t = torch.as_tensor(np.asarray(v), dtype=torch.float32) if not torch.is_tensor(v) else v.detach().clone()
+            self.vars[k] = t.to(dev).requires_grad_(bool(self.trainable))
+        self._built = True
+
+    def _apply(self, x, L_prev):
+        gb, X = _resolve_batch(x)
+        self.build(X.device)
+        cfg = _Cfg(self.n_atom_feature, self.nb_filter, self.K, self.laplacian_mode, self._variant,
+                   "relu" if self.activation == "relu" else "linear")
+        if gb.plan.B != self.batch_size:
+            raise ValueError("batch holds %d graphs, layer was built for batch_size=%d" % (gb.plan.B, self.batch_size))
+        v = self.vars
+        Y, res_L, res_W, L_sum = SgcLLFunction.apply(X, v["weight"], v["bias"], v["M_L"], v["alpha"],
+                                                     v.get("beta"), L_prev, gb, cfg)
+        nodes = RowViews(Y, gb.plan)
+        nodes.batch = gb
+        return gb, nodes, TileViews(res_L, gb.plan), TileViews(res_W, gb.plan), TileViews(L_sum, gb.plan)
+
+    def call(self, x):
+        _, nodes, res_L, res_W, _ = self._apply(x, None)
+        return nodes, res_L, res_W
+
+
+class SGC_LL_Reslap(SGC_LL):
+    """SGC_LL plus beta * (previous layer's summed Laplacian) (graphconv_reslap.py:15-230).
+    call(x) -> (activated_atoms, res_L_updated, res_W_updated, L_sum_updated)."""
+    _variant = "SGC_LL_Reslap"
+
+    def call(self, x):
+        gb, X = _resolve_batch(x)
+        self.early_laps = x["res_lap"]
+        L_prev = _pack_tiles(self.early_laps, gb.plan, X.device)
+        x2 = dict(x)
+        x2["graph_batch"], x2["node_features"] = gb, X
+        _, nodes, res_L, res_W, L_sum = self._apply(x2, L_prev)
+        return nodes, res_L, res_W, L_sum
+
+
+class GraphGatherMol(Layer):
+    """Per-graph row-sum readout + activation (graphgather.py:11-77).
+    GraphGatherMol(batch_size, activation='relu'); call(x) -> tensor [batch_size, n_feat]."""
+
+    def __init__(self, batch_size, activation="relu", **kwargs):
+        super(GraphGatherMol, self).__init__(**kwargs)
+        if activation not in ("relu", "tanh", "linear", None):
+            raise ValueError("Invalid activation function: %s" % (activation,))
+        self.activation = activation
+        self.batch_size = batch_size
+
+    def build(self, input_shape=None):
+        pass
+
+    def get_output_shape_for(self, input_shape):
+        return self.batch_size, input_shape[0][1]
+
+    def call(self, x, mask=None):
+        nf = x["node_features"]
+        gb = x.get("graph_batch")
+        if isinstance(nf, RowViews):
+            gb = gb if gb is not None else getattr(nf, "batch", None)
+            X = nf.data
+        elif gb is not None and torch.is_tensor(nf):
+            X = nf
+        else:
+            X3 = nf if torch.is_tensor(nf) else torch.stack(list(nf))
+            ds = x["data_slice"]
+            ds = ds.detach().cpu().numpy() if torch.is_tensor(ds) else np.asarray(ds)
+            from .batch import Plan
+            plan = Plan(ds[:, 0], X3.shape[1], X3.device)
+            gb = GraphBatch(plan, X3.reshape(-1, X3.shape[2]))
+            X = gb.X
+        if gb is None:
+            raise ValueError("packed node_features need x['graph_batch']")
+        return GraphGatherFunction.apply(X, gb, self.activation)

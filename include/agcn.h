@@ -1,0 +1,205 @@
+/*
+ * agcn.h -- C ABI of the MI355X-native AGCN adaptive graph-convolution path.
+ *
+ * One call = one layer over a whole ragged batch of graphs (not one call per
+ * graph).  Plain pointers and sizes only; the caller (PyTorch host code, via
+ * ctypes) owns every buffer including workspace and reserve space; the
+ * library allocates nothing on the device, keeps no state between calls, never
+ * synchronises, and enqueues all work on the stream it is given.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference repository root):
+ *
+ *   agcn_sgc_ll_forward    models/layers/graphconv.py:85-252  (SGC_LL.call + specgraph_LL,
+ *                          incl. the tf.py_func body :163-211) and
+ *                          models/layers/graphconv_reslap.py:45-230 (SGC_LL_Reslap)
+ *   agcn_sgc_ll_backward   the TF autodiff of the above, driven by
+ *                          models/tf_modules/multitask_classifier.py:237
+ *   agcn_graph_gather_*    models/layers/graphgather.py:40-77 (GraphGatherMol)
+ *   agcn_plan_*            the per-graph slice bookkeeping of
+ *                          models/tf_modules/graph_topology.py:84-135 (data_slice / lap_slice)
+ *
+ * All functions return 0 on success or a negative AGCN_E* code;
+ * agcn_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef AGCN_H_
+#define AGCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGCN_VERSION 100 /* 0.1.0 */
+
+enum {
+  AGCN_OK = 0,
+  AGCN_EINVAL = -1,    /* bad argument / unsupported combination */
+  AGCN_ENOSPACE = -2,  /* workspace / reserve / plan buffer too small */
+  AGCN_EDEVICE = -3,   /* HIP launch or runtime error */
+  AGCN_EPLAN = -4      /* corrupt or mismatching plan blob */
+};
+
+/* laplacian_mode: how the residual Laplacian is formed from the similarity W
+ * (graphconv.py:195-200).  REFERENCE reproduces the repository bit for bit:
+ * `I - D * W * D` with numpy's ELEMENTWISE `*`, i.e. res_L == I, and no
+ * gradient to M_L (py_func).  PAPER is the matrix product I - D^-1/2 W D^-1/2
+ * the comment at graphconv.py:194 intends, differentiable w.r.t. M_L and X. */
+enum { AGCN_MODE_REFERENCE = 0, AGCN_MODE_PAPER = 1 };
+/* layer variant: SGC_LL (graphconv.py) or SGC_LL_Reslap (graphconv_reslap.py) */
+enum { AGCN_SGC_LL = 0, AGCN_SGC_LL_RESLAP = 1 };
+/* activations.get(): the networks only use these */
+enum { AGCN_ACT_LINEAR = 0, AGCN_ACT_RELU = 1, AGCN_ACT_TANH = 2 };
+
+/* ------------------------------------------------------------------------
+ * Plan: the integer bookkeeping of one ragged batch (graph sizes, row and
+ * tile offsets, size-sorted schedule).  Built on the host, in caller memory;
+ * the caller uploads the same bytes to the device and passes both copies.
+ *
+ * Layout of the node-feature matrices ("rows"): graph b owns rows
+ * [row_off[b], row_off[b+1]) of X / Y / dX / dY, of which the first n[b] are
+ * real nodes; the rest (if any) are padding.  Packed batches have
+ * row_off = prefix sums of n; the reference's padded feed
+ * (graph_topology.py:84-90) has row_off[b] = b * max_atom.
+ * Layout of the per-graph square tiles (res_L, res_W, L_sum, L_prev, dense
+ * L_orig): graph b owns n[b]*n[b] floats, row-major with leading dimension
+ * n[b], starting at tile_off[b] (each tile start is 16-byte aligned).
+ */
+typedef struct AgcnPlanInfo {
+  int32_t B;          /* graphs */
+  int32_t N1;         /* sum of n[b] (real nodes) */
+  int32_t rows;       /* row_off[B] (== N1 when packed) */
+  int32_t max_n;      /* largest graph */
+  int64_t N2;         /* sum of n[b]^2 */
+  int64_t tile_elems; /* tile_off[B]: floats to allocate for one tile array */
+  int64_t plan_bytes; /* size of the blob */
+  /* byte offsets of the arrays inside the blob */
+  int64_t off_n;        /* int32 [B]   */
+  int64_t off_row_off;  /* int32 [B+1] */
+  int64_t off_tile_off; /* int64 [B+1] */
+  int64_t off_order;    /* int32 [B]   graph ids, largest first */
+  int64_t off_wtile_off; /* int64 [B+1] scratch-tile offsets (global-memory tile mode) */
+} AgcnPlanInfo;
+
+/* Bytes needed for a plan of B graphs. */
+size_t agcn_plan_bytes(int32_t B);
+
+/* Build a plan from host arrays.  n[B] = node counts (data_slice[:,0] /
+ * lap_slice[:,0], graph_topology.py:90,98).  row_stride = 0 -> packed rows,
+ * otherwise every graph owns row_stride rows (the reference's max_atom).
+ * Fails with AGCN_EINVAL if any n[b] < 1, n[b] > row_stride (padded mode) or
+ * the batch does not fit 32-bit row indexing. */
+int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, void* plan_host, size_t plan_bytes);
+
+/* Read the header back (validates the magic). */
+int agcn_plan_info(const void* plan_host, AgcnPlanInfo* info);
+
+/* ------------------------------------------------------------------------ */
+typedef struct AgcnLayerDesc {
+  int32_t Fin;        /* n_atom_feature  (graphconv.py:58) */
+  int32_t Fout;       /* nb_filter       (graphconv.py:57) */
+  int32_t K;          /* Chebyshev order (graphconv.py:61); any K >= 1 */
+  int32_t mode;       /* AGCN_MODE_* */
+  int32_t variant;    /* AGCN_SGC_LL / AGCN_SGC_LL_RESLAP */
+  int32_t activation; /* AGCN_ACT_LINEAR or AGCN_ACT_RELU (graphconv.py:53,117-123) */
+  int32_t ldx;        /* row stride of X and dX in floats (>= Fin) */
+  int32_t ldy;        /* row stride of Y and dY in floats (>= Fout) */
+} AgcnLayerDesc;
+
+/* Device pointers unless stated otherwise. */
+typedef struct AgcnGraphBatch {
+  const void* plan_host;     /* HOST copy of the plan blob */
+  const void* plan_dev;      /* DEVICE copy of the same bytes */
+  const float* X;            /* [rows, ldx]  node_features */
+  /* original Laplacian (graph_structure.py:85-130, cast to f32 at the feed):
+   * either dense or CSR, the other NULL.
+   * dense: L0_ld == 0 -> packed tiles at tile_off[b] with ld n[b];
+   *        L0_ld  > 0 -> padded feed, graph b at b*L0_ld*L0_ld with ld L0_ld
+   *                      (graph_topology.py:92-98).
+   * CSR:   rowptr[rows+1] over the row space of X (pad rows are empty),
+   *        col = column index INSIDE the graph, val f32. */
+  const float* L0_dense;
+  int32_t L0_ld;
+  int32_t reserved0;
+  const int32_t* L0_rowptr;
+  const int32_t* L0_col;
+  const float* L0_val;
+  const float* L_prev;       /* Reslap only: res_lap tiles (graphconv_reslap.py:68,188-190) or NULL */
+} AgcnGraphBatch;
+
+typedef struct AgcnParams { /* graphconv.py:75-83, graphconv_reslap.py:30-43 */
+  const float* weight;       /* [Fin*K, Fout], row index f*K + k */
+  const float* bias;         /* [Fout] */
+  const float* M_L;          /* [Fin, Fin] */
+  const float* alpha;        /* [1] */
+  const float* beta;         /* [1] (Reslap; may be NULL when L_prev is NULL) */
+} AgcnParams;
+
+typedef struct AgcnOutputs { /* graphconv.py:125,252; graphconv_reslap.py:89,230 */
+  float* Y;                  /* [rows, ldy] activated nodes; pad rows are written as 0 */
+  float* res_L;              /* tiles: residual Laplacian after clip + leaky-ReLU */
+  float* res_W;              /* tiles: similarity matrix exp(-||(x_i-x_j) M_L||) */
+  float* L_sum;              /* tiles: Reslap's 4th output; for SGC_LL optional (may be NULL) */
+} AgcnOutputs;
+
+typedef struct AgcnGrads {
+  float* dX;                 /* [rows, ldx] */
+  float* dweight;            /* [Fin*K, Fout] */
+  float* dbias;              /* [Fout] */
+  float* dM_L;               /* [Fin, Fin]; written only in AGCN_MODE_PAPER (else untouched; may be NULL) */
+  float* dalpha;             /* [1] */
+  float* dbeta;              /* [1]; written only for Reslap with L_prev (may be NULL otherwise) */
+  float* dL_prev;            /* tiles; written only for Reslap with L_prev (may be NULL otherwise) */
+} AgcnGrads;
+
+/* Reserve space: intermediates the forward keeps for the backward (opaque
+ * layout).  Workspace: scratch for one call. */
+size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host);
+size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
+size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
+
+int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+                        const AgcnOutputs* out, void* reserve, size_t reserve_bytes,
+                        void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* `fwd` are the tensors the forward produced (read only here).  dY [rows, ldy]
+ * is the gradient w.r.t. Y; dL_sum (tiles, nullable) is the gradient arriving
+ * on the L_sum output from a later Reslap layer's dL_prev. */
+int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+                         const AgcnOutputs* fwd, const float* dY, const float* dL_sum,
+                         const AgcnGrads* grads, const void* reserve, size_t reserve_bytes,
+                         void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* The two stages of agcn_sgc_ll_backward as separate calls (same arguments, same workspace):
+ * _nodes  = everything local to a graph: dX, dL_prev, and the per-graph partials in workspace;
+ * _params = the reductions over the batch: dweight, dbias, dM_L, dalpha, dbeta.
+ * _params must follow _nodes on the same stream with the same workspace. */
+int agcn_sgc_ll_backward_nodes(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+                               const AgcnOutputs* fwd, const float* dY, const float* dL_sum,
+                               const AgcnGrads* grads, const void* reserve, size_t reserve_bytes,
+                               void* workspace, size_t workspace_bytes, void* hip_stream);
+int agcn_sgc_ll_backward_params(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+                                const AgcnOutputs* fwd, const float* dY, const float* dL_sum,
+                                const AgcnGrads* grads, const void* reserve, size_t reserve_bytes,
+                                void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* GraphGatherMol (graphgather.py:40-77): out[b, :] = act(sum of graph b's real rows). */
+int agcn_graph_gather_forward(const void* plan_host, const void* plan_dev, const float* X, int32_t F,
+                              int32_t ldx, int32_t activation, float* out /* [B, F] */, void* hip_stream);
+int agcn_graph_gather_backward(const void* plan_host, const void* plan_dev, const float* out,
+                               const float* dOut, int32_t F, int32_t ldx, int32_t activation,
+                               float* dX /* [rows, ldx], pad rows zeroed */, void* hip_stream);
+
+int32_t agcn_version(void);
+const char* agcn_last_error(void);
+/* LDS bytes per workgroup above which a graph is processed with its tile in
+ * global memory instead of LDS (default 160 KiB; settable for tests). */
+int32_t agcn_get_lds_limit(void);
+void agcn_set_lds_limit(int32_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGCN_H_ */

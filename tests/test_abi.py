@@ -1,0 +1,100 @@
+"""C-ABI library: loads without a GPU, exports every symbol include/agcn.h declares, and its
+host-only entry points (plan building, size queries, argument validation) behave.  CPU only:
+no kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import agcn_amd
+    if agcn_amd._build.is_stale():
+        agcn_amd._build.build()
+    return agcn_amd
+
+
+def test_exports_every_declared_symbol(amd):
+    hdr = open(os.path.join(ROOT, "include", "agcn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(agcn_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    lib = amd._ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name), "libagcn_hip.so does not export %s" % name
+    assert sorted(amd._ffi.SYMBOLS) == declared
+    assert lib.agcn_version() == 100
+
+
+def test_plan_packed(amd):
+    n = np.array([5, 3, 9, 4, 9], dtype=np.int32)
+    p = amd.Plan(n)
+    assert p.B == 5 and p.N1 == 30 and p.rows == 30 and p.max_n == 9 and p.N2 == int((n.astype(np.int64) ** 2).sum())
+    np.testing.assert_array_equal(p.n, n)
+    np.testing.assert_array_equal(p.row_off, np.concatenate([[0], np.cumsum(n)]))
+    assert p.row_off.dtype == np.int32 and p.tile_off.dtype == np.int64
+    # tiles: 16-byte aligned starts, non-overlapping
+    assert np.all(p.tile_off % 4 == 0)
+    assert np.all(np.diff(p.tile_off) >= n.astype(np.int64) ** 2)
+    # schedule: largest first, stable
+    np.testing.assert_array_equal(p.order, [2, 4, 0, 3, 1])
+
+
+def test_plan_padded_matches_reference_slices(amd):
+    # graph_topology.py:84-98: every graph owns max_atom rows; data_slice rows are [n, -1]
+    n = np.array([4, 9, 5, 17], dtype=np.int32)
+    p = amd.Plan(n, 20)
+    np.testing.assert_array_equal(p.row_off, np.arange(5) * 20)
+    assert p.rows == 80 and p.N1 == 35
+
+
+def test_plan_rejects_bad_input(amd):
+    with pytest.raises(amd._ffi.AgcnError):
+        amd.Plan([4, 0, 3])
+    with pytest.raises(amd._ffi.AgcnError):
+        amd.Plan([4, 30], 20)        # graph larger than max_atom
+    with pytest.raises(amd._ffi.AgcnError):
+        amd.Plan([5000])             # beyond AGCN_MAX_NODES
+    lib = amd._ffi.lib()
+    info = amd._ffi.PlanInfo()
+    junk = np.zeros(256, dtype=np.uint8)
+    assert lib.agcn_plan_info(junk.ctypes.data, C.byref(info)) == -4
+    assert b"magic" in lib.agcn_last_error()
+
+
+def test_size_queries_and_validation(amd):
+    lib = amd._ffi.lib()
+    p = amd.Plan([18, 48, 7, 23])
+    d = amd._ffi.LayerDesc(75, 64, 2, 1, 0, 1, 75, 64)
+    r = lib.agcn_sgc_ll_reserve_bytes(C.byref(d), p.host_ptr)
+    assert r >= 4 * (p.rows + 4 * p.B + p.rows * 75)
+    assert lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(d), p.host_ptr) >= 256
+    wb = lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(d), p.host_ptr)
+    assert wb >= 4 * (p.rows * 75 * 2 + 2 * 75 * 64)
+    # forcing the global-tile path needs scratch for the tiles
+    lib.agcn_set_lds_limit(0)
+    try:
+        assert lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(d), p.host_ptr) >= 4 * int(p.N2)
+    finally:
+        lib.agcn_set_lds_limit(160 * 1024)
+    assert lib.agcn_get_lds_limit() == 160 * 1024
+    bad = amd._ffi.LayerDesc(75, 64, 0, 1, 0, 1, 75, 64)     # K = 0
+    assert lib.agcn_sgc_ll_reserve_bytes(C.byref(bad), p.host_ptr) == 0
+    assert b"K must be" in lib.agcn_last_error()
+    # argument validation happens before any device work
+    gb = amd._ffi.GraphBatch()
+    rc = lib.agcn_sgc_ll_forward(C.byref(d), C.byref(gb), C.byref(amd._ffi.Params()), C.byref(amd._ffi.Outputs()),
+                                 None, 0, None, 0, None)
+    assert rc == -1
+
+
+def test_missing_library_fails_loudly(amd, monkeypatch):
+    monkeypatch.setattr(amd._ffi, "_lib", None)
+    monkeypatch.setenv("AGCN_HIP_LIB", "/nonexistent/libagcn_hip.so")
+    with pytest.raises(amd._ffi.AgcnError, match="no CPU fallback"):
+        amd._ffi.lib()

@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI) against golden vectors made from the reference's
+own layer code and against the oracle.  Needs a real MI355X: run with `-m gpu`."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import agcn_oracle as orc
+from conftest import GOLDEN
+from helpers import (FEATURE_RTOL, GRAD_RTOL, assert_close, compare_with_oracle, golden_params, load_golden,
+                     make_layer, oracle_run, run_packed, synth_case, to_np)
+
+pytestmark = pytest.mark.gpu
+
+LAYER = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "sgc_*.npz")) +
+               glob.glob(os.path.join(GOLDEN, "reslap_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import agcn_amd
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    agcn_amd._ffi.lib()          # fail loudly if the HIP library is missing
+    agcn_amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
+    return agcn_amd
+
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("lds_limit", [160 * 1024, 0], ids=["lds", "globaltile"])
+@pytest.mark.parametrize("name", LAYER)
+def test_golden_reference_feed(amd, name, lds_limit):
+    """The reference's own feed layout (lists of padded tensors + int32 slices) in, the
+    reference's outputs and TF-autodiff gradients out (laplacian_mode='reference')."""
+    amd._ffi.lib().agcn_set_lds_limit(lds_limit)
+    try:
+        g = load_golden(name)
+        ns = g["ns"]
+        B, K, variant, chain = len(ns), int(g["K"]), int(g["variant"]), int(g["chain"])
+        Fin, Fout, max_atom = int(g["Fin"]), int(g["Fout"]), int(g["max_atom"])
+        Xl = [torch.from_numpy(g["X"][b]).to(DEV).requires_grad_(True) for b in range(B)]
+        Ll = [torch.from_numpy(g["L"][b]).to(DEV) for b in range(B)]
+        x = {"node_features": Xl, "original_laplacian": Ll, "data_slice": g["data_slice"], "lap_slice": g["lap_slice"]}
+        l1 = make_layer(amd, variant, Fout, Fin, B, K, orc.REFERENCE, golden_params(g, "l1_"), DEV)
+        if variant == orc.SGC_LL:
+            out = l1(x)
+            assert len(out) == 3
+            nodes, res_L, res_W = out
+            L_sum = None
+        else:
+            x["res_lap"] = [][-B:]
+            out = l1(x)
+            assert len(out) == 4
+            nodes, res_L, res_W, L_sum = out
+
+        def check(prefix, nodes, res_L, res_W, L_sum):
+            assert len(nodes) == B and len(res_L) == B and len(res_W) == B
+            for b, n in enumerate(ns):
+                y = to_np(nodes[b])
+                assert y.shape == (max_atom, Fout)
+                assert np.all(y[n:] == 0), "pad rows must be exactly 0"
+                assert_close(y, g[prefix + "Y"][b], FEATURE_RTOL, "Y[%d]" % b)
+                assert tuple(res_L[b].shape) == (n, n) and tuple(res_W[b].shape) == (n, n)
+                assert_close(to_np(res_W[b]), g[prefix + "res_W"][b, :n, :n], FEATURE_RTOL, "res_W[%d]" % b)
+                assert_close(to_np(res_L[b]), g[prefix + "res_L"][b, :n, :n], FEATURE_RTOL, "res_L[%d]" % b)
+                w = to_np(res_W[b])
+                assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
+                if L_sum is not None:
+                    assert_close(to_np(L_sum[b]), g[prefix + "L_sum"][b, :n, :n], FEATURE_RTOL, "L_sum[%d]" % b)
+            if variant == orc.SGC_LL:
+                for b, n in enumerate(ns):   # res_L == I bit for bit
+                    assert np.array_equal(to_np(res_L[b]), np.eye(n, dtype=np.float32))
+
+        check("l1_", nodes, res_L, res_W, L_sum)
+        final, layers = nodes, [("l1_", l1)]
+        if chain:
+            l2 = make_layer(amd, variant, Fout, Fout, B, K, orc.REFERENCE, golden_params(g, "l2_"), DEV)
+            x2 = {"node_features": nodes, "original_laplacian": Ll, "data_slice": g["data_slice"],
+                  "lap_slice": g["lap_slice"], "res_lap": L_sum[-B:]}
+            nodes2, res_L2, res_W2, L_sum2 = l2(x2)
+            check("l2_", nodes2, res_L2, res_W2, L_sum2)
+            final = nodes2
+            layers.append(("l2_", l2))
+        G = torch.from_numpy(g["G"]).to(DEV)
+        loss = sum((final[b] * G[b]).sum() for b in range(B))
+        loss.backward()
+        for b, n in enumerate(ns):
+            dx = to_np(Xl[b].grad)
+            assert np.all(dx[n:] == 0)
+        assert_close(np.stack([to_np(t.grad) for t in Xl]), g["dX"], GRAD_RTOL, "dX")
+        for prefix, layer in layers:
+            scale = float(np.abs(g[prefix + "d_weight"]).max())
+            for k, v in layer.vars.items():
+                has = int(g[prefix + "has_d_" + k])
+                if k in ("alpha", "beta"):
+                    got = 0.0 if v.grad is None else float(v.grad[0])
+                    want = float(g[prefix + "d_" + k][0]) if has else 0.0
+                    assert abs(got - want) <= 10 * GRAD_RTOL * max(abs(want), scale), (prefix, k, got, want)
+                elif k == "M_L":
+                    assert not has and v.grad is None     # the reference gives M_L no gradient
+                else:
+                    assert has
+                    assert_close(to_np(v.grad), g[prefix + "d_" + k], GRAD_RTOL, prefix + "d" + k)
+    finally:
+        amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
+
+
+CASES = [
+    # ns,                       Fin, Fout, K
+    ([4, 5, 7, 18, 33, 6],       75,  64,  2),
+    ([5, 9, 12],                  6,   5,  1),
+    ([6, 11, 4, 20],              7,   5,  3),
+    ([48, 17],                  128, 128,  2),
+    ([1, 2, 3, 4],                5,   3,  2),      # degenerate sizes the plan still accepts
+]
+
+
+@pytest.mark.parametrize("lds_limit", [160 * 1024, 0], ids=["lds", "globaltile"])
+@pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
+@pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc", "reslap"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_packed_vs_oracle(amd, case, variant, mode, lds_limit):
+    """Packed batch + CSR Laplacian; ground truth = the oracle evaluated in float64."""
+    ns, Fin, Fout, K = CASES[case]
+    amd._ffi.lib().agcn_set_lds_limit(lds_limit)
+    try:
+        rs, X, L0, csr, p, G = synth_case(1000 + case, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
+        Lp = dLsum = None
+        if variant == orc.SGC_LL_RESLAP:
+            Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
+            dLsum = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
+        caches, tot = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLsum)
+        out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, variant, Lp, dLsum)
+        compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
+    finally:
+        amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
+
+
+def test_reslap_without_prev(amd):
+    ns, Fin, Fout, K = [6, 9, 14], 8, 6, 2
+    for mode in (orc.REFERENCE, orc.PAPER):
+        rs, X, L0, csr, p, G = synth_case(77, ns, Fin, Fout, K, orc.SGC_LL_RESLAP)
+        caches, tot = oracle_run(X, L0, p, K, mode, orc.SGC_LL_RESLAP, G)
+        out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, orc.SGC_LL_RESLAP)
+        compare_with_oracle(out, caches, tot, orc.SGC_LL_RESLAP, mode, K, has_prev=False)
+        assert out["dbeta"] is None      # beta unused => no gradient, like TF
+
+
+def test_linear_activation(amd):
+    ns, Fin, Fout, K = [5, 8], 6, 4, 2
+    rs, X, L0, csr, p, G = synth_case(5, ns, Fin, Fout, K, orc.SGC_LL)
+    out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, orc.PAPER, orc.SGC_LL, activation="linear")
+    caches = orc.layer_forward([x.astype(np.float64) for x in X], [l.astype(np.float64) for l in L0],
+                               {k: v.astype(np.float64) for k, v in p.items()}, K, orc.PAPER, orc.SGC_LL)
+    assert_close(np.concatenate(out["Y"]), np.concatenate([c["Ypre"] for c in caches]), FEATURE_RTOL, "Ypre")
+
+
+def test_large_graph_global_tile(amd):
+    """A graph too large for 160 KiB of LDS goes through the global-tile kernels on its own;
+    the small graphs of the same batch still use LDS."""
+    ns, Fin, Fout, K = [300, 12, 7], 16, 8, 2
+    for variant in (orc.SGC_LL, orc.SGC_LL_RESLAP):
+        rs, X, L0, csr, p, G = synth_case(9, ns, Fin, Fout, K, variant)
+        caches, tot = oracle_run(X, L0, p, K, orc.PAPER, variant, G)
+        out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, orc.PAPER, variant)
+        compare_with_oracle(out, caches, tot, variant, orc.PAPER, K, has_prev=False)
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_graph_gather_golden(amd, act):
+    g = load_golden("gather_%s.npz" % act)
+    ns = g["ns"]
+    Xl = [torch.from_numpy(g["X"][b]).to(DEV).requires_grad_(True) for b in range(len(ns))]
+    layer = amd.GraphGatherMol(len(ns), activation=act)
+    out = layer({"node_features": Xl, "data_slice": g["data_slice"]})
+    assert_close(to_np(out), g["out"], FEATURE_RTOL, "gather out")
+    (out * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+    assert_close(np.stack([to_np(x.grad) for x in Xl]), g["dX"], FEATURE_RTOL, "gather dX")
+
+
+def test_full_size_properties(amd):
+    """BASELINE config[1] size (Tox21-shaped B=256, 75->64, K=2): size-independent properties."""
+    B, Fin, Fout, K = 256, 75, 64, 2
+    sb = orc.synth_batch(123, B)
+    ns = sb["ns"]
+    rs = np.random.RandomState(123)
+    p = orc.init_params(rs, Fin, Fout, K)
+    gb = amd.GraphBatch.from_arrays(ns, np.concatenate(sb["X"], 0), sb["csr"], DEV)
+    G1 = torch.randn(gb.plan.rows, Fout, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    G2 = torch.randn(gb.plan.rows, Fout, device=DEV, generator=torch.Generator(DEV).manual_seed(2))
+
+    def run(mode, G):
+        layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, mode, p, DEV, activation="linear")
+        Xt = gb.X.clone().requires_grad_(True)
+        nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+        (nodes.data * G).sum().backward()
+        return nodes, res_L, res_W, Xt.grad, [layer.vars[k].grad for k in ("weight", "bias", "M_L", "alpha")]
+
+    nodes, res_L, res_W, dX, grads = run(orc.REFERENCE, G1)
+    for b in (0, 17, 255):
+        n = int(ns[b])
+        w = to_np(res_W[b])
+        assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0) and w.max() <= 1.0 and w.min() >= 0.0
+        assert np.array_equal(to_np(res_L[b]), np.eye(n, dtype=np.float32))
+    # determinism: bit-identical on a second run (no atomics anywhere)
+    nodes_b, _, res_W_b, dX_b, grads_b = run(orc.REFERENCE, G1)
+    assert torch.equal(nodes.data, nodes_b.data) and torch.equal(res_W.data, res_W_b.data)
+    assert torch.equal(dX, dX_b) and all(torch.equal(a, b) for a, b in zip(grads[:2], grads_b[:2]))
+    # with a linear activation the backward is linear in dY
+    _, _, _, dXp1, gp1 = run(orc.PAPER, G1)
+    _, _, _, dXp2, gp2 = run(orc.PAPER, G2)
+    _, _, _, dXp3, gp3 = run(orc.PAPER, G1 + G2)
+    assert_close(to_np(dXp3), to_np(dXp1 + dXp2), 5e-5, "linearity dX")
+    for a, b, c in zip(gp1[:3], gp2[:3], gp3[:3]):
+        assert_close(to_np(c), to_np(a + b), 5e-5, "linearity param grad")
+    # a sample of graphs against the oracle at full size
+    caches = orc.layer_forward([sb["X"][b] for b in (0, 100, 255)], [sb["L0"][b] for b in (0, 100, 255)],
+                               p, K, orc.PAPER, orc.SGC_LL)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, orc.PAPER, p, DEV)
+    nodes, res_L, res_W = layer({"node_features": gb.X, "graph_batch": gb})
+    for c, b in zip(caches, (0, 100, 255)):
+        assert_close(to_np(nodes[b]), c["Y"], FEATURE_RTOL, "Y full-size")
+        assert_close(to_np(res_L[b]), c["R2"], FEATURE_RTOL, "res_L full-size")
+
+
+def test_errors_are_loud(amd):
+    gb = amd.GraphBatch.from_arrays(np.array([4], np.int32), np.zeros((4, 5), np.float32),
+                                    [orc.graph_laplacian([[1], [0, 2], [1, 3], [2]])[:3]], DEV)
+    layer = amd.SGC_LL(3, 5, 2, device=DEV)      # wrong batch size
+    with pytest.raises(ValueError):
+        layer({"node_features": gb.X, "graph_batch": gb})
+    layer = amd.SGC_LL(3, 5, 1, device=DEV)
+    with pytest.raises(amd._ffi.AgcnError):
+        layer({"node_features": gb.X.cpu(), "graph_batch": gb})   # no CPU fallback

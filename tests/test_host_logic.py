@@ -1,0 +1,123 @@
+"""Host-side product code (graph preprocessing, batch packing, layer boundary) on CPU."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import agcn_amd
+    if agcn_amd._build.is_stale():
+        agcn_amd._build.build()
+    return agcn_amd
+
+
+def _adj(g):
+    ptr, flat = g["adj_ptr"], g["adj_flat"]
+    return [list(map(int, flat[ptr[i]:ptr[i + 1]])) for i in range(len(ptr) - 1)]
+
+
+LAP = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "lap_*.npz")))
+
+
+@pytest.mark.parametrize("name", LAP)
+def test_molgraph_matches_reference(amd, name):
+    """agcn_amd.MolGraph vs the reference's MolGraph (graph_structure.py:22-55,85-130):
+    integer outputs bit exact, float64 values to 1e-15."""
+    g = dict(np.load(os.path.join(GOLDEN, name)))
+    adj = _adj(g)
+    n = len(adj)
+    mg = amd.MolGraph(np.zeros((n, 3), np.float32), adj)
+    np.testing.assert_array_equal(mg.degree_list, g["degree_list"])
+    assert mg.degree_list.dtype == np.int32
+    assert mg.has_Lap == bool(g["has_lap"])
+    assert (mg.n_node, mg.n_feat, mg.max_deg, mg.min_deg) == (n, 3, 10, 0)
+    if not mg.has_Lap:
+        assert mg.Laplacian is None
+        return
+    L = mg.Laplacian
+    assert L.dtype == np.float64 and L.format == "csr"
+    np.testing.assert_array_equal(L.indptr, g["indptr"])
+    np.testing.assert_array_equal(L.indices, g["sorted_indices"])
+    np.testing.assert_allclose(L.data, g["sorted_data"], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(np.asarray(L.todense()), g["dense"], rtol=1e-15, atol=0)
+
+
+def test_graph_batch_packing(amd):
+    import agcn_oracle as orc
+    sb = orc.synth_batch(5, 6)
+    graphs = [amd.MolGraph(x, a) for x, a in zip(sb["X"], sb["adj"])]
+    gb = amd.GraphBatch.from_graphs(graphs, "cpu")
+    p = gb.plan
+    assert p.B == 6 and p.rows == p.N1 == int(sb["ns"].sum())
+    np.testing.assert_array_equal(gb.X.numpy(), np.concatenate(sb["X"], 0))
+    rp, col, val = gb.l0_rowptr.numpy(), gb.l0_col.numpy(), gb.l0_val.numpy()
+    assert rp.dtype == np.int32 and col.dtype == np.int32 and val.dtype == np.float32
+    for b in range(p.B):                      # CSR over the row space reproduces each dense L (as f32)
+        n, r0 = int(p.n[b]), int(p.row_off[b])
+        dense = np.zeros((n, n), np.float32)
+        for i in range(n):
+            for q in range(rp[r0 + i], rp[r0 + i + 1]):
+                dense[i, col[q]] = val[q]
+        np.testing.assert_array_equal(dense, sb["L0"][b])
+
+
+def test_padded_feed_batch(amd):
+    g = dict(np.load(os.path.join(GOLDEN, "topo_tox4.npz")))
+    Xl = [torch.from_numpy(x) for x in g["X"]]
+    Ll = [torch.from_numpy(l) for l in g["L"]]
+    gb = amd.GraphBatch.from_padded(Xl, Ll, g["data_slice"])
+    np.testing.assert_array_equal(gb.plan.n, g["ns"])
+    assert gb.plan.row_stride == int(g["max_atom"]) and gb.l0_ld == int(g["max_atom"])
+    views = gb.rows(gb.X)
+    assert len(views) == 4 and tuple(views[1].shape) == (20, 75)
+    assert torch.equal(views[2], Xl[2])
+
+
+def test_layer_contract(amd):
+    """Names, constructor arguments and read-back attributes the reference's containers rely on
+    (tf_graphs.py:41-73,173-194; basic_layer.py:57-67)."""
+    a = amd.SGC_LL(64, 75, 256)
+    b = amd.SGC_LL_Reslap(128, 64, 256, activation="relu", dropout=None, K=2, save_lap=True, save_output=False)
+    gth = amd.GraphGatherMol(256, activation="tanh")
+    assert [type(x).__name__ for x in (a, b, gth)] == ["SGC_LL", "SGC_LL_Reslap", "GraphGatherMol"]
+    assert a.nb_filter == 64 and a.n_atom_feature == 75 and a.K == 2 and a.batch_size == 256
+    assert b.save_lap is True and b.save_output is False and a.save_lap is False
+    assert a.name.startswith("sgc_ll_") and b.name.startswith("sgc_ll_reslap_")
+    n1 = int(amd.SGC_LL(4, 4, 1).name.rsplit("_", 1)[1])
+    assert int(amd.SGC_LL(4, 4, 1).name.rsplit("_", 1)[1]) == n1 + 1     # uid counter per class prefix
+    with pytest.raises(TypeError):
+        amd.SGC_LL(64, 75, 256, foo=1)                                      # kwargs whitelist
+    assert amd.SGC_LL(4, 4, 1, name="x", trainable=False).trainable is False
+    a.build()
+    assert set(a.vars) == {"weight", "bias", "M_L", "alpha"} and tuple(a.vars["weight"].shape) == (150, 64)
+    b.build()
+    assert set(b.vars) == {"weight", "bias", "M_L", "alpha", "beta"}
+    r = np.sqrt(6.0 / (150 + 64))
+    assert float(a.vars["weight"].detach().abs().max()) <= r and float(a.vars["bias"].detach().abs().max()) == 0
+    assert float(a.vars["alpha"][0]) == 1.0 and float(b.vars["beta"][0]) == 1.0
+
+
+def test_no_cpu_fallback(amd):
+    import agcn_oracle as orc
+    sb = orc.synth_batch(5, 2)
+    gb = amd.GraphBatch.from_arrays(sb["ns"], np.concatenate(sb["X"], 0), sb["csr"], "cpu")
+    layer = amd.SGC_LL(8, 75, 2)
+    with pytest.raises(amd._ffi.AgcnError, match="no CPU fallback"):
+        layer({"node_features": gb.X, "graph_batch": gb})
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must not depend on oracle/ in any way."""
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "adaptive-graph-convolutional-network_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "agcn_oracle" not in src and "oracle/" not in src, f
