@@ -150,6 +150,10 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
     }
   }
 
+  if (a.dL_prev) {
+    const int npadt = (int)(a.tile_off[b + 1] - toff) - nn;
+    if (tid < npadt) a.dL_prev[toff + nn + tid] = 0.f;
+  }
   // dX pad rows carry no gradient
   {
     const int npad = (nrows_owned - n) * Fin;

@@ -110,6 +110,15 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_forward_kernel(SgcA
     s_vec[j] = s;
     a.sv_s[row0 + j] = s;
   }
+  // the (<= 3) alignment floats between consecutive tiles are kept at 0
+  {
+    const int npadt = (int)(a.tile_off[b + 1] - toff) - nn;
+    if (tid < npadt) {
+      a.res_W[toff + nn + tid] = 0.f;
+      a.res_L[toff + nn + tid] = 0.f;
+      if (a.L_sum) a.L_sum[toff + nn + tid] = 0.f;
+    }
+  }
   // res_W output (graphconv.py:215)
   for (int idx = tid; idx < nn; idx += nthr) {
     const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;

@@ -1,0 +1,105 @@
+"""Static-buffer execution of one layer's forward + backward for a fixed batch: every
+device buffer and every ctypes argument block is created once, so a step is nothing but the
+C-ABI launches (no allocation, no marshalling) and can be captured into a HIP graph.
+
+All parameter gradients of the layer live in ONE flat fp32 bucket
+([dweight | dbias | dM_L | dalpha | dbeta]) so that data-parallel training needs a single
+RCCL all-reduce per step (see dist.py)."""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+from .functional import _Cfg, _desc, _gbatch, _ptr
+
+
+class SgcLLStep(object):
+    def __init__(self, layer, batch, X=None, L_prev=None, dY=None, dL_sum=None):
+        lib = _ffi.lib()
+        self.lib, self.layer, self.batch = lib, layer, batch
+        plan = batch.plan
+        X = batch.X if X is None else X
+        if not X.is_cuda:
+            raise _ffi.AgcnError("node features must live on the GPU: there is no CPU fallback")
+        dev = X.device
+        layer.build(dev)
+        self.device = dev
+        cfg = _Cfg(layer.n_atom_feature, layer.nb_filter, layer.K, layer.laplacian_mode, layer._variant,
+                   "relu" if layer.activation == "relu" else "linear")
+        self.cfg = cfg
+        reslap = cfg.variant == "SGC_LL_Reslap"
+        paper = cfg.mode == "paper"
+        self.X = X.detach().contiguous()
+        self.L_prev = L_prev if reslap else None
+        v = layer.vars
+        ldx, ldy = self.X.shape[1], cfg.Fout
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.Y = torch.zeros((plan.rows, ldy), **f32)
+        self.res_L = torch.zeros(plan.tile_elems, **f32)
+        self.res_W = torch.zeros(plan.tile_elems, **f32)
+        self.L_sum = torch.zeros(plan.tile_elems, **f32)
+        self.dY = dY if dY is not None else torch.zeros((plan.rows, ldy), **f32)
+        self.dL_sum = dL_sum
+        self.dX = torch.zeros_like(self.X)
+        has_prev = self.L_prev is not None
+        self.dL_prev = torch.zeros(plan.tile_elems, **f32) if has_prev else None
+        # flat gradient bucket
+        sizes = [("weight", cfg.Fin * cfg.K * cfg.Fout), ("bias", cfg.Fout)]
+        if paper:
+            sizes.append(("M_L", cfg.Fin * cfg.Fin))
+        sizes.append(("alpha", 1))
+        if has_prev:
+            sizes.append(("beta", 1))
+        self.bucket = torch.zeros(sum(s for _, s in sizes), **f32)
+        self.grads, o = {}, 0
+        for k, s in sizes:
+            self.grads[k] = self.bucket[o:o + s].view(v[k].shape)
+            o += s
+        self.desc = _desc(cfg, ldx, ldy)
+        self.rbytes = lib.agcn_sgc_ll_reserve_bytes(C.byref(self.desc), plan.host_ptr)
+        self.wf = lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
+        self.wb = lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
+        self.reserve = torch.zeros(self.rbytes, dtype=torch.uint8, device=dev)
+        self.ws = torch.zeros(max(self.wf, self.wb), dtype=torch.uint8, device=dev)
+        self.gb = _gbatch(batch, self.X, self.L_prev)
+        self.pr = _ffi.Params(v["weight"].data_ptr(), v["bias"].data_ptr(), v["M_L"].data_ptr(),
+                              v["alpha"].data_ptr(), _ptr(v.get("beta")))
+        self.out = _ffi.Outputs(self.Y.data_ptr(), self.res_L.data_ptr(), self.res_W.data_ptr(),
+                                self.L_sum.data_ptr())
+        g = self.grads
+        self.gr = _ffi.Grads(self.dX.data_ptr(), g["weight"].data_ptr(), g["bias"].data_ptr(),
+                             _ptr(g.get("M_L")), g["alpha"].data_ptr(), _ptr(g.get("beta")), _ptr(self.dL_prev))
+        self._graph = None
+        self._bwd = {3: lib.agcn_sgc_ll_backward, 1: lib.agcn_sgc_ll_backward_nodes,
+                     2: lib.agcn_sgc_ll_backward_params}
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self):
+        _ffi.check(self.lib.agcn_sgc_ll_forward(
+            C.byref(self.desc), C.byref(self.gb), C.byref(self.pr), C.byref(self.out),
+            self.reserve.data_ptr(), self.rbytes, self.ws.data_ptr(), self.ws.numel(), self._stream()))
+
+    def backward(self, stages=3):
+        _ffi.check(self._bwd[stages](
+            C.byref(self.desc), C.byref(self.gb), C.byref(self.pr), C.byref(self.out),
+            self.dY.data_ptr(), _ptr(self.dL_sum), C.byref(self.gr), self.reserve.data_ptr(), self.rbytes,
+            self.ws.data_ptr(), self.ws.numel(), self._stream()))
+
+    def step(self):
+        self.forward()
+        self.backward()
+
+    def capture(self):
+        """Capture forward + backward into a HIP graph (torch.cuda.CUDAGraph on ROCm)."""
+        self.step()                      # warm-up outside capture (sets function attributes)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step()
+        self._graph = g
+        return g
+
+    def replay(self):
+        self._graph.replay()

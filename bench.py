@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Headline benchmark: AGCN layer forward+backward graphs/sec on Tox21-shaped batches
+(batch 256 per GPU, SGC_LL 75 -> 64, K = 2, fp32), BASELINE.json's metric.
+
+A "step" is one pass of the hot path over one batch: SGC_LL forward (similarity tile, learned
+Laplacian, Chebyshev, filter GEMM, all outputs incl. res_L / res_W written) + backward (dX and all
+parameter gradients) and, for N > 1, the RCCL all-reduce of the flat gradient bucket.
+Inputs are resident in HBM in the packed layout before the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode paper|reference] [--no-graph]
+N > 1 is launched with torch.distributed.run, one rank per GPU.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(n, nnz, Fin, Fout, K):
+    """minimal HBM bytes of one layer call (CSR Laplacian)."""
+    n = n.astype(np.int64)
+    N1, N2, B = int(n.sum()), int((n * n).sum()), len(n)
+    P = Fin * Fin + K * Fin * Fout + Fout + 1
+    L_bytes = 8 * nnz + 4 * (N1 + B)
+    fwd = 4 * N1 * Fin + L_bytes + 4 * N1 * Fout + 8 * N2 + 4 * P
+    bwd = 4 * N1 * Fout + 8 * N1 * Fin + L_bytes + 8 * P
+    return N1, N2, fwd, bwd
+
+
+def cpu_baseline(sample, p, G, K, mode_name, budget_s=12.0):
+    """The oracle (numpy port of the reference algorithm, vectorised per graph) timed on this
+    box's host cores, single thread, same inputs, fwd+bwd.  Reported baseline, not a target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import agcn_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                    # pragma: no cover
+        threadpool_limits = None
+    mode = orc.PAPER if mode_name == "paper" else orc.REFERENCE
+    X = sample["X"]
+    L0 = []
+    for (ip, ix, dat), nb in zip(sample["csr"], sample["n"]):
+        L = np.zeros((nb, nb), np.float32)
+        for i in range(nb):
+            L[i, ix[ip[i]:ip[i + 1]]] = dat[ip[i]:ip[i + 1]]
+        L0.append(L)
+
+    def one():
+        caches = orc.layer_forward(X, L0, p, K, mode, orc.SGC_LL)
+        orc.layer_backward(caches, G, p, K, mode, orc.SGC_LL)
+
+    import contextlib
+    with (threadpool_limits(limits=1) if threadpool_limits else contextlib.nullcontext()):
+        one()
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            one()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or reps >= 20:
+                break
+    gps = len(X) * reps / dt
+    # reference-faithful variant (O(n^2) Python loop with one np.linalg.norm per pair,
+    # graphconv.py:168-178), forward only, small sample
+    m = min(32, len(X))
+    t0 = time.perf_counter()
+    orc.layer_forward(X[:m], L0[:m], p, K, orc.REFERENCE, orc.SGC_LL, loop_similarity=True)
+    loop_gps = m / (time.perf_counter() - t0)
+    return {"value": round(gps, 1), "unit": "graphs/s", "cores": 1, "kind": "port",
+            "sample": "same %d-graph batch, %d fwd+bwd passes of oracle/agcn_oracle.py (%s mode, numpy, 1 thread)"
+                      % (len(X), reps, mode_name),
+            "reference_loop_fwd_graphs_per_s": round(loop_gps, 1), "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
+    ap.add_argument("--mode", default="paper", choices=["paper", "reference"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import agcn_amd
+    from agcn_amd import synth
+
+    rank, local, world = agcn_amd.dist.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    agcn_amd._ffi.lib()
+
+    Fin, Fout, K = 75, 64, 2
+    B_global = args.batch * world
+    data = synth.tox21_batch(123, B_global, Fin)
+    shards = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(data["n"], Fin, Fout, K), world)
+    mine = shards[rank]
+    n = data["n"][mine]
+    X = [data["X"][i] for i in mine]
+    csr = [data["csr"][i] for i in mine]
+    p = synth.glorot_params(np.random.RandomState(123), Fin, Fout, K)
+    gb = agcn_amd.GraphBatch.from_arrays(n, np.concatenate(X, 0), csr, dev)
+    Gnp = np.random.RandomState(7 + rank).randn(gb.plan.rows, Fout).astype(np.float32)
+    dY = torch.from_numpy(Gnp).to(dev)
+
+    def make(mode):
+        layer = agcn_amd.SGC_LL(Fout, Fin, len(n), K=K, laplacian_mode=mode, device=dev)
+        layer.load_vars(p)
+        return agcn_amd.SgcLLStep(layer, gb, dY=dY)
+
+    st = make(args.mode)
+    use_graph = not args.no_graph
+    if use_graph:
+        st.capture()
+
+    def step():
+        if use_graph:
+            st.replay()
+        else:
+            st.step()
+        if world > 1:
+            agcn_amd.dist.allreduce_bucket(st.bucket)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed(step, args.steps, args.warmup)
+    value = B_global * args.steps / elapsed
+
+    # ---- per-kernel durations: HIP events on the launch stream, same number of steps -----------
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    names = ["sgc_forward_kernel", "sgc_backward_kernel", "param_grad_kernels"]
+    tot = [0.0, 0.0, 0.0]
+    for _ in range(5):
+        st.step()
+    torch.cuda.synchronize(dev)
+    evs = []
+    for _ in range(args.steps):
+        e = [ev() for _ in range(4)]
+        e[0].record(); st.forward()
+        e[1].record(); st.backward(1)
+        e[2].record(); st.backward(2)
+        e[3].record()
+        evs.append(e)
+    torch.cuda.synchronize(dev)
+    for e in evs:
+        for i in range(3):
+            tot[i] += e[i].elapsed_time(e[i + 1])
+    avg_ms = [t / args.steps for t in tot]
+
+    nnz = int(sum(len(c[1]) for c in csr))
+    N1, N2, fwd_b, bwd_b = algorithmic_bytes(n, nnz, Fin, Fout, K)
+    dom = 0 if avg_ms[0] >= avg_ms[1] else 1
+    dom_bytes = fwd_b if dom == 0 else bwd_b
+    achieved = dom_bytes / (avg_ms[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": int(dom_bytes),
+                "avg_launch_ms": {k: round(v, 5) for k, v in zip(names, avg_ms)},
+                "fwd_bytes": int(fwd_b), "bwd_bytes": int(bwd_b)}
+
+    # ---- the other laplacian mode, same protocol (reported beside the headline) ------------------
+    other = "reference" if args.mode == "paper" else "paper"
+    st2 = make(other)
+    if use_graph:
+        st2.capture()
+
+    def step2():
+        if use_graph:
+            st2.replay()
+        else:
+            st2.step()
+        if world > 1:
+            agcn_amd.dist.allreduce_bucket(st2.bucket)
+
+    el2 = timed(step2, args.steps, args.warmup)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        G = [Gnp[int(gb.plan.row_off[b]):int(gb.plan.row_off[b]) + int(n[b])] for b in range(len(n))]
+        cpu = cpu_baseline({"X": X, "csr": csr, "n": n}, p, G, K, args.mode)
+
+    if rank == 0:
+        line = {
+            "metric": "AGCN layer fwd+bwd graphs/sec, Tox21 batch=256 K=2",
+            "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Tox21-shaped batch=%d per GPU, SGC_LL 75->64, K=2, laplacian_mode=%s, "
+                                   "packed rows + CSR original Laplacian, fwd+bwd%s"
+                                   % (args.batch, args.mode, " + RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": B_global, "N1_local": N1, "N2_local": N2,
+                       "launch": "hip_graph" if use_graph else "eager", "parallelism": "dp%d" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "other_mode": {"laplacian_mode": other, "value": round(B_global * args.steps / el2, 1),
+                           "ms_per_step": round(1e3 * el2 / args.steps, 5)},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Data-parallel plumbing on CPU: deterministic sharding and the flat-bucket all-reduce over a
+world_size-2 gloo group.  The per-rank compute is replaced by a cheap stand-in (numpy sums over
+the rank's graphs) because the HIP path cannot run here; what is tested is that shard + SUM
+all-reduce reproduces the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import agcn_amd
+    return agcn_amd
+
+
+def test_shard_graphs_properties(amd):
+    rs = np.random.RandomState(0)
+    n = np.clip(np.rint(rs.lognormal(np.log(16), 0.5, size=2048)), 4, 132).astype(np.int32)
+    cost = amd.dist.graph_cost(n, 75, 64, 2)
+    for world in (1, 2, 4, 8):
+        shards = amd.dist.shard_graphs(cost, world)
+        assert len(shards) == world
+        allidx = np.sort(np.concatenate(shards))
+        np.testing.assert_array_equal(allidx, np.arange(2048))          # a partition
+        assert all(len(s) == 2048 // world for s in shards)              # equal graph counts
+        loads = np.array([cost[s].sum() for s in shards], dtype=np.float64)
+        assert loads.max() / loads.mean() < 1.01                          # balanced work
+        again = amd.dist.shard_graphs(cost, world)
+        assert all(np.array_equal(a, b) for a, b in zip(shards, again))  # deterministic
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, feats, out_q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import agcn_amd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, _, w = agcn_amd.dist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    shards = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(n, 75, 64, 2), world)
+    mine = shards[rank]
+    # stand-in "gradients": two tensors that are sums over the rank's graphs
+    g1 = torch.from_numpy(np.stack([feats[i] for i in mine]).sum(0))
+    g2 = torch.tensor([float(n[mine].sum())], dtype=torch.float32)
+    flat, views = agcn_amd.dist.flatten_grads([g1, g2])
+    agcn_amd.dist.allreduce_bucket(flat)
+    if rank == 0:
+        out_q.put((views[0].numpy().copy(), views[1].numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_allreduce_world2(amd):
+    rs = np.random.RandomState(1)
+    B = 16
+    n = rs.randint(4, 60, size=B).astype(np.int32)
+    feats = [rs.randn(5, 3).astype(np.float32) for _ in range(B)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, feats, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g1, g2 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(g1, np.stack(feats).sum(0), rtol=1e-6, atol=1e-6)   # == single process
+    assert float(g2[0]) == float(n.sum())                                           # integers: exact
+
+
+def test_single_process_is_noop(amd):
+    t = torch.arange(4, dtype=torch.float32)
+    assert torch.equal(amd.dist.allreduce_bucket(t.clone()), t)

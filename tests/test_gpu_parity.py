@@ -235,3 +235,37 @@ def test_errors_are_loud(amd):
     layer = amd.SGC_LL(3, 5, 1, device=DEV)
     with pytest.raises(amd._ffi.AgcnError):
         layer({"node_features": gb.X.cpu(), "graph_batch": gb})   # no CPU fallback
+
+
+def test_static_step_and_hip_graph(amd):
+    """SgcLLStep (static buffers, direct C-ABI calls, flat gradient bucket) and its HIP-graph
+    replay give bit-identical results to the autograd path."""
+    ns, Fin, Fout, K = [18, 7, 33, 4, 12], 75, 64, 2
+    for variant, mode in ((orc.SGC_LL, orc.PAPER), (orc.SGC_LL, orc.REFERENCE), (orc.SGC_LL_RESLAP, orc.PAPER)):
+        rs, X, L0, csr, p, G = synth_case(31, ns, Fin, Fout, K, variant, atoms=True)
+        gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+        layer = make_layer(amd, variant, Fout, Fin, len(ns), K, mode, p, DEV)
+        dY = torch.from_numpy(np.concatenate(G, 0)).to(DEV)
+        Xt = gb.X.clone().requires_grad_(True)
+        x = {"node_features": Xt, "graph_batch": gb}
+        if variant == orc.SGC_LL_RESLAP:
+            x["res_lap"] = []
+        out = layer(x)
+        (out[0].data * dY).sum().backward()
+        st = amd.SgcLLStep(layer, gb, dY=dY)
+        st.step()
+        torch.cuda.synchronize()
+
+        def same():
+            assert torch.equal(st.Y, out[0].data) and torch.equal(st.res_W, out[2].data)
+            assert torch.equal(st.res_L, out[1].data) and torch.equal(st.dX, Xt.grad)
+            for k, gview in st.grads.items():
+                assert torch.equal(gview, layer.vars[k].grad), k
+
+        same()
+        st.capture()
+        for t in (st.Y, st.dX, st.bucket, st.res_W):
+            t.zero_()
+        st.replay()
+        torch.cuda.synchronize()
+        same()
