@@ -4,6 +4,7 @@
 Python here is host code only: hand-written HIP kernels (csrc/) are reached through the C ABI
 of include/agcn.h via ctypes.  There is no CPU or eager fallback."""
 from . import _build, _ffi  # noqa: F401
+from ._ffi import AgcnError  # noqa: F401
 from .batch import GraphBatch, Plan, RowViews, TileViews  # noqa: F401
 from .graph_structure import Graph, MolGraph, laplacian_csr  # noqa: F401
 from .layers import SGC_LL, SGC_LL_Reslap, GraphGatherMol, Layer  # noqa: F401
