@@ -57,6 +57,7 @@ SYMBOLS = [
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
+    "agcn_profile_enable", "agcn_profile_kernels", "agcn_profile_kernel_name", "agcn_profile_collect",
 ]
 
 
@@ -93,6 +94,14 @@ def _declare(lib):
     lib.agcn_get_lds_limit.argtypes = []
     lib.agcn_set_lds_limit.restype = None
     lib.agcn_set_lds_limit.argtypes = [I32]
+    lib.agcn_profile_enable.restype = None
+    lib.agcn_profile_enable.argtypes = [C.c_int]
+    lib.agcn_profile_kernels.restype = I32
+    lib.agcn_profile_kernels.argtypes = []
+    lib.agcn_profile_kernel_name.restype = C.c_char_p
+    lib.agcn_profile_kernel_name.argtypes = [I32]
+    lib.agcn_profile_collect.restype = C.c_int
+    lib.agcn_profile_collect.argtypes = [P, P]
 
 
 def lib():
@@ -115,3 +124,14 @@ def lib():
 def check(rc):
     if rc != 0:
         raise AgcnError("agcn error %d: %s" % (rc, lib().agcn_last_error().decode()))
+
+
+def profile_collect():
+    """{kernel name: (total_ms, launches)} since the last collect (needs agcn_profile_enable(1))."""
+    import numpy as np
+    l = lib()
+    k = l.agcn_profile_kernels()
+    ms = np.zeros(k, dtype=np.float64)
+    calls = np.zeros(k, dtype=np.int64)
+    check(l.agcn_profile_collect(ms.ctypes.data, calls.ctypes.data))
+    return {l.agcn_profile_kernel_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(k)}

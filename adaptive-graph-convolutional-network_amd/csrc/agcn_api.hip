@@ -6,7 +6,6 @@
 #include "sgc_kernels.h"
 
 namespace agcn {
-size_t sgc_lds_bytes_bwd(int32_t n, int32_t Fin);
 
 namespace {
 
@@ -49,10 +48,11 @@ int count_global(const PlanView& host, int32_t Fin, bool bwd) {
   return g;
 }
 
-struct ReserveLayout { size_t s, scal, X, Lpre, total; };
+struct ReserveLayout { size_t Z, s, scal, X, Lpre, total; };
 ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   Carver c(nullptr);
   ReserveLayout r;
+  r.Z = c.off; c.take((size_t)pi.rows * d->Fin);
   r.s = c.off; c.take((size_t)pi.rows);
   r.scal = c.off; c.take((size_t)4 * pi.B);
   r.X = c.off; c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
@@ -61,11 +61,21 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   return r;
 }
 
+// Row chunks of the parameter-gradient partial products: 64-row chunks (16 MFMA k-steps) give
+// a few thousand wave-sized work items at Tox21 batch sizes; capped so the partial buffer stays small.
 int n_chunks_for(int32_t rows) {
-  int c = (rows + 255) / 256;
+  int c = (rows + 63) / 64;
   if (c < 1) c = 1;
-  if (c > 128) c = 128;
+  if (c > 256) c = 256;
   return c;
+}
+
+void fill_rows(RowsGemmArgs& g, const AgcnLayerDesc* d, const PlanView& host, const PlanView& dev) {
+  std::memset(&g, 0, sizeof(g));
+  g.rows = host.info.rows; g.Fin = d->Fin; g.Fout = d->Fout; g.K = d->K; g.activation = d->activation;
+  // padded rows: every graph owns the same number of rows
+  g.row_stride = (host.info.rows != host.info.N1) ? host.info.rows / host.info.B : 0;
+  g.n = dev.n;
 }
 
 void fill_common(SgcArgs& a, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnParams* p,
@@ -112,7 +122,8 @@ static size_t global_scratch_floats(const AgcnLayerDesc* d, const PlanView& host
   *tile = *buf = nullptr;
   if (ng > 0) {
     *tile = c->take((size_t)host.wtile_off[host.info.B]);
-    *buf = c->take((size_t)host.info.rows * (size_t)(d->Fin | 1));
+    // one image region per graph forward, two (g_k and X_{k-1} / Z^T) backward
+    *buf = c->take((bwd ? 2 : 1) * graph_scratch_floats(host.info.rows, host.info.B, d->Fin));
   }
   return ng;
 }
@@ -127,7 +138,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *pg, *part, *tile, *buf; int n_chunks; int64_t part_stride; int n_glb; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf; int n_chunks; int64_t part_stride; int n_glb; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -135,6 +146,7 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
   const bool paper = d->mode == AGCN_MODE_PAPER;
   w->g = c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
   w->dZ = paper ? c.take((size_t)pi.rows * d->Fin) : nullptr;
+  w->Gp = c.take((size_t)pi.rows * d->Fout);
   w->pg = c.take((size_t)2 * pi.B);
   w->n_chunks = n_chunks_for(pi.rows);
   w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
@@ -174,6 +186,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   SgcArgs a;
   fill_common(a, desc, batch, params, out, dev);
   char* rb = static_cast<char*>(reserve);
+  a.sv_Z = reinterpret_cast<float*>(rb + rl.Z);
   a.sv_s = reinterpret_cast<float*>(rb + rl.s);
   a.sv_scal = reinterpret_cast<float*>(rb + rl.scal);
   a.sv_X = reinterpret_cast<float*>(rb + rl.X);
@@ -184,6 +197,15 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   if (c.off > workspace_bytes || (n_glb > 0 && !workspace))
     return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, c.off);
 
+  // 1. Z = X . M_L over the packed rows (graphconv.py:164)
+  RowsGemmArgs g;
+  fill_rows(g, desc, host, dev);
+  g.Kd = desc->Fin; g.N = desc->Fin;
+  g.A0 = batch->X; g.lda0 = desc->ldx; g.Bm = params->M_L; g.Out0 = a.sv_Z; g.ldo0 = desc->Fin;
+  rc = launch_rows_gemm(g, RG_PROJECT, hip_stream);
+  if (rc != AGCN_OK) return rc;
+
+  // 2. graph-local stages (similarity tile, learned Laplacian, Chebyshev terms)
   const int B = host.info.B;
   if (n_glb > 0) {
     const size_t lds = 4 * (32 + (size_t)((host.info.max_n + 3) & ~3));
@@ -195,7 +217,13 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     rc = launch_sgc_forward(a, n_glb, B - n_glb, true, lds, hip_stream);
     if (rc != AGCN_OK) return rc;
   }
-  return AGCN_OK;
+
+  // 3. Y = act([X_0|X_1|..] . W + b), pad rows 0 (graphconv.py:238-251,117-123)
+  fill_rows(g, desc, host, dev);
+  g.Kd = desc->Fin * desc->K; g.N = desc->Fout;
+  g.A0 = batch->X; g.lda0 = desc->ldx; g.A1 = a.sv_X; g.a1_plane = (int64_t)host.info.rows * desc->Fin;
+  g.Bm = params->weight; g.bias = params->bias; g.Out0 = out->Y; g.ldo0 = desc->ldy;
+  return launch_rows_gemm(g, RG_FILTER, hip_stream);
 }
 
 // stages: bit 0 = per-graph adjoints (dX, dL_prev, dZ, per-graph dalpha/dbeta partials),
@@ -233,6 +261,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   SgcArgs a;
   fill_common(a, desc, batch, params, fwd, dev);
   char* rb = const_cast<char*>(static_cast<const char*>(reserve));
+  a.sv_Z = reinterpret_cast<float*>(rb + rl.Z);
   a.sv_s = reinterpret_cast<float*>(rb + rl.s);
   a.sv_scal = reinterpret_cast<float*>(rb + rl.scal);
   a.sv_X = reinterpret_cast<float*>(rb + rl.X);
@@ -249,6 +278,16 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
 
   const int B = host.info.B;
   if (stages & 1) {
+    // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace
+    RowsGemmArgs g;
+    fill_rows(g, desc, host, dev);
+    g.Kd = desc->Fout; g.N = desc->Fin * desc->K;
+    g.A0 = dY; g.lda0 = desc->ldy; g.Yact = fwd->Y; g.ldy = desc->ldy; g.Bm = params->weight;
+    g.Out0 = grads->dX; g.ldo0 = desc->ldx; g.Out1 = w.g; g.o1_plane = (int64_t)host.info.rows * desc->Fin;
+    g.Gp = w.Gp;
+    rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
+    if (rc != AGCN_OK) return rc;
+    // 2. graph-local adjoints
     if (w.n_glb > 0) {
       const size_t lds = 4 * (32 + 2 * (size_t)((host.info.max_n + 3) & ~3));
       rc = launch_sgc_backward(a, 0, w.n_glb, false, lds, hip_stream);
@@ -259,17 +298,25 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       rc = launch_sgc_backward(a, w.n_glb, B - w.n_glb, true, lds, hip_stream);
       if (rc != AGCN_OK) return rc;
     }
+    // 3. paper mode: dX += dZ . M_L^T
+    if (paper) {
+      fill_rows(g, desc, host, dev);
+      g.Kd = desc->Fin; g.N = desc->Fin;
+      g.A0 = w.dZ; g.lda0 = desc->Fin; g.Bm = params->M_L; g.Out0 = grads->dX; g.ldo0 = desc->ldx;
+      rc = launch_rows_gemm(g, RG_PROJECT_BWD, hip_stream);
+      if (rc != AGCN_OK) return rc;
+    }
   }
   if (!(stages & 2)) return AGCN_OK;
 
   ParamGradArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.rows = host.info.rows; pa.Fin = desc->Fin; pa.Fout = desc->Fout; pa.K = desc->K;
-  pa.activation = desc->activation; pa.ldx = desc->ldx; pa.ldy = desc->ldy; pa.paper = paper ? 1 : 0;
+  pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
-  pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 3) / 4 * 4;
+  pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = B; pa.part_stride = w.part_stride;
-  pa.X = batch->X; pa.sv_X = a.sv_X; pa.Y = fwd->Y; pa.dY = dY; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
+  pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
   return launch_param_grads(pa, hip_stream);

@@ -9,6 +9,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "agcn_internal.h"
+
+// Diagnostic build only (-DAGCN_STAMPS): per-workgroup 100 MHz wall-clock stamps at phase
+// boundaries, written to a buffer that nothing else reads.  No stamp exists in the product build.
+#ifdef AGCN_STAMPS
+extern __device__ unsigned long long g_agcn_stamps[];
+#define AGCN_STAMP(kernel_slot, i)                                                              \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0)                               \
+      g_agcn_stamps[((kernel_slot) * 1024 + blockIdx.x) * 16 + (i)] = wall_clock64();           \
+  } while (0)
+#else
+#define AGCN_STAMP(kernel_slot, i) do {} while (0)
+#endif
+
 namespace agcn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,7 +37,8 @@ struct FastDiv {
   __device__ __forceinline__ uint32_t div(uint32_t x) const { return d == 1 ? x : __umulhi(x, m); }
 };
 
-__device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
+__host__ __device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
+
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -46,6 +62,76 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   }
   __syncthreads();
   return red[31];
+}
+
+// Bulk copy with U independent loads in flight per thread: at these sizes every kernel is bound by
+// memory LATENCY, so loops are written as "issue all the loads, then consume".
+//   ld(idx) -> value; must be safe for every idx in [0, total) and is called UNCONDITIONALLY with a
+//   clamped index (so the compiler can issue the U loads back to back);  st(idx, v) consumes it.
+template <int U, class LD, class ST>
+__device__ __forceinline__ void bulk_for(int total, LD ld, ST st) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (total <= 0) return;
+  for (int base = tid; base < total; base += U * nthr) {
+    float t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[u] = ld(min(base + u * nthr, total - 1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nthr;
+      if (idx < total) st(idx, t[u]);
+    }
+  }
+}
+
+// 2-D variant over a [nrows x ncols] index space, lanes along the column index.  The (row, col)
+// pair is advanced incrementally (no division per element).
+//   ld(i, c) -> value (called unconditionally with an in-range pair);  st(i, c, v).
+template <int U, class LD, class ST>
+__device__ __forceinline__ void bulk_for2d(int nrows, int ncols, LD ld, ST st) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int total = nrows * ncols;
+  if (total <= 0) return;
+  const FastDiv dc((uint32_t)ncols);
+  const int di = (int)dc.div((uint32_t)nthr), dcn = nthr - di * ncols;   // step of one stride
+  int i = (int)dc.div((uint32_t)tid), c = tid - i * ncols;
+  for (int base = tid; base < total; base += U * nthr) {
+    float t[U];
+    int ii[U], cc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ii[u] = i; cc[u] = c;
+      const bool in = i < nrows;
+      t[u] = ld(in ? i : nrows - 1, in ? c : 0);
+      c += dcn; i += di;
+      if (c >= ncols) { c -= ncols; ++i; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ii[u] < nrows) st(ii[u], cc[u], t[u]);
+  }
+}
+
+// tile[i][col] += val for the CSR rows of one graph (one thread per row; entries of a row are
+// fetched four at a time so their latencies overlap).
+__device__ __forceinline__ void csr_scatter_add(float* tile, int ldt, int n, const int32_t* rp,
+                                                const int32_t* col, const float* val) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int p0 = rp[i], p1 = rp[i + 1];
+    for (int p = p0; p < p1; p += 4) {
+      int c[4];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = min(p + u, p1 - 1);
+        c[u] = col[pp];
+        v[u] = val[pp];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p + u < p1) tile[i * ldt + c[u]] += v[u];
+    }
+  }
 }
 
 // relu(x) - alpha * relu(-x)   (models/operators/model_operatos.py:534-558, tensor alpha)
@@ -72,6 +158,7 @@ template <int NT, class LA, class LB>
 __device__ __forceinline__ void mfma_acc(f32x4 (&acc)[NT], int row0, int col0, int Kd, LA la, LB lb) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
+#pragma unroll 4
   for (int k0 = 0; k0 < Kd; k0 += 4) {
     const float av = la(row0 + r, k0 + q);
 #pragma unroll

@@ -10,13 +10,35 @@
 // n^3 must stay below 2^32 for the exact magic-number division used by the kernels.
 #define AGCN_MAX_NODES 1600
 
+#if defined(__HIPCC__) || defined(__HIP__)
+#define AGCN_HD __host__ __device__
+#else
+#define AGCN_HD
+#endif
+
 namespace agcn {
 
 int fail(int code, const char* fmt, ...);
 
-// Leading dimension of an on-chip [rows x cols] float image: odd, so that a
-// column walk (stride ld) touches 32 different LDS banks.
-inline int32_t odd_ld(int32_t cols) { return cols | 1; }
+// Leading dimensions of on-chip images, chosen so that MFMA fragment reads are LDS
+// bank-conflict free:
+//  * an image read as the A operand (lane (r, q) reads [row0 + r][k0 + q]) -- or, transposed,
+//    as the B operand -- wants ld mod 16 in {2, 14}: r*ld + q hits 32 different banks per
+//    half-wave;
+//  * a row-major image read as the B operand (lane (r, q) reads [k0 + q][c0 + r]) wants
+//    ld = 16 mod 32.
+AGCN_HD inline int32_t ld_frag(int32_t cols) {
+  int32_t v = cols < 2 ? 2 : cols;
+  while ((v & 15) != 2 && (v & 15) != 14) ++v;
+  return v;
+}
+AGCN_HD inline int32_t ld_b(int32_t cols) { return cols <= 16 ? 16 : ((cols - 16 + 31) / 32) * 32 + 16; }
+// row stride (floats) of the per-graph image scratch used in global-tile mode
+AGCN_HD inline int32_t scratch_fs(int32_t Fin) { return (Fin + 35) & ~3; }
+// floats of one per-graph image scratch region for the whole batch (global-tile mode)
+AGCN_HD inline int64_t graph_scratch_floats_dev(int32_t rows, int32_t B, int32_t Fin) {
+  return ((int64_t)rows + 16 * (int64_t)B) * (int64_t)scratch_fs(Fin);
+}
 
 // Read-only view of a plan blob (host or device copy).
 struct PlanView {

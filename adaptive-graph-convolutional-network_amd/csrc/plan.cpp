@@ -66,7 +66,7 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
     N1 += nb;
     N2 += (int64_t)nb * nb;
     tiles += align_up((int64_t)nb * nb, 4);
-    wtiles += align_up((int64_t)nb * agcn::odd_ld(nb), 4);
+    wtiles += align_up((int64_t)nb * agcn::ld_frag(nb), 4);
     max_n = std::max(max_n, nb);
     if (rows > 0x7fffffffll / 2) return agcn::fail(AGCN_EINVAL, "agcn_plan_build: batch too large for 32-bit rows");
   }

@@ -1,0 +1,286 @@
+// Feature contractions over the PACKED row space of the whole batch (every graph's nodes at
+// once): Out[rows, N] = epilogue(A[rows, Kd] . B[Kd, N]) on the f32 matrix cores.
+// Rows are uniform work, so these launches are load-balanced however ragged the graphs are.
+//
+//   RG_PROJECT      Z  = X . M_L                                   graphconv.py:164
+//   RG_FILTER       Y  = act([X_0|X_1|..] . W + b), pad rows = 0   graphconv.py:238-251,117-123
+//                        (A column j = f*K + k is X_k[:, f]: the interleaved concat is never built)
+//   RG_FILTER_BWD   [g_0|g_1|..] = (dY . act'(Y)) . W^T            adjoint of the above; also emits Gp
+//   RG_PROJECT_BWD  dX += dZ . M_L^T                               adjoint of RG_PROJECT (paper mode)
+//
+// Workgroup = 1024 threads on 64 rows x up to 192 columns: all 16 waves stage the operands (the
+// whole K extent, or the largest chunk that fits LDS, with 8 independent loads in flight per
+// thread -- the kernel is latency-bound, not bandwidth-bound), then wave (rg, cg) owns row group rg
+// (16 rows) and the column tiles cg, cg+4, cg+8.  A image ld = 2|14 mod 16, B image ld = 16 mod 32:
+// conflict-free fragment reads.
+// v_mfma_f32_16x16x4_f32 keeps exact fp32 fmaf-chain semantics.
+#include <cstdlib>
+
+#include "agcn_device.h"
+#include "sgc_kernels.h"
+
+namespace agcn {
+
+namespace {
+constexpr int BM = 64;
+constexpr int NTHR = 1024;
+constexpr int LDS_BUDGET_FLOATS = 36 * 1024;   // 144 KiB
+}  // namespace
+
+template <int MODE, int NTW>
+__global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nwaves = blockDim.x >> 6, nthr = blockDim.x;   // 4, 8 or 16 waves
+  const int ncg = nwaves >> 2;                              // column groups (4 row groups always)
+  const int rg = wave & 3, cg = wave >> 2;
+  const int r = lane & 15, q = lane >> 4;
+  const int row_base = blockIdx.x * BM;
+  const int ntb = a.nt;                // column tiles per workgroup
+  const int col_base = blockIdx.y * (16 * ntb);
+  const int Kd = a.Kd, N = a.N;
+  const int bn = min(16 * ntb, N - col_base);
+  const int KC = a.kc;                 // K chunk, multiple of 4
+  const int ldA = ld_frag(KC);
+  const int ldB = ld_b(16 * ntb);
+  float* As = smem;                    // [BM][ldA]
+  float* Bs = smem + BM * ldA;         // [KC][ldB]
+  const int K = a.K, Fin = a.Fin, Fout = a.Fout;
+  const bool relu = a.activation == AGCN_ACT_RELU;
+  const int last_row = a.rows - 1;
+  const FastDiv dK((uint32_t)K);
+  const FastDiv dRS((uint32_t)(a.row_stride > 0 ? a.row_stride : 1));
+
+  // row validity (padded feeds only: rows >= n[b] of a graph are padding), computed once per row
+  float* rowok = Bs + KC * ldB;        // [BM] 1.0f / 0.0f
+  if (tid < BM) {
+    const int row = row_base + tid;
+    bool ok = row < a.rows;
+    if (ok && a.row_stride > 0) {
+      const int g = (int)dRS.div((uint32_t)row);
+      ok = row - g * a.row_stride < a.n[g];
+    }
+    rowok[tid] = ok ? 1.f : 0.f;
+  }
+  __syncthreads();
+
+  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 0);
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // this wave's column tiles: cg, cg + ncg, cg + 2 ncg, .. (those below ntb)
+  int my_nt = 0;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) my_nt += (cg + ncg * j < ntb) ? 1 : 0;
+
+  // Staging layout: wave `wave` (0..15) x lane; lanes run along the source-contiguous index, waves
+  // along the other one.  No divisions, 32-bit offsets from per-row base pointers, and every load of
+  // a round is issued before the first LDS store (the kernel is latency-bound).
+  for (int k0 = 0; k0 < Kd; k0 += KC) {
+    const int kc = min(KC, Kd - k0);
+    // ---- B[KC x bn] loads (flat index, 4 per thread per round; rows kc..KC are zero) ---------------------
+    // source orientation: PROJECT/FILTER  B[k][c] = Bm[k * ldbm + col_base + c]   (lanes along c)
+    //                     *_BWD           B[k][c] = Bm[(col_base + c) * ldbm + k] (lanes along k)
+    const bool transposed = (MODE == RG_FILTER_BWD || MODE == RG_PROJECT_BWD);
+    const int ldbm = (MODE == RG_PROJECT) ? Fin : (MODE == RG_FILTER) ? Fout : (MODE == RG_FILTER_BWD) ? Fout : Fin;
+    const int inner = transposed ? KC : bn;            // contiguous index extent
+    const FastDiv dInner((uint32_t)inner);
+    const int btotal = KC * bn;
+    auto b_load = [&](int e) -> float {
+      e = min(e, btotal - 1);
+      const int o = (int)dInner.div((uint32_t)e), in = e - o * inner;
+      const int kk = transposed ? in : o, c = transposed ? o : in;
+      const int k = min(k0 + kk, Kd - 1);
+      return transposed ? a.Bm[(int64_t)(col_base + c) * ldbm + k] : a.Bm[(int64_t)k * ldbm + col_base + c];
+    };
+    auto b_store = [&](int e, float v) {
+      if (e < btotal) {
+        const int o = (int)dInner.div((uint32_t)e), in = e - o * inner;
+        const int kk = transposed ? in : o, c = transposed ? o : in;
+        Bs[kk * ldB + c] = (kk < kc) ? v : 0.f;
+      }
+    };
+    // ---- A[BM x KC]: 4 rows per wave, up to 3 column passes of 64 lanes.  The first round of B loads
+    // is issued together with the A loads so that both latencies overlap. ---------------------------------
+    float tb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tb[u] = b_load(tid + nthr * u);
+    for (int ipass = 0; ipass < BM; ipass += 4 * nwaves)
+    for (int c0 = 0; c0 < KC; c0 += 192) {
+      float t[4][3];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int i = min(wave + nwaves * rr + ipass, BM - 1);
+        const int row = min(row_base + i, last_row);
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const int kk = c0 + lane + 64 * cc;
+          const int k = min(k0 + kk, Kd - 1);
+          if (MODE == RG_FILTER) {
+            const int f = (int)dK.div((uint32_t)k), kx = k - f * K;
+            const float* p0 = a.A0 + (int64_t)row * a.lda0 + f;
+            const float* p1 = a.A1 + (int64_t)(kx > 0 ? kx - 1 : 0) * a.a1_plane + (int64_t)row * Fin + f;
+            t[rr][cc] = *(kx == 0 ? p0 : p1);
+          } else if (MODE == RG_FILTER_BWD) {
+            const float g = a.A0[(int64_t)row * a.lda0 + k];
+            const float y = relu ? a.Yact[(int64_t)row * a.ldy + k] : 1.f;
+            t[rr][cc] = y > 0.f ? g : 0.f;
+          } else {
+            t[rr][cc] = a.A0[(int64_t)row * a.lda0 + k];
+          }
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int i = wave + nwaves * rr + ipass;
+        if (i >= BM) continue;
+        const float ok = rowok[i];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const int kk = c0 + lane + 64 * cc;
+          if (kk < KC) {
+            const float v = (kk < kc) ? t[rr][cc] * ok : 0.f;
+            if (MODE == RG_FILTER_BWD) {
+              const int row = row_base + i;
+              if (kk < kc && row < a.rows && blockIdx.y == 0)
+                a.Gp[(int64_t)row * Fout + k0 + kk] = v;   // masked upstream gradient, 0 on pad rows
+            }
+            As[i * ldA + kk] = v;
+          }
+        }
+      }
+    }
+    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b_store(tid + nthr * u, tb[u]);
+    for (int base = 4 * nthr; base < btotal; base += 4 * nthr) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tb[u] = b_load(base + tid + nthr * u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b_store(base + tid + nthr * u, tb[u]);
+    }
+    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 2);
+    __syncthreads();
+    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 3);
+    if (my_nt > 0) {
+      const float* Aw = As + (rg * 16 + r) * ldA + q;
+      const float* Bw = Bs + q * ldB + 16 * cg + r;
+      // KC is a multiple of 16: four MFMA k-steps per iteration, operands fetched first
+      for (int kk = 0; kk < KC; kk += 16) {
+        float av[4], bv[4][NTW];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = Aw[kk + 4 * u];
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) bv[u][j] = (j < my_nt) ? Bw[(kk + 4 * u) * ldB + 16 * ncg * j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][j], acc[j], 0, 0, 0);
+      }
+    }
+    if (k0 + KC < Kd) __syncthreads();
+  }
+
+  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 4);
+  // ---- epilogue -----------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    if (j >= my_nt) continue;
+    const int c = col_base + 16 * (cg + ncg * j) + r;
+    if (c >= N) continue;
+    const float bias_c = (MODE == RG_FILTER) ? a.bias[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row_base + rg * 16 + q * 4 + i;
+      if (row >= a.rows) continue;
+      float v = acc[j][i];
+      if (MODE == RG_PROJECT) {
+        a.Out0[(int64_t)row * a.ldo0 + c] = v;
+      } else if (MODE == RG_FILTER) {
+        v = v + bias_c;
+        if (relu) v = fmaxf(v, 0.f);
+        v = v * rowok[rg * 16 + q * 4 + i];   // tf.pad rows (graphconv.py:249-250)
+        a.Out0[(int64_t)row * a.ldo0 + c] = v;
+      } else if (MODE == RG_FILTER_BWD) {
+        const int f = (int)dK.div((uint32_t)c), kx = c - f * K;   // column f*K + k: adjoint of X_k[:, f]
+        if (kx == 0) a.Out0[(int64_t)row * a.ldo0 + f] = v;
+        else a.Out1[(int64_t)(kx - 1) * a.o1_plane + (int64_t)row * Fin + f] = v;
+      } else {
+        a.Out0[(int64_t)row * a.ldo0 + c] += v;
+      }
+    }
+  }
+  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 5);
+}
+
+namespace {
+int env_int(const char* name) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : 0;
+}
+}  // namespace
+
+template <int MODE, int NTW>
+static int launch_ntw(RowsGemmArgs a, int gy, int nt, int threads, hipStream_t s) {
+  a.nt = nt;
+  // largest K chunk whose A and B images fit the LDS budget
+  // (multiple of 16: the MFMA loop consumes four k-steps per iteration; at most 192: one lane pass
+  // of the staging covers it)
+  int kc = (a.Kd + 15) & ~15;
+  if (kc > 192) kc = 192;
+  while (kc > 32 && (int64_t)BM * ld_frag(kc) + (int64_t)kc * ld_b(16 * nt) + BM > LDS_BUDGET_FLOATS)
+    kc = ((kc / 2) + 15) & ~15;
+  a.kc = kc;
+  const size_t lds = sizeof(float) * ((size_t)BM * ld_frag(kc) + (size_t)kc * ld_b(16 * nt) + BM);
+  static const int kProfId[4] = {PK_PROJECT, PK_FILTER, PK_FILTER_BWD, PK_PROJECT_BWD};
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_gemm_kernel<MODE, NTW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(rows_gemm): %s", hipGetErrorString(e));
+  }
+  const dim3 grid((a.rows + BM - 1) / BM, gy);
+  prof_begin(kProfId[MODE], s);
+  hipLaunchKernelGGL((rows_gemm_kernel<MODE, NTW>), grid, dim3(threads), lds, s, a);
+  prof_end(s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "rows_gemm launch: %s", hipGetErrorString(e));
+  return AGCN_OK;
+}
+
+template <int MODE>
+static int launch_mode(const RowsGemmArgs& a, hipStream_t s) {
+  static const int env_gy = env_int("AGCN_RG_GY"), env_thr = env_int("AGCN_RG_THREADS");
+  int threads = (env_thr == 256 || env_thr == 512 || env_thr == 1024) ? env_thr : NTHR;
+  const int ncg = threads / 256;
+  // split N into gy column blocks: at most 3 tiles per wave, and enough blocks that the grid
+  // covers the chip (few rows => narrow blocks; the A image is then re-staged from L2 by each)
+  const int nt_total = (a.N + 15) / 16;
+  const int row_blocks = (a.rows + BM - 1) / BM;
+  int want_gy = env_gy > 0 ? env_gy : (128 + row_blocks - 1) / row_blocks;   // measured: ~150 workgroups of 1024 threads is the sweet spot
+  if (want_gy < 1) want_gy = 1;
+  if (want_gy > nt_total) want_gy = nt_total;
+  int nt = (nt_total + want_gy - 1) / want_gy;
+  if (nt > 3 * ncg) nt = 3 * ncg;
+  const int gy = (nt_total + nt - 1) / nt;
+  const int ntw = (nt + ncg - 1) / ncg;
+  if (ntw <= 1) return launch_ntw<MODE, 1>(a, gy, nt, threads, s);
+  if (ntw == 2) return launch_ntw<MODE, 2>(a, gy, nt, threads, s);
+  return launch_ntw<MODE, 3>(a, gy, nt, threads, s);
+}
+
+int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (mode) {
+    case RG_PROJECT: return launch_mode<RG_PROJECT>(a, s);
+    case RG_FILTER: return launch_mode<RG_FILTER>(a, s);
+    case RG_FILTER_BWD: return launch_mode<RG_FILTER_BWD>(a, s);
+    case RG_PROJECT_BWD: return launch_mode<RG_PROJECT_BWD>(a, s);
+  }
+  return fail(AGCN_EINVAL, "rows_gemm: bad mode");
+}
+
+}  // namespace agcn

@@ -1,25 +1,23 @@
-// Backward of SGC_LL / SGC_LL_Reslap: one workgroup per graph for everything that is local
-// to a graph (dX, the chain through the learned Laplacian, dZ, dL_prev, per-graph dalpha /
-// dbeta); the parameter gradients that reduce over all rows (dweight, dbias, dM_L) are
-// formed by param_grads.hip.
+// Graph-local part of the SGC_LL / SGC_LL_Reslap backward: one workgroup per graph.
+// The row-wise pieces run as packed GEMMs around it (rows_gemm.hip: g_k = Gp . W_k^T before,
+// dX += dZ . M_L^T after; param_grads.hip: dweight, dbias, dM_L).
 //
 // The reference gets these from TF autodiff (models/tf_modules/multitask_classifier.py:237)
 // of models/layers/graphconv.py:127-252 / graphconv_reslap.py:91-230; the analytic form is
 // SURVEY.md Appendix A.
 //
-//   Q1  g_k = (dY . act') . W_k^T                      k = 0..K-1      (MFMA f32)
 //   Q2  tile = L  (L_sum for Reslap, res_L + L_orig for SGC_LL)
-//   Q3  Chebyshev adjoint: g_{k-1} += c L^T g_k, g_{k-2} -= g_k       (MFMA f32)
-//   Q5  dL = sum_k c_k g_k X_{k-1}^T (+ dL_sum)                       (MFMA f32)
+//   Q3  Chebyshev adjoint: g_{k-1} += c L^T g_k, g_{k-2} -= g_k       (MFMA f32, operands in LDS)
+//   Q5  dL = sum_k c_k g_k X_{k-1}^T (+ dL_sum)                       (MFMA f32, operands in LDS)
 //   Q6  chain: leaky-ReLU / clip adjoints, dalpha, dbeta, dL_prev; paper mode continues
-//       through R = I - s S s, S = exp(-r), r = ||Z_i - Z_j|| to dZ, dX += dZ M^T
+//       through R = I - s S s, S = exp(-r), r = ||Z_i - Z_j|| to dZ = (diag(c 1) - c) Z
 #include "agcn_device.h"
 #include "sgc_kernels.h"
 
 namespace agcn {
 
 template <bool LDS_TILE>
-__global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(SgcArgs a, int first) {
+__global__ __launch_bounds__(1024) void sgc_backward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int b = a.order[first + blockIdx.x];
@@ -27,79 +25,73 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
   const int row0 = a.row_off[b];
   const int nrows_owned = a.row_off[b + 1] - row0;
   const int64_t toff = a.tile_off[b];
-  const int Fin = a.Fin, Fout = a.Fout, K = a.K;
-  const int ldt = n | 1, ldb = Fin | 1;
-  const int ldx = a.ldx, ldy = a.ldy;
+  const int Fin = a.Fin, K = a.K;
+  const int ldt = ld_frag(n);    // tile, Z^T image
+  const int ldf = ld_frag(Fin);  // row-major [node][f] images of g_k and X_{k-1}
+  const int ldx = a.ldx;
   const bool reslap = a.variant == AGCN_SGC_LL_RESLAP;
   const bool paper = a.mode == AGCN_MODE_PAPER;
-  const bool relu = a.activation == AGCN_ACT_RELU;
 
   float* red = smem;               // 32
   float* s_vec = smem + 32;        // n   s_i
   float* v1 = s_vec + round4(n);   // n   dd_j, later rowsum(c)_i
   float* tile;
-  float* buf;
+  float* bufA;                     // g_k image
+  float* bufB;                     // X_{k-1} image, later Z^T image
+  const int n4 = round4(n);
   if (LDS_TILE) {
     tile = v1 + round4(n);
-    buf = tile + round4(n * ldt);
+    bufA = tile + round4(n * ldt);
+    bufB = bufA + round4(n4 * ldf);
   } else {
     tile = a.ws_tile + a.wtile_off[b];
-    buf = a.ws_buf + (int64_t)row0 * ldb;
+    bufA = a.ws_buf + ((int64_t)row0 + 16 * (int64_t)b) * scratch_fs(Fin);
+    bufB = bufA + graph_scratch_floats_dev(a.rows, a.B, Fin);
   }
   const float* Xg = a.X + (int64_t)row0 * ldx;
-  const float* Yg = a.Y + (int64_t)row0 * ldy;
-  const float* dYg = a.dY + (int64_t)row0 * ldy;
   float* dXg = a.dX + (int64_t)row0 * ldx;
   const int64_t row_stride_F = (int64_t)a.rows * Fin;   // stride between k-planes of sv_X / ws_g
   const FastDiv divn((uint32_t)n);
+  const FastDiv divF((uint32_t)Fin);
   const int nn = n * n;
   const float alpha = a.alpha[0];
 
-  auto gptr = [&](int k) -> float* {  // adjoint of X_k; g_0 lives in dX
+  auto gptr = [&](int k) -> float* {  // adjoint of X_k (k >= 1); g_0 lives in dX
     return a.ws_g + (int64_t)(k - 1) * row_stride_F + (int64_t)row0 * Fin;
   };
   auto xptr = [&](int k) -> const float* { return a.sv_X + (int64_t)(k - 1) * row_stride_F + (int64_t)row0 * Fin; };
-
-  // ---- Q1: g_k = Gp . W_k^T ----------------------------------------------------------------
-  {
-    const float* Wt = a.weight;
-    for (int k = 0; k < K; ++k) {
-      float* gk = (k == 0) ? dXg : gptr(k);
-      const int ldg = (k == 0) ? ldx : Fin;
-      wg_gemm<2>(
-          n, Fin, Fout,
-          [&](int i, int c) {
-            if (i >= n || c >= Fout) return 0.f;
-            const float g = dYg[(int64_t)i * ldy + c];
-            return (!relu || Yg[(int64_t)i * ldy + c] > 0.f) ? g : 0.f;
-          },
-          [&](int c, int f) { return (c < Fout && f < Fin) ? Wt[(int64_t)(f * K + k) * Fout + c] : 0.f; },
-          [&](int i, int f, float v) { if (i < n && f < Fin) gk[(int64_t)i * ldg + f] = v; });
-    }
-  }
-  // paper mode: Z = X . M_L is needed again (r_ij and dZ); buf is otherwise unused here
-  if (paper) {
-    const float* M = a.M_L;
-    wg_gemm<2>(
-        n, Fin, Fin,
-        [&](int i, int k) { return (i < n && k < Fin) ? Xg[(int64_t)i * ldx + k] : 0.f; },
-        [&](int k, int c) { return (k < Fin && c < Fin) ? M[k * Fin + c] : 0.f; },
-        [&](int i, int c, float v) { if (i < n && c < Fin) buf[i * ldb + c] = v; });
-    for (int j = tid; j < n; j += nthr) s_vec[j] = a.sv_s[row0 + j];
-  }
-  __syncthreads();
+  // row-major image [node][f] (ld ldf) of a global [n x Fin] matrix; rows n..n4 zeroed
+  auto stage_rows = [&](float* img, const float* src, int lds) {
+    bulk_for<8>(
+        n4 * Fin,
+        [&](int idx) {
+          const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
+          return src[(int64_t)min(i, n - 1) * lds + f];
+        },
+        [&](int idx, float v) {
+          const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
+          img[i * ldf + f] = (i < n) ? v : 0.f;
+        });
+  };
 
   const bool l0_dense = a.L0_dense != nullptr;
   const bool l0_csr = a.L0_rowptr != nullptr;
   const bool has_prev = reslap && a.L_prev != nullptr;
 
+  if (paper) {
+    for (int j = tid; j < n; j += nthr) s_vec[j] = a.sv_s[row0 + j];
+  }
+
+  AGCN_STAMP(4, 0);
   if (K > 1) {
-    // ---- Q2: tile = L ------------------------------------------------------------------------
+    // ---- Q2: tile = L ----------------------------------------------------------------------------
     if (reslap) {
-      for (int idx = tid; idx < nn; idx += nthr) {
-        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
-        tile[i * ldt + j] = a.L_sum[toff + idx];
-      }
+      bulk_for<8>(
+          nn, [&](int idx) { return a.L_sum[toff + idx]; },
+          [&](int idx, float v) {
+            const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+            tile[i * ldt + j] = v;
+          });
     } else {
       const float* L0d = nullptr;
       int l0ld = n;
@@ -107,62 +99,67 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
         if (a.L0_ld > 0) { L0d = a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld; l0ld = a.L0_ld; }
         else { L0d = a.L0_dense + toff; }
       }
-      for (int idx = tid; idx < nn; idx += nthr) {
-        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
-        float v = a.res_L[toff + idx];
-        if (l0_dense) v = v + L0d[(int64_t)i * l0ld + j];
-        tile[i * ldt + j] = v;
-      }
+      bulk_for<8>(
+          nn,
+          [&](int idx) {
+            float v = a.res_L[toff + idx];
+            if (l0_dense) {
+              const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+              v = v + L0d[(int64_t)i * l0ld + j];
+            }
+            return v;
+          },
+          [&](int idx, float v) {
+            const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+            tile[i * ldt + j] = v;
+          });
       if (l0_csr) {
         __syncthreads();
-        const int32_t* rp = a.L0_rowptr + row0;
-        for (int i = tid; i < n; i += nthr) {
-          const int p0 = rp[i], p1 = rp[i + 1];
-          for (int p = p0; p < p1; ++p) tile[i * ldt + a.L0_col[p]] += a.L0_val[p];
-        }
+        csr_scatter_add(tile, ldt, n, a.L0_rowptr + row0, a.L0_col, a.L0_val);
       }
     }
-    __syncthreads();
 
-    // ---- Q3: adjoint of the Chebyshev recurrence, k = K-1 .. 1 ---------------------------------
+    AGCN_STAMP(4, 1);
+    // ---- Q3: adjoint of the Chebyshev recurrence, k = K-1 .. 1 -------------------------------------
     for (int k = K - 1; k >= 1; --k) {
       const float ck = (k >= 2) ? 2.0f : 1.0f;
-      const float* gk = gptr(k);
+      float* gk = gptr(k);
       float* gkm1 = (k == 1) ? dXg : gptr(k - 1);
       const int ldm1 = (k == 1) ? ldx : Fin;
+      __syncthreads();          // tile ready / g_k final (previous iteration's global updates)
+      stage_rows(bufA, gk, Fin);
+      __syncthreads();
       wg_gemm<2>(
           n, Fin, n,
           [&](int i, int kk) { return (i < n && kk < n) ? tile[kk * ldt + i] : 0.f; },  // L^T
-          [&](int kk, int f) { return (kk < n && f < Fin) ? gk[(int64_t)kk * Fin + f] : 0.f; },
+          [&](int kk, int f) { return (f < Fin) ? bufA[kk * ldf + f] : 0.f; },
           [&](int i, int f, float v) {
             if (i < n && f < Fin) gkm1[(int64_t)i * ldm1 + f] += ck * v;
           });
       if (k >= 2) {
         float* gkm2 = (k == 2) ? dXg : gptr(k - 2);
         const int ldm2 = (k == 2) ? ldx : Fin;
-        const FastDiv divF((uint32_t)Fin);
         for (int idx = tid; idx < n * Fin; idx += nthr) {
           const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
-          gkm2[(int64_t)i * ldm2 + f] -= gk[(int64_t)i * Fin + f];
+          gkm2[(int64_t)i * ldm2 + f] -= bufA[i * ldf + f];
         }
       }
-      __syncthreads();
     }
   }
 
-  if (a.dL_prev) {
-    const int npadt = (int)(a.tile_off[b + 1] - toff) - nn;
-    if (tid < npadt) a.dL_prev[toff + nn + tid] = 0.f;
-  }
-  // dX pad rows carry no gradient
+  AGCN_STAMP(4, 2);
+  // pad rows carry no gradient
   {
     const int npad = (nrows_owned - n) * Fin;
-    const FastDiv divF((uint32_t)Fin);
     for (int idx = tid; idx < npad; idx += nthr) {
       const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
       dXg[(int64_t)(n + i) * ldx + f] = 0.f;
       if (paper) a.ws_dZ[(int64_t)(row0 + n + i) * Fin + f] = 0.f;
     }
+  }
+  if (a.dL_prev) {
+    const int npadt = (int)(a.tile_off[b + 1] - toff) - nn;
+    if (tid < npadt) a.dL_prev[toff + nn + tid] = 0.f;
   }
 
   // Does anything consume dL?  SGC_LL in reference mode: R is a constant and min(R1, 0) == 0,
@@ -170,30 +167,33 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
   const bool need_dL = (reslap || paper) && (K > 1 || a.dL_sum != nullptr);
   float dalpha_part = 0.f, dbeta_part = 0.f;
   if (need_dL) {
-    // ---- Q5: tile = dL = sum_k c_k g_k X_{k-1}^T (+ dL_sum) ---------------------------------------
-    wg_tiles<2>(
-        n, n,
-        [&](f32x4 (&acc)[2], int r0, int c0) {
-          for (int k = 1; k < K; ++k) {
-            const float ck = (k >= 2) ? 2.0f : 1.0f;
-            const float* gk = gptr(k);
-            const float* Xp = (k == 1) ? Xg : xptr(k - 1);
-            const int ldp = (k == 1) ? ldx : Fin;
-            mfma_acc<2>(
-                acc, r0, c0, Fin,
-                [&](int i, int f) { return (i < n && f < Fin) ? ck * gk[(int64_t)i * Fin + f] : 0.f; },
-                [&](int f, int j) { return (f < Fin && j < n) ? Xp[(int64_t)j * ldp + f] : 0.f; });
-          }
-        },
-        [&](int i, int j, float v) {
-          if (i < n && j < n) {
-            if (a.dL_sum) v = v + a.dL_sum[toff + (int64_t)i * n + j];
-            tile[i * ldt + j] = v;
-          }
+    // ---- Q5: tile = dL = sum_k c_k g_k X_{k-1}^T (+ dL_sum) ----------------------------------------
+    __syncthreads();   // L^T reads done; g_k final
+    bulk_for<8>(
+        nn, [&](int idx) { return a.dL_sum ? a.dL_sum[toff + idx] : 0.f; },
+        [&](int idx, float v) {
+          const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+          tile[i * ldt + j] = v;
         });
+    for (int k = 1; k < K; ++k) {
+      const float ck = (k >= 2) ? 2.0f : 1.0f;
+      const float* Xp = (k == 1) ? Xg : xptr(k - 1);
+      const int ldp = (k == 1) ? ldx : Fin;
+      __syncthreads();
+      // for K == 2, bufA still holds g_1 (final: nothing updates g_{K-1})
+      if (!(K == 2)) stage_rows(bufA, gptr(k), Fin);
+      stage_rows(bufB, Xp, ldp);
+      __syncthreads();
+      wg_gemm<2>(
+          n, n, Fin,
+          [&](int i, int f) { return (i < n && f < Fin) ? bufA[i * ldf + f] : 0.f; },
+          [&](int f, int j) { return (f < Fin && j < n) ? bufB[j * ldf + f] : 0.f; },
+          [&](int i, int j, float v) { if (i < n && j < n) tile[i * ldt + j] += ck * v; });
+    }
     __syncthreads();
 
-    // ---- Q6: chain -------------------------------------------------------------------------------
+    AGCN_STAMP(4, 3);
+    // ---- Q6: chain ---------------------------------------------------------------------------------
     const float* sc = a.sv_scal + 4 * b;
     if (reslap) {
       const float ssL = sc[2], scL = sc[3];
@@ -226,7 +226,17 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
       }
     }
     if (paper) {
-      // tile = dR2.  R1 = scR * R, R = I - s S s (recomputed from res_W and s).
+      // Z^T image for r_ij and dZ (bufB is free now); tile = dR2.
+      {
+        const float* Zg = a.sv_Z + (int64_t)row0 * Fin;
+        bulk_for<8>(
+            n * Fin, [&](int idx) { return Zg[idx]; },
+            [&](int idx, float v) {
+              const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
+              bufB[f * ldt + i] = v;
+            });
+      }
+      // R1 = scR * R, R = I - s S s (recomputed from res_W and s).
       const float ssR = sc[0], scR = sc[1];
       const float q = reslap ? 1.0f : (float)nn;
       const float invR = 1.0f / sqrtf(ssR);
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
         tile[i * ldt + j] = -d;
       }
       __syncthreads();
+      AGCN_STAMP(4, 4);
       // ds_k = sum_j dA_kj S_kj s_j + sum_i dA_ik s_i S_ik ;  dd_k = -1/2 s_k^3 ds_k
       for (int k = tid; k < n; k += nthr) {
         float r1 = 0.f, r2 = 0.f;
@@ -275,6 +286,7 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
         tile[i * ldt + j] = -S[idx] * dS;
       }
       __syncthreads();
+      AGCN_STAMP(4, 5);
       // c_ij = (dr_ij + dr_ji) / r_ij, defined 0 where r_ij == 0 (duplicate atoms) and on the diagonal
       {
         const int nb2 = (n + 1) >> 1;
@@ -284,19 +296,18 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
           int bi, bj;
           if (!tri.get(t, dW, bi, bj)) continue;
           const int i0 = 2 * bi, j0 = 2 * bj;
-          const int i1 = min(i0 + 1, n - 1), j1 = min(j0 + 1, n - 1);
-          const float* zi0 = buf + i0 * ldb;
-          const float* zi1 = buf + i1 * ldb;
-          const float* zj0 = buf + j0 * ldb;
-          const float* zj1 = buf + j1 * ldb;
+          const float* zi = bufB + i0;
+          const float* zj = bufB + j0;
           float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+#pragma unroll 5
           for (int f = 0; f < Fin; ++f) {
-            const float u0 = zi0[f], u1 = zi1[f], w0 = zj0[f], w1 = zj1[f];
+            const float2 u = *reinterpret_cast<const float2*>(zi + f * ldt);
+            const float2 w = *reinterpret_cast<const float2*>(zj + f * ldt);
             float d;
-            d = u0 - w0; a00 = fmaf(d, d, a00);
-            d = u0 - w1; a01 = fmaf(d, d, a01);
-            d = u1 - w0; a10 = fmaf(d, d, a10);
-            d = u1 - w1; a11 = fmaf(d, d, a11);
+            d = u.x - w.x; a00 = fmaf(d, d, a00);
+            d = u.x - w.y; a01 = fmaf(d, d, a01);
+            d = u.y - w.x; a10 = fmaf(d, d, a10);
+            d = u.y - w.y; a11 = fmaf(d, d, a11);
           }
           const float acc[2][2] = {{a00, a01}, {a10, a11}};
 #pragma unroll
@@ -324,32 +335,25 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
         v1[i] = r;
       }
       __syncthreads();
-      // dZ_i = rowsum(c)_i Z_i - (c Z)_i
+      AGCN_STAMP(4, 6);
+      // dZ_i = rowsum(c)_i Z_i - (c Z)_i   (B operand = the Z^T image read transposed)
       float* dZg = a.ws_dZ + (int64_t)row0 * Fin;
       wg_gemm<2>(
           n, Fin, n,
           [&](int i, int kk) { return (i < n && kk < n) ? tile[i * ldt + kk] : 0.f; },
-          [&](int kk, int f) { return (kk < n && f < Fin) ? buf[kk * ldb + f] : 0.f; },
+          [&](int kk, int f) { return (kk < n && f < Fin) ? bufB[f * ldt + kk] : 0.f; },
           [&](int i, int f, float v) {
-            if (i < n && f < Fin) dZg[(int64_t)i * Fin + f] = v1[i] * buf[i * ldb + f] - v;
+            if (i < n && f < Fin) dZg[(int64_t)i * Fin + f] = v1[i] * bufB[f * ldt + i] - v;
           });
-      __syncthreads();
-      // dX += dZ . M_L^T
-      const float* M = a.M_L;
-      wg_gemm<2>(
-          n, Fin, Fin,
-          [&](int i, int kk) { return (i < n && kk < Fin) ? dZg[(int64_t)i * Fin + kk] : 0.f; },
-          [&](int kk, int f) { return (kk < Fin && f < Fin) ? M[f * Fin + kk] : 0.f; },
-          [&](int i, int f, float v) { if (i < n && f < Fin) dXg[(int64_t)i * ldx + f] += v; });
     }
   } else if (paper) {
     // K == 1 and no dL_sum: L never reaches Y, so dZ == 0
-    const FastDiv divF((uint32_t)Fin);
     for (int idx = tid; idx < n * Fin; idx += nthr) {
       const int i = (int)divF.div((uint32_t)idx), f = idx - i * Fin;
       a.ws_dZ[(int64_t)(row0 + i) * Fin + f] = 0.f;
     }
   }
+  AGCN_STAMP(4, 7);
   const float da = block_sum(dalpha_part, red);
   const float db = block_sum(dbeta_part, red);
   if (tid == 0) {
@@ -358,10 +362,16 @@ __global__ __launch_bounds__(LDS_TILE ? 256 : 1024) void sgc_backward_kernel(Sgc
   }
 }
 
+namespace {
+inline int64_t r4(int64_t v) { return (v + 3) & ~int64_t(3); }
+inline int64_t imax(int64_t x, int64_t y) { return x > y ? x : y; }
+}  // namespace
+
 size_t sgc_lds_bytes_bwd(int32_t n, int32_t Fin) {
-  auto r4 = [](int64_t v) { return (v + 3) & ~int64_t(3); };
-  const int64_t ldt = n | 1, ldb = Fin | 1;
-  return (size_t)(4 * (32 + 2 * r4(n) + r4((int64_t)n * ldt) + r4((int64_t)n * ldb)));
+  const int64_t ldt = ld_frag(n), ldf = ld_frag(Fin);
+  const int64_t bufA = r4(r4(n) * ldf);
+  const int64_t bufB = r4(imax(r4(n) * ldf, (int64_t)Fin * ldt));
+  return (size_t)(4 * (32 + 2 * r4(n) + r4((int64_t)n * ldt) + bufA + bufB));
 }
 
 int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
@@ -369,16 +379,18 @@ int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds
   if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
+  prof_begin(PK_GRAPH_BWD, stream);
   if (lds_tile) {
     if (lds_bytes > 64 * 1024) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sgc_backward_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(bwd): %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(sgc_backward_kernel<true>, dim3(count), dim3(256), lds_bytes, s, a, first);
+    hipLaunchKernelGGL(sgc_backward_kernel<true>, dim3(count), dim3(graph_threads(count)), lds_bytes, s, a, first);
   } else {
     hipLaunchKernelGGL(sgc_backward_kernel<false>, dim3(count), dim3(1024), lds_bytes, s, a, first);
   }
+  prof_end(stream);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "sgc_backward launch: %s", hipGetErrorString(e));
   return AGCN_OK;

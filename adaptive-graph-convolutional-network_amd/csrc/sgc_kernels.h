@@ -29,13 +29,14 @@ struct SgcArgs {
   // forward outputs (const in backward)
   float *Y, *res_L, *res_W, *L_sum;
   // reserve (forward writes, backward reads)
+  float* sv_Z;     // [rows][Fin]  Z = X . M_L
   float* sv_s;     // [rows]       s_i = d_i^-1/2
   float* sv_scal;  // [B][4]       ssR, scR, ssL, scL
   float* sv_X;     // [K-1][rows][Fin]  Chebyshev terms X_1..X_{K-1}
   float* sv_Lpre;  // [tile_elems] Reslap: L before the second clip
   // global-tile mode scratch
   float* ws_tile;  // [wtile_off[B]]
-  float* ws_buf;   // [rows][Fin|1]
+  float* ws_buf;   // per-graph image scratch, see graph_scratch_floats()
   // backward only
   const float* dY;
   const float* dL_sum;
@@ -45,28 +46,60 @@ struct SgcArgs {
   float* ws_pg;    // [B][2]            per-graph dalpha, dbeta
 };
 
+enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3 };
+
+struct RowsGemmArgs {
+  int32_t rows, Kd, N;
+  int32_t Fin, Fout, K, activation;
+  int32_t row_stride;       // 0 = packed rows (all valid)
+  const int32_t* n;         // [B] (padded rows only)
+  const float* A0; int32_t lda0;
+  const float* A1; int64_t a1_plane;
+  const float* Yact; int32_t ldy;
+  const float* Bm;
+  const float* bias;
+  float* Out0; int32_t ldo0;
+  float* Out1; int64_t o1_plane;
+  float* Gp;                // RG_FILTER_BWD: [rows][Fout] masked upstream gradient
+  int32_t kc;               // K chunk staged in LDS (set by the launcher)
+  int32_t nt;               // column tiles per workgroup (set by the launcher)
+};
+
 struct ParamGradArgs {
-  int32_t rows, Fin, Fout, K, activation, ldx, ldy, paper;
+  int32_t rows, Fin, Fout, K, ldx, paper;
   int32_t n_chunks, chunk_rows, B;
   int64_t part_stride;  // floats per chunk in `part`
   const float* X;
   const float* sv_X;
-  const float* Y;
-  const float* dY;
+  const float* Gp;      // [rows][Fout]
   const float* dZ;
   float* part;          // [n_chunks][part_stride]
   const float* pg;      // [B][2]
   float *dweight, *dbias, *dM_L, *dalpha, *dbeta;
 };
 
+// profiling ids (profile.hip)
+enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
+       PK_PARAM_REDUCE, PK_COUNT };
+bool prof_on();
+void prof_begin(int id, void* stream);
+void prof_end(void* stream);
+
+// threads per workgroup of the per-graph kernels in LDS-tile mode (256..1024)
+int graph_threads(int32_t n_graphs);
+
 // LDS bytes one graph of n nodes needs in LDS-tile mode.
 size_t sgc_lds_bytes(int32_t n, int32_t Fin);
+size_t sgc_lds_bytes_bwd(int32_t n, int32_t Fin);
+// floats of per-graph image scratch (global-tile mode) for the whole batch
+size_t graph_scratch_floats(int32_t rows, int32_t B, int32_t Fin);
 
 // `first`/`count` select a slice of plan.order; lds_tile picks the kernel flavour.
 int launch_sgc_forward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
                        void* stream);
 int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
                         void* stream);
+int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream);
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 
 }  // namespace agcn

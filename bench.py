@@ -38,6 +38,27 @@ def algorithmic_bytes(n, nnz, Fin, Fout, K):
     return N1, N2, fwd, bwd
 
 
+def kernel_bytes(N1, N2, nnz, B, Fin, Fout, K, paper):
+    """Compulsory HBM bytes of each kernel of the path (its own inputs + outputs, each counted
+    once), keyed by the profiling names of agcn_profile_kernel_name()."""
+    Lb = 8 * nnz + 4 * (N1 + B)
+    W, M = 4 * K * Fin * Fout, 4 * Fin * Fin
+    kb = {
+        "rows_gemm_kernel<PROJECT>": 8 * N1 * Fin + M,
+        # Z + X in, res_W + res_L + X_1..X_{K-1} + s out
+        "sgc_forward_kernel": 8 * N1 * Fin + Lb + 8 * N2 + 4 * (K - 1) * N1 * Fin + 4 * N1,
+        "rows_gemm_kernel<FILTER>": 4 * K * N1 * Fin + W + 4 * Fout + 4 * N1 * Fout,
+        "rows_gemm_kernel<FILTER_BWD>": 8 * N1 * Fout + W + 4 * K * N1 * Fin + 4 * N1 * Fout,
+        # g_1.. in, dX read+write, L (res_L + CSR) in; paper adds X, Z, res_W, s in and dZ out
+        "sgc_backward_kernel": 4 * (K - 1) * N1 * Fin + 8 * N1 * Fin + 4 * N2 + Lb
+                               + ((12 * N1 * Fin + 4 * N2 + 4 * N1) if paper else 0),
+        "rows_gemm_kernel<PROJECT_BWD>": 12 * N1 * Fin + M,
+        "param_grad_partial_kernel": 4 * K * N1 * Fin + 4 * N1 * Fout + (8 * N1 * Fin if paper else 0),
+        "param_grad_reduce_kernel": W + 4 * Fout + (M if paper else 0),
+    }
+    return kb
+
+
 def cpu_baseline(sample, p, G, K, mode_name, budget_s=12.0):
     """The oracle (numpy port of the reference algorithm, vectorised per graph) timed on this
     box's host cores, single thread, same inputs, fwd+bwd.  Reported baseline, not a target."""
@@ -160,39 +181,32 @@ def main():
     elapsed = timed(step, args.steps, args.warmup)
     value = B_global * args.steps / elapsed
 
-    # ---- per-kernel durations: HIP events on the launch stream, same number of steps -----------
-    def ev():
-        return torch.cuda.Event(enable_timing=True)
-
-    names = ["sgc_forward_kernel", "sgc_backward_kernel", "param_grad_kernels"]
-    tot = [0.0, 0.0, 0.0]
+    # ---- per-kernel durations: HIP events recorded by the library on the launch stream around
+    # every kernel (agcn_profile_*), over the same number of (eager) steps ---------------------------
+    lib = agcn_amd._ffi.lib()
     for _ in range(5):
         st.step()
     torch.cuda.synchronize(dev)
-    evs = []
+    lib.agcn_profile_enable(1)
     for _ in range(args.steps):
-        e = [ev() for _ in range(4)]
-        e[0].record(); st.forward()
-        e[1].record(); st.backward(1)
-        e[2].record(); st.backward(2)
-        e[3].record()
-        evs.append(e)
-    torch.cuda.synchronize(dev)
-    for e in evs:
-        for i in range(3):
-            tot[i] += e[i].elapsed_time(e[i + 1])
-    avg_ms = [t / args.steps for t in tot]
+        st.step()
+    prof = agcn_amd._ffi.profile_collect()
+    lib.agcn_profile_enable(0)
+    avg_ms = {k: (ms / c) for k, (ms, c) in prof.items() if c > 0}
 
     nnz = int(sum(len(c[1]) for c in csr))
     N1, N2, fwd_b, bwd_b = algorithmic_bytes(n, nnz, Fin, Fout, K)
-    dom = 0 if avg_ms[0] >= avg_ms[1] else 1
-    dom_bytes = fwd_b if dom == 0 else bwd_b
-    achieved = dom_bytes / (avg_ms[dom] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    kb = kernel_bytes(N1, N2, nnz, len(n), Fin, Fout, K, args.mode == "paper")
+    dom = max(avg_ms, key=avg_ms.get)
+    achieved = kb[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    step_ms = 1e3 * elapsed / args.steps
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": int(dom_bytes),
-                "avg_launch_ms": {k: round(v, 5) for k, v in zip(names, avg_ms)},
-                "fwd_bytes": int(fwd_b), "bwd_bytes": int(bwd_b)}
+                "algorithmic_bytes_per_launch": int(kb[dom]),
+                "avg_launch_ms": {k: round(v, 5) for k, v in avg_ms.items()},
+                "kernel_bytes": {k: int(v) for k, v in kb.items() if k in avg_ms},
+                "layer_fwd_bytes": int(fwd_b), "layer_bwd_bytes": int(bwd_b),
+                "layer_achieved_GBs": round((fwd_b + bwd_b) / (step_ms * 1e-3) / 1e9, 2)}
 
     # ---- the other laplacian mode, same protocol (reported beside the headline) ------------------
     other = "reference" if args.mode == "paper" else "paper"

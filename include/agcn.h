@@ -192,6 +192,15 @@ int agcn_graph_gather_backward(const void* plan_host, const void* plan_dev, cons
                                const float* dOut, int32_t F, int32_t ldx, int32_t activation,
                                float* dX /* [rows, ldx], pad rows zeroed */, void* hip_stream);
 
+/* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel of
+ * the path).  Off by default.  agcn_profile_collect waits for the events recorded since the last
+ * collect and returns, per kernel id < agcn_profile_kernels(), the total milliseconds and the
+ * number of launches.  Debug facility: not thread safe, not capturable into a HIP graph. */
+void agcn_profile_enable(int on);
+int32_t agcn_profile_kernels(void);
+const char* agcn_profile_kernel_name(int32_t id);
+int agcn_profile_collect(double* total_ms, int64_t* calls);
+
 int32_t agcn_version(void);
 const char* agcn_last_error(void);
 /* LDS bytes per workgroup above which a graph is processed with its tile in

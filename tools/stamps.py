@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Diagnostic: builds lib/libagcn_hip_stamps.so with -DAGCN_STAMPS (per-workgroup wall-clock stamps
+at phase boundaries), runs a few benchmark steps and prints, per kernel, the phase breakdown.
+Never used by the product, tests or bench.py."""
+import ctypes as C
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "adaptive-graph-convolutional-network_amd")
+LIB = os.path.join(PKG, "lib", "libagcn_hip_stamps.so")
+
+
+def build():
+    src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.cpp")))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+           "-DAGCN_STAMPS", "-fgpu-rdc", "-o", LIB] + src
+    subprocess.check_call(cmd)
+
+
+def main():
+    if "--build" in sys.argv:
+        build()
+        return
+    os.environ["AGCN_HIP_LIB"] = LIB
+    import numpy as np
+    import torch
+    import agcn_amd
+    from agcn_amd import synth
+    mode = "paper" if "--reference" not in sys.argv else "reference"
+    B = 256
+    data = synth.tox21_batch(123, B)
+    p = synth.glorot_params(np.random.RandomState(123), 75, 64, 2)
+    gb = agcn_amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], "cuda:0")
+    layer = agcn_amd.SGC_LL(64, 75, B, K=2, laplacian_mode=mode, device="cuda:0")
+    layer.load_vars(p)
+    st = agcn_amd.SgcLLStep(layer, gb, dY=torch.randn(gb.plan.rows, 64, device="cuda:0"))
+    lib = agcn_amd._ffi.lib()
+    lib.agcn_debug_read_stamps.restype = C.c_int
+    lib.agcn_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    for _ in range(5):
+        st.step()
+    buf = np.zeros(8 * 1024 * 16, dtype=np.uint64)
+    lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
+    st.step()
+    lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
+    s = buf.reshape(8, 1024, 16).astype(np.int64)
+    names = ["PROJECT", "graph_fwd", "FILTER", "FILTER_BWD", "graph_bwd", "PROJECT_BWD"]
+    for k, nm in enumerate(names):
+        blk = s[k]
+        used = blk[:, 0] > 0
+        if not used.any():
+            continue
+        t0 = blk[used, 0].min()
+        cols = [c for c in range(16) if (blk[used, c] > 0).any()]
+        last = max(cols)
+        print("%-12s blocks %4d  span %.2f us (first start -> last end)" % (nm, used.sum(), (blk[used, last].max() - t0) / 100.0))
+        rel = (blk[used][:, cols] - t0) / 100.0
+        print("   stamp idx      :", cols)
+        print("   median (us)    :", np.round(np.median(rel, 0), 2))
+        print("   max    (us)    :", np.round(rel.max(0), 2))
+        # the block that ends last
+        w = np.argmax(blk[used, last])
+        print("   slowest block  :", np.round(rel[w], 2), "(block %d)" % np.nonzero(used)[0][w])
+
+
+if __name__ == "__main__":
+    main()
