@@ -17,7 +17,9 @@ class PlanInfo(C.Structure):
     _fields_ = [("B", C.c_int32), ("N1", C.c_int32), ("rows", C.c_int32), ("max_n", C.c_int32),
                 ("N2", C.c_int64), ("tile_elems", C.c_int64), ("plan_bytes", C.c_int64),
                 ("off_n", C.c_int64), ("off_row_off", C.c_int64), ("off_tile_off", C.c_int64),
-                ("off_order", C.c_int64), ("off_wtile_off", C.c_int64)]
+                ("off_order", C.c_int64), ("off_wtile_off", C.c_int64),
+                ("n_slabs", C.c_int32), ("reserved1", C.c_int32),
+                ("off_slab_graph", C.c_int64), ("off_slab_row", C.c_int64)]
 
 
 class LayerDesc(C.Structure):
@@ -27,7 +29,7 @@ class LayerDesc(C.Structure):
 
 class GraphBatch(C.Structure):
     _fields_ = [("plan_host", C.c_void_p), ("plan_dev", C.c_void_p), ("X", C.c_void_p),
-                ("L0_dense", C.c_void_p), ("L0_ld", C.c_int32), ("reserved0", C.c_int32),
+                ("L0_dense", C.c_void_p), ("L0_ld", C.c_int32), ("L0_symmetric", C.c_int32),
                 ("L0_rowptr", C.c_void_p), ("L0_col", C.c_void_p), ("L0_val", C.c_void_p),
                 ("L_prev", C.c_void_p)]
 
@@ -52,11 +54,12 @@ ACT = {None: 0, "linear": 0, "relu": 1, "tanh": 2}
 
 # every symbol include/agcn.h declares (tests/test_abi.py checks the two lists agree)
 SYMBOLS = [
-    "agcn_plan_bytes", "agcn_plan_build", "agcn_plan_info",
+    "agcn_plan_bytes", "agcn_plan_bytes_for", "agcn_plan_build", "agcn_plan_info",
     "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
+    "agcn_get_slab_mode", "agcn_set_slab_mode",
     "agcn_profile_enable", "agcn_profile_kernels", "agcn_profile_kernel_name", "agcn_profile_collect",
 ]
 
@@ -65,6 +68,8 @@ def _declare(lib):
     P, I32, SZ = C.c_void_p, C.c_int32, C.c_size_t
     lib.agcn_plan_bytes.restype = SZ
     lib.agcn_plan_bytes.argtypes = [I32]
+    lib.agcn_plan_bytes_for.restype = SZ
+    lib.agcn_plan_bytes_for.argtypes = [P, I32]
     lib.agcn_plan_build.restype = C.c_int
     lib.agcn_plan_build.argtypes = [P, I32, I32, P, SZ]
     lib.agcn_plan_info.restype = C.c_int
@@ -94,6 +99,10 @@ def _declare(lib):
     lib.agcn_get_lds_limit.argtypes = []
     lib.agcn_set_lds_limit.restype = None
     lib.agcn_set_lds_limit.argtypes = [I32]
+    lib.agcn_get_slab_mode.restype = I32
+    lib.agcn_get_slab_mode.argtypes = []
+    lib.agcn_set_slab_mode.restype = None
+    lib.agcn_set_slab_mode.argtypes = [I32]
     lib.agcn_profile_enable.restype = None
     lib.agcn_profile_enable.argtypes = [C.c_int]
     lib.agcn_profile_kernels.restype = I32

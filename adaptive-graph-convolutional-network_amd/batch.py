@@ -20,6 +20,13 @@ import torch
 from . import _ffi
 
 
+def _csr_is_symmetric(n, indptr, indices, data):
+    """Exact (bitwise, after the float32 cast the device sees) symmetry of one CSR matrix."""
+    import scipy.sparse as sp
+    m = sp.csr_matrix((np.asarray(data).astype(np.float32), np.asarray(indices), np.asarray(indptr)), shape=(n, n))
+    return (m != m.T).nnz == 0
+
+
 class Plan(object):
     """Host + device copies of the plan blob, plus numpy views of its arrays."""
 
@@ -29,7 +36,9 @@ class Plan(object):
         if n.ndim != 1 or n.size < 1:
             raise ValueError("n_nodes must be a non-empty 1-D array")
         B = int(n.size)
-        nbytes = lib.agcn_plan_bytes(B)
+        nbytes = lib.agcn_plan_bytes_for(n.ctypes.data, B)
+        if nbytes == 0:
+            raise _ffi.AgcnError('invalid node counts')
         self.host = np.zeros(nbytes, dtype=np.uint8)
         _ffi.check(lib.agcn_plan_build(n.ctypes.data, B, int(row_stride), self.host.ctypes.data, nbytes))
         info = _ffi.PlanInfo()
@@ -46,6 +55,9 @@ class Plan(object):
         self.row_off = view(info.off_row_off, np.int32, B + 1)
         self.tile_off = view(info.off_tile_off, np.int64, B + 1)
         self.order = view(info.off_order, np.int32, B)
+        self.n_slabs = info.n_slabs
+        self.slab_graph = view(info.off_slab_graph, np.int32, info.n_slabs)
+        self.slab_row = view(info.off_slab_row, np.int32, info.n_slabs)
         self.dev = None
         self.device = None
         if device is not None:
@@ -113,11 +125,15 @@ class RowViews(Sequence):
 class GraphBatch(object):
     """A batch of graphs resident on the device in the packed layout."""
 
-    def __init__(self, plan, X, l0_rowptr=None, l0_col=None, l0_val=None, l0_dense=None, l0_ld=0):
+    def __init__(self, plan, X, l0_rowptr=None, l0_col=None, l0_val=None, l0_dense=None, l0_ld=0,
+                 l0_symmetric=False):
         self.plan = plan
         self.X = X
         self.l0_rowptr, self.l0_col, self.l0_val = l0_rowptr, l0_col, l0_val
         self.l0_dense, self.l0_ld = l0_dense, int(l0_ld)
+        # True only when every original Laplacian equals its transpose (checked on the host at
+        # pack time); the slab-parallel kernels rely on it
+        self.l0_symmetric = bool(l0_symmetric)
 
     @property
     def device(self):
@@ -150,8 +166,10 @@ class GraphBatch(object):
         col = np.concatenate([np.asarray(c[1], dtype=np.int32) for c in csr_list]) if len(csr_list) else np.zeros(0, np.int32)
         val = np.concatenate([np.asarray(c[2]).astype(np.float32) for c in csr_list]) if len(csr_list) else np.zeros(0, np.float32)
         dev = torch.device(device)
+        sym = all(_csr_is_symmetric(int(n[b]), *csr_list[b]) for b in range(len(csr_list)))
         return cls(plan, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev),
-                   torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev))
+                   torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
+                   l0_symmetric=sym)
 
     @classmethod
     def from_padded(cls, node_features, laplacians, data_slice, device=None):

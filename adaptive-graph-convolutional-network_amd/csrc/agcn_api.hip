@@ -48,7 +48,14 @@ int count_global(const PlanView& host, int32_t Fin, bool bwd) {
   return g;
 }
 
-struct ReserveLayout { size_t Z, s, scal, X, Lpre, total; };
+// Slab-parallel kernels (slab_kernels.hip): SGC_LL, K = 2, packed rows, symmetric CSR L_orig.
+bool use_slabs(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
+  if (agcn_get_slab_mode() == 0) return false;
+  return d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
+         g->L0_dense == nullptr && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
+}
+
+struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, total; };
 ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   Carver c(nullptr);
   ReserveLayout r;
@@ -57,6 +64,9 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   r.scal = c.off; c.take((size_t)4 * pi.B);
   r.X = c.off; c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
   r.Lpre = c.off; if (d->variant == AGCN_SGC_LL_RESLAP) c.take((size_t)pi.tile_elems);
+  // r_ij tiles (slab path, paper mode): reserved whenever the slab path COULD be taken
+  r.r = c.off;
+  if (d->variant == AGCN_SGC_LL && d->K == 2 && d->mode == AGCN_MODE_PAPER) c.take((size_t)pi.tile_elems);
   r.total = c.off;
   return r;
 }
@@ -138,7 +148,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf; int n_chunks; int64_t part_stride; int n_glb; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dd; int n_chunks; int64_t part_stride; int n_glb; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -147,7 +157,12 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
   w->g = c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
   w->dZ = paper ? c.take((size_t)pi.rows * d->Fin) : nullptr;
   w->Gp = c.take((size_t)pi.rows * d->Fout);
-  w->pg = c.take((size_t)2 * pi.B);
+  w->pg = c.take((size_t)2 * (pi.n_slabs > pi.B ? pi.n_slabs : pi.B));
+  w->dA = w->dd = nullptr;
+  if (d->variant == AGCN_SGC_LL && d->K == 2 && paper) {   // slab path scratch
+    w->dA = c.take((size_t)pi.tile_elems);
+    w->dd = c.take((size_t)pi.rows);
+  }
   w->n_chunks = n_chunks_for(pi.rows);
   w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
   w->part_stride = (w->part_stride + 3) / 4 * 4;
@@ -207,6 +222,12 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
 
   // 2. graph-local stages (similarity tile, learned Laplacian, Chebyshev terms)
   const int B = host.info.B;
+  a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+  a.sv_r = reinterpret_cast<float*>(rb + rl.r);
+  if (use_slabs(desc, batch, host.info)) {
+    rc = launch_slab_forward(a, hip_stream);
+    if (rc != AGCN_OK) return rc;
+  } else {
   if (n_glb > 0) {
     const size_t lds = 4 * (32 + (size_t)((host.info.max_n + 3) & ~3));
     rc = launch_sgc_forward(a, 0, n_glb, false, lds, hip_stream);
@@ -216,6 +237,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     const size_t lds = sgc_lds_bytes(host.n[host.order[n_glb]], desc->Fin);
     rc = launch_sgc_forward(a, n_glb, B - n_glb, true, lds, hip_stream);
     if (rc != AGCN_OK) return rc;
+  }
   }
 
   // 3. Y = act([X_0|X_1|..] . W + b), pad rows 0 (graphconv.py:238-251,117-123)
@@ -277,6 +299,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   }
 
   const int B = host.info.B;
+  const bool slabs = use_slabs(desc, batch, host.info);
   if (stages & 1) {
     // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace
     RowsGemmArgs g;
@@ -288,6 +311,13 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
     if (rc != AGCN_OK) return rc;
     // 2. graph-local adjoints
+    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.sv_r = reinterpret_cast<float*>(rb + rl.r);
+    a.ws_dA = w.dA; a.ws_dd = w.dd;
+    if (slabs) {
+      rc = launch_slab_backward(a, hip_stream);
+      if (rc != AGCN_OK) return rc;
+    } else {
     if (w.n_glb > 0) {
       const size_t lds = 4 * (32 + 2 * (size_t)((host.info.max_n + 3) & ~3));
       rc = launch_sgc_backward(a, 0, w.n_glb, false, lds, hip_stream);
@@ -297,6 +327,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       const size_t lds = sgc_lds_bytes_bwd(host.n[host.order[w.n_glb]], desc->Fin);
       rc = launch_sgc_backward(a, w.n_glb, B - w.n_glb, true, lds, hip_stream);
       if (rc != AGCN_OK) return rc;
+    }
     }
     // 3. paper mode: dX += dZ . M_L^T
     if (paper) {
@@ -315,7 +346,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
-  pa.B = B; pa.part_stride = w.part_stride;
+  pa.B = slabs ? host.info.n_slabs : B; pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;

@@ -48,6 +48,8 @@ struct PlanView {
   const int64_t* tile_off;
   const int32_t* order;
   const int64_t* wtile_off;
+  const int32_t* slab_graph;
+  const int32_t* slab_row;
 };
 
 // Validates the HOST blob and returns views whose pointers point into `base`
@@ -61,6 +63,8 @@ inline int plan_view(const void* plan_host, const void* base, PlanView* v) {
   v->tile_off = reinterpret_cast<const int64_t*>(p + v->info.off_tile_off);
   v->order = reinterpret_cast<const int32_t*>(p + v->info.off_order);
   v->wtile_off = reinterpret_cast<const int64_t*>(p + v->info.off_wtile_off);
+  v->slab_graph = reinterpret_cast<const int32_t*>(p + v->info.off_slab_graph);
+  v->slab_row = reinterpret_cast<const int32_t*>(p + v->info.off_slab_row);
   return AGCN_OK;
 }
 

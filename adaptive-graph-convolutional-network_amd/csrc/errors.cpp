@@ -9,6 +9,10 @@
 namespace {
 thread_local char g_err[512] = "";
 std::atomic<int32_t> g_lds_limit{160 * 1024};
+std::atomic<int32_t> g_slab_mode{[] {
+  const char* e = std::getenv("AGCN_SLAB_MODE");   // 0 disables the slab-parallel kernels
+  return (e && e[0] == '0') ? 0 : 1;
+}()};
 }  // namespace
 
 namespace agcn {
@@ -24,6 +28,8 @@ int fail(int code, const char* fmt, ...) {
 extern "C" const char* agcn_last_error(void) { return g_err; }
 extern "C" int32_t agcn_version(void) { return AGCN_VERSION; }
 extern "C" int32_t agcn_get_lds_limit(void) { return g_lds_limit.load(); }
+extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }
+extern "C" void agcn_set_slab_mode(int32_t mode) { g_slab_mode.store(mode ? 1 : 0); }
 extern "C" void agcn_set_lds_limit(int32_t bytes) {
   if (bytes < 0) bytes = 0;
   if (bytes > 160 * 1024) bytes = 160 * 1024;

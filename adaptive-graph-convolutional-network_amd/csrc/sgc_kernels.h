@@ -43,7 +43,14 @@ struct SgcArgs {
   float *dX, *dL_prev;
   float* ws_g;     // [K-1][rows][Fin]  adjoints of X_1..X_{K-1}
   float* ws_dZ;    // [rows][Fin]       (paper mode)
-  float* ws_pg;    // [B][2]            per-graph dalpha, dbeta
+  float* ws_pg;    // [B or n_slabs][2] per-graph / per-slab dalpha, dbeta
+  // slab-parallel path (slab_kernels.hip)
+  const int32_t* slab_graph;
+  const int32_t* slab_row;
+  int32_t n_slabs;
+  float* sv_r;     // [tile_elems]  r_ij = ||Z_i - Z_j||  (paper mode, forward -> backward)
+  float* ws_dA;    // [tile_elems]  dA = -dR               (paper mode, bwd1 -> bwd2)
+  float* ws_dd;    // [rows]        dd_j                   (paper mode, bwd1 -> bwd2)
 };
 
 enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3 };
@@ -67,7 +74,7 @@ struct RowsGemmArgs {
 
 struct ParamGradArgs {
   int32_t rows, Fin, Fout, K, ldx, paper;
-  int32_t n_chunks, chunk_rows, B;
+  int32_t n_chunks, chunk_rows, B;   // B = number of [dalpha, dbeta] partial pairs in pg
   int64_t part_stride;  // floats per chunk in `part`
   const float* X;
   const float* sv_X;
@@ -80,7 +87,7 @@ struct ParamGradArgs {
 
 // profiling ids (profile.hip)
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
-       PK_PARAM_REDUCE, PK_COUNT };
+       PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_COUNT };
 bool prof_on();
 void prof_begin(int id, void* stream);
 void prof_end(void* stream);
@@ -100,6 +107,10 @@ int launch_sgc_forward(const SgcArgs& a, int32_t first, int32_t count, bool lds_
 int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
                         void* stream);
 int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream);
+// slab-parallel SGC_LL (K = 2, packed rows, symmetric CSR L_orig)
+bool slab_path_fits(int32_t Fin);
+int launch_slab_forward(const SgcArgs& a, void* stream);
+int launch_slab_backward(const SgcArgs& a, void* stream);
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 
 }  // namespace agcn

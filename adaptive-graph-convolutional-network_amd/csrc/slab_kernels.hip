@@ -1,0 +1,553 @@
+// Slab-parallel SGC_LL (K = 2): the graph-local n x n work of one layer cut into strips of
+// AGCN_SLAB_ROWS = 16 consecutive rows of one graph's tile -- one 256-thread workgroup per slab,
+// columns walked in chunks, so the work is balanced over the CUs however ragged the batch is and
+// any n fits (LDS holds chunk-sized images only).  Same math as sgc_forward.hip / sgc_backward.hip
+// (graphconv.py:163-236 and its TF autodiff), valid because for SGC_LL
+//   * clip_by_average_norm never clips (|R_ij| <= 1 => ||R||_F <= n < n^2), so the scale is exactly 1
+//     and no graph-wide norm is needed (graphconv.py:212);
+//   * L = lrelu(R) + L_orig is symmetric when L_orig is (the caller states it: L0_symmetric), so
+//     column strips of L are row strips.
+// Graph-wide quantities that a strip needs from other strips cross a kernel boundary:
+//   slab_sim  : S strip = exp(-||Z_i - Z_j||), r strip, degree -> s_i          (res_W, sv_r, sv_s)
+//   slab_lap  : R strip, res_L, L strip = lrelu(R) + L_orig, X_1[I] = L[I,:] X_0
+//   slab_bwd1 : dX[I] += L[I,:] g_1; dL row/column strips, dA strip, dd_i, dalpha partial
+//   slab_bwd2 : c strip = (dr_ij + dr_ji) / r_ij, dZ[I] = rowsum(c) Z[I] - c Z
+// Wave w of a workgroup owns slab rows 4w..4w+3 in the element-wise phases (lanes run along the
+// columns: coalesced row accesses of the packed tiles) and column tiles w, w+4 of the 16 x Fin MFMA
+// outputs.  Reductions are per-lane sequential + a fixed shuffle tree: reproducible bit for bit.
+#include "agcn_device.h"
+#include "sgc_kernels.h"
+
+#include <float.h>
+
+namespace agcn {
+
+namespace {
+constexpr int SH = AGCN_SLAB_ROWS;   // 16
+constexpr int CH = 64;               // columns per chunk (element-wise + MFMA phases)
+constexpr int CHP = 66;              // strip chunk leading dimension (66 mod 16 = 2: conflict-free A reads)
+constexpr int CH1 = 128;             // columns per chunk of the pairwise-distance phase
+constexpr int CH1P = 130;
+
+struct SlabCtx {
+  int b, i0, n, nr, row0;
+  int64_t toff;
+};
+
+__device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a) {
+  SlabCtx c;
+  const int s = blockIdx.x;
+  c.b = a.slab_graph[s];
+  c.i0 = a.slab_row[s];
+  c.n = a.n[c.b];
+  c.nr = min(SH, c.n - c.i0);
+  c.row0 = a.row_off[c.b];
+  c.toff = a.tile_off[c.b];
+  return c;
+}
+
+// wave-wide sum, result in every lane (fixed xor tree)
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Stage `nrows` (<= maxrows) rows of a row-major global matrix into an LDS image [maxrows][ld];
+// rows nrows..maxrows and columns Fin..F4 are zero.  Lanes along the feature index.
+__device__ __forceinline__ void stage_rows_img(float* img, int ld, const float* src, int lds, int nrows,
+                                                int maxrows, int Fin) {
+  const int F4 = round4(Fin);
+  bulk_for2d<8>(
+      maxrows, F4,
+      [&](int i, int f) { return src[(int64_t)min(i, nrows - 1) * lds + min(f, Fin - 1)]; },
+      [&](int i, int f, float v) { img[i * ld + f] = (i < nrows && f < Fin) ? v : 0.f; });
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Fin = a.Fin, n = c.n;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  float* Zit = smem;                 // [Fin][16]   slab rows, transposed
+  float* Zjt = smem + Fin * SH;      // [Fin][CH1P] column chunk, transposed
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
+
+  // slab rows (lanes along f: contiguous source)
+  bulk_for2d<4>(
+      SH, Fin, [&](int ii, int f) { return Zg[(int64_t)(c.i0 + min(ii, c.nr - 1)) * Fin + f]; },
+      [&](int ii, int f, float v) { Zit[f * SH + ii] = (ii < c.nr) ? v : 0.f; });
+
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < n; c0 += CH1) {
+    const int nc = min(CH1, n - c0);
+    if (c0 > 0) __syncthreads();
+    bulk_for2d<8>(
+        nc, Fin, [&](int jj, int f) { return Zg[(int64_t)(c0 + jj) * Fin + f]; },
+        [&](int jj, int f, float v) { Zjt[f * CH1P + jj] = v; });
+    __syncthreads();
+    // rows 4*wave .. 4*wave+3  x  columns 2*lane, 2*lane+1 of the chunk
+    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const float* zi = Zit + 4 * wave;
+    const float* zj = Zjt + 2 * lane;
+#pragma unroll 5
+    for (int f = 0; f < Fin; ++f) {
+      const float4 u = *reinterpret_cast<const float4*>(zi + f * SH);
+      const float2 v = *reinterpret_cast<const float2*>(zj + f * CH1P);
+      float d;
+      d = u.x - v.x; acc[0][0] = fmaf(d, d, acc[0][0]);
+      d = u.x - v.y; acc[0][1] = fmaf(d, d, acc[0][1]);
+      d = u.y - v.x; acc[1][0] = fmaf(d, d, acc[1][0]);
+      d = u.y - v.y; acc[1][1] = fmaf(d, d, acc[1][1]);
+      d = u.z - v.x; acc[2][0] = fmaf(d, d, acc[2][0]);
+      d = u.z - v.y; acc[2][1] = fmaf(d, d, acc[2][1]);
+      d = u.w - v.x; acc[3][0] = fmaf(d, d, acc[3][0]);
+      d = u.w - v.y; acc[3][1] = fmaf(d, d, acc[3][1]);
+    }
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int il = 4 * wave + di, i = c.i0 + il;
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const int jj = 2 * lane + dj, j = c0 + jj;
+        if (il < c.nr && jj < nc) {
+          const float r = sqrtf(acc[di][dj]);
+          // S_ii = 0 (graphconv.py:171-173); exp(-1 * norm) otherwise (:176-177)
+          const float sv = (i == j) ? 0.f : expf(-r);
+          a.res_W[c.toff + (int64_t)i * n + j] = sv;
+          if (paper) a.sv_r[c.toff + (int64_t)i * n + j] = r;
+          rs[di] += sv;
+        }
+      }
+    }
+  }
+  // degree of the slab's rows (S is bit-symmetric, so row sums == column sums), s = d^-1/2
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const float d = wave_allsum(rs[di]) + FLT_TRUE_MIN;   // np.spacing(0), graphconv.py:196
+    const int il = 4 * wave + di;
+    if (lane == 0 && il < c.nr) a.sv_s[c.row0 + c.i0 + il] = 1.0f / sqrtf(d);
+  }
+  // alignment floats behind the tile stay 0
+  if (c.i0 + SH >= n) {
+    const int nn = n * n, npadt = (int)(a.tile_off[c.b + 1] - c.toff) - nn;
+    if (tid < npadt) {
+      a.res_W[c.toff + nn + tid] = 0.f;
+      a.res_L[c.toff + nn + tid] = 0.f;
+      if (a.L_sum) a.L_sum[c.toff + nn + tid] = 0.f;
+      if (paper) a.sv_r[c.toff + nn + tid] = 0.f;
+    }
+    if (tid == 0) {   // clip_by_average_norm(R, 1) never clips for SGC_LL: scale exactly 1
+      float* sc = a.sv_scal + 4 * c.b;
+      sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared by slab_lap and slab_bwd1: the chunk [16 x CH] of L = lrelu(R) + L_orig in LDS.
+//   FWD: R from res_W and s (computes and writes res_L);  !FWD: lrelu(R) read back from res_L.
+template <bool FWD>
+__device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c, float* Ls, int c0, int nc,
+                                              const float (&si)[4], float alpha, int csr_p0, int csr_p1) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = c.n, j = c0 + lane;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const bool cv = lane < nc;
+  float sj = 0.f;
+  if (FWD && paper) sj = a.sv_s[c.row0 + min(j, n - 1)];
+  float v[4];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = 4 * wave + di, i = c.i0 + il;
+    const int64_t o = c.toff + (int64_t)min(i, n - 1) * n + min(j, n - 1);
+    if (FWD) v[di] = paper ? a.res_W[o] : 0.f;
+    else v[di] = a.res_L[o];
+  }
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = 4 * wave + di, i = c.i0 + il;
+    const bool ok = cv && il < c.nr;
+    float L = v[di];
+    if (FWD) {
+      float R = (i == j) ? 1.f : 0.f;            // reference: I - D*W*D elementwise == I
+      if (paper) R = R - (si[di] * v[di]) * sj;  // paper: I - s S s
+      L = lrelu(R, alpha);                       // (R * 1.0f: the clip scale is exactly 1)
+      if (ok) a.res_L[c.toff + (int64_t)i * n + j] = L;
+    }
+    Ls[il * CHP + lane] = ok ? L : 0.f;
+  }
+  __syncthreads();
+  // + L_orig rows of the slab (CSR, one thread per row)
+  if (tid < c.nr) {
+    for (int p = csr_p0; p < csr_p1; p += 4) {
+      int cc[4];
+      float vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = min(p + u, csr_p1 - 1);
+        cc[u] = a.L0_col[pp];
+        vv[u] = a.L0_val[pp];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p + u < csr_p1 && cc[u] >= c0 && cc[u] < c0 + CH) Ls[tid * CHP + cc[u] - c0] += vv[u];
+    }
+  }
+}
+
+// acc[j] += A[16 x kdim] (LDS image, ld lda) . B[kdim x Fin] (LDS row-major image, ld ldb), this wave's
+// column tiles w and w + 4
+__device__ __forceinline__ void strip_gemm_rowmajor(f32x4 (&acc)[2], const float* A, int lda, const float* B,
+                                                    int ldb, int kdim, int ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const bool t1 = wave + 4 < ntiles;
+  if (wave >= ntiles) return;
+  for (int k0 = 0; k0 < kdim; k0 += 16) {
+    float av[4], b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = A[r * lda + k0 + 4 * u + q];
+      b0[u] = B[(k0 + 4 * u + q) * ldb + 16 * wave + r];
+      b1[u] = t1 ? B[(k0 + 4 * u + q) * ldb + 16 * (wave + 4) + r] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b0[u], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b1[u], acc[1], 0, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int Fin = a.Fin, n = c.n;
+  const int ldbx = ld_b(Fin);
+  const int ntiles = (Fin + 15) >> 4;
+  float* Ls = smem;                // [16][CHP]
+  float* Xs = smem + SH * CHP;     // [CH][ldbx]
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+
+  float si[4];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) si[di] = a.sv_s[c.row0 + c.i0 + min(4 * wave + di, c.nr - 1)];
+  int csr_p0 = 0, csr_p1 = 0;
+  if (tid < c.nr) {
+    csr_p0 = a.L0_rowptr[c.row0 + c.i0 + tid];
+    csr_p1 = a.L0_rowptr[c.row0 + c.i0 + tid + 1];
+  }
+
+  f32x4 acc[2];
+  acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const int nc = min(CH, n - c0);
+    if (c0 > 0) __syncthreads();
+    build_L_chunk<true>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1);
+    stage_rows_img(Xs, ldbx, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
+    __syncthreads();
+    if (a.L_sum) {   // optional 4th output of SGC_LL: the combined Laplacian
+#pragma unroll
+      for (int di = 0; di < 4; ++di) {
+        const int il = 4 * wave + di;
+        if (il < c.nr && lane < nc) a.L_sum[c.toff + (int64_t)(c.i0 + il) * n + c0 + lane] = Ls[il * CHP + lane];
+      }
+    }
+    strip_gemm_rowmajor(acc, Ls, CHP, Xs, ldbx, (nc + 15) & ~15, ntiles);
+  }
+  // X_1[I] = L[I, :] X_0   (graphconv.py:231)
+  float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * Fin;
+  if (wave < ntiles) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = 16 * (wave + 4 * t) + r;
+      if (wave + 4 * t < ntiles && col < Fin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * q + i < c.nr) Xo[(int64_t)(4 * q + i) * Fin + col] = acc[t][i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile[16 x 64] = A[16 x Fin] . T^T, T = row image [64][ldf] of the chunk's nodes (B[f][j] = T[j][f]);
+// wave w owns column tile w.  Result written to the LDS strip `out` [16][CHP].
+__device__ __forceinline__ void strip_gemm_transposed(float* out, const float* A, const float* T, int ldf, int F16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < F16; k0 += 16) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = A[r * ldf + k0 + 4 * u + q];
+      bv[u] = T[(16 * wave + r) * ldf + k0 + 4 * u + q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[(4 * q + i) * CHP + 16 * wave + r] = acc[i];
+}
+
+__global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int Fin = a.Fin, n = c.n;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const int ldf = ld_frag((Fin + 15) & ~15);   // images are read in k-steps of 16: pad columns are zero
+  const int F16 = (Fin + 15) & ~15;
+  const int ntiles = (Fin + 15) >> 4;
+  float* Ls = smem;                     // [16][CHP]  L chunk
+  float* G1s = Ls + SH * CHP;           // [CH][ldf]  g_1 rows of the chunk
+  float* red = G1s + CH * ldf;          // 32
+  float* T = red + 32;                  // [16][CHP]  dL row strip        (paper)
+  float* Cc = T + SH * CHP;             // [16][CHP]  dL column strip^T   (paper)
+  float* gI = Cc + SH * CHP;            // [16][ldf]  g_1 rows of the slab (paper)
+  float* xI = gI + SH * ldf;            // [16][ldf]  X_0 rows of the slab (paper)
+  float* X0s = xI + SH * ldf;           // [CH][ldf]  X_0 rows of the chunk (paper)
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * Fin;   // adjoint of X_1 (K = 2: plane 0)
+
+  float si[4];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) si[di] = paper ? a.sv_s[c.row0 + c.i0 + min(4 * wave + di, c.nr - 1)] : 0.f;
+  int csr_p0 = 0, csr_p1 = 0;
+  if (tid < c.nr) {
+    csr_p0 = a.L0_rowptr[c.row0 + c.i0 + tid];
+    csr_p1 = a.L0_rowptr[c.row0 + c.i0 + tid + 1];
+  }
+  if (paper) {
+    stage_rows_img(gI, ldf, g1 + (int64_t)c.i0 * Fin, Fin, c.nr, SH, F16 <= Fin ? Fin : Fin);
+    stage_rows_img(xI, ldf, Xg + (int64_t)c.i0 * a.ldx, a.ldx, c.nr, SH, Fin);
+    // columns round4(Fin)..F16 of the A images must be zero as well
+    for (int idx = tid; idx < SH * (F16 - round4(Fin)); idx += 256) {
+      const int w = F16 - round4(Fin), i = idx / w, f = round4(Fin) + idx - i * w;
+      gI[i * ldf + f] = 0.f;
+      xI[i * ldf + f] = 0.f;
+    }
+  }
+
+  f32x4 acc[2];
+  acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ds[4] = {0.f, 0.f, 0.f, 0.f};
+  float dalpha_part = 0.f;
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const int nc = min(CH, n - c0);
+    if (c0 > 0) __syncthreads();
+    build_L_chunk<false>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1);
+    stage_rows_img(G1s, ldf, g1 + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
+    if (paper) {
+      stage_rows_img(X0s, ldf, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
+      for (int idx = tid; idx < CH * (F16 - round4(Fin)); idx += 256) {
+        const int w = F16 - round4(Fin), i = idx / w, f = round4(Fin) + idx - i * w;
+        G1s[i * ldf + f] = 0.f;
+        X0s[i * ldf + f] = 0.f;
+      }
+    }
+    __syncthreads();
+    // dX[I] += L[I, :] g_1   (== (L^T g_1)[I]: L is symmetric)
+    strip_gemm_rowmajor(acc, Ls, CHP, G1s, ldf, (nc + 15) & ~15, ntiles);
+    if (paper) {
+      strip_gemm_transposed(T, gI, X0s, ldf, F16);    // dL[I, chunk]   = g_1[I] . X_0[chunk]^T
+      strip_gemm_transposed(Cc, xI, G1s, ldf, F16);   // dL[chunk, I]^T = X_0[I] . g_1[chunk]^T
+      __syncthreads();
+      const int j = c0 + lane;
+      const bool cv = lane < nc;
+      const float sj = a.sv_s[c.row0 + min(j, n - 1)];
+      float Sv[4];
+#pragma unroll
+      for (int di = 0; di < 4; ++di) {
+        const int i = c.i0 + min(4 * wave + di, c.nr - 1);
+        Sv[di] = a.res_W[c.toff + (int64_t)i * n + min(j, n - 1)];
+      }
+#pragma unroll
+      for (int di = 0; di < 4; ++di) {
+        const int il = 4 * wave + di, i = c.i0 + il;
+        if (cv && il < c.nr) {
+          float R = (i == j) ? 1.f : 0.f;
+          R = R - (si[di] * Sv[di]) * sj;                 // R1 == R (clip scale 1)
+          const float lg = lrelu_grad(R, alpha);
+          const float dL = T[il * CHP + lane];
+          dalpha_part += dL * fminf(R, 0.f);
+          const float dA = -(dL * lg);                     // dA_ij = -dR_ij
+          const float dAt = -(Cc[il * CHP + lane] * lg);   // dA_ji (R symmetric)
+          a.ws_dA[c.toff + (int64_t)i * n + j] = dA;
+          // ds_i = sum_j dA_ij S_ij s_j + sum_j dA_ji S_ij s_j
+          ds[di] += (dA * Sv[di]) * sj + (dAt * Sv[di]) * sj;
+        }
+      }
+    }
+  }
+  // dX rows of the slab (g_0 already there from the packed filter adjoint)
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+  if (wave < ntiles) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = 16 * (wave + 4 * t) + r;
+      if (wave + 4 * t < ntiles && col < Fin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * q + i < c.nr) dXg[(int64_t)(4 * q + i) * a.ldx + col] += acc[t][i];
+      }
+    }
+  }
+  if (paper) {
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const float t = wave_allsum(ds[di]);
+      const int il = 4 * wave + di;
+      if (lane == 0 && il < c.nr) {
+        const float sk = si[di];
+        a.ws_dd[c.row0 + c.i0 + il] = -0.5f * sk * sk * sk * t;   // dd_k = -1/2 s_k^3 ds_k
+      }
+    }
+  }
+  const float da = block_sum(dalpha_part, red);
+  if (tid == 0) {
+    a.ws_pg[2 * blockIdx.x + 0] = da;
+    a.ws_pg[2 * blockIdx.x + 1] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int Fin = a.Fin, n = c.n;
+  const int ldbx = ld_b(Fin);
+  const int ntiles = (Fin + 15) >> 4;
+  float* Cs = smem;                // [16][CHP]  c strip chunk
+  float* Zs = Cs + SH * CHP;       // [CH][ldbx] Z rows of the chunk
+  float* csum = Zs + CH * ldbx;    // [16]
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
+
+  float si[4], ddi[4];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int row = c.row0 + c.i0 + min(4 * wave + di, c.nr - 1);
+    si[di] = a.sv_s[row];
+    ddi[di] = a.ws_dd[row];
+  }
+  f32x4 acc[2];
+  acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const int nc = min(CH, n - c0);
+    if (c0 > 0) __syncthreads();
+    const int j = c0 + lane, jc = min(j, n - 1);
+    const bool cv = lane < nc;
+    const float sj = a.sv_s[c.row0 + jc], ddj = a.ws_dd[c.row0 + jc];
+    float dA[4], dAt[4], Sv[4], rv[4];
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int i = c.i0 + min(4 * wave + di, c.nr - 1);
+      const int64_t o = c.toff + (int64_t)i * n + jc;
+      dA[di] = a.ws_dA[o];
+      dAt[di] = a.ws_dA[c.toff + (int64_t)jc * n + i];
+      Sv[di] = a.res_W[o];
+      rv[di] = a.sv_r[o];
+    }
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int il = 4 * wave + di, i = c.i0 + il;
+      float cij = 0.f;
+      if (cv && il < c.nr && i != j && rv[di] > 0.f) {
+        // dS_ij = dA_ij s_i s_j + dd_j ; dr_ij = -S_ij dS_ij  (and the transposed pair)
+        const float dr_ij = -Sv[di] * (dA[di] * si[di] * sj + ddj);
+        const float dr_ji = -Sv[di] * (dAt[di] * sj * si[di] + ddi[di]);
+        cij = (dr_ij + dr_ji) / rv[di];   // defined 0 where r_ij == 0 (duplicate atoms)
+      }
+      Cs[il * CHP + lane] = cij;
+      cs[di] += cij;
+    }
+    stage_rows_img(Zs, ldbx, Zg + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
+    __syncthreads();
+    strip_gemm_rowmajor(acc, Cs, CHP, Zs, ldbx, (nc + 15) & ~15, ntiles);
+  }
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const float t = wave_allsum(cs[di]);
+    if (lane == 0) csum[4 * wave + di] = t;
+  }
+  __syncthreads();
+  // dZ_i = rowsum(c)_i Z_i - (c Z)_i
+  float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * Fin;
+  const float* Zi = Zg + (int64_t)c.i0 * Fin;
+  if (wave < ntiles) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = 16 * (wave + 4 * t) + r;
+      if (wave + 4 * t < ntiles && col < Fin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int il = 4 * q + i;
+          if (il < c.nr) dZg[(int64_t)il * Fin + col] = csum[il] * Zi[(int64_t)il * Fin + col] - acc[t][i];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+size_t lds_sim(int Fin) { return sizeof(float) * ((size_t)Fin * SH + (size_t)Fin * CH1P); }
+size_t lds_lap(int Fin) { return sizeof(float) * ((size_t)SH * CHP + (size_t)CH * ld_b(Fin)); }
+size_t lds_bwd1(int Fin, bool paper) {
+  const size_t ldf = ld_frag((Fin + 15) & ~15);
+  size_t f = (size_t)SH * CHP + (size_t)CH * ldf + 32;
+  if (paper) f += 2 * (size_t)SH * CHP + 2 * (size_t)SH * ldf + (size_t)CH * ldf;
+  return sizeof(float) * f;
+}
+size_t lds_bwd2(int Fin) { return sizeof(float) * ((size_t)SH * CHP + (size_t)CH * ld_b(Fin) + SH); }
+
+template <class K>
+int launch_slab(K kernel, const SgcArgs& a, size_t lds, int prof_id, const char* what, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+  }
+  prof_begin(prof_id, stream);
+  hipLaunchKernelGGL(kernel, dim3(a.n_slabs), dim3(256), lds, s, a);
+  prof_end(stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s launch: %s", what, hipGetErrorString(e));
+  return AGCN_OK;
+}
+}  // namespace
+
+bool slab_path_fits(int32_t Fin) {
+  const size_t lim = 150 * 1024;
+  return lds_sim(Fin) <= lim && lds_lap(Fin) <= lim && lds_bwd1(Fin, true) <= lim && lds_bwd2(Fin) <= lim;
+}
+
+int launch_slab_forward(const SgcArgs& a, void* stream) {
+  int rc = launch_slab(slab_sim_kernel, a, lds_sim(a.Fin), PK_SLAB_SIM, "slab_sim", stream);
+  if (rc != AGCN_OK) return rc;
+  return launch_slab(slab_lap_kernel, a, lds_lap(a.Fin), PK_SLAB_LAP, "slab_lap", stream);
+}
+
+int launch_slab_backward(const SgcArgs& a, void* stream) {
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  int rc = launch_slab(slab_bwd1_kernel, a, lds_bwd1(a.Fin, paper), PK_SLAB_BWD1, "slab_bwd1", stream);
+  if (rc != AGCN_OK || !paper) return rc;
+  return launch_slab(slab_bwd2_kernel, a, lds_bwd2(a.Fin), PK_SLAB_BWD2, "slab_bwd2", stream);
+}
+
+}  // namespace agcn

@@ -42,7 +42,8 @@ def _desc(cfg, ldx, ldy):
 
 def _gbatch(batch, X, L_prev):
     p = batch.plan
-    return _ffi.GraphBatch(p.host_ptr, p.dev_ptr, X.data_ptr(), _ptr(batch.l0_dense), batch.l0_ld, 0,
+    return _ffi.GraphBatch(p.host_ptr, p.dev_ptr, X.data_ptr(), _ptr(batch.l0_dense), batch.l0_ld,
+                           1 if batch.l0_symmetric else 0,
                            _ptr(batch.l0_rowptr), _ptr(batch.l0_col), _ptr(batch.l0_val), _ptr(L_prev))
 
 

@@ -55,6 +55,11 @@ def kernel_bytes(N1, N2, nnz, B, Fin, Fout, K, paper):
         "rows_gemm_kernel<PROJECT_BWD>": 12 * N1 * Fin + M,
         "param_grad_partial_kernel": 4 * K * N1 * Fin + 4 * N1 * Fout + (8 * N1 * Fin if paper else 0),
         "param_grad_reduce_kernel": W + 4 * Fout + (M if paper else 0),
+        # slab-parallel path (SGC_LL, K = 2)
+        "slab_sim_kernel": 4 * N1 * Fin + 4 * N2 * (2 if paper else 1) + 4 * N1,
+        "slab_lap_kernel": (4 * N2 if paper else 0) + 4 * N2 + Lb + 8 * N1 * Fin + 4 * N1,
+        "slab_bwd1_kernel": 4 * N2 + Lb + 12 * N1 * Fin + ((4 * N1 * Fin + 8 * N2 + 4 * N1) if paper else 0),
+        "slab_bwd2_kernel": 12 * N2 + 8 * N1 * Fin + 8 * N1,
     }
     return kb
 
@@ -198,11 +203,11 @@ def main():
     N1, N2, fwd_b, bwd_b = algorithmic_bytes(n, nnz, Fin, Fout, K)
     kb = kernel_bytes(N1, N2, nnz, len(n), Fin, Fout, K, args.mode == "paper")
     dom = max(avg_ms, key=avg_ms.get)
-    achieved = kb[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    achieved = kb.get(dom, 0) / (avg_ms[dom] * 1e-3) / 1e9
     step_ms = 1e3 * elapsed / args.steps
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": int(kb[dom]),
+                "algorithmic_bytes_per_launch": int(kb.get(dom, 0)),
                 "avg_launch_ms": {k: round(v, 5) for k, v in avg_ms.items()},
                 "kernel_bytes": {k: int(v) for k, v in kb.items() if k in avg_ms},
                 "layer_fwd_bytes": int(fwd_b), "layer_bwd_bytes": int(bwd_b),

@@ -81,10 +81,19 @@ typedef struct AgcnPlanInfo {
   int64_t off_tile_off; /* int64 [B+1] */
   int64_t off_order;    /* int32 [B]   graph ids, largest first */
   int64_t off_wtile_off; /* int64 [B+1] scratch-tile offsets (global-memory tile mode) */
+  /* slabs: strips of AGCN_SLAB_ROWS consecutive rows of one graph's n x n tile; the unit of work
+   * of the slab-parallel kernels (largest graphs first) */
+  int32_t n_slabs;
+  int32_t reserved1;
+  int64_t off_slab_graph; /* int32 [n_slabs] graph id      */
+  int64_t off_slab_row;   /* int32 [n_slabs] first row inside the graph */
 } AgcnPlanInfo;
 
-/* Bytes needed for a plan of B graphs. */
+#define AGCN_SLAB_ROWS 16
+
+/* Bytes needed for a plan: worst case for B graphs / exact for the given node counts. */
 size_t agcn_plan_bytes(int32_t B);
+size_t agcn_plan_bytes_for(const int32_t* n, int32_t B);
 
 /* Build a plan from host arrays.  n[B] = node counts (data_slice[:,0] /
  * lap_slice[:,0], graph_topology.py:90,98).  row_stride = 0 -> packed rows,
@@ -122,7 +131,8 @@ typedef struct AgcnGraphBatch {
    *        col = column index INSIDE the graph, val f32. */
   const float* L0_dense;
   int32_t L0_ld;
-  int32_t reserved0;
+  int32_t L0_symmetric;      /* 1 = caller guarantees L_orig == L_orig^T (graph_structure.py:106 asserts it);
+                              * enables the slab-parallel kernels, which read L_orig^T rows as L_orig rows */
   const int32_t* L0_rowptr;
   const int32_t* L0_col;
   const float* L0_val;
@@ -207,6 +217,11 @@ const char* agcn_last_error(void);
  * global memory instead of LDS (default 160 KiB; settable for tests). */
 int32_t agcn_get_lds_limit(void);
 void agcn_set_lds_limit(int32_t bytes);
+/* 1 (default): SGC_LL with K = 2 on packed rows with a symmetric CSR L_orig runs on the
+ * slab-parallel kernels (16-row strips of every graph's tile, balanced over the CUs);
+ * 0: always one workgroup per graph.  Same results either way (tested). */
+int32_t agcn_get_slab_mode(void);
+void agcn_set_slab_mode(int32_t mode);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,7 @@ def run_packed(agcn_amd, device, ns, X, csr, p, G, Fin, Fout, K, mode, variant, 
     """Runs the HIP layer on a packed batch (CSR Laplacian); returns numpy results."""
     gb = agcn_amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, device)
     plan = gb.plan
+    assert gb.l0_symmetric, "synthetic Laplacians are symmetric: the slab path must be eligible"
     layer = make_layer(agcn_amd, variant, Fout, Fin, len(ns), K, mode, p, device, activation)
     Xt = gb.X.clone().requires_grad_(True)
     x = {"node_features": Xt, "graph_batch": gb}

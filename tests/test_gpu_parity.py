@@ -118,14 +118,19 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("lds_limit", [160 * 1024, 0], ids=["lds", "globaltile"])
+@pytest.mark.parametrize("path", ["slab", "lds", "globaltile"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 @pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc", "reslap"])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_packed_vs_oracle(amd, case, variant, mode, lds_limit):
-    """Packed batch + CSR Laplacian; ground truth = the oracle evaluated in float64."""
+def test_packed_vs_oracle(amd, case, variant, mode, path):
+    """Packed batch + CSR Laplacian; ground truth = the oracle evaluated in float64.
+    path: slab = slab-parallel kernels where eligible (SGC_LL, K = 2), lds = one workgroup per graph
+    with the tile in LDS, globaltile = one workgroup per graph with the tile in global scratch."""
     ns, Fin, Fout, K = CASES[case]
-    amd._ffi.lib().agcn_set_lds_limit(lds_limit)
+    if path == "slab" and not (variant == orc.SGC_LL and K == 2):
+        pytest.skip("slab path covers SGC_LL with K = 2 only")
+    amd._ffi.lib().agcn_set_lds_limit(0 if path == "globaltile" else 160 * 1024)
+    amd._ffi.lib().agcn_set_slab_mode(1 if path == "slab" else 0)
     try:
         rs, X, L0, csr, p, G = synth_case(1000 + case, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
         Lp = dLsum = None
@@ -137,6 +142,20 @@ def test_packed_vs_oracle(amd, case, variant, mode, lds_limit):
         compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
     finally:
         amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
+        amd._ffi.lib().agcn_set_slab_mode(1)
+
+
+def test_slab_path_large_and_ragged(amd):
+    """Slab kernels on graphs that span several slabs and several column chunks (n up to 300),
+    against the oracle in float64, and bit-symmetric res_W across slabs."""
+    ns, Fin, Fout, K = [300, 130, 65, 64, 17, 16, 15, 4], 24, 16, 2
+    for mode in (orc.REFERENCE, orc.PAPER):
+        rs, X, L0, csr, p, G = synth_case(321, ns, Fin, Fout, K, orc.SGC_LL)
+        caches, tot = oracle_run(X, L0, p, K, mode, orc.SGC_LL, G)
+        out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, orc.SGC_LL)
+        compare_with_oracle(out, caches, tot, orc.SGC_LL, mode, K, has_prev=False)
+        for w in out["res_W"]:
+            assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
 
 
 def test_reslap_without_prev(amd):
