@@ -59,7 +59,7 @@ SYMBOLS = [
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
-    "agcn_get_slab_mode", "agcn_set_slab_mode",
+    "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
     "agcn_profile_enable", "agcn_profile_kernels", "agcn_profile_kernel_name", "agcn_profile_collect",
 ]
 
@@ -103,6 +103,10 @@ def _declare(lib):
     lib.agcn_get_slab_mode.argtypes = []
     lib.agcn_set_slab_mode.restype = None
     lib.agcn_set_slab_mode.argtypes = [I32]
+    lib.agcn_get_fused_mode.restype = I32
+    lib.agcn_get_fused_mode.argtypes = []
+    lib.agcn_set_fused_mode.restype = None
+    lib.agcn_set_fused_mode.argtypes = [I32]
     lib.agcn_profile_enable.restype = None
     lib.agcn_profile_enable.argtypes = [C.c_int]
     lib.agcn_profile_kernels.restype = I32

@@ -3,6 +3,8 @@
 // No allocation, no synchronisation, everything on the caller's stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "sgc_kernels.h"
 
 namespace agcn {
@@ -53,6 +55,17 @@ bool use_slabs(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanIn
   if (agcn_get_slab_mode() == 0) return false;
   return d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
          g->L0_dense == nullptr && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
+}
+
+// Fused per-graph kernels (fused_kernels.hip): SGC_LL, K = 2, packed rows, CSR L_orig, and the
+// largest graph's working set fits LDS.  mode knob: agcn_set_fused_mode (1 = auto).
+bool use_fused(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
+  if (agcn_get_fused_mode() == 0) return false;
+  if (!(d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
+        g->L0_dense == nullptr)) return false;
+  const size_t need = std::max(fused_lds_bytes(pi.max_n, d->Fin, d->Fout, d->K),
+                               fused_bwd_lds_bytes(pi.max_n, d->Fin, d->Fout, d->K));
+  return need <= (size_t)agcn_get_lds_limit() && need <= 160 * 1024;
 }
 
 struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, total; };
@@ -212,6 +225,13 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   if (c.off > workspace_bytes || (n_glb > 0 && !workspace))
     return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, c.off);
 
+  a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+  a.sv_r = reinterpret_cast<float*>(rb + rl.r);
+  if (use_fused(desc, batch, host.info)) {
+    // small graphs: the whole layer forward in one launch, everything staged in LDS once
+    return launch_fused_forward(a, host.info.B, fused_lds_bytes(host.info.max_n, desc->Fin, desc->Fout, desc->K),
+                                hip_stream);
+  }
   // 1. Z = X . M_L over the packed rows (graphconv.py:164)
   RowsGemmArgs g;
   fill_rows(g, desc, host, dev);
@@ -300,7 +320,14 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
 
   const int B = host.info.B;
   const bool slabs = use_slabs(desc, batch, host.info);
-  if (stages & 1) {
+  const bool fused = use_fused(desc, batch, host.info);
+  if ((stages & 1) && fused) {
+    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.sv_r = reinterpret_cast<float*>(rb + rl.r);
+    a.ws_Gp = w.Gp;
+    rc = launch_fused_backward(a, B, fused_bwd_lds_bytes(host.info.max_n, desc->Fin, desc->Fout, desc->K), hip_stream);
+    if (rc != AGCN_OK) return rc;
+  } else if (stages & 1) {
     // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace
     RowsGemmArgs g;
     fill_rows(g, desc, host, dev);
@@ -346,7 +373,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
-  pa.B = slabs ? host.info.n_slabs : B; pa.part_stride = w.part_stride;
+  pa.B = (slabs && !fused) ? host.info.n_slabs : B; pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;

@@ -112,6 +112,38 @@ __device__ __forceinline__ void bulk_for2d(int nrows, int ncols, LD ld, ST st) {
   }
 }
 
+// Copy a row-major global matrix into an LDS image with (almost) no index arithmetic: wave w takes
+// rows w, w + nwaves, ..; lanes run along the columns in passes of 64.  Up to 4 rows x CP column
+// passes of loads are in flight per thread.  Image rows nrows..prow and columns ncols..pcol are
+// zero-filled.  map_row(r) gives the SOURCE row of image row r (identity for plain copies), or a
+// negative value for an image row that must be zero.
+template <int CP, class MAP>
+__device__ __forceinline__ void stage_matrix(float* img, int ld, const float* src, int64_t src_ld, int nrows,
+                                             int ncols, int prow, int pcol, MAP map_row) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r0 = wave; r0 < prow; r0 += 4 * nw) {
+    float t[4][CP];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = min(r0 + u * nw, nrows - 1);
+      const float* rp = src + (int64_t)max(map_row(r), 0) * src_ld;
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) t[u][cp] = rp[min(lane + 64 * cp, ncols - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * nw;
+      if (r < prow) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < pcol) img[r * ld + c] = (r < nrows && c < ncols && map_row(r) >= 0) ? t[u][cp] : 0.f;
+        }
+      }
+    }
+  }
+}
+
 // tile[i][col] += val for the CSR rows of one graph (one thread per row; entries of a row are
 // fetched four at a time so their latencies overlap).
 __device__ __forceinline__ void csr_scatter_add(float* tile, int ldt, int n, const int32_t* rp,

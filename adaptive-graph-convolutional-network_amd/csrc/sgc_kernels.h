@@ -44,6 +44,7 @@ struct SgcArgs {
   float* ws_g;     // [K-1][rows][Fin]  adjoints of X_1..X_{K-1}
   float* ws_dZ;    // [rows][Fin]       (paper mode)
   float* ws_pg;    // [B or n_slabs][2] per-graph / per-slab dalpha, dbeta
+  float* ws_Gp;    // [rows][Fout]      masked upstream gradient (fused backward writes it)
   // slab-parallel path (slab_kernels.hip)
   const int32_t* slab_graph;
   const int32_t* slab_row;
@@ -87,7 +88,7 @@ struct ParamGradArgs {
 
 // profiling ids (profile.hip)
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
-       PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_COUNT };
+       PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD, PK_COUNT };
 bool prof_on();
 void prof_begin(int id, void* stream);
 void prof_end(void* stream);
@@ -107,6 +108,11 @@ int launch_sgc_forward(const SgcArgs& a, int32_t first, int32_t count, bool lds_
 int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds_tile, size_t lds_bytes,
                         void* stream);
 int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream);
+// fused per-graph SGC_LL (K = 2) for graphs whose whole working set fits LDS
+size_t fused_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
+int launch_fused_forward(const SgcArgs& a, int32_t count, size_t lds_bytes, void* stream);
+size_t fused_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
+int launch_fused_backward(const SgcArgs& a, int32_t count, size_t lds_bytes, void* stream);
 // slab-parallel SGC_LL (K = 2, packed rows, symmetric CSR L_orig)
 bool slab_path_fits(int32_t Fin);
 int launch_slab_forward(const SgcArgs& a, void* stream);

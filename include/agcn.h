@@ -222,6 +222,10 @@ void agcn_set_lds_limit(int32_t bytes);
  * 0: always one workgroup per graph.  Same results either way (tested). */
 int32_t agcn_get_slab_mode(void);
 void agcn_set_slab_mode(int32_t mode);
+/* 1 (default): batches of small graphs (the largest graph's X, M_L, W, n x n tile and Z^T fit
+ * LDS) run SGC_LL K = 2 on the fused one-launch-per-direction kernels; 0: never. */
+int32_t agcn_get_fused_mode(void);
+void agcn_set_fused_mode(int32_t mode);
 
 #ifdef __cplusplus
 }

@@ -118,7 +118,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["slab", "lds", "globaltile"])
+@pytest.mark.parametrize("path", ["fused", "slab", "lds", "globaltile"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 @pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc", "reslap"])
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -127,10 +127,11 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     path: slab = slab-parallel kernels where eligible (SGC_LL, K = 2), lds = one workgroup per graph
     with the tile in LDS, globaltile = one workgroup per graph with the tile in global scratch."""
     ns, Fin, Fout, K = CASES[case]
-    if path == "slab" and not (variant == orc.SGC_LL and K == 2):
-        pytest.skip("slab path covers SGC_LL with K = 2 only")
+    if path in ("slab", "fused") and not (variant == orc.SGC_LL and K == 2):
+        pytest.skip("the slab and fused paths cover SGC_LL with K = 2 only")
     amd._ffi.lib().agcn_set_lds_limit(0 if path == "globaltile" else 160 * 1024)
-    amd._ffi.lib().agcn_set_slab_mode(1 if path == "slab" else 0)
+    amd._ffi.lib().agcn_set_slab_mode(1 if path in ("slab", "fused") else 0)
+    amd._ffi.lib().agcn_set_fused_mode(1 if path == "fused" else 0)
     try:
         rs, X, L0, csr, p, G = synth_case(1000 + case, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
         Lp = dLsum = None
@@ -143,6 +144,7 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     finally:
         amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
         amd._ffi.lib().agcn_set_slab_mode(1)
+        amd._ffi.lib().agcn_set_fused_mode(1)
 
 
 def test_slab_path_large_and_ragged(amd):
