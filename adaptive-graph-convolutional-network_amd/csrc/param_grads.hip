@@ -28,11 +28,14 @@ __global__ __launch_bounds__(256) void param_grad_partial_kernel(ParamGradArgs a
   else if (p == 1) { Fa = 1; Fb = Fout; out_base = (int64_t)K * Fin * Fout; }
   else { Fa = Fin; Fb = Fin; out_base = (int64_t)K * Fin * Fout + Fout; }
   const int tf = (Fa + 15) >> 4, tc = (Fb + 31) >> 5;
-  const int items = tf * tc * a.n_chunks;
-  const int item = blockIdx.x * 4 + wave;
-  if (item >= items) return;
-  const int chunk = item / (tf * tc);
-  const int rem = item - chunk * (tf * tc);
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 share one, the
+  // grid's x extent is a multiple of 8), and every output tile of one ROW CHUNK is computed on the same
+  // XCD, so the chunk's rows of X / Gp / dZ are fetched into ONE L2 instead of up to eight.
+  const int W = a.wgs_per_chunk;                       // workgroups (of 4 wave items) per chunk
+  const int g = blockIdx.x;
+  const int chunk = (g / (8 * W)) * 8 + (g & 7);
+  const int rem = ((g >> 3) % W) * 4 + wave;           // tile index inside the chunk
+  if (chunk >= a.n_chunks || rem >= tf * tc) return;
   const int itc = rem / tf, itf = rem - itc * tf;
   const int f0 = itf * 16, c0 = itc * 32;
   const int r_begin = chunk * a.chunk_rows;
@@ -118,10 +121,12 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
   const int tfM = (a.Fin + 15) / 16, tcM = (a.Fin + 31) / 32;
   int items = tfW * tcW;
   if (a.paper && tfM * tcM > items) items = tfM * tcM;
-  items *= a.n_chunks;
+  ParamGradArgs aa = a;
+  aa.wgs_per_chunk = (items + 3) / 4;
+  const int gx = 8 * aa.wgs_per_chunk * ((a.n_chunks + 7) / 8);
   const int nprob = a.paper ? 3 : 2;
   prof_begin(PK_PARAM_PARTIAL, stream);
-  hipLaunchKernelGGL(param_grad_partial_kernel, dim3((items + 3) / 4, nprob), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(param_grad_partial_kernel, dim3(gx, nprob), dim3(256), 0, s, aa);
   prof_end(stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_partial launch: %s", hipGetErrorString(e));

@@ -76,6 +76,7 @@ struct RowsGemmArgs {
 struct ParamGradArgs {
   int32_t rows, Fin, Fout, K, ldx, paper;
   int32_t n_chunks, chunk_rows, B;   // B = number of [dalpha, dbeta] partial pairs in pg
+  int32_t wgs_per_chunk; // set by the launcher
   int64_t part_stride;  // floats per chunk in `part`
   const float* X;
   const float* sv_X;

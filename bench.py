@@ -55,6 +55,13 @@ def kernel_bytes(N1, N2, nnz, B, Fin, Fout, K, paper):
         "rows_gemm_kernel<PROJECT_BWD>": 12 * N1 * Fin + M,
         "param_grad_partial_kernel": 4 * K * N1 * Fin + 4 * N1 * Fout + (8 * N1 * Fin if paper else 0),
         "param_grad_reduce_kernel": W + 4 * Fout + (M if paper else 0),
+        # fused per-graph path (SGC_LL, K = 2): the layer-level algorithmic traffic of SURVEY 8(d) plus the
+        # forward->backward reserve (Z, X_1, s, and r tiles in paper mode) and the Gp / dZ hand-off to the
+        # parameter-gradient kernels
+        "fused_forward_kernel": 4 * N1 * Fin + Lb + 4 * N1 * Fout + 8 * N2 + M + W + 4 * Fout
+                                + 8 * N1 * Fin + 4 * N1 + (4 * N2 if paper else 0),
+        "fused_backward_kernel": 8 * N1 * Fout + W + 4 * N2 + Lb + 4 * N1 * Fin + 4 * N1 * Fout
+                                 + ((12 * N1 * Fin + 8 * N2 + 4 * N1 + M) if paper else 0),
         # slab-parallel path (SGC_LL, K = 2)
         "slab_sim_kernel": 4 * N1 * Fin + 4 * N2 * (2 if paper else 1) + 4 * N1,
         "slab_lap_kernel": (4 * N2 if paper else 0) + 4 * N2 + Lb + 8 * N1 * Fin + 4 * N1,
@@ -118,6 +125,8 @@ def main():
     ap.add_argument("--mode", default="paper", choices=["paper", "reference"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-other-mode", action="store_true",
+                    help="profiling runs: do not also time the other laplacian_mode")
     args = ap.parse_args()
 
     import agcn_amd
@@ -205,8 +214,20 @@ def main():
     dom = max(avg_ms, key=avg_ms.get)
     achieved = kb.get(dom, 0) / (avg_ms[dom] * 1e-3) / 1e9
     step_ms = 1e3 * elapsed / args.steps
+    # HBM traffic of the dominant kernel: TCC FETCH_SIZE / WRITE_SIZE collected with rocprofv3 --pmc
+    # (tools/traffic.sh, corrected as MI355X_MICROARCH.md prescribes) and committed under profiles/
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.mode)
+    if os.path.exists(tpath) and world == 1 and args.batch == 256:
+        try:
+            tj = json.load(open(tpath))
+            for kname, v in tj.items():
+                if kname.split("::")[-1].split("<")[0] == dom.split("<")[0] and "<" not in dom:
+                    traffic, traffic_src = v["hbm_bytes"], "profiles/traffic_%s.json" % args.mode
+        except Exception:
+            pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(kb.get(dom, 0)),
                 "avg_launch_ms": {k: round(v, 5) for k, v in avg_ms.items()},
                 "kernel_bytes": {k: int(v) for k, v in kb.items() if k in avg_ms},
@@ -215,8 +236,8 @@ def main():
 
     # ---- the other laplacian mode, same protocol (reported beside the headline) ------------------
     other = "reference" if args.mode == "paper" else "paper"
-    st2 = make(other)
-    if use_graph:
+    st2 = make(other) if not args.skip_other_mode else None
+    if use_graph and st2 is not None:
         st2.capture()
 
     def step2():
@@ -227,7 +248,7 @@ def main():
         if world > 1:
             agcn_amd.dist.allreduce_bucket(st2.bucket)
 
-    el2 = timed(step2, args.steps, args.warmup)
+    el2 = timed(step2, args.steps, args.warmup) if st2 is not None else None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -248,8 +269,9 @@ def main():
                        "launch": "hip_graph" if use_graph else "eager", "parallelism": "dp%d" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "other_mode": {"laplacian_mode": other, "value": round(B_global * args.steps / el2, 1),
-                           "ms_per_step": round(1e3 * el2 / args.steps, 5)},
+            "other_mode": None if el2 is None else {
+                "laplacian_mode": other, "value": round(B_global * args.steps / el2, 1),
+                "ms_per_step": round(1e3 * el2 / args.steps, 5)},
         }
         print(json.dumps(line))
     if world > 1:
