@@ -48,6 +48,11 @@ class Grads(C.Structure):
                 ("dalpha", C.c_void_p), ("dbeta", C.c_void_p), ("dL_prev", C.c_void_p)]
 
 
+class DenseDesc(C.Structure):
+    _fields_ = [("Fin", C.c_int32), ("Fout", C.c_int32), ("activation", C.c_int32), ("keep_pad_rows", C.c_int32),
+                ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldadd", C.c_int32), ("reserved", C.c_int32)]
+
+
 MODE = {"reference": 0, "paper": 1}
 VARIANT = {"SGC_LL": 0, "SGC_LL_Reslap": 1}
 ACT = {None: 0, "linear": 0, "relu": 1, "tanh": 2}
@@ -58,6 +63,8 @@ SYMBOLS = [
     "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
+    "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
+    "agcn_graph_pool_forward", "agcn_graph_pool_backward",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
     "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
     "agcn_profile_enable", "agcn_profile_kernels", "agcn_profile_kernel_name", "agcn_profile_collect",
@@ -91,6 +98,16 @@ def _declare(lib):
     lib.agcn_graph_gather_forward.argtypes = [P, P, P, I32, I32, I32, P, P]
     lib.agcn_graph_gather_backward.restype = C.c_int
     lib.agcn_graph_gather_backward.argtypes = [P, P, P, P, I32, I32, I32, P, P]
+    lib.agcn_rows_dense_forward.restype = C.c_int
+    lib.agcn_rows_dense_forward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P]
+    lib.agcn_rows_dense_backward_workspace_bytes.restype = SZ
+    lib.agcn_rows_dense_backward_workspace_bytes.argtypes = [C.POINTER(DenseDesc), P]
+    lib.agcn_rows_dense_backward.restype = C.c_int
+    lib.agcn_rows_dense_backward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P, P, P, SZ, P]
+    lib.agcn_graph_pool_forward.restype = C.c_int
+    lib.agcn_graph_pool_forward.argtypes = [P, P, C.POINTER(GraphBatch), P, I32, I32, P, P, P]
+    lib.agcn_graph_pool_backward.restype = C.c_int
+    lib.agcn_graph_pool_backward.argtypes = [P, P, C.POINTER(GraphBatch), P, P, I32, I32, P, P]
     lib.agcn_version.restype = I32
     lib.agcn_version.argtypes = []
     lib.agcn_last_error.restype = C.c_char_p

@@ -188,7 +188,8 @@ class GraphBatch(object):
         plan = Plan(n, max_atom, device)
         X = X3.to(device=device, dtype=torch.float32).reshape(B * max_atom, F)
         L = L3.to(device=device, dtype=torch.float32).contiguous()
-        return cls(plan, X, l0_dense=L, l0_ld=max_atom)
+        sym = bool(torch.equal(L, L.transpose(1, 2)))
+        return cls(plan, X, l0_dense=L, l0_ld=max_atom, l0_symmetric=sym)
 
     def rows(self, data):
         return RowViews(data, self.plan)

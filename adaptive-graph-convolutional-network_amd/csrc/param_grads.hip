@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(ParamGradArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave < 2) {
       float* dst = wave == 0 ? a.dalpha : a.dbeta;
-      if (dst != nullptr) {
+      if (dst != nullptr && a.pg != nullptr) {
         float s = 0.f;
         for (int b = lane; b < a.B; b += 64) s += a.pg[2 * b + wave];
         s = wave_sum(s);

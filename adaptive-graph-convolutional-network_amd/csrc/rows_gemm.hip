@@ -7,6 +7,8 @@
 //                        (A column j = f*K + k is X_k[:, f]: the interleaved concat is never built)
 //   RG_FILTER_BWD   [g_0|g_1|..] = (dY . act'(Y)) . W^T            adjoint of the above; also emits Gp
 //   RG_PROJECT_BWD  dX += dZ . M_L^T                               adjoint of RG_PROJECT (paper mode)
+//   RG_DENSE        Y  = act(A . W [+ b] [+ Add])                  DenseMol (dense_layer.py:33-50, bias also on pad
+//                                                                  rows) and BlockEnd (blockend.py:67-86, x + x_res . W)
 //
 // Workgroup = 1024 threads on 64 rows x up to 192 columns: all 16 waves stage the operands (the
 // whole K extent, or the largest chunk that fits LDS, with 8 independent loads in flight per
@@ -61,11 +63,12 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
       const int g = (int)dRS.div((uint32_t)row);
       ok = row - g * a.row_stride < a.n[g];
     }
+    if (a.keep_pad && row < a.rows) ok = true;
     rowok[tid] = ok ? 1.f : 0.f;
   }
   __syncthreads();
 
-  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 0);
+  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 0);
   f32x4 acc[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -83,7 +86,8 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
     // source orientation: PROJECT/FILTER  B[k][c] = Bm[k * ldbm + col_base + c]   (lanes along c)
     //                     *_BWD           B[k][c] = Bm[(col_base + c) * ldbm + k] (lanes along k)
     const bool transposed = (MODE == RG_FILTER_BWD || MODE == RG_PROJECT_BWD);
-    const int ldbm = (MODE == RG_PROJECT) ? Fin : (MODE == RG_FILTER) ? Fout : (MODE == RG_FILTER_BWD) ? Fout : Fin;
+    const int ldbm = (MODE == RG_PROJECT) ? Fin : (MODE == RG_FILTER) ? Fout : (MODE == RG_FILTER_BWD) ? Fout
+                     : (MODE == RG_DENSE) ? N : Fin;
     const int inner = transposed ? KC : bn;            // contiguous index extent
     const FastDiv dInner((uint32_t)inner);
     const int btotal = KC * bn;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
         }
       }
     }
-    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 1);
+    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 1);
 #pragma unroll
     for (int u = 0; u < 4; ++u) b_store(tid + nthr * u, tb[u]);
     for (int base = 4 * nthr; base < btotal; base += 4 * nthr) {
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) b_store(base + tid + nthr * u, tb[u]);
     }
-    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 2);
+    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 2);
     __syncthreads();
-    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 3);
+    AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 3);
     if (my_nt > 0) {
       const float* Aw = As + (rg * 16 + r) * ldA + q;
       const float* Bw = Bs + q * ldB + 16 * cg + r;
@@ -185,14 +189,14 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
     if (k0 + KC < Kd) __syncthreads();
   }
 
-  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 4);
+  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 4);
   // ---- epilogue -----------------------------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     if (j >= my_nt) continue;
     const int c = col_base + 16 * (cg + ncg * j) + r;
     if (c >= N) continue;
-    const float bias_c = (MODE == RG_FILTER) ? a.bias[c] : 0.f;
+    const float bias_c = (MODE == RG_FILTER || (MODE == RG_DENSE && a.bias)) ? a.bias[c] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row_base + rg * 16 + q * 4 + i;
@@ -205,6 +209,12 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
         if (relu) v = fmaxf(v, 0.f);
         v = v * rowok[rg * 16 + q * 4 + i];   // tf.pad rows (graphconv.py:249-250)
         a.Out0[(int64_t)row * a.ldo0 + c] = v;
+      } else if (MODE == RG_DENSE) {
+        if (a.bias) v = v + bias_c;
+        if (a.Add) v = v + a.Add[(int64_t)row * a.ldadd + c];
+        if (relu) v = fmaxf(v, 0.f);
+        v = v * rowok[rg * 16 + q * 4 + i];
+        a.Out0[(int64_t)row * a.ldo0 + c] = v;
       } else if (MODE == RG_FILTER_BWD) {
         const int f = (int)dK.div((uint32_t)c), kx = c - f * K;   // column f*K + k: adjoint of X_k[:, f]
         if (kx == 0) a.Out0[(int64_t)row * a.ldo0 + f] = v;
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
       }
     }
   }
-  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : 5, 5);
+  AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 5);
 }
 
 namespace {
@@ -236,7 +246,7 @@ static int launch_ntw(RowsGemmArgs a, int gy, int nt, int threads, hipStream_t s
     kc = ((kc / 2) + 15) & ~15;
   a.kc = kc;
   const size_t lds = sizeof(float) * ((size_t)BM * ld_frag(kc) + (size_t)kc * ld_b(16 * nt) + BM);
-  static const int kProfId[4] = {PK_PROJECT, PK_FILTER, PK_FILTER_BWD, PK_PROJECT_BWD};
+  static const int kProfId[5] = {PK_PROJECT, PK_FILTER, PK_FILTER_BWD, PK_PROJECT_BWD, PK_FILTER};
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_gemm_kernel<MODE, NTW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -279,6 +289,7 @@ int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream) {
     case RG_FILTER: return launch_mode<RG_FILTER>(a, s);
     case RG_FILTER_BWD: return launch_mode<RG_FILTER_BWD>(a, s);
     case RG_PROJECT_BWD: return launch_mode<RG_PROJECT_BWD>(a, s);
+    case RG_DENSE: return launch_mode<RG_DENSE>(a, s);
   }
   return fail(AGCN_EINVAL, "rows_gemm: bad mode");
 }

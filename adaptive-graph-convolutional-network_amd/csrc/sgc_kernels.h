@@ -54,7 +54,7 @@ struct SgcArgs {
   float* ws_dd;    // [rows]        dd_j                   (paper mode, bwd1 -> bwd2)
 };
 
-enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3 };
+enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3, RG_DENSE = 4 };
 
 struct RowsGemmArgs {
   int32_t rows, Kd, N;
@@ -69,6 +69,8 @@ struct RowsGemmArgs {
   float* Out0; int32_t ldo0;
   float* Out1; int64_t o1_plane;
   float* Gp;                // RG_FILTER_BWD: [rows][Fout] masked upstream gradient
+  const float* Add; int32_t ldadd;   // RG_DENSE: optional addend [rows][ldadd]
+  int32_t keep_pad;         // RG_DENSE / RG_FILTER_BWD: 1 = pad rows are ordinary rows (DenseMol, dense_layer.py:42-50)
   int32_t kc;               // K chunk staged in LDS (set by the launcher)
   int32_t nt;               // column tiles per workgroup (set by the launcher)
 };

@@ -160,3 +160,90 @@ class GraphGatherFunction(torch.autograd.Function):
                                                   ctx.F, ctx.F, _ffi.ACT[ctx.activation], dX.data_ptr(),
                                                   _stream(out.device)))
         return dX, None, None
+
+
+class RowsDenseFunction(torch.autograd.Function):
+    """Y = act(A . W [+ bias] [+ Add]) over the row space: DenseMol (dense_layer.py:33-50) and
+    BlockEnd (blockend.py:67-86)."""
+
+    @staticmethod
+    def forward(ctx, A, W, bias, Add, batch, activation, keep_pad_rows):
+        lib = _ffi.lib()
+        _require_gpu(A, "node features")
+        A, W = _f32c(A, "node features"), _f32c(W, "weight")
+        plan = batch.plan
+        Fin, Fout = W.shape
+        if A.dim() != 2 or A.shape[0] != plan.rows or A.shape[1] < Fin:
+            raise ValueError("node features must be [rows=%d, >=%d]" % (plan.rows, Fin))
+        if bias is not None:
+            bias = _f32c(bias, "bias")
+        if Add is not None:
+            Add = _f32c(Add, "Add")
+            if tuple(Add.shape) != (plan.rows, Fout):
+                raise ValueError("Add must be [rows, Fout]")
+        Y = torch.empty((plan.rows, Fout), dtype=torch.float32, device=A.device)
+        desc = _ffi.DenseDesc(Fin, Fout, _ffi.ACT[activation], 1 if keep_pad_rows else 0, A.shape[1], Fout, Fout, 0)
+        _ffi.check(lib.agcn_rows_dense_forward(C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(), W.data_ptr(),
+                                               _ptr(bias), _ptr(Add), Y.data_ptr(), _stream(A.device)))
+        ctx.batch, ctx.desc, ctx.has_bias, ctx.has_add = batch, desc, bias is not None, Add is not None
+        ctx.save_for_backward(A, W, Y)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = _ffi.lib()
+        A, W, Y = ctx.saved_tensors
+        plan, desc = ctx.batch.plan, ctx.desc
+        dY = _f32c(dY, "dY")
+        dA = torch.empty_like(A)
+        if A.shape[1] > desc.Fin:
+            dA.zero_()
+        dW = torch.empty_like(W)
+        db = torch.empty(desc.Fout, dtype=torch.float32, device=A.device) if ctx.has_bias else None
+        dAdd = torch.empty((plan.rows, desc.Fout), dtype=torch.float32, device=A.device) if ctx.has_add else None
+        wbytes = lib.agcn_rows_dense_backward_workspace_bytes(C.byref(desc), plan.host_ptr)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=A.device)
+        _ffi.check(lib.agcn_rows_dense_backward(C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(), W.data_ptr(),
+                                                Y.data_ptr(), dY.data_ptr(), dA.data_ptr(), _ptr(dAdd), dW.data_ptr(),
+                                                _ptr(db), ws.data_ptr(), wbytes, _stream(A.device)))
+        return dA, dW, db, dAdd, None, None, None
+
+
+class GraphPoolFunction(torch.autograd.Function):
+    """GraphPoolMol (graphpool.py:55-110).  grad='reference': no gradient, like the reference's py_func;
+    grad='argmax': route the gradient to the arg-max rows (extension)."""
+
+    @staticmethod
+    def forward(ctx, X, batch, grad):
+        lib = _ffi.lib()
+        _require_gpu(X, "node features")
+        X = _f32c(X, "node features")
+        plan = batch.plan
+        if X.dim() != 2 or X.shape[0] != plan.rows:
+            raise ValueError("node features must be [rows=%d, F]" % plan.rows)
+        F = X.shape[1]
+        out = torch.empty((plan.rows, F), dtype=torch.float32, device=X.device)
+        argmax = torch.empty((plan.rows, F), dtype=torch.int32, device=X.device) if grad == "argmax" else None
+        gb = _gbatch(batch, X, None)
+        _ffi.check(lib.agcn_graph_pool_forward(plan.host_ptr, plan.dev_ptr, C.byref(gb), X.data_ptr(), F, F,
+                                               out.data_ptr(), _ptr(argmax), _stream(X.device)))
+        ctx.batch, ctx.grad, ctx.F = batch, grad, F
+        if argmax is not None:
+            ctx.save_for_backward(argmax)
+        else:
+            ctx.mark_non_differentiable(out)     # like tf.py_func: no gradient
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        if ctx.grad != "argmax":
+            return None, None, None
+        lib = _ffi.lib()
+        (argmax,) = ctx.saved_tensors
+        plan = ctx.batch.plan
+        dOut = _f32c(dOut, "dOut")
+        dX = torch.empty((plan.rows, ctx.F), dtype=torch.float32, device=dOut.device)
+        gb = _gbatch(ctx.batch, dOut, None)
+        _ffi.check(lib.agcn_graph_pool_backward(plan.host_ptr, plan.dev_ptr, C.byref(gb), argmax.data_ptr(),
+                                                dOut.data_ptr(), ctx.F, ctx.F, dX.data_ptr(), _stream(dOut.device)))
+        return dX, None, None

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .batch import GraphBatch, RowViews, TileViews
-from .functional import GraphGatherFunction, SgcLLFunction, _Cfg
+from .functional import GraphGatherFunction, GraphPoolFunction, RowsDenseFunction, SgcLLFunction, _Cfg
 
 _UID_PREFIXES = defaultdict(int)
 
@@ -238,3 +238,141 @@ class GraphGatherMol(Layer):
         if gb is None:
             raise ValueError("packed node_features need x['graph_batch']")
         return GraphGatherFunction.apply(X, gb, self.activation)
+
+
+def _rows_of(x, key="node_features"):
+    """(GraphBatch, 2-D tensor) for a node-feature input that is either a RowViews of this package,
+    a 2-D tensor + x['graph_batch'], or the reference's list of padded tensors (+ 'data_slice')."""
+    nf = x[key]
+    gb = x.get("graph_batch")
+    if isinstance(nf, RowViews):
+        return (gb if gb is not None else getattr(nf, "batch", None)), nf.data
+    if gb is not None and torch.is_tensor(nf) and nf.dim() == 2:
+        return gb, nf
+    X3 = nf if torch.is_tensor(nf) else torch.stack(list(nf))
+    ds = x["data_slice"]
+    ds = ds.detach().cpu().numpy() if torch.is_tensor(ds) else np.asarray(ds)
+    from .batch import Plan
+    if "original_laplacian" in x:
+        gb = GraphBatch.from_padded(X3, x["original_laplacian"], ds)
+        return gb, gb.X
+    plan = Plan(ds[:, 0], X3.shape[1], X3.device)
+    gb = GraphBatch(plan, X3.reshape(-1, X3.shape[2]))
+    return gb, gb.X
+
+
+def _row_views(data, gb):
+    v = RowViews(data, gb.plan)
+    v.batch = gb
+    return v
+
+
+class DenseMol(Layer):
+    """Per-node dense layer (dense_layer.py:13-50): xx . W + b for every row INCLUDING pad rows; the
+    activation given to the constructor is stored but never applied, exactly like the reference.
+    DenseMol(output_dim, input_dim, init='glorot_uniform', activation='relu', bias=True)."""
+
+    def __init__(self, output_dim, input_dim, init="glorot_uniform", activation="relu", bias=True, device=None,
+                 generator=None, **kwargs):
+        if init != "glorot_uniform":
+            raise ValueError("only glorot_uniform is reached by the reference networks")
+        self.init = init
+        self.activation = activation          # stored, never applied (dense_layer.py:23,42-50)
+        self.output_dim = output_dim
+        self.input_dim = input_dim
+        self.bias = bias
+        self.input_shape = (self.input_dim,)
+        if self.input_dim:
+            kwargs["input_shape"] = (self.input_dim,)
+        super(DenseMol, self).__init__(**kwargs)
+        self._device, self._generator = device, generator
+        self.W = self.b = None
+
+    def build(self, device=None):
+        if self.W is None:
+            device = self._device if self._device is not None else device
+            self.W = glorot([self.input_dim, self.output_dim], self._generator, device).requires_grad_(bool(self.trainable))
+            self.b = torch.zeros(self.output_dim, dtype=torch.float32, device=device).requires_grad_(bool(self.trainable))
+
+    def load_vars(self, W, b):
+        dev = self._device
+        self.W = torch.as_tensor(np.asarray(W), dtype=torch.float32).to(dev).requires_grad_(bool(self.trainable))
+        self.b = torch.as_tensor(np.asarray(b), dtype=torch.float32).to(dev).requires_grad_(bool(self.trainable))
+
+    def parameters(self):
+        self.build()
+        return [self.W, self.b]
+
+    def __call__(self, x):
+        gb, X = _rows_of(x)
+        self.build(X.device)
+        Y = RowsDenseFunction.apply(X, self.W, self.b if self.bias else None, None, gb, "linear", True)
+        return _row_views(Y, gb)
+
+
+class BlockEnd(Layer):
+    """Last layer of a residual block (blockend.py:13-86): act(x + x_res . W), pad rows 0.
+    BlockEnd(block_id, res_n_features, n_features, activation='relu', max_atom=128, batch_size=256);
+    input keys: node_features, data_slice, block_outputs."""
+
+    def __init__(self, block_id, res_n_features, n_features, activation="relu", max_atom=128, batch_size=256,
+                 device=None, generator=None, **kwargs):
+        super(BlockEnd, self).__init__(**kwargs)
+        if activation not in ("relu", "linear", None):
+            raise ValueError("Invalid activation function: %s" % (activation,))
+        self.max_atom, self.batch_size, self.block_id = max_atom, batch_size, block_id
+        self.activation = activation
+        self.res_n_features, self.n_features = res_n_features, n_features
+        self.vars = {}
+        self._device, self._generator = device, generator
+
+    def build(self, device=None):
+        if "weight" not in self.vars:
+            device = self._device if self._device is not None else device
+            self.vars["weight"] = glorot([self.res_n_features, self.n_features], self._generator,
+                                         device).requires_grad_(bool(self.trainable))
+
+    def load_vars(self, arrays):
+        for k, v in arrays.items():
+            self.vars[k] = torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self._device).requires_grad_(
+                bool(self.trainable))
+
+    def parameters(self):
+        self.build()
+        return list(self.vars.values())
+
+    def call(self, x):
+        gb, X = _rows_of(x)
+        x2 = dict(x)
+        x2["graph_batch"] = gb
+        _, Xres = _rows_of(x2, "block_outputs") if isinstance(x["block_outputs"], RowViews) else (None, None)
+        if Xres is None:
+            bo = x["block_outputs"]
+            X3 = bo if torch.is_tensor(bo) else torch.stack(list(bo))
+            Xres = X3.reshape(-1, X3.shape[-1]) if X3.dim() == 3 else X3
+        self.build(X.device)
+        Y = RowsDenseFunction.apply(Xres, self.vars["weight"], None, X.contiguous(), gb,
+                                    "relu" if self.activation == "relu" else "linear", False)
+        return _row_views(Y, gb)
+
+
+class GraphPoolMol(Layer):
+    """Neighbourhood max-pooling (graphpool.py:11-110).  GraphPoolMol(batch_size).  grad: 'reference' (the
+    reference's py_func passes no gradient) or 'argmax' (extension)."""
+
+    def __init__(self, batch_size, grad="reference", **kwargs):
+        super(GraphPoolMol, self).__init__(**kwargs)
+        if grad not in ("reference", "argmax"):
+            raise ValueError("grad must be 'reference' or 'argmax'")
+        self.batch_size = batch_size
+        self.sparse_inputs = True
+        self.grad = grad
+
+    def get_output_shape_for(self, input_shape):
+        return input_shape[0]
+
+    def call(self, x, mask=None):
+        gb, X = _rows_of(x)
+        if gb.l0_dense is None and gb.l0_rowptr is None:
+            raise ValueError("GraphPoolMol needs the original Laplacian")
+        return _row_views(GraphPoolFunction.apply(X, gb, self.grad), gb)

@@ -202,6 +202,41 @@ int agcn_graph_gather_backward(const void* plan_host, const void* plan_dev, cons
                                const float* dOut, int32_t F, int32_t ldx, int32_t activation,
                                float* dX /* [rows, ldx], pad rows zeroed */, void* hip_stream);
 
+/* ---- "next" rows: the layers around the SGC stack --------------------------------
+ * rows_dense: Y = act(A . W [+ bias] [+ Add]) over the row space of a batch.
+ *   DenseMol  (models/layers/dense_layer.py:33-50): activation LINEAR (the layer stores one but never
+ *             applies it), bias, keep_pad_rows = 1 (the bias also lands on pad rows), Add = NULL.
+ *   BlockEnd  (models/layers/blockend.py:67-86): Y = act(x + x_res . W): A = x_res, Add = x, no bias,
+ *             keep_pad_rows = 0 (tf.pad -> pad rows 0).
+ * Backward: Gp = dY . act'(Y); dX = Gp . W^T; dW = A^T Gp; dbias = colsum(Gp) (nullable); dAdd = Gp
+ * (nullable; contiguous [rows, Fout]). */
+typedef struct AgcnDenseDesc {
+  int32_t Fin, Fout;
+  int32_t activation;    /* AGCN_ACT_LINEAR | AGCN_ACT_RELU */
+  int32_t keep_pad_rows; /* 1: pad rows are ordinary rows */
+  int32_t ldx, ldy, ldadd;
+  int32_t reserved;
+} AgcnDenseDesc;
+int agcn_rows_dense_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+                            const float* X, const float* W, const float* bias, const float* Add, float* Y,
+                            void* hip_stream);
+size_t agcn_rows_dense_backward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host);
+int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+                             const float* X, const float* W, const float* Y, const float* dY, float* dX,
+                             float* dAdd, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                             void* hip_stream);
+
+/* GraphPoolMol (models/layers/graphpool.py:55-110): out[i] = max over {x_j : L_ij != 0} (x_i if the row
+ * is empty), pad rows 0.  `lap`: only the L0_* members are read.  argmax [rows, F] int32 is optional.
+ * The reference passes NO gradient through this layer (py_func); agcn_graph_pool_backward is the
+ * arg-max-routing extension and needs a symmetric pattern. */
+int agcn_graph_pool_forward(const void* plan_host, const void* plan_dev, const AgcnGraphBatch* lap,
+                            const float* X, int32_t F, int32_t ldx, float* out, int32_t* argmax,
+                            void* hip_stream);
+int agcn_graph_pool_backward(const void* plan_host, const void* plan_dev, const AgcnGraphBatch* lap,
+                             const int32_t* argmax, const float* dOut, int32_t F, int32_t ldx, float* dX,
+                             void* hip_stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel of
  * the path).  Off by default.  agcn_profile_collect waits for the events recorded since the last
  * collect and returns, per kernel id < agcn_profile_kernels(), the total milliseconds and the

@@ -401,6 +401,57 @@ def graph_gather_backward(out, pre, G, ns, activation="tanh"):
 
 
 # ----------------------------------------------------------------------------
+# N1 / N2 / N4 "next" rows
+def dense_mol_forward(X_pad, W, b):
+    """models/layers/dense_layer.py:33-50: xx = matmul(xx, W) + b on the PADDED [max_atom, Fin] tensor
+    (so pad rows come out as b); the stored activation is never applied."""
+    return X_pad @ W + b
+
+
+def dense_mol_backward(X_pad, W, G):
+    """Returns (dX, dW, db) for one padded graph (sum the parameter gradients over the batch)."""
+    return G @ W.T, X_pad.T @ G, G.sum(axis=0, dtype=G.dtype)
+
+
+def block_end_forward(x, x_res, W, activation="relu"):
+    """models/layers/blockend.py:67-86 on the sliced rows [n, F]: act(x_res . W + x) (pad rows are 0)."""
+    pre = x_res @ W + x
+    return (np.maximum(pre, 0) if activation == "relu" else pre), pre
+
+
+def block_end_backward(x_res, W, pre, G, activation="relu"):
+    """Returns (dx, dx_res, dW)."""
+    Gp = G * (pre > 0) if activation == "relu" else G
+    return Gp, Gp @ W.T, x_res.T @ Gp
+
+
+def graph_pool_forward(x, L):
+    """models/layers/graphpool.py:91-103 as written: per node, max over the rows of x selected by the
+    non-zeros of the node's Laplacian row; an empty row keeps x[i].  Returns (pooled, argmax)."""
+    acc, arg = [], []
+    for i, l in enumerate(list(L)):
+        idx = np.nonzero(l)[0]
+        if len(idx) != 0:
+            rows = x[idx]
+            acc.append(np.amax(rows, axis=0))
+            arg.append(idx[np.argmax(rows, axis=0)])       # first maximum in index order
+        else:
+            acc.append(x[i])
+            arg.append(np.full(x.shape[1], i))
+    return np.vstack(acc), np.vstack(arg)
+
+
+def graph_pool_backward(argmax, G):
+    """Arg-max routing (extension: the reference's py_func passes no gradient)."""
+    dX = np.zeros_like(G)
+    n, F = G.shape
+    for i in range(n):
+        for f in range(F):
+            dX[argmax[i, f], f] += G[i, f]
+    return dX
+
+
+# ----------------------------------------------------------------------------
 # synthetic Tox21-shaped batches (SURVEY.md section 8(d)); used by tests and bench
 ONE_HOT_BLOCKS = (44, 11, 5, 7)   # symbol, degree, numH, implicit valence (graph_features.py:160-179)
 

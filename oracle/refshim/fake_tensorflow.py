@@ -212,7 +212,13 @@ def _make_var(value, name):
     return v
 
 
-def Variable(initial_value, name=None, **_):
+def Variable(initial_value, *args, **kwargs):
+    # model_operatos.zeros() passes (value, dtype, name) positionally (model_operatos.py:495-496):
+    # take the first string among the positionals as the name
+    name = kwargs.get("name")
+    for a in args:
+        if name is None and isinstance(a, str):
+            name = a
     return _make_var(_raw(initial_value).to(torch.float32), name)
 
 
@@ -223,7 +229,7 @@ def get_variable(name, shape=None, initializer=None, dtype=None, **_):
 
 
 def constant_initializer(value=0.0, **_):
-    return lambda shape: torch.full(shape, float(value), dtype=torch.float32)
+    return lambda shape: torch.full(tuple(int(s) for s in shape), float(value), dtype=torch.float32)
 
 
 def truncated_normal_initializer(mean=0.0, stddev=1.0, **_):
@@ -231,6 +237,20 @@ def truncated_normal_initializer(mean=0.0, stddev=1.0, **_):
         v = STATE.rng.normal(mean, stddev, size=shape)
         v = np.clip(v, mean - 2 * stddev, mean + 2 * stddev)
         return torch.from_numpy(v.astype(np.float32))
+    return f
+
+
+def random_uniform_initializer(minval=0.0, maxval=1.0, dtype=None, seed=None, **_):
+    def f(shape):
+        v = STATE.rng.uniform(minval, maxval, size=tuple(int(s) for s in shape))
+        return Tensor(torch.from_numpy(v.astype(np.float32)))
+    return f
+
+
+def random_normal_initializer(mean=0.0, stddev=1.0, dtype=None, seed=None, **_):
+    def f(shape):
+        v = STATE.rng.normal(mean, stddev, size=tuple(int(s) for s in shape))
+        return Tensor(torch.from_numpy(v.astype(np.float32)))
     return f
 
 

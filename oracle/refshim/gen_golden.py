@@ -214,6 +214,57 @@ def run_gather_case(ftf, layers):
     print("wrote gather cases")
 
 
+def run_next_rows(ftf, layers, gs, topo_cls):
+    """DenseMol (dense_layer.py:33-50), BlockEnd (blockend.py:40-86), GraphPoolMol (graphpool.py:38-110)."""
+    rs = np.random.RandomState(21)
+    ns, Fin, Fout = [5, 9, 4, 12], 7, 6
+    B, max_atom = len(ns), 13
+    graphs = _graphs(rs, ns, Fin, gs, atoms=False)
+    Xn, Ln, ds, ls = _feed(ftf, topo_cls, graphs, Fin, B, max_atom)
+    dsT, lsT = ftf.constant(ds), ftf.constant(ls)
+
+    # DenseMol
+    X = [ftf.Tensor(torch.from_numpy(x.copy()).requires_grad_(True)) for x in Xn]
+    dm = layers.DenseMol(Fout, Fin, activation="relu")
+    # non-zero bias through the shim's variable override (the layer creates its variables inside __call__)
+    ftf.reset_state(5, {"%s_b" % dm.name: (0.1 * rs.randn(Fout)).astype(np.float32)})
+    ref = dm({"node_features": X})
+    G = rs.randn(B, max_atom, Fout).astype(np.float32)
+    sum((o.t * torch.from_numpy(G[b])).sum() for b, o in enumerate(ref)).backward()
+    np.savez_compressed(os.path.join(OUT, "dense_mol.npz"), ns=np.asarray(ns, np.int32), X=np.stack(Xn), data_slice=ds,
+                        W=dm.W.t.detach().numpy(), b=dm.b.t.detach().numpy(), G=G,
+                        Y=np.stack([o.t.detach().numpy() for o in ref]), dX=np.stack([_grad(x) for x in X]),
+                        dW=_grad(dm.W), db=_grad(dm.b))
+
+    # BlockEnd
+    Fres = 5
+    X = [ftf.Tensor(torch.from_numpy(x.copy()).requires_grad_(True)) for x in np.stack(Xn)[:, :, :Fout].copy()]
+    Xn = np.stack(Xn)
+    Rn = np.zeros((B, max_atom, Fres), dtype=np.float32)
+    for b, n in enumerate(ns):
+        Rn[b, :n] = rs.randn(n, Fres)
+    R = [ftf.Tensor(torch.from_numpy(r.copy()).requires_grad_(True)) for r in Rn]
+    ftf.reset_state(6)
+    be = layers.BlockEnd(0, Fres, Fout, activation="relu", max_atom=max_atom, batch_size=B)
+    out = list(be({"node_features": X, "data_slice": dsT, "block_outputs": R}))
+    G = rs.randn(B, max_atom, Fout).astype(np.float32)
+    sum((o.t * torch.from_numpy(G[b])).sum() for b, o in enumerate(out)).backward()
+    np.savez_compressed(os.path.join(OUT, "block_end.npz"), ns=np.asarray(ns, np.int32), data_slice=ds,
+                        X=np.stack([x.t.detach().numpy() for x in X]), R=Rn, W=be.vars["weight"].t.detach().numpy(),
+                        G=G, Y=np.stack([o.t.detach().numpy() for o in out]), dX=np.stack([_grad(x) for x in X]),
+                        dR=np.stack([_grad(r) for r in R]), dW=_grad(be.vars["weight"]))
+
+    # GraphPoolMol (forward only: py_func passes no gradient)
+    X = [ftf.Tensor(torch.from_numpy(x.copy()).requires_grad_(True)) for x in Xn]
+    L = [ftf.Tensor(torch.from_numpy(l.copy())) for l in Ln]
+    gp = layers.GraphPoolMol(B)
+    out = gp({"node_features": X, "original_laplacian": L, "data_slice": dsT, "lap_slice": lsT})
+    assert all(o.t.grad_fn is None for o in out), "GraphPoolMol must not carry a gradient in the reference"
+    np.savez_compressed(os.path.join(OUT, "graph_pool.npz"), ns=np.asarray(ns, np.int32), X=np.stack(Xn),
+                        L=np.stack(Ln), data_slice=ds, lap_slice=ls, Y=np.stack([o.t.detach().numpy() for o in out]))
+    print("wrote dense_mol, block_end, graph_pool")
+
+
 def main():
     assert load_reference.available(), "reference tree not found"
     os.makedirs(OUT, exist_ok=True)
@@ -230,6 +281,7 @@ def main():
     run_lap_cases(gs)
     run_topo_case(ftf, gs, topo_cls)
     run_gather_case(ftf, layers)
+    run_next_rows(ftf, layers, gs, topo_cls)
 
     L = (ftf, layers, gs, topo_cls)
     #                 name                 variant   ns                 Fin Fout K seed fancy

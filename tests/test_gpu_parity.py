@@ -290,3 +290,113 @@ def test_static_step_and_hip_graph(amd):
         st.replay()
         torch.cuda.synchronize()
         same()
+
+
+def test_dense_mol_golden(amd):
+    """DenseMol (dense_layer.py:33-50) through the reference feed: bias lands on pad rows, no activation."""
+    g = load_golden("dense_mol.npz")
+    B = len(g["ns"])
+    Xl = [torch.from_numpy(g["X"][b]).to(DEV).requires_grad_(True) for b in range(B)]
+    layer = amd.DenseMol(g["W"].shape[1], g["W"].shape[0], activation="relu", device=DEV)
+    layer.load_vars(g["W"], g["b"])
+    out = layer({"node_features": Xl, "data_slice": g["data_slice"]})
+    assert len(out) == B
+    assert_close(np.stack([to_np(out[b]) for b in range(B)]), g["Y"], FEATURE_RTOL, "DenseMol Y")
+    G = torch.from_numpy(g["G"]).to(DEV)
+    sum((out[b] * G[b]).sum() for b in range(B)).backward()
+    assert_close(np.stack([to_np(x.grad) for x in Xl]), g["dX"], GRAD_RTOL, "DenseMol dX")
+    assert_close(to_np(layer.W.grad), g["dW"], GRAD_RTOL, "DenseMol dW")
+    assert_close(to_np(layer.b.grad), g["db"], GRAD_RTOL, "DenseMol db")
+
+
+def test_block_end_golden(amd):
+    g = load_golden("block_end.npz")
+    B = len(g["ns"])
+    Xl = [torch.from_numpy(g["X"][b]).to(DEV).requires_grad_(True) for b in range(B)]
+    Rl = [torch.from_numpy(g["R"][b]).to(DEV).requires_grad_(True) for b in range(B)]
+    layer = amd.BlockEnd(0, g["W"].shape[0], g["W"].shape[1], activation="relu", max_atom=g["X"].shape[1],
+                         batch_size=B, device=DEV)
+    layer.load_vars({"weight": g["W"]})
+    out = layer({"node_features": Xl, "data_slice": g["data_slice"], "block_outputs": Rl})
+    Y = np.stack([to_np(out[b]) for b in range(B)])
+    assert_close(Y, g["Y"], FEATURE_RTOL, "BlockEnd Y")
+    for b, n in enumerate(g["ns"]):
+        assert np.all(Y[b, n:] == 0)
+    G = torch.from_numpy(g["G"]).to(DEV)
+    sum((out[b] * G[b]).sum() for b in range(B)).backward()
+    assert_close(np.stack([to_np(x.grad) for x in Xl]), g["dX"], GRAD_RTOL, "BlockEnd dX")
+    assert_close(np.stack([to_np(r.grad) for r in Rl]), g["dR"], GRAD_RTOL, "BlockEnd dR")
+    assert_close(to_np(layer.vars["weight"].grad), g["dW"], GRAD_RTOL, "BlockEnd dW")
+
+
+def test_graph_pool_golden_and_argmax_grad(amd):
+    g = load_golden("graph_pool.npz")
+    B = len(g["ns"])
+    Xl = [torch.from_numpy(g["X"][b]).to(DEV).requires_grad_(True) for b in range(B)]
+    Ll = [torch.from_numpy(g["L"][b]).to(DEV) for b in range(B)]
+    x = {"node_features": Xl, "original_laplacian": Ll, "data_slice": g["data_slice"], "lap_slice": g["lap_slice"]}
+    out = amd.GraphPoolMol(B)(x)
+    Y = np.stack([to_np(out[b]) for b in range(B)])
+    assert np.array_equal(Y, g["Y"])                      # max of inputs: bit exact, pad rows 0
+    assert not out.data.requires_grad                      # the reference passes no gradient (py_func)
+    # extension: arg-max routing against the oracle, packed batch + CSR
+    ns = [int(n) for n in g["ns"]]
+    rs, X, L0, csr, p, _ = synth_case(41, ns, 9, 4, 2, orc.SGC_LL)
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+    Xt = gb.X.clone().requires_grad_(True)
+    out = amd.GraphPoolMol(B, grad="argmax")({"node_features": Xt, "graph_batch": gb})
+    Gs = [rs.randn(n, 9).astype(np.float32) for n in ns]
+    (out.data * torch.from_numpy(np.concatenate(Gs, 0)).to(DEV)).sum().backward()
+    off = gb.plan.row_off
+    for b, n in enumerate(ns):
+        y, arg = orc.graph_pool_forward(X[b], L0[b])
+        assert np.array_equal(to_np(out[b]), y)
+        assert_close(to_np(Xt.grad)[off[b]:off[b] + n], orc.graph_pool_backward(arg, Gs[b]), GRAD_RTOL, "pool dX")
+
+
+def test_simple_agcn_stack_packed(amd):
+    """SimpleAGCN-shaped stack (models/networks/basic_AGCN.py:13-49: 4 x SGC_LL -> DenseMol -> GraphGatherMol)
+    on a packed batch, forward + backward, against the oracle composed the same way (float64)."""
+    ns, widths, Fin, K = [9, 17, 5, 24, 12], [16, 24, 24, 16], 75, 2
+    rs, X, L0, csr, _, _ = synth_case(55, ns, Fin, widths[0], K, orc.SGC_LL, atoms=True)
+    B = len(ns)
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+    layers, params, fin = [], [], Fin
+    for w in widths:
+        p = orc.init_params(rs, fin, w, K)
+        p["bias"] = (0.1 * rs.randn(w)).astype(np.float32)
+        lay = amd.SGC_LL(w, fin, B, K=K, laplacian_mode="paper", device=DEV)
+        lay.load_vars(p)
+        layers.append(lay)
+        params.append(p)
+        fin = w
+    Wd = orc.glorot_uniform(rs, (fin, 32))
+    bd = (0.1 * rs.randn(32)).astype(np.float32)
+    dense = amd.DenseMol(32, fin, device=DEV)
+    dense.load_vars(Wd, bd)
+    gather = amd.GraphGatherMol(B, activation="tanh")
+    Xt = gb.X.clone().requires_grad_(True)
+    h = Xt
+    for lay in layers:
+        h, _, _ = lay({"node_features": h, "graph_batch": gb})
+    h = dense({"node_features": h, "graph_batch": gb})
+    out = gather({"node_features": h, "graph_batch": gb})
+    Gout = rs.randn(B, 32)
+    (out * torch.from_numpy(Gout.astype(np.float32)).to(DEV)).sum().backward()
+    # oracle, float64
+    f64 = lambda d: {k: v.astype(np.float64) for k, v in d.items()}
+    hs, caches = [x.astype(np.float64) for x in X], []
+    for p in params:
+        c = orc.layer_forward(hs, [l.astype(np.float64) for l in L0], f64(p), K, orc.PAPER, orc.SGC_LL)
+        caches.append(c)
+        hs = [ci["Y"] for ci in c]
+    hd = [orc.dense_mol_forward(x, Wd.astype(np.float64), bd.astype(np.float64)) for x in hs]
+    o, pre = orc.graph_gather_forward(hd, "tanh")
+    assert_close(to_np(out), o, 5e-5, "stack output")
+    g = orc.graph_gather_backward(o, pre, Gout, ns, "tanh")
+    g = [orc.dense_mol_backward(x, Wd.astype(np.float64), gi)[0] for x, gi in zip(hs, g)]
+    for c, p in zip(caches[::-1], params[::-1]):
+        tot = orc.layer_backward(c, g, f64(p), K, orc.PAPER, orc.SGC_LL)
+        g = tot["dX"]
+    assert_close(to_np(Xt.grad), np.concatenate(g, 0), 2e-4, "stack dX")
+    assert_close(to_np(layers[0].vars["M_L"].grad), tot["dM_L"], 2e-4, "stack dM_L (layer 1)")

@@ -181,3 +181,43 @@ def test_graph_gather(act):
     for b, n in enumerate(ns):
         _close(dX[b], g["dX"][b, :n], "gather dX")
         assert np.all(g["dX"][b, n:] == 0)
+
+
+def test_dense_mol_golden():
+    g = _load("dense_mol.npz")
+    dW = 0
+    db = 0
+    for b in range(len(g["ns"])):
+        _close(orc.dense_mol_forward(g["X"][b], g["W"], g["b"]), g["Y"][b], "DenseMol Y")
+        dx, dw, dbb = orc.dense_mol_backward(g["X"][b], g["W"], g["G"][b])
+        _close(dx, g["dX"][b], "DenseMol dX", rtol=2e-5, atol=2e-5)
+        dW, db = dW + dw, db + dbb
+    _close(dW, g["dW"], "DenseMol dW", rtol=2e-5, atol=2e-5)
+    _close(db, g["db"], "DenseMol db", rtol=2e-5, atol=2e-5)
+    n0 = int(g["ns"][0])
+    assert np.allclose(g["Y"][0][n0:], g["b"])        # the bias lands on pad rows (dense_layer.py:42-50)
+
+
+def test_block_end_golden():
+    g = _load("block_end.npz")
+    dW = 0
+    for b, n in enumerate(g["ns"]):
+        y, pre = orc.block_end_forward(g["X"][b, :n], g["R"][b, :n], g["W"])
+        _close(y, g["Y"][b, :n], "BlockEnd Y")
+        assert np.all(g["Y"][b, n:] == 0)
+        dx, dr, dw = orc.block_end_backward(g["R"][b, :n], g["W"], pre, g["G"][b, :n])
+        _close(dx, g["dX"][b, :n], "BlockEnd dX", rtol=2e-5, atol=2e-5)
+        _close(dr, g["dR"][b, :n], "BlockEnd dR", rtol=2e-5, atol=2e-5)
+        dW = dW + dw
+    _close(dW, g["dW"], "BlockEnd dW", rtol=2e-5, atol=2e-5)
+
+
+def test_graph_pool_golden():
+    g = _load("graph_pool.npz")
+    for b, n in enumerate(g["ns"]):
+        y, arg = orc.graph_pool_forward(g["X"][b, :n], g["L"][b, :n, :n])
+        np.testing.assert_array_equal(y, g["Y"][b, :n])          # a max of inputs: bit exact
+        assert np.all(g["Y"][b, n:] == 0)
+        G = np.random.RandomState(b).randn(n, y.shape[1]).astype(np.float32)
+        dX = orc.graph_pool_backward(arg, G)
+        assert abs(dX.sum() - G.sum()) < 1e-4                     # routing conserves the gradient mass
