@@ -19,7 +19,7 @@ class PlanInfo(C.Structure):
                 ("off_n", C.c_int64), ("off_row_off", C.c_int64), ("off_tile_off", C.c_int64),
                 ("off_order", C.c_int64), ("off_wtile_off", C.c_int64),
                 ("n_slabs", C.c_int32), ("reserved1", C.c_int32),
-                ("off_slab_graph", C.c_int64), ("off_slab_row", C.c_int64)]
+                ("off_slab_graph", C.c_int64), ("off_slab_row", C.c_int64), ("off_row_graph", C.c_int64)]
 
 
 class LayerDesc(C.Structure):
@@ -76,7 +76,7 @@ def _declare(lib):
     lib.agcn_plan_bytes.restype = SZ
     lib.agcn_plan_bytes.argtypes = [I32]
     lib.agcn_plan_bytes_for.restype = SZ
-    lib.agcn_plan_bytes_for.argtypes = [P, I32]
+    lib.agcn_plan_bytes_for.argtypes = [P, I32, I32]
     lib.agcn_plan_build.restype = C.c_int
     lib.agcn_plan_build.argtypes = [P, I32, I32, P, SZ]
     lib.agcn_plan_info.restype = C.c_int

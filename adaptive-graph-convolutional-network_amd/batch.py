@@ -36,7 +36,7 @@ class Plan(object):
         if n.ndim != 1 or n.size < 1:
             raise ValueError("n_nodes must be a non-empty 1-D array")
         B = int(n.size)
-        nbytes = lib.agcn_plan_bytes_for(n.ctypes.data, B)
+        nbytes = lib.agcn_plan_bytes_for(n.ctypes.data, B, int(row_stride))
         if nbytes == 0:
             raise _ffi.AgcnError('invalid node counts')
         self.host = np.zeros(nbytes, dtype=np.uint8)

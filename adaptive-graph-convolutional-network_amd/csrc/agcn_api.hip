@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "sgc_kernels.h"
 
@@ -57,15 +58,71 @@ bool use_slabs(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanIn
          g->L0_dense == nullptr && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
 }
 
-// Fused per-graph kernels (fused_kernels.hip): SGC_LL, K = 2, packed rows, CSR L_orig, and the
-// largest graph's working set fits LDS.  mode knob: agcn_set_fused_mode (1 = auto).
-bool use_fused(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
-  if (agcn_get_fused_mode() == 0) return false;
+// Fused per-graph kernels (fused_kernels.hip): SGC_LL, K = 2, packed rows, CSR L_orig, for the graphs
+// whose working set fits LDS.  Graphs are scheduled largest first, so the ones that do NOT fit are a
+// prefix of plan.order (and their slabs a prefix of the slab table): with `mixed` dispatch those few
+// graphs run on the slab-parallel kernels on a side stream, concurrently with the fused kernels.
+struct FusedSplit {
+  int mode;        // 0: fused path not used; 1: every graph fused; 2: mixed
+  int n_big;       // graphs (prefix of order) that do not fit
+  int n_big_slabs; // their slabs (prefix of the slab table)
+  int thr;         // largest fitting graph size: a graph is "big" iff n > thr
+};
+
+FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
+  FusedSplit f{0, 0, 0, 0};
+  const AgcnPlanInfo& pi = host.info;
+  if (agcn_get_fused_mode() == 0) return f;
   if (!(d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
-        g->L0_dense == nullptr)) return false;
-  const size_t need = std::max(fused_lds_bytes(pi.max_n, d->Fin, d->Fout, d->K),
-                               fused_bwd_lds_bytes(pi.max_n, d->Fin, d->Fout, d->K));
-  return need <= (size_t)agcn_get_lds_limit() && need <= 160 * 1024;
+        g->L0_dense == nullptr)) return f;
+  size_t lim = (size_t)agcn_get_lds_limit();
+  if (lim > 160 * 1024) lim = 160 * 1024;
+  auto need = [&](int n) {
+    return std::max(fused_lds_bytes(n, d->Fin, d->Fout, d->K), fused_bwd_lds_bytes(n, d->Fin, d->Fout, d->K));
+  };
+  auto count_big = [&](size_t limit, int* slabs) {
+    int nb = 0, ns = 0;
+    while (nb < pi.B && need(host.n[host.order[nb]]) > limit) {
+      ns += (host.n[host.order[nb]] + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
+      ++nb;
+    }
+    *slabs = ns;
+    return nb;
+  };
+  int ns = 0;
+  int nb = count_big(lim, &ns);
+  if (nb == 0) { f.mode = 1; f.thr = pi.max_n; return f; }
+  // Some graph does not fit.  Measured on MI355X (Tox21-shaped, 256 graphs per GPU, one n = 95 graph):
+  // all-slab 117 us/step, mixed 144 us/step -- the side chain of four dependent launches is longer than
+  // the fused kernel it runs beside, so mixed dispatch is opt-in (agcn_set_fused_mode(2)) and the whole
+  // batch takes the slab path by default.
+  if (agcn_get_fused_mode() != 2) return f;
+  if (!use_slabs(d, g, pi)) return f;   // the big graphs have no slab path
+  // Mixed dispatch only pays if the side-stream kernels can be CO-RESIDENT with the fused workgroups
+  // (a fused workgroup is 16 waves + up to 150 KiB of LDS, i.e. a whole CU).  So the fused part is limited
+  // to graphs whose image leaves ~48 KiB of LDS (one slab workgroup) free on every CU; everything larger
+  // goes to the slab-parallel side chain, which is spread over all CUs.
+  const size_t co_lim = 112 * 1024;
+  if (lim > co_lim) nb = count_big(co_lim, &ns);
+  if (nb == pi.B) return f;
+  f.mode = 2; f.n_big = nb; f.n_big_slabs = ns; f.thr = host.n[host.order[nb]];
+  return f;
+}
+
+// Side stream for the mixed dispatch (created once per process; one process drives one GPU).
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int ok = 0;
+};
+SideStream& side_stream() {
+  static SideStream ss;
+  if (!ss.ok) {
+    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess) ss.ok = 1;
+  }
+  return ss;
 }
 
 struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, total; };
@@ -87,7 +144,9 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
 // Row chunks of the parameter-gradient partial products: 64-row chunks (16 MFMA k-steps) give
 // a few thousand wave-sized work items at Tox21 batch sizes; capped so the partial buffer stays small.
 int n_chunks_for(int32_t rows) {
-  int c = (rows + 63) / 64;
+  static const int env_rows = [] { const char* e = std::getenv("AGCN_PG_CHUNK_ROWS"); return e ? std::atoi(e) : 0; }();
+  const int cr = env_rows >= 16 ? env_rows : 64;
+  int c = (rows + cr - 1) / cr;
   if (c < 1) c = 1;
   if (c > 256) c = 256;
   return c;
@@ -170,7 +229,7 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
   w->g = c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
   w->dZ = paper ? c.take((size_t)pi.rows * d->Fin) : nullptr;
   w->Gp = c.take((size_t)pi.rows * d->Fout);
-  w->pg = c.take((size_t)2 * (pi.n_slabs > pi.B ? pi.n_slabs : pi.B));
+  w->pg = c.take((size_t)2 * ((size_t)pi.n_slabs + pi.B));
   w->dA = w->dd = nullptr;
   if (d->variant == AGCN_SGC_LL && d->K == 2 && paper) {   // slab path scratch
     w->dA = c.take((size_t)pi.tile_elems);
@@ -227,10 +286,44 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
 
   a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
-  if (use_fused(desc, batch, host.info)) {
+  const FusedSplit fs = fused_split(desc, batch, host);
+  if (fs.mode == 1) {
     // small graphs: the whole layer forward in one launch, everything staged in LDS once
-    return launch_fused_forward(a, host.info.B, fused_lds_bytes(host.info.max_n, desc->Fin, desc->Fout, desc->K),
+    return launch_fused_forward(a, 0, host.info.B, fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K),
                                 hip_stream);
+  }
+  if (fs.mode == 2) {
+    // mixed: the few graphs too large for the fused kernel go through the slab-parallel pipeline on a side
+    // stream (row-restricted packed GEMMs + the prefix of the slab table), the rest through the fused kernel
+    SideStream& ss = side_stream();
+    if (!ss.ok) return fail(AGCN_EDEVICE, "%s: cannot create the side stream", who);
+    hipStream_t main_s = static_cast<hipStream_t>(hip_stream);
+    if (hipEventRecord(ss.fork, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess)
+      return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
+    RowsGemmArgs g;
+    fill_rows(g, desc, host, dev);
+    g.big_n = fs.thr; g.row_graph = dev.row_graph;
+    g.Kd = desc->Fin; g.N = desc->Fin;
+    g.A0 = batch->X; g.lda0 = desc->ldx; g.Bm = params->M_L; g.Out0 = a.sv_Z; g.ldo0 = desc->Fin;
+    rc = launch_rows_gemm(g, RG_PROJECT, ss.s);
+    if (rc != AGCN_OK) return rc;
+    SgcArgs ab = a;
+    ab.n_slabs = fs.n_big_slabs;
+    rc = launch_slab_forward(ab, ss.s);
+    if (rc != AGCN_OK) return rc;
+    fill_rows(g, desc, host, dev);
+    g.big_n = fs.thr; g.row_graph = dev.row_graph;
+    g.Kd = desc->Fin * desc->K; g.N = desc->Fout;
+    g.A0 = batch->X; g.lda0 = desc->ldx; g.A1 = a.sv_X; g.a1_plane = (int64_t)host.info.rows * desc->Fin;
+    g.Bm = params->weight; g.bias = params->bias; g.Out0 = out->Y; g.ldo0 = desc->ldy;
+    rc = launch_rows_gemm(g, RG_FILTER, ss.s);
+    if (rc != AGCN_OK) return rc;
+    rc = launch_fused_forward(a, fs.n_big, host.info.B - fs.n_big,
+                              fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), hip_stream);
+    if (rc != AGCN_OK) return rc;
+    if (hipEventRecord(ss.join, ss.s) != hipSuccess || hipStreamWaitEvent(main_s, ss.join, 0) != hipSuccess)
+      return fail(AGCN_EDEVICE, "%s: stream join failed", who);
+    return AGCN_OK;
   }
   // 1. Z = X . M_L over the packed rows (graphconv.py:164)
   RowsGemmArgs g;
@@ -320,13 +413,50 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
 
   const int B = host.info.B;
   const bool slabs = use_slabs(desc, batch, host.info);
-  const bool fused = use_fused(desc, batch, host.info);
+  const FusedSplit fs = fused_split(desc, batch, host);
+  const bool fused = fs.mode != 0;
   if ((stages & 1) && fused) {
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_Gp = w.Gp;
-    rc = launch_fused_backward(a, B, fused_bwd_lds_bytes(host.info.max_n, desc->Fin, desc->Fout, desc->K), hip_stream);
+    a.ws_dA = w.dA; a.ws_dd = w.dd;
+    SideStream* ss = nullptr;
+    hipStream_t main_s = static_cast<hipStream_t>(hip_stream);
+    if (fs.mode == 2) {
+      ss = &side_stream();
+      if (!ss->ok) return fail(AGCN_EDEVICE, "%s: cannot create the side stream", who);
+      if (hipEventRecord(ss->fork, main_s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
+        return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
+      RowsGemmArgs g;
+      fill_rows(g, desc, host, dev);
+      g.big_n = fs.thr; g.row_graph = dev.row_graph;
+      g.Kd = desc->Fout; g.N = desc->Fin * desc->K;
+      g.A0 = dY; g.lda0 = desc->ldy; g.Yact = fwd->Y; g.ldy = desc->ldy; g.Bm = params->weight;
+      g.Out0 = grads->dX; g.ldo0 = desc->ldx; g.Out1 = w.g; g.o1_plane = (int64_t)host.info.rows * desc->Fin;
+      g.Gp = w.Gp;
+      rc = launch_rows_gemm(g, RG_FILTER_BWD, ss->s);
+      if (rc != AGCN_OK) return rc;
+      SgcArgs ab = a;
+      ab.n_slabs = fs.n_big_slabs;
+      ab.pg_slab_base = B;
+      rc = launch_slab_backward(ab, ss->s);
+      if (rc != AGCN_OK) return rc;
+      if (paper) {
+        fill_rows(g, desc, host, dev);
+        g.big_n = fs.thr; g.row_graph = dev.row_graph;
+        g.Kd = desc->Fin; g.N = desc->Fin;
+        g.A0 = w.dZ; g.lda0 = desc->Fin; g.Bm = params->M_L; g.Out0 = grads->dX; g.ldo0 = desc->ldx;
+        rc = launch_rows_gemm(g, RG_PROJECT_BWD, ss->s);
+        if (rc != AGCN_OK) return rc;
+      }
+    }
+    rc = launch_fused_backward(a, fs.n_big, B - fs.n_big,
+                               fused_bwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), hip_stream);
     if (rc != AGCN_OK) return rc;
+    if (ss) {
+      if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(main_s, ss->join, 0) != hipSuccess)
+        return fail(AGCN_EDEVICE, "%s: stream join failed", who);
+    }
   } else if (stages & 1) {
     // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace
     RowsGemmArgs g;
@@ -373,7 +503,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
-  pa.B = (slabs && !fused) ? host.info.n_slabs : B; pa.part_stride = w.part_stride;
+  pa.B = fused ? B + fs.n_big_slabs : (slabs ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;

@@ -50,6 +50,7 @@ struct PlanView {
   const int64_t* wtile_off;
   const int32_t* slab_graph;
   const int32_t* slab_row;
+  const int32_t* row_graph;
 };
 
 // Validates the HOST blob and returns views whose pointers point into `base`
@@ -65,6 +66,7 @@ inline int plan_view(const void* plan_host, const void* base, PlanView* v) {
   v->wtile_off = reinterpret_cast<const int64_t*>(p + v->info.off_wtile_off);
   v->slab_graph = reinterpret_cast<const int32_t*>(p + v->info.off_slab_graph);
   v->slab_row = reinterpret_cast<const int32_t*>(p + v->info.off_slab_row);
+  v->row_graph = reinterpret_cast<const int32_t*>(p + v->info.off_row_graph);
   return AGCN_OK;
 }
 

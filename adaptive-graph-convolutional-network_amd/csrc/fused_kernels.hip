@@ -174,6 +174,9 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
     csr_p0 = a.L0_rowptr[row0 + tid];
     csr_p1 = a.L0_rowptr[row0 + tid + 1];
   }
+  int csr_c[4] = {0, 0, 0, 0};
+  float csr_v[4] = {0.f, 0.f, 0.f, 0.f};
+  bool csr_loaded = false;
   const int cpF = (F4 + 63) >> 6, cpO = (Fout + 63) >> 6;   // column passes of 64 lanes
   auto ident = [](int r) { return r; };
   // image row k*F4 + f  <-  W row f*K + k   (graphconv.py:243-244 interleaving undone once, here)
@@ -200,6 +203,17 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
       const int jr = min(wave + 16 * u, K * F4 - 1);
       wr[u] = a.weight[(int64_t)max(wmap(jr), 0) * Fout + min(lane, Fout - 1)];
     }
+    // CSR entries of this thread's row: their addresses depend on the row pointers, which were the FIRST
+    // loads issued -- requesting them here, before the LDS stores below, hides this dependent round trip
+    if (tid < n && csr_p1 > csr_p0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = min(csr_p0 + u, csr_p1 - 1);
+        csr_c[u] = a.L0_col[pp];
+        csr_v[u] = a.L0_val[pp];
+      }
+    }
+    csr_loaded = true;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int i = wave + 16 * u;
@@ -232,9 +246,7 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
     if (cpO <= 1) stage_matrix<1>(Wimg, ldw, a.weight, Fout, K * F4, Fout, K * F4, Fout, wmap);
     else stage_matrix<4>(Wimg, ldw, a.weight, Fout, K * F4, Fout, K * F4, Fout, wmap);
   }
-  int csr_c[4] = {0, 0, 0, 0};
-  float csr_v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (tid < n && csr_p1 > csr_p0) {
+  if (!csr_loaded && tid < n && csr_p1 > csr_p0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int pp = min(csr_p0 + u, csr_p1 - 1);
@@ -480,12 +492,24 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   const int nn = n * n;
   const float alpha = a.alpha[0];
 
+  AGCN_STAMP(4, 0);
   // ---- B0: loads: dY, Y rows -> Gp image (+ global copy); W -> regrouped image; CSR rows; s --------
   int csr_p0 = 0, csr_p1 = 0;
   if (tid < n) {
     csr_p0 = a.L0_rowptr[row0 + tid];
     csr_p1 = a.L0_rowptr[row0 + tid + 1];
     s_vec[tid] = paper ? a.sv_s[row0 + tid] : 0.f;
+  }
+  // res_L rows (wave = row, lanes = columns, 2 column passes): requested now, stored after the staging
+  const bool lpref = (nw == 16 && n4 <= 128);
+  float lreg[8][2];
+  if (lpref) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(wave + 16 * u, n - 1);
+      lreg[u][0] = a.res_L[toff + (int64_t)i * n + min(lane, n - 1)];
+      lreg[u][1] = a.res_L[toff + (int64_t)i * n + min(lane + 64, n - 1)];
+    }
   }
   {
     // rows i = wave, wave + 16, ..; lanes along the Fout columns (passes of 64)
@@ -524,12 +548,25 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       csr_v[u] = a.L0_val[pp];
     }
   }
-  // tile = L = res_L + L_orig (the tile's 16-padding is zeroed: it is the MFMA k range)
-  for (int i = wave; i < n4; i += nw) {
-    for (int j = lane; j < n4; j += 64) {
-      float v = 0.f;
-      if (i < n && j < n) v = a.res_L[toff + (int64_t)i * n + j];
-      tile[i * ldt + j] = v;
+  AGCN_STAMP(4, 1);
+  // tile = L = res_L + L_orig (the tile's 16-padding is zeroed: it is the MFMA k range).  The res_L
+  // loads were requested at the top of the kernel (lreg), together with the dY / Y / W loads.
+  if (lpref) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = wave + nw * u;
+      if (i < n4) {
+        if (lane < n4) tile[i * ldt + lane] = (i < n && lane < n) ? lreg[u][0] : 0.f;
+        if (lane + 64 < n4) tile[i * ldt + lane + 64] = (i < n && lane + 64 < n) ? lreg[u][1] : 0.f;
+      }
+    }
+  } else {
+    for (int i = wave; i < n4; i += nw) {
+      for (int j = lane; j < n4; j += 64) {
+        float v = 0.f;
+        if (i < n && j < n) v = a.res_L[toff + (int64_t)i * n + j];
+        tile[i * ldt + j] = v;
+      }
     }
   }
   __syncthreads();
@@ -539,6 +576,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
     for (int p = csr_p0 + 4; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
   }
+  AGCN_STAMP(4, 2);
   // [g_0 | g_1] = Gp . W^T : output columns jr = k*F4 + f
   {
     const int tm = n4 >> 4, tn = (K * F4) >> 4;
@@ -555,6 +593,28 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   }
   __syncthreads();
 
+  AGCN_STAMP(4, 3);
+  // paper mode: the X_0, M_L and Z rows needed by B2 are requested NOW so that their round trip overlaps the
+  // matrix work of B1; they are written to LDS after the barrier that retires the B0 images.
+  const bool xpref = paper && nw == 16 && n4 <= 80 && F4 <= 128;
+  float x0r[5][2], m0r[8][2], z0r[5][2];
+  if (xpref) {
+    const float* Zg0 = a.sv_Z + (int64_t)row0 * Fin;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = min(wave + 16 * u, n - 1);
+      x0r[u][0] = Xg[(int64_t)i * a.ldx + min(lane, Fin - 1)];
+      x0r[u][1] = Xg[(int64_t)i * a.ldx + min(lane + 64, Fin - 1)];
+      z0r[u][0] = Zg0[(int64_t)i * Fin + min(lane, Fin - 1)];
+      z0r[u][1] = Zg0[(int64_t)i * Fin + min(lane + 64, Fin - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = min(wave + 16 * u, Fin - 1);
+      m0r[u][0] = a.M_L[(int64_t)k * Fin + min(lane, Fin - 1)];
+      m0r[u][1] = a.M_L[(int64_t)k * Fin + min(lane + 64, Fin - 1)];
+    }
+  }
   // ---- B1: dX += L^T g_1 -----------------------------------------------------------------------------------
   {
     const int tm = n4 >> 4, tn = F4 >> 4;
@@ -570,8 +630,26 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   float dalpha_part = 0.f;
   if (paper) {
     __syncthreads();   // GPimg / WTimg and the L tile are dead
+    AGCN_STAMP(4, 4);
     // ---- B2: stage X_0 and M_L (row-major) over the dead B0 images -----------------------------------
-    {
+    if (xpref) {
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int i = wave + 16 * u;
+        if (i < n4) {
+          if (lane < F4) X0img[i * ldxa + lane] = (i < n && lane < Fin) ? x0r[u][0] : 0.f;
+          if (lane + 64 < F4) X0img[i * ldxa + lane + 64] = (i < n && lane + 64 < Fin) ? x0r[u][1] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = wave + 16 * u;
+        if (k < F4) {
+          if (lane < F4) Mimg[k * ldxa + lane] = (k < Fin && lane < Fin) ? m0r[u][0] : 0.f;
+          if (lane + 64 < F4) Mimg[k * ldxa + lane + 64] = (k < Fin && lane + 64 < Fin) ? m0r[u][1] : 0.f;
+        }
+      }
+    } else {
       auto ident = [](int rr) { return rr; };
       if (F4 <= 128) {
         stage_matrix<2>(X0img, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
@@ -582,6 +660,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       }
     }
     __syncthreads();
+    AGCN_STAMP(4, 5);
     // dL = g_1 X_0^T -> tile
     {
       const int tm = n4 >> 4;
@@ -594,8 +673,18 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       }
     }
     __syncthreads();
+    AGCN_STAMP(4, 6);
     // Z rows -> G1img region (row-major B operand), g_1 is dead
-    {
+    if (xpref) {
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int i = wave + 16 * u;
+        if (i < n4) {
+          if (lane < F4) G1img[i * ldxa + lane] = (i < n && lane < Fin) ? z0r[u][0] : 0.f;
+          if (lane + 64 < F4) G1img[i * ldxa + lane + 64] = (i < n && lane + 64 < Fin) ? z0r[u][1] : 0.f;
+        }
+      }
+    } else {
       auto ident = [](int rr) { return rr; };
       const float* Zg = a.sv_Z + (int64_t)row0 * Fin;
       if (F4 <= 128) stage_matrix<2>(G1img, ldxa, Zg, Fin, n, Fin, n4, F4, ident);
@@ -628,6 +717,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       ddv[k] = -0.5f * sk * sk * sk * (rsv[k] + cs);   // dd_k = -1/2 s_k^3 ds_k
     }
     __syncthreads();
+    AGCN_STAMP(4, 7);
     // pass 2: dr_ij = -S_ij (dA_ij s_i s_j + dd_j), in place
     for (int i = wave; i < n; i += nw) {
       const float si = s_vec[i];
@@ -640,6 +730,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       }
     }
     __syncthreads();
+    AGCN_STAMP(4, 8);
     // pass 3: c_ij = (dr_ij + dr_ji) / r_ij for i < j (0 where r_ij == 0), mirrored; diagonal 0
     for (int i = wave; i < n; i += nw) {
       for (int j = lane; j < n; j += 64) {
@@ -662,6 +753,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       if (lane == 0) rsv[i] = rsum;
     }
     __syncthreads();
+    AGCN_STAMP(4, 9);
     // dZ = rowsum(c) Z - c Z -> X0img region (A operand) + global
     {
       float* dZg = a.ws_dZ + (int64_t)row0 * Fin;
@@ -681,6 +773,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       }
     }
     __syncthreads();
+    AGCN_STAMP(4, 10);
     // dX += dZ M_L^T   (B[kk][f] = M[f][kk]: transposed read of the row-major M image)
     {
       const int tm = n4 >> 4, tn = F4 >> 4;
@@ -695,6 +788,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     }
   }
   __syncthreads();
+  AGCN_STAMP(4, 11);
   // ---- B3: dX rows out ---------------------------------------------------------------------------------------
   {
     float* dXg = a.dX + (int64_t)row0 * a.ldx;
@@ -716,7 +810,8 @@ size_t fused_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
   return sizeof(float) * (size_t)fused_bwd_dims(n, Fin, Fout, K).total;
 }
 
-int launch_fused_backward(const SgcArgs& a, int32_t count, size_t lds_bytes, void* stream) {
+int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream) {
+  if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_backward_kernel),
@@ -724,14 +819,15 @@ int launch_fused_backward(const SgcArgs& a, int32_t count, size_t lds_bytes, voi
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_BWD, stream);
-  hipLaunchKernelGGL(fused_backward_kernel, dim3(count), dim3(1024), lds_bytes, s, a, 0);
+  hipLaunchKernelGGL(fused_backward_kernel, dim3(count), dim3(1024), lds_bytes, s, a, first);
   prof_end(stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_backward launch: %s", hipGetErrorString(e));
   return AGCN_OK;
 }
 
-int launch_fused_forward(const SgcArgs& a, int32_t count, size_t lds_bytes, void* stream) {
+int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream) {
+  if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_forward_kernel),
@@ -739,7 +835,7 @@ int launch_fused_forward(const SgcArgs& a, int32_t count, size_t lds_bytes, void
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_fwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_FWD, stream);
-  hipLaunchKernelGGL(fused_forward_kernel, dim3(count), dim3(1024), lds_bytes, s, a, 0);
+  hipLaunchKernelGGL(fused_forward_kernel, dim3(count), dim3(1024), lds_bytes, s, a, first);
   prof_end(stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_forward launch: %s", hipGetErrorString(e));

@@ -16,7 +16,7 @@ constexpr uint64_t kMagic = 0x4147434E504C4E31ull;  // "AGCNPLN1"
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
-  int64_t off_n, off_row_off, off_tile_off, off_order, off_wtile_off, off_slab_graph, off_slab_row, total;
+  int64_t off_n, off_row_off, off_tile_off, off_order, off_wtile_off, off_slab_graph, off_slab_row, off_row_graph, total;
 };
 
 // max_slabs: upper bound used for sizing (sum of ceil(n/16) <= N1/16 + B, but N1 is unknown when
@@ -24,7 +24,7 @@ struct Layout {
 // slab tables are therefore sized from the ACTUAL node counts: agcn_plan_bytes(B) returns the size
 // for the worst case of the plan WITHOUT slab tables plus a fixed per-graph allowance, and
 // agcn_plan_build fails with AGCN_ENOSPACE if the batch needs more (see agcn_plan_bytes_for).
-Layout layout_for(int32_t B, int64_t n_slabs) {
+Layout layout_for(int32_t B, int64_t n_slabs, int64_t rows) {
   Layout l;
   int64_t o = align_up((int64_t)sizeof(uint64_t) + (int64_t)sizeof(AgcnPlanInfo), 16);
   l.off_n = o;           o = align_up(o + 4ll * B, 16);
@@ -34,6 +34,7 @@ Layout layout_for(int32_t B, int64_t n_slabs) {
   l.off_wtile_off = o;   o = align_up(o + 8ll * (B + 1), 16);
   l.off_slab_graph = o;  o = align_up(o + 4ll * n_slabs, 16);
   l.off_slab_row = o;    o = align_up(o + 4ll * n_slabs, 16);
+  l.off_row_graph = o;   o = align_up(o + 4ll * rows, 16);
   l.total = o;
   return l;
 }
@@ -44,14 +45,18 @@ int64_t slabs_of(int32_t n) { return (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS; 
 extern "C" size_t agcn_plan_bytes(int32_t B) {
   // worst case: every graph has AGCN_MAX_NODES nodes
   if (B < 0) return 0;
-  return (size_t)layout_for(B, (int64_t)B * slabs_of(AGCN_MAX_NODES)).total;
+  return (size_t)layout_for(B, (int64_t)B * slabs_of(AGCN_MAX_NODES), (int64_t)B * AGCN_MAX_NODES).total;
 }
 
-extern "C" size_t agcn_plan_bytes_for(const int32_t* n, int32_t B) {
+extern "C" size_t agcn_plan_bytes_for(const int32_t* n, int32_t B, int32_t row_stride) {
   if (B < 0 || !n) return 0;
-  int64_t ns = 0;
-  for (int32_t b = 0; b < B; ++b) ns += slabs_of(n[b] > 0 ? n[b] : 1);
-  return (size_t)layout_for(B, ns).total;
+  int64_t ns = 0, rows = 0;
+  for (int32_t b = 0; b < B; ++b) {
+    const int32_t nb = n[b] > 0 ? n[b] : 1;
+    ns += slabs_of(nb);
+    rows += row_stride > 0 ? row_stride : nb;
+  }
+  return (size_t)layout_for(B, ns, rows).total;
 }
 
 extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, void* plan_host,
@@ -63,7 +68,9 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
     if (n[b] > AGCN_MAX_NODES) return agcn::fail(AGCN_EINVAL, "agcn_plan_build: graph larger than AGCN_MAX_NODES");
     n_slabs += slabs_of(n[b]);
   }
-  const Layout l = layout_for(B, n_slabs);
+  int64_t rows_total = 0;
+  for (int32_t b = 0; b < B; ++b) rows_total += row_stride > 0 ? row_stride : n[b];
+  const Layout l = layout_for(B, n_slabs, rows_total);
   if (plan_bytes < (size_t)l.total) return agcn::fail(AGCN_ENOSPACE, "agcn_plan_build: plan buffer too small");
   char* base = static_cast<char*>(plan_host);
   std::memset(base, 0, (size_t)l.total);
@@ -74,6 +81,7 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
   int64_t* wtile_off = reinterpret_cast<int64_t*>(base + l.off_wtile_off);
   int32_t* slab_graph = reinterpret_cast<int32_t*>(base + l.off_slab_graph);
   int32_t* slab_row = reinterpret_cast<int32_t*>(base + l.off_slab_row);
+  int32_t* row_graph = reinterpret_cast<int32_t*>(base + l.off_row_graph);
 
   int64_t N1 = 0, N2 = 0, rows = 0, tiles = 0, wtiles = 0;
   int32_t max_n = 0;
@@ -85,6 +93,7 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
       return agcn::fail(AGCN_EINVAL, "agcn_plan_build: graph larger than row_stride (max_atom)");
     pn[b] = nb;
     row_off[b] = (int32_t)rows;
+    for (int64_t rr = rows; rr < rows + (row_stride > 0 ? row_stride : nb); ++rr) row_graph[rr] = b;
     tile_off[b] = tiles;
     wtile_off[b] = wtiles;
     rows += row_stride > 0 ? row_stride : nb;
@@ -127,6 +136,7 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
   info.n_slabs = (int32_t)n_slabs;
   info.off_slab_graph = l.off_slab_graph;
   info.off_slab_row = l.off_slab_row;
+  info.off_row_graph = l.off_row_graph;
   std::memcpy(base, &kMagic, sizeof(kMagic));
   std::memcpy(base + sizeof(kMagic), &info, sizeof(info));
   return AGCN_OK;
@@ -138,7 +148,7 @@ extern "C" int agcn_plan_info(const void* plan_host, AgcnPlanInfo* info) {
   std::memcpy(&magic, plan_host, sizeof(magic));
   if (magic != kMagic) return agcn::fail(AGCN_EPLAN, "agcn_plan_info: bad magic (not a plan blob)");
   std::memcpy(info, static_cast<const char*>(plan_host) + sizeof(kMagic), sizeof(*info));
-  if (info->B < 1 || info->n_slabs < info->B || info->plan_bytes != layout_for(info->B, info->n_slabs).total)
+  if (info->B < 1 || info->n_slabs < info->B || info->plan_bytes != layout_for(info->B, info->n_slabs, info->rows).total)
     return agcn::fail(AGCN_EPLAN, "agcn_plan_info: corrupt header");
   return AGCN_OK;
 }

@@ -64,9 +64,15 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
       ok = row - g * a.row_stride < a.n[g];
     }
     if (a.keep_pad && row < a.rows) ok = true;
+    if (ok && a.big_n > 0) ok = a.n[a.row_graph[row]] > a.big_n;   // mixed dispatch: big graphs only
     rowok[tid] = ok ? 1.f : 0.f;
   }
   __syncthreads();
+  if (a.big_n > 0) {   // nothing to do for a block without rows of big graphs
+    float any = 0.f;
+    for (int i = 0; i < BM; ++i) any += rowok[i];
+    if (any == 0.f) return;
+  }
 
   AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 0);
   f32x4 acc[NTW];
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
             const float v = (kk < kc) ? t[rr][cc] * ok : 0.f;
             if (MODE == RG_FILTER_BWD) {
               const int row = row_base + i;
-              if (kk < kc && row < a.rows && blockIdx.y == 0)
+              if (kk < kc && row < a.rows && blockIdx.y == 0 && (a.big_n == 0 || ok != 0.f))
                 a.Gp[(int64_t)row * Fout + k0 + kk] = v;   // masked upstream gradient, 0 on pad rows
             }
             As[i * ldA + kk] = v;
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int row = row_base + rg * 16 + q * 4 + i;
       if (row >= a.rows) continue;
+      if (a.big_n > 0 && rowok[rg * 16 + q * 4 + i] == 0.f) continue;   // row owned by another kernel
       float v = acc[j][i];
       if (MODE == RG_PROJECT) {
         a.Out0[(int64_t)row * a.ldo0 + c] = v;

@@ -52,6 +52,7 @@ struct SgcArgs {
   float* sv_r;     // [tile_elems]  r_ij = ||Z_i - Z_j||  (paper mode, forward -> backward)
   float* ws_dA;    // [tile_elems]  dA = -dR               (paper mode, bwd1 -> bwd2)
   float* ws_dd;    // [rows]        dd_j                   (paper mode, bwd1 -> bwd2)
+  int32_t pg_slab_base;  // mixed dispatch: slab s writes its partials at ws_pg[2 * (pg_slab_base + s)]
 };
 
 enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3, RG_DENSE = 4 };
@@ -71,6 +72,9 @@ struct RowsGemmArgs {
   float* Gp;                // RG_FILTER_BWD: [rows][Fout] masked upstream gradient
   const float* Add; int32_t ldadd;   // RG_DENSE: optional addend [rows][ldadd]
   int32_t keep_pad;         // RG_DENSE / RG_FILTER_BWD: 1 = pad rows are ordinary rows (DenseMol, dense_layer.py:42-50)
+  // mixed dispatch: only rows of graphs with more than big_n nodes are processed (0 = all rows)
+  int32_t big_n;
+  const int32_t* row_graph; // [rows]
   int32_t kc;               // K chunk staged in LDS (set by the launcher)
   int32_t nt;               // column tiles per workgroup (set by the launcher)
 };
@@ -113,9 +117,9 @@ int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds
 int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream);
 // fused per-graph SGC_LL (K = 2) for graphs whose whole working set fits LDS
 size_t fused_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
-int launch_fused_forward(const SgcArgs& a, int32_t count, size_t lds_bytes, void* stream);
+int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
 size_t fused_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
-int launch_fused_backward(const SgcArgs& a, int32_t count, size_t lds_bytes, void* stream);
+int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
 // slab-parallel SGC_LL (K = 2, packed rows, symmetric CSR L_orig)
 bool slab_path_fits(int32_t Fin);
 int launch_slab_forward(const SgcArgs& a, void* stream);

@@ -417,8 +417,12 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
   }
   const float da = block_sum(dalpha_part, red);
   if (tid == 0) {
-    a.ws_pg[2 * blockIdx.x + 0] = da;
-    a.ws_pg[2 * blockIdx.x + 1] = 0.f;
+    a.ws_pg[2 * (a.pg_slab_base + blockIdx.x) + 0] = da;
+    a.ws_pg[2 * (a.pg_slab_base + blockIdx.x) + 1] = 0.f;
+    if (a.pg_slab_base > 0 && c.i0 == 0) {   // mixed dispatch: this graph's per-graph slot stays 0
+      a.ws_pg[2 * c.b + 0] = 0.f;
+      a.ws_pg[2 * c.b + 1] = 0.f;
+    }
   }
 }
 
@@ -517,6 +521,7 @@ size_t lds_bwd2(int Fin) { return sizeof(float) * ((size_t)SH * CHP + (size_t)CH
 
 template <class K>
 int launch_slab(K kernel, const SgcArgs& a, size_t lds, int prof_id, const char* what, void* stream) {
+  if (a.n_slabs <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),

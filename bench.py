@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--mode", default="paper", choices=["paper", "reference"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="single-GPU diagnostic: build the global batch of an N-GPU run and time shard --shard of it")
+    ap.add_argument("--shard", type=int, default=0)
     ap.add_argument("--skip-other-mode", action="store_true",
                     help="profiling runs: do not also time the other laplacian_mode")
     args = ap.parse_args()
@@ -142,9 +145,10 @@ def main():
 
     Fin, Fout, K = 75, 64, 2
     B_global = args.batch * world
-    data = synth.tox21_batch(123, B_global, Fin)
-    shards = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(data["n"], Fin, Fout, K), world)
-    mine = shards[rank]
+    emu = args.shard_of if (world == 1 and args.shard_of > 1) else 0
+    data = synth.tox21_batch(123, args.batch * (emu or world), Fin)
+    shards = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(data["n"], Fin, Fout, K), emu or world)
+    mine = shards[args.shard if emu else rank]
     n = data["n"][mine]
     X = [data["X"][i] for i in mine]
     csr = [data["csr"][i] for i in mine]

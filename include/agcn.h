@@ -87,13 +87,14 @@ typedef struct AgcnPlanInfo {
   int32_t reserved1;
   int64_t off_slab_graph; /* int32 [n_slabs] graph id      */
   int64_t off_slab_row;   /* int32 [n_slabs] first row inside the graph */
+  int64_t off_row_graph;  /* int32 [rows]    owning graph of every row (pad rows included) */
 } AgcnPlanInfo;
 
 #define AGCN_SLAB_ROWS 16
 
 /* Bytes needed for a plan: worst case for B graphs / exact for the given node counts. */
 size_t agcn_plan_bytes(int32_t B);
-size_t agcn_plan_bytes_for(const int32_t* n, int32_t B);
+size_t agcn_plan_bytes_for(const int32_t* n, int32_t B, int32_t row_stride);
 
 /* Build a plan from host arrays.  n[B] = node counts (data_slice[:,0] /
  * lap_slice[:,0], graph_topology.py:90,98).  row_stride = 0 -> packed rows,
@@ -258,7 +259,9 @@ void agcn_set_lds_limit(int32_t bytes);
 int32_t agcn_get_slab_mode(void);
 void agcn_set_slab_mode(int32_t mode);
 /* 1 (default): batches of small graphs (the largest graph's X, M_L, W, n x n tile and Z^T fit
- * LDS) run SGC_LL K = 2 on the fused one-launch-per-direction kernels; 0: never. */
+ * LDS) run SGC_LL K = 2 on the fused one-launch-per-direction kernels; 0: never; 2: additionally,
+ * when only a few graphs are too large, run those on the slab kernels on a side stream next to the
+ * fused kernels ("mixed" dispatch; slower than the all-slab path at 256 graphs per GPU, hence opt-in). */
 int32_t agcn_get_fused_mode(void);
 void agcn_set_fused_mode(int32_t mode);
 

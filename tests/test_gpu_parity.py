@@ -118,7 +118,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["fused", "slab", "lds", "globaltile"])
+@pytest.mark.parametrize("path", ["fused", "mixed", "slab", "lds", "globaltile"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 @pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc", "reslap"])
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -127,11 +127,15 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     path: slab = slab-parallel kernels where eligible (SGC_LL, K = 2), lds = one workgroup per graph
     with the tile in LDS, globaltile = one workgroup per graph with the tile in global scratch."""
     ns, Fin, Fout, K = CASES[case]
-    if path in ("slab", "fused") and not (variant == orc.SGC_LL and K == 2):
+    if path in ("slab", "fused", "mixed") and not (variant == orc.SGC_LL and K == 2):
         pytest.skip("the slab and fused paths cover SGC_LL with K = 2 only")
-    amd._ffi.lib().agcn_set_lds_limit(0 if path == "globaltile" else 160 * 1024)
-    amd._ffi.lib().agcn_set_slab_mode(1 if path in ("slab", "fused") else 0)
-    amd._ffi.lib().agcn_set_fused_mode(1 if path == "fused" else 0)
+    if path == "mixed" and case != 0:
+        pytest.skip("mixed dispatch is exercised on the 75 -> 64 case (LDS limit chosen for it)")
+    # mixed: with a 110 KiB limit the n = 33 graph of case 0 does not fit the fused kernel (118 KiB) while
+    # the others do, so it runs on the slab kernels on the side stream, concurrently with the fused kernel
+    amd._ffi.lib().agcn_set_lds_limit({"globaltile": 0, "mixed": 110 * 1024}.get(path, 160 * 1024))
+    amd._ffi.lib().agcn_set_slab_mode(1 if path in ("slab", "fused", "mixed") else 0)
+    amd._ffi.lib().agcn_set_fused_mode({"fused": 1, "mixed": 2}.get(path, 0))
     try:
         rs, X, L0, csr, p, G = synth_case(1000 + case, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
         Lp = dLsum = None
@@ -145,6 +149,42 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
         amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
         amd._ffi.lib().agcn_set_slab_mode(1)
         amd._ffi.lib().agcn_set_fused_mode(1)
+
+
+def test_mixed_dispatch_full_batch(amd):
+    """Tox21-shaped B = 256 with an LDS limit that sends the ~10 largest graphs to the slab kernels on the
+    side stream: same results as the all-fused run (the two paths differ by reduction order only), and
+    bit-reproducible across runs (the concurrent streams write disjoint rows / tiles)."""
+    B, Fin, Fout, K = 256, 75, 64, 2
+    sb = orc.synth_batch(123, B)
+    p = orc.init_params(np.random.RandomState(1), Fin, Fout, K)
+    gb = amd.GraphBatch.from_arrays(sb["ns"], np.concatenate(sb["X"], 0), sb["csr"], DEV)
+    G = torch.randn(gb.plan.rows, Fout, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    lib = amd._ffi.lib()
+
+    def run():
+        layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, orc.PAPER, p, DEV)
+        Xt = gb.X.clone().requires_grad_(True)
+        nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+        (nodes.data * G).sum().backward()
+        torch.cuda.synchronize()
+        return [nodes.data.detach(), res_L.data, res_W.data, Xt.grad] + [layer.vars[k].grad for k in
+                                                                           ("weight", "bias", "M_L", "alpha")]
+
+    try:
+        ref = run()                                   # all fused
+        lib.agcn_set_fused_mode(2)                     # opt in to mixed dispatch
+        lib.agcn_set_lds_limit(118 * 1024)             # graphs with round16(n) >= 48 no longer fit
+        big = int((((sb["ns"] + 15) // 16) * 16 >= 48).sum())
+        assert 0 < big < 40, big
+        a = run()
+        b2 = run()
+        for x, y, z in zip(ref, a, b2):
+            assert torch.equal(y, z), "mixed dispatch must be reproducible"
+            assert_close(to_np(y), to_np(x), 5e-5, "mixed vs fused")
+    finally:
+        lib.agcn_set_lds_limit(160 * 1024)
+        lib.agcn_set_fused_mode(1)
 
 
 def test_slab_path_large_and_ragged(amd):
@@ -400,3 +440,37 @@ def test_simple_agcn_stack_packed(amd):
         g = tot["dX"]
     assert_close(to_np(Xt.grad), np.concatenate(g, 0), 2e-4, "stack dX")
     assert_close(to_np(layers[0].vars["M_L"].grad), tot["dM_L"], 2e-4, "stack dM_L (layer 1)")
+
+
+def test_modelnet_shaped_dense_adjacency(amd):
+    """BASELINE config[2]: point-cloud graph, N = 1024, DENSE original Laplacian (mean-distance threshold
+    adjacency, ~50 % dense), first layer 3 -> 64.  Goes through the global-tile per-graph kernels (dense
+    L_orig, tile far beyond LDS).  Checked against the oracle on the full tensors."""
+    n, Fin, Fout, K = 1024, 3, 64, 2
+    rs = np.random.RandomState(10)
+    pts = rs.uniform(-1, 1, size=(n, Fin)).astype(np.float32)          # unit-cube points (meshloader.py:34)
+    d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+    A = (d < d.mean()).astype(np.float64)                                # meshloader.py:264-285 threshold rule
+    np.fill_diagonal(A, 0)
+    adj = [list(np.nonzero(A[i])[0]) for i in range(n)]
+    _, _, _, L = orc.graph_laplacian(adj)
+    L32 = L.astype(np.float32)
+    p = orc.init_params(rs, Fin, Fout, K)
+    G = rs.randn(n, Fout).astype(np.float32)
+    plan = amd.Plan([n], 0, DEV)
+    gb = amd.GraphBatch(plan, torch.from_numpy(pts).to(DEV), l0_dense=torch.from_numpy(L32.reshape(-1)).to(DEV), l0_ld=0)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, 1, K, orc.PAPER, p, DEV)
+    Xt = gb.X.clone().requires_grad_(True)
+    nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+    (nodes.data * torch.from_numpy(G).to(DEV)).sum().backward()
+    caches = orc.layer_forward([pts], [L32], p, K, orc.PAPER, orc.SGC_LL)
+    tot = orc.layer_backward(caches, [G], p, K, orc.PAPER, orc.SGC_LL)
+    c = caches[0]
+    assert_close(to_np(nodes.data), c["Y"], 2e-5, "Y n=1024")
+    w = to_np(res_W[0])
+    assert_close(w, c["S"], FEATURE_RTOL, "res_W n=1024")
+    assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
+    assert_close(to_np(res_L[0]), c["R2"], 2e-5, "res_L n=1024")
+    assert_close(to_np(Xt.grad), tot["dX"][0], 1e-4, "dX n=1024")
+    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], 1e-4, "dweight n=1024")
+    assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], 2e-4, "dM_L n=1024")
