@@ -27,6 +27,7 @@ extern __device__ unsigned long long g_agcn_stamps[];
 namespace agcn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // packed fp32 math (v_pk_add_f32 / v_pk_fma_f32)
 
 // Exact x / d for x * d < 2^32 (d >= 1) by one mul-hi.
 struct FastDiv {

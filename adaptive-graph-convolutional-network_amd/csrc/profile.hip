@@ -22,7 +22,7 @@ const char* const kNames[PK_COUNT] = {
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   return e;
 }
 }  // namespace
@@ -32,13 +32,13 @@ bool prof_on() { return g_on; }
 void prof_begin(int id, void* stream) {
   if (!g_on) return;
   Rec r{id, get_event(), get_event()};
-  hipEventRecord(r.a, static_cast<hipStream_t>(stream));
+  (void)hipEventRecord(r.a, static_cast<hipStream_t>(stream));
   g_recs.push_back(r);
 }
 
 void prof_end(void* stream) {
   if (!g_on || g_recs.empty()) return;
-  hipEventRecord(g_recs.back().b, static_cast<hipStream_t>(stream));
+  (void)hipEventRecord(g_recs.back().b, static_cast<hipStream_t>(stream));
 }
 }  // namespace agcn
 
@@ -59,7 +59,7 @@ extern "C" int agcn_profile_collect(double* total_ms /* [PK_COUNT] */, int64_t* 
   for (Rec& r : g_recs) {
     if (hipEventSynchronize(r.b) != hipSuccess) return fail(AGCN_EDEVICE, "agcn_profile_collect: event sync failed");
     float ms = 0.f;
-    hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
     total_ms[r.id] += ms;
     calls[r.id] += 1;
     g_pool.push_back(r.a);
@@ -72,13 +72,13 @@ extern "C" int agcn_profile_collect(double* total_ms /* [PK_COUNT] */, int64_t* 
 #ifdef AGCN_STAMPS
 __device__ unsigned long long g_agcn_stamps[8 * 1024 * 16];
 extern "C" int agcn_debug_read_stamps(unsigned long long* out, size_t count, int clear) {
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   if (count > 8 * 1024 * 16) count = 8 * 1024 * 16;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_agcn_stamps), count * sizeof(unsigned long long)) != hipSuccess)
     return -3;
   if (clear) {
     static unsigned long long zeros[8 * 1024 * 16];
-    hipMemcpyToSymbol(HIP_SYMBOL(g_agcn_stamps), zeros, sizeof(zeros));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_agcn_stamps), zeros, sizeof(zeros));
   }
   return 0;
 }

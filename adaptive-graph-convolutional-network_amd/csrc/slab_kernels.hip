@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Fin = a.Fin, n = c.n;
   const bool paper = a.mode == AGCN_MODE_PAPER;
+  AGCN_STAMP(1, 0);
   float* Zit = smem;                 // [Fin][16]   slab rows, transposed
   float* Zjt = smem + Fin * SH;      // [Fin][CH1P] column chunk, transposed
   const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
       SH, Fin, [&](int ii, int f) { return Zg[(int64_t)(c.i0 + min(ii, c.nr - 1)) * Fin + f]; },
       [&](int ii, int f, float v) { Zit[f * SH + ii] = (ii < c.nr) ? v : 0.f; });
 
+  AGCN_STAMP(1, 1);
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < n; c0 += CH1) {
     const int nc = min(CH1, n - c0);
@@ -89,24 +91,26 @@ __global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
         nc, Fin, [&](int jj, int f) { return Zg[(int64_t)(c0 + jj) * Fin + f]; },
         [&](int jj, int f, float v) { Zjt[f * CH1P + jj] = v; });
     __syncthreads();
+    if (c0 == 0) AGCN_STAMP(1, 2);
     // rows 4*wave .. 4*wave+3  x  columns 2*lane, 2*lane+1 of the chunk
-    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    f32x2 pacc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const float* zi = Zit + 4 * wave;
     const float* zj = Zjt + 2 * lane;
 #pragma unroll 5
     for (int f = 0; f < Fin; ++f) {
-      const float4 u = *reinterpret_cast<const float4*>(zi + f * SH);
-      const float2 v = *reinterpret_cast<const float2*>(zj + f * CH1P);
-      float d;
-      d = u.x - v.x; acc[0][0] = fmaf(d, d, acc[0][0]);
-      d = u.x - v.y; acc[0][1] = fmaf(d, d, acc[0][1]);
-      d = u.y - v.x; acc[1][0] = fmaf(d, d, acc[1][0]);
-      d = u.y - v.y; acc[1][1] = fmaf(d, d, acc[1][1]);
-      d = u.z - v.x; acc[2][0] = fmaf(d, d, acc[2][0]);
-      d = u.z - v.y; acc[2][1] = fmaf(d, d, acc[2][1]);
-      d = u.w - v.x; acc[3][0] = fmaf(d, d, acc[3][0]);
-      d = u.w - v.y; acc[3][1] = fmaf(d, d, acc[3][1]);
+      // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two columns per instruction
+      const f32x4 u = *reinterpret_cast<const f32x4*>(zi + f * SH);
+      const f32x2 v = *reinterpret_cast<const f32x2*>(zj + f * CH1P);
+      const f32x2 d0 = (f32x2){u.x, u.x} - v, d1 = (f32x2){u.y, u.y} - v;
+      const f32x2 d2 = (f32x2){u.z, u.z} - v, d3 = (f32x2){u.w, u.w} - v;
+      pacc[0] = __builtin_elementwise_fma(d0, d0, pacc[0]);
+      pacc[1] = __builtin_elementwise_fma(d1, d1, pacc[1]);
+      pacc[2] = __builtin_elementwise_fma(d2, d2, pacc[2]);
+      pacc[3] = __builtin_elementwise_fma(d3, d3, pacc[3]);
     }
+    const float acc[4][2] = {{pacc[0].x, pacc[0].y}, {pacc[1].x, pacc[1].y}, {pacc[2].x, pacc[2].y},
+                             {pacc[3].x, pacc[3].y}};
+    if (c0 == 0) AGCN_STAMP(1, 3);
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int il = 4 * wave + di, i = c.i0 + il;
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
       }
     }
   }
+  AGCN_STAMP(1, 4);
   // degree of the slab's rows (S is bit-symmetric, so row sums == column sums), s = d^-1/2
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
   const int Fin = a.Fin, n = c.n;
   const int ldbx = ld_b(Fin);
   const int ntiles = (Fin + 15) >> 4;
+  AGCN_STAMP(6, 0);
   float* Ls = smem;                // [16][CHP]
   float* Xs = smem + SH * CHP;     // [CH][ldbx]
   const float alpha = a.alpha[0];
@@ -251,9 +257,12 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
   for (int c0 = 0; c0 < n; c0 += CH) {
     const int nc = min(CH, n - c0);
     if (c0 > 0) __syncthreads();
+    if (c0 == 0) AGCN_STAMP(6, 1);
     build_L_chunk<true>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1);
+    if (c0 == 0) AGCN_STAMP(6, 2);
     stage_rows_img(Xs, ldbx, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
     __syncthreads();
+    if (c0 == 0) AGCN_STAMP(6, 3);
     if (a.L_sum) {   // optional 4th output of SGC_LL: the combined Laplacian
 #pragma unroll
       for (int di = 0; di < 4; ++di) {
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
     }
     strip_gemm_rowmajor(acc, Ls, CHP, Xs, ldbx, (nc + 15) & ~15, ntiles);
   }
+  AGCN_STAMP(6, 4);
   // X_1[I] = L[I, :] X_0   (graphconv.py:231)
   float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * Fin;
   if (wave < ntiles) {

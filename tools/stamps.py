@@ -48,7 +48,7 @@ def main():
     st.step()
     lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
     s = buf.reshape(8, 1024, 16).astype(np.int64)
-    names = ["PROJECT", "graph_fwd", "FILTER", "FILTER_BWD", "graph_bwd", "PROJECT_BWD"]
+    names = ["PROJECT", "graph_fwd/slab_sim", "FILTER", "FILTER_BWD", "graph_bwd", "PROJECT_BWD", "slab_lap/DENSE", "slot7"]
     for k, nm in enumerate(names):
         blk = s[k]
         used = blk[:, 0] > 0
