@@ -51,11 +51,11 @@ int count_global(const PlanView& host, int32_t Fin, bool bwd) {
   return g;
 }
 
-// Slab-parallel kernels (slab_kernels.hip): SGC_LL, K = 2, packed rows, symmetric CSR L_orig.
+// Slab-parallel kernels (slab_kernels.hip): SGC_LL, K = 2, packed rows, symmetric L_orig (CSR or dense).
 bool use_slabs(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
   if (agcn_get_slab_mode() == 0) return false;
-  return d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
-         g->L0_dense == nullptr && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
+  return d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 &&
+         (g->L0_rowptr != nullptr || g->L0_dense != nullptr) && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
 }
 
 // Fused per-graph kernels (fused_kernels.hip): SGC_LL, K = 2, packed rows, CSR L_orig, for the graphs

@@ -164,13 +164,18 @@ __device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c
   const bool cv = lane < nc;
   float sj = 0.f;
   if (FWD && paper) sj = a.sv_s[c.row0 + min(j, n - 1)];
-  float v[4];
+  // dense L_orig feed (graph_topology.py:93-103: [max_atom, max_atom] per graph): read with the tile
+  const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+  const float* L0d = !a.L0_dense ? nullptr
+                                 : (a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff);
+  float v[4], l0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
     const int il = 4 * wave + di, i = c.i0 + il;
     const int64_t o = c.toff + (int64_t)min(i, n - 1) * n + min(j, n - 1);
     if (FWD) v[di] = paper ? a.res_W[o] : 0.f;
     else v[di] = a.res_L[o];
+    if (L0d) l0[di] = L0d[(int64_t)min(i, n - 1) * l0ld + min(j, n - 1)];
   }
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
@@ -183,11 +188,11 @@ __device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c
       L = lrelu(R, alpha);                       // (R * 1.0f: the clip scale is exactly 1)
       if (ok) a.res_L[c.toff + (int64_t)i * n + j] = L;
     }
-    Ls[il * CHP + lane] = ok ? L : 0.f;
+    Ls[il * CHP + lane] = ok ? L + l0[di] : 0.f;
   }
   __syncthreads();
   // + L_orig rows of the slab (CSR, one thread per row)
-  if (tid < c.nr) {
+  if (!L0d && tid < c.nr) {
     for (int p = csr_p0; p < csr_p1; p += 4) {
       int cc[4];
       float vv[4];
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
 #pragma unroll
   for (int di = 0; di < 4; ++di) si[di] = a.sv_s[c.row0 + c.i0 + min(4 * wave + di, c.nr - 1)];
   int csr_p0 = 0, csr_p1 = 0;
-  if (tid < c.nr) {
+  if (a.L0_rowptr && tid < c.nr) {
     csr_p0 = a.L0_rowptr[c.row0 + c.i0 + tid];
     csr_p1 = a.L0_rowptr[c.row0 + c.i0 + tid + 1];
   }
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
 #pragma unroll
   for (int di = 0; di < 4; ++di) si[di] = paper ? a.sv_s[c.row0 + c.i0 + min(4 * wave + di, c.nr - 1)] : 0.f;
   int csr_p0 = 0, csr_p1 = 0;
-  if (tid < c.nr) {
+  if (a.L0_rowptr && tid < c.nr) {
     csr_p0 = a.L0_rowptr[c.row0 + c.i0 + tid];
     csr_p1 = a.L0_rowptr[c.row0 + c.i0 + tid + 1];
   }

@@ -200,6 +200,36 @@ def test_slab_path_large_and_ragged(amd):
             assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
 
 
+def test_slab_path_dense_laplacian_feed(amd):
+    """Equal-size graphs in the reference's padded feed (max_atom == n, dense [max_atom, max_atom] Laplacians,
+    graph_topology.py:92-98) are eligible for the slab kernels, which then read L_orig with the tile instead
+    of scattering CSR rows.  Same oracle parity; outputs bit-identical to the CSR feed of the same batch."""
+    ns, Fin, Fout, K = [150] * 3, 24, 16, 2
+    lib = amd._ffi.lib()
+    lib.agcn_set_fused_mode(0)
+    try:
+        for mode in (orc.REFERENCE, orc.PAPER):
+            rs, X, L0, csr, p, G = synth_case(11, ns, Fin, Fout, K, orc.SGC_LL)
+            caches, tot = oracle_run(X, L0, p, K, mode, orc.SGC_LL, G)
+            ref = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, orc.SGC_LL)
+            ds = np.stack([np.asarray(ns), -np.ones(len(ns))], 1).astype(np.int32)
+            gb = amd.GraphBatch.from_padded(torch.from_numpy(np.stack(X)).to(DEV),
+                                            torch.from_numpy(np.stack(L0).astype(np.float32)).to(DEV), ds, DEV)
+            assert gb.l0_symmetric and gb.plan.rows == sum(ns)
+            layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, mode, p, DEV)
+            Xt = gb.X.clone().requires_grad_(True)
+            nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+            (nodes.data * torch.from_numpy(np.concatenate(G, 0)).to(DEV)).sum().backward()
+            assert np.array_equal(to_np(nodes.data), np.concatenate(ref["Y"]))
+            assert np.array_equal(to_np(Xt.grad), np.concatenate(ref["dX"]))
+            assert np.array_equal(to_np(layer.vars["weight"].grad), ref["dweight"])
+            for b in range(len(ns)):
+                assert np.array_equal(to_np(res_L[b]), ref["res_L"][b])
+            compare_with_oracle(ref, caches, tot, orc.SGC_LL, mode, K, has_prev=False)
+    finally:
+        lib.agcn_set_fused_mode(1)
+
+
 def test_reslap_without_prev(amd):
     ns, Fin, Fout, K = [6, 9, 14], 8, 6, 2
     for mode in (orc.REFERENCE, orc.PAPER):
@@ -442,10 +472,12 @@ def test_simple_agcn_stack_packed(amd):
     assert_close(to_np(layers[0].vars["M_L"].grad), tot["dM_L"], 2e-4, "stack dM_L (layer 1)")
 
 
-def test_modelnet_shaped_dense_adjacency(amd):
+@pytest.mark.parametrize("symmetric", [True, False], ids=["slab", "globaltile"])
+def test_modelnet_shaped_dense_adjacency(amd, symmetric):
     """BASELINE config[2]: point-cloud graph, N = 1024, DENSE original Laplacian (mean-distance threshold
-    adjacency, ~50 % dense), first layer 3 -> 64.  Goes through the global-tile per-graph kernels (dense
-    L_orig, tile far beyond LDS).  Checked against the oracle on the full tensors."""
+    adjacency, ~50 % dense), first layer 3 -> 64.  With the caller's symmetry guarantee the batch takes the
+    slab-parallel kernels (dense L_orig read with the tile); without it the global-tile per-graph kernels
+    (tile far beyond LDS).  Checked against the oracle on the full tensors."""
     n, Fin, Fout, K = 1024, 3, 64, 2
     rs = np.random.RandomState(10)
     pts = rs.uniform(-1, 1, size=(n, Fin)).astype(np.float32)          # unit-cube points (meshloader.py:34)
@@ -458,7 +490,8 @@ def test_modelnet_shaped_dense_adjacency(amd):
     p = orc.init_params(rs, Fin, Fout, K)
     G = rs.randn(n, Fout).astype(np.float32)
     plan = amd.Plan([n], 0, DEV)
-    gb = amd.GraphBatch(plan, torch.from_numpy(pts).to(DEV), l0_dense=torch.from_numpy(L32.reshape(-1)).to(DEV), l0_ld=0)
+    gb = amd.GraphBatch(plan, torch.from_numpy(pts).to(DEV), l0_dense=torch.from_numpy(L32.reshape(-1)).to(DEV), l0_ld=0,
+                        l0_symmetric=symmetric)
     layer = make_layer(amd, orc.SGC_LL, Fout, Fin, 1, K, orc.PAPER, p, DEV)
     Xt = gb.X.clone().requires_grad_(True)
     nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})

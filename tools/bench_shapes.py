@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Secondary workloads of SURVEY.md §8(d) / BASELINE.json `configs`, same protocol as bench.py
+(inputs resident, HIP-graph replay, wall clock around K steps bracketed by synchronize):
+
+  tox21-l1 / l2 / l3 / l4 : the four SimpleAGCN layer shapes 75->64, 64->128, 128->128, 128->64 at B=256
+  tox21-2048              : 75->64 at B=2048 (config[3] on one GPU)
+  modelnet-3-64 / 64-128  : B graphs of n=1024 points, dense original Laplacian (config[2])
+  stack                   : 4 x SGC_LL -> DenseMol 64->256 -> GraphGatherMol(tanh), autograd, eager launches
+
+One JSON line per workload; `--prof` adds the library's per-kernel HIP-event averages.
+Not part of the driver contract (bench.py is); results are copied into profiles/."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, steps, warmup, dev):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+def kernel_profile(amd, fn, steps, dev):
+    lib = amd._ffi.lib()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(dev)
+    lib.agcn_profile_enable(1)
+    for _ in range(steps):
+        fn()
+    prof = amd._ffi.profile_collect()
+    lib.agcn_profile_enable(0)
+    return {k: round(1e3 * ms / c, 2) for k, (ms, c) in prof.items() if c > 0}   # us per launch
+
+
+def flops_layer(n, Fin, Fout, K, paper):
+    """SURVEY.md §8(d) flop model."""
+    n = np.asarray(n, np.float64)
+    N1, N2 = n.sum(), (n * n).sum()
+    fwd = 2 * N1 * Fin * Fin + (3 * Fin + 10) * N2 + 2 * (K - 1) * N2 * Fin + 2 * N1 * K * Fin * Fout
+    bwd = 2 * (2 * N1 * K * Fin * Fout) + 2 * (2 * (K - 1) * N2 * Fin)
+    if paper:
+        bwd += 4 * N2 * Fin + 4 * N1 * Fin * Fin
+    return fwd + bwd
+
+
+def bytes_layer(n, nnz, Fin, Fout, K, dense_l0):
+    n = np.asarray(n, np.float64)
+    N1, N2, B = n.sum(), (n * n).sum(), len(n)
+    P = Fin * Fin + K * Fin * Fout + Fout + 1
+    Lb = 4 * N2 if dense_l0 else 8 * nnz + 4 * (N1 + B)
+    fwd = 4 * N1 * Fin + Lb + 4 * N1 * Fout + 8 * N2 + 4 * P
+    bwd = 4 * N1 * Fout + 4 * N1 * Fin + Lb + 4 * N1 * Fin + 8 * P
+    return fwd + bwd
+
+
+def modelnet_batch(amd, B, n, Fin, dev, seed=10):
+    """Unit-cube point clouds, mean-distance-threshold adjacency (utils/meshloader.py:264-285), dense feed."""
+    rs = np.random.RandomState(seed)
+    Xs, Ls = [], []
+    for _ in range(B):
+        pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        A = d < d.mean()
+        np.fill_diagonal(A, False)
+        adj = [np.nonzero(A[i])[0].tolist() for i in range(n)]
+        ip, ix, val = amd.laplacian_csr(adj)
+        L = np.zeros((n, n), np.float32)
+        rows = np.repeat(np.arange(n), np.diff(ip))
+        L[rows, ix] = val.astype(np.float32)
+        Ls.append(L)
+        Xs.append(pts if Fin == 3 else np.maximum(rs.randn(n, Fin), 0).astype(np.float32))
+    ds = np.stack([np.full(B, n), np.full(B, -1)], 1).astype(np.int32)
+    X3 = torch.from_numpy(np.stack(Xs)).to(dev)
+    L3 = torch.from_numpy(np.stack(Ls)).to(dev)
+    return amd.GraphBatch.from_padded(X3, L3, ds, dev), np.full(B, n, np.int32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="paper", choices=["paper", "reference"])
+    ap.add_argument("--only", default="", help="comma list of workload names")
+    ap.add_argument("--modelnet-batch", type=int, default=8)
+    ap.add_argument("--prof", action="store_true")
+    args = ap.parse_args()
+    import agcn_amd as amd
+    from agcn_amd import synth
+
+    dev = torch.device("cuda", 0)
+    amd._ffi.lib()
+    only = set(x for x in args.only.split(",") if x)
+    K = 2
+
+    def want(name):
+        return not only or name in only
+
+    def run_layer(name, gb, n, nnz, Fin, Fout, dense):
+        p = synth.glorot_params(np.random.RandomState(123), Fin, Fout, K)
+        layer = amd.SGC_LL(Fout, Fin, len(n), K=K, laplacian_mode=args.mode, device=dev)
+        layer.load_vars(p)
+        dY = torch.from_numpy(np.random.RandomState(7).randn(gb.plan.rows, Fout).astype(np.float32)).to(dev)
+        st = amd.SgcLLStep(layer, gb, dY=dY)
+        st.capture()
+        t = timed(st.replay, args.steps, args.warmup, dev)
+        fl = flops_layer(n, Fin, Fout, K, args.mode == "paper")
+        by = bytes_layer(n, nnz, Fin, Fout, K, dense)
+        out = {"workload": name, "mode": args.mode, "graphs": int(len(n)), "N1": int(np.sum(n)),
+               "N2": int(np.sum(np.asarray(n, np.int64) ** 2)), "Fin": Fin, "Fout": Fout,
+               "us_per_step": round(t * 1e6, 2), "graphs_per_s": round(len(n) / t, 1),
+               "algorithmic_GB_s": round(by / t / 1e9, 1), "algorithmic_TFLOP_s": round(fl / t / 1e12, 3)}
+        if args.prof:
+            out["kernel_us"] = kernel_profile(amd, st.step, 20, dev)
+        print(json.dumps(out), flush=True)
+
+    shapes = [("tox21-l1", 75, 64), ("tox21-l2", 64, 128), ("tox21-l3", 128, 128), ("tox21-l4", 128, 64)]
+    for name, Fin, Fout in shapes:
+        if not want(name):
+            continue
+        data = synth.tox21_batch(123, 256, Fin)
+        gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
+        run_layer(name, gb, data["n"], sum(len(c[1]) for c in data["csr"]), Fin, Fout, False)
+
+    if want("tox21-2048"):
+        data = synth.tox21_batch(123, 2048, 75)
+        gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
+        run_layer("tox21-2048", gb, data["n"], sum(len(c[1]) for c in data["csr"]), 75, 64, False)
+
+    for name, Fin, Fout in (("modelnet-3-64", 3, 64), ("modelnet-64-128", 64, 128)):
+        if not want(name):
+            continue
+        gb, n = modelnet_batch(amd, args.modelnet_batch, 1024, Fin, dev)
+        run_layer(name, gb, n, 0, Fin, Fout, True)
+
+    if want("stack"):
+        data = synth.tox21_batch(123, 256, 75)
+        B = len(data["n"])
+        gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
+        rs = np.random.RandomState(123)
+        layers, fin = [], 75
+        for w in (64, 128, 128, 64):
+            lay = amd.SGC_LL(w, fin, B, K=K, laplacian_mode=args.mode, device=dev)
+            lay.load_vars(synth.glorot_params(rs, fin, w, K))
+            layers.append(lay)
+            fin = w
+        dense = amd.DenseMol(256, fin, device=dev)
+        dense.build(dev)
+        gather = amd.GraphGatherMol(B, activation="tanh")
+        G = torch.from_numpy(rs.randn(B, 256).astype(np.float32)).to(dev)
+        params = [v for lay in layers for v in lay.vars.values()] + dense.parameters()
+
+        def step():
+            for q in params:
+                q.grad = None
+            h = gb.X
+            for lay in layers:
+                h, _, _ = lay({"node_features": h, "graph_batch": gb})
+            h = dense({"node_features": h, "graph_batch": gb})
+            out = gather({"node_features": h, "graph_batch": gb})
+            out.backward(G)
+
+        t = timed(step, args.steps, args.warmup, dev)
+        out = {"workload": "stack 75-64-128-128-64 + DenseMol 256 + GraphGather, autograd eager",
+               "mode": args.mode, "graphs": B, "us_per_step": round(t * 1e6, 2),
+               "graphs_per_s": round(B / t, 1)}
+        if args.prof:
+            out["kernel_us"] = kernel_profile(amd, step, 10, dev)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
