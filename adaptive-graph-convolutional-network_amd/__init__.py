@@ -7,7 +7,8 @@ from . import _build, _ffi  # noqa: F401
 from ._ffi import AgcnError  # noqa: F401
 from .batch import GraphBatch, Plan, RowViews, TileViews  # noqa: F401
 from .graph_structure import Graph, MolGraph, laplacian_csr  # noqa: F401
-from .layers import SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, GraphPoolMol, Layer  # noqa: F401
+from .layers import (SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, DenseBlockEnd, GraphPoolMol,  # noqa: F401
+                     MultitaskHead, Layer)
 from .engine import SgcLLStep  # noqa: F401
 from . import dist  # noqa: F401
 

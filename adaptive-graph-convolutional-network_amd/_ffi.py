@@ -64,6 +64,8 @@ SYMBOLS = [
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
+    "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
+    "agcn_multitask_ce_workspace_bytes", "agcn_multitask_ce_forward", "agcn_multitask_ce_backward",
     "agcn_graph_pool_forward", "agcn_graph_pool_backward",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
     "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
@@ -104,6 +106,16 @@ def _declare(lib):
     lib.agcn_rows_dense_backward_workspace_bytes.argtypes = [C.POINTER(DenseDesc), P]
     lib.agcn_rows_dense_backward.restype = C.c_int
     lib.agcn_rows_dense_backward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P, P, P, SZ, P]
+    lib.agcn_rows_dense_scaled_forward.restype = C.c_int
+    lib.agcn_rows_dense_scaled_forward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P]
+    lib.agcn_rows_dense_scaled_backward.restype = C.c_int
+    lib.agcn_rows_dense_scaled_backward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]
+    lib.agcn_multitask_ce_workspace_bytes.restype = SZ
+    lib.agcn_multitask_ce_workspace_bytes.argtypes = [I32, I32, I32]
+    lib.agcn_multitask_ce_forward.restype = C.c_int
+    lib.agcn_multitask_ce_forward.argtypes = [I32, I32, I32, P, I32, P, P, P, P, C.c_float, P, P, P, SZ, P]
+    lib.agcn_multitask_ce_backward.restype = C.c_int
+    lib.agcn_multitask_ce_backward.argtypes = [I32, I32, I32, P, I32, P, P, P, P, C.c_float, P, P, P, P, P, SZ, P]
     lib.agcn_graph_pool_forward.restype = C.c_int
     lib.agcn_graph_pool_forward.argtypes = [P, P, C.POINTER(GraphBatch), P, I32, I32, P, P, P]
     lib.agcn_graph_pool_backward.restype = C.c_int

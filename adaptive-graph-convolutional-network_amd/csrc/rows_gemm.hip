@@ -7,8 +7,9 @@
 //                        (A column j = f*K + k is X_k[:, f]: the interleaved concat is never built)
 //   RG_FILTER_BWD   [g_0|g_1|..] = (dY . act'(Y)) . W^T            adjoint of the above; also emits Gp
 //   RG_PROJECT_BWD  dX += dZ . M_L^T                               adjoint of RG_PROJECT (paper mode)
-//   RG_DENSE        Y  = act(A . W [+ b] [+ Add])                  DenseMol (dense_layer.py:33-50, bias also on pad
-//                                                                  rows) and BlockEnd (blockend.py:67-86, x + x_res . W)
+//   RG_DENSE        Y  = act([s *] A . W [+ b] [+ Add])            DenseMol (dense_layer.py:33-50, bias also on pad
+//                                                                  rows), BlockEnd (blockend.py:67-86, x + x_res . W) and
+//                                                                  one term of DenseBlockEnd (densenet_block.py:113-123)
 //
 // Workgroup = 1024 threads on 64 rows x up to 192 columns: all 16 waves stage the operands (the
 // whole K extent, or the largest chunk that fits LDS, with 8 independent loads in flight per
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
     const int c = col_base + 16 * (cg + ncg * j) + r;
     if (c >= N) continue;
     const float bias_c = (MODE == RG_FILTER || (MODE == RG_DENSE && a.bias)) ? a.bias[c] : 0.f;
+    const float scale = ((MODE == RG_DENSE || MODE == RG_FILTER_BWD) && a.scale) ? a.scale[0] : 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row_base + rg * 16 + q * 4 + i;
@@ -217,12 +219,14 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
         v = v * rowok[rg * 16 + q * 4 + i];   // tf.pad rows (graphconv.py:249-250)
         a.Out0[(int64_t)row * a.ldo0 + c] = v;
       } else if (MODE == RG_DENSE) {
+        if (a.scale) v = v * scale;            // (x_res . W) * beta, then + x  (densenet_block.py:116,122)
         if (a.bias) v = v + bias_c;
         if (a.Add) v = v + a.Add[(int64_t)row * a.ldadd + c];
         if (relu) v = fmaxf(v, 0.f);
         v = v * rowok[rg * 16 + q * 4 + i];
         a.Out0[(int64_t)row * a.ldo0 + c] = v;
       } else if (MODE == RG_FILTER_BWD) {
+        if (a.scale) v = v * scale;
         const int f = (int)dK.div((uint32_t)c), kx = c - f * K;   // column f*K + k: adjoint of X_k[:, f]
         if (kx == 0) a.Out0[(int64_t)row * a.ldo0 + f] = v;
         else a.Out1[(int64_t)(kx - 1) * a.o1_plane + (int64_t)row * Fin + f] = v;

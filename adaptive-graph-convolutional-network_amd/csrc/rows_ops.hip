@@ -48,6 +48,18 @@ size_t carve_dense(const AgcnDenseDesc* d, const AgcnPlanInfo& pi, void* ws, boo
   return off;
 }
 
+// ds = sum_e W[e] U[e] (per-thread sequential partial + fixed tree), then U <- s U in place.
+__global__ __launch_bounds__(1024) void dense_scale_grad_kernel(const float* W, const float* scale, float* U,
+                                                                float* dscale, int total) {
+  __shared__ float red[32];
+  const float s = scale[0];
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < total; e += 1024) acc += W[e] * U[e];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) dscale[0] = acc;
+  for (int e = threadIdx.x; e < total; e += 1024) U[e] = s * U[e];
+}
+
 // ---- GraphPoolMol ---------------------------------------------------------------------------------------
 struct PoolArgs {
   const int32_t *n, *row_off;
@@ -136,6 +148,13 @@ using namespace agcn;
 extern "C" int agcn_rows_dense_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                                        const float* X, const float* W, const float* bias, const float* Add,
                                        float* Y, void* hip_stream) {
+  return agcn_rows_dense_scaled_forward(desc, plan_host, plan_dev, X, W, nullptr, bias, Add, Y, hip_stream);
+}
+
+extern "C" int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const void* plan_host,
+                                              const void* plan_dev, const float* X, const float* W,
+                                              const float* scale, const float* bias, const float* Add, float* Y,
+                                              void* hip_stream) {
   const char* who = "agcn_rows_dense_forward";
   int rc = check_dense(desc, who);
   if (rc != AGCN_OK) return rc;
@@ -148,7 +167,7 @@ extern "C" int agcn_rows_dense_forward(const AgcnDenseDesc* desc, const void* pl
   RowsGemmArgs g;
   fill_rows_dense(g, desc, host, dev);
   g.Kd = desc->Fin; g.N = desc->Fout;
-  g.A0 = X; g.lda0 = desc->ldx; g.Bm = W; g.bias = bias; g.Add = Add; g.ldadd = desc->ldadd;
+  g.A0 = X; g.lda0 = desc->ldx; g.Bm = W; g.bias = bias; g.Add = Add; g.ldadd = desc->ldadd; g.scale = scale;
   g.Out0 = Y; g.ldo0 = desc->ldy;
   return launch_rows_gemm(g, RG_DENSE, hip_stream);
 }
@@ -161,12 +180,24 @@ extern "C" size_t agcn_rows_dense_backward_workspace_bytes(const AgcnDenseDesc* 
   return carve_dense(desc, pi, nullptr, true, &w) + 256;
 }
 
-// dX = Gp . W^T, dW = A^T Gp, dbias = colsum(Gp), dAdd = Gp, with Gp = dY . act'(Y).
 extern "C" int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                                         const float* X, const float* W, const float* Y, const float* dY,
                                         float* dX, float* dAdd, float* dW, float* dbias, void* workspace,
                                         size_t workspace_bytes, void* hip_stream) {
+  return agcn_rows_dense_scaled_backward(desc, plan_host, plan_dev, X, W, nullptr, Y, dY, dX, dAdd, dW, dbias,
+                                         nullptr, workspace, workspace_bytes, hip_stream);
+}
+
+// dX = s Gp . W^T, dW = s A^T Gp, dbias = colsum(Gp), dAdd = Gp, ds = <W, A^T Gp>, with Gp = dY . act'(Y)
+// and s = scale[0] (1 when scale is NULL).
+extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const void* plan_host,
+                                               const void* plan_dev, const float* X, const float* W,
+                                               const float* scale, const float* Y, const float* dY, float* dX,
+                                               float* dAdd, float* dW, float* dbias, float* dscale,
+                                               void* workspace, size_t workspace_bytes, void* hip_stream) {
   const char* who = "agcn_rows_dense_backward";
+  if ((scale == nullptr) != (dscale == nullptr))
+    return fail(AGCN_EINVAL, "%s: scale and dscale go together", who);
   int rc = check_dense(desc, who);
   if (rc != AGCN_OK) return rc;
   if (!X || !W || !Y || !dY || !dX || !dW) return fail(AGCN_EINVAL, "%s: null tensor", who);
@@ -183,7 +214,7 @@ extern "C" int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* p
   fill_rows_dense(g, desc, host, dev);
   g.Kd = desc->Fout; g.N = desc->Fin;
   g.A0 = dY; g.lda0 = desc->ldy; g.Yact = Y; g.ldy = desc->ldy; g.Bm = W;
-  g.Out0 = dX; g.ldo0 = desc->ldx; g.Gp = Gp;
+  g.Out0 = dX; g.ldo0 = desc->ldx; g.Gp = Gp; g.scale = scale;
   rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
   if (rc != AGCN_OK) return rc;
 
@@ -195,7 +226,14 @@ extern "C" int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* p
   pa.B = 0; pa.part_stride = w.part_stride;
   pa.X = X; pa.Gp = Gp; pa.part = w.part;
   pa.dweight = dW; pa.dbias = dbias ? dbias : w.dbias;
-  return launch_param_grads(pa, hip_stream);
+  rc = launch_param_grads(pa, hip_stream);
+  if (rc != AGCN_OK || !scale) return rc;
+  // dW holds U = A^T Gp: ds = <W, U>, then dW = s U  (one workgroup, fixed order)
+  hipLaunchKernelGGL(dense_scale_grad_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(hip_stream), W, scale,
+                     dW, dscale, desc->Fin * desc->Fout);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: %s", who, hipGetErrorString(e));
+  return AGCN_OK;
 }
 
 static int pool_args(PoolArgs& a, const void* plan_host, const void* plan_dev, const AgcnGraphBatch* lap,

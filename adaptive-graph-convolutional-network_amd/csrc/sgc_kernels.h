@@ -71,6 +71,7 @@ struct RowsGemmArgs {
   float* Out1; int64_t o1_plane;
   float* Gp;                // RG_FILTER_BWD: [rows][Fout] masked upstream gradient
   const float* Add; int32_t ldadd;   // RG_DENSE: optional addend [rows][ldadd]
+  const float* scale;       // RG_DENSE / RG_FILTER_BWD: optional device scalar on the product (DenseBlockEnd's beta)
   int32_t keep_pad;         // RG_DENSE / RG_FILTER_BWD: 1 = pad rows are ordinary rows (DenseMol, dense_layer.py:42-50)
   // mixed dispatch: only rows of graphs with more than big_n nodes are processed (0 = all rows)
   int32_t big_n;

@@ -163,11 +163,12 @@ class GraphGatherFunction(torch.autograd.Function):
 
 
 class RowsDenseFunction(torch.autograd.Function):
-    """Y = act(A . W [+ bias] [+ Add]) over the row space: DenseMol (dense_layer.py:33-50) and
-    BlockEnd (blockend.py:67-86)."""
+    """Y = act([scale *] A . W [+ bias] [+ Add]) over the row space: DenseMol (dense_layer.py:33-50),
+    BlockEnd (blockend.py:67-86) and, with the device scalar `scale`, one term of DenseBlockEnd
+    (densenet_block.py:113-123)."""
 
     @staticmethod
-    def forward(ctx, A, W, bias, Add, batch, activation, keep_pad_rows):
+    def forward(ctx, A, W, bias, Add, batch, activation, keep_pad_rows, scale=None):
         lib = _ffi.lib()
         _require_gpu(A, "node features")
         A, W = _f32c(A, "node features"), _f32c(W, "weight")
@@ -181,18 +182,29 @@ class RowsDenseFunction(torch.autograd.Function):
             Add = _f32c(Add, "Add")
             if tuple(Add.shape) != (plan.rows, Fout):
                 raise ValueError("Add must be [rows, Fout]")
+        if scale is not None:
+            scale = _f32c(scale, "scale")
+            if scale.numel() != 1:
+                raise ValueError("scale must hold one element")
         Y = torch.empty((plan.rows, Fout), dtype=torch.float32, device=A.device)
         desc = _ffi.DenseDesc(Fin, Fout, _ffi.ACT[activation], 1 if keep_pad_rows else 0, A.shape[1], Fout, Fout, 0)
-        _ffi.check(lib.agcn_rows_dense_forward(C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(), W.data_ptr(),
-                                               _ptr(bias), _ptr(Add), Y.data_ptr(), _stream(A.device)))
+        _ffi.check(lib.agcn_rows_dense_scaled_forward(C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(),
+                                                      W.data_ptr(), _ptr(scale), _ptr(bias), _ptr(Add), Y.data_ptr(),
+                                                      _stream(A.device)))
         ctx.batch, ctx.desc, ctx.has_bias, ctx.has_add = batch, desc, bias is not None, Add is not None
-        ctx.save_for_backward(A, W, Y)
+        ctx.has_scale = scale is not None
+        if scale is not None:
+            ctx.save_for_backward(A, W, Y, scale)
+        else:
+            ctx.save_for_backward(A, W, Y)
         return Y
 
     @staticmethod
     def backward(ctx, dY):
         lib = _ffi.lib()
-        A, W, Y = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        A, W, Y = saved[:3]
+        scale = saved[3] if ctx.has_scale else None
         plan, desc = ctx.batch.plan, ctx.desc
         dY = _f32c(dY, "dY")
         dA = torch.empty_like(A)
@@ -201,12 +213,66 @@ class RowsDenseFunction(torch.autograd.Function):
         dW = torch.empty_like(W)
         db = torch.empty(desc.Fout, dtype=torch.float32, device=A.device) if ctx.has_bias else None
         dAdd = torch.empty((plan.rows, desc.Fout), dtype=torch.float32, device=A.device) if ctx.has_add else None
+        ds = torch.empty_like(scale) if scale is not None else None
         wbytes = lib.agcn_rows_dense_backward_workspace_bytes(C.byref(desc), plan.host_ptr)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=A.device)
-        _ffi.check(lib.agcn_rows_dense_backward(C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(), W.data_ptr(),
-                                                Y.data_ptr(), dY.data_ptr(), dA.data_ptr(), _ptr(dAdd), dW.data_ptr(),
-                                                _ptr(db), ws.data_ptr(), wbytes, _stream(A.device)))
-        return dA, dW, db, dAdd, None, None, None
+        _ffi.check(lib.agcn_rows_dense_scaled_backward(
+            C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(), W.data_ptr(), _ptr(scale), Y.data_ptr(),
+            dY.data_ptr(), dA.data_ptr(), _ptr(dAdd), dW.data_ptr(), _ptr(db), _ptr(ds), ws.data_ptr(), wbytes,
+            _stream(A.device)))
+        return dA, dW, db, dAdd, None, None, None, ds
+
+
+class MultitaskCEFunction(torch.autograd.Function):
+    """T two-class heads + the weighted sigmoid cross-entropy training loss
+    (model_operatos.py:710-759,792-864; multitask_classifier.py:41-44,187-209).
+    Returns (loss [1], logits [T, B, 2]); the gradient flows through the loss only."""
+
+    @staticmethod
+    def forward(ctx, feat, W, bias, labels, weights, batch_size):
+        lib = _ffi.lib()
+        _require_gpu(feat, "graph features")
+        feat, W, bias = _f32c(feat, "graph features"), _f32c(W, "head weights"), _f32c(bias, "head biases")
+        labels, weights = _f32c(labels, "labels"), _f32c(weights, "weights")
+        T, F = W.shape[0], W.shape[1]
+        B = feat.shape[0]
+        if feat.dim() != 2 or feat.shape[1] < F or tuple(W.shape) != (T, F, 2) or tuple(bias.shape) != (T, 2):
+            raise ValueError("feat [B, >=F], W [T, F, 2], bias [T, 2] expected")
+        if tuple(labels.shape) != (B, T) or tuple(weights.shape) != (B, T):
+            raise ValueError("labels and weights must be [B, T]")
+        dev = feat.device
+        logits = torch.empty((T, B, 2), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        wbytes = lib.agcn_multitask_ce_workspace_bytes(B, F, T)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        inv = 1.0 / float(batch_size)
+        _ffi.check(lib.agcn_multitask_ce_forward(B, F, T, feat.data_ptr(), feat.shape[1], W.data_ptr(), bias.data_ptr(),
+                                                 labels.data_ptr(), weights.data_ptr(), inv, logits.data_ptr(),
+                                                 loss.data_ptr(), ws.data_ptr(), wbytes, _stream(dev)))
+        ctx.dims, ctx.inv = (B, F, T), inv
+        ctx.save_for_backward(feat, W, logits, labels, weights)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        lib = _ffi.lib()
+        feat, W, logits, labels, weights = ctx.saved_tensors
+        B, F, T = ctx.dims
+        dev = feat.device
+        dloss = _f32c(dloss.reshape(1), "dloss")
+        dfeat = torch.empty_like(feat)
+        if feat.shape[1] > F:
+            dfeat.zero_()
+        dW = torch.empty_like(W)
+        db = torch.empty((T, 2), dtype=torch.float32, device=dev)
+        wbytes = lib.agcn_multitask_ce_workspace_bytes(B, F, T)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        _ffi.check(lib.agcn_multitask_ce_backward(B, F, T, feat.data_ptr(), feat.shape[1], W.data_ptr(),
+                                                  logits.data_ptr(), labels.data_ptr(), weights.data_ptr(), ctx.inv,
+                                                  dloss.data_ptr(), dfeat.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                                  ws.data_ptr(), wbytes, _stream(dev)))
+        return dfeat, dW, db, None, None, None
 
 
 class GraphPoolFunction(torch.autograd.Function):

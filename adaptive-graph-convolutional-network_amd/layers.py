@@ -22,7 +22,8 @@ import numpy as np
 import torch
 
 from .batch import GraphBatch, RowViews, TileViews
-from .functional import GraphGatherFunction, GraphPoolFunction, RowsDenseFunction, SgcLLFunction, _Cfg
+from .functional import (GraphGatherFunction, GraphPoolFunction, MultitaskCEFunction, RowsDenseFunction, SgcLLFunction,
+                         _Cfg)
 
 _UID_PREFIXES = defaultdict(int)
 
@@ -354,6 +355,148 @@ class BlockEnd(Layer):
         Y = RowsDenseFunction.apply(Xres, self.vars["weight"], None, X.contiguous(), gb,
                                     "relu" if self.activation == "relu" else "linear", False)
         return _row_views(Y, gb)
+
+
+def _source_rows(src, F, gb):
+    """One [rows, F] tensor for a residual source given as a RowViews, a 2-D tensor, or B per-graph tensors
+    (what the reference's containers accumulate with `list += layer_output`, tf_graphs.py:268,292).  Per-graph
+    views produced by this package are recognised and mapped back to their packed parent without a copy."""
+    plan = gb.plan
+    if isinstance(src, RowViews):
+        return src.data
+    if torch.is_tensor(src):
+        return src if src.dim() == 2 else src.reshape(-1, src.shape[-1])
+    ts = list(src)
+    if len(ts) != plan.B:
+        raise ValueError("a residual source must hold one tensor per graph (%d), got %d" % (plan.B, len(ts)))
+    base = ts[0]._base
+    if base is not None and base.dim() == 2 and base.shape[0] == plan.rows and base.is_contiguous():
+        w = base.shape[1] * base.element_size()
+        if all(t._base is base and t.data_ptr() == base.data_ptr() + int(plan.row_off[b]) * w
+               for b, t in enumerate(ts)):
+            return base
+    if plan.rows == plan.N1:      # packed rows
+        return torch.cat([t[:int(plan.n[b])] for b, t in enumerate(ts)], 0)
+    return torch.stack(ts).reshape(-1, ts[0].shape[-1])
+
+
+class DenseBlockEnd(Layer):
+    """Last layer of a densely connected block (densenet_block.py:15-131):
+        act(x + beta_inblock * sum_l a_l . W_in_l + beta_outblock * sum_b o_b . W_out_b), pad rows 0.
+    DenseBlockEnd(block_id, res_n_features_list, output_n_features, activation='relu', K=2, max_atom=128,
+    batch_size=256); input keys: node_features, data_slice, inblock_activations(+_dim), block_outputs(+_dim).
+    The two activation lists are flat, source-major (entry l * batch_size + graph, :114,120), as the
+    reference's container builds them; a list of per-source RowViews / 2-D tensors is accepted as well."""
+
+    def __init__(self, block_id, res_n_features_list, output_n_features, activation="relu", K=2, max_atom=128,
+                 batch_size=256, device=None, generator=None, **kwargs):
+        super(DenseBlockEnd, self).__init__(**kwargs)
+        if activation not in ("relu", "linear", None):
+            raise ValueError("Invalid activation function: %s" % (activation,))
+        assert type(res_n_features_list) == list
+        self.max_atom, self.batch_size, self.block_id = max_atom, batch_size, block_id
+        self.activation, self.K = activation, K
+        self.res_n_features_list = res_n_features_list
+        self.output_n_features = output_n_features
+        self.vars = {}
+        self.inblock_activations_dim, self.preceding_blocks_dim = [], []
+        self._device, self._generator = device, generator
+
+    def build(self, device=None):
+        if "beta_inblock" in self.vars:
+            return
+        device = self._device if self._device is not None else device
+        tr = bool(self.trainable)
+        mk = lambda F: glorot([F, self.output_n_features], self._generator, device).requires_grad_(tr)  # noqa: E731
+        # creation order of the reference: out-of-block weights, in-block weights, beta1, beta2 (:50-68)
+        self.vars["weight_outblock"] = [mk(F) for F in self.preceding_blocks_dim]
+        self.vars["weight_inblock"] = [mk(F) for F in self.inblock_activations_dim]
+        self.vars["beta_inblock"] = torch.ones(1, dtype=torch.float32, device=device).requires_grad_(tr)
+        self.vars["beta_outblock"] = torch.ones(1, dtype=torch.float32, device=device).requires_grad_(tr)
+
+    def load_vars(self, weight_inblock, weight_outblock, beta_inblock, beta_outblock):
+        dev, tr = self._device, bool(self.trainable)
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(dev).requires_grad_(tr)  # noqa: E731
+        self.vars = {"weight_inblock": [t(w) for w in weight_inblock], "weight_outblock": [t(w) for w in weight_outblock],
+                     "beta_inblock": t(beta_inblock).reshape(1).detach().requires_grad_(tr),
+                     "beta_outblock": t(beta_outblock).reshape(1).detach().requires_grad_(tr)}
+        self.inblock_activations_dim = [int(w.shape[0]) for w in self.vars["weight_inblock"]]
+        self.preceding_blocks_dim = [int(w.shape[0]) for w in self.vars["weight_outblock"]]
+
+    def parameters(self):
+        self.build()
+        return (list(self.vars["weight_inblock"]) + list(self.vars["weight_outblock"]) +
+                [self.vars["beta_inblock"], self.vars["beta_outblock"]])
+
+    @staticmethod
+    def _split(lst, dims, B):
+        """flat source-major list of len(dims) * B tensors -> len(dims) sources"""
+        lst = lst if isinstance(lst, (list, tuple)) else list(lst)
+        if len(lst) == len(dims):                                        # one entry per source
+            return list(lst)
+        if len(lst) != len(dims) * B:                                   # densenet_block.py:108
+            raise ValueError("expected %d x %d tensors, got %d" % (len(dims), B, len(lst)))
+        return [lst[i * B:(i + 1) * B] for i in range(len(dims))]
+
+    def call(self, x):
+        gb, X = _rows_of(x)
+        B = gb.plan.B
+        in_dims, out_dims = list(x["inblock_activations_dim"]), list(x["block_outputs_dim"])
+        if "beta_inblock" not in self.vars:
+            self.inblock_activations_dim, self.preceding_blocks_dim = in_dims, out_dims
+        self.build(X.device)
+        if [int(w.shape[0]) for w in self.vars["weight_inblock"]] != in_dims or \
+                [int(w.shape[0]) for w in self.vars["weight_outblock"]] != out_dims:
+            raise ValueError("source widths do not match the layer's weights")
+        ins = self._split(x["inblock_activations"], in_dims, B)
+        outs = self._split(x["block_outputs"], out_dims, B)
+        terms = [(_source_rows(a, F, gb), w, self.vars["beta_inblock"])
+                 for a, F, w in zip(ins, in_dims, self.vars["weight_inblock"])]
+        terms += [(_source_rows(o, F, gb), w, self.vars["beta_outblock"])
+                  for o, F, w in zip(outs, out_dims, self.vars["weight_outblock"])]
+        if not terms:
+            raise ValueError("DenseBlockEnd needs at least one saved activation (tf_graphs.py:281)")
+        act = "relu" if self.activation == "relu" else "linear"
+        acc = X
+        for i, (A, W, beta) in enumerate(terms):
+            last = i == len(terms) - 1
+            acc = RowsDenseFunction.apply(A, W, None, acc.contiguous(), gb, act if last else "linear", False, beta)
+        return _row_views(acc, gb)
+
+
+class MultitaskHead(object):
+    """The classifier tail of MultitaskGraphClassifier: `multitask_logits(feat, n_tasks, n_feature=...)`
+    (model_operatos.py:792-829: one fully connected 2-class head per task, w ~ truncated_normal(stddev 0.01),
+    b = 0, :744-750) and `add_training_loss('cross_entropy', logits)` (multitask_classifier.py:41-44,187-209:
+    per-task weighted sigmoid cross-entropy against one-hot labels, summed, divided by batch_size)."""
+
+    def __init__(self, n_tasks, n_feature, batch_size, device=None, generator=None, trainable=True):
+        self.n_tasks, self.n_feature, self.batch_size = n_tasks, n_feature, batch_size
+        w = torch.empty((n_tasks, n_feature, 2), dtype=torch.float32)
+        torch.nn.init.trunc_normal_(w, mean=0.0, std=0.01, a=-0.02, b=0.02, generator=generator)
+        self.vars = {"w": w.to(device).requires_grad_(bool(trainable)),
+                     "b": torch.zeros((n_tasks, 2), dtype=torch.float32, device=device).requires_grad_(bool(trainable))}
+
+    def load_vars(self, w, b):
+        dev, tr = self.vars["w"].device, self.vars["w"].requires_grad
+        self.vars["w"] = torch.as_tensor(np.asarray(w), dtype=torch.float32).to(dev).requires_grad_(tr)
+        self.vars["b"] = torch.as_tensor(np.asarray(b), dtype=torch.float32).to(dev).requires_grad_(tr)
+
+    def parameters(self):
+        return [self.vars["w"], self.vars["b"]]
+
+    def loss(self, feat, labels, weights):
+        """feat [B, n_feature]; labels, weights [B, n_tasks] (label_placeholder / weight_placeholder).
+        Returns (loss 0-dim tensor, list of n_tasks logits tensors [B, 2])."""
+        loss, logits = MultitaskCEFunction.apply(feat, self.vars["w"], self.vars["b"], labels, weights,
+                                                 self.batch_size)
+        return loss.reshape(()), [logits[t] for t in range(self.n_tasks)]
+
+    def logits(self, feat):
+        """Prediction path: labels and weights all zero, as construct_feed_dict does when none are given
+        (multitask_classifier.py:172-176)."""
+        z = torch.zeros((feat.shape[0], self.n_tasks), dtype=torch.float32, device=feat.device)
+        return self.loss(feat, z, z)[1]
 
 
 class GraphPoolMol(Layer):

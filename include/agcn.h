@@ -227,6 +227,41 @@ int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* plan_host, c
                              float* dAdd, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                              void* hip_stream);
 
+/* The same with a DEVICE scalar on the product: Y = act(scale[0] * (A . W) [+ bias] [+ Add]).
+ *   DenseBlockEnd (models/layers/densenet_block.py:99-131) is a chain of these, one per in-block activation
+ *   (scale = beta_inblock, :113-117) and per preceding block output (scale = beta_outblock, :119-123), each
+ *   adding onto the previous sum (Add), the last one carrying the activation (:92) and zeroing pad rows (:126).
+ * Backward additionally returns dscale[0] = <W, A^T Gp>; dX and dW carry the factor scale[0].
+ * scale == NULL (and dscale == NULL) is exactly agcn_rows_dense_forward / _backward. */
+int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+                                   const float* X, const float* W, const float* scale, const float* bias,
+                                   const float* Add, float* Y, void* hip_stream);
+int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+                                    const float* X, const float* W, const float* scale, const float* Y,
+                                    const float* dY, float* dX, float* dAdd, float* dW, float* dbias,
+                                    float* dscale, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Classifier tail: T task heads + the weighted sigmoid cross-entropy training loss.
+ *   logits[t][b][c] = feat[b, :] . W[t][:, c] + bias[t][c], c in {0, 1}
+ *       (models/operators/model_operatos.py:710-759 fully_connected_layer, :792-864 multitask_logits / logits)
+ *   loss = inv_batch * sum_t sum_b sum_c w[b][t] * sce(logits[t][b][c], one_hot(int(y[b][t]), 2)[c])
+ *       sce(x, z) = max(x, 0) - x z + log(1 + exp(-|x|))   (tf.nn.sigmoid_cross_entropy_with_logits)
+ *       (models/tf_modules/multitask_classifier.py:41-44 'cross_entropy' loss_fn, :187-209 add_training_loss;
+ *        inv_batch = 1 / batch_size, :207-208)
+ * feat [B, ldf] (F used), W [T][F][2], bias [T][2], labels / weights [B][T] fp32 (the reference's placeholders),
+ * logits [T][B][2], loss [1].  workspace: agcn_multitask_ce_workspace_bytes(B, F, T).
+ * Backward: dloss is a DEVICE scalar (the upstream gradient of the loss); writes dfeat [B, ldf] (columns < F),
+ * dW [T][F][2], dbias [T][2].  Reductions run in a fixed order (no atomics). */
+size_t agcn_multitask_ce_workspace_bytes(int32_t B, int32_t F, int32_t T);
+int agcn_multitask_ce_forward(int32_t B, int32_t F, int32_t T, const float* feat, int32_t ldf, const float* W,
+                              const float* bias, const float* labels, const float* weights, float inv_batch,
+                              float* logits, float* loss, void* workspace, size_t workspace_bytes,
+                              void* hip_stream);
+int agcn_multitask_ce_backward(int32_t B, int32_t F, int32_t T, const float* feat, int32_t ldf, const float* W,
+                               const float* logits, const float* labels, const float* weights, float inv_batch,
+                               const float* dloss, float* dfeat, float* dW, float* dbias, void* workspace,
+                               size_t workspace_bytes, void* hip_stream);
+
 /* GraphPoolMol (models/layers/graphpool.py:55-110): out[i] = max over {x_j : L_ij != 0} (x_i if the row
  * is empty), pad rows 0.  `lap`: only the L0_* members are read.  argmax [rows, F] int32 is optional.
  * The reference passes NO gradient through this layer (py_func); agcn_graph_pool_backward is the

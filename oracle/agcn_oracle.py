@@ -425,6 +425,61 @@ def block_end_backward(x_res, W, pre, G, activation="relu"):
     return Gp, Gp @ W.T, x_res.T @ Gp
 
 
+def dense_block_end_forward(x, ins, W_in, outs, W_out, beta1, beta2, activation="relu"):
+    """models/layers/densenet_block.py:99-131 on the sliced rows [n, F] of one graph:
+    x + sum_l beta1 * (a_l . W_in_l) + sum_b beta2 * (o_b . W_out_b), accumulated in the reference's order
+    (:113-123), then the activation (:92); pad rows are 0 (:126).  Returns (y, pre)."""
+    b1, b2 = x.dtype.type(np.asarray(beta1).reshape(-1)[0]), x.dtype.type(np.asarray(beta2).reshape(-1)[0])
+    pre = x.copy()
+    for a, W in zip(ins, W_in):
+        pre = pre + (a @ W) * b1
+    for o, W in zip(outs, W_out):
+        pre = pre + (o @ W) * b2
+    return (np.maximum(pre, 0) if activation == "relu" else pre), pre
+
+
+def dense_block_end_backward(ins, W_in, outs, W_out, beta1, beta2, pre, G, activation="relu"):
+    """Returns (dx, [da_l], [dW_in_l], [do_b], [dW_out_b], dbeta1, dbeta2)."""
+    b1, b2 = G.dtype.type(np.asarray(beta1).reshape(-1)[0]), G.dtype.type(np.asarray(beta2).reshape(-1)[0])
+    Gp = G * (pre > 0) if activation == "relu" else G
+    da = [b1 * (Gp @ W.T) for W in W_in]
+    dWi = [b1 * (a.T @ Gp) for a in ins]
+    do = [b2 * (Gp @ W.T) for W in W_out]
+    dWo = [b2 * (o.T @ Gp) for o in outs]
+    db1 = sum(((a @ W) * Gp).sum() for a, W in zip(ins, W_in))
+    db2 = sum(((o @ W) * Gp).sum() for o, W in zip(outs, W_out))
+    return Gp, da, dWi, do, dWo, db1, db2
+
+
+def multitask_ce_forward(feat, W, b, labels, weights, batch_size):
+    """Classifier tail: T heads logits_t = feat . W[t] + b[t]  (model_operatos.py:710-759 fully_connected_layer,
+    :792-864 multitask_logits/logits) and the 'cross_entropy' training loss (multitask_classifier.py:41-44):
+    per task sum_{b,c} w[b,t] * sce(logits_t[b,c], one_hot(y[b,t], 2)[c]), summed over tasks, divided by
+    batch_size (:187-209).  sce(x, z) = max(x,0) - x z + log(1 + exp(-|x|)).
+    feat [B,F], W [T,F,2], b [T,2], labels/weights [B,T].  Returns (loss, logits [T,B,2])."""
+    T = W.shape[0]
+    logits = np.stack([feat @ W[t] + b[t] for t in range(T)])
+    y = labels.astype(np.int64)
+    z = np.stack([(y == c) for c in range(2)], axis=-1).astype(feat.dtype)          # [B,T,2]; out of range -> zeros
+    x = np.transpose(logits, (1, 0, 2))                                              # [B,T,2]
+    sce = np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))
+    loss = (sce * weights[:, :, None].astype(feat.dtype)).sum() / feat.dtype.type(batch_size)
+    return loss, logits
+
+
+def multitask_ce_backward(feat, W, logits, labels, weights, batch_size, dloss=1.0):
+    """Returns (dfeat [B,F], dW [T,F,2], db [T,2])."""
+    T = W.shape[0]
+    y = labels.astype(np.int64)
+    z = np.stack([(y == c) for c in range(2)], axis=-1).astype(feat.dtype)
+    x = np.transpose(logits, (1, 0, 2))
+    dx = (1.0 / (1.0 + np.exp(-x)) - z) * weights[:, :, None] * (dloss / batch_size)   # [B,T,2]
+    dfeat = sum(dx[:, t, :] @ W[t].T for t in range(T))
+    dW = np.stack([feat.T @ dx[:, t, :] for t in range(T)])
+    db = np.stack([dx[:, t, :].sum(axis=0) for t in range(T)])
+    return dfeat, dW, db
+
+
 def graph_pool_forward(x, L):
     """models/layers/graphpool.py:91-103 as written: per node, max over the rows of x selected by the
     non-zeros of the node's Laplacian row; an empty row keeps x[i].  Returns (pooled, argmax)."""

@@ -567,6 +567,47 @@ tanh = _tanh
 sigmoid = _sigmoid
 
 
+# ---- the few extra ops the classifier head / loss use (model_operatos.py:710-759,
+# multitask_classifier.py:41-44,187-209) --------------------------------------------------
+def split(split_dim, num_split, value, **_):
+    """TF 0.12 argument order: tf.split(split_dim, num_split, value)."""
+    return [Tensor(c) for c in torch.chunk(_raw(value), int(num_split), dim=int(split_dim))]
+
+
+def to_int32(x, **_):
+    return Tensor(_raw(x).to(torch.int32))
+
+
+def to_float(x, **_):
+    return Tensor(_raw(x).to(torch.float32))
+
+
+def one_hot(indices, depth, **_):
+    idx = _raw(indices).to(torch.int64)
+    out = torch.zeros(tuple(idx.shape) + (int(depth),), dtype=torch.float32)
+    ok = (idx >= 0) & (idx < int(depth))          # out-of-range index -> all-zero row, like TF
+    out[ok, idx[ok]] = 1.0
+    return Tensor(out)
+
+
+def div(a, b, **_):
+    return Tensor(_raw(a) / _raw(b))
+
+
+def _xw_plus_b(x, w, b, **_):
+    return Tensor(torch.matmul(_raw(x), _raw(w)) + _raw(b))
+
+
+def _sigmoid_cross_entropy_with_logits(logits, targets, **_):
+    """TF 0.12 positional order (logits, targets): max(x, 0) - x z + log(1 + exp(-|x|))."""
+    x, z = _raw(logits), _raw(targets)
+    return Tensor(torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x))))
+
+
+nn.xw_plus_b = _xw_plus_b
+nn.sigmoid_cross_entropy_with_logits = _sigmoid_cross_entropy_with_logits
+
+
 # --------------------------------------------------------------------------
 def install():
     """Register this module as `tensorflow` (+ the sub-modules the reference

@@ -14,6 +14,10 @@ What each file pins (reference file:line):
   sgc_*.npz      layers/graphconv.py:85-252          SGC_LL fwd + TF-autodiff grads
   reslap_*.npz   layers/graphconv_reslap.py:45-230   SGC_LL_Reslap (single layer and 2-layer chain)
   gather_*.npz   layers/graphgather.py:40-77         GraphGatherMol fwd + grads
+  dense_mol / block_end / graph_pool .npz   layers/dense_layer.py, blockend.py, graphpool.py
+  dense_block_end.npz  layers/densenet_block.py:48-131  DenseBlockEnd fwd + grads (incl. both betas)
+  multitask_head.npz   operators/model_operatos.py:792-864 + tf_modules/multitask_classifier.py:41-44,187-209
+                       12-task-style heads + weighted sigmoid cross-entropy, fwd + grads
 """
 import os
 import sys
@@ -265,6 +269,104 @@ def run_next_rows(ftf, layers, gs, topo_cls):
     print("wrote dense_mol, block_end, graph_pool")
 
 
+def run_tail_rows(ftf, layers):
+    """DenseBlockEnd (densenet_block.py:48-131) and the classifier tail: multitask_logits
+    (model_operatos.py:710-759,792-864) + the 'cross_entropy' training loss
+    (multitask_classifier.py:41-44,187-209), both executed from the reference's own code."""
+    import importlib
+    import types
+    rs = np.random.RandomState(31)
+    ns, Fout = [5, 9, 4, 12], 6
+    B, max_atom = len(ns), 13
+    ds = np.stack([np.asarray(ns), -np.ones(B)], 1).astype(np.int32)        # graph_topology.py:90
+    dsT = ftf.constant(ds)
+
+    def padded(F):
+        a = np.zeros((B, max_atom, F), dtype=np.float32)
+        for b, n in enumerate(ns):
+            a[b, :n] = rs.randn(n, F)
+        return a
+
+    def leaves(a):
+        return [ftf.Tensor(torch.from_numpy(x.copy()).requires_grad_(True)) for x in a]
+
+    # ---- DenseBlockEnd: x + beta1 * sum_l a_l W_in_l + beta2 * sum_b o_b W_out_b, relu, pad rows 0 ----
+    in_dims, out_dims = [6, 5], [7]
+    Xn = padded(Fout)
+    An = [padded(F) for F in in_dims]
+    On = [padded(F) for F in out_dims]
+    X, A, O = leaves(Xn), [leaves(a) for a in An], [leaves(o) for o in On]
+    ftf.reset_state(8, {"beta1": np.array([0.7], np.float32), "beta2": np.array([1.3], np.float32)})
+    dbe = layers.DenseBlockEnd(0, in_dims, Fout, activation="relu", max_atom=max_atom, batch_size=B)
+    out = list(dbe({"node_features": X, "data_slice": dsT,
+                    "inblock_activations": [t for a in A for t in a], "inblock_activations_dim": in_dims,
+                    "block_outputs": [t for o in O for t in o], "block_outputs_dim": out_dims}))
+    G = rs.randn(B, max_atom, Fout).astype(np.float32)
+    sum((o.t * torch.from_numpy(G[b])).sum() for b, o in enumerate(out)).backward()
+    rec = dict(ns=np.asarray(ns, np.int32), data_slice=ds, X=Xn, G=G,
+               Y=np.stack([o.t.detach().numpy() for o in out]), dX=np.stack([_grad(x) for x in X]),
+               beta1=dbe.vars["beta_inblock"].t.detach().numpy(), beta2=dbe.vars["beta_outblock"].t.detach().numpy(),
+               dbeta1=_grad(dbe.vars["beta_inblock"]), dbeta2=_grad(dbe.vars["beta_outblock"]),
+               n_in=np.int32(len(in_dims)), n_out=np.int32(len(out_dims)))
+    for i in range(len(in_dims)):
+        rec["A%d" % i] = An[i]
+        rec["dA%d" % i] = np.stack([_grad(t) for t in A[i]])
+        rec["Win%d" % i] = dbe.vars["weight_inblock"][i].t.detach().numpy()
+        rec["dWin%d" % i] = _grad(dbe.vars["weight_inblock"][i])
+    for i in range(len(out_dims)):
+        rec["O%d" % i] = On[i]
+        rec["dO%d" % i] = np.stack([_grad(t) for t in O[i]])
+        rec["Wout%d" % i] = dbe.vars["weight_outblock"][i].t.detach().numpy()
+        rec["dWout%d" % i] = _grad(dbe.vars["weight_outblock"][i])
+    np.savez_compressed(os.path.join(OUT, "dense_block_end.npz"), **rec)
+
+    # ---- multitask heads + weighted sigmoid cross-entropy ---------------------------------------------
+    # multitask_classifier.py imports matplotlib / the trainer base classes at module level: give it
+    # empty stand-ins for THOSE (they are not on the path) and run its own get_loss_fn / add_training_loss.
+    for name, attrs in (("AGCN.utils", {}), ("AGCN.utils.save", {"log": lambda *a, **k: None}),
+                        ("AGCN.models.tf_modules.basic_model", {"Model": object}),
+                        ("AGCN.models.tf_modules.evaluation", {"Evaluator": object})):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules.setdefault(name, m)
+    pkg = types.ModuleType("AGCN.models.tf_modules")
+    pkg.__path__ = [os.path.join(load_reference.REF_ROOT, "models", "tf_modules")]
+    sys.modules.setdefault("AGCN.models.tf_modules", pkg)
+    mc = importlib.import_module("AGCN.models.tf_modules.multitask_classifier")
+    model_ops = importlib.import_module("AGCN.models.operators.model_operatos")
+
+    Bh, F, T = 7, 10, 3
+    feat_n = rs.randn(Bh, F).astype(np.float32)
+    labels = rs.randint(0, 2, size=(Bh, T)).astype(np.float32)
+    weights = (rs.rand(Bh, T) * (rs.rand(Bh, T) > 0.25)).astype(np.float32)      # some masked (0) entries
+    feat = ftf.Tensor(torch.from_numpy(feat_n.copy()).requires_grad_(True))
+    ftf.reset_state(9)
+    # the reference's initialisers (stddev 0.01 weights, zero biases) make every logit ~0; swap the two
+    # initialiser ops for larger random draws while ITS multitask_logits builds the heads
+    tn, zr = ftf.truncated_normal, ftf.zeros
+    ftf.truncated_normal = lambda shape, **k: ftf.Tensor(torch.from_numpy(
+        (0.5 * rs.randn(*[int(v) for v in shape])).astype(np.float32)))
+    ftf.zeros = lambda shape, **k: ftf.Tensor(torch.from_numpy(
+        (0.3 * rs.randn(*[int(v) for v in shape])).astype(np.float32)))
+    try:
+        logits = model_ops.multitask_logits(feat, T, n_feature=F)
+    finally:
+        ftf.truncated_normal, ftf.zeros = tn, zr
+    created = list(ftf.STATE.created)           # [(name, var)]: w, b per task in creation order
+    assert len(created) == 2 * T
+    me = types.SimpleNamespace(n_tasks=T, batch_size=Bh, label_placeholder=ftf.constant(labels),
+                               weight_placeholder=ftf.constant(weights))
+    loss = mc.MultitaskGraphClassifier.add_training_loss(me, "cross_entropy", logits)
+    loss.t.backward()
+    np.savez_compressed(os.path.join(OUT, "multitask_head.npz"), feat=feat_n, labels=labels, weights=weights,
+                        W=np.stack([created[2 * t][1].t.detach().numpy() for t in range(T)]),
+                        b=np.stack([created[2 * t + 1][1].t.detach().numpy() for t in range(T)]),
+                        logits=np.stack([l.t.detach().numpy() for l in logits]), loss=loss.t.detach().numpy(),
+                        dfeat=_grad(feat), dW=np.stack([_grad(created[2 * t][1]) for t in range(T)]),
+                        db=np.stack([_grad(created[2 * t + 1][1]) for t in range(T)]))
+    print("wrote dense_block_end, multitask_head")
+
+
 def main():
     assert load_reference.available(), "reference tree not found"
     os.makedirs(OUT, exist_ok=True)
@@ -282,6 +384,9 @@ def main():
     run_topo_case(ftf, gs, topo_cls)
     run_gather_case(ftf, layers)
     run_next_rows(ftf, layers, gs, topo_cls)
+    run_tail_rows(ftf, layers)
+    if os.environ.get("AGCN_GOLDEN_ONLY") == "tail":
+        return
 
     L = (ftf, layers, gs, topo_cls)
     #                 name                 variant   ns                 Fin Fout K seed fancy

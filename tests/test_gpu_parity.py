@@ -399,6 +399,114 @@ def test_block_end_golden(amd):
     assert_close(to_np(layer.vars["weight"].grad), g["dW"], GRAD_RTOL, "BlockEnd dW")
 
 
+def test_dense_block_end_golden(amd):
+    """DenseBlockEnd (densenet_block.py:48-131) in the reference's own feed: flat, source-major lists of padded
+    per-graph tensors; checked against vectors produced by the reference's class."""
+    g = load_golden("dense_block_end.npz")
+    B, n_in, n_out = len(g["ns"]), int(g["n_in"]), int(g["n_out"])
+    leaves = lambda a: [torch.from_numpy(a[b]).to(DEV).requires_grad_(True) for b in range(B)]  # noqa: E731
+    Xl = leaves(g["X"])
+    Al = [leaves(g["A%d" % i]) for i in range(n_in)]
+    Ol = [leaves(g["O%d" % i]) for i in range(n_out)]
+    in_dims = [int(g["Win%d" % i].shape[0]) for i in range(n_in)]
+    out_dims = [int(g["Wout%d" % i].shape[0]) for i in range(n_out)]
+    layer = amd.DenseBlockEnd(0, in_dims, g["X"].shape[2], activation="relu", max_atom=g["X"].shape[1],
+                              batch_size=B, device=DEV)
+    layer.load_vars([g["Win%d" % i] for i in range(n_in)], [g["Wout%d" % i] for i in range(n_out)],
+                    g["beta1"], g["beta2"])
+    out = layer({"node_features": Xl, "data_slice": g["data_slice"],
+                 "inblock_activations": [t for a in Al for t in a], "inblock_activations_dim": in_dims,
+                 "block_outputs": [t for o in Ol for t in o], "block_outputs_dim": out_dims})
+    assert type(layer).__name__ == "DenseBlockEnd" and len(out) == B
+    Y = np.stack([to_np(out[b]) for b in range(B)])
+    assert_close(Y, g["Y"], FEATURE_RTOL, "DenseBlockEnd Y")
+    for b, n in enumerate(g["ns"]):
+        assert np.all(Y[b, n:] == 0)
+    G = torch.from_numpy(g["G"]).to(DEV)
+    sum((out[b] * G[b]).sum() for b in range(B)).backward()
+    assert_close(np.stack([to_np(x.grad) for x in Xl]), g["dX"], GRAD_RTOL, "DenseBlockEnd dX")
+    for i in range(n_in):
+        assert_close(np.stack([to_np(t.grad) for t in Al[i]]), g["dA%d" % i], GRAD_RTOL, "DenseBlockEnd dA%d" % i)
+        assert_close(to_np(layer.vars["weight_inblock"][i].grad), g["dWin%d" % i], GRAD_RTOL, "DenseBlockEnd dWin")
+    for i in range(n_out):
+        assert_close(np.stack([to_np(t.grad) for t in Ol[i]]), g["dO%d" % i], GRAD_RTOL, "DenseBlockEnd dO%d" % i)
+        assert_close(to_np(layer.vars["weight_outblock"][i].grad), g["dWout%d" % i], GRAD_RTOL, "DenseBlockEnd dWout")
+    for k, ref in (("beta_inblock", "dbeta1"), ("beta_outblock", "dbeta2")):
+        got, want = float(layer.vars[k].grad[0]), float(g[ref][0])
+        assert abs(got - want) <= 5 * GRAD_RTOL * abs(want), (k, got, want)
+
+
+def test_dense_block_end_packed_chain(amd):
+    """The same layer fed by this package's own layer outputs (packed RowViews accumulated the way the
+    reference's container does, `list += output`): no copies, same numbers as the oracle."""
+    ns, Fin, F = [9, 17, 5, 24], 12, 8
+    rs, X, L0, csr, _, _ = synth_case(77, ns, Fin, F, 2, orc.SGC_LL)
+    B = len(ns)
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+    p1, p2 = orc.init_params(rs, Fin, F, 2), orc.init_params(rs, F, F, 2)
+    l1 = make_layer(amd, orc.SGC_LL, F, Fin, B, 2, orc.PAPER, p1, DEV)
+    l2 = make_layer(amd, orc.SGC_LL, F, F, B, 2, orc.PAPER, p2, DEV)
+    h1, _, _ = l1({"node_features": gb.X, "graph_batch": gb})
+    h2, _, _ = l2({"node_features": h1, "graph_batch": gb})
+    saved, dims = [], []
+    saved += h1                      # tf_graphs.py:268: self.inblock_activations[block] += self.output
+    dims += [F]
+    Win = orc.glorot_uniform(rs, (F, F))
+    layer = amd.DenseBlockEnd(0, [F], F, batch_size=B, device=DEV)
+    layer.load_vars([Win], [], [0.6], [1.0])
+    out = layer({"node_features": h2, "graph_batch": gb, "inblock_activations": saved,
+                 "inblock_activations_dim": dims, "block_outputs": [], "block_outputs_dim": []})
+    a1, a2 = to_np(h1.data), to_np(h2.data)
+    want = np.maximum(a2.astype(np.float64) + 0.6 * (a1.astype(np.float64) @ Win.astype(np.float64)), 0)
+    assert_close(to_np(out.data), want, FEATURE_RTOL, "packed DenseBlockEnd")
+    out.data.sum().backward()
+    assert l1.vars["weight"].grad is not None and layer.vars["beta_inblock"].grad is not None
+
+
+def test_multitask_head_golden(amd):
+    """12-task-style classifier tail: logits, loss and every gradient against vectors produced by the
+    reference's multitask_logits + add_training_loss('cross_entropy')."""
+    g = load_golden("multitask_head.npz")
+    B, T = g["feat"].shape[0], g["W"].shape[0]
+    head = amd.MultitaskHead(T, g["feat"].shape[1], B, device=DEV)
+    head.load_vars(g["W"], g["b"])
+    feat = torch.from_numpy(g["feat"]).to(DEV).requires_grad_(True)
+    loss, logits = head.loss(feat, torch.from_numpy(g["labels"]).to(DEV), torch.from_numpy(g["weights"]).to(DEV))
+    assert len(logits) == T and tuple(logits[0].shape) == (B, 2)
+    assert_close(np.stack([to_np(l) for l in logits]), g["logits"], FEATURE_RTOL, "logits")
+    assert abs(float(loss.detach()) - float(g["loss"])) <= FEATURE_RTOL * abs(float(g["loss"]))
+    loss.backward()
+    assert_close(to_np(feat.grad), g["dfeat"], GRAD_RTOL, "head dfeat")
+    assert_close(to_np(head.vars["w"].grad), g["dW"], GRAD_RTOL, "head dW")
+    assert_close(to_np(head.vars["b"].grad), g["db"], GRAD_RTOL, "head db")
+    # prediction path: same logits, no labels
+    assert np.array_equal(np.stack([to_np(l) for l in head.logits(feat.detach())]),
+                          np.stack([to_np(l) for l in logits]))
+
+
+def test_multitask_head_tox21_size(amd):
+    """Tox21 tail size (B = 256 graphs, 256 features, 12 tasks) against the oracle in float64."""
+    rs = np.random.RandomState(3)
+    B, F, T = 256, 256, 12
+    feat = np.tanh(rs.randn(B, F)).astype(np.float32)
+    W, b = (0.1 * rs.randn(T, F, 2)).astype(np.float32), (0.1 * rs.randn(T, 2)).astype(np.float32)
+    y = rs.randint(0, 2, size=(B, T)).astype(np.float32)
+    w = (rs.rand(B, T) * (rs.rand(B, T) > 0.3)).astype(np.float32)
+    head = amd.MultitaskHead(T, F, B, device=DEV)
+    head.load_vars(W, b)
+    ft = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+    loss, logits = head.loss(ft, torch.from_numpy(y).to(DEV), torch.from_numpy(w).to(DEV))
+    (3.0 * loss).backward()
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    l_ref, lg_ref = orc.multitask_ce_forward(f64(feat), f64(W), f64(b), y, f64(w), B)
+    dfeat, dW, db = orc.multitask_ce_backward(f64(feat), f64(W), lg_ref, y, f64(w), B, dloss=3.0)
+    assert_close(np.stack([to_np(l) for l in logits]), lg_ref, FEATURE_RTOL, "logits")
+    assert abs(float(loss.detach()) - l_ref) <= FEATURE_RTOL * abs(l_ref)
+    assert_close(to_np(ft.grad), dfeat, GRAD_RTOL, "dfeat")
+    assert_close(to_np(head.vars["w"].grad), dW, GRAD_RTOL, "dW")
+    assert_close(to_np(head.vars["b"].grad), db, GRAD_RTOL, "db")
+
+
 def test_graph_pool_golden_and_argmax_grad(amd):
     g = load_golden("graph_pool.npz")
     B = len(g["ns"])

@@ -212,6 +212,51 @@ def test_block_end_golden():
     _close(dW, g["dW"], "BlockEnd dW", rtol=2e-5, atol=2e-5)
 
 
+def test_dense_block_end_golden():
+    """densenet_block.py:48-131 executed from the reference: forward, node / weight / beta gradients."""
+    g = _load("dense_block_end.npz")
+    n_in, n_out = int(g["n_in"]), int(g["n_out"])
+    Win = [g["Win%d" % i] for i in range(n_in)]
+    Wout = [g["Wout%d" % i] for i in range(n_out)]
+    dWi, dWo, db1, db2 = [0] * n_in, [0] * n_out, 0.0, 0.0
+    for b, n in enumerate(g["ns"]):
+        ins = [g["A%d" % i][b, :n] for i in range(n_in)]
+        outs = [g["O%d" % i][b, :n] for i in range(n_out)]
+        y, pre = orc.dense_block_end_forward(g["X"][b, :n], ins, Win, outs, Wout, g["beta1"], g["beta2"])
+        _close(y, g["Y"][b, :n], "DenseBlockEnd Y", rtol=2e-5, atol=2e-5)
+        assert np.all(g["Y"][b, n:] == 0)
+        dx, da, dwi, do, dwo, d1, d2 = orc.dense_block_end_backward(ins, Win, outs, Wout, g["beta1"], g["beta2"], pre,
+                                                                    g["G"][b, :n])
+        _close(dx, g["dX"][b, :n], "DenseBlockEnd dX", rtol=2e-5, atol=2e-5)
+        for i in range(n_in):
+            _close(da[i], g["dA%d" % i][b, :n], "DenseBlockEnd dA", rtol=2e-5, atol=2e-5)
+            dWi[i] = dWi[i] + dwi[i]
+        for i in range(n_out):
+            _close(do[i], g["dO%d" % i][b, :n], "DenseBlockEnd dO", rtol=2e-5, atol=2e-5)
+            dWo[i] = dWo[i] + dwo[i]
+        db1, db2 = db1 + d1, db2 + d2
+    for i in range(n_in):
+        _close(dWi[i], g["dWin%d" % i], "DenseBlockEnd dWin", rtol=2e-5, atol=2e-5)
+    for i in range(n_out):
+        _close(dWo[i], g["dWout%d" % i], "DenseBlockEnd dWout", rtol=2e-5, atol=2e-5)
+    assert abs(db1 - float(g["dbeta1"][0])) <= 2e-5 * abs(float(g["dbeta1"][0])) + 1e-5
+    assert abs(db2 - float(g["dbeta2"][0])) <= 2e-5 * abs(float(g["dbeta2"][0])) + 1e-5
+
+
+def test_multitask_head_golden():
+    """multitask_logits + 'cross_entropy' training loss executed from the reference
+    (model_operatos.py:792-864, multitask_classifier.py:41-44,187-209)."""
+    g = _load("multitask_head.npz")
+    B = g["feat"].shape[0]
+    loss, logits = orc.multitask_ce_forward(g["feat"], g["W"], g["b"], g["labels"], g["weights"], B)
+    _close(logits, g["logits"], "logits", rtol=1e-5, atol=1e-6)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    dfeat, dW, db = orc.multitask_ce_backward(g["feat"], g["W"], logits, g["labels"], g["weights"], B)
+    _close(dfeat, g["dfeat"], "dfeat", rtol=2e-5, atol=1e-6)
+    _close(dW, g["dW"], "dW", rtol=2e-5, atol=1e-6)
+    _close(db, g["db"], "db", rtol=2e-5, atol=1e-6)
+
+
 def test_graph_pool_golden():
     g = _load("graph_pool.npz")
     for b, n in enumerate(g["ns"]):
