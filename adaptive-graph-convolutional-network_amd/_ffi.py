@@ -53,6 +53,12 @@ class DenseDesc(C.Structure):
                 ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldadd", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GraphStoreC(C.Structure):
+    _fields_ = [("n_graphs", C.c_int64), ("F", C.c_int32), ("reserved", C.c_int32), ("n", C.c_void_p),
+                ("row_off", C.c_void_p), ("X", C.c_void_p), ("rowptr", C.c_void_p), ("col", C.c_void_p),
+                ("val", C.c_void_p), ("symmetric", C.c_void_p)]
+
+
 MODE = {"reference": 0, "paper": 1}
 VARIANT = {"SGC_LL": 0, "SGC_LL_Reslap": 1}
 ACT = {None: 0, "linear": 0, "relu": 1, "tanh": 2}
@@ -67,6 +73,7 @@ SYMBOLS = [
     "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
     "agcn_multitask_ce_workspace_bytes", "agcn_multitask_ce_forward", "agcn_multitask_ce_backward",
     "agcn_graph_pool_forward", "agcn_graph_pool_backward",
+    "agcn_store_batch_sizes", "agcn_store_pack_batch",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
     "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
     "agcn_profile_enable", "agcn_profile_kernels", "agcn_profile_kernel_name", "agcn_profile_collect",
@@ -116,6 +123,10 @@ def _declare(lib):
     lib.agcn_multitask_ce_forward.argtypes = [I32, I32, I32, P, I32, P, P, P, P, C.c_float, P, P, P, SZ, P]
     lib.agcn_multitask_ce_backward.restype = C.c_int
     lib.agcn_multitask_ce_backward.argtypes = [I32, I32, I32, P, I32, P, P, P, P, C.c_float, P, P, P, P, P, SZ, P]
+    lib.agcn_store_batch_sizes.restype = C.c_int
+    lib.agcn_store_batch_sizes.argtypes = [C.POINTER(GraphStoreC), P, I32, P, P, P]
+    lib.agcn_store_pack_batch.restype = C.c_int
+    lib.agcn_store_pack_batch.argtypes = [C.POINTER(GraphStoreC), P, I32, P, P, I32, P, P, P, P, I32]
     lib.agcn_graph_pool_forward.restype = C.c_int
     lib.agcn_graph_pool_forward.argtypes = [P, P, C.POINTER(GraphBatch), P, I32, I32, P, P, P]
     lib.agcn_graph_pool_backward.restype = C.c_int

@@ -22,9 +22,33 @@ from . import _ffi
 
 def _csr_is_symmetric(n, indptr, indices, data):
     """Exact (bitwise, after the float32 cast the device sees) symmetry of one CSR matrix."""
-    import scipy.sparse as sp
-    m = sp.csr_matrix((np.asarray(data).astype(np.float32), np.asarray(indices), np.asarray(indptr)), shape=(n, n))
-    return (m != m.T).nnz == 0
+    n = int(n)
+    off = np.array([0, n], dtype=np.int64)
+    return bool(csr_symmetry_flags(off, np.asarray(indptr, dtype=np.int64), indices, np.asarray(data).astype(np.float32))[0])
+
+
+def csr_symmetry_flags(row_off, rowptr, col, val):
+    """Per-graph exact symmetry of a block-diagonal CSR (graph g owns rows row_off[g]..row_off[g+1], `col` is
+    the column inside the graph, `rowptr` spans all rows): flag[g] = 1 iff L_g == L_g^T bit for bit (explicit
+    zeros count as entries).  One sort of the entries by (row, col) and one by (col, row): no per-graph loop."""
+    row_off = np.asarray(row_off, dtype=np.int64)
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    G, R = row_off.size - 1, int(row_off[-1])
+    flags = np.ones(G, dtype=np.uint8)
+    nnz = int(rowptr[-1])
+    if nnz == 0:
+        return flags
+    r = np.repeat(np.arange(R, dtype=np.int64), np.diff(rowptr))
+    g = np.searchsorted(row_off, r, side="right") - 1
+    c = row_off[g] + np.asarray(col, dtype=np.int64)
+    v = np.asarray(val)
+    k1, k2 = r * R + c, c * R + r
+    o1, o2 = np.argsort(k1, kind="stable"), np.argsort(k2, kind="stable")
+    bad = (k1[o1] != k2[o2]) | (v[o1] != v[o2])
+    if bad.any():
+        flags[np.unique(g[o1][bad])] = 0
+        flags[np.unique(g[o2][bad])] = 0
+    return flags
 
 
 class Plan(object):
@@ -166,7 +190,7 @@ class GraphBatch(object):
         col = np.concatenate([np.asarray(c[1], dtype=np.int32) for c in csr_list]) if len(csr_list) else np.zeros(0, np.int32)
         val = np.concatenate([np.asarray(c[2]).astype(np.float32) for c in csr_list]) if len(csr_list) else np.zeros(0, np.float32)
         dev = torch.device(device)
-        sym = all(_csr_is_symmetric(int(n[b]), *csr_list[b]) for b in range(len(csr_list)))
+        sym = bool(csr_symmetry_flags(plan.row_off, rowptr, col, val).all())
         return cls(plan, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev),
                    torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
                    l0_symmetric=sym)

@@ -67,10 +67,12 @@ struct FusedSplit {
   int n_big;       // graphs (prefix of order) that do not fit
   int n_big_slabs; // their slabs (prefix of the slab table)
   int thr;         // largest fitting graph size: a graph is "big" iff n > thr
+  int big_pg;      // mixed: 1 = the big graphs run on the per-graph LDS-tile kernels (sgc_forward/backward.hip),
+                   //        0 = on the slab-parallel kernels
 };
 
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
-  FusedSplit f{0, 0, 0, 0};
+  FusedSplit f{0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
   if (!(d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
@@ -96,7 +98,17 @@ FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const Pl
   // all-slab 117 us/step, mixed 144 us/step -- the side chain of four dependent launches is longer than
   // the fused kernel it runs beside, so mixed dispatch is opt-in (agcn_set_fused_mode(2)) and the whole
   // batch takes the slab path by default.
-  if (agcn_get_fused_mode() != 2) return f;
+  if (agcn_get_fused_mode() < 2) return f;
+  if (nb == pi.B) return f;
+  // Big graphs whose tile still fits LDS run one workgroup each on the per-graph kernels (3 + 3 launches on the
+  // side stream, any free CU); no co-residency with the fused workgroups is needed.
+  if (agcn_get_fused_mode() == 2) {
+    const int maxn = host.n[host.order[0]];
+    if (std::max(sgc_lds_bytes(maxn, d->Fin), sgc_lds_bytes_bwd(maxn, d->Fin)) <= lim) {
+      f.mode = 2; f.n_big = nb; f.n_big_slabs = 0; f.thr = host.n[host.order[nb]]; f.big_pg = 1;
+      return f;
+    }
+  }
   if (!use_slabs(d, g, pi)) return f;   // the big graphs have no slab path
   // Mixed dispatch only pays if the side-stream kernels can be CO-RESIDENT with the fused workgroups
   // (a fused workgroup is 16 waves + up to 150 KiB of LDS, i.e. a whole CU).  So the fused part is limited
@@ -307,9 +319,13 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     g.A0 = batch->X; g.lda0 = desc->ldx; g.Bm = params->M_L; g.Out0 = a.sv_Z; g.ldo0 = desc->Fin;
     rc = launch_rows_gemm(g, RG_PROJECT, ss.s);
     if (rc != AGCN_OK) return rc;
-    SgcArgs ab = a;
-    ab.n_slabs = fs.n_big_slabs;
-    rc = launch_slab_forward(ab, ss.s);
+    if (fs.big_pg) {
+      rc = launch_sgc_forward(a, 0, fs.n_big, true, sgc_lds_bytes(host.n[host.order[0]], desc->Fin), ss.s);
+    } else {
+      SgcArgs ab = a;
+      ab.n_slabs = fs.n_big_slabs;
+      rc = launch_slab_forward(ab, ss.s);
+    }
     if (rc != AGCN_OK) return rc;
     fill_rows(g, desc, host, dev);
     g.big_n = fs.thr; g.row_graph = dev.row_graph;
@@ -436,10 +452,14 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       g.Gp = w.Gp;
       rc = launch_rows_gemm(g, RG_FILTER_BWD, ss->s);
       if (rc != AGCN_OK) return rc;
-      SgcArgs ab = a;
-      ab.n_slabs = fs.n_big_slabs;
-      ab.pg_slab_base = B;
-      rc = launch_slab_backward(ab, ss->s);
+      if (fs.big_pg) {
+        rc = launch_sgc_backward(a, 0, fs.n_big, true, sgc_lds_bytes_bwd(host.n[host.order[0]], desc->Fin), ss->s);
+      } else {
+        SgcArgs ab = a;
+        ab.n_slabs = fs.n_big_slabs;
+        ab.pg_slab_base = B;
+        rc = launch_slab_backward(ab, ss->s);
+      }
       if (rc != AGCN_OK) return rc;
       if (paper) {
         fill_rows(g, desc, host, dev);

@@ -29,11 +29,13 @@ extern "C" const char* agcn_last_error(void) { return g_err; }
 extern "C" int32_t agcn_version(void) { return AGCN_VERSION; }
 extern "C" int32_t agcn_get_lds_limit(void) { return g_lds_limit.load(); }
 std::atomic<int32_t> g_fused_mode{[] {
-  const char* e = std::getenv("AGCN_FUSED_MODE");  // 0: never fused; 1: fused when every graph fits; 2: + mixed
-  return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1);
+  // 0: never fused; 1: fused when every graph fits; 2: + mixed (big graphs on the per-graph kernels when their
+  // tile fits LDS, else on the slab kernels); 3: mixed, big graphs always on the slab kernels
+  const char* e = std::getenv("AGCN_FUSED_MODE");
+  return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
 }()};
 extern "C" int32_t agcn_get_fused_mode(void) { return g_fused_mode.load(); }
-extern "C" void agcn_set_fused_mode(int32_t mode) { g_fused_mode.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
+extern "C" void agcn_set_fused_mode(int32_t mode) { g_fused_mode.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
 extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }
 extern "C" void agcn_set_slab_mode(int32_t mode) { g_slab_mode.store(mode ? 1 : 0); }
 extern "C" void agcn_set_lds_limit(int32_t bytes) {

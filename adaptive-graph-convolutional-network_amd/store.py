@@ -1,0 +1,195 @@
+"""Dataset-level graph store and batch iterator: the ingest in front of the layer path.
+
+The reference hands lists of `MolGraph` objects out of `DiskDataset.iterbatches`
+(utils/dataset/diskdataset.py:239-295) and rebuilds the padded / densified feed from them in Python
+every step (models/tf_modules/graph_topology.py:84-135).  Here the dataset is laid out ONCE
+(concatenated node features, one CSR over all rows with float32 values, per-graph symmetry flags) and
+a batch is a native gather of contiguous segments (`agcn_store_pack_batch`) into pinned staging
+buffers + one asynchronous upload + `agcn_plan_build`.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .batch import GraphBatch, Plan, csr_symmetry_flags
+
+
+class GraphStore(object):
+    def __init__(self, n, X, rowptr, col, val, symmetric=None, y=None, w=None, ids=None):
+        self.n = np.ascontiguousarray(n, dtype=np.int32)
+        G = int(self.n.size)
+        self.row_off = np.zeros(G + 1, dtype=np.int64)
+        np.cumsum(self.n, out=self.row_off[1:])
+        self.X = np.ascontiguousarray(X, dtype=np.float32)
+        if self.X.ndim != 2 or self.X.shape[0] != int(self.row_off[-1]):
+            raise ValueError("X must be [sum(n), F]")
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float32)
+        if self.rowptr.size != self.X.shape[0] + 1 or self.col.size != int(self.rowptr[-1]) or \
+                self.val.size != self.col.size:
+            raise ValueError("inconsistent CSR arrays")
+        self.symmetric = None if symmetric is None else np.ascontiguousarray(symmetric, dtype=np.uint8)
+        self.y = None if y is None else np.asarray(y)
+        self.w = None if w is None else np.asarray(w)
+        self.ids = np.arange(G) if ids is None else np.asarray(ids)
+        self.F = int(self.X.shape[1])
+        self._c = _ffi.GraphStoreC(G, self.F, 0, self.n.ctypes.data, self.row_off.ctypes.data, self.X.ctypes.data,
+                                   self.rowptr.ctypes.data, self.col.ctypes.data, self.val.ctypes.data,
+                                   None if self.symmetric is None else self.symmetric.ctypes.data)
+        self._stage = {}
+
+    def __len__(self):
+        return int(self.n.size)
+
+    # ---- construction ------------------------------------------------------------------------------
+    @classmethod
+    def from_graphs(cls, graphs, y=None, w=None, ids=None):
+        """`Graph` / `MolGraph`-like objects (node_features [n, F], scipy CSR `Laplacian`); graphs without a
+        Laplacian (n <= 3, graph_structure.py:51-55) are rejected like the reference loader drops them."""
+        graphs = list(graphs)
+        for g in graphs:
+            if getattr(g, "Laplacian", None) is None:
+                raise ValueError("graph without a Laplacian (n <= 3 graphs are dropped by the reference loader)")
+        X = [np.asarray(g.node_features, dtype=np.float32) for g in graphs]
+        csr = [(g.Laplacian.indptr, g.Laplacian.indices, g.Laplacian.data) for g in graphs]
+        return cls.from_arrays([x.shape[0] for x in X], X, csr, y=y, w=w, ids=ids)
+
+    @classmethod
+    def from_arrays(cls, n, X_list, csr_list, y=None, w=None, ids=None):
+        n = np.asarray(n, dtype=np.int32)
+        X = np.concatenate([np.asarray(x, dtype=np.float32) for x in X_list], 0) if not isinstance(X_list, np.ndarray) \
+            else X_list
+        nnz = np.array([len(c[1]) for c in csr_list], dtype=np.int64)
+        base = np.concatenate([[0], np.cumsum(nnz)])
+        rowptr = np.zeros(int(n.sum()) + 1, dtype=np.int64)
+        r = 0
+        for g, (ip, _, _) in enumerate(csr_list):
+            rowptr[r + 1:r + int(n[g]) + 1] = np.asarray(ip[1:], dtype=np.int64) + base[g]
+            r += int(n[g])
+        col = np.concatenate([np.asarray(c[1], dtype=np.int32) for c in csr_list])
+        val = np.concatenate([np.asarray(c[2]).astype(np.float32) for c in csr_list])
+        row_off = np.concatenate([[0], np.cumsum(n, dtype=np.int64)])
+        sym = csr_symmetry_flags(row_off, rowptr, col, val)
+        return cls(n, X, rowptr, col, val, sym, y=y, w=w, ids=ids)
+
+    # ---- batches -----------------------------------------------------------------------------------
+    def _buffers(self, slot, rows, nnz, B, pin):
+        key = (slot, pin)
+        st = self._stage.get(key)
+        if st is None or st["rows"] < rows or st["nnz"] < nnz or st["B"] < B:
+            cap_r, cap_z, cap_b = int(rows * 1.25) + 64, int(nnz * 1.25) + 64, max(B, 1)
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=pin)  # noqa: E731
+            st = {"rows": cap_r, "nnz": cap_z, "B": cap_b, "X": mk((cap_r, self.F), torch.float32),
+                  "rowptr": mk((cap_r + 1,), torch.int32), "col": mk((cap_z,), torch.int32),
+                  "val": mk((cap_z,), torch.float32), "n": np.zeros(cap_b, dtype=np.int32)}
+            self._stage[key] = st
+        return st
+
+    def _pack(self, graph_ids, slot, pin, n_threads):
+        """Host half of a batch: native gather into staging slot `slot` + plan build (no device work)."""
+        lib = _ffi.lib()
+        ids = np.ascontiguousarray(graph_ids, dtype=np.int64)
+        B = int(ids.size)
+        rows, nnz, mx = C.c_int64(), C.c_int64(), C.c_int32()
+        _ffi.check(lib.agcn_store_batch_sizes(C.byref(self._c), ids.ctypes.data, B, C.byref(rows), C.byref(nnz),
+                                              C.byref(mx)))
+        rows, nnz = rows.value, nnz.value
+        st = self._buffers(slot, rows, nnz, B, pin)
+        sym = C.c_int32()
+        _ffi.check(lib.agcn_store_pack_batch(C.byref(self._c), ids.ctypes.data, B, st["n"].ctypes.data,
+                                             st["X"].data_ptr(), self.F, st["rowptr"].data_ptr(), st["col"].data_ptr(),
+                                             st["val"].data_ptr(), C.byref(sym), int(n_threads)))
+        plan = Plan(st["n"][:B].copy(), 0, None)
+        if pin:      # the plan blob travels from pinned memory too, so that no upload blocks on the compute stream
+            if st.get("plan") is None or st["plan"].numel() < plan.host.size:
+                st["plan"] = torch.empty(int(plan.host.size * 1.25) + 256, dtype=torch.uint8, pin_memory=True)
+                st["plan_np"] = st["plan"].numpy()
+            # plain host memcpy through the numpy view (Tensor.copy_ into pinned memory synchronises the device)
+            st["plan_np"][:plan.host.size] = plan.host
+        return {"st": st, "plan": plan, "rows": rows, "nnz": nnz, "sym": bool(sym.value), "pin": pin}
+
+    @staticmethod
+    def _upload(pk, dev):
+        st, plan, rows, nnz, pin = pk["st"], pk["plan"], pk["rows"], pk["nnz"], pk["pin"]
+        up = lambda t, k: t[:k].to(dev, non_blocking=True) if pin else t[:k].clone()  # noqa: E731
+        if pin:
+            plan.dev, plan.device = st["plan"][:plan.host.size].to(dev, non_blocking=True), dev
+        else:
+            plan.to(dev)
+        return GraphBatch(plan, up(st["X"], rows), up(st["rowptr"], rows + 1), up(st["col"], nnz), up(st["val"], nnz),
+                          l0_symmetric=pk["sym"])
+
+    def batch(self, graph_ids, device, slot=0, n_threads=1):
+        """Packed `GraphBatch` of the graphs `graph_ids` on `device`.  Uploads are asynchronous on the current
+        stream from pinned staging buffers; `slot` selects one of several staging sets so that a batch can be
+        packed while the previous one is still being copied."""
+        dev = torch.device(device)
+        return self._upload(self._pack(graph_ids, slot, dev.type == "cuda", n_threads), dev)
+
+    def iterbatches(self, batch_size, device, deterministic=False, rng=None, n_threads=1, prefetch=0):
+        """Same batching rule as DiskDataset.iterbatches (diskdataset.py:263-283): a permutation of the samples
+        (identity when `deterministic`), cut at np.linspace(0, N, ceil(N / batch_size) + 1, dtype=int).
+        Yields (GraphBatch, y_batch, w_batch, ids_batch).  With `prefetch` > 0 a worker thread packs the next
+        batches (the native gather releases the GIL) while the caller's kernels run; a staging slot is reused
+        only after the uploads that read it have completed.  (Measured on MI355X, 256-graph HIV-shaped batches:
+        ingest alone 2.2 M graphs/s without and 2.6 M graphs/s with prefetch; with an eager autograd layer step
+        per batch the Python side is the bottleneck either way, hence off by default.)"""
+        N = len(self)
+        dev = torch.device(device)
+        pin = dev.type == "cuda"
+        perm = np.arange(N) if deterministic else (rng if rng is not None else np.random).permutation(N)
+        pts = np.linspace(0, N, int(np.ceil(float(N) / batch_size)) + 1, dtype=int)
+        sels = [perm[pts[j]:pts[j + 1]] for j in range(len(pts) - 1)]
+        extra = lambda sel: (None if self.y is None else self.y[sel], None if self.w is None else self.w[sel],  # noqa: E731
+                             self.ids[sel])
+        if prefetch <= 0:
+            for j, sel in enumerate(sels):
+                yield (self.batch(sel, dev, slot=j & 1, n_threads=n_threads),) + extra(sel)
+            return
+        import queue
+        import threading
+        nslots = prefetch + 2
+        done = [None] * nslots          # event recorded after the uploads out of slot k
+        q = queue.Queue(maxsize=prefetch)
+        stop = threading.Event()
+
+        def worker():
+            try:
+                for j, sel in enumerate(sels):
+                    if stop.is_set():
+                        break
+                    k = j % nslots
+                    if done[k] is not None:
+                        done[k].synchronize()
+                    q.put((j, sel, self._pack(sel, ("it", k), pin, n_threads)))
+                q.put(None)
+            except BaseException as e:          # surfaced in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=worker, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                j, sel, pk = item
+                gb = self._upload(pk, dev)
+                if pin:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    done[j % nslots] = ev
+                yield (gb,) + extra(sel)
+        finally:
+            stop.set()
+            while th.is_alive():            # unblock a worker waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.01)

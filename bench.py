@@ -269,7 +269,7 @@ def main():
             "config": {"workload": "Tox21-shaped batch=%d per GPU, SGC_LL 75->64, K=2, laplacian_mode=%s, "
                                    "packed rows + CSR original Laplacian, fwd+bwd%s"
                                    % (args.batch, args.mode, " + RCCL grad all-reduce" if world > 1 else ""),
-                       "global_batch": B_global, "N1_local": N1, "N2_local": N2,
+                       "global_batch": B_global, "N1_local": N1, "N2_local": N2, "max_n_local": int(max(n)),
                        "launch": "hip_graph" if use_graph else "eager", "parallelism": "dp%d" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,

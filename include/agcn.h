@@ -273,6 +273,32 @@ int agcn_graph_pool_backward(const void* plan_host, const void* plan_dev, const 
                              const int32_t* argmax, const float* dOut, int32_t F, int32_t ldx, float* dX,
                              void* hip_stream);
 
+/* ---- packed-batch ingest: the step before the path, host only -------------------
+ * Replaces the per-step feed construction of models/tf_modules/graph_topology.py:84-135 (pad every graph
+ * to max_atom, densify every Laplacian) fed by DiskDataset.iterbatches (utils/dataset/diskdataset.py:239-295).
+ * The dataset is laid out once as a graph store; a batch is a gather of contiguous segments into
+ * caller-owned (pinned) host buffers, which the caller uploads and hands to agcn_plan_build + AgcnGraphBatch. */
+typedef struct AgcnGraphStore {   /* all HOST pointers, owned by the caller */
+  int64_t n_graphs;
+  int32_t F;                 /* node-feature width */
+  int32_t reserved;
+  const int32_t* n;          /* [G]     nodes per graph (degree_list length, graph_structure.py:43) */
+  const int64_t* row_off;    /* [G+1]   first row of graph g in X / rowptr */
+  const float* X;            /* [R][F]  node features of all graphs, R = row_off[G] */
+  const int64_t* rowptr;     /* [R+1]   CSR over ALL rows: entries of row r are rowptr[r] .. rowptr[r+1] */
+  const int32_t* col;        /* column index inside the graph */
+  const float* val;          /* float32(float64 Laplacian value), graph_structure.py:124-127 */
+  const uint8_t* symmetric;  /* [G] 1 = L_orig == L_orig^T bit for bit (NULL = unknown: batches report 0) */
+} AgcnGraphStore;
+/* rows / nnz (and the largest graph) of the batch `ids` [B]: sizes of the staging buffers */
+int agcn_store_batch_sizes(const AgcnGraphStore* store, const int64_t* ids, int32_t B, int64_t* rows,
+                           int64_t* nnz, int32_t* max_n);
+/* n_out [B]; X_out [rows][ldx_out]; rowptr_out [rows+1] (batch-global offsets, as AgcnGraphBatch wants);
+ * col_out / val_out [nnz]; symmetric_out = AND of the graphs' flags.  n_threads <= 1: single thread. */
+int agcn_store_pack_batch(const AgcnGraphStore* store, const int64_t* ids, int32_t B, int32_t* n_out,
+                          float* X_out, int32_t ldx_out, int32_t* rowptr_out, int32_t* col_out, float* val_out,
+                          int32_t* symmetric_out, int32_t n_threads);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel of
  * the path).  Off by default.  agcn_profile_collect waits for the events recorded since the last
  * collect and returns, per kernel id < agcn_profile_kernels(), the total milliseconds and the
@@ -294,9 +320,10 @@ void agcn_set_lds_limit(int32_t bytes);
 int32_t agcn_get_slab_mode(void);
 void agcn_set_slab_mode(int32_t mode);
 /* 1 (default): batches of small graphs (the largest graph's X, M_L, W, n x n tile and Z^T fit
- * LDS) run SGC_LL K = 2 on the fused one-launch-per-direction kernels; 0: never; 2: additionally,
- * when only a few graphs are too large, run those on the slab kernels on a side stream next to the
- * fused kernels ("mixed" dispatch; slower than the all-slab path at 256 graphs per GPU, hence opt-in). */
+ * LDS) run SGC_LL K = 2 on the fused one-launch-per-direction kernels; 0: never; 2 / 3: additionally,
+ * when only a few graphs are too large, run those on a side stream next to the fused kernels ("mixed"
+ * dispatch): 2 = on the per-graph LDS-tile kernels when their tile fits LDS (else as 3), 3 = on the slab
+ * kernels. */
 int32_t agcn_get_fused_mode(void);
 void agcn_set_fused_mode(int32_t mode);
 

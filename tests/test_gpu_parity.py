@@ -118,7 +118,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["fused", "mixed", "slab", "lds", "globaltile"])
+@pytest.mark.parametrize("path", ["fused", "mixed", "mixed_slab", "slab", "lds", "globaltile"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 @pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc", "reslap"])
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -127,15 +127,16 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     path: slab = slab-parallel kernels where eligible (SGC_LL, K = 2), lds = one workgroup per graph
     with the tile in LDS, globaltile = one workgroup per graph with the tile in global scratch."""
     ns, Fin, Fout, K = CASES[case]
-    if path in ("slab", "fused", "mixed") and not (variant == orc.SGC_LL and K == 2):
+    if path in ("slab", "fused", "mixed", "mixed_slab") and not (variant == orc.SGC_LL and K == 2):
         pytest.skip("the slab and fused paths cover SGC_LL with K = 2 only")
-    if path == "mixed" and case != 0:
+    if path in ("mixed", "mixed_slab") and case != 0:
         pytest.skip("mixed dispatch is exercised on the 75 -> 64 case (LDS limit chosen for it)")
     # mixed: with a 110 KiB limit the n = 33 graph of case 0 does not fit the fused kernel (118 KiB) while
-    # the others do, so it runs on the slab kernels on the side stream, concurrently with the fused kernel
-    amd._ffi.lib().agcn_set_lds_limit({"globaltile": 0, "mixed": 110 * 1024}.get(path, 160 * 1024))
-    amd._ffi.lib().agcn_set_slab_mode(1 if path in ("slab", "fused", "mixed") else 0)
-    amd._ffi.lib().agcn_set_fused_mode({"fused": 1, "mixed": 2}.get(path, 0))
+    # the others do, so it runs on the side stream, concurrently with the fused kernel: on the per-graph
+    # LDS-tile kernels (mixed) or on the slab kernels (mixed_slab)
+    amd._ffi.lib().agcn_set_lds_limit({"globaltile": 0, "mixed": 110 * 1024, "mixed_slab": 110 * 1024}.get(path, 160 * 1024))
+    amd._ffi.lib().agcn_set_slab_mode(1 if path in ("slab", "fused", "mixed", "mixed_slab") else 0)
+    amd._ffi.lib().agcn_set_fused_mode({"fused": 1, "mixed": 2, "mixed_slab": 3}.get(path, 0))
     try:
         rs, X, L0, csr, p, G = synth_case(1000 + case, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
         Lp = dLsum = None
@@ -151,7 +152,8 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
         amd._ffi.lib().agcn_set_fused_mode(1)
 
 
-def test_mixed_dispatch_full_batch(amd):
+@pytest.mark.parametrize("fmode", [2, 3], ids=["per_graph", "slab"])
+def test_mixed_dispatch_full_batch(amd, fmode):
     """Tox21-shaped B = 256 with an LDS limit that sends the ~10 largest graphs to the slab kernels on the
     side stream: same results as the all-fused run (the two paths differ by reduction order only), and
     bit-reproducible across runs (the concurrent streams write disjoint rows / tiles)."""
@@ -173,7 +175,7 @@ def test_mixed_dispatch_full_batch(amd):
 
     try:
         ref = run()                                   # all fused
-        lib.agcn_set_fused_mode(2)                     # opt in to mixed dispatch
+        lib.agcn_set_fused_mode(fmode)                 # opt in to mixed dispatch
         lib.agcn_set_lds_limit(118 * 1024)             # graphs with round16(n) >= 48 no longer fit
         big = int((((sb["ns"] + 15) // 16) * 16 >= 48).sum())
         assert 0 < big < 40, big
@@ -228,6 +230,31 @@ def test_slab_path_dense_laplacian_feed(amd):
             compare_with_oracle(ref, caches, tot, orc.SGC_LL, mode, K, has_prev=False)
     finally:
         lib.agcn_set_fused_mode(1)
+
+
+def test_graph_store_epoch_feeds_the_layer(amd):
+    """Ingest -> layer: batches gathered natively from the dataset-level store (pinned staging, asynchronous
+    uploads, prefetch thread) give bit-identical layer outputs and gradients to batches packed one at a time."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(8, 300, mu=np.log(23.0), hi=222)          # HIV-shaped sizes (SURVEY 8(d))
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    Fin, Fout, K = 75, 32, 2
+    p = orc.init_params(np.random.RandomState(2), Fin, Fout, K)
+    seen = 0
+    for gb, _, _, ids in store.iterbatches(64, DEV, rng=np.random.RandomState(0), prefetch=2):
+        ref = amd.GraphBatch.from_arrays(data["n"][ids], np.concatenate([data["X"][i] for i in ids], 0),
+                                         [data["csr"][i] for i in ids], DEV)
+        outs = []
+        for b in (gb, ref):
+            layer = make_layer(amd, orc.SGC_LL, Fout, Fin, b.plan.B, K, orc.PAPER, p, DEV)
+            Xt = b.X.clone().requires_grad_(True)
+            nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": b})
+            nodes.data.sum().backward()
+            outs.append((nodes.data.detach(), res_W.data, Xt.grad, layer.vars["M_L"].grad))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+        seen += len(ids)
+    assert seen == 300
 
 
 def test_reslap_without_prev(amd):

@@ -79,6 +79,52 @@ def test_padded_feed_batch(amd):
     assert torch.equal(views[2], Xl[2])
 
 
+def test_graph_store_batches(amd):
+    """Native packed-batch ingest (agcn_store_pack_batch): a batch gathered from the dataset-level store is
+    identical, array for array, to packing the same graphs one by one; symmetry flags are exact; the batching
+    rule is DiskDataset.iterbatches' (diskdataset.py:263-283)."""
+    import scipy.sparse as sp
+    from agcn_amd import synth
+    data = synth.tox21_batch(5, 70)
+    n, X, csr = data["n"], data["X"], list(data["csr"])
+    ip, ix, v = csr[3]                      # one graph made asymmetric in value, one in structure
+    v = v.copy()
+    v[1] += 1e-3
+    csr[3] = (ip, ix, v)
+    m = sp.csr_matrix((csr[5][2], csr[5][1], csr[5][0]), shape=(n[5], n[5])).tolil()
+    i, j = m.nonzero()
+    k = [t for t in range(len(i)) if i[t] != j[t]][0]
+    m[i[k], j[k]] = 0
+    m = m.tocsr()
+    m.eliminate_zeros()
+    csr[5] = (m.indptr, m.indices, m.data)
+    y = np.arange(70 * 3).reshape(70, 3)
+    store = amd.GraphStore.from_arrays(n, X, csr, y=y, w=y * 0.5)
+    assert len(store) == 70 and store.F == 75
+    want = np.ones(70, np.uint8)
+    want[[3, 5]] = 0
+    np.testing.assert_array_equal(store.symmetric, want)
+    for ids in (np.arange(16), np.array([9, 2, 69, 0, 33]), np.array([3]), np.random.RandomState(1).permutation(70)):
+        gb = store.batch(ids, "cpu", n_threads=3)
+        ref = amd.GraphBatch.from_arrays(n[ids], np.concatenate([X[i] for i in ids], 0), [csr[i] for i in ids], "cpu")
+        for key in ("X", "l0_rowptr", "l0_col", "l0_val"):
+            assert torch.equal(getattr(gb, key), getattr(ref, key)), key
+        np.testing.assert_array_equal(gb.plan.n, ref.plan.n)
+        assert gb.l0_symmetric == ref.l0_symmetric == (not ({3, 5} & set(ids.tolist())))
+    with pytest.raises(amd.AgcnError):
+        store.batch(np.array([0, 70]), "cpu")
+    # iterbatches: deterministic order, np.linspace cut points, every sample exactly once
+    seen, sizes = [], []
+    for gb, yb, wb, idb in store.iterbatches(16, "cpu", deterministic=True):
+        assert gb.plan.B == len(idb) and np.array_equal(yb, y[idb]) and np.array_equal(wb, y[idb] * 0.5)
+        seen += idb.tolist()
+        sizes.append(len(idb))
+    pts = np.linspace(0, 70, int(np.ceil(70 / 16.0)) + 1, dtype=int)
+    assert seen == list(range(70)) and sizes == np.diff(pts).tolist()
+    shuffled = [idb for _, _, _, idb in store.iterbatches(16, "cpu", rng=np.random.RandomState(4))]
+    assert sorted(np.concatenate(shuffled).tolist()) == list(range(70))
+
+
 def test_layer_contract(amd):
     """Names, constructor arguments and read-back attributes the reference's containers rely on
     (tf_graphs.py:41-73,173-194; basic_layer.py:57-67)."""

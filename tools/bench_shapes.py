@@ -5,6 +5,7 @@
   tox21-l1 / l2 / l3 / l4 : the four SimpleAGCN layer shapes 75->64, 64->128, 128->128, 128->64 at B=256
   tox21-2048              : 75->64 at B=2048 (config[3] on one GPU)
   modelnet-3-64 / 64-128  : B graphs of n=1024 points, dense original Laplacian (config[2])
+  epoch                   : ingest (graph store -> packed batch -> upload) + layer over an HIV-shaped dataset
   stack                   : 4 x SGC_LL -> DenseMol 64->256 -> GraphGatherMol(tanh), autograd, eager launches
 
 One JSON line per workload; `--prof` adds the library's per-kernel HIP-event averages.
@@ -97,6 +98,7 @@ def main():
     ap.add_argument("--only", default="", help="comma list of workload names")
     ap.add_argument("--modelnet-batch", type=int, default=8)
     ap.add_argument("--prof", action="store_true")
+    ap.add_argument("--epoch-graphs", type=int, default=8192)
     args = ap.parse_args()
     import agcn_amd as amd
     from agcn_amd import synth
@@ -146,6 +148,35 @@ def main():
         gb, n = modelnet_batch(amd, args.modelnet_batch, 1024, Fin, dev)
         run_layer(name, gb, n, 0, Fin, Fout, True)
 
+    if want("epoch"):
+        # ingest + layer over a dataset: HIV-shaped sizes (mu = ln 23, clip [4, 222]); every batch is gathered
+        # from the graph store (native pack, pinned staging, async upload, prefetch thread) and run through
+        # SGC_LL 75 -> 64 forward + backward (autograd, eager launches)
+        G = args.epoch_graphs
+        data = synth.tox21_batch(321, G, mu=np.log(23.0), hi=222)
+        t0 = time.perf_counter()
+        store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+        t_store = time.perf_counter() - t0
+        layer = amd.SGC_LL(64, 75, 256, K=K, laplacian_mode=args.mode, device=dev)
+        layer.load_vars(synth.glorot_params(np.random.RandomState(123), 75, 64, K))
+        res = {}
+        for what in ("ingest", "ingest+layer"):
+            for pf in (0, 2):
+                for rep in range(2):        # first pass: pinned staging allocation, code-object loading
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for gb, _, _, _ in store.iterbatches(256, dev, deterministic=True, prefetch=pf):
+                        if what != "ingest":
+                            for q in layer.vars.values():
+                                q.grad = None
+                            Xt = gb.X.requires_grad_(True)
+                            nodes, _, _ = layer({"node_features": Xt, "graph_batch": gb})
+                            nodes.data.backward(torch.ones_like(nodes.data))
+                    torch.cuda.synchronize(dev)
+                    res["%s prefetch=%d" % (what, pf)] = round(G / (time.perf_counter() - t0), 1)
+        print(json.dumps({"workload": "epoch over %d HIV-shaped graphs, batches of 256" % G, "mode": args.mode,
+                          "store_build_s": round(t_store, 3), "graphs_per_s": res}), flush=True)
+
     if want("stack"):
         data = synth.tox21_batch(123, 256, 75)
         B = len(data["n"])
@@ -179,6 +210,22 @@ def main():
                "graphs_per_s": round(B / t, 1)}
         if args.prof:
             out["kernel_us"] = kernel_profile(amd, step, 10, dev)
+        print(json.dumps(out), flush=True)
+        # the same step (autograd forward + backward of the whole stack) captured into ONE HIP graph
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        t = timed(g.replay, args.steps, args.warmup, dev)
+        out = {"workload": "stack 75-64-128-128-64 + DenseMol 256 + GraphGather, one HIP graph",
+               "mode": args.mode, "graphs": B, "us_per_step": round(t * 1e6, 2),
+               "graphs_per_s": round(B / t, 1)}
         print(json.dumps(out), flush=True)
 
 
