@@ -27,6 +27,32 @@ def _f32c(t, what):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+class CastRowsFunction(torch.autograd.Function):
+    """Storage-dtype conversion of a feature matrix (bf16 <-> f32) through the C ABI; the gradient is cast back."""
+
+    @staticmethod
+    def forward(ctx, X, dtype):
+        _require_gpu(X, "features")
+        if X.dtype not in _DT or dtype not in _DT:
+            raise TypeError("features must be float32 or bfloat16")
+        ctx.src = X.dtype
+        if X.dtype == dtype:
+            return X
+        X = X if X.is_contiguous() else X.contiguous()
+        out = torch.empty(X.shape, dtype=dtype, device=X.device)
+        cols = X.shape[-1]
+        _ffi.check(_ffi.lib().agcn_cast_rows(X.data_ptr(), _DT[X.dtype], out.data_ptr(), _DT[dtype],
+                                             X.numel() // cols, cols, cols, cols, _stream(X.device)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return CastRowsFunction.apply(g, ctx.src), None
+
+
 class _Cfg(object):
     __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation")
 

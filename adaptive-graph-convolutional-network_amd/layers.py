@@ -22,10 +22,20 @@ import numpy as np
 import torch
 
 from .batch import GraphBatch, RowViews, TileViews
-from .functional import (GraphGatherFunction, GraphPoolFunction, MultitaskCEFunction, RowsDenseFunction, SgcLLFunction,
-                         _Cfg)
+from .functional import (CastRowsFunction, GraphGatherFunction, GraphPoolFunction, MultitaskCEFunction,
+                         RowsDenseFunction, SgcLLFunction, _Cfg)
 
 _UID_PREFIXES = defaultdict(int)
+
+
+def _in32(X):
+    """bf16-stored features are widened once at the layer input; every kernel computes in fp32."""
+    return CastRowsFunction.apply(X, torch.float32) if X.dtype == torch.bfloat16 else X
+
+
+def _out_as(Y, dtype):
+    """... and the layer output goes back to the storage dtype the features came in."""
+    return CastRowsFunction.apply(Y, torch.bfloat16) if dtype == torch.bfloat16 else Y
 
 
 def get_uid(prefix=""):
@@ -177,9 +187,9 @@ class SGC_LL(Layer):
         if gb.plan.B != self.batch_size:
             raise ValueError("batch holds %d graphs, layer was built for batch_size=%d" % (gb.plan.B, self.batch_size))
         v = self.vars
-        Y, res_L, res_W, L_sum = SgcLLFunction.apply(X, v["weight"], v["bias"], v["M_L"], v["alpha"],
+        Y, res_L, res_W, L_sum = SgcLLFunction.apply(_in32(X), v["weight"], v["bias"], v["M_L"], v["alpha"],
                                                      v.get("beta"), L_prev, gb, cfg)
-        nodes = RowViews(Y, gb.plan)
+        nodes = RowViews(_out_as(Y, X.dtype), gb.plan)
         nodes.batch = gb
         return gb, nodes, TileViews(res_L, gb.plan), TileViews(res_W, gb.plan), TileViews(L_sum, gb.plan)
 
@@ -238,7 +248,7 @@ class GraphGatherMol(Layer):
             X = gb.X
         if gb is None:
             raise ValueError("packed node_features need x['graph_batch']")
-        return GraphGatherFunction.apply(X, gb, self.activation)
+        return _out_as(GraphGatherFunction.apply(_in32(X), gb, self.activation), X.dtype)
 
 
 def _rows_of(x, key="node_features"):
@@ -307,8 +317,8 @@ class DenseMol(Layer):
     def __call__(self, x):
         gb, X = _rows_of(x)
         self.build(X.device)
-        Y = RowsDenseFunction.apply(X, self.W, self.b if self.bias else None, None, gb, "linear", True)
-        return _row_views(Y, gb)
+        Y = RowsDenseFunction.apply(_in32(X), self.W, self.b if self.bias else None, None, gb, "linear", True)
+        return _row_views(_out_as(Y, X.dtype), gb)
 
 
 class BlockEnd(Layer):
@@ -352,9 +362,9 @@ class BlockEnd(Layer):
             X3 = bo if torch.is_tensor(bo) else torch.stack(list(bo))
             Xres = X3.reshape(-1, X3.shape[-1]) if X3.dim() == 3 else X3
         self.build(X.device)
-        Y = RowsDenseFunction.apply(Xres, self.vars["weight"], None, X.contiguous(), gb,
+        Y = RowsDenseFunction.apply(_in32(Xres), self.vars["weight"], None, _in32(X).contiguous(), gb,
                                     "relu" if self.activation == "relu" else "linear", False)
-        return _row_views(Y, gb)
+        return _row_views(_out_as(Y, X.dtype), gb)
 
 
 def _source_rows(src, F, gb):
@@ -457,11 +467,11 @@ class DenseBlockEnd(Layer):
         if not terms:
             raise ValueError("DenseBlockEnd needs at least one saved activation (tf_graphs.py:281)")
         act = "relu" if self.activation == "relu" else "linear"
-        acc = X
+        acc = _in32(X)
         for i, (A, W, beta) in enumerate(terms):
             last = i == len(terms) - 1
-            acc = RowsDenseFunction.apply(A, W, None, acc.contiguous(), gb, act if last else "linear", False, beta)
-        return _row_views(acc, gb)
+            acc = RowsDenseFunction.apply(_in32(A), W, None, acc.contiguous(), gb, act if last else "linear", False, beta)
+        return _row_views(_out_as(acc, X.dtype), gb)
 
 
 class MultitaskHead(object):

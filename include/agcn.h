@@ -273,6 +273,14 @@ int agcn_graph_pool_backward(const void* plan_host, const void* plan_dev, const 
                              const int32_t* argmax, const float* dOut, int32_t F, int32_t ldx, float* dX,
                              void* hip_stream);
 
+/* Storage-dtype conversion of a [rows, cols] feature matrix (bf16 <-> f32) for the "bf16 features + fp32
+ * Laplacian" configuration: features / activations / their gradients may be stored in bf16 between layers,
+ * every kernel of the path computes in fp32.  f32 -> bf16 rounds to nearest even. */
+#define AGCN_DTYPE_F32 0
+#define AGCN_DTYPE_BF16 1
+int agcn_cast_rows(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t rows, int32_t cols,
+                   int32_t ld_src, int32_t ld_dst, void* hip_stream);
+
 /* ---- packed-batch ingest: the step before the path, host only -------------------
  * Replaces the per-step feed construction of models/tf_modules/graph_topology.py:84-135 (pad every graph
  * to max_atom, densify every Laplacian) fed by DiskDataset.iterbatches (utils/dataset/diskdataset.py:239-295).

@@ -257,6 +257,43 @@ def test_graph_store_epoch_feeds_the_layer(amd):
     assert seen == 300
 
 
+BF16_RTOL = 2.0 ** -8      # one round-to-nearest-even to bf16 (8 significand bits) of the stored value
+
+
+def test_bf16_feature_storage(amd):
+    """BASELINE config "bf16 features + fp32 Laplacian": node features, activations and their gradients are
+    STORED in bf16 between layers, every kernel computes in fp32.  Declared tolerance: the fp32 result of the
+    oracle evaluated on the bf16-rounded inputs, re-rounded to bf16 (relative 2^-8 of the largest entry);
+    tiles (res_W, res_L) stay fp32 at the usual 1e-5."""
+    ns, Fin, Fout, K = [9, 17, 5, 24, 40], 75, 64, 2
+    rs, X, L0, csr, p, G = synth_case(91, ns, Fin, Fout, K, orc.SGC_LL, atoms=False)
+    B = len(ns)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()  # noqa: E731
+    Xb = [bf(x) for x in X]
+    Gb = [bf(g) for g in G]
+    caches, tot = oracle_run(Xb, L0, p, K, orc.PAPER, orc.SGC_LL, Gb)
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(Xb, 0), csr, DEV)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, orc.PAPER, p, DEV)
+    Xt = gb.X.to(torch.bfloat16).requires_grad_(True)
+    nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+    assert nodes.data.dtype == torch.bfloat16 and res_W.data.dtype == torch.float32
+    Gt = torch.from_numpy(np.concatenate(Gb, 0)).to(DEV).to(torch.bfloat16)
+    nodes.data.backward(Gt)
+    assert Xt.grad.dtype == torch.bfloat16
+    Yref = np.concatenate([c["Y"] for c in caches])
+    assert_close(to_np(nodes.data.float()), Yref, BF16_RTOL, "Y (bf16 storage)")
+    assert_close(to_np(Xt.grad.float()), np.concatenate(tot["dX"]), BF16_RTOL, "dX (bf16 storage)")
+    for b in range(B):
+        assert_close(to_np(res_W[b]), caches[b]["S"], FEATURE_RTOL, "res_W fp32")
+    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight fp32")
+    assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], 5 * GRAD_RTOL, "dM_L fp32")
+    # conversion itself: round to nearest even, exact widening
+    x = torch.randn(1000, 7, device=DEV)
+    from agcn_amd.functional import CastRowsFunction
+    assert torch.equal(CastRowsFunction.apply(x, torch.bfloat16), x.to(torch.bfloat16))
+    assert torch.equal(CastRowsFunction.apply(x.to(torch.bfloat16), torch.float32), x.to(torch.bfloat16).float())
+
+
 def test_reslap_without_prev(amd):
     ns, Fin, Fout, K = [6, 9, 14], 8, 6, 2
     for mode in (orc.REFERENCE, orc.PAPER):
