@@ -232,7 +232,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dd; int n_chunks; int64_t part_stride; int n_glb; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dd; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -250,7 +250,9 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
   w->n_chunks = n_chunks_for(pi.rows);
   w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
   w->part_stride = (w->part_stride + 3) / 4 * 4;
-  w->part = c.take((size_t)w->n_chunks * w->part_stride);
+  w->part_floats = std::max((size_t)w->n_chunks * w->part_stride,
+                            param_grad_onepass_floats(pi.rows, d->Fin, d->Fout, d->K, paper ? 1 : 0));
+  w->part = c.take(w->part_floats);
   w->n_glb = (int)global_scratch_floats(d, host, true, &c, &w->tile, &w->buf);
   return c.off;
 }
@@ -431,6 +433,11 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   const bool slabs = use_slabs(desc, batch, host.info);
   const FusedSplit fs = fused_split(desc, batch, host);
   const bool fused = fs.mode != 0;
+  // arrival counters of the one-pass parameter-gradient kernel: zeroed by the first kernel of this call
+  int32_t n_counters = 0;
+  int32_t* counters = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, desc->K,
+                                          paper ? 1 : 0, &n_counters);
+  a.zero_ptr = counters; a.zero_count = n_counters;
   if ((stages & 1) && fused) {
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
@@ -484,7 +491,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     g.Kd = desc->Fout; g.N = desc->Fin * desc->K;
     g.A0 = dY; g.lda0 = desc->ldy; g.Yact = fwd->Y; g.ldy = desc->ldy; g.Bm = params->weight;
     g.Out0 = grads->dX; g.ldo0 = desc->ldx; g.Out1 = w.g; g.o1_plane = (int64_t)host.info.rows * desc->Fin;
-    g.Gp = w.Gp;
+    g.Gp = w.Gp; g.zero_ptr = counters; g.zero_count = n_counters;
     rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
     if (rc != AGCN_OK) return rc;
     // 2. graph-local adjoints
@@ -525,6 +532,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = fused ? B + fs.n_big_slabs : (slabs ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
+  pa.part_floats = w.part_floats;
+  pa.counters_zeroed = (stages & 1) ? 1 : 0;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
   return launch_param_grads(pa, hip_stream);

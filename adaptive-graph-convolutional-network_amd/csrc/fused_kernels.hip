@@ -490,6 +490,9 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   const float* dYg = a.dY + (int64_t)row0 * a.ldy;
   const float alpha = a.alpha[0];
 
+  if (blockIdx.x == 0) {   // arrival counters of the parameter-gradient kernel that follows this one
+    for (int e = tid; e < a.zero_count; e += nthr) a.zero_ptr[e] = 0;
+  }
   AGCN_STAMP(4, 0);
   // ---- B0: loads: dY, Y rows -> Gp image (+ global copy); W -> regrouped image; CSR rows; s --------
   int csr_p0 = 0, csr_p1 = 0;

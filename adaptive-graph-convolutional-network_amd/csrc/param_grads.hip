@@ -6,6 +6,9 @@
 // with Gp = dY . act'(Y) (written by the RG_FILTER_BWD launch).  Two launches: per-chunk partial
 // products on the matrix cores (A^T B with the row index as the MFMA k dimension), then a
 // fixed-order reduction -- no atomics, so the result is reproducible bit for bit.
+#include <algorithm>
+#include <cstdlib>
+
 #include "agcn_device.h"
 #include "sgc_kernels.h"
 
@@ -115,8 +118,187 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(ParamGradArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-pass variant: ONE launch instead of partial + reduce.
+//   grid.x = n_tiles * S workgroups of 1024 threads.  Workgroup (tile t, split s) owns rows
+//   [s * rps, (s + 1) * rps) of the batch; its 16 waves take 32-row slices (all 24 operand loads of a slice are
+//   issued before the first MFMA: one memory round trip), the 16 wave accumulators are summed through LDS in
+//   wave order, and the workgroup's [16 x 32] partial goes to `part`.  The LAST workgroup of a tile to arrive
+//   (one agent-scope atomic counter per tile) adds the S partials in split order -- the sum order is
+//   fixed whichever workgroup performs it, so the result is reproducible bit for bit -- and writes the
+//   gradient.  Counters are zeroed by the launcher (or by the preceding kernel of the same call).
+// Tiles: dweight tf x tc, then dbias tc, then (paper) dM_L tfM x tcM; 16 x 32 outputs each.
+__global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs a) {
+  __shared__ float wsum[16][512 + 16];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int K = a.K, Fin = a.Fin, Fout = a.Fout;
+  const int S = a.n_chunks;                 // row splits
+  const int t = blockIdx.x / S, s = blockIdx.x - t * S;
+  const int tfW = (Fin * K + 15) >> 4, tcW = (Fout + 31) >> 5;
+  const int tfM = (Fin + 15) >> 4, tcM = (Fin + 31) >> 5;
+  int p, rem;                               // problem, tile index inside it
+  if (t < tfW * tcW) { p = 0; rem = t; }
+  else if (t < tfW * tcW + tcW) { p = 1; rem = t - tfW * tcW; }
+  else { p = 2; rem = t - tfW * tcW - tcW; }
+  const int Fa = p == 0 ? Fin * K : (p == 1 ? 1 : Fin), Fb = p == 2 ? Fin : Fout;
+  const int tf = p == 0 ? tfW : (p == 1 ? 1 : tfM);
+  const int itc = rem / tf, itf = rem - itc * tf;
+  const int f0 = itf * 16, c0 = itc * 32;
+  const int last_row = a.rows - 1;
+  const int r_begin = s * a.chunk_rows + wave * a.wgs_per_chunk;   // chunk_rows: rows per split, wgs_per_chunk: rows per wave
+  const int r_end = min(min(a.rows, (s + 1) * a.chunk_rows), r_begin + a.wgs_per_chunk);
+
+  const int j = min(f0 + r, Fa - 1);
+  const bool jv = (f0 + r) < Fa;
+  const float* Ap;
+  int64_t lda;
+  if (p == 0) {
+    const int f = j / K, kx = j - f * K;
+    if (kx == 0) { Ap = a.X + f; lda = a.ldx; }
+    else { Ap = a.sv_X + (int64_t)(kx - 1) * a.rows * Fin + f; lda = Fin; }
+  } else if (p == 2) { Ap = a.X + j; lda = a.ldx; }
+  else { Ap = a.X; lda = 0; }
+  const float* Bp = (p == 2) ? a.dZ : a.Gp;
+  const int ldb = (p == 2) ? Fin : Fout;
+  const int cA = min(c0 + r, Fb - 1), cB = min(c0 + 16 + r, Fb - 1);
+  const bool cAv = (c0 + r) < Fb, cBv = (c0 + 16 + r) < Fb;
+
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  for (int rr = r_begin; rr < r_end; rr += 32) {
+    float av[8], b0[8], b1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = min(rr + 4 * u + q, last_row);
+      av[u] = (p == 1) ? 1.0f : Ap[(int64_t)row * lda];
+      b0[u] = Bp[(int64_t)row * ldb + cA];
+      b1[u] = Bp[(int64_t)row * ldb + cB];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool rv = (rr + 4 * u + q) < r_end;
+      const float x = (rv && jv) ? av[u] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, (rv && cAv) ? b0[u] : 0.f, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, (rv && cBv) ? b1[u] : 0.f, acc1, 0, 0, 0);
+    }
+  }
+  // element e = ff * 32 + c of the 16 x 32 tile; lane holds rows 4q .. 4q+3 of columns r and 16 + r
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    wsum[wave][(4 * q + i) * 32 + r] = acc0[i];
+    wsum[wave][(4 * q + i) * 32 + 16 + r] = acc1[i];
+  }
+  __syncthreads();
+  // The hand-off to the tile's last workgroup uses agent-scope (sc1) stores and loads of exactly the bytes
+  // handed off -- no release / acquire fence: an agent-scope release would write back the whole L2, which
+  // holds megabytes of this step's outputs (measured: 158 us for this kernel with __threadfence()).
+  float* mine = a.part + ((int64_t)t * S + s) * 512;
+  if (tid < 512) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += wsum[w][tid];
+    __hip_atomic_store(mine + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();   // every storing wave has drained its stores (vmcnt(0)) before the arrival is counted
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(a.counters + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (old == S - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last_flag) {
+    if (tid < 512) {
+      const float* base = a.part + (int64_t)t * S * 512 + tid;
+      float v = 0.f;
+      for (int s0 = 0; s0 < S; s0 += 8) {   // eight loads in flight, added in split order
+        float l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          l[u] = __hip_atomic_load(base + (int64_t)min(s0 + u, S - 1) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < S) v += l[u];
+      }
+      const int ff = f0 + (tid >> 5), c = c0 + (tid & 31);
+      if (ff < Fa && c < Fb) {
+        if (p == 0) a.dweight[(int64_t)ff * Fout + c] = v;
+        else if (p == 1) a.dbias[c] = v;
+        else a.dM_L[(int64_t)ff * Fin + c] = v;
+      }
+    }
+  }
+  // scalars: one wave each of workgroup 0, fixed order (the per-graph partials come from the previous kernel)
+  if (blockIdx.x == 0 && wave < 2) {
+    float* dst = wave == 0 ? a.dalpha : a.dbeta;
+    if (dst != nullptr && a.pg != nullptr) {
+      float v = 0.f;
+      for (int b = lane; b < a.B; b += 64) v += a.pg[2 * b + wave];
+      v = wave_sum(v);
+      if (lane == 0) dst[0] = v;
+    }
+  }
+}
+
+namespace {
+int pg_tiles(int Fin, int Fout, int K, bool paper) {
+  const int tfW = (Fin * K + 15) / 16, tcW = (Fout + 31) / 32;
+  const int tfM = (Fin + 15) / 16, tcM = (Fin + 31) / 32;
+  return tfW * tcW + tcW + (paper ? tfM * tcM : 0);
+}
+// rows per wave (multiple of 32) and number of row splits
+void pg_split(int rows, int* rows_per_wave, int* S) {
+  static const int env_rpw = [] { const char* e = std::getenv("AGCN_PG_RPW"); const int v = e ? std::atoi(e) : 0;
+                                  return (v >= 32 && v % 32 == 0) ? v : 32; }();
+  int rpw = env_rpw;
+  while ((rows + 16 * rpw - 1) / (16 * rpw) > 64) rpw += 32;
+  *rows_per_wave = rpw;
+  *S = std::max(1, (rows + 16 * rpw - 1) / (16 * rpw));
+}
+int pg_mode() {
+  static const int m = [] { const char* e = std::getenv("AGCN_PG_ONEPASS"); return (e && e[0] == '0') ? 0 : 1; }();
+  return m;
+}
+}  // namespace
+
+// floats of `part` the one-pass kernel needs: S partial tiles per output tile + the arrival counters
+size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper) {
+  int rpw, S;
+  pg_split(rows, &rpw, &S);
+  const size_t nt = (size_t)pg_tiles(Fin, Fout, K, paper != 0);
+  return nt * S * 512 + ((nt + 63) / 64) * 64;
+}
+
+int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int32_t Fin, int32_t Fout, int32_t K,
+                             int32_t paper, int32_t* count) {
+  *count = 0;
+  if (pg_mode() != 1 || !part || part_floats < param_grad_onepass_floats(rows, Fin, Fout, K, paper)) return nullptr;
+  int rpw, S;
+  pg_split(rows, &rpw, &S);
+  const int nt = pg_tiles(Fin, Fout, K, paper != 0);
+  *count = nt;
+  return reinterpret_cast<int32_t*>(part + (size_t)nt * S * 512);
+}
+
 int launch_param_grads(const ParamGradArgs& a, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (pg_mode() == 1 && a.part_floats >= param_grad_onepass_floats(a.rows, a.Fin, a.Fout, a.K, a.paper)) {
+    ParamGradArgs aa = a;
+    int rpw, S;
+    pg_split(a.rows, &rpw, &S);
+    const int nt = pg_tiles(a.Fin, a.Fout, a.K, a.paper != 0);
+    aa.n_chunks = S; aa.wgs_per_chunk = rpw; aa.chunk_rows = 16 * rpw;
+    aa.counters = reinterpret_cast<int32_t*>(a.part + (size_t)nt * S * 512);
+    if (!a.counters_zeroed) {
+      hipError_t e = hipMemsetAsync(aa.counters, 0, sizeof(int32_t) * (size_t)nt, s);
+      if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad counters memset: %s", hipGetErrorString(e));
+    }
+    prof_begin(PK_PARAM_PARTIAL, stream);
+    hipLaunchKernelGGL(param_grad_onepass_kernel, dim3((unsigned)(nt * S)), dim3(1024), 0, s, aa);
+    prof_end(stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_onepass launch: %s", hipGetErrorString(e));
+    return AGCN_OK;
+  }
   const int tfW = (a.Fin * a.K + 15) / 16, tcW = (a.Fout + 31) / 32;
   const int tfM = (a.Fin + 15) / 16, tcM = (a.Fin + 31) / 32;
   int items = tfW * tcW;

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
     if (ok && a.big_n > 0) ok = a.n[a.row_graph[row]] > a.big_n;   // mixed dispatch: big graphs only
     rowok[tid] = ok ? 1.f : 0.f;
   }
+  if (MODE == RG_FILTER_BWD && blockIdx.x == 0 && blockIdx.y == 0) {
+    for (int e = tid; e < a.zero_count; e += nthr) a.zero_ptr[e] = 0;
+  }
   __syncthreads();
   if (a.big_n > 0) {   // nothing to do for a block without rows of big graphs
     float any = 0.f;

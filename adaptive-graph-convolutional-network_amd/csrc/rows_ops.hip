@@ -31,7 +31,7 @@ void fill_rows_dense(RowsGemmArgs& g, const AgcnDenseDesc* d, const PlanView& ho
   g.keep_pad = d->keep_pad_rows ? 1 : 0;
 }
 
-struct DenseWs { float *Gp, *part, *dbias; int n_chunks; int64_t part_stride; };
+struct DenseWs { float *Gp, *part, *dbias; int n_chunks; int64_t part_stride; size_t part_floats; };
 size_t carve_dense(const AgcnDenseDesc* d, const AgcnPlanInfo& pi, void* ws, bool need_gp, DenseWs* w) {
   char* base = static_cast<char*>(ws);
   size_t off = 0;
@@ -43,7 +43,8 @@ size_t carve_dense(const AgcnDenseDesc* d, const AgcnPlanInfo& pi, void* ws, boo
   if (c > 256) c = 256;
   w->n_chunks = c;
   w->part_stride = ((int64_t)d->Fin * d->Fout + d->Fout + 3) / 4 * 4;
-  w->part = take((size_t)c * w->part_stride);
+  w->part_floats = std::max((size_t)c * w->part_stride, param_grad_onepass_floats(pi.rows, d->Fin, d->Fout, 1, 0));
+  w->part = take(w->part_floats);
   w->dbias = take((size_t)d->Fout);
   return off;
 }
@@ -215,6 +216,7 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   g.Kd = desc->Fout; g.N = desc->Fin;
   g.A0 = dY; g.lda0 = desc->ldy; g.Yact = Y; g.ldy = desc->ldy; g.Bm = W;
   g.Out0 = dX; g.ldo0 = desc->ldx; g.Gp = Gp; g.scale = scale;
+  g.zero_ptr = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &g.zero_count);
   rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
   if (rc != AGCN_OK) return rc;
 
@@ -224,7 +226,7 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = 0; pa.part_stride = w.part_stride;
-  pa.X = X; pa.Gp = Gp; pa.part = w.part;
+  pa.X = X; pa.Gp = Gp; pa.part = w.part; pa.part_floats = w.part_floats; pa.counters_zeroed = 1;
   pa.dweight = dW; pa.dbias = dbias ? dbias : w.dbias;
   rc = launch_param_grads(pa, hip_stream);
   if (rc != AGCN_OK || !scale) return rc;

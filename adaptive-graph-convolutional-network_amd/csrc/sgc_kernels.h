@@ -53,6 +53,10 @@ struct SgcArgs {
   float* ws_dA;    // [tile_elems]  dA = -dR               (paper mode, bwd1 -> bwd2)
   float* ws_dd;    // [rows]        dd_j                   (paper mode, bwd1 -> bwd2)
   int32_t pg_slab_base;  // mixed dispatch: slab s writes its partials at ws_pg[2 * (pg_slab_base + s)]
+  // arrival counters of the one-pass parameter-gradient kernel that follows: zeroed by workgroup 0 of the
+  // fused backward kernel (saves a memset node in front of it)
+  int32_t* zero_ptr;
+  int32_t zero_count;
 };
 
 enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3, RG_DENSE = 4 };
@@ -76,6 +80,8 @@ struct RowsGemmArgs {
   // mixed dispatch: only rows of graphs with more than big_n nodes are processed (0 = all rows)
   int32_t big_n;
   const int32_t* row_graph; // [rows]
+  int32_t* zero_ptr;        // RG_FILTER_BWD: counters to zero for the parameter-gradient kernel that follows
+  int32_t zero_count;
   int32_t kc;               // K chunk staged in LDS (set by the launcher)
   int32_t nt;               // column tiles per workgroup (set by the launcher)
 };
@@ -90,6 +96,9 @@ struct ParamGradArgs {
   const float* Gp;      // [rows][Fout]
   const float* dZ;
   float* part;          // [n_chunks][part_stride]
+  size_t part_floats;   // capacity of `part` (set by the caller; 0 = unknown: two-launch path)
+  int32_t* counters;    // one-pass kernel: per-tile arrival counters (set by the launcher)
+  int32_t counters_zeroed;  // 1 = a preceding kernel of the same call already zeroed them
   const float* pg;      // [B][2]
   float *dweight, *dbias, *dM_L, *dalpha, *dbeta;
 };
@@ -126,6 +135,10 @@ bool slab_path_fits(int32_t Fin);
 int launch_slab_forward(const SgcArgs& a, void* stream);
 int launch_slab_backward(const SgcArgs& a, void* stream);
 int launch_param_grads(const ParamGradArgs& a, void* stream);
+size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper);
+// the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number
+int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int32_t Fin, int32_t Fout, int32_t K,
+                             int32_t paper, int32_t* count);
 
 }  // namespace agcn
 #endif
