@@ -69,10 +69,13 @@ struct FusedSplit {
   int thr;         // largest fitting graph size: a graph is "big" iff n > thr
   int big_pg;      // mixed: 1 = the big graphs run on the per-graph LDS-tile kernels (sgc_forward/backward.hip),
                    //        0 = on the slab-parallel kernels
+  // 1 = the fused forward / backward kernel reads M_L / W straight from global memory (no LDS images of them):
+  // wide layers (Fin = 128) and graphs up to ~100 nodes fit this way
+  int gb_fwd, gb_bwd;
 };
 
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
-  FusedSplit f{0, 0, 0, 0, 0};
+  FusedSplit f{0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
   if (!(d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
@@ -91,9 +94,28 @@ FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const Pl
     *slabs = ns;
     return nb;
   };
+  static const int force_gb = [] { const char* e = std::getenv("AGCN_FUSED_GB"); return e ? std::atoi(e) : -1; }();
   int ns = 0;
   int nb = count_big(lim, &ns);
-  if (nb == 0) { f.mode = 1; f.thr = pi.max_n; return f; }
+  const bool gb_fits = std::max(fused_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K),
+                                fused_bwd_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K)) <= lim;
+  if (nb == 0) {
+    // Both flavours fit.  Measured on MI355X (256 Tox21-shaped graphs): reading the parameters from global
+    // memory is faster in the forward kernel (75->64: 23.5 vs 24.7 us; 64->128: 27.5 vs 29.9 us) and, when the
+    // rows of W and M_L are 16-byte aligned (vector loads along k), in the backward kernel too
+    // (64->128: 35.7 vs 36.4 us; 75->64, rows of 75 floats: 33.7 vs 32.1 us -> LDS images).
+    f.mode = 1; f.thr = pi.max_n;
+    if (gb_fits && force_gb != 0) {
+      f.gb_fwd = 1;
+      f.gb_bwd = (force_gb == 1 || ((d->Fin & 3) == 0 && (d->Fout & 3) == 0)) ? 1 : 0;
+    }
+    return f;
+  }
+  // the parameter images are what does not fit: read M_L / W from global memory instead (AGCN_FUSED_GB=0 disables)
+  if (gb_fits && force_gb != 0) {
+    f.mode = 1; f.thr = pi.max_n; f.gb_fwd = f.gb_bwd = 1;
+    return f;
+  }
   // Some graph does not fit.  Measured on MI355X (Tox21-shaped, 256 graphs per GPU, one n = 95 graph):
   // all-slab 117 us/step, mixed 144 us/step -- the side chain of four dependent launches is longer than
   // the fused kernel it runs beside, so mixed dispatch is opt-in (agcn_set_fused_mode(2)) and the whole
@@ -303,7 +325,10 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   const FusedSplit fs = fused_split(desc, batch, host);
   if (fs.mode == 1) {
     // small graphs: the whole layer forward in one launch, everything staged in LDS once
-    return launch_fused_forward(a, 0, host.info.B, fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K),
+    if (fs.gb_fwd)
+      return launch_fused_forward(a, 0, host.info.B, fused_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K), true,
+                                  hip_stream);
+    return launch_fused_forward(a, 0, host.info.B, fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), false,
                                 hip_stream);
   }
   if (fs.mode == 2) {
@@ -337,7 +362,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     rc = launch_rows_gemm(g, RG_FILTER, ss.s);
     if (rc != AGCN_OK) return rc;
     rc = launch_fused_forward(a, fs.n_big, host.info.B - fs.n_big,
-                              fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), hip_stream);
+                              fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), false, hip_stream);
     if (rc != AGCN_OK) return rc;
     if (hipEventRecord(ss.join, ss.s) != hipSuccess || hipStreamWaitEvent(main_s, ss.join, 0) != hipSuccess)
       return fail(AGCN_EDEVICE, "%s: stream join failed", who);
@@ -478,7 +503,9 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       }
     }
     rc = launch_fused_backward(a, fs.n_big, B - fs.n_big,
-                               fused_bwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), hip_stream);
+                               fs.gb_bwd ? fused_bwd_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K)
+                                         : fused_bwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K),
+                               fs.gb_bwd != 0, hip_stream);
     if (rc != AGCN_OK) return rc;
     if (ss) {
       if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(main_s, ss->join, 0) != hipSuccess)

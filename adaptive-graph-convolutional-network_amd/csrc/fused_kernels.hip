@@ -86,12 +86,95 @@ __device__ __forceinline__ void tile_gemm_ta(f32x4& acc, const float* At, int ld
   }
 }
 
+// B operand straight from global memory (L2-resident parameters), no LDS image:
+//   B[k][c] = Bg[k * krow + c] for k < kvalid, c < cvalid; addresses are clamped, the A image's zero padding
+//   (columns >= kvalid) cancels the clamped rows and out-of-range columns are never stored.
+// The loads of the next 16-k block are issued before the MFMAs of the current one.
+__device__ __forceinline__ void tile_gemm_gbx(f32x4& acc, const float* A, int lda, int row0, const float* Bp,
+                                              int kstride, int klast, int kdim) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* Ap = A + (row0 + r) * lda + q;
+  float b0[4], b1[4];
+  auto ldb = [&](int k0, float (&dst)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dst[u] = Bp[(int64_t)min(k0 + 4 * u + q, klast) * kstride];
+  };
+  auto step = [&](int k0, const float (&bv)[4]) {
+    float av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) av[u] = Ap[k0 + 4 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  };
+  ldb(0, b0);
+#pragma unroll 1
+  for (int k0 = 0; k0 < kdim; k0 += 32) {
+    const bool more1 = k0 + 16 < kdim, more2 = k0 + 32 < kdim;
+    if (more1) ldb(k0 + 16, b1);
+    step(k0, b0);
+    if (more1) {
+      if (more2) ldb(k0 + 32, b0);
+      step(k0 + 16, b1);
+    }
+  }
+}
+// row-major B in global memory: B[k][c] = Bg[k * krow + c]
+__device__ __forceinline__ void tile_gemm_gb(f32x4& acc, const float* A, int lda, int row0, const float* Bg,
+                                             int krow, int kvalid, int col0, int cvalid, int kdim) {
+  const int r = threadIdx.x & 15;
+  tile_gemm_gbx(acc, A, lda, row0, Bg + min(col0 + r, cvalid - 1), krow, kvalid - 1, kdim);
+}
+// Transposed B with k contiguous in memory, 16-byte loads: lane (r, q) fetches Brow[k0 + 4q .. 4q + 3] in one
+// instruction (the 16 rows of a wave-load are 64 contiguous bytes each: every fetched line is fully used; the
+// dword form above touches the same 16 lines four times).  MFMA step j therefore pairs B[k0 + 4q + j] with the A
+// element at image position k0 + 4j + q: the A image must be stored k-permuted inside every 16-block (perm16).
+__device__ __forceinline__ int perm16(int c) { return (c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3); }
+__device__ __forceinline__ void tile_gemm_gbt4(f32x4& acc, const float* A, int lda, int row0, const float* Brow,
+                                               int kvalid, int kdim) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* Ap = A + (row0 + r) * lda + q;
+  const float* Bq = Brow + 4 * q;
+  const int klast = kvalid - 1;
+  // full 16-blocks of 16-byte aligned rows: one 16-byte load; otherwise (tail block, rows of e.g. 75 floats):
+  // clamped dword loads of the same elements (the A image's zero padding cancels the clamped ones)
+  const bool al = (reinterpret_cast<uintptr_t>(Brow) & 15) == 0;   // wave-uniform when the row stride is 16-byte
+  auto ldb = [&](int k0, float (&dst)[4]) {
+    if (al && k0 + 16 <= kvalid) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(Bq + k0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[u] = t[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[u] = Brow[min(k0 + 4 * q + u, klast)];
+    }
+  };
+  auto step = [&](int k0, const float (&bv)[4]) {
+    float av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) av[u] = Ap[k0 + 4 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  };
+  float b0[4], b1[4];
+  ldb(0, b0);
+#pragma unroll 1
+  for (int k0 = 0; k0 < kdim; k0 += 32) {
+    const bool more1 = k0 + 16 < kdim, more2 = k0 + 32 < kdim;
+    if (more1) ldb(k0 + 16, b1);
+    step(k0, b0);
+    if (more1) {
+      if (more2) ldb(k0 + 32, b0);
+      step(k0 + 16, b1);
+    }
+  }
+}
+
 struct FusedBwdDims {
   int n4, F4, O4, ldt, ldxa, ldg;
   int64_t o_svec, o_dd, o_rs, o_colp, o_tile, o_dx, o_g1, o_r3, o_wt, o_x0, o_m, total;
 };
 
-AGCN_HD inline FusedBwdDims fused_bwd_dims(int n, int Fin, int Fout, int K) {
+AGCN_HD inline FusedBwdDims fused_bwd_dims(int n, int Fin, int Fout, int K, bool gb = false) {
   FusedBwdDims d;
   d.n4 = (n + 15) & ~15;
   d.F4 = (Fin + 15) & ~15;
@@ -109,8 +192,8 @@ AGCN_HD inline FusedBwdDims fused_bwd_dims(int n, int Fin, int Fout, int K) {
   d.o_dx = o;   o += r4((int64_t)d.n4 * d.ldxa);
   d.o_g1 = o;   o += r4((int64_t)d.n4 * d.ldxa);
   d.o_r3 = o;
-  const int64_t gp = r4((int64_t)d.n4 * d.ldg), wt = r4((int64_t)K * d.F4 * d.ldg);
-  const int64_t x0 = r4((int64_t)d.n4 * d.ldxa), m = r4((int64_t)d.F4 * d.ldxa);
+  const int64_t gp = r4((int64_t)d.n4 * d.ldg), wt = gb ? 0 : r4((int64_t)K * d.F4 * d.ldg);
+  const int64_t x0 = r4((int64_t)d.n4 * d.ldxa), m = gb ? 0 : r4((int64_t)d.F4 * d.ldxa);
   d.o_wt = o + gp;
   d.o_x0 = o;
   d.o_m = o + x0;
@@ -119,7 +202,7 @@ AGCN_HD inline FusedBwdDims fused_bwd_dims(int n, int Fin, int Fout, int K) {
   return d;
 }
 
-AGCN_HD inline FusedDims fused_dims(int n, int Fin, int Fout, int K) {
+AGCN_HD inline FusedDims fused_dims(int n, int Fin, int Fout, int K, bool gb = false) {
   FusedDims d;
   d.n4 = (n + 15) & ~15;
   d.F4 = (Fin + 15) & ~15;
@@ -136,13 +219,14 @@ AGCN_HD inline FusedDims fused_dims(int n, int Fin, int Fout, int K) {
   d.o_ximg = o; o += r4((int64_t)d.n4 * d.ldxa);
   const int64_t zt = (int64_t)Fin * d.ldt, x1 = (int64_t)d.n4 * d.ldxa;
   d.o_zx = o; o += r4(zt > x1 ? zt : x1);
-  d.o_mimg = o; o += r4((int64_t)d.F4 * d.ldm);
-  d.o_wimg = o; o += r4((int64_t)d.KF4 * d.ldw);
+  d.o_mimg = o; if (!gb) o += r4((int64_t)d.F4 * d.ldm);   // gb: M_L and W are read from global memory
+  d.o_wimg = o; if (!gb) o += r4((int64_t)d.KF4 * d.ldw);
   d.total = o;
   return d;
 }
 }  // namespace
 
+template <bool GB>
 __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -151,7 +235,7 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
   const int row0 = a.row_off[b];
   const int64_t toff = a.tile_off[b];
   const int Fin = a.Fin, Fout = a.Fout, K = a.K;   // K == 2
-  const FusedDims d = fused_dims(n, Fin, Fout, K);
+  const FusedDims d = fused_dims(n, Fin, Fout, K, GB);
   const int n4 = d.n4, F4 = d.F4, ldt = d.ldt, ldxa = d.ldxa, ldm = d.ldm, ldw = d.ldw;
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const bool relu = a.activation == AGCN_ACT_RELU;
@@ -181,7 +265,11 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
   // image row k*F4 + f  <-  W row f*K + k   (graphconv.py:243-244 interleaving undone once, here)
   auto wmap = [&](int jr) { const int k = jr >= F4 ? 1 : 0; const int f = jr - k * F4; return f < Fin ? f * K + k : -1; };
   const int lane = tid & 63, wave = tid >> 6;
-  if (nthr == 1024 && n4 <= 80 && F4 <= 128 && Fout <= 64 && K * F4 <= 160 && ldw >= 64) {
+  if (GB) {
+    // parameters stay in global memory: only the graph's own rows are staged
+    if (cpF <= 2) stage_matrix<2>(Ximg, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
+    else stage_matrix<4>(Ximg, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
+  } else if (nthr == 1024 && n4 <= 80 && F4 <= 128 && Fout <= 64 && K * F4 <= 160 && ldw >= 64) {
     // common shapes: ALL loads of X, M_L and W are issued before the first LDS store (one round trip):
     // wave w takes rows w, w+16, ..; lanes run along the columns (2 passes for the features)
     float xr[5][2], mr[8][2], wr[10];
@@ -264,7 +352,8 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
     for (int t = wv; t < tm * tn; t += nw) {
       const int in = t / tm, im = t - in * tm;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      tile_gemm_rm(acc, Ximg, ldxa, 16 * im, Mimg, ldm, 16 * in, F4);
+      if (GB) tile_gemm_gb(acc, Ximg, ldxa, 16 * im, a.M_L, Fin, Fin, 16 * in, Fin, F4);
+      else tile_gemm_rm(acc, Ximg, ldxa, 16 * im, Mimg, ldm, 16 * in, F4);
       const int c = 16 * in + r;
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
@@ -432,8 +521,13 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
     for (int t = wv; t < tm * tn; t += nw) {
       const int in = t / tm, im = t - in * tm;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      tile_gemm_rm(acc, Ximg, ldxa, 16 * im, Wimg, ldw, 16 * in, F4);
-      tile_gemm_rm(acc, X1img, ldxa, 16 * im, Wimg + F4 * ldw, ldw, 16 * in, F4);
+      if (GB) {   // W row f*K + k (graphconv.py:243-244): consecutive f are K rows apart
+        tile_gemm_gb(acc, Ximg, ldxa, 16 * im, a.weight, K * Fout, Fin, 16 * in, Fout, F4);
+        tile_gemm_gb(acc, X1img, ldxa, 16 * im, a.weight + Fout, K * Fout, Fin, 16 * in, Fout, F4);
+      } else {
+        tile_gemm_rm(acc, Ximg, ldxa, 16 * im, Wimg, ldw, 16 * in, F4);
+        tile_gemm_rm(acc, X1img, ldxa, 16 * im, Wimg + F4 * ldw, ldw, 16 * in, F4);
+      }
       const int c = 16 * in + r;
       if (c < Fout) {
         const float bc = a.bias[c];
@@ -459,6 +553,7 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
 //   B2  (paper) dL = g_1 X_0^T -> dalpha, dA, dd, dr, c -> dZ = (diag(c 1) - c) Z;  dX += dZ M_L^T
 // The parameter gradients that reduce over the whole batch (dweight, dbias, dM_L) are formed by
 // param_grads.hip from Gp / dZ written here.
+template <bool GB>
 __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -469,7 +564,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   const int row0 = a.row_off[b];
   const int64_t toff = a.tile_off[b];
   const int Fin = a.Fin, Fout = a.Fout, K = a.K;   // K == 2
-  const FusedBwdDims d = fused_bwd_dims(n, Fin, Fout, K);
+  const FusedBwdDims d = fused_bwd_dims(n, Fin, Fout, K, GB);
   const int n4 = d.n4, F4 = d.F4, O4 = d.O4, ldt = d.ldt, ldxa = d.ldxa, ldg = d.ldg;
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const bool relu = a.activation == AGCN_ACT_RELU;
@@ -493,6 +588,8 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   if (blockIdx.x == 0) {   // arrival counters of the parameter-gradient kernel that follows this one
     for (int e = tid; e < a.zero_count; e += nthr) a.zero_ptr[e] = 0;
   }
+  // global-B with 16-byte loads along the contiguous k of W^T / M_L^T rows (A images stored k-permuted)
+  const bool vecW = GB, vecM = GB;
   AGCN_STAMP(4, 0);
   // ---- B0: loads: dY, Y rows -> Gp image (+ global copy); W -> regrouped image; CSR rows; s --------
   int csr_p0 = 0, csr_p1 = 0;
@@ -528,7 +625,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
           const int i = i0 + u * nw, c = cp + lane;
           if (i < n4 && c < O4) {
             const float v = (i < n && c < Fout && y[u] > 0.f) ? g[u] : 0.f;
-            GPimg[i * ldg + c] = v;
+            GPimg[i * ldg + (vecW ? perm16(c) : c)] = v;
             if (i < n && c < Fout) a.ws_Gp[(int64_t)(row0 + i) * Fout + c] = v;
           }
         }
@@ -536,8 +633,10 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     }
     // W image row k*F4 + f <- W row f*K + k, columns = Fout (the GEMM's k dimension)
     auto wmap = [&](int jr) { const int k = jr >= F4 ? 1 : 0; const int f = jr - k * F4; return f < Fin ? f * K + k : -1; };
-    if (O4 <= 64) stage_matrix<1>(WTimg, ldg, a.weight, Fout, K * F4, Fout, K * F4, O4, wmap);
-    else stage_matrix<4>(WTimg, ldg, a.weight, Fout, K * F4, Fout, K * F4, O4, wmap);
+    if (!GB) {
+      if (O4 <= 64) stage_matrix<1>(WTimg, ldg, a.weight, Fout, K * F4, Fout, K * F4, O4, wmap);
+      else stage_matrix<4>(WTimg, ldg, a.weight, Fout, K * F4, Fout, K * F4, O4, wmap);
+    }
   }
   int csr_c[4] = {0, 0, 0, 0};
   float csr_v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -584,10 +683,17 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     for (int t = wave; t < tm * tn; t += nw) {
       const int in = t / tm, im = t - in * tm;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      tile_gemm_tb(acc, GPimg, ldg, 16 * im, WTimg, ldg, 16 * in, O4);
       const int jr = 16 * in + r;
       float* dst = (jr < F4) ? dXimg : G1img;
       const int f = (jr < F4) ? jr : jr - F4;
+      if (GB) {   // B[c][jr] = W[f*K + k][c]: the lane's W row, k along the Fout columns
+        const int kk = (jr < F4) ? 0 : 1;
+        const float* wrow = a.weight + (int64_t)(min(f, Fin - 1) * K + kk) * Fout;
+        tile_gemm_gbt4(acc, GPimg, ldg, 16 * im, wrow, Fout, O4);
+        if (f >= Fin) acc = (f32x4){0.f, 0.f, 0.f, 0.f};   // image columns Fin..F4 are the zero padding
+      } else {
+        tile_gemm_tb(acc, GPimg, ldg, 16 * im, WTimg, ldg, 16 * in, O4);
+      }
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) dst[(16 * im + 4 * q + i4) * ldxa + f] = acc[i4];
     }
@@ -609,11 +715,13 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       z0r[u][0] = Zg0[(int64_t)i * Fin + min(lane, Fin - 1)];
       z0r[u][1] = Zg0[(int64_t)i * Fin + min(lane + 64, Fin - 1)];
     }
+    if (!GB) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = min(wave + 16 * u, Fin - 1);
-      m0r[u][0] = a.M_L[(int64_t)k * Fin + min(lane, Fin - 1)];
-      m0r[u][1] = a.M_L[(int64_t)k * Fin + min(lane + 64, Fin - 1)];
+      for (int u = 0; u < 8; ++u) {
+        const int k = min(wave + 16 * u, Fin - 1);
+        m0r[u][0] = a.M_L[(int64_t)k * Fin + min(lane, Fin - 1)];
+        m0r[u][1] = a.M_L[(int64_t)k * Fin + min(lane + 64, Fin - 1)];
+      }
     }
   }
   // ---- B1: dX += L^T g_1 -----------------------------------------------------------------------------------
@@ -642,22 +750,24 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
           if (lane + 64 < F4) X0img[i * ldxa + lane + 64] = (i < n && lane + 64 < Fin) ? x0r[u][1] : 0.f;
         }
       }
+      if (!GB) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = wave + 16 * u;
-        if (k < F4) {
-          if (lane < F4) Mimg[k * ldxa + lane] = (k < Fin && lane < Fin) ? m0r[u][0] : 0.f;
-          if (lane + 64 < F4) Mimg[k * ldxa + lane + 64] = (k < Fin && lane + 64 < Fin) ? m0r[u][1] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+          const int k = wave + 16 * u;
+          if (k < F4) {
+            if (lane < F4) Mimg[k * ldxa + lane] = (k < Fin && lane < Fin) ? m0r[u][0] : 0.f;
+            if (lane + 64 < F4) Mimg[k * ldxa + lane + 64] = (k < Fin && lane + 64 < Fin) ? m0r[u][1] : 0.f;
+          }
         }
       }
     } else {
       auto ident = [](int rr) { return rr; };
       if (F4 <= 128) {
         stage_matrix<2>(X0img, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
-        stage_matrix<2>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
+        if (!GB) stage_matrix<2>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
       } else {
         stage_matrix<4>(X0img, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
-        stage_matrix<4>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
+        if (!GB) stage_matrix<4>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
       }
     }
     __syncthreads();
@@ -768,7 +878,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
         for (int i4 = 0; i4 < 4; ++i4) {
           const int i = 16 * im + 4 * q + i4;
           const float v = (i < n) ? rsv[i] * G1img[i * ldxa + f] - acc[i4] : 0.f;
-          X0img[i * ldxa + f] = v;
+          X0img[i * ldxa + (vecM ? perm16(f) : f)] = v;
           if (i < n && f < Fin) dZg[(int64_t)i * Fin + f] = v;
         }
       }
@@ -781,8 +891,14 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       for (int t = wave; t < tm * tn; t += nw) {
         const int in = t / tm, im = t - in * tm;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        tile_gemm_tb(acc, X0img, ldxa, 16 * im, Mimg, ldxa, 16 * in, F4);
         const int f = 16 * in + r;
+        if (GB) {   // the lane's M_L row f, k along its columns
+          const float* mrow = a.M_L + (int64_t)min(f, Fin - 1) * Fin;
+          tile_gemm_gbt4(acc, X0img, ldxa, 16 * im, mrow, Fin, F4);
+          if (f >= Fin) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+          tile_gemm_tb(acc, X0img, ldxa, 16 * im, Mimg, ldxa, 16 * in, F4);
+        }
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) dXimg[(16 * im + 4 * q + i4) * ldxa + f] += acc[i4];
       }
@@ -806,41 +922,61 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
 size_t fused_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
   return sizeof(float) * (size_t)fused_dims(n, Fin, Fout, K).total;
 }
+size_t fused_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
+  return sizeof(float) * (size_t)fused_dims(n, Fin, Fout, K, true).total;
+}
 
 size_t fused_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
   return sizeof(float) * (size_t)fused_bwd_dims(n, Fin, Fout, K).total;
 }
+size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
+  return sizeof(float) * (size_t)fused_bwd_dims(n, Fin, Fout, K, true).total;
+}
 
-int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream) {
-  if (count <= 0) return AGCN_OK;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+template <bool GB>
+static int launch_fused_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_backward_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_backward_kernel<GB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_bwd): %s", hipGetErrorString(e));
   }
-  prof_begin(PK_FUSED_BWD, stream);
-  hipLaunchKernelGGL(fused_backward_kernel, dim3(count), dim3(1024), lds_bytes, s, a, first);
-  prof_end(stream);
+  prof_begin(PK_FUSED_BWD, s);
+  hipLaunchKernelGGL(fused_backward_kernel<GB>, dim3(count), dim3(1024), lds_bytes, s, a, first);
+  prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_backward launch: %s", hipGetErrorString(e));
   return AGCN_OK;
 }
 
-int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream) {
+int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_b,
+                          void* stream) {
   if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  return global_b ? launch_fused_backward_t<true>(a, first, count, lds_bytes, s)
+                  : launch_fused_backward_t<false>(a, first, count, lds_bytes, s);
+}
+
+template <bool GB>
+static int launch_fused_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_forward_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_forward_kernel<GB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_fwd): %s", hipGetErrorString(e));
   }
-  prof_begin(PK_FUSED_FWD, stream);
-  hipLaunchKernelGGL(fused_forward_kernel, dim3(count), dim3(1024), lds_bytes, s, a, first);
-  prof_end(stream);
+  prof_begin(PK_FUSED_FWD, s);
+  hipLaunchKernelGGL(fused_forward_kernel<GB>, dim3(count), dim3(1024), lds_bytes, s, a, first);
+  prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_forward launch: %s", hipGetErrorString(e));
   return AGCN_OK;
+}
+
+int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_b,
+                         void* stream) {
+  if (count <= 0) return AGCN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return global_b ? launch_fused_forward_t<true>(a, first, count, lds_bytes, s)
+                  : launch_fused_forward_t<false>(a, first, count, lds_bytes, s);
 }
 
 }  // namespace agcn

@@ -127,9 +127,13 @@ int launch_sgc_backward(const SgcArgs& a, int32_t first, int32_t count, bool lds
 int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream);
 // fused per-graph SGC_LL (K = 2) for graphs whose whole working set fits LDS
 size_t fused_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
-int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
+size_t fused_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K);   // parameters read from global memory
+int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_b,
+                         void* stream);
 size_t fused_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
-int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
+size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
+int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_b,
+                          void* stream);
 // slab-parallel SGC_LL (K = 2, packed rows, symmetric CSR L_orig)
 bool slab_path_fits(int32_t Fin);
 int launch_slab_forward(const SgcArgs& a, void* stream);
