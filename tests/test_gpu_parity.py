@@ -294,6 +294,29 @@ def test_bf16_feature_storage(amd):
     assert torch.equal(CastRowsFunction.apply(x.to(torch.bfloat16), torch.float32), x.to(torch.bfloat16).float())
 
 
+def test_fused_path_large_graph_and_wide_layer(amd):
+    """The fused kernels with the parameters read from global memory (no LDS images of M_L / W): a 95-node graph
+    at 75 -> 64 (the straggler of a 2048-graph Tox21-shaped batch) and a 128 -> 128 layer, both of which do not fit
+    LDS with parameter images; checked against the oracle, and against the slab path on the same inputs."""
+    lib = amd._ffi.lib()
+    for ns, Fin, Fout in (([95, 20, 7, 64], 75, 64), ([59, 33, 16, 4], 128, 128), ([96, 5], 64, 128)):
+        K = 2
+        for mode in (orc.REFERENCE, orc.PAPER):
+            rs, X, L0, csr, p, G = synth_case(500 + Fin, ns, Fin, Fout, K, orc.SGC_LL, atoms=(Fin == 75))
+            caches, tot = oracle_run(X, L0, p, K, mode, orc.SGC_LL, G)
+            out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, orc.SGC_LL)
+            compare_with_oracle(out, caches, tot, orc.SGC_LL, mode, K, has_prev=False)
+            lib.agcn_set_fused_mode(0)
+            try:
+                slab = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, orc.SGC_LL)
+            finally:
+                lib.agcn_set_fused_mode(1)
+            for b in range(len(ns)):
+                assert np.array_equal(out["res_W"][b], out["res_W"][b].T)
+                assert_close(out["res_W"][b], slab["res_W"][b], FEATURE_RTOL, "res_W fused vs slab")
+            assert_close(np.concatenate(out["dX"]), np.concatenate(slab["dX"]), 5 * GRAD_RTOL, "dX fused vs slab")
+
+
 def test_reslap_without_prev(amd):
     ns, Fin, Fout, K = [6, 9, 14], 8, 6, 2
     for mode in (orc.REFERENCE, orc.PAPER):
