@@ -105,7 +105,8 @@ struct ParamGradArgs {
 
 // profiling ids (profile.hip)
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
-       PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD, PK_COUNT };
+       PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD,
+       PK_PARAM_ONEPASS, PK_COUNT };
 bool prof_on();
 void prof_begin(int id, void* stream);
 void prof_end(void* stream);

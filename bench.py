@@ -55,6 +55,8 @@ def kernel_bytes(N1, N2, nnz, B, Fin, Fout, K, paper):
         "rows_gemm_kernel<PROJECT_BWD>": 12 * N1 * Fin + M,
         "param_grad_partial_kernel": 4 * K * N1 * Fin + 4 * N1 * Fout + (8 * N1 * Fin if paper else 0),
         "param_grad_reduce_kernel": W + 4 * Fout + (M if paper else 0),
+        "param_grad_onepass_kernel": 4 * K * N1 * Fin + 4 * N1 * Fout + (8 * N1 * Fin if paper else 0)
+                                     + W + 4 * Fout + (M if paper else 0),
         # fused per-graph path (SGC_LL, K = 2): the layer-level algorithmic traffic of SURVEY 8(d) plus the
         # forward->backward reserve (Z, X_1, s, and r tiles in paper mode) and the Gp / dZ hand-off to the
         # parameter-gradient kernels

@@ -20,8 +20,8 @@ for k,v in acc.items():
     m={c:sum(x)/len(x) for c,x in v.items()}
     gui=m.get("GRBM_GUI_ACTIVE",0)
     busy=m.get("SQ_VALU_MFMA_BUSY_CYCLES",0)
-    # 256 CUs x 4 SIMDs each own a matrix pipe
-    m["mfma_util_of_chip"]=busy/(gui*1024) if gui else None
+    # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs; each XCD has 32 CUs x 4 SIMDs = 128 matrix pipes
+    m["mfma_util_of_chip"]=busy/(gui*128) if gui else None
     res[k]=m
     print("%-46s mfma_busy %12.0f  mops_f32 %10.0f  gui %8.0f  sq_busy %10.0f waves %7.0f  util %.4f" % (k[:46], busy, m.get("SQ_INSTS_VALU_MFMA_MOPS_F32",0), gui, m.get("SQ_BUSY_CYCLES",0), m.get("SQ_WAVES",0), m["mfma_util_of_chip"] or 0))
 json.dump(res, open("$out/mfma.json","w"), indent=1)
