@@ -94,7 +94,7 @@ FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const Pl
     *slabs = ns;
     return nb;
   };
-  static const int force_gb = [] { const char* e = std::getenv("AGCN_FUSED_GB"); return e ? std::atoi(e) : -1; }();
+  const int force_gb = agcn_get_fused_global_b();
   int ns = 0;
   int nb = count_big(lim, &ns);
   const bool gb_fits = std::max(fused_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K),

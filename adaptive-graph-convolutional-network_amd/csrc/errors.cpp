@@ -36,6 +36,21 @@ std::atomic<int32_t> g_fused_mode{[] {
 }()};
 extern "C" int32_t agcn_get_fused_mode(void) { return g_fused_mode.load(); }
 extern "C" void agcn_set_fused_mode(int32_t mode) { g_fused_mode.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
+// -1 (default): the library picks the flavour of the fused kernels per direction; 0: always LDS parameter images;
+// 1: always parameters from global memory (when the working set fits)
+std::atomic<int32_t> g_fused_gb{[] {
+  const char* e = std::getenv("AGCN_FUSED_GB");
+  return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
+}()};
+extern "C" int32_t agcn_get_fused_global_b(void) { return g_fused_gb.load(); }
+extern "C" void agcn_set_fused_global_b(int32_t mode) { g_fused_gb.store(mode < 0 ? -1 : (mode > 0 ? 1 : 0)); }
+// 1 (default): one-pass parameter-gradient kernel; 0: partial + reduce launches
+std::atomic<int32_t> g_pg_onepass{[] {
+  const char* e = std::getenv("AGCN_PG_ONEPASS");
+  return (e && e[0] == '0') ? 0 : 1;
+}()};
+extern "C" int32_t agcn_get_param_grad_onepass(void) { return g_pg_onepass.load(); }
+extern "C" void agcn_set_param_grad_onepass(int32_t on) { g_pg_onepass.store(on ? 1 : 0); }
 extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }
 extern "C" void agcn_set_slab_mode(int32_t mode) { g_slab_mode.store(mode ? 1 : 0); }
 extern "C" void agcn_set_lds_limit(int32_t bytes) {

@@ -257,10 +257,7 @@ void pg_split(int rows, int* rows_per_wave, int* S) {
   *rows_per_wave = rpw;
   *S = std::max(1, (rows + 16 * rpw - 1) / (16 * rpw));
 }
-int pg_mode() {
-  static const int m = [] { const char* e = std::getenv("AGCN_PG_ONEPASS"); return (e && e[0] == '0') ? 0 : 1; }();
-  return m;
-}
+int pg_mode() { return agcn_get_param_grad_onepass(); }
 }  // namespace
 
 // floats of `part` the one-pass kernel needs: S partial tiles per output tile + the arrival counters

@@ -334,6 +334,15 @@ void agcn_set_slab_mode(int32_t mode);
  * kernels. */
 int32_t agcn_get_fused_mode(void);
 void agcn_set_fused_mode(int32_t mode);
+/* Flavour of the fused kernels: -1 (default) the library picks per direction from measurements;
+ * 0: always stage M_L / W as LDS images; 1: always read them from global memory inside the k-loops (whenever the
+ * graph's own working set fits LDS).  Same results to the last few ulps (different summation grouping). */
+int32_t agcn_get_fused_global_b(void);
+void agcn_set_fused_global_b(int32_t mode);
+/* 1 (default): parameter gradients in one launch (row splits reduced by the last-arriving workgroup in fixed
+ * order); 0: partial + reduce launches.  Both bit-reproducible. */
+int32_t agcn_get_param_grad_onepass(void);
+void agcn_set_param_grad_onepass(int32_t on);
 
 #ifdef __cplusplus
 }

@@ -118,7 +118,8 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["fused", "mixed", "mixed_slab", "slab", "lds", "globaltile"])
+@pytest.mark.parametrize("path", ["fused", "fused_lds_images", "fused_global_b", "mixed", "mixed_slab", "slab", "lds",
+                                  "globaltile"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 @pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc", "reslap"])
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -127,6 +128,9 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     path: slab = slab-parallel kernels where eligible (SGC_LL, K = 2), lds = one workgroup per graph
     with the tile in LDS, globaltile = one workgroup per graph with the tile in global scratch."""
     ns, Fin, Fout, K = CASES[case]
+    gb = {"fused_lds_images": 0, "fused_global_b": 1}.get(path, -1)
+    if gb >= 0:
+        path = "fused"
     if path in ("slab", "fused", "mixed", "mixed_slab") and not (variant == orc.SGC_LL and K == 2):
         pytest.skip("the slab and fused paths cover SGC_LL with K = 2 only")
     if path in ("mixed", "mixed_slab") and case != 0:
@@ -137,6 +141,9 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     amd._ffi.lib().agcn_set_lds_limit({"globaltile": 0, "mixed": 110 * 1024, "mixed_slab": 110 * 1024}.get(path, 160 * 1024))
     amd._ffi.lib().agcn_set_slab_mode(1 if path in ("slab", "fused", "mixed", "mixed_slab") else 0)
     amd._ffi.lib().agcn_set_fused_mode({"fused": 1, "mixed": 2, "mixed_slab": 3}.get(path, 0))
+    amd._ffi.lib().agcn_set_fused_global_b(gb)
+    # the legacy two-launch parameter gradients ride along on the LDS-image flavour
+    amd._ffi.lib().agcn_set_param_grad_onepass(0 if gb == 0 else 1)
     try:
         rs, X, L0, csr, p, G = synth_case(1000 + case, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
         Lp = dLsum = None
@@ -147,6 +154,8 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
         out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, variant, Lp, dLsum)
         compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
     finally:
+        amd._ffi.lib().agcn_set_fused_global_b(-1)
+        amd._ffi.lib().agcn_set_param_grad_onepass(1)
         amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
         amd._ffi.lib().agcn_set_slab_mode(1)
         amd._ffi.lib().agcn_set_fused_mode(1)
