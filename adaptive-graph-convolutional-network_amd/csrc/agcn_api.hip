@@ -354,13 +354,15 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
       rc = launch_slab_forward(ab, ss.s);
     }
     if (rc != AGCN_OK) return rc;
-    fill_rows(g, desc, host, dev);
-    g.big_n = fs.thr; g.row_graph = dev.row_graph;
-    g.Kd = desc->Fin * desc->K; g.N = desc->Fout;
-    g.A0 = batch->X; g.lda0 = desc->ldx; g.A1 = a.sv_X; g.a1_plane = (int64_t)host.info.rows * desc->Fin;
-    g.Bm = params->weight; g.bias = params->bias; g.Out0 = out->Y; g.ldo0 = desc->ldy;
-    rc = launch_rows_gemm(g, RG_FILTER, ss.s);
-    if (rc != AGCN_OK) return rc;
+    if (fs.big_pg) {   // (the slab kernels apply the filter themselves)
+      fill_rows(g, desc, host, dev);
+      g.big_n = fs.thr; g.row_graph = dev.row_graph;
+      g.Kd = desc->Fin * desc->K; g.N = desc->Fout;
+      g.A0 = batch->X; g.lda0 = desc->ldx; g.A1 = a.sv_X; g.a1_plane = (int64_t)host.info.rows * desc->Fin;
+      g.Bm = params->weight; g.bias = params->bias; g.Out0 = out->Y; g.ldo0 = desc->ldy;
+      rc = launch_rows_gemm(g, RG_FILTER, ss.s);
+      if (rc != AGCN_OK) return rc;
+    }
     rc = launch_fused_forward(a, fs.n_big, host.info.B - fs.n_big,
                               fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), false, hip_stream);
     if (rc != AGCN_OK) return rc;
@@ -381,8 +383,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
   if (use_slabs(desc, batch, host.info)) {
-    rc = launch_slab_forward(a, hip_stream);
-    if (rc != AGCN_OK) return rc;
+    // slab_lap also applies the filter to its rows (Y = act([X_0|X_1] . W + b)): no packed FILTER launch
+    return launch_slab_forward(a, hip_stream);
   } else {
   if (n_glb > 0) {
     const size_t lds = 4 * (32 + (size_t)((host.info.max_n + 3) & ~3));
@@ -493,7 +495,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         rc = launch_slab_backward(ab, ss->s);
       }
       if (rc != AGCN_OK) return rc;
-      if (paper) {
+      if (paper && fs.big_pg) {   // (slab_bwd2 adds dZ . M_L^T to its rows itself)
         fill_rows(g, desc, host, dev);
         g.big_n = fs.thr; g.row_graph = dev.row_graph;
         g.Kd = desc->Fin; g.N = desc->Fin;
@@ -540,8 +542,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       if (rc != AGCN_OK) return rc;
     }
     }
-    // 3. paper mode: dX += dZ . M_L^T
-    if (paper) {
+    // 3. paper mode: dX += dZ . M_L^T  (the slab path does it inside slab_bwd2)
+    if (paper && !slabs) {
       fill_rows(g, desc, host, dev);
       g.Kd = desc->Fin; g.N = desc->Fin;
       g.A0 = w.dZ; g.lda0 = desc->Fin; g.Bm = params->M_L; g.Out0 = grads->dX; g.ldo0 = desc->ldx;

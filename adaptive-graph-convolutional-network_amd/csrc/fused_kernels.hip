@@ -86,89 +86,6 @@ __device__ __forceinline__ void tile_gemm_ta(f32x4& acc, const float* At, int ld
   }
 }
 
-// B operand straight from global memory (L2-resident parameters), no LDS image:
-//   B[k][c] = Bg[k * krow + c] for k < kvalid, c < cvalid; addresses are clamped, the A image's zero padding
-//   (columns >= kvalid) cancels the clamped rows and out-of-range columns are never stored.
-// The loads of the next 16-k block are issued before the MFMAs of the current one.
-__device__ __forceinline__ void tile_gemm_gbx(f32x4& acc, const float* A, int lda, int row0, const float* Bp,
-                                              int kstride, int klast, int kdim) {
-  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const float* Ap = A + (row0 + r) * lda + q;
-  float b0[4], b1[4];
-  auto ldb = [&](int k0, float (&dst)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) dst[u] = Bp[(int64_t)min(k0 + 4 * u + q, klast) * kstride];
-  };
-  auto step = [&](int k0, const float (&bv)[4]) {
-    float av[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) av[u] = Ap[k0 + 4 * u];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-  };
-  ldb(0, b0);
-#pragma unroll 1
-  for (int k0 = 0; k0 < kdim; k0 += 32) {
-    const bool more1 = k0 + 16 < kdim, more2 = k0 + 32 < kdim;
-    if (more1) ldb(k0 + 16, b1);
-    step(k0, b0);
-    if (more1) {
-      if (more2) ldb(k0 + 32, b0);
-      step(k0 + 16, b1);
-    }
-  }
-}
-// row-major B in global memory: B[k][c] = Bg[k * krow + c]
-__device__ __forceinline__ void tile_gemm_gb(f32x4& acc, const float* A, int lda, int row0, const float* Bg,
-                                             int krow, int kvalid, int col0, int cvalid, int kdim) {
-  const int r = threadIdx.x & 15;
-  tile_gemm_gbx(acc, A, lda, row0, Bg + min(col0 + r, cvalid - 1), krow, kvalid - 1, kdim);
-}
-// Transposed B with k contiguous in memory, 16-byte loads: lane (r, q) fetches Brow[k0 + 4q .. 4q + 3] in one
-// instruction (the 16 rows of a wave-load are 64 contiguous bytes each: every fetched line is fully used; the
-// dword form above touches the same 16 lines four times).  MFMA step j therefore pairs B[k0 + 4q + j] with the A
-// element at image position k0 + 4j + q: the A image must be stored k-permuted inside every 16-block (perm16).
-__device__ __forceinline__ int perm16(int c) { return (c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3); }
-__device__ __forceinline__ void tile_gemm_gbt4(f32x4& acc, const float* A, int lda, int row0, const float* Brow,
-                                               int kvalid, int kdim) {
-  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const float* Ap = A + (row0 + r) * lda + q;
-  const float* Bq = Brow + 4 * q;
-  const int klast = kvalid - 1;
-  // full 16-blocks of 16-byte aligned rows: one 16-byte load; otherwise (tail block, rows of e.g. 75 floats):
-  // clamped dword loads of the same elements (the A image's zero padding cancels the clamped ones)
-  const bool al = (reinterpret_cast<uintptr_t>(Brow) & 15) == 0;   // wave-uniform when the row stride is 16-byte
-  auto ldb = [&](int k0, float (&dst)[4]) {
-    if (al && k0 + 16 <= kvalid) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(Bq + k0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dst[u] = t[u];
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dst[u] = Brow[min(k0 + 4 * q + u, klast)];
-    }
-  };
-  auto step = [&](int k0, const float (&bv)[4]) {
-    float av[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) av[u] = Ap[k0 + 4 * u];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-  };
-  float b0[4], b1[4];
-  ldb(0, b0);
-#pragma unroll 1
-  for (int k0 = 0; k0 < kdim; k0 += 32) {
-    const bool more1 = k0 + 16 < kdim, more2 = k0 + 32 < kdim;
-    if (more1) ldb(k0 + 16, b1);
-    step(k0, b0);
-    if (more1) {
-      if (more2) ldb(k0 + 32, b0);
-      step(k0 + 16, b1);
-    }
-  }
-}
-
 struct FusedBwdDims {
   int n4, F4, O4, ldt, ldxa, ldg;
   int64_t o_svec, o_dd, o_rs, o_colp, o_tile, o_dx, o_g1, o_r3, o_wt, o_x0, o_m, total;

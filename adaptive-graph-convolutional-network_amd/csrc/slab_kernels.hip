@@ -20,6 +20,8 @@
 
 #include <float.h>
 
+#include <algorithm>
+
 namespace agcn {
 
 namespace {
@@ -278,16 +280,51 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
     strip_gemm_rowmajor(acc, Ls, CHP, Xs, ldbx, (nc + 15) & ~15, ntiles);
   }
   AGCN_STAMP(6, 4);
-  // X_1[I] = L[I, :] X_0   (graphconv.py:231)
+  // X_1[I] = L[I, :] X_0   (graphconv.py:231) -> reserve, and as an A image for the filter product below
+  const int F16 = (Fin + 15) & ~15, ldxa = ld_frag(F16);
+  __syncthreads();                   // the chunk images are dead
+  float* X0s = smem;                 // [16][ldxa] X_0 rows of the slab (zero padded)
+  float* X1s = smem + SH * ldxa;     // [16][ldxa] X_1 rows of the slab
   float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * Fin;
   if (wave < ntiles) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int col = 16 * (wave + 4 * t) + r;
-      if (wave + 4 * t < ntiles && col < Fin) {
+      if (wave + 4 * t < ntiles) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (4 * q + i < c.nr) Xo[(int64_t)(4 * q + i) * Fin + col] = acc[t][i];
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = 4 * q + i < c.nr && col < Fin;
+          X1s[(4 * q + i) * ldxa + col] = ok ? acc[t][i] : 0.f;
+          if (ok) Xo[(int64_t)(4 * q + i) * Fin + col] = acc[t][i];
+        }
+      }
+    }
+  }
+  bulk_for2d<4>(
+      SH, F16, [&](int ii, int f) { return Xg[(int64_t)(c.i0 + min(ii, c.nr - 1)) * a.ldx + min(f, Fin - 1)]; },
+      [&](int ii, int f, float v) { X0s[ii * ldxa + f] = (ii < c.nr && f < Fin) ? v : 0.f; });
+  __syncthreads();
+  // Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b)   (graphconv.py:238-251,117-123): W row f*K + k straight from global
+  // memory, one 16 x 16 output tile per wave and pass (this replaces the packed FILTER launch on the slab path)
+  {
+    const int Fout = a.Fout, K = a.K;
+    const bool relu = a.activation == AGCN_ACT_RELU;
+    float* Yg = a.Y + (int64_t)(c.row0 + c.i0) * a.ldy;
+    for (int tcol = wave; tcol < ((Fout + 15) >> 4); tcol += 4) {
+      f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+      tile_gemm_gb(y, X0s, ldxa, 0, a.weight, K * Fout, Fin, 16 * tcol, Fout, F16);
+      tile_gemm_gb(y, X1s, ldxa, 0, a.weight + Fout, K * Fout, Fin, 16 * tcol, Fout, F16);
+      const int col = 16 * tcol + r;
+      if (col < Fout) {
+        const float bc = a.bias[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (4 * q + i < c.nr) {
+            float v = y[i] + bc;
+            if (relu) v = fmaxf(v, 0.f);
+            Yg[(int64_t)(4 * q + i) * a.ldy + col] = v;
+          }
+        }
       }
     }
   }
@@ -504,19 +541,40 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
     if (lane == 0) csum[4 * wave + di] = t;
   }
   __syncthreads();
-  // dZ_i = rowsum(c)_i Z_i - (c Z)_i
+  // dZ_i = rowsum(c)_i Z_i - (c Z)_i  -> workspace (for dM_L) and, k-permuted, an A image for the product below
+  const int F16 = (Fin + 15) & ~15, ldxa = ld_frag(F16);
+  float* dZs = Zs;                   // [16][ldxa]  (the chunk images are dead after the barrier above)
   float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * Fin;
   const float* Zi = Zg + (int64_t)c.i0 * Fin;
   if (wave < ntiles) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int col = 16 * (wave + 4 * t) + r;
-      if (wave + 4 * t < ntiles && col < Fin) {
+      if (wave + 4 * t < ntiles) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int il = 4 * q + i;
-          if (il < c.nr) dZg[(int64_t)il * Fin + col] = csum[il] * Zi[(int64_t)il * Fin + col] - acc[t][i];
+          const bool ok = il < c.nr && col < Fin;
+          const float v = ok ? csum[il] * Zi[(int64_t)il * Fin + col] - acc[t][i] : 0.f;
+          dZs[il * ldxa + perm16(col)] = v;
+          if (ok) dZg[(int64_t)il * Fin + col] = v;
         }
+      }
+    }
+  }
+  __syncthreads();
+  // dX[I] += dZ[I] M_L^T   (adjoint of graphconv.py:164; replaces the packed PROJECT_BWD launch on the slab path):
+  // B[k][f] = M_L[f][k], the lane's M_L row read along k
+  {
+    float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+    for (int tcol = wave; tcol < ntiles; tcol += 4) {
+      const int f = 16 * tcol + r;
+      f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+      tile_gemm_gbt4(d, dZs, ldxa, 0, a.M_L + (int64_t)min(f, Fin - 1) * Fin, Fin, F16);
+      if (f < Fin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * q + i < c.nr) dXg[(int64_t)(4 * q + i) * a.ldx + f] += d[i];
       }
     }
   }
@@ -525,14 +583,20 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 size_t lds_sim(int Fin) { return sizeof(float) * ((size_t)Fin * SH + (size_t)Fin * CH1P); }
-size_t lds_lap(int Fin) { return sizeof(float) * ((size_t)SH * CHP + (size_t)CH * ld_b(Fin)); }
+size_t lds_lap(int Fin) {
+  const size_t strips = 2 * (size_t)SH * ld_frag((Fin + 15) & ~15);   // X_0 / X_1 images of the fused filter product
+  return sizeof(float) * std::max((size_t)SH * CHP + (size_t)CH * ld_b(Fin), strips);
+}
 size_t lds_bwd1(int Fin, bool paper) {
   const size_t ldf = ld_frag((Fin + 15) & ~15);
   size_t f = (size_t)SH * CHP + (size_t)CH * ldf + 32;
   if (paper) f += 2 * (size_t)SH * CHP + 2 * (size_t)SH * ldf + (size_t)CH * ldf;
   return sizeof(float) * f;
 }
-size_t lds_bwd2(int Fin) { return sizeof(float) * ((size_t)SH * CHP + (size_t)CH * ld_b(Fin) + SH); }
+size_t lds_bwd2(int Fin) {
+  const size_t img = std::max((size_t)CH * ld_b(Fin), (size_t)SH * ld_frag((Fin + 15) & ~15));   // chunk rows / dZ image
+  return sizeof(float) * ((size_t)SH * CHP + img + SH);
+}
 
 template <class K>
 int launch_slab(K kernel, const SgcArgs& a, size_t lds, int prof_id, const char* what, void* stream) {
