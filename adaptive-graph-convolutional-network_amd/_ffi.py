@@ -73,7 +73,7 @@ SYMBOLS = [
     "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
     "agcn_multitask_ce_workspace_bytes", "agcn_multitask_ce_forward", "agcn_multitask_ce_backward",
     "agcn_graph_pool_forward", "agcn_graph_pool_backward",
-    "agcn_store_batch_sizes", "agcn_store_pack_batch", "agcn_cast_rows",
+    "agcn_store_batch_sizes", "agcn_store_pack_batch", "agcn_cast_rows", "agcn_rows_pack", "agcn_rows_unpack",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
     "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
     "agcn_get_fused_global_b", "agcn_set_fused_global_b", "agcn_get_param_grad_onepass", "agcn_set_param_grad_onepass",
@@ -124,6 +124,10 @@ def _declare(lib):
     lib.agcn_multitask_ce_forward.argtypes = [I32, I32, I32, P, I32, P, P, P, P, C.c_float, P, P, P, SZ, P]
     lib.agcn_multitask_ce_backward.restype = C.c_int
     lib.agcn_multitask_ce_backward.argtypes = [I32, I32, I32, P, I32, P, P, P, P, C.c_float, P, P, P, P, P, SZ, P]
+    lib.agcn_rows_pack.restype = C.c_int
+    lib.agcn_rows_pack.argtypes = [P, P, P, I32, I32, I32, P, I32, P]
+    lib.agcn_rows_unpack.restype = C.c_int
+    lib.agcn_rows_unpack.argtypes = [P, P, P, I32, I32, P, I32, I32, P, P]
     lib.agcn_cast_rows.restype = C.c_int
     lib.agcn_cast_rows.argtypes = [P, I32, P, I32, C.c_int64, I32, I32, I32, P]
     lib.agcn_store_batch_sizes.restype = C.c_int

@@ -20,6 +20,11 @@ import torch
 from . import _ffi
 
 
+# The reference's padded feed is gathered into packed rows at the first layer (GraphBatch.from_padded); set to
+# False to keep the rows padded end to end (slower; the layout the reference itself computes on).
+PACK_REFERENCE_FEED = True
+
+
 def _csr_is_symmetric(n, indptr, indices, data):
     """Exact (bitwise, after the float32 cast the device sees) symmetry of one CSR matrix."""
     n = int(n)
@@ -126,14 +131,27 @@ class TileViews(Sequence):
 
 
 class RowViews(Sequence):
-    """Lazy list of per-graph node-feature matrices.  With padded rows (row_stride > 0) item b
-    is the reference's [max_atom, F] tensor; with packed rows it is [n_b, F]."""
+    """Lazy list of per-graph node-feature matrices (what the reference passes between layers as a Python list of
+    B [max_atom, F] tensors).  `data` is the row matrix the kernels work on:
+      * packed rows (the fast layout): item b is [n_b, F] -- unless the batch came from the reference's padded
+        feed (`batch.pad_stride` = max_atom): then item b is the reference's [max_atom, F] tensor, cut out of a
+        padded copy that is produced (one `agcn_rows_unpack` launch, differentiable) only when an item is first
+        looked at; layers of this package take `data` and never trigger it;
+      * padded rows (row_stride > 0, `GraphBatch.from_padded(..., pack=False)`): item b is a view."""
 
-    def __init__(self, data, plan):
-        self.data, self.plan = data, plan
+    def __init__(self, data, plan, batch=None, pad_fill=None):
+        self.data, self.plan, self.batch, self.pad_fill = data, plan, batch, pad_fill
+        self._padded = None
 
     def __len__(self):
         return self.plan.B
+
+    def padded(self):
+        """[B * max_atom, F] padded copy (reference layout) of packed rows."""
+        if self._padded is None:
+            from .functional import UnpackRowsFunction
+            self._padded = UnpackRowsFunction.apply(self.data, self.batch, self.batch.pad_stride, self.pad_fill)
+        return self._padded
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -143,6 +161,9 @@ class RowViews(Sequence):
             return [self[j] for j in idx]
         if i < 0:
             i += len(self)
+        stride = getattr(self.batch, "pad_stride", 0) if self.plan.row_stride == 0 else 0
+        if stride:
+            return self.padded()[i * stride:(i + 1) * stride]
         return self.data[int(self.plan.row_off[i]):int(self.plan.row_off[i + 1])]
 
 
@@ -158,6 +179,9 @@ class GraphBatch(object):
         # True only when every original Laplacian equals its transpose (checked on the host at
         # pack time); the slab-parallel kernels rely on it
         self.l0_symmetric = bool(l0_symmetric)
+        # > 0: the batch came from the reference's padded feed with this max_atom; per-graph views of layer outputs
+        # are then padded to it on demand (RowViews)
+        self.pad_stride = 0
 
     @property
     def device(self):
@@ -196,24 +220,39 @@ class GraphBatch(object):
                    l0_symmetric=sym)
 
     @classmethod
-    def from_padded(cls, node_features, laplacians, data_slice, device=None):
-        """Batch in the REFERENCE's feed layout: node_features / laplacians are lists of B
-        [max_atom, F] / [max_atom, max_atom] tensors (or one 3-D tensor each), data_slice is the
-        int32 [B, 2] array with rows [n, -1] (graph_topology.py:90).  Rows stay padded
-        (row_stride = max_atom) so outputs alias the reference's per-graph tensors."""
+    def from_padded(cls, node_features, laplacians, data_slice, device=None, pack=None):
+        """Batch from the REFERENCE's feed layout: node_features / laplacians are lists of B [max_atom, F] /
+        [max_atom, max_atom] tensors (or one 3-D tensor each; laplacians may be None for layers that do not need
+        them), data_slice is the int32 [B, 2] array with rows [n, -1] (graph_topology.py:90).
+        pack=True (default on the GPU): the real rows are gathered once into PACKED rows (`agcn_rows_pack`,
+        differentiable), the dense Laplacians are used in place, and everything downstream runs on the fast packed
+        paths; per-graph outputs are padded back to [max_atom, F] only when looked at (RowViews).
+        pack=False: rows stay padded (row_stride = max_atom), outputs alias the reference's per-graph tensors."""
         X3 = node_features if torch.is_tensor(node_features) else torch.stack(list(node_features))
-        L3 = laplacians if torch.is_tensor(laplacians) else torch.stack(list(laplacians))
         ds = data_slice.detach().cpu().numpy() if torch.is_tensor(data_slice) else np.asarray(data_slice)
         n = np.ascontiguousarray(ds[:, 0], dtype=np.int32)
         B, max_atom, F = X3.shape
-        if L3.shape != (B, max_atom, max_atom) or n.shape[0] != B:
-            raise ValueError("inconsistent padded batch shapes")
         device = X3.device if device is None else torch.device(device)
-        plan = Plan(n, max_atom, device)
+        L = None
+        if laplacians is not None:
+            L3 = laplacians if torch.is_tensor(laplacians) else torch.stack(list(laplacians))
+            if L3.shape != (B, max_atom, max_atom):
+                raise ValueError("inconsistent padded batch shapes")
+            L = L3.to(device=device, dtype=torch.float32).contiguous()
+        if n.shape[0] != B:
+            raise ValueError("inconsistent padded batch shapes")
+        sym = bool(torch.equal(L, L.transpose(1, 2))) if L is not None else False
         X = X3.to(device=device, dtype=torch.float32).reshape(B * max_atom, F)
-        L = L3.to(device=device, dtype=torch.float32).contiguous()
-        sym = bool(torch.equal(L, L.transpose(1, 2)))
-        return cls(plan, X, l0_dense=L, l0_ld=max_atom, l0_symmetric=sym)
+        if pack is None:
+            pack = PACK_REFERENCE_FEED and device.type == "cuda"
+        if not pack:
+            plan = Plan(n, max_atom, device)
+            return cls(plan, X, l0_dense=L, l0_ld=max_atom if L is not None else 0, l0_symmetric=sym)
+        from .functional import PackRowsFunction
+        gb = cls(Plan(n, 0, device), None, l0_dense=L, l0_ld=max_atom if L is not None else 0, l0_symmetric=sym)
+        gb.pad_stride = int(max_atom)
+        gb.X = PackRowsFunction.apply(X, gb, max_atom)
+        return gb
 
     def rows(self, data):
         return RowViews(data, self.plan)

@@ -58,7 +58,7 @@ bool use_slabs(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanIn
          (g->L0_rowptr != nullptr || g->L0_dense != nullptr) && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
 }
 
-// Fused per-graph kernels (fused_kernels.hip): SGC_LL, K = 2, packed rows, CSR L_orig, for the graphs
+// Fused per-graph kernels (fused_kernels.hip): SGC_LL, K = 2, packed rows, CSR or dense L_orig, for the graphs
 // whose working set fits LDS.  Graphs are scheduled largest first, so the ones that do NOT fit are a
 // prefix of plan.order (and their slabs a prefix of the slab table): with `mixed` dispatch those few
 // graphs run on the slab-parallel kernels on a side stream, concurrently with the fused kernels.
@@ -78,8 +78,8 @@ FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const Pl
   FusedSplit f{0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
-  if (!(d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 && g->L0_rowptr != nullptr &&
-        g->L0_dense == nullptr)) return f;
+  if (!(d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 &&
+        (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;
   size_t lim = (size_t)agcn_get_lds_limit();
   if (lim > 160 * 1024) lim = 160 * 1024;
   auto need = [&](int n) {

@@ -170,10 +170,14 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
   AGCN_STAMP(1, 0);
   // ---- F0: one bulk round for everything the graph needs from memory -------------------------------
   int csr_p0 = 0, csr_p1 = 0;
-  if (tid < n) {
+  if (a.L0_rowptr && tid < n) {
     csr_p0 = a.L0_rowptr[row0 + tid];
     csr_p1 = a.L0_rowptr[row0 + tid + 1];
   }
+  // dense original Laplacian (the reference's feed, graph_topology.py:92-98, or packed tiles): added row by row
+  const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+  const float* L0d = !a.L0_dense ? nullptr
+                                 : (a.L0_ld > 0 ? a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
   int csr_c[4] = {0, 0, 0, 0};
   float csr_v[4] = {0.f, 0.f, 0.f, 0.f};
   bool csr_loaded = false;
@@ -391,7 +395,10 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
       tile[i * ldt + j] = 0.f;
     }
     __syncthreads();
-    if (tid < n) {
+    if (L0d) {
+      for (int i = wave; i < n; i += nthr >> 6)
+        for (int j = lane; j < n; j += 64) tile[i * ldt + j] += L0d[(int64_t)i * l0ld + j];
+    } else if (tid < n) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
@@ -511,10 +518,15 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   // ---- B0: loads: dY, Y rows -> Gp image (+ global copy); W -> regrouped image; CSR rows; s --------
   int csr_p0 = 0, csr_p1 = 0;
   if (tid < n) {
-    csr_p0 = a.L0_rowptr[row0 + tid];
-    csr_p1 = a.L0_rowptr[row0 + tid + 1];
+    if (a.L0_rowptr) {
+      csr_p0 = a.L0_rowptr[row0 + tid];
+      csr_p1 = a.L0_rowptr[row0 + tid + 1];
+    }
     s_vec[tid] = paper ? a.sv_s[row0 + tid] : 0.f;
   }
+  const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+  const float* L0d = !a.L0_dense ? nullptr
+                                 : (a.L0_ld > 0 ? a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
   // res_L rows (wave = row, lanes = columns, 2 column passes): requested now, stored after the staging
   const bool lpref = (nw == 16 && n4 <= 128);
   float lreg[8][2];
@@ -587,7 +599,10 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     }
   }
   __syncthreads();
-  if (tid < n) {
+  if (L0d) {
+    for (int i = wave; i < n; i += nw)
+      for (int j = lane; j < n; j += 64) tile[i * ldt + j] += L0d[(int64_t)i * l0ld + j];
+  } else if (tid < n) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];

@@ -53,6 +53,50 @@ class CastRowsFunction(torch.autograd.Function):
         return CastRowsFunction.apply(g, ctx.src), None
 
 
+class PackRowsFunction(torch.autograd.Function):
+    """Reference feed -> packed rows: [B * stride, F] (graph b at rows b*stride .. b*stride + n_b) -> [N1, F].
+    `batch.plan` is the PACKED plan.  Backward unpacks the gradient (pad rows get 0)."""
+
+    @staticmethod
+    def forward(ctx, Xpad, batch, stride):
+        _require_gpu(Xpad, "node features")
+        Xpad = _f32c(Xpad, "node features")
+        plan, F = batch.plan, Xpad.shape[1]
+        if Xpad.shape[0] != plan.B * stride:
+            raise ValueError("padded node features must be [B * max_atom, F]")
+        out = torch.empty((plan.N1, F), dtype=torch.float32, device=Xpad.device)
+        _ffi.check(_ffi.lib().agcn_rows_pack(plan.host_ptr, plan.dev_ptr, Xpad.data_ptr(), int(stride), F, F,
+                                             out.data_ptr(), F, _stream(Xpad.device)))
+        ctx.batch, ctx.stride = batch, int(stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return UnpackRowsFunction.apply(g, ctx.batch, ctx.stride, None), None, None
+
+
+class UnpackRowsFunction(torch.autograd.Function):
+    """Packed rows -> the reference's padded layout [B * stride, F]; pad rows are 0, or `fill` [F] (DenseMol's
+    bias lands on pad rows too, dense_layer.py:42-50).  Backward packs the gradient."""
+
+    @staticmethod
+    def forward(ctx, Xp, batch, stride, fill):
+        _require_gpu(Xp, "node features")
+        Xp = _f32c(Xp, "node features")
+        plan, F = batch.plan, Xp.shape[1]
+        out = torch.empty((plan.B * int(stride), F), dtype=torch.float32, device=Xp.device)
+        if fill is not None:
+            fill = _f32c(fill.detach(), "fill")
+        _ffi.check(_ffi.lib().agcn_rows_unpack(plan.host_ptr, plan.dev_ptr, Xp.data_ptr(), F, F, out.data_ptr(),
+                                               int(stride), F, _ptr(fill), _stream(Xp.device)))
+        ctx.batch, ctx.stride = batch, int(stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return PackRowsFunction.apply(g, ctx.batch, ctx.stride), None, None, None
+
+
 class _Cfg(object):
     __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation")
 

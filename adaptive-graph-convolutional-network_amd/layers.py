@@ -23,7 +23,7 @@ import torch
 
 from .batch import GraphBatch, RowViews, TileViews
 from .functional import (CastRowsFunction, GraphGatherFunction, GraphPoolFunction, MultitaskCEFunction,
-                         RowsDenseFunction, SgcLLFunction, _Cfg)
+                         PackRowsFunction, RowsDenseFunction, SgcLLFunction, _Cfg)
 
 _UID_PREFIXES = defaultdict(int)
 
@@ -189,8 +189,7 @@ class SGC_LL(Layer):
         v = self.vars
         Y, res_L, res_W, L_sum = SgcLLFunction.apply(_in32(X), v["weight"], v["bias"], v["M_L"], v["alpha"],
                                                      v.get("beta"), L_prev, gb, cfg)
-        nodes = RowViews(_out_as(Y, X.dtype), gb.plan)
-        nodes.batch = gb
+        nodes = RowViews(_out_as(Y, X.dtype), gb.plan, gb)
         return gb, nodes, TileViews(res_L, gb.plan), TileViews(res_W, gb.plan), TileViews(L_sum, gb.plan)
 
     def call(self, x):
@@ -251,7 +250,7 @@ class GraphGatherMol(Layer):
         return _out_as(GraphGatherFunction.apply(_in32(X), gb, self.activation), X.dtype)
 
 
-def _rows_of(x, key="node_features"):
+def _rows_of(x, key="node_features", pack=None):
     """(GraphBatch, 2-D tensor) for a node-feature input that is either a RowViews of this package,
     a 2-D tensor + x['graph_batch'], or the reference's list of padded tensors (+ 'data_slice')."""
     nf = x[key]
@@ -263,19 +262,12 @@ def _rows_of(x, key="node_features"):
     X3 = nf if torch.is_tensor(nf) else torch.stack(list(nf))
     ds = x["data_slice"]
     ds = ds.detach().cpu().numpy() if torch.is_tensor(ds) else np.asarray(ds)
-    from .batch import Plan
-    if "original_laplacian" in x:
-        gb = GraphBatch.from_padded(X3, x["original_laplacian"], ds)
-        return gb, gb.X
-    plan = Plan(ds[:, 0], X3.shape[1], X3.device)
-    gb = GraphBatch(plan, X3.reshape(-1, X3.shape[2]))
+    gb = GraphBatch.from_padded(X3, x.get("original_laplacian"), ds, pack=pack)
     return gb, gb.X
 
 
-def _row_views(data, gb):
-    v = RowViews(data, gb.plan)
-    v.batch = gb
-    return v
+def _row_views(data, gb, pad_fill=None):
+    return RowViews(data, gb.plan, gb, pad_fill)
 
 
 class DenseMol(Layer):
@@ -315,10 +307,15 @@ class DenseMol(Layer):
         return [self.W, self.b]
 
     def __call__(self, x):
-        gb, X = _rows_of(x)
+        # Fed the raw padded lists, the layer works on ALL max_atom rows like the reference (pad rows give the bias
+        # and carry gradient into it, dense_layer.py:42-50).  Fed the packed output of a previous layer, pad rows
+        # exist only in the lazily padded view (= bias, no gradient) -- the same thing for every reference network,
+        # whose only consumer of this layer, GraphGatherMol, slices the real rows (graphgather.py:50-58).
+        gb, X = _rows_of(x, pack=False)
         self.build(X.device)
         Y = RowsDenseFunction.apply(_in32(X), self.W, self.b if self.bias else None, None, gb, "linear", True)
-        return _row_views(_out_as(Y, X.dtype), gb)
+        # pad rows of the reference's output hold the bias (xx . W + b on all max_atom rows, dense_layer.py:42-50)
+        return _row_views(_out_as(Y, X.dtype), gb, self.b if self.bias else None)
 
 
 class BlockEnd(Layer):
@@ -356,11 +353,7 @@ class BlockEnd(Layer):
         gb, X = _rows_of(x)
         x2 = dict(x)
         x2["graph_batch"] = gb
-        _, Xres = _rows_of(x2, "block_outputs") if isinstance(x["block_outputs"], RowViews) else (None, None)
-        if Xres is None:
-            bo = x["block_outputs"]
-            X3 = bo if torch.is_tensor(bo) else torch.stack(list(bo))
-            Xres = X3.reshape(-1, X3.shape[-1]) if X3.dim() == 3 else X3
+        Xres = _source_rows(x["block_outputs"], self.res_n_features, gb)
         self.build(X.device)
         Y = RowsDenseFunction.apply(_in32(Xres), self.vars["weight"], None, _in32(X).contiguous(), gb,
                                     "relu" if self.activation == "relu" else "linear", False)
@@ -372,10 +365,14 @@ def _source_rows(src, F, gb):
     (what the reference's containers accumulate with `list += layer_output`, tf_graphs.py:268,292).  Per-graph
     views produced by this package are recognised and mapped back to their packed parent without a copy."""
     plan = gb.plan
+    stride = getattr(gb, "pad_stride", 0) if plan.rows == plan.N1 else 0
     if isinstance(src, RowViews):
         return src.data
     if torch.is_tensor(src):
-        return src if src.dim() == 2 else src.reshape(-1, src.shape[-1])
+        src2 = src if src.dim() == 2 else src.reshape(-1, src.shape[-1])
+        if stride and src2.shape[0] == plan.B * stride and src2.shape[0] != plan.rows:
+            return PackRowsFunction.apply(src2, gb, stride)      # padded 3-D / 2-D source, packed batch
+        return src2
     ts = list(src)
     if len(ts) != plan.B:
         raise ValueError("a residual source must hold one tensor per graph (%d), got %d" % (plan.B, len(ts)))
@@ -385,6 +382,8 @@ def _source_rows(src, F, gb):
         if all(t._base is base and t.data_ptr() == base.data_ptr() + int(plan.row_off[b]) * w
                for b, t in enumerate(ts)):
             return base
+    if stride and all(t.shape[0] == stride for t in ts):   # the reference's padded per-graph tensors
+        return PackRowsFunction.apply(torch.stack(ts).reshape(-1, ts[0].shape[-1]), gb, stride)
     if plan.rows == plan.N1:      # packed rows
         return torch.cat([t[:int(plan.n[b])] for b, t in enumerate(ts)], 0)
     return torch.stack(ts).reshape(-1, ts[0].shape[-1])

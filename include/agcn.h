@@ -281,6 +281,17 @@ int agcn_graph_pool_backward(const void* plan_host, const void* plan_dev, const 
 int agcn_cast_rows(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t rows, int32_t cols,
                    int32_t ld_src, int32_t ld_dst, void* hip_stream);
 
+/* Row layout conversion between the reference's padded feed and packed rows.  The reference hands every layer
+ * lists of B [max_atom, F] tensors (graph_topology.py:84-91) and slices the real rows off again inside the layer
+ * (graphconv.py:145-154); here the first layer of a network packs them once (agcn_rows_pack), the whole network
+ * runs on packed rows, and a padded copy is produced only if the caller looks at per-graph outputs
+ * (agcn_rows_unpack; pad rows = 0, or pad_fill[F] for DenseMol whose bias also lands on pad rows,
+ * dense_layer.py:42-50).  `plan` must be a packed plan (row_stride 0) of the same node counts. */
+int agcn_rows_pack(const void* plan_host, const void* plan_dev, const float* padded, int32_t stride_rows, int32_t F,
+                   int32_t ld_padded, float* packed, int32_t ld_packed, void* hip_stream);
+int agcn_rows_unpack(const void* plan_host, const void* plan_dev, const float* packed, int32_t F, int32_t ld_packed,
+                     float* padded, int32_t stride_rows, int32_t ld_padded, const float* pad_fill, void* hip_stream);
+
 /* ---- packed-batch ingest: the step before the path, host only -------------------
  * Replaces the per-step feed construction of models/tf_modules/graph_topology.py:84-135 (pad every graph
  * to max_atom, densify every Laplacian) fed by DiskDataset.iterbatches (utils/dataset/diskdataset.py:239-295).

@@ -30,12 +30,17 @@ def amd():
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("pack", [True, False], ids=["packed", "padded_rows"])
 @pytest.mark.parametrize("lds_limit", [160 * 1024, 0], ids=["lds", "globaltile"])
 @pytest.mark.parametrize("name", LAYER)
-def test_golden_reference_feed(amd, name, lds_limit):
+def test_golden_reference_feed(amd, name, lds_limit, pack):
     """The reference's own feed layout (lists of padded tensors + int32 slices) in, the
-    reference's outputs and TF-autodiff gradients out (laplacian_mode='reference')."""
+    reference's outputs and TF-autodiff gradients out (laplacian_mode='reference').
+    packed: the first layer gathers the real rows once and everything runs on packed rows (fused / slab / split
+    kernels), per-graph outputs are padded back on demand; padded_rows: rows stay padded end to end."""
+    import agcn_amd.batch as batch_mod
     amd._ffi.lib().agcn_set_lds_limit(lds_limit)
+    batch_mod.PACK_REFERENCE_FEED = pack
     try:
         g = load_golden(name)
         ns = g["ns"]
@@ -105,6 +110,7 @@ def test_golden_reference_feed(amd, name, lds_limit):
                     assert has
                     assert_close(to_np(v.grad), g[prefix + "d_" + k], GRAD_RTOL, prefix + "d" + k)
     finally:
+        batch_mod.PACK_REFERENCE_FEED = True
         amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
 
 

@@ -3,6 +3,7 @@
 (inputs resident, HIP-graph replay, wall clock around K steps bracketed by synchronize):
 
   tox21-l1 / l2 / l3 / l4 : the four SimpleAGCN layer shapes 75->64, 64->128, 128->128, 128->64 at B=256
+  ref-feed                : 75->64 at B=256 in the reference's padded feed layout (max_atom 132, dense Laplacians)
   tox21-2048              : 75->64 at B=2048 (config[3] on one GPU)
   modelnet-3-64 / 64-128  : B graphs of n=1024 points, dense original Laplacian (config[2])
   epoch                   : ingest (graph store -> packed batch -> upload) + layer over an HIV-shaped dataset
@@ -136,6 +137,22 @@ def main():
         data = synth.tox21_batch(123, 256, Fin)
         gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
         run_layer(name, gb, data["n"], sum(len(c[1]) for c in data["csr"]), Fin, Fout, False)
+
+    if want("ref-feed"):
+        # the reference's own feed layout (graph_topology.py:84-135): every graph padded to max_atom = 132 rows,
+        # dense [max_atom, max_atom] Laplacians -- the literal drop-in call
+        data = synth.tox21_batch(123, 256, 75)
+        n, B, MA = data["n"], 256, 132
+        Xp = np.zeros((B, MA, 75), np.float32)
+        Lp = np.zeros((B, MA, MA), np.float32)
+        for b in range(B):
+            Xp[b, :n[b]] = data["X"][b]
+            ip, ix, v = data["csr"][b]
+            rr = np.repeat(np.arange(n[b]), np.diff(ip))
+            Lp[b, rr, ix] = v.astype(np.float32)
+        ds = np.stack([n, -np.ones(B)], 1).astype(np.int32)
+        gb = amd.GraphBatch.from_padded(torch.from_numpy(Xp).to(dev), torch.from_numpy(Lp).to(dev), ds, dev)
+        run_layer("ref-feed (padded lists in, rows packed once by agcn_rows_pack, dense L in place)", gb, n, 0, 75, 64, True)
 
     if want("tox21-2048"):
         data = synth.tox21_batch(123, 2048, 75)
