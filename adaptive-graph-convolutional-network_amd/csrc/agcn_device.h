@@ -248,7 +248,7 @@ struct TriFold {
 // B operand straight from global memory (L2-resident parameters), no LDS image:
 //   B[k][c] = Bg[k * krow + c] for k < kvalid, c < cvalid; addresses are clamped, the A image's zero padding
 //   (columns >= kvalid) cancels the clamped rows and out-of-range columns are never stored.
-// The loads of the next 16-k block are issued before the MFMAs of the current one.
+// The loads of the block two ahead are issued before the MFMAs of the current 16-k block.
 __device__ __forceinline__ void tile_gemm_gbx(f32x4& acc, const float* A, int lda, int row0, const float* Bp,
                                               int kstride, int klast, int kdim) {
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
@@ -265,15 +265,21 @@ __device__ __forceinline__ void tile_gemm_gbx(f32x4& acc, const float* A, int ld
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
   };
+  float b2[4];
   ldb(0, b0);
+  if (16 < kdim) ldb(16, b1);
+  // the loads of the block TWO ahead are issued before the MFMAs of the current one
 #pragma unroll 1
-  for (int k0 = 0; k0 < kdim; k0 += 32) {
-    const bool more1 = k0 + 16 < kdim, more2 = k0 + 32 < kdim;
-    if (more1) ldb(k0 + 16, b1);
+  for (int k0 = 0; k0 < kdim; k0 += 48) {
+    if (k0 + 32 < kdim) ldb(k0 + 32, b2);
     step(k0, b0);
-    if (more1) {
-      if (more2) ldb(k0 + 32, b0);
+    if (k0 + 16 < kdim) {
+      if (k0 + 48 < kdim) ldb(k0 + 48, b0);
       step(k0 + 16, b1);
+    }
+    if (k0 + 32 < kdim) {
+      if (k0 + 64 < kdim) ldb(k0 + 64, b1);
+      step(k0 + 32, b2);
     }
   }
 }
@@ -315,15 +321,21 @@ __device__ __forceinline__ void tile_gemm_gbt4(f32x4& acc, const float* A, int l
     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
   };
   float b0[4], b1[4];
+  float b2[4];
   ldb(0, b0);
+  if (16 < kdim) ldb(16, b1);
+  // the loads of the block TWO ahead are issued before the MFMAs of the current one
 #pragma unroll 1
-  for (int k0 = 0; k0 < kdim; k0 += 32) {
-    const bool more1 = k0 + 16 < kdim, more2 = k0 + 32 < kdim;
-    if (more1) ldb(k0 + 16, b1);
+  for (int k0 = 0; k0 < kdim; k0 += 48) {
+    if (k0 + 32 < kdim) ldb(k0 + 32, b2);
     step(k0, b0);
-    if (more1) {
-      if (more2) ldb(k0 + 32, b0);
+    if (k0 + 16 < kdim) {
+      if (k0 + 48 < kdim) ldb(k0 + 48, b0);
       step(k0 + 16, b1);
+    }
+    if (k0 + 32 < kdim) {
+      if (k0 + 64 < kdim) ldb(k0 + 64, b1);
+      step(k0 + 32, b2);
     }
   }
 }

@@ -33,6 +33,11 @@ def main():
     mode = "paper" if "--reference" not in sys.argv else "reference"
     B = 256
     data = synth.tox21_batch(123, B)
+    if os.environ.get("AGCN_STAMP_SHARD_OF"):      # shard 0 of an emulated N-GPU run (holds the largest graph)
+        N = int(os.environ["AGCN_STAMP_SHARD_OF"])
+        big = synth.tox21_batch(123, B * N)
+        mine = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(big["n"], 75, 64, 2), N)[0]
+        data = {"n": big["n"][mine], "X": [big["X"][i] for i in mine], "csr": [big["csr"][i] for i in mine]}
     p = synth.glorot_params(np.random.RandomState(123), 75, 64, 2)
     gb = agcn_amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], "cuda:0")
     layer = agcn_amd.SGC_LL(64, 75, B, K=2, laplacian_mode=mode, device="cuda:0")
