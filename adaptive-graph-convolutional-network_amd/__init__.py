@@ -10,7 +10,7 @@ from .graph_structure import Graph, MolGraph, laplacian_csr  # noqa: F401
 from .layers import (SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, DenseBlockEnd, GraphPoolMol,  # noqa: F401
                      MultitaskHead, Layer)
 from .store import GraphStore  # noqa: F401
-from .engine import SgcLLStep  # noqa: F401
+from .engine import GraphedStep, SgcLLStep  # noqa: F401
 from . import dist  # noqa: F401
 
 __version__ = "0.1.0"
