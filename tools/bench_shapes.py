@@ -138,6 +138,23 @@ def main():
         gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
         run_layer(name, gb, data["n"], sum(len(c[1]) for c in data["csr"]), Fin, Fout, False)
 
+    if want("reslap"):
+        # SGC_LL_Reslap 64 -> 64 with a previous summed Laplacian (ResAGCN-style second layer)
+        data = synth.tox21_batch(123, 256, 64)
+        gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
+        layer = amd.SGC_LL_Reslap(64, 64, 256, K=K, laplacian_mode=args.mode, device=dev)
+        layer.load_vars(synth.glorot_params(np.random.RandomState(123), 64, 64, K, reslap=True))
+        Lp = 0.1 * torch.randn(gb.plan.tile_elems, device=dev)
+        dY = torch.randn(gb.plan.rows, 64, device=dev)
+        st = amd.SgcLLStep(layer, gb, L_prev=Lp, dY=dY)
+        st.capture()
+        t = timed(st.replay, args.steps, args.warmup, dev)
+        out = {"workload": "reslap 64->64 with L_prev, B=256", "mode": args.mode, "graphs": 256,
+               "us_per_step": round(t * 1e6, 2), "graphs_per_s": round(256 / t, 1)}
+        if args.prof:
+            out["kernel_us"] = kernel_profile(amd, st.step, 20, dev)
+        print(json.dumps(out), flush=True)
+
     if want("ref-feed"):
         # the reference's own feed layout (graph_topology.py:84-135): every graph padded to max_atom = 132 rows,
         # dense [max_atom, max_atom] Laplacians -- the literal drop-in call
