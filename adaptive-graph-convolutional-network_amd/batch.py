@@ -215,6 +215,8 @@ class GraphBatch(object):
         val = np.concatenate([np.asarray(c[2]).astype(np.float32) for c in csr_list]) if len(csr_list) else np.zeros(0, np.float32)
         dev = torch.device(device)
         sym = bool(csr_symmetry_flags(plan.row_off, rowptr, col, val).all())
+        if col.size == 0:       # all-zero Laplacians: keep the device pointers non-null (never dereferenced)
+            col, val = np.zeros(1, np.int32), np.zeros(1, np.float32)
         return cls(plan, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev),
                    torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
                    l0_symmetric=sym)

@@ -389,6 +389,52 @@ def test_graphed_network_step(amd):
     assert float(step_out) == l2 and l2 != eager[0]
 
 
+@pytest.mark.parametrize("path", ["fused", "slab", "lds"])
+def test_known_answers_on_the_gpu(amd, path):
+    """The analytic pins of SURVEY 8(c) (i)-(iv),(vi),(vii), which need no oracle at all, through the HIP path."""
+    lib = amd._ffi.lib()
+    lib.agcn_set_fused_mode(1 if path == "fused" else 0)
+    lib.agcn_set_slab_mode(0 if path == "lds" else 1)
+    try:
+        rs = np.random.RandomState(3)
+        ns, Fin, Fout, K = [6, 9, 4], 5, 4, 2
+        X = [rs.randn(n, Fin).astype(np.float32) for n in ns]
+        csr0 = [(np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float64)) for n in ns]   # L_orig = 0
+        p = orc.init_params(rs, Fin, Fout, K)
+
+        def run(params, mode):
+            gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr0, DEV)
+            layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, mode, params, DEV)
+            return layer({"node_features": gb.X, "graph_batch": gb})
+
+        nodes, res_L, res_W = run(p, orc.REFERENCE)
+        for b, n in enumerate(ns):
+            assert np.array_equal(to_np(res_L[b]), np.eye(n, dtype=np.float32))                  # (i)
+            want = np.maximum(np.repeat(X[b], K, axis=1) @ p["weight"] + p["bias"], 0)           # (iv)
+            assert_close(to_np(nodes[b]), want, FEATURE_RTOL, "Y = relu([X|X] W + b)")
+            w = to_np(res_W[b])
+            assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)                            # (vii)
+        p0 = dict(p)
+        p0["M_L"] = np.zeros_like(p["M_L"])
+        nodes, res_L, res_W = run(p0, orc.PAPER)
+        for b, n in enumerate(ns):
+            assert np.array_equal(to_np(res_W[b]), 1 - np.eye(n, dtype=np.float32))               # (ii)
+            # d_j = n - 1  =>  R = I - (1 - I) / (n - 1)
+            assert_close(to_np(res_L[b]), np.eye(n) - (1 - np.eye(n)) / (n - 1), FEATURE_RTOL, "R with d = n - 1")
+        # (iii) n = 2, Fin = 1, M = [[1]], x = (0, a)  =>  W_01 = exp(-|a|)
+        a_ = np.float32(-1.75)
+        gb = amd.GraphBatch.from_arrays(np.asarray([2], np.int32), np.array([[0.0], [a_]], np.float32),
+                                        [(np.zeros(3, np.int32), np.zeros(0, np.int32), np.zeros(0))], DEV)
+        p1 = {"weight": np.ones((2, 1), np.float32), "bias": np.zeros(1, np.float32), "M_L": np.ones((1, 1), np.float32),
+              "alpha": np.ones(1, np.float32)}
+        layer = make_layer(amd, orc.SGC_LL, 1, 1, 1, 2, orc.PAPER, p1, DEV)
+        _, _, rw = layer({"node_features": gb.X, "graph_batch": gb})
+        assert abs(float(rw[0][0, 1]) - np.exp(-abs(a_))) <= 1e-6 * np.exp(-abs(a_))
+    finally:
+        lib.agcn_set_fused_mode(1)
+        lib.agcn_set_slab_mode(1)
+
+
 def test_reslap_without_prev(amd):
     ns, Fin, Fout, K = [6, 9, 14], 8, 6, 2
     for mode in (orc.REFERENCE, orc.PAPER):
