@@ -178,9 +178,7 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
 // Row chunks of the parameter-gradient partial products: 64-row chunks (16 MFMA k-steps) give
 // a few thousand wave-sized work items at Tox21 batch sizes; capped so the partial buffer stays small.
 int n_chunks_for(int32_t rows) {
-  static const int env_rows = [] { const char* e = std::getenv("AGCN_PG_CHUNK_ROWS"); return e ? std::atoi(e) : 0; }();
-  const int cr = env_rows >= 16 ? env_rows : 64;
-  int c = (rows + cr - 1) / cr;
+  int c = (rows + 63) / 64;
   if (c < 1) c = 1;
   if (c > 256) c = 256;
   return c;

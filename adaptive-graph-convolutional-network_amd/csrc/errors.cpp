@@ -63,12 +63,6 @@ namespace agcn {
 // One workgroup per graph: with few graphs per CU, 16 waves per graph hide the memory latency of
 // the bulk loads and spread the MFMA tiles; with many graphs per CU the CU is full anyway.
 int graph_threads(int32_t n_graphs) {
-  static const int forced = [] {
-    const char* e = std::getenv("AGCN_GRAPH_THREADS");
-    const int v = e ? std::atoi(e) : 0;
-    return (v == 256 || v == 512 || v == 1024) ? v : 0;
-  }();
-  if (forced) return forced;
   if (n_graphs <= 2 * 256) return 1024;
   if (n_graphs <= 4 * 256) return 512;
   return 256;

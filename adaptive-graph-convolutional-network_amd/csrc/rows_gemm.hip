@@ -241,13 +241,6 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
   AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 5);
 }
 
-namespace {
-int env_int(const char* name) {
-  const char* e = std::getenv(name);
-  return e ? std::atoi(e) : 0;
-}
-}  // namespace
-
 template <int MODE, int NTW>
 static int launch_ntw(RowsGemmArgs a, int gy, int nt, int threads, hipStream_t s) {
   a.nt = nt;
@@ -277,14 +270,13 @@ static int launch_ntw(RowsGemmArgs a, int gy, int nt, int threads, hipStream_t s
 
 template <int MODE>
 static int launch_mode(const RowsGemmArgs& a, hipStream_t s) {
-  static const int env_gy = env_int("AGCN_RG_GY"), env_thr = env_int("AGCN_RG_THREADS");
-  int threads = (env_thr == 256 || env_thr == 512 || env_thr == 1024) ? env_thr : NTHR;
+  const int threads = NTHR;
   const int ncg = threads / 256;
   // split N into gy column blocks: at most 3 tiles per wave, and enough blocks that the grid
   // covers the chip (few rows => narrow blocks; the A image is then re-staged from L2 by each)
   const int nt_total = (a.N + 15) / 16;
   const int row_blocks = (a.rows + BM - 1) / BM;
-  int want_gy = env_gy > 0 ? env_gy : (128 + row_blocks - 1) / row_blocks;   // measured: ~150 workgroups of 1024 threads is the sweet spot
+  int want_gy = (128 + row_blocks - 1) / row_blocks;   // measured: ~150 workgroups of 1024 threads is the sweet spot
   if (want_gy < 1) want_gy = 1;
   if (want_gy > nt_total) want_gy = nt_total;
   int nt = (nt_total + want_gy - 1) / want_gy;
