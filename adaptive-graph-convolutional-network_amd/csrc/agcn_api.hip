@@ -58,7 +58,7 @@ bool use_slabs(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanIn
          (g->L0_rowptr != nullptr || g->L0_dense != nullptr) && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
 }
 
-// Fused per-graph kernels (fused_kernels.hip): SGC_LL, K = 2, packed rows, CSR or dense L_orig, for the graphs
+// Fused per-graph kernels (fused_kernels.hip): SGC_LL and SGC_LL_Reslap, K = 2, packed rows, CSR or dense L_orig, for the graphs
 // whose working set fits LDS.  Graphs are scheduled largest first, so the ones that do NOT fit are a
 // prefix of plan.order (and their slabs a prefix of the slab table): with `mixed` dispatch those few
 // graphs run on the slab-parallel kernels on a side stream, concurrently with the fused kernels.
@@ -78,8 +78,7 @@ FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const Pl
   FusedSplit f{0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
-  if (!(d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 &&
-        (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;
+  if (!(d->K == 2 && pi.rows == pi.N1 && (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;
   size_t lim = (size_t)agcn_get_lds_limit();
   if (lim > 160 * 1024) lim = 160 * 1024;
   auto need = [&](int n) {
@@ -168,9 +167,9 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   r.scal = c.off; c.take((size_t)4 * pi.B);
   r.X = c.off; c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
   r.Lpre = c.off; if (d->variant == AGCN_SGC_LL_RESLAP) c.take((size_t)pi.tile_elems);
-  // r_ij tiles (slab path, paper mode): reserved whenever the slab path COULD be taken
+  // r_ij tiles (fused and slab paths, paper mode): reserved whenever one of them COULD be taken
   r.r = c.off;
-  if (d->variant == AGCN_SGC_LL && d->K == 2 && d->mode == AGCN_MODE_PAPER) c.take((size_t)pi.tile_elems);
+  if (d->K == 2 && d->mode == AGCN_MODE_PAPER) c.take((size_t)pi.tile_elems);
   r.total = c.off;
   return r;
 }

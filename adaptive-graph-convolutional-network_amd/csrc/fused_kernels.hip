@@ -143,7 +143,7 @@ AGCN_HD inline FusedDims fused_dims(int n, int Fin, int Fout, int K, bool gb = f
 }
 }  // namespace
 
-template <bool GB>
+template <bool GB, bool RESLAP>
 __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
       if (a.L_sum) a.L_sum[toff + nn + tid] = 0.f;
       if (paper) a.sv_r[toff + nn + tid] = 0.f;
     }
-    if (tid == 0) {   // clip_by_average_norm never clips for SGC_LL: scale exactly 1 (see slab_kernels.hip)
+    if (!RESLAP && tid == 0) {   // clip_by_average_norm never clips for SGC_LL: scale exactly 1 (see slab_kernels.hip)
       float* sc = a.sv_scal + 4 * b;
       sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
     }
@@ -372,18 +372,42 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
   __syncthreads();
 
   AGCN_STAMP(1, 4);
-  // ---- F3: res_W out; R, leaky-ReLU, res_L out; L = lrelu(R) + L_orig --------------------------------
+  // ---- F3: res_W out; R, (clip,) leaky-ReLU, res_L out; L = lrelu(R) + L_orig (+ Reslap combine) ------------
+  float* red = smem;   // the 32 floats in front of s_vec: block reductions
+  float ssR = 1.f, scR = 1.f, ssL = 0.f, scL = 1.f;
   {
     const float alpha = a.alpha[0];
-    for (int idx = tid; idx < nn; idx += nthr) {
-      const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
-      const float S = tile[i * ldt + j];
-      a.res_W[toff + idx] = S;
-      float R = (i == j) ? 1.f : 0.f;
-      if (paper) R = R - (s_vec[i] * S) * s_vec[j];
-      const float R2 = lrelu(R, alpha);   // (R * 1.0f: clip scale exactly 1)
-      a.res_L[toff + idx] = R2;
-      tile[i * ldt + j] = R2;
+    if (RESLAP) {
+      // clip_by_norm(R, 1) needs ||R||_F of the whole tile first (graphconv_reslap.py:185)
+      float part = 0.f;
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        const float S = tile[i * ldt + j];
+        a.res_W[toff + idx] = S;
+        float R = (i == j) ? 1.f : 0.f;
+        if (paper) R = R - (s_vec[i] * S) * s_vec[j];
+        tile[i * ldt + j] = R;
+        part += R * R;
+      }
+      ssR = block_sum(part, red);
+      scR = clip_scale(ssR, 1.0f);
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        const float R2 = lrelu(tile[i * ldt + j] * scR, alpha);
+        a.res_L[toff + idx] = R2;
+        tile[i * ldt + j] = R2;
+      }
+    } else {
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        const float S = tile[i * ldt + j];
+        a.res_W[toff + idx] = S;
+        float R = (i == j) ? 1.f : 0.f;
+        if (paper) R = R - (s_vec[i] * S) * s_vec[j];
+        const float R2 = lrelu(R, alpha);   // (R * 1.0f: clip scale exactly 1)
+        a.res_L[toff + idx] = R2;
+        tile[i * ldt + j] = R2;
+      }
     }
     // the MFMA loops read the 16-padded tile: zero columns n..n4 of the real rows and rows n..n4
     for (int idx = tid; idx < n * (n4 - n); idx += nthr) {
@@ -405,7 +429,33 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
       for (int p = csr_p0 + 4; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
     }
     __syncthreads();
-    if (a.L_sum) {
+    if (RESLAP) {
+      // + beta * L_prev (graphconv_reslap.py:188-190); keep L_pre for the backward; second clip + leaky (:194-198)
+      const bool has_prev = a.L_prev != nullptr;
+      const float beta = has_prev ? a.beta[0] : 0.f;
+      float part = 0.f;
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        float v = tile[i * ldt + j];
+        if (has_prev) v = v + a.L_prev[toff + idx] * beta;
+        tile[i * ldt + j] = v;
+        a.sv_Lpre[toff + idx] = v;
+        part += v * v;
+      }
+      ssL = block_sum(part, red);
+      scL = clip_scale(ssL, 1.0f);
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        const float La = lrelu(tile[i * ldt + j] * scL, alpha);
+        tile[i * ldt + j] = La;
+        a.L_sum[toff + idx] = La;
+      }
+      if (tid == 0) {   // norms / scales for the backward projections
+        float* sc = a.sv_scal + 4 * b;
+        sc[0] = ssR; sc[1] = scR; sc[2] = ssL; sc[3] = scL;
+      }
+      __syncthreads();
+    } else if (a.L_sum) {
       for (int idx = tid; idx < nn; idx += nthr) {
         const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
         a.L_sum[toff + idx] = tile[i * ldt + j];
@@ -477,7 +527,7 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
 //   B2  (paper) dL = g_1 X_0^T -> dalpha, dA, dd, dr, c -> dZ = (diag(c 1) - c) Z;  dX += dZ M_L^T
 // The parameter gradients that reduce over the whole batch (dweight, dbias, dM_L) are formed by
 // param_grads.hip from Gp / dZ written here.
-template <bool GB>
+template <bool GB, bool RESLAP>
 __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -527,15 +577,17 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
   const float* L0d = !a.L0_dense ? nullptr
                                  : (a.L0_ld > 0 ? a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
-  // res_L rows (wave = row, lanes = columns, 2 column passes): requested now, stored after the staging
+  // L rows (wave = row, lanes = columns, 2 column passes): requested now, stored after the staging.
+  // SGC_LL: L = res_L + L_orig is rebuilt; Reslap: the combined, twice clipped Laplacian is the saved 4th output
+  const float* Lsrc = RESLAP ? a.L_sum : a.res_L;
   const bool lpref = (nw == 16 && n4 <= 128);
   float lreg[8][2];
   if (lpref) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = min(wave + 16 * u, n - 1);
-      lreg[u][0] = a.res_L[toff + (int64_t)i * n + min(lane, n - 1)];
-      lreg[u][1] = a.res_L[toff + (int64_t)i * n + min(lane + 64, n - 1)];
+      lreg[u][0] = Lsrc[toff + (int64_t)i * n + min(lane, n - 1)];
+      lreg[u][1] = Lsrc[toff + (int64_t)i * n + min(lane + 64, n - 1)];
     }
   }
   {
@@ -593,13 +645,15 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     for (int i = wave; i < n4; i += nw) {
       for (int j = lane; j < n4; j += 64) {
         float v = 0.f;
-        if (i < n && j < n) v = a.res_L[toff + (int64_t)i * n + j];
+        if (i < n && j < n) v = Lsrc[toff + (int64_t)i * n + j];
         tile[i * ldt + j] = v;
       }
     }
   }
   __syncthreads();
-  if (L0d) {
+  if (RESLAP) {
+    // (L_sum already contains L_orig and beta * L_prev)
+  } else if (L0d) {
     for (int i = wave; i < n; i += nw)
       for (int j = lane; j < n; j += 64) tile[i * ldt + j] += L0d[(int64_t)i * l0ld + j];
   } else if (tid < n) {
@@ -668,8 +722,12 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       for (int i4 = 0; i4 < 4; ++i4) dXimg[(16 * im + 4 * q + i4) * ldxa + f] += acc[i4];
     }
   }
-  float dalpha_part = 0.f;
-  if (paper) {
+  float dalpha_part = 0.f, dbeta_part = 0.f;
+  if (RESLAP && a.dL_prev) {   // alignment floats behind the tile
+    const int npadt = (int)(a.tile_off[b + 1] - toff) - n * n;
+    if (tid < npadt) a.dL_prev[toff + n * n + tid] = 0.f;
+  }
+  if (paper || RESLAP) {
     __syncthreads();   // GPimg / WTimg and the L tile are dead
     AGCN_STAMP(4, 4);
     // ---- B2: stage X_0 and M_L (row-major) over the dead B0 images -----------------------------------
@@ -696,10 +754,10 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       auto ident = [](int rr) { return rr; };
       if (F4 <= 128) {
         stage_matrix<2>(X0img, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
-        if (!GB) stage_matrix<2>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
+        if (!GB && paper) stage_matrix<2>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
       } else {
         stage_matrix<4>(X0img, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
-        if (!GB) stage_matrix<4>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
+        if (!GB && paper) stage_matrix<4>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
       }
     }
     __syncthreads();
@@ -717,6 +775,82 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     }
     __syncthreads();
     AGCN_STAMP(4, 6);
+    const FastDiv divn((uint32_t)n);
+    const int nn = n * n;
+    if (a.dL_sum) {   // upstream gradient of the combined Laplacian (4th output; the next Reslap layer's L_prev)
+      for (int idx = tid; idx < nn; idx += nthr) {
+        const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+        tile[i * ldt + j] += a.dL_sum[toff + idx];
+      }
+      __syncthreads();
+    }
+    if (RESLAP) {
+      // adjoint of  La = lrelu(cn(Lpre)),  Lpre = R2 + L_orig + beta L_prev   (graphconv_reslap.py:188-198)
+      const float* sc = a.sv_scal + 4 * b;
+      const bool has_prev = a.L_prev != nullptr && a.dL_prev != nullptr;
+      {
+        const float ssL = sc[2], scL = sc[3];
+        const float invL = 1.0f / sqrtf(ssL);
+        const bool clipped = invL <= 1.0f;   // TF MinimumGrad: ties take the norm branch
+        float dot_part = 0.f;
+        for (int idx = tid; idx < nn; idx += nthr) {
+          const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+          const float Lpre = a.sv_Lpre[toff + idx];
+          const float Lc = Lpre * scL;
+          const float dLa = tile[i * ldt + j];
+          dalpha_part += dLa * fminf(Lc, 0.f);
+          const float dLc = dLa * lrelu_grad(Lc, alpha);
+          tile[i * ldt + j] = dLc;
+          dot_part += dLc * Lpre;
+        }
+        float dot = 0.f;
+        if (clipped) dot = block_sum(dot_part, red);
+        const float beta = has_prev ? a.beta[0] : 0.f;
+        const float k3 = dot * invL * invL * invL;
+        for (int idx = tid; idx < nn; idx += nthr) {
+          const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+          float dv = tile[i * ldt + j];
+          if (clipped) dv = dv * invL - a.sv_Lpre[toff + idx] * k3;
+          tile[i * ldt + j] = dv;   // dLpre == dR2
+          if (has_prev) {
+            dbeta_part += dv * a.L_prev[toff + idx];
+            a.dL_prev[toff + idx] = dv * beta;
+          }
+        }
+      }
+      if (paper) {
+        // adjoint of  R2 = lrelu(cn(R)),  R = I - s S s  (clip_by_norm: q = 1): the tile becomes dR
+        const float ssR = sc[0], scR = sc[1];
+        const float invR = 1.0f / sqrtf(ssR);
+        const bool clippedR = invR <= 1.0f;
+        const float* Sg = a.res_W + toff;
+        float dot_part = 0.f;
+        for (int idx = tid; idx < nn; idx += nthr) {
+          const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+          float R = (i == j) ? 1.f : 0.f;
+          R = R - (s_vec[i] * Sg[idx]) * s_vec[j];
+          const float R1 = R * scR;
+          const float dR2 = tile[i * ldt + j];
+          dalpha_part += dR2 * fminf(R1, 0.f);
+          const float dR1 = dR2 * lrelu_grad(R1, alpha);
+          tile[i * ldt + j] = dR1;
+          dot_part += dR1 * R;
+        }
+        float dotR = 0.f;
+        if (clippedR) dotR = block_sum(dot_part, red);
+        const float k3 = dotR * invR * invR * invR;
+        if (clippedR) {
+          for (int idx = tid; idx < nn; idx += nthr) {
+            const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
+            float R = (i == j) ? 1.f : 0.f;
+            R = R - (s_vec[i] * Sg[idx]) * s_vec[j];
+            tile[i * ldt + j] = tile[i * ldt + j] * invR - R * k3;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (paper) {
     // Z rows -> G1img region (row-major B operand), g_1 is dead
     if (xpref) {
 #pragma unroll
@@ -744,8 +878,8 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
         float R = (i == j) ? 1.f : 0.f;
         R = R - (si * Sv) * s_vec[j];                  // R1 == R (clip scale 1)
         const float dL = tile[i * ldt + j];
-        dalpha_part += dL * fminf(R, 0.f);
-        const float P = -(dL * lrelu_grad(R, alpha)) * Sv;   // dA_ij S_ij
+        if (!RESLAP) dalpha_part += dL * fminf(R, 0.f);
+        const float P = -(RESLAP ? dL : dL * lrelu_grad(R, alpha)) * Sv;   // dA_ij S_ij (Reslap: the tile is dR already)
         rsum += P * s_vec[j];
         colp[wave * n4 + j] += P * si;
       }
@@ -768,7 +902,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
         const float Sv = S[(int64_t)i * n + j];
         float R = (i == j) ? 1.f : 0.f;
         R = R - (si * Sv) * s_vec[j];
-        const float dA = -(tile[i * ldt + j] * lrelu_grad(R, alpha));
+        const float dA = -(RESLAP ? tile[i * ldt + j] : tile[i * ldt + j] * lrelu_grad(R, alpha));
         tile[i * ldt + j] = -Sv * (dA * si * s_vec[j] + ddv[j]);
       }
     }
@@ -835,6 +969,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
         for (int i4 = 0; i4 < 4; ++i4) dXimg[(16 * im + 4 * q + i4) * ldxa + f] += acc[i4];
       }
     }
+    }   // paper
   }
   __syncthreads();
   AGCN_STAMP(4, 11);
@@ -845,9 +980,10 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       for (int f = lane; f < Fin; f += 64) dXg[(int64_t)i * a.ldx + f] = dXimg[i * ldxa + f];
   }
   const float da = block_sum(dalpha_part, red);
+  const float db = RESLAP ? block_sum(dbeta_part, red) : 0.f;
   if (tid == 0) {
     a.ws_pg[2 * b + 0] = da;
-    a.ws_pg[2 * b + 1] = 0.f;
+    a.ws_pg[2 * b + 1] = db;
   }
 }
 
@@ -865,15 +1001,15 @@ size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
   return sizeof(float) * (size_t)fused_bwd_dims(n, Fin, Fout, K, true).total;
 }
 
-template <bool GB>
+template <bool GB, bool RESLAP>
 static int launch_fused_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_backward_kernel<GB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_backward_kernel<GB, RESLAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_BWD, s);
-  hipLaunchKernelGGL(fused_backward_kernel<GB>, dim3(count), dim3(1024), lds_bytes, s, a, first);
+  hipLaunchKernelGGL((fused_backward_kernel<GB, RESLAP>), dim3(count), dim3(1024), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_backward launch: %s", hipGetErrorString(e));
@@ -884,19 +1020,22 @@ int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t
                           void* stream) {
   if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return global_b ? launch_fused_backward_t<true>(a, first, count, lds_bytes, s)
-                  : launch_fused_backward_t<false>(a, first, count, lds_bytes, s);
+  if (a.variant == AGCN_SGC_LL_RESLAP)
+    return global_b ? launch_fused_backward_t<true, true>(a, first, count, lds_bytes, s)
+                    : launch_fused_backward_t<false, true>(a, first, count, lds_bytes, s);
+  return global_b ? launch_fused_backward_t<true, false>(a, first, count, lds_bytes, s)
+                  : launch_fused_backward_t<false, false>(a, first, count, lds_bytes, s);
 }
 
-template <bool GB>
+template <bool GB, bool RESLAP>
 static int launch_fused_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_forward_kernel<GB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_forward_kernel<GB, RESLAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_fwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_FWD, s);
-  hipLaunchKernelGGL(fused_forward_kernel<GB>, dim3(count), dim3(1024), lds_bytes, s, a, first);
+  hipLaunchKernelGGL((fused_forward_kernel<GB, RESLAP>), dim3(count), dim3(1024), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_forward launch: %s", hipGetErrorString(e));
@@ -907,8 +1046,11 @@ int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t 
                          void* stream) {
   if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return global_b ? launch_fused_forward_t<true>(a, first, count, lds_bytes, s)
-                  : launch_fused_forward_t<false>(a, first, count, lds_bytes, s);
+  const bool reslap = a.variant == AGCN_SGC_LL_RESLAP;
+  if (reslap) return global_b ? launch_fused_forward_t<true, true>(a, first, count, lds_bytes, s)
+                              : launch_fused_forward_t<false, true>(a, first, count, lds_bytes, s);
+  return global_b ? launch_fused_forward_t<true, false>(a, first, count, lds_bytes, s)
+                  : launch_fused_forward_t<false, false>(a, first, count, lds_bytes, s);
 }
 
 }  // namespace agcn

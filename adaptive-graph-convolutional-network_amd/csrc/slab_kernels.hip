@@ -419,11 +419,15 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
       const int j = c0 + lane;
       const bool cv = lane < nc;
       const float sj = a.sv_s[c.row0 + min(j, n - 1)];
-      float Sv[4];
+      float Sv[4], up[4] = {0.f, 0.f, 0.f, 0.f}, upt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int di = 0; di < 4; ++di) {
-        const int i = c.i0 + min(4 * wave + di, c.nr - 1);
-        Sv[di] = a.res_W[c.toff + (int64_t)i * n + min(j, n - 1)];
+        const int i = c.i0 + min(4 * wave + di, c.nr - 1), jc = min(j, n - 1);
+        Sv[di] = a.res_W[c.toff + (int64_t)i * n + jc];
+        if (a.dL_sum) {   // upstream gradient of the 4th output (the combined Laplacian), both orientations
+          up[di] = a.dL_sum[c.toff + (int64_t)i * n + jc];
+          upt[di] = a.dL_sum[c.toff + (int64_t)jc * n + i];
+        }
       }
 #pragma unroll
       for (int di = 0; di < 4; ++di) {
@@ -432,10 +436,10 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
           float R = (i == j) ? 1.f : 0.f;
           R = R - (si[di] * Sv[di]) * sj;                 // R1 == R (clip scale 1)
           const float lg = lrelu_grad(R, alpha);
-          const float dL = T[il * CHP + lane];
+          const float dL = T[il * CHP + lane] + up[di];
           dalpha_part += dL * fminf(R, 0.f);
           const float dA = -(dL * lg);                     // dA_ij = -dR_ij
-          const float dAt = -(Cc[il * CHP + lane] * lg);   // dA_ji (R symmetric)
+          const float dAt = -((Cc[il * CHP + lane] + upt[di]) * lg);   // dA_ji (R symmetric)
           a.ws_dA[c.toff + (int64_t)i * n + j] = dA;
           // ds_i = sum_j dA_ij S_ij s_j + sum_j dA_ji S_ij s_j
           ds[di] += (dA * Sv[di]) * sj + (dAt * Sv[di]) * sj;

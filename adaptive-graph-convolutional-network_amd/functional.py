@@ -160,6 +160,7 @@ class SgcLLFunction(torch.autograd.Function):
         ctx.save_for_backward(X, weight, bias, M_L, alpha, beta, L_prev if reslap else None,
                               Y, res_L, res_W, L_sum, reserve)
         ctx.mark_non_differentiable(res_L, res_W)
+        ctx.set_materialize_grads(False)      # an unused L_sum must reach the library as "no upstream gradient"
         return Y, res_L, res_W, L_sum
 
     @staticmethod

@@ -137,8 +137,10 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     gb = {"fused_lds_images": 0, "fused_global_b": 1}.get(path, -1)
     if gb >= 0:
         path = "fused"
-    if path in ("slab", "fused", "mixed", "mixed_slab") and not (variant == orc.SGC_LL and K == 2):
-        pytest.skip("the slab and fused paths cover SGC_LL with K = 2 only")
+    if path == "fused" and K != 2:
+        pytest.skip("the fused kernels cover K = 2")
+    if path in ("slab", "mixed", "mixed_slab") and not (variant == orc.SGC_LL and K == 2):
+        pytest.skip("the slab paths cover SGC_LL with K = 2 only")
     if path in ("mixed", "mixed_slab") and case != 0:
         pytest.skip("mixed dispatch is exercised on the 75 -> 64 case (LDS limit chosen for it)")
     # mixed: with a 110 KiB limit the n = 33 graph of case 0 does not fit the fused kernel (118 KiB) while
@@ -430,6 +432,38 @@ def test_known_answers_on_the_gpu(amd, path):
         layer = make_layer(amd, orc.SGC_LL, 1, 1, 1, 2, orc.PAPER, p1, DEV)
         _, _, rw = layer({"node_features": gb.X, "graph_batch": gb})
         assert abs(float(rw[0][0, 1]) - np.exp(-abs(a_))) <= 1e-6 * np.exp(-abs(a_))
+    finally:
+        lib.agcn_set_fused_mode(1)
+        lib.agcn_set_slab_mode(1)
+
+
+@pytest.mark.parametrize("path", ["fused", "slab", "lds"])
+def test_sgc_ll_upstream_gradient_of_the_combined_laplacian(amd, path):
+    """SGC_LL's combined Laplacian (the optional 4th output of the C ABI) with an upstream gradient: every kernel
+    path must add dL_sum to dL (the fused and slab kernels used to ignore it)."""
+    from agcn_amd.functional import SgcLLFunction, _Cfg
+    lib = amd._ffi.lib()
+    lib.agcn_set_fused_mode(1 if path == "fused" else 0)
+    lib.agcn_set_slab_mode(0 if path == "lds" else 1)
+    try:
+        ns, Fin, Fout, K = [7, 20, 33, 5], 12, 8, 2
+        rs, X, L0, csr, p, G = synth_case(88, ns, Fin, Fout, K, orc.SGC_LL)
+        dLsum = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
+        caches, tot = oracle_run(X, L0, p, K, orc.PAPER, orc.SGC_LL, G, None, dLsum)
+        gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+        layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, orc.PAPER, p, DEV)
+        v = layer.vars
+        Xt = gb.X.clone().requires_grad_(True)
+        cfg = _Cfg(Fin, Fout, K, "paper", "SGC_LL", "relu")
+        Y, res_L, res_W, L_sum = SgcLLFunction.apply(Xt, v["weight"], v["bias"], v["M_L"], v["alpha"], None, None, gb, cfg)
+        from helpers import pack_tiles_np
+        loss = (Y * torch.from_numpy(np.concatenate(G, 0)).to(DEV)).sum() + \
+            (L_sum * torch.from_numpy(pack_tiles_np(dLsum, gb.plan)).to(DEV)).sum()
+        loss.backward()
+        assert_close(to_np(Xt.grad), np.concatenate(tot["dX"]), GRAD_RTOL, "dX with dL_sum")
+        assert_close(to_np(v["M_L"].grad), tot["dM_L"], 5 * GRAD_RTOL, "dM_L with dL_sum")
+        da = float(np.asarray(tot["dalpha"]).reshape(-1)[0])
+        assert abs(float(v["alpha"].grad[0]) - da) <= 10 * GRAD_RTOL * max(abs(da), float(np.abs(tot["dweight"]).max()))
     finally:
         lib.agcn_set_fused_mode(1)
         lib.agcn_set_slab_mode(1)
