@@ -469,6 +469,17 @@ def test_sgc_ll_upstream_gradient_of_the_combined_laplacian(amd, path):
         lib.agcn_set_slab_mode(1)
 
 
+def test_random_shapes_on_every_path(amd):
+    """Randomised widths / graph sizes / variants / modes / leaky slopes / L_prev / upstream dL_sum, every kernel
+    path (auto, fused with LDS parameter images, fused with parameters from global memory, slab, per-graph with the
+    tile in LDS or in global scratch) against the oracle in float64.  (tools/fuzz_paths.py runs more of them;
+    Fin = 1 is left to it: dM_L is then one cancelling sum and sits at 1-2e-4 relative.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_paths
+    assert fuzz_paths.run(60, 11, fin_choices=(3, 5, 16, 33, 64, 75, 128), verbose=False) == 0
+
+
 def test_reslap_without_prev(amd):
     ns, Fin, Fout, K = [6, 9, 14], 8, 6, 2
     for mode in (orc.REFERENCE, orc.PAPER):
