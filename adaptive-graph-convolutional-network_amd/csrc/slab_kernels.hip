@@ -157,44 +157,56 @@ __global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Shared by slab_lap and slab_bwd1: the chunk [16 x CH] of L = lrelu(R) + L_orig in LDS.
 //   FWD: R from res_W and s (computes and writes res_L);  !FWD: lrelu(R) read back from res_L.
+struct LChunkRegs { float v[4], l0[4], sj; };
+
+// the global loads of one chunk (issued one chunk ahead of their use: the chunk loops are latency-bound)
 template <bool FWD>
-__device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c, float* Ls, int c0, int nc,
-                                              const float (&si)[4], float alpha, int csr_p0, int csr_p1) {
+__device__ __forceinline__ LChunkRegs load_L_chunk(const SgcArgs& a, const SlabCtx& c, int c0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = c.n, j = c0 + lane;
+  const int n = c.n, jc = min(c0 + lane, n - 1);
   const bool paper = a.mode == AGCN_MODE_PAPER;
-  const bool cv = lane < nc;
-  float sj = 0.f;
-  if (FWD && paper) sj = a.sv_s[c.row0 + min(j, n - 1)];
+  LChunkRegs g;
+  g.sj = (FWD && paper) ? a.sv_s[c.row0 + jc] : 0.f;
   // dense L_orig feed (graph_topology.py:93-103: [max_atom, max_atom] per graph): read with the tile
   const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
   const float* L0d = !a.L0_dense ? nullptr
                                  : (a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff);
-  float v[4], l0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
-    const int il = 4 * wave + di, i = c.i0 + il;
-    const int64_t o = c.toff + (int64_t)min(i, n - 1) * n + min(j, n - 1);
-    if (FWD) v[di] = paper ? a.res_W[o] : 0.f;
-    else v[di] = a.res_L[o];
-    if (L0d) l0[di] = L0d[(int64_t)min(i, n - 1) * l0ld + min(j, n - 1)];
+    const int i = min(c.i0 + 4 * wave + di, n - 1);
+    const int64_t o = c.toff + (int64_t)i * n + jc;
+    if (FWD) g.v[di] = paper ? a.res_W[o] : 0.f;
+    else g.v[di] = a.res_L[o];
+    g.l0[di] = L0d ? L0d[(int64_t)i * l0ld + jc] : 0.f;
   }
+  return g;
+}
+
+template <bool FWD>
+__device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c, float* Ls, int c0, int nc,
+                                              const float (&si)[4], float alpha, int csr_p0, int csr_p1,
+                                              const LChunkRegs& g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = c.n, j = c0 + lane;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const bool cv = lane < nc;
+  const bool dense_l0 = a.L0_dense != nullptr;
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
     const int il = 4 * wave + di, i = c.i0 + il;
     const bool ok = cv && il < c.nr;
-    float L = v[di];
+    float L = g.v[di];
     if (FWD) {
-      float R = (i == j) ? 1.f : 0.f;            // reference: I - D*W*D elementwise == I
-      if (paper) R = R - (si[di] * v[di]) * sj;  // paper: I - s S s
-      L = lrelu(R, alpha);                       // (R * 1.0f: the clip scale is exactly 1)
+      float R = (i == j) ? 1.f : 0.f;              // reference: I - D*W*D elementwise == I
+      if (paper) R = R - (si[di] * g.v[di]) * g.sj;  // paper: I - s S s
+      L = lrelu(R, alpha);                         // (R * 1.0f: the clip scale is exactly 1)
       if (ok) a.res_L[c.toff + (int64_t)i * n + j] = L;
     }
-    Ls[il * CHP + lane] = ok ? L + l0[di] : 0.f;
+    Ls[il * CHP + lane] = ok ? L + g.l0[di] : 0.f;
   }
   __syncthreads();
   // + L_orig rows of the slab (CSR, one thread per row)
-  if (!L0d && tid < c.nr) {
+  if (!dense_l0 && tid < c.nr) {
     for (int p = csr_p0; p < csr_p1; p += 4) {
       int cc[4];
       float vv[4];
@@ -261,11 +273,14 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
 
   f32x4 acc[2];
   acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  LChunkRegs cur = load_L_chunk<true>(a, c, 0);
   for (int c0 = 0; c0 < n; c0 += CH) {
     const int nc = min(CH, n - c0);
     if (c0 > 0) __syncthreads();
     if (c0 == 0) AGCN_STAMP(6, 1);
-    build_L_chunk<true>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1);
+    const LChunkRegs nxt = (c0 + CH < n) ? load_L_chunk<true>(a, c, c0 + CH) : cur;   // next chunk's loads in flight
+    build_L_chunk<true>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1, cur);
+    cur = nxt;
     if (c0 == 0) AGCN_STAMP(6, 2);
     stage_rows_img(Xs, ldbx, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
     __syncthreads();
@@ -396,10 +411,13 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
   acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float ds[4] = {0.f, 0.f, 0.f, 0.f};
   float dalpha_part = 0.f;
+  LChunkRegs cur = load_L_chunk<false>(a, c, 0);
   for (int c0 = 0; c0 < n; c0 += CH) {
     const int nc = min(CH, n - c0);
     if (c0 > 0) __syncthreads();
-    build_L_chunk<false>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1);
+    const LChunkRegs nxt = (c0 + CH < n) ? load_L_chunk<false>(a, c, c0 + CH) : cur;   // next chunk's loads in flight
+    build_L_chunk<false>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1, cur);
+    cur = nxt;
     stage_rows_img(G1s, ldf, g1 + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
     if (paper) {
       stage_rows_img(X0s, ldf, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
@@ -506,22 +524,35 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
   f32x4 acc[2];
   acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < n; c0 += CH) {
-    const int nc = min(CH, n - c0);
-    if (c0 > 0) __syncthreads();
-    const int j = c0 + lane, jc = min(j, n - 1);
-    const bool cv = lane < nc;
-    const float sj = a.sv_s[c.row0 + jc], ddj = a.ws_dd[c.row0 + jc];
-    float dA[4], dAt[4], Sv[4], rv[4];
+  struct Regs { float sj, ddj, dA[4], dAt[4], Sv[4], rv[4]; };
+  auto load_chunk = [&](int c0) {
+    Regs g;
+    const int jc = min(c0 + lane, n - 1);
+    g.sj = a.sv_s[c.row0 + jc];
+    g.ddj = a.ws_dd[c.row0 + jc];
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int i = c.i0 + min(4 * wave + di, c.nr - 1);
       const int64_t o = c.toff + (int64_t)i * n + jc;
-      dA[di] = a.ws_dA[o];
-      dAt[di] = a.ws_dA[c.toff + (int64_t)jc * n + i];
-      Sv[di] = a.res_W[o];
-      rv[di] = a.sv_r[o];
+      g.dA[di] = a.ws_dA[o];
+      g.dAt[di] = a.ws_dA[c.toff + (int64_t)jc * n + i];
+      g.Sv[di] = a.res_W[o];
+      g.rv[di] = a.sv_r[o];
     }
+    return g;
+  };
+  Regs cur = load_chunk(0);
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const int nc = min(CH, n - c0);
+    if (c0 > 0) __syncthreads();
+    const int j = c0 + lane;
+    const bool cv = lane < nc;
+    const Regs nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;   // next chunk's loads in flight
+    const float sj = cur.sj, ddj = cur.ddj;
+    float dA[4], dAt[4], Sv[4], rv[4];
+#pragma unroll
+    for (int di = 0; di < 4; ++di) { dA[di] = cur.dA[di]; dAt[di] = cur.dAt[di]; Sv[di] = cur.Sv[di]; rv[di] = cur.rv[di]; }
+    cur = nxt;
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int il = 4 * wave + di, i = c.i0 + il;
