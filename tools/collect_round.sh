@@ -1,6 +1,6 @@
 set -x
 O=$GRAFT_REPO_ROOT/gpurun_out/final
-rm -rf $O; mkdir -p $O
+rm -rf $O $GRAFT_REPO_ROOT/gpurun_out/traffic $GRAFT_REPO_ROOT/gpurun_out/mfma; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 250 python bench.py --steps 200 --warmup 20 > $O/bench_paper.json 2>$O/bench_paper.err
 timeout 250 python bench.py --steps 200 --warmup 20 --mode reference --no-cpu-baseline > $O/bench_reference.json 2>/dev/null
@@ -11,6 +11,7 @@ cp gpurun_out/traffic/traffic_*.json $O/
 bash tools/mfma.sh > $O/mfma.txt 2>&1; cp gpurun_out/mfma/mfma.json $O/
 for N in 2 4 8; do for s in 0 1; do timeout 100 python bench.py --shard-of $N --shard $s --no-cpu-baseline --skip-other-mode >> $O/shards.json 2>/dev/null; done; done
 for b in 512 1024 2048 4096; do timeout 200 python bench.py --batch $b --no-cpu-baseline --skip-other-mode >> $O/batch_sweep.json 2>/dev/null; done
-timeout 500 python tools/bench_shapes.py --prof --epoch-graphs 16384 > $O/shapes_paper.json 2>/dev/null
-timeout 300 python tools/bench_shapes.py --mode reference --only tox21-l1,tox21-l3,stack > $O/shapes_reference.json 2>/dev/null
+timeout 700 python tools/bench_shapes.py --prof --epoch-graphs 16384 > $O/shapes_paper.json 2>/dev/null
+timeout 300 python tools/bench_shapes.py --mode reference --only tox21-l1,tox21-l3,reslap,stack > $O/shapes_reference.json 2>/dev/null
+AGCN_FUSED_MODE=0 timeout 100 python bench.py --no-cpu-baseline --skip-other-mode > $O/bench_slab_forced.json 2>/dev/null
 ls -la $O
