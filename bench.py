@@ -137,7 +137,12 @@ def main():
     import agcn_amd
     from agcn_amd import synth
 
-    rank, local, world = agcn_amd.dist.init_from_env("nccl")
+    # AGCN_BENCH_SELFTEST=1 (development only): several ranks share cuda:0 over gloo, to exercise the multi-process
+    # control flow on a one-GPU box; the driver's runs use one GPU per rank over RCCL
+    selftest = os.environ.get("AGCN_BENCH_SELFTEST") == "1"
+    rank, local, world = agcn_amd.dist.init_from_env("gloo" if selftest else "nccl")
+    if selftest:
+        local = 0
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
