@@ -19,7 +19,8 @@ class PlanInfo(C.Structure):
                 ("off_n", C.c_int64), ("off_row_off", C.c_int64), ("off_tile_off", C.c_int64),
                 ("off_order", C.c_int64), ("off_wtile_off", C.c_int64),
                 ("n_slabs", C.c_int32), ("reserved1", C.c_int32),
-                ("off_slab_graph", C.c_int64), ("off_slab_row", C.c_int64), ("off_row_graph", C.c_int64)]
+                ("off_slab_graph", C.c_int64), ("off_slab_row", C.c_int64), ("off_row_graph", C.c_int64),
+                ("off_graph_desc", C.c_int64)]
 
 
 class LayerDesc(C.Structure):

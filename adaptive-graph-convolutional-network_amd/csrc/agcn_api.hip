@@ -195,6 +195,7 @@ void fill_common(SgcArgs& a, const AgcnLayerDesc* d, const AgcnGraphBatch* g, co
                  const AgcnOutputs* o, const PlanView& dev) {
   std::memset(&a, 0, sizeof(a));
   a.n = dev.n; a.row_off = dev.row_off; a.tile_off = dev.tile_off; a.order = dev.order;
+  a.graph_desc = dev.graph_desc;
   a.wtile_off = dev.wtile_off;
   a.B = dev.info.B; a.rows = dev.info.rows;
   a.Fin = d->Fin; a.Fout = d->Fout; a.K = d->K; a.mode = d->mode; a.variant = d->variant;

@@ -147,10 +147,14 @@ template <bool GB, bool RESLAP>
 __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int b = a.order[first + blockIdx.x];
-  const int n = a.n[b];
-  const int row0 = a.row_off[b];
-  const int64_t toff = a.tile_off[b];
+  // one 32-byte record instead of the dependent order -> n / row_off / tile_off loads
+  const f32x4* gdp = reinterpret_cast<const f32x4*>(a.graph_desc + first + blockIdx.x);
+  const f32x4 gd0 = gdp[0], gd1 = gdp[1];
+  const int b = __float_as_int(gd0[0]);
+  const int n = __float_as_int(gd0[1]);
+  const int row0 = __float_as_int(gd0[2]);
+  const int64_t toff = (int64_t)(((uint64_t)(uint32_t)__float_as_int(gd1[1]) << 32) | (uint32_t)__float_as_int(gd1[0]));
+  const int64_t tend = (int64_t)(((uint64_t)(uint32_t)__float_as_int(gd1[3]) << 32) | (uint32_t)__float_as_int(gd1[2]));
   const int Fin = a.Fin, Fout = a.Fout, K = a.K;   // K == 2
   const FusedDims d = fused_dims(n, Fin, Fout, K, GB);
   const int n4 = d.n4, F4 = d.F4, ldt = d.ldt, ldxa = d.ldxa, ldm = d.ldm, ldw = d.ldw;
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
     a.sv_s[row0 + j] = s;
   }
   {
-    const int npadt = (int)(a.tile_off[b + 1] - toff) - nn;
+    const int npadt = (int)(tend - toff) - nn;
     if (tid < npadt) {
       a.res_W[toff + nn + tid] = 0.f;
       a.res_L[toff + nn + tid] = 0.f;
@@ -533,10 +537,14 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int b = a.order[first + blockIdx.x];
-  const int n = a.n[b];
-  const int row0 = a.row_off[b];
-  const int64_t toff = a.tile_off[b];
+  // one 32-byte record instead of the dependent order -> n / row_off / tile_off loads
+  const f32x4* gdp = reinterpret_cast<const f32x4*>(a.graph_desc + first + blockIdx.x);
+  const f32x4 gd0 = gdp[0], gd1 = gdp[1];
+  const int b = __float_as_int(gd0[0]);
+  const int n = __float_as_int(gd0[1]);
+  const int row0 = __float_as_int(gd0[2]);
+  const int64_t toff = (int64_t)(((uint64_t)(uint32_t)__float_as_int(gd1[1]) << 32) | (uint32_t)__float_as_int(gd1[0]));
+  const int64_t tend = (int64_t)(((uint64_t)(uint32_t)__float_as_int(gd1[3]) << 32) | (uint32_t)__float_as_int(gd1[2]));
   const int Fin = a.Fin, Fout = a.Fout, K = a.K;   // K == 2
   const FusedBwdDims d = fused_bwd_dims(n, Fin, Fout, K, GB);
   const int n4 = d.n4, F4 = d.F4, O4 = d.O4, ldt = d.ldt, ldxa = d.ldxa, ldg = d.ldg;
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   }
   float dalpha_part = 0.f, dbeta_part = 0.f;
   if (RESLAP && a.dL_prev) {   // alignment floats behind the tile
-    const int npadt = (int)(a.tile_off[b + 1] - toff) - n * n;
+    const int npadt = (int)(tend - toff) - n * n;
     if (tid < npadt) a.dL_prev[toff + n * n + tid] = 0.f;
   }
   if (paper || RESLAP) {

@@ -16,7 +16,8 @@ constexpr uint64_t kMagic = 0x4147434E504C4E31ull;  // "AGCNPLN1"
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
-  int64_t off_n, off_row_off, off_tile_off, off_order, off_wtile_off, off_slab_graph, off_slab_row, off_row_graph, total;
+  int64_t off_n, off_row_off, off_tile_off, off_order, off_wtile_off, off_slab_graph, off_slab_row, off_row_graph,
+      off_graph_desc, total;
 };
 
 // max_slabs: upper bound used for sizing (sum of ceil(n/16) <= N1/16 + B, but N1 is unknown when
@@ -35,6 +36,7 @@ Layout layout_for(int32_t B, int64_t n_slabs, int64_t rows) {
   l.off_slab_graph = o;  o = align_up(o + 4ll * n_slabs, 16);
   l.off_slab_row = o;    o = align_up(o + 4ll * n_slabs, 16);
   l.off_row_graph = o;   o = align_up(o + 4ll * rows, 16);
+  l.off_graph_desc = o;  o = align_up(o + (int64_t)sizeof(AgcnGraphDesc) * B, 16);
   l.total = o;
   return l;
 }
@@ -119,6 +121,16 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
     }
   }
 
+  // one 32-byte record per schedule position: everything a per-graph workgroup needs to find its graph in ONE load
+  {
+    AgcnGraphDesc* gd = reinterpret_cast<AgcnGraphDesc*>(base + l.off_graph_desc);
+    for (int32_t i = 0; i < B; ++i) {
+      const int32_t g = order[i];
+      gd[i].graph = g; gd[i].n = pn[g]; gd[i].row0 = row_off[g]; gd[i].reserved = 0;
+      gd[i].tile_off = tile_off[g]; gd[i].tile_end = tile_off[g + 1];
+    }
+  }
+
   AgcnPlanInfo info;
   std::memset(&info, 0, sizeof(info));
   info.B = B;
@@ -137,6 +149,7 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
   info.off_slab_graph = l.off_slab_graph;
   info.off_slab_row = l.off_slab_row;
   info.off_row_graph = l.off_row_graph;
+  info.off_graph_desc = l.off_graph_desc;
   std::memcpy(base, &kMagic, sizeof(kMagic));
   std::memcpy(base + sizeof(kMagic), &info, sizeof(info));
   return AGCN_OK;

@@ -13,6 +13,7 @@ struct SgcArgs {
   const int32_t* row_off;
   const int64_t* tile_off;
   const int32_t* order;
+  const AgcnGraphDesc* graph_desc;   // [B] in schedule order: one 32-byte load per workgroup (fused kernels)
   const int64_t* wtile_off;
   int32_t B, rows;
   // layer

@@ -88,7 +88,19 @@ typedef struct AgcnPlanInfo {
   int64_t off_slab_graph; /* int32 [n_slabs] graph id      */
   int64_t off_slab_row;   /* int32 [n_slabs] first row inside the graph */
   int64_t off_row_graph;  /* int32 [rows]    owning graph of every row (pad rows included) */
+  int64_t off_graph_desc; /* AgcnGraphDesc [B], in schedule order (largest graph first) */
 } AgcnPlanInfo;
+
+/* Per-graph record of the plan, indexed by schedule position: a per-graph workgroup finds its graph with one
+ * 32-byte load instead of the dependent order -> n / row_off / tile_off chain. */
+typedef struct AgcnGraphDesc {
+  int32_t graph;     /* graph id (= order[position]) */
+  int32_t n;         /* nodes */
+  int32_t row0;      /* row_off[graph] */
+  int32_t reserved;
+  int64_t tile_off;  /* tile_off[graph] */
+  int64_t tile_end;  /* tile_off[graph + 1] */
+} AgcnGraphDesc;
 
 #define AGCN_SLAB_ROWS 16
 
