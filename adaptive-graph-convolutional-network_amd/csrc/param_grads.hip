@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(ParamGradArgs a)
 //   fixed whichever workgroup performs it, so the result is reproducible bit for bit -- and writes the
 //   gradient.  Counters are zeroed by the launcher (or by the preceding kernel of the same call).
 // Tiles: dweight tf x tc, then dbias tc, then (paper) dM_L tfM x tcM; 16 x 32 outputs each.
-// (An XCD-aware workgroup order -- every workgroup of one row split on the same XCD -- cuts this kernel's HBM
-// fetch from 22 MB to 6 MB but makes it SLOWER, 9.4 -> 12.0 us: the splits' rows then come out of one L2
-// instead of eight.  Measured, not kept.)
+// (An XCD-aware workgroup order -- every workgroup of one row split on the same XCD, AGCN_PG_XCD=1 -- cuts this
+// kernel's HBM fetch from 22 MB to 6 MB but makes it SLOWER, 9.4 -> 12.0 us eager / -1.7 % graphs/s on the whole
+// step: the splits' rows then come out of one L2 instead of eight.  Measured; off by default.)
 __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs a) {
   __shared__ float wsum[16][512 + 16];
   __shared__ int last_flag;
@@ -138,7 +138,12 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   const int r = lane & 15, q = lane >> 4;
   const int K = a.K, Fin = a.Fin, Fout = a.Fout;
   const int S = a.n_chunks;                 // row splits
-  const int t = blockIdx.x / S, s = blockIdx.x - t * S;
+  // a.xcd != 0: XCD-aware order -- consecutive workgroup ids go round-robin over the 8 XCDs, so with the split
+  // index running fastest over a multiple of 8 slots every workgroup of split s lands on XCD s % 8 and a row
+  // range of X / Gp / dZ is fetched into ONE L2
+  const int S8 = a.xcd ? ((S + 7) & ~7) : S;
+  const int t = blockIdx.x / S8, s = blockIdx.x - t * S8;
+  if (s >= S) return;
   const int tfW = (Fin * K + 15) >> 4, tcW = (Fout + 31) >> 5;
   const int tfM = (Fin + 15) >> 4, tcM = (Fin + 31) >> 5;
   int p, rem;                               // problem, tile index inside it
@@ -291,7 +296,9 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad counters memset: %s", hipGetErrorString(e));
     }
     prof_begin(PK_PARAM_ONEPASS, stream);
-    hipLaunchKernelGGL(param_grad_onepass_kernel, dim3((unsigned)(nt * S)), dim3(1024), 0, s, aa);
+    static const int xcd = [] { const char* e = std::getenv("AGCN_PG_XCD"); return (e && e[0] == '1') ? 1 : 0; }();
+    aa.xcd = xcd;
+    hipLaunchKernelGGL(param_grad_onepass_kernel, dim3((unsigned)(nt * (xcd ? ((S + 7) & ~7) : S))), dim3(1024), 0, s, aa);
     prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_onepass launch: %s", hipGetErrorString(e));

@@ -100,6 +100,7 @@ struct ParamGradArgs {
   size_t part_floats;   // capacity of `part` (set by the caller; 0 = unknown: two-launch path)
   int32_t* counters;    // one-pass kernel: per-tile arrival counters (set by the launcher)
   int32_t counters_zeroed;  // 1 = a preceding kernel of the same call already zeroed them
+  int32_t xcd;              // one-pass kernel: XCD-aware workgroup order (set by the launcher)
   const float* pg;      // [B][2]
   float *dweight, *dbias, *dM_L, *dalpha, *dbeta;
 };
