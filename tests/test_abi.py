@@ -93,6 +93,56 @@ def test_size_queries_and_validation(amd):
     assert rc == -1
 
 
+def test_graph_descriptor_table(amd):
+    """AgcnGraphDesc records, in schedule order (largest graph first), agree with the plain plan arrays."""
+    n = np.array([5, 3, 9, 4, 9, 1], dtype=np.int32)
+    p = amd.Plan(n)
+    rec = np.dtype([("graph", "<i4"), ("n", "<i4"), ("row0", "<i4"), ("reserved", "<i4"), ("tile_off", "<i8"),
+                    ("tile_end", "<i8")])
+    assert rec.itemsize == 32
+    gd = p.host[p.info.off_graph_desc:p.info.off_graph_desc + 32 * p.B].view(rec)
+    np.testing.assert_array_equal(gd["graph"], p.order)
+    np.testing.assert_array_equal(gd["n"], n[p.order])
+    np.testing.assert_array_equal(gd["row0"], p.row_off[p.order])
+    np.testing.assert_array_equal(gd["tile_off"], p.tile_off[p.order])
+    np.testing.assert_array_equal(gd["tile_end"], p.tile_off[p.order + 1])
+    assert list(n[p.order]) == sorted(n, reverse=True)
+
+
+def test_new_entry_points_validate_before_launching(amd):
+    """Host-side argument checks of the tail / ingest / layout entry points (no kernel is launched on an error)."""
+    lib = amd._ffi.lib()
+    # classifier tail
+    assert lib.agcn_multitask_ce_workspace_bytes(0, 16, 3) == 0
+    assert lib.agcn_multitask_ce_workspace_bytes(256, 256, 12) > 0
+    rc = lib.agcn_multitask_ce_forward(8, 16, 3, None, 16, None, None, None, None, C.c_float(0.125), None, None, None, 0, None)
+    assert rc != 0 and b"null tensor" in lib.agcn_last_error()
+    # row layout conversion needs a packed plan and a stride that holds the largest graph
+    padded = amd.Plan(np.array([3, 5], np.int32), 8)
+    packed = amd.Plan(np.array([3, 5], np.int32))
+    buf = np.zeros(1024, np.float32)
+    rc = lib.agcn_rows_pack(padded.host_ptr, padded.host_ptr, buf.ctypes.data, 8, 4, 4, buf.ctypes.data, 4, None)
+    assert rc != 0 and b"packed plan" in lib.agcn_last_error()
+    rc = lib.agcn_rows_pack(packed.host_ptr, packed.host_ptr, buf.ctypes.data, 4, 4, 4, buf.ctypes.data, 4, None)
+    assert rc != 0 and b"stride" in lib.agcn_last_error()
+    # storage conversion: only f32 <-> bf16
+    rc = lib.agcn_cast_rows(buf.ctypes.data, 0, buf.ctypes.data, 0, 4, 4, 4, 4, None)
+    assert rc != 0 and b"unsupported conversion" in lib.agcn_last_error()
+    # scaled dense: scale and dscale go together
+    d = amd._ffi.DenseDesc(4, 4, 0, 0, 4, 4, 4, 0)
+    rc = lib.agcn_rows_dense_scaled_backward(C.byref(d), packed.host_ptr, packed.host_ptr, buf.ctypes.data, buf.ctypes.data,
+                                             buf.ctypes.data, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data, None,
+                                             buf.ctypes.data, None, None, buf.ctypes.data, buf.nbytes, None)
+    assert rc != 0 and b"go together" in lib.agcn_last_error()
+    # knobs round-trip
+    for setter, getter, values in ((lib.agcn_set_fused_global_b, lib.agcn_get_fused_global_b, (0, 1, -1)),
+                                   (lib.agcn_set_param_grad_onepass, lib.agcn_get_param_grad_onepass, (0, 1)),
+                                   (lib.agcn_set_fused_mode, lib.agcn_get_fused_mode, (0, 2, 3, 1))):
+        for v in values:
+            setter(v)
+            assert getter() == v
+
+
 def test_missing_library_fails_loudly(amd, monkeypatch):
     monkeypatch.setattr(amd._ffi, "_lib", None)
     monkeypatch.setenv("AGCN_HIP_LIB", "/nonexistent/libagcn_hip.so")
