@@ -1012,8 +1012,7 @@ size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
 template <bool GB, bool RESLAP>
 static int launch_fused_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_backward_kernel<GB, RESLAP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_backward_kernel<GB, RESLAP>), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_BWD, s);
@@ -1038,8 +1037,7 @@ int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t
 template <bool GB, bool RESLAP>
 static int launch_fused_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_forward_kernel<GB, RESLAP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_forward_kernel<GB, RESLAP>), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_fwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_FWD, s);

@@ -3,6 +3,8 @@
 // not touch it.  Debug facility: single-threaded use only.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "sgc_kernels.h"
@@ -27,6 +29,18 @@ hipEvent_t get_event() {
   return e;
 }
 }  // namespace
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> cap;
+  if (bytes <= 64 * 1024) return 0;
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& have = cap[kernel];
+  if (have >= bytes) return 0;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return (int)e;
+}
 
 bool prof_on() { return g_on; }
 

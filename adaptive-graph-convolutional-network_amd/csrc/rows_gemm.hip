@@ -255,8 +255,7 @@ static int launch_ntw(RowsGemmArgs a, int gy, int nt, int threads, hipStream_t s
   const size_t lds = sizeof(float) * ((size_t)BM * ld_frag(kc) + (size_t)kc * ld_b(16 * nt) + BM);
   static const int kProfId[5] = {PK_PROJECT, PK_FILTER, PK_FILTER_BWD, PK_PROJECT_BWD, PK_FILTER};
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_gemm_kernel<MODE, NTW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(&rows_gemm_kernel<MODE, NTW>), lds));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(rows_gemm): %s", hipGetErrorString(e));
   }
   const dim3 grid((a.rows + BM - 1) / BM, gy);

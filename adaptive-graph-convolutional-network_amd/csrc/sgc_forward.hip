@@ -353,8 +353,7 @@ int launch_sgc_forward(const SgcArgs& a, int32_t first, int32_t count, bool lds_
   prof_begin(PK_GRAPH_FWD, stream);
   if (lds_tile) {
     if (lds_bytes > 64 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sgc_forward_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(&sgc_forward_kernel<true>), lds_bytes));
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fwd): %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(sgc_forward_kernel<true>, dim3(count), dim3(graph_threads(count)), lds_bytes, s, a, first);

@@ -109,6 +109,10 @@ struct ParamGradArgs {
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
        PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD,
        PK_PARAM_ONEPASS, PK_COUNT };
+// Raises a kernel's dynamic-LDS cap (hipFuncAttributeMaxDynamicSharedMemorySize) once per kernel and size: the
+// driver call is skipped when the cap already covers `bytes` (it costs several microseconds per launch otherwise).
+// One process drives one GPU.  Returns hipSuccess (0) or the HIP error code.
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
 bool prof_on();
 void prof_begin(int id, void* stream);
 void prof_end(void* stream);

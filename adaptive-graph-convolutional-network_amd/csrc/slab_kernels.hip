@@ -638,8 +638,7 @@ int launch_slab(K kernel, const SgcArgs& a, size_t lds, int prof_id, const char*
   if (a.n_slabs <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
   }
   prof_begin(prof_id, stream);

@@ -117,6 +117,22 @@ def _gbatch(batch, X, L_prev):
                            _ptr(batch.l0_rowptr), _ptr(batch.l0_col), _ptr(batch.l0_val), _ptr(L_prev))
 
 
+def _sizes(plan, cfg, ldx, ldy):
+    """(desc, reserve bytes, forward workspace bytes, backward workspace bytes) of a layer on a plan: three host-side
+    FFI calls, cached on the plan (a plan is immutable)."""
+    key = (cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, int(ldx), int(ldy))
+    cache = plan.__dict__.setdefault("_size_cache", {})
+    hit = cache.get(key)
+    if hit is None:
+        lib = _ffi.lib()
+        desc = _desc(cfg, ldx, ldy)
+        hit = (desc, lib.agcn_sgc_ll_reserve_bytes(C.byref(desc), plan.host_ptr),
+               lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(desc), plan.host_ptr),
+               lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(desc), plan.host_ptr))
+        cache[key] = hit
+    return hit
+
+
 class SgcLLFunction(torch.autograd.Function):
     """(Y, res_L, res_W, L_sum) = SGC_LL[_Reslap](X; weight, bias, M_L, alpha, beta, L_prev)."""
 
@@ -146,9 +162,7 @@ class SgcLLFunction(torch.autograd.Function):
         res_L = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         L_sum = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
-        desc = _desc(cfg, ldx, ldy)
-        rbytes = lib.agcn_sgc_ll_reserve_bytes(C.byref(desc), plan.host_ptr)
-        wbytes = lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(desc), plan.host_ptr)
+        desc, rbytes, wbytes, _ = _sizes(plan, cfg, ldx, ldy)
         reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         gb = _gbatch(batch, X, L_prev if reslap else None)
@@ -176,7 +190,7 @@ class SgcLLFunction(torch.autograd.Function):
         if dL_sum is not None:
             dL_sum = _f32c(dL_sum, "dL_sum")
         ldx, ldy = X.shape[1], cfg.Fout
-        desc = _desc(cfg, ldx, ldy)
+        desc, _, _, wbytes = _sizes(plan, cfg, ldx, ldy)
         dX = torch.empty_like(X)
         if ldx > cfg.Fin:
             dX.zero_()
@@ -186,7 +200,6 @@ class SgcLLFunction(torch.autograd.Function):
         dalpha = torch.empty_like(alpha)
         dbeta = torch.empty_like(beta) if ctx.has_prev else None
         dLp = torch.empty_like(L_prev) if ctx.has_prev else None
-        wbytes = lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(desc), plan.host_ptr)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         gb = _gbatch(batch, X, L_prev)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
