@@ -101,7 +101,10 @@ class Plan(object):
 
     @property
     def host_ptr(self):
-        return self.host.ctypes.data
+        p = self.__dict__.get("_host_ptr")
+        if p is None:                    # (numpy's .ctypes accessor costs ~2 us per use: looked up once)
+            p = self.__dict__["_host_ptr"] = self.host.ctypes.data
+        return p
 
     @property
     def dev_ptr(self):
