@@ -71,11 +71,11 @@ struct FusedSplit {
                    //        0 = on the slab-parallel kernels
   // 1 = the fused forward / backward kernel reads M_L / W straight from global memory (no LDS images of them):
   // wide layers (Fin = 128) and graphs up to ~100 nodes fit this way
-  int gb_fwd, gb_bwd;
+  int gb_fwd, gb_bwd_w, gb_bwd_m;   // backward: W and M_L separately
 };
 
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
-  FusedSplit f{0, 0, 0, 0, 0, 0, 0};
+  FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
   if (!(d->K == 2 && pi.rows == pi.N1 && (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;
@@ -97,22 +97,26 @@ FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const Pl
   int ns = 0;
   int nb = count_big(lim, &ns);
   const bool gb_fits = std::max(fused_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K),
-                                fused_bwd_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K)) <= lim;
+                                fused_bwd_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K, true, true)) <= lim;
   if (nb == 0) {
     // Both flavours fit.  Measured on MI355X (256 Tox21-shaped graphs): reading the parameters from global
     // memory is faster in the forward kernel (75->64: 23.5 vs 24.7 us; 64->128: 27.5 vs 29.9 us) and, when the
-    // rows of W and M_L are 16-byte aligned (vector loads along k), in the backward kernel too
-    // (64->128: 35.7 vs 36.4 us; 75->64, rows of 75 floats: 33.7 vs 32.1 us -> LDS images).
+    // rows of the parameter are 16-byte aligned (vector loads along k), in the backward kernel too -- decided per
+    // parameter: W rows have Fout floats, M_L rows Fin floats (64->128: 35.7 vs 36.4 us with both from global
+    // memory; 75->64: W from global memory, M_L, rows of 75 floats, as an LDS image).
     f.mode = 1; f.thr = pi.max_n;
     if (gb_fits && force_gb != 0) {
       f.gb_fwd = 1;
-      f.gb_bwd = (force_gb == 1 || ((d->Fin & 3) == 0 && (d->Fout & 3) == 0)) ? 1 : 0;
+      f.gb_bwd_w = (force_gb == 1 || (d->Fout & 3) == 0) ? 1 : 0;
+      f.gb_bwd_m = (force_gb == 1 || (d->Fin & 3) == 0) ? 1 : 0;
+      if (fused_bwd_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K, f.gb_bwd_w != 0, f.gb_bwd_m != 0) > lim)
+        f.gb_bwd_w = f.gb_bwd_m = 1;
     }
     return f;
   }
   // the parameter images are what does not fit: read M_L / W from global memory instead (AGCN_FUSED_GB=0 disables)
   if (gb_fits && force_gb != 0) {
-    f.mode = 1; f.thr = pi.max_n; f.gb_fwd = f.gb_bwd = 1;
+    f.mode = 1; f.thr = pi.max_n; f.gb_fwd = f.gb_bwd_w = f.gb_bwd_m = 1;
     return f;
   }
   // Some graph does not fit.  Measured on MI355X (Tox21-shaped, 256 graphs per GPU, one n = 95 graph):
@@ -503,9 +507,9 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       }
     }
     rc = launch_fused_backward(a, fs.n_big, B - fs.n_big,
-                               fs.gb_bwd ? fused_bwd_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K)
-                                         : fused_bwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K),
-                               fs.gb_bwd != 0, hip_stream);
+                               fused_bwd_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K, fs.gb_bwd_w != 0,
+                                                      fs.gb_bwd_m != 0),
+                               fs.gb_bwd_w != 0, fs.gb_bwd_m != 0, hip_stream);
     if (rc != AGCN_OK) return rc;
     if (ss) {
       if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(main_s, ss->join, 0) != hipSuccess)

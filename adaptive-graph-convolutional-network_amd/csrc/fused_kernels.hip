@@ -91,7 +91,7 @@ struct FusedBwdDims {
   int64_t o_svec, o_dd, o_rs, o_colp, o_tile, o_dx, o_g1, o_r3, o_wt, o_x0, o_m, total;
 };
 
-AGCN_HD inline FusedBwdDims fused_bwd_dims(int n, int Fin, int Fout, int K, bool gb = false) {
+AGCN_HD inline FusedBwdDims fused_bwd_dims(int n, int Fin, int Fout, int K, bool gbw = false, bool gbm = false) {
   FusedBwdDims d;
   d.n4 = (n + 15) & ~15;
   d.F4 = (Fin + 15) & ~15;
@@ -109,8 +109,8 @@ AGCN_HD inline FusedBwdDims fused_bwd_dims(int n, int Fin, int Fout, int K, bool
   d.o_dx = o;   o += r4((int64_t)d.n4 * d.ldxa);
   d.o_g1 = o;   o += r4((int64_t)d.n4 * d.ldxa);
   d.o_r3 = o;
-  const int64_t gp = r4((int64_t)d.n4 * d.ldg), wt = gb ? 0 : r4((int64_t)K * d.F4 * d.ldg);
-  const int64_t x0 = r4((int64_t)d.n4 * d.ldxa), m = gb ? 0 : r4((int64_t)d.F4 * d.ldxa);
+  const int64_t gp = r4((int64_t)d.n4 * d.ldg), wt = gbw ? 0 : r4((int64_t)K * d.F4 * d.ldg);
+  const int64_t x0 = r4((int64_t)d.n4 * d.ldxa), m = gbm ? 0 : r4((int64_t)d.F4 * d.ldxa);
   d.o_wt = o + gp;
   d.o_x0 = o;
   d.o_m = o + x0;
@@ -531,7 +531,8 @@ __global__ __launch_bounds__(1024) void fused_forward_kernel(SgcArgs a, int firs
 //   B2  (paper) dL = g_1 X_0^T -> dalpha, dA, dd, dr, c -> dZ = (diag(c 1) - c) Z;  dX += dZ M_L^T
 // The parameter gradients that reduce over the whole batch (dweight, dbias, dM_L) are formed by
 // param_grads.hip from Gp / dZ written here.
-template <bool GB, bool RESLAP>
+// GBW / GBM: W (for [g_0|g_1] = Gp . W^T) / M_L (for dX += dZ . M_L^T) read from global memory instead of an LDS image
+template <bool GBW, bool GBM, bool RESLAP>
 __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   const int64_t toff = (int64_t)(((uint64_t)(uint32_t)__float_as_int(gd1[1]) << 32) | (uint32_t)__float_as_int(gd1[0]));
   const int64_t tend = (int64_t)(((uint64_t)(uint32_t)__float_as_int(gd1[3]) << 32) | (uint32_t)__float_as_int(gd1[2]));
   const int Fin = a.Fin, Fout = a.Fout, K = a.K;   // K == 2
-  const FusedBwdDims d = fused_bwd_dims(n, Fin, Fout, K, GB);
+  const FusedBwdDims d = fused_bwd_dims(n, Fin, Fout, K, GBW, GBM);
   const int n4 = d.n4, F4 = d.F4, O4 = d.O4, ldt = d.ldt, ldxa = d.ldxa, ldg = d.ldg;
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const bool relu = a.activation == AGCN_ACT_RELU;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     for (int e = tid; e < a.zero_count; e += nthr) a.zero_ptr[e] = 0;
   }
   // global-B with 16-byte loads along the contiguous k of W^T / M_L^T rows (A images stored k-permuted)
-  const bool vecW = GB, vecM = GB;
+  const bool vecW = GBW, vecM = GBM;
   AGCN_STAMP(4, 0);
   // ---- B0: loads: dY, Y rows -> Gp image (+ global copy); W -> regrouped image; CSR rows; s --------
   int csr_p0 = 0, csr_p1 = 0;
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
     }
     // W image row k*F4 + f <- W row f*K + k, columns = Fout (the GEMM's k dimension)
     auto wmap = [&](int jr) { const int k = jr >= F4 ? 1 : 0; const int f = jr - k * F4; return f < Fin ? f * K + k : -1; };
-    if (!GB) {
+    if (!GBW) {
       if (O4 <= 64) stage_matrix<1>(WTimg, ldg, a.weight, Fout, K * F4, Fout, K * F4, O4, wmap);
       else stage_matrix<4>(WTimg, ldg, a.weight, Fout, K * F4, Fout, K * F4, O4, wmap);
     }
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       const int jr = 16 * in + r;
       float* dst = (jr < F4) ? dXimg : G1img;
       const int f = (jr < F4) ? jr : jr - F4;
-      if (GB) {   // B[c][jr] = W[f*K + k][c]: the lane's W row, k along the Fout columns
+      if (GBW) {   // B[c][jr] = W[f*K + k][c]: the lane's W row, k along the Fout columns
         const int kk = (jr < F4) ? 0 : 1;
         const float* wrow = a.weight + (int64_t)(min(f, Fin - 1) * K + kk) * Fout;
         tile_gemm_gbt4(acc, GPimg, ldg, 16 * im, wrow, Fout, O4);
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       z0r[u][0] = Zg0[(int64_t)i * Fin + min(lane, Fin - 1)];
       z0r[u][1] = Zg0[(int64_t)i * Fin + min(lane + 64, Fin - 1)];
     }
-    if (!GB) {
+    if (!GBM) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int k = min(wave + 16 * u, Fin - 1);
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
           if (lane + 64 < F4) X0img[i * ldxa + lane + 64] = (i < n && lane + 64 < Fin) ? x0r[u][1] : 0.f;
         }
       }
-      if (!GB) {
+      if (!GBM) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int k = wave + 16 * u;
@@ -762,10 +763,10 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       auto ident = [](int rr) { return rr; };
       if (F4 <= 128) {
         stage_matrix<2>(X0img, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
-        if (!GB && paper) stage_matrix<2>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
+        if (!GBM && paper) stage_matrix<2>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
       } else {
         stage_matrix<4>(X0img, ldxa, Xg, a.ldx, n, Fin, n4, F4, ident);
-        if (!GB && paper) stage_matrix<4>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
+        if (!GBM && paper) stage_matrix<4>(Mimg, ldxa, a.M_L, Fin, Fin, Fin, F4, F4, ident);
       }
     }
     __syncthreads();
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
         const int in = t / tm, im = t - in * tm;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int f = 16 * in + r;
-        if (GB) {   // the lane's M_L row f, k along its columns
+        if (GBM) {   // the lane's M_L row f, k along its columns
           const float* mrow = a.M_L + (int64_t)min(f, Fin - 1) * Fin;
           tile_gemm_gbt4(acc, X0img, ldxa, 16 * im, mrow, Fin, F4);
           if (f >= Fin) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1005,33 +1006,40 @@ size_t fused_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
 size_t fused_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
   return sizeof(float) * (size_t)fused_bwd_dims(n, Fin, Fout, K).total;
 }
-size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
-  return sizeof(float) * (size_t)fused_bwd_dims(n, Fin, Fout, K, true).total;
+size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K, bool gbw, bool gbm) {
+  return sizeof(float) * (size_t)fused_bwd_dims(n, Fin, Fout, K, gbw, gbm).total;
 }
 
-template <bool GB, bool RESLAP>
+template <bool GBW, bool GBM, bool RESLAP>
 static int launch_fused_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_backward_kernel<GB, RESLAP>), lds_bytes));
+    hipError_t e = static_cast<hipError_t>(
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_backward_kernel<GBW, GBM, RESLAP>), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_kernel<GB, RESLAP>), dim3(count), dim3(1024), lds_bytes, s, a, first);
+  hipLaunchKernelGGL((fused_backward_kernel<GBW, GBM, RESLAP>), dim3(count), dim3(1024), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_backward launch: %s", hipGetErrorString(e));
   return AGCN_OK;
 }
 
-int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_b,
-                          void* stream) {
+template <bool RESLAP>
+static int launch_fused_backward_v(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool gbw, bool gbm,
+                                   hipStream_t s) {
+  if (gbw) return gbm ? launch_fused_backward_t<true, true, RESLAP>(a, first, count, lds_bytes, s)
+                      : launch_fused_backward_t<true, false, RESLAP>(a, first, count, lds_bytes, s);
+  return gbm ? launch_fused_backward_t<false, true, RESLAP>(a, first, count, lds_bytes, s)
+             : launch_fused_backward_t<false, false, RESLAP>(a, first, count, lds_bytes, s);
+}
+
+int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_w,
+                          bool global_m, void* stream) {
   if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a.variant == AGCN_SGC_LL_RESLAP)
-    return global_b ? launch_fused_backward_t<true, true>(a, first, count, lds_bytes, s)
-                    : launch_fused_backward_t<false, true>(a, first, count, lds_bytes, s);
-  return global_b ? launch_fused_backward_t<true, false>(a, first, count, lds_bytes, s)
-                  : launch_fused_backward_t<false, false>(a, first, count, lds_bytes, s);
+  if (a.variant == AGCN_SGC_LL_RESLAP) return launch_fused_backward_v<true>(a, first, count, lds_bytes, global_w, global_m, s);
+  return launch_fused_backward_v<false>(a, first, count, lds_bytes, global_w, global_m, s);
 }
 
 template <bool GB, bool RESLAP>

@@ -138,9 +138,10 @@ size_t fused_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K);   //
 int launch_fused_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_b,
                          void* stream);
 size_t fused_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
-size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K);
-int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_b,
-                          void* stream);
+// global_w / global_m: W / M_L read from global memory instead of an LDS image
+size_t fused_bwd_lds_bytes_gb(int32_t n, int32_t Fin, int32_t Fout, int32_t K, bool global_w, bool global_m);
+int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, bool global_w,
+                          bool global_m, void* stream);
 // slab-parallel SGC_LL (K = 2, packed rows, symmetric CSR L_orig)
 bool slab_path_fits(int32_t Fin);
 int launch_slab_forward(const SgcArgs& a, void* stream);
