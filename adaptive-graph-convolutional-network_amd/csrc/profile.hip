@@ -32,10 +32,12 @@ hipEvent_t get_event() {
 
 int ensure_dynamic_lds(const void* kernel, size_t bytes) {
   static std::mutex mu;
-  static std::unordered_map<const void*, size_t> cap;
+  static std::unordered_map<uint64_t, size_t> cap;   // (device, kernel) -> cap already set
   if (bytes <= 64 * 1024) return 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lk(mu);
-  size_t& have = cap[kernel];
+  size_t& have = cap[reinterpret_cast<uint64_t>(kernel) ^ ((uint64_t)(dev + 1) << 56)];
   if (have >= bytes) return 0;
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e == hipSuccess) have = bytes;

@@ -111,7 +111,7 @@ enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_
        PK_PARAM_ONEPASS, PK_COUNT };
 // Raises a kernel's dynamic-LDS cap (hipFuncAttributeMaxDynamicSharedMemorySize) once per kernel and size: the
 // driver call is skipped when the cap already covers `bytes` (it costs several microseconds per launch otherwise).
-// One process drives one GPU.  Returns hipSuccess (0) or the HIP error code.
+// Tracked per (device, kernel).  Returns hipSuccess (0) or the HIP error code.
 int ensure_dynamic_lds(const void* kernel, size_t bytes);
 bool prof_on();
 void prof_begin(int id, void* stream);
