@@ -1,6 +1,6 @@
 """Randomised cross-check of every kernel path against the oracle (float64): random widths, graph sizes,
 variants, modes, with and without L_prev / upstream dL_sum, leaky slopes != 1.
-usage: python tools/fuzz_paths.py [n_cases] [seed]"""
+usage: python tools/fuzz_paths.py [n_cases] [seed] [big]"""
 import os
 import sys
 
@@ -19,7 +19,7 @@ PATHS = {"auto": (1, 1, -1, 160 * 1024), "fused_lds": (1, 1, 0, 160 * 1024), "fu
          "slab": (0, 1, -1, 160 * 1024), "pergraph_lds": (0, 0, -1, 160 * 1024), "pergraph_global": (0, 0, -1, 0)}
 
 
-def run(n_cases, seed, fin_choices=(1, 3, 5, 16, 33, 64, 75, 128), verbose=True):
+def run(n_cases, seed, fin_choices=(1, 3, 5, 16, 33, 64, 75, 128), verbose=True, mu=np.log(12), sigma=0.7, nmax=110):
     import agcn_amd as amd
     lib = amd._ffi.lib()
     rs0 = np.random.RandomState(seed)
@@ -27,7 +27,7 @@ def run(n_cases, seed, fin_choices=(1, 3, 5, 16, 33, 64, 75, 128), verbose=True)
     try:
         for case in range(n_cases):
             B = int(rs0.randint(1, 9))
-            ns = [int(v) for v in np.clip(np.rint(rs0.lognormal(np.log(12), 0.7, size=B)), 1, 110)]
+            ns = [int(v) for v in np.clip(np.rint(rs0.lognormal(mu, sigma, size=B)), 1, nmax)]
             Fin = int(rs0.choice(list(fin_choices)))
             Fout = int(rs0.choice([1, 4, 17, 64, 128]))
             K = int(rs0.choice([1, 2, 2, 2, 3]))
@@ -66,4 +66,6 @@ def run(n_cases, seed, fin_choices=(1, 3, 5, 16, 33, 64, 75, 128), verbose=True)
 
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"       # graphs up to 400 nodes (slab / global-tile territory)
+    kw = dict(mu=np.log(50), sigma=0.9, nmax=400) if big else {}
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0, **kw) else 0)
