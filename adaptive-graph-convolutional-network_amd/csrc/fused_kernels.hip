@@ -1,20 +1,24 @@
-// Fused per-graph kernels for small graphs: SGC_LL (K = 2) forward in ONE launch, one 1024-thread
-// workgroup per graph, every operand staged in LDS once.
+// Fused per-graph kernels: the whole SGC_LL / SGC_LL_Reslap layer (K = 2) forward in ONE launch and backward in
+// ONE launch, one 1024-thread workgroup per graph, the graph's working set staged in LDS once.
 //
-// At Tox21 sizes a launch costs more than the arithmetic inside it (each kernel sits on a
-// ~5-9 us floor of launch + dependent memory round trips), so the split pipeline
-// (rows_gemm -> graph kernel -> rows_gemm) is latency-bound by its kernel COUNT.  When the whole
-// working set of a graph -- X, M_L, W, the n x n tile, Z^T / X_1 -- fits the 160 KiB of LDS
-// (n <~ 80 at 75 -> 64), all stages run back to back out of LDS after a single bulk-load round:
+// At Tox21 sizes a launch costs more than the arithmetic inside it (each kernel sits on a ~5-9 us floor of launch +
+// dependent memory round trips), so the split pipeline (rows_gemm -> graph kernel -> rows_gemm) is latency-bound by
+// its kernel COUNT.  When the working set of a graph fits the 160 KiB of LDS all stages run back to back:
 //
-//   F0  bulk loads: X rows, M_L, W (rows regrouped [k][f]), CSR rows of L_orig        (one round)
-//   F1  Z = X . M_L                      graphconv.py:164        MFMA, operands in LDS -> Z^T image
+//   F0  bulk loads: X rows, CSR rows of L_orig (+ M_L, W images in the LDS-image flavour)            (one round)
+//   F1  Z = X . M_L                      graphconv.py:164        MFMA -> Z^T image + reserve
 //   F2  S = exp(-||Z_i - Z_j||), degree  graphconv.py:168-197    2x2 blocks, feature-split lanes
-//   F3  R = I | I - s S s, leaky-ReLU, + L_orig                  graphconv.py:198-216 (clip scale == 1)
+//   F3  R = I | I - s S s, (Reslap: clip_by_norm,) leaky-ReLU, + L_orig (CSR scatter or dense rows),
+//       (Reslap: + beta L_prev, second clip + leaky-ReLU)        graphconv.py:198-216, graphconv_reslap.py:184-198
 //   F4  X_1 = L X_0                      graphconv.py:231        MFMA, operands in LDS
-//   F5  Y = act(X_0 W_0 + X_1 W_1 + b)   graphconv.py:238-251    MFMA, operands in LDS
+//   F5  Y = act(X_0 W_0 + X_1 W_1 + b)   graphconv.py:238-251    MFMA
 //
-// Same arithmetic (and the same fixed reduction orders) as sgc_forward.hip + rows_gemm.hip.
+// Template flags: GB (forward) / GBW, GBM (backward) -- the parameter (W, M_L) is read straight from global memory
+// (L2-resident) inside the MFMA k-loops instead of being staged as an LDS image: no image => wide layers (Fin = 128)
+// and graphs up to 96 nodes fit, and for 16-byte aligned rows it is also the faster choice; RESLAP -- the
+// SGC_LL_Reslap combine and its adjoints.  agcn_api.hip (fused_split) picks the flavour per batch.
+//
+// Same arithmetic (and the same fixed reduction orders) as sgc_forward.hip / sgc_backward.hip + rows_gemm.hip.
 #include "agcn_device.h"
 #include "sgc_kernels.h"
 
