@@ -9,9 +9,10 @@
 //     column strips of L are row strips.
 // Graph-wide quantities that a strip needs from other strips cross a kernel boundary:
 //   slab_sim  : S strip = exp(-||Z_i - Z_j||), r strip, degree -> s_i          (res_W, sv_r, sv_s)
-//   slab_lap  : R strip, res_L, L strip = lrelu(R) + L_orig, X_1[I] = L[I,:] X_0
+//   slab_lap  : R strip, res_L, L strip = lrelu(R) + L_orig (CSR rows or dense), X_1[I] = L[I,:] X_0, and the
+//               filter product Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b) with W read from global memory
 //   slab_bwd1 : dX[I] += L[I,:] g_1; dL row/column strips, dA strip, dd_i, dalpha partial
-//   slab_bwd2 : c strip = (dr_ij + dr_ji) / r_ij, dZ[I] = rowsum(c) Z[I] - c Z
+//   slab_bwd2 : c strip = (dr_ij + dr_ji) / r_ij, dZ[I] = rowsum(c) Z[I] - c Z, dX[I] += dZ[I] M_L^T
 // Wave w of a workgroup owns slab rows 4w..4w+3 in the element-wise phases (lanes run along the
 // columns: coalesced row accesses of the packed tiles) and column tiles w, w+4 of the 16 x Fin MFMA
 // outputs.  Reductions are per-lane sequential + a fixed shuffle tree: reproducible bit for bit.
