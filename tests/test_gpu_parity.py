@@ -480,6 +480,40 @@ def test_random_shapes_on_every_path(amd):
     assert fuzz_paths.run(60, 11, fin_choices=(3, 5, 16, 33, 64, 75, 128), verbose=False) == 0
 
 
+def test_hiv_shaped_epoch_properties(amd):
+    """BASELINE config "HIV (~40k mols), bf16 features + fp32 Laplacian": an epoch slice of HIV-shaped graphs
+    (4..222 atoms) through ingest -> SGC_LL with bf16 feature storage, checked through size-independent properties:
+    res_W symmetric bit for bit with a zero diagonal and entries in (0, 1], res_L rows consistent with the degree
+    normalisation (diag(R) == 1 exactly), finite outputs / gradients, and bit-identical parameter gradients when the
+    same batch is run twice."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(99, 1200, mu=np.log(23.0), hi=222)
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    Fin, Fout, K = 75, 64, 2
+    p = orc.init_params(np.random.RandomState(4), Fin, Fout, K)
+    seen = 0
+    for gb, _, _, ids in store.iterbatches(256, DEV, deterministic=True):
+        grads = []
+        for rep in range(2):
+            layer = make_layer(amd, orc.SGC_LL, Fout, Fin, gb.plan.B, K, orc.PAPER, p, DEV)
+            Xb = gb.X.to(torch.bfloat16).requires_grad_(True)
+            nodes, res_L, res_W = layer({"node_features": Xb, "graph_batch": gb})
+            nodes.data.float().sum().backward()
+            grads.append([layer.vars[k].grad.clone() for k in ("weight", "bias", "M_L", "alpha")] + [Xb.grad.clone()])
+        for a_, b_ in zip(*grads):
+            assert torch.equal(a_, b_)
+            assert bool(torch.isfinite(a_.float()).all())
+        assert nodes.data.dtype == torch.bfloat16 and bool(torch.isfinite(nodes.data.float()).all())
+        for b in (0, gb.plan.B // 2, gb.plan.B - 1, int(np.argmax(gb.plan.n))):
+            w, r_ = to_np(res_W[b]), to_np(res_L[b])
+            assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
+            off = w[~np.eye(w.shape[0], dtype=bool)]
+            assert np.all(off > 0) and np.all(off <= 1)
+            assert np.all(np.diag(r_) == 1.0)
+        seen += len(ids)
+    assert seen == 1200
+
+
 def test_reslap_without_prev(amd):
     ns, Fin, Fout, K = [6, 9, 14], 8, 6, 2
     for mode in (orc.REFERENCE, orc.PAPER):
