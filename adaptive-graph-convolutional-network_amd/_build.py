@@ -9,8 +9,10 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libagcn_hip.so")
 ARCH = "gfx950"
 # -Wno-pass-failed: "loop not unrolled" remarks for unroll hints on runtime-bounded loops of the per-graph kernels
-FLAGS = ["-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-Wno-pass-failed"]
+# -fno-slp-vectorize: keeps adjacent scalar fp32 adds / fmas as v_add_f32 / v_fma_f32; the packed v_pk_*_f32 forms the
+# SLP vectoriser would build issue several times slower on gfx950 (measured in the pairwise-distance loop)
+FLAGS = ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17", "-Wall",
+         "-Wno-unused-function", "-Wno-pass-failed"]
 
 
 def sources():

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "sgc_kernels.h"
+#include "spec_kernels.h"
 
 namespace agcn {
 
@@ -72,10 +73,29 @@ struct FusedSplit {
   // 1 = the fused forward / backward kernel reads M_L / W straight from global memory (no LDS images of them):
   // wide layers (Fin = 128) and graphs up to ~100 nodes fit this way
   int gb_fwd, gb_bwd_w, gb_bwd_m;   // backward: W and M_L separately
+  // shape-specialised kernels (spec_*.hip) instead of the general fused ones, per direction
+  int spec_fwd, spec_bwd;
 };
 
+// The specialised kernels cover the whole batch or nothing (one launch per direction).
+void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnPlanInfo& pi, size_t lim) {
+  f->spec_fwd = f->spec_bwd = 0;
+  if (f->mode != 1 || !spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
+  const int m = agcn_get_spec_mode();
+  if ((m & 1) && spec_fwd_lds_bytes(pi.max_n, d->Fin, d->Fout) <= lim) f->spec_fwd = 1;
+  if ((m & 2) && spec_bwd_lds_bytes(pi.max_n, d->Fin, d->Fout) <= lim) f->spec_bwd = 1;
+}
+
+FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host);
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
-  FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0};
+  FusedSplit f = fused_split_general(d, g, host);
+  size_t lim = (size_t)agcn_get_lds_limit();
+  if (lim > 160 * 1024) lim = 160 * 1024;
+  pick_spec(&f, d, host.info, lim);
+  return f;
+}
+FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
+  FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
   if (!(d->K == 2 && pi.rows == pi.N1 && (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;
@@ -327,6 +347,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   const FusedSplit fs = fused_split(desc, batch, host);
   if (fs.mode == 1) {
     // small graphs: the whole layer forward in one launch, everything staged in LDS once
+    if (fs.spec_fwd)
+      return launch_spec_forward(a, 0, host.info.B, spec_fwd_lds_bytes(fs.thr, desc->Fin, desc->Fout), hip_stream);
     if (fs.gb_fwd)
       return launch_fused_forward(a, 0, host.info.B, fused_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K), true,
                                   hip_stream);

@@ -176,6 +176,14 @@ __device__ __forceinline__ float lrelu_grad(float x, float alpha) {
   return x > 0.f ? 1.f : (x < 0.f ? alpha : 0.f);
 }
 
+// dd_k = -1/2 s_k^3 ds_k (s = d^-1/2).  A node whose similarities all underflow has d_k = FLT_TRUE_MIN, s_k ~ 2.7e22 and
+// s_k^3 = inf while ds_k = 0: inf * 0 would poison dM_L of the whole batch with NaN.  Such a node is cut out of the
+// degree gradient instead (dd_k = 0 whenever s_k^3 is not finite or ds_k == 0); the oracle applies the same rule.
+__device__ __forceinline__ float degree_grad(float sk, float dsk) {
+  const float s3 = sk * sk * sk;
+  return (dsk == 0.f || !(fabsf(s3) <= 3.402823466e+38f)) ? 0.f : -0.5f * s3 * dsk;
+}
+
 // TF-0.12 clip_by_norm(t, 1) / clip_by_average_norm(t, 1):
 //   scale = min(rsqrt(sum t^2) [* numel], 1)
 __device__ __forceinline__ float clip_scale(float ss, float q) {

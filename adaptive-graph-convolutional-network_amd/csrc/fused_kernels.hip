@@ -23,6 +23,7 @@
 #include "sgc_kernels.h"
 
 #include <float.h>
+#include <cstdlib>
 
 namespace agcn {
 
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
       float cs = 0.f;
       for (int w = 0; w < nw; ++w) cs += colp[w * n4 + k];
       const float sk = s_vec[k];
-      ddv[k] = -0.5f * sk * sk * sk * (rsv[k] + cs);   // dd_k = -1/2 s_k^3 ds_k
+      ddv[k] = degree_grad(sk, rsv[k] + cs);   // dd_k = -1/2 s_k^3 ds_k
     }
     __syncthreads();
     AGCN_STAMP(4, 7);
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
         float R = (i == j) ? 1.f : 0.f;
         R = R - (si * Sv) * s_vec[j];
         const float dA = -(RESLAP ? tile[i * ldt + j] : tile[i * ldt + j] * lrelu_grad(R, alpha));
-        tile[i * ldt + j] = -Sv * (dA * si * s_vec[j] + ddv[j]);
+        tile[i * ldt + j] = (Sv == 0.f) ? 0.f : -Sv * (dA * si * s_vec[j] + ddv[j]);   // S == 0: no inf * 0
       }
     }
     __syncthreads();
@@ -1000,6 +1001,17 @@ __global__ __launch_bounds__(1024) void fused_backward_kernel(SgcArgs a, int fir
   }
 }
 
+// diagnostic: AGCN_FUSED_THREADS overrides the workgroup size of the fused kernels (multiple of 64)
+static int fused_threads() {
+  static const int t = [] {
+    const char* e = std::getenv("AGCN_FUSED_THREADS");
+    int v = e ? std::atoi(e) : 1024;
+    if (v < 64 || v > 1024 || (v & 63)) v = 1024;
+    return v;
+  }();
+  return t;
+}
+
 size_t fused_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t K) {
   return sizeof(float) * (size_t)fused_dims(n, Fin, Fout, K).total;
 }
@@ -1022,7 +1034,7 @@ static int launch_fused_backward_t(const SgcArgs& a, int32_t first, int32_t coun
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_kernel<GBW, GBM, RESLAP>), dim3(count), dim3(1024), lds_bytes, s, a, first);
+  hipLaunchKernelGGL((fused_backward_kernel<GBW, GBM, RESLAP>), dim3(count), dim3(fused_threads()), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_backward launch: %s", hipGetErrorString(e));
@@ -1053,7 +1065,7 @@ static int launch_fused_forward_t(const SgcArgs& a, int32_t first, int32_t count
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(fused_fwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_kernel<GB, RESLAP>), dim3(count), dim3(1024), lds_bytes, s, a, first);
+  hipLaunchKernelGGL((fused_forward_kernel<GB, RESLAP>), dim3(count), dim3(fused_threads()), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "fused_forward launch: %s", hipGetErrorString(e));

@@ -208,7 +208,11 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
     for (int w = 0; w < 16; ++w) v += wsum[w][tid];
     __hip_atomic_store(mine + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();   // every storing wave has drained its stores (vmcnt(0)) before the arrival is counted
+  // Every storing wave drains its sc1 stores BEFORE the barrier that precedes the arrival count: a workgroup-scope
+  // barrier alone emits no vmcnt wait on gfx950, and the relaxed counter add could then overtake the partial tile
+  // (MI355X_MICROARCH.md, inter-workgroup visibility, condition (3)).  Inline asm: invisible to the waitcnt pass.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (tid == 0) {
     const int old = __hip_atomic_fetch_add(a.counters + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_flag = (old == S - 1) ? 1 : 0;

@@ -276,14 +276,14 @@ __global__ __launch_bounds__(1024) void sgc_backward_kernel(SgcArgs a, int first
         for (int j = 0; j < n; ++j) r1 += (tile[k * ldt + j] * S[(int64_t)k * n + j]) * s_vec[j];
         for (int i = 0; i < n; ++i) r2 += (tile[i * ldt + k] * S[(int64_t)i * n + k]) * s_vec[i];
         const float sk = s_vec[k];
-        v1[k] = -0.5f * sk * sk * sk * (r1 + r2);
+        v1[k] = degree_grad(sk, r1 + r2);
       }
       __syncthreads();
       // dS_ij = dA_ij s_i s_j + dd_j ; dr_ij = -S_ij dS_ij   (S_ii = 0 kills the diagonal)
       for (int idx = tid; idx < nn; idx += nthr) {
         const int i = (int)divn.div((uint32_t)idx), j = idx - i * n;
         const float dS = tile[i * ldt + j] * s_vec[i] * s_vec[j] + v1[j];
-        tile[i * ldt + j] = -S[idx] * dS;
+        tile[i * ldt + j] = (S[idx] == 0.f) ? 0.f : -S[idx] * dS;   // S == 0: no inf * 0
       }
       __syncthreads();
       AGCN_STAMP(4, 5);

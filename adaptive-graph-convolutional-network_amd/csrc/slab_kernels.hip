@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
       const int il = 4 * wave + di;
       if (lane == 0 && il < c.nr) {
         const float sk = si[di];
-        a.ws_dd[c.row0 + c.i0 + il] = -0.5f * sk * sk * sk * t;   // dd_k = -1/2 s_k^3 ds_k
+        a.ws_dd[c.row0 + c.i0 + il] = degree_grad(sk, t);   // dd_k = -1/2 s_k^3 ds_k
       }
     }
   }
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
     for (int di = 0; di < 4; ++di) {
       const int il = 4 * wave + di, i = c.i0 + il;
       float cij = 0.f;
-      if (cv && il < c.nr && i != j && rv[di] > 0.f) {
+      if (cv && il < c.nr && i != j && rv[di] > 0.f && Sv[di] != 0.f) {   // S == 0 (underflow): dr = 0, never inf * 0
         // dS_ij = dA_ij s_i s_j + dd_j ; dr_ij = -S_ij dS_ij  (and the transposed pair)
         const float dr_ij = -Sv[di] * (dA[di] * si[di] * sj + ddj);
         const float dr_ji = -Sv[di] * (dAt[di] * sj * si[di] + ddi[di]);

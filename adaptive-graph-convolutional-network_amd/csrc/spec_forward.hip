@@ -1,0 +1,393 @@
+// Shape-specialised fused forward of SGC_LL (K = 2): the whole layer for one graph in one 1024-thread workgroup.
+// Same math, same outputs and the same reserve layout as fused_forward_kernel (fused_kernels.hip), so either
+// backward kernel can follow it.  See spec_kernels.h for why it exists.
+//
+//   F0  X rows -> LDS image (zero padded); CSR row pointers / entries requested; first M_L fragment requested
+//   F1  Z = X . M_L                      graphconv.py:164        MFMA, B fragments streamed from L2 -> Z^T image
+//   F2  S = exp(-||Z_i - Z_j||)          graphconv.py:168-180    2x2 register blocks over the upper triangle
+//   F2b d_j = sum_i S_ij (row order), s = d^-1/2                 graphconv.py:195-197
+//   F3  res_W, res_L out; L = lrelu(I | I - s S s) + L_orig      graphconv.py:198-216   (in place over S)
+//   F4  X_1 = L X_0                      graphconv.py:231        MFMA, both operands in LDS
+//   F5  Y = act(X_0 W_0 + X_1 W_1 + b)   graphconv.py:238-251    MFMA, W fragments streamed from L2
+//   F6  Y, X_1 (reserve) out
+//
+// Where the global stores sit matters: gfx950 counts loads and stores in ONE in-order counter (vmcnt), so a load
+// issued after a store cannot be waited for without also waiting for that store's acknowledgement from L2 (~1 us).
+// The reserve and the n x n outputs are stored in F1 .. F3, at least a phase before the next load (the W fragments,
+// requested at the start of F4) is waited for; the outputs of F4 / F5 (X_1, Y) are stored after the last W fragment
+// has been requested (the Y accumulators wait in registers).  Fragments are requested one phase ahead at most: held
+// longer, the register allocator moves them around and has to wait for them on the spot (measured).
+#include "spec_kernels.h"
+
+#include <float.h>
+
+namespace agcn {
+namespace spec {
+
+constexpr int MAXT = 3;   // most MFMA tiles of one phase a wave may own (accumulators are held in registers)
+
+template <int FIN, int FOUT>
+__global__ __launch_bounds__(NT) void spec_forward_kernel(SgcArgs a, int first) {
+  using FT = Feat<FIN>;
+  constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
+  constexpr int NOB = FOUT / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = uni(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const GraphRec g = load_graph(a.graph_desc + first + blockIdx.x);
+  const int n = g.n, row0 = g.row0;
+  const uint32_t toff = g.toff;
+  const FwdLds d = fwd_lds(n, F4);
+  const int n4 = d.n4, ldt = d.ldt, ldz = d.ldz, ntm = n4 >> 4;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const bool relu = a.activation == AGCN_ACT_RELU;
+  float* s_vec = smem + d.o_s;
+  float* tile = smem + d.o_tile;   // [n4][ldt] S, then L = lrelu(R) + L_orig with the 16-padding zeroed
+  float* Ximg = smem + d.o_x;      // [n4][LDX] X_0; rows >= n and columns >= FIN zero
+  float* Zt = smem + d.o_z;        // [FIN][ldz] Z^T; later
+  float* X1img = smem + d.o_z;     // [n4][LDX] X_1
+  const float* Xg = a.X + (int64_t)row0 * a.ldx;
+
+  AGCN_STAMP(1, 0);
+  // ---- F0 ------------------------------------------------------------------------------------------------
+  // first M_L fragment of this wave's F1 tiles: requested before anything else (it is consumed last)
+  int t1a, t1b;
+  tile_range(ntm * NCB, wave, t1a, t1b);
+  float bA[NKS], bB[NKS];
+  const float* mq = a.M_L + q * FIN;
+  auto load_m = [&](float (&bf)[NKS], int t) {
+    const int cb = t % NCB;
+    const float* p = mq + min(cb * 16 + r, FIN - 1);
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      // row 4u + q of M_L; only the last k-step can run past FIN - 1 (the A image is zero there)
+      if (4 * u + 3 < FIN) bf[u] = p[4 * u * FIN];
+      else bf[u] = p[(min(4 * u + q, FIN - 1) - q) * FIN];
+    }
+  };
+  if (t1a < t1b) load_m(bA, t1a);
+
+  int csr_p0 = 0, csr_p1 = 0;
+  if (a.L0_rowptr && tid < n) {
+    csr_p0 = a.L0_rowptr[row0 + tid];
+    csr_p1 = a.L0_rowptr[row0 + tid + 1];
+  }
+  const float alpha = a.alpha[0];
+  // X rows: wave w takes rows w, w + 16, ..; lanes run along the features
+  for (int i0 = wave; i0 < n4; i0 += 4 * NW) {
+    float xr[4][CP];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* rp = Xg + (int64_t)min(i0 + NW * u, n - 1) * a.ldx;
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) xr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + NW * u;
+      if (i < n4) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < F4) Ximg[i * LDX + c] = (i < n && c < FIN) ? xr[u][cp] : 0.f;
+        }
+      }
+    }
+  }
+  // (a molecule row has at most 5 entries: the diagonal + 4 bonds; longer rows take the dependent tail loop)
+  int csr_c[6] = {0, 0, 0, 0, 0, 0};
+  float csr_v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tid < n && csr_p1 > csr_p0) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int pp = min(csr_p0 + u, csr_p1 - 1);
+      csr_c[u] = a.L0_col[pp];
+      csr_v[u] = a.L0_val[pp];
+    }
+  }
+  lds_barrier();
+
+  AGCN_STAMP(1, 1);
+  // ---- F1: Z = X . M_L -> Z^T image + reserve ----------------------------------------------------------------
+  {
+    float* Zg = a.sv_Z + (int64_t)row0 * FIN;
+    auto tile_f1 = [&](const float (&bf)[NKS], int t) {
+      const int rt = t / NCB, cb = t - rt * NCB;
+      const float* Ap = Ximg + (rt * 16 + r) * LDX + q;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
+      const int c = cb * 16 + r, i0 = rt * 16 + 4 * q;
+      if (c < FIN) {
+        *reinterpret_cast<f32x4*>(Zt + c * ldz + i0) = acc;   // rows >= n come out 0 (zero rows of the X image)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+          if (i0 + i4 < n) Zg[(i0 + i4) * FIN + c] = acc[i4];
+      }
+    };
+    for (int t = t1a; t < t1b; t += 2) {
+      if (t + 1 < t1b) load_m(bB, t + 1);
+      tile_f1(bA, t);
+      if (t + 1 < t1b) {
+        if (t + 2 < t1b) load_m(bA, t + 2);
+        tile_f1(bB, t + 1);
+      }
+    }
+  }
+  // W fragments of this wave's F5 tiles
+  int t5a, t5b;
+  tile_range(ntm * NOB, wave, t5a, t5b);
+  const float* wq = a.weight + q * 2 * FOUT + r;
+  auto load_w = [&](float (&bf)[NKS], int t, int h) {
+    const int ob = t % NOB;
+    const float* p = wq + h * FOUT + ob * 16;   // W row f*K + h (graphconv.py:243-244), f = 4u + q
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      if (4 * u + 3 < FIN) bf[u] = p[4 * u * 2 * FOUT];
+      else bf[u] = p[(min(4 * u + q, FIN - 1) - q) * 2 * FOUT];
+    }
+  };
+  lds_barrier();
+
+  AGCN_STAMP(1, 2);
+  // ---- F2: similarity (2x2 blocks, upper triangle, feature loop split over adjacent lanes) -----------------
+  {
+    const int nb2 = (n + 1) >> 1;
+    const TriFold19 tri(nb2);
+    const int cnt = tri.cnt;
+    int fs_log = 0;
+    while (fs_log < 4 && (cnt << (fs_log + 1)) <= NT) ++fs_log;
+    const int fs = 1 << fs_log;
+    const int part = tid & (fs - 1);
+    const int step = fs >= 4 ? 4 : fs;        // results of a block handled per lane group pass
+    for (int tb = 0; tb < cnt * fs; tb += NT) {
+      const int t = (tb + tid) >> fs_log;
+      int bi = 0, bj = 0;
+      const bool live = t < cnt && tri.get(t, bi, bj);
+      const int i0 = 2 * bi, j0 = 2 * bj;
+      const float* zi = Zt + i0;
+      const float* zj = Zt + j0;
+      // packed fp32: a v_pk_add_f32 / v_pk_fma_f32 takes one issue slot like its scalar form and does two pairs
+      f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+      if (live) {
+#pragma unroll 5
+        for (int f = part; f < FIN; f += fs) {
+          const f32x2 u = *reinterpret_cast<const f32x2*>(zi + f * ldz);
+          const f32x2 v = *reinterpret_cast<const f32x2*>(zj + f * ldz);
+          const f32x2 d0 = (f32x2){u.x, u.x} - v, d1 = (f32x2){u.y, u.y} - v;
+          acc0 = __builtin_elementwise_fma(d0, d0, acc0);
+          acc1 = __builtin_elementwise_fma(d1, d1, acc1);
+        }
+      }
+      float a00 = acc0.x, a01 = acc0.y, a10 = acc1.x, a11 = acc1.y;
+      for (int o = 1; o < fs; o <<= 1) {
+        a00 += __shfl_xor(a00, o, 64);
+        a01 += __shfl_xor(a01, o, 64);
+        a10 += __shfl_xor(a10, o, 64);
+        a11 += __shfl_xor(a11, o, 64);
+      }
+      // every lane of the group now holds the four sums; lane `part` finishes element e0 + part, so that the
+      // sqrt / exp / store sequence is issued once per `step` elements instead of once per element
+      for (int e0 = 0; e0 < 4; e0 += step) {
+        const int e = e0 + (part & (step - 1));
+        const float v2 = (e & 2) ? ((e & 1) ? a11 : a10) : ((e & 1) ? a01 : a00);
+        const int i = i0 + (e >> 1), j = j0 + (e & 1);
+        if (live && part < step && i < n && j < n) {
+          const float rr = fast_sqrt(v2);
+          const float sv = (i == j) ? 0.f : fast_exp_neg(rr);   // graphconv.py:171-177
+          tile[i * ldt + j] = sv;
+          tile[j * ldt + i] = sv;   // bit-symmetric by construction
+          if (paper && i < j) a.sv_r[toff + (uint32_t)(i * n + j)] = rr;   // the backward reads r_ij for i < j only
+        }
+      }
+    }
+  }
+  lds_barrier();
+  AGCN_STAMP(1, 3);
+  // degree: column sums in row order (numpy's axis-0 order), s = d^-1/2   graphconv.py:195-197
+  if (tid < n) {
+    float dsum = 0.f;
+    const float* col = tile + tid;
+    for (int i = 0; i < n; ++i) dsum += col[i * ldt];
+    dsum += FLT_TRUE_MIN;
+    const float sd = 1.0f / sqrtf(dsum);
+    s_vec[tid] = sd;
+    a.sv_s[row0 + tid] = sd;
+  }
+  if (tid < (int)g.npad) {   // alignment floats behind the tile
+    a.res_W[toff + (uint32_t)(n * n) + tid] = 0.f;
+    a.res_L[toff + (uint32_t)(n * n) + tid] = 0.f;
+    if (a.L_sum) a.L_sum[toff + (uint32_t)(n * n) + tid] = 0.f;
+  }
+  if (tid == 0) {   // clip_by_average_norm never clips for SGC_LL: scale exactly 1 (see slab_kernels.hip)
+    float* sc = a.sv_scal + 4 * g.b;
+    sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
+  }
+  lds_barrier();
+
+  AGCN_STAMP(1, 4);
+  // ---- F3: res_W out; R, leaky-ReLU, res_L out; tile <- lrelu(R) (+ dense L_orig), 16-padding zeroed --------
+  {
+    const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+    const float* L0d = !a.L0_dense ? nullptr
+                                   : (a.L0_ld > 0 ? a.L0_dense + (int64_t)g.b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
+    for (int j = lane; j < n4; j += 64) {
+      const bool jv = j < n;
+      const float sj = (paper && jv) ? s_vec[j] : 0.f;
+      for (int i = wave; i < n4; i += NW) {
+        float out = 0.f;
+        if (jv && i < n) {
+          const float l0 = L0d ? L0d[(int64_t)i * l0ld + j] : 0.f;
+          const float S = tile[i * ldt + j];
+          float R = (i == j) ? 1.f : 0.f;
+          if (paper) R = R - (s_vec[i] * S) * sj;
+          const float R2 = lrelu(R, alpha);   // (clip_by_average_norm never clips for SGC_LL: scale exactly 1)
+          const uint32_t o = toff + (uint32_t)(i * n + j);
+          a.res_W[o] = S;
+          a.res_L[o] = R2;
+          out = R2 + l0;
+        }
+        tile[i * ldt + j] = out;
+      }
+    }
+  }
+  lds_barrier();
+  if (a.L0_rowptr && tid < n) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
+    for (int p = csr_p0 + 6; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+  }
+  lds_barrier();
+  if (a.L_sum) {   // SGC_LL with the combined Laplacian requested
+    for (int i = wave; i < n; i += NW)
+      for (int j = lane; j < n; j += 64) a.L_sum[toff + (uint32_t)(i * n + j)] = tile[i * ldt + j];
+  }
+
+  AGCN_STAMP(1, 5);
+  // ---- F4: X_1 = L X_0 -> X_1 image (over Z^T) -------------------------------------------------------------
+  if (t5a < t5b) load_w(bA, t5a, 0);   // first W fragment of F5: its round trip overlaps F4
+  {
+    int t4a, t4b;
+    tile_range(ntm * NCB, wave, t4a, t4b);
+    for (int t = t4a; t < t4b; ++t) {
+      const int rt = t / NCB, cb = t - rt * NCB;
+      const float* Ap = tile + (rt * 16 + r) * ldt + q;
+      const float* Bp = Ximg + q * LDX + cb * 16 + r;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < n4; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = Ap[k0 + 4 * u];
+          bv[u] = Bp[(k0 + 4 * u) * LDX];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      }
+      const int c = cb * 16 + r, i0 = rt * 16 + 4 * q;
+      // every cell of the 16-padded image is written: rows >= n and columns >= FIN come out as 0
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) X1img[(i0 + i4) * LDX + c] = acc[i4];
+    }
+  }
+  lds_barrier();
+
+  AGCN_STAMP(1, 6);
+  // ---- F5: Y = act(X_0 W_0 + X_1 W_1 + b); accumulators held until every W fragment has been requested -----
+  f32x4 yacc[MAXT];
+  float ybias[MAXT];
+#pragma unroll
+  for (int sl = 0; sl < MAXT; ++sl) {
+    const int t = t5a + sl;
+    if (t < t5b) {
+      const int rt = t / NOB, ob = t - rt * NOB;
+      load_w(bB, t, 1);
+      ybias[sl] = a.bias[ob * 16 + r];
+      const float* A0 = Ximg + (rt * 16 + r) * LDX + q;
+      const float* A1 = X1img + (rt * 16 + r) * LDX + q;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bA[u], acc, 0, 0, 0);
+      if (t + 1 < t5b) load_w(bA, t + 1, 0);
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * u], bB[u], acc, 0, 0, 0);
+      yacc[sl] = acc;
+    }
+  }
+  AGCN_STAMP(1, 7);
+  // ---- F6: Y and X_1 out -------------------------------------------------------------------------------
+  {
+    float* Yg = a.Y + (int64_t)row0 * a.ldy;
+#pragma unroll
+    for (int sl = 0; sl < MAXT; ++sl) {
+      const int t = t5a + sl;
+      if (t < t5b) {
+        const int rt = t / NOB, ob = t - rt * NOB;
+        const int c = ob * 16 + r, i0 = rt * 16 + 4 * q;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          if (i0 + i4 < n) {
+            float v = yacc[sl][i4] + ybias[sl];
+            if (relu) v = fmaxf(v, 0.f);
+            Yg[(int64_t)(i0 + i4) * a.ldy + c] = v;
+          }
+        }
+      }
+    }
+    // X_1 rows (reserve: the parameter gradients read them)
+    float* Xo = a.sv_X + (int64_t)row0 * FIN;
+    for (int i = wave; i < n; i += NW)
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        const int c = lane + 64 * cp;
+        if (c < FIN) Xo[i * FIN + c] = X1img[i * LDX + c];
+      }
+  }
+  AGCN_STAMP(1, 8);
+}
+
+}  // namespace spec
+
+bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant) {
+  if (K != 2 || variant != AGCN_SGC_LL) return false;
+  return (Fin == 75 && Fout == 64) || (Fin == 64 && Fout == 128) || (Fin == 128 && Fout == 128) ||
+         (Fin == 128 && Fout == 64) || (Fin == 64 && Fout == 64);
+}
+
+// LDS bytes of the forward kernel for a largest graph of n nodes; SIZE_MAX when a wave would own more than MAXT
+// tiles of an MFMA phase (their accumulators are held in registers until the final store phase)
+size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout) {
+  const int F4 = (Fin + 15) & ~15, ntm = (n + 15) / 16;
+  if (ntm * (F4 / 16) > spec::MAXT * spec::NW || ntm * (Fout / 16) > spec::MAXT * spec::NW) return ~(size_t)0;
+  return sizeof(float) * (size_t)spec::fwd_lds(n, F4).total;
+}
+
+template <int FIN, int FOUT>
+static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = static_cast<hipError_t>(
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&spec::spec_forward_kernel<FIN, FOUT>), lds_bytes));
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_fwd): %s", hipGetErrorString(e));
+  }
+  prof_begin(PK_FUSED_FWD, s);
+  hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT>), dim3(count), dim3(spec::NT), lds_bytes, s, a, first);
+  prof_end(s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_forward launch: %s", hipGetErrorString(e));
+  return AGCN_OK;
+}
+
+int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream) {
+  if (count <= 0) return AGCN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.Fin == 75 && a.Fout == 64) return launch_spec_forward_t<75, 64>(a, first, count, lds_bytes, s);
+  if (a.Fin == 64 && a.Fout == 128) return launch_spec_forward_t<64, 128>(a, first, count, lds_bytes, s);
+  if (a.Fin == 128 && a.Fout == 128) return launch_spec_forward_t<128, 128>(a, first, count, lds_bytes, s);
+  if (a.Fin == 128 && a.Fout == 64) return launch_spec_forward_t<128, 64>(a, first, count, lds_bytes, s);
+  if (a.Fin == 64 && a.Fout == 64) return launch_spec_forward_t<64, 64>(a, first, count, lds_bytes, s);
+  return fail(AGCN_EINVAL, "spec_forward: unsupported layer shape %d -> %d", a.Fin, a.Fout);
+}
+
+}  // namespace agcn

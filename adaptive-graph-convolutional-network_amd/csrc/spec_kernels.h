@@ -1,0 +1,145 @@
+// Shared pieces of the shape-specialised fused kernels (spec_forward.hip / spec_backward.hip).
+//
+// Why these exist (measured, profiles/README.md r02): the per-graph kernels are bound by instruction ISSUE, not by
+// memory or the matrix cores -- a SIMD retires about one wave-instruction per cycle whatever the number of resident
+// waves, and with fully runtime-parameterised shapes most of those instructions are index arithmetic and the precise
+// sqrtf / expf sequences.  So the layer shapes that matter (SimpleAGCN's 75->64, 64->128, 128->128, 128->64, and
+// 64->64) get kernels in which the feature widths are template constants (strides and k-loops fold into immediates
+// and unrolled MFMA chains), the parameter fragments of the MFMA B operand are streamed from L2 into registers one
+// tile ahead, the pairwise-distance loop uses packed fp32 math (a v_pk_fma_f32 costs one issue slot like a
+// v_fma_f32), and sqrt / exp use the hardware instructions directly.
+#ifndef AGCN_SPEC_KERNELS_H_
+#define AGCN_SPEC_KERNELS_H_
+
+#include "agcn_device.h"
+#include "sgc_kernels.h"
+
+namespace agcn {
+namespace spec {
+
+// One wave issues at most one vector instruction every ~5.5 cycles on gfx950 (tools/ubench/valu_rate.hip: v_fma_f32,
+// v_pk_fma_f32, v_sub_f32 and v_add_u32 alike, independent operands), and a SIMD only approaches its issue rate
+// (~1.4 cycles per instruction) with four resident waves.  With one graph per CU, latency is therefore
+// (instructions of the busiest wave) x 5.5 cycles: the graph is spread over the largest workgroup there is.
+constexpr int NT = 1024;  // threads per workgroup
+constexpr int NW = 16;    // waves per workgroup
+
+template <int FIN>
+struct Feat {
+  static constexpr int F4 = (FIN + 15) & ~15;   // 16-padded feature count (MFMA k / n extent)
+  static constexpr int LDX = F4 + 2;            // row stride of the node-feature images: A-fragment reads conflict-free
+  static constexpr int NCB = F4 / 16;           // 16-column blocks over the features
+  static constexpr int NKS = (FIN + 3) / 4;     // MFMA k-steps over the features
+  static constexpr int CP = (F4 + 63) / 64;     // passes of 64 lanes over a feature row
+};
+
+// LDS plan of the forward kernel for a graph of n nodes (floats; every offset a multiple of 4).
+struct FwdLds {
+  int n4, ldt, ldz;
+  int o_s, o_tile, o_x, o_z, total;
+};
+AGCN_HD inline FwdLds fwd_lds(int n, int F4) {
+  FwdLds d;
+  d.n4 = (n + 15) & ~15;
+  d.ldt = d.n4 + 2;    // n x n tile read as an MFMA A operand: ld mod 16 == 2
+  d.ldz = d.n4 + 4;    // Z^T rows: 16-byte aligned for the b128 accumulator stores
+  const int ldx = F4 + 2;
+  d.o_s = 32;
+  d.o_tile = d.o_s + d.n4;
+  d.o_x = d.o_tile + d.n4 * d.ldt;
+  d.o_z = d.o_x + d.n4 * ldx;
+  const int zt = F4 * d.ldz, x1 = d.n4 * ldx;
+  d.total = d.o_z + (zt > x1 ? zt : x1);
+  return d;
+}
+
+// LDS plan of the backward kernel.
+struct BwdLds {
+  int n4, ldt, ldg;
+  int o_s, o_dd, o_rs, o_tile, o_dx, o_g1, o_u, total;   // o_u: Gp image, later X_0 image, later dZ image
+};
+AGCN_HD inline BwdLds bwd_lds(int n, int F4, int O4) {
+  BwdLds d;
+  d.n4 = (n + 15) & ~15;
+  d.ldt = d.n4 + 2;
+  d.ldg = O4 + 2;
+  const int ldx = F4 + 2;
+  d.o_s = 32;
+  d.o_dd = d.o_s + d.n4;
+  d.o_rs = d.o_dd + d.n4;
+  d.o_tile = d.o_rs + d.n4;
+  d.o_dx = d.o_tile + d.n4 * d.ldt;
+  d.o_g1 = d.o_dx + d.n4 * ldx;
+  d.o_u = d.o_g1 + d.n4 * ldx;
+  const int gp = d.n4 * d.ldg, x0 = d.n4 * ldx;
+  d.total = d.o_u + (gp > x0 ? gp : x0);
+  return d;
+}
+
+#if defined(__HIPCC__)
+// exp(-r) and sqrt on the hardware transcendental instructions (1 ulp each; exp(-r) = exp2(-r log2 e) carries a
+// relative error of about r * 6e-8 from the rounded product -- far inside the 1e-5 bar).  The
+// precise library sequences are ~45 instructions per pair, which is what the similarity phase was made of.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_exp_neg(float r) { return __builtin_amdgcn_exp2f(r * -1.44269504088896341f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// LDS-only workgroup barrier: global stores issued before it need not have completed.
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+
+// wave-uniform value -> SGPR
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct GraphRec { int b, n, row0; uint32_t toff, npad; };
+// one 32-byte record per schedule position (plan.cpp); tile offsets fit 32 bits on this path (checked by the launcher)
+__device__ __forceinline__ GraphRec load_graph(const AgcnGraphDesc* gd) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(gd);
+  const f32x4 g0 = p[0], g1 = p[1];
+  GraphRec g;
+  g.b = uni(__float_as_int(g0[0]));
+  g.n = uni(__float_as_int(g0[1]));
+  g.row0 = uni(__float_as_int(g0[2]));
+  g.toff = (uint32_t)uni(__float_as_int(g1[0]));
+  g.npad = (uint32_t)uni(__float_as_int(g1[2])) - g.toff - (uint32_t)(g.n * g.n);
+  return g;
+}
+
+// Enumerates the 2x2 blocks (bi <= bj) of the upper triangle of an nb2 x nb2 block grid without idle iterations
+// (rows r and nb2-1-r folded into one strip of nb2+1 entries, as TriFold in agcn_device.h), with the strip division
+// done by a 19-bit magic number from the hardware reciprocal: exact for t < 2^12 and strip widths < 2^7
+// (n <= 128 nodes), and no 64-bit division in the kernel prologue.
+struct TriFold19 {
+  int nb2, W, cnt;
+  uint32_t m;
+  __device__ explicit TriFold19(int nb2_) : nb2(nb2_), W(nb2_ + 1), cnt(((nb2_ + 1) >> 1) * (nb2_ + 1)) {
+    m = (uint32_t)(524288.0f * __builtin_amdgcn_rcpf((float)W)) + 1u;
+  }
+  __device__ __forceinline__ bool get(int t, int& bi, int& bj) const {
+    const int rr = (int)(((uint32_t)t * m) >> 19), c = t - rr * W;
+    if (c < nb2 - rr) { bi = rr; bj = rr + c; return true; }
+    const int r2 = nb2 - 1 - rr;
+    if (r2 == rr) return false;   // middle row of an odd grid is covered by the first branch
+    bi = r2; bj = r2 + (c - (nb2 - rr));
+    return true;
+  }
+};
+
+// contiguous, balanced share of T tiles for wave w of NW
+__device__ __forceinline__ void tile_range(int T, int w, int& t0, int& t1) {
+  const int base = T / NW, rem = T - base * NW;
+  t0 = w * base + min(w, rem);
+  t1 = t0 + base + (w < rem ? 1 : 0);
+}
+#endif
+
+}  // namespace spec
+
+// host-side entry points (agcn_api.hip)
+bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant);
+size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout);
+size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout);
+int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
+int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
+
+}  // namespace agcn
+#endif  // AGCN_SPEC_KERNELS_H_

@@ -37,7 +37,7 @@ class SgcLLStep(object):
         self.Y = torch.zeros((plan.rows, ldy), **f32)
         self.res_L = torch.zeros(plan.tile_elems, **f32)
         self.res_W = torch.zeros(plan.tile_elems, **f32)
-        self.L_sum = torch.zeros(plan.tile_elems, **f32)
+        self.L_sum = torch.zeros(plan.tile_elems, **f32) if reslap else None   # SGC_LL has three outputs
         self.dY = dY if dY is not None else torch.zeros((plan.rows, ldy), **f32)
         self.dL_sum = dL_sum
         self.dX = torch.zeros_like(self.X)
@@ -64,8 +64,7 @@ class SgcLLStep(object):
         self.gb = _gbatch(batch, self.X, self.L_prev)
         self.pr = _ffi.Params(v["weight"].data_ptr(), v["bias"].data_ptr(), v["M_L"].data_ptr(),
                               v["alpha"].data_ptr(), _ptr(v.get("beta")))
-        self.out = _ffi.Outputs(self.Y.data_ptr(), self.res_L.data_ptr(), self.res_W.data_ptr(),
-                                self.L_sum.data_ptr())
+        self.out = _ffi.Outputs(self.Y.data_ptr(), self.res_L.data_ptr(), self.res_W.data_ptr(), _ptr(self.L_sum))
         g = self.grads
         self.gr = _ffi.Grads(self.dX.data_ptr(), g["weight"].data_ptr(), g["bias"].data_ptr(),
                              _ptr(g.get("M_L")), g["alpha"].data_ptr(), _ptr(g.get("beta")), _ptr(self.dL_prev))

@@ -98,11 +98,14 @@ class UnpackRowsFunction(torch.autograd.Function):
 
 
 class _Cfg(object):
-    __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation")
+    __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation", "lsum")
 
-    def __init__(self, Fin, Fout, K, mode, variant, activation):
+    def __init__(self, Fin, Fout, K, mode, variant, activation, lsum=True):
         self.Fin, self.Fout, self.K = int(Fin), int(Fout), int(K)
         self.mode, self.variant, self.activation = mode, variant, activation
+        # lsum=False: an SGC_LL call whose combined Laplacian nobody reads (the reference's SGC_LL returns three
+        # outputs, graphconv.py:252) -- the L_sum tile is then neither allocated nor written
+        self.lsum = bool(lsum) or variant == "SGC_LL_Reslap"
 
 
 def _desc(cfg, ldx, ldy):
@@ -120,7 +123,11 @@ def _gbatch(batch, X, L_prev):
 def _sizes(plan, cfg, ldx, ldy):
     """(desc, reserve bytes, forward workspace bytes, backward workspace bytes) of a layer on a plan: three host-side
     FFI calls, cached on the plan (a plan is immutable)."""
-    key = (cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, int(ldx), int(ldy))
+    lib = _ffi.lib()
+    # the library's process-wide dispatch knobs change which kernels (and so which workspaces) a call takes
+    knobs = (lib.agcn_get_lds_limit(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(),
+             lib.agcn_get_fused_global_b(), lib.agcn_get_param_grad_onepass(), lib.agcn_get_spec_mode())
+    key = (cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, int(ldx), int(ldy)) + knobs
     cache = plan.__dict__.setdefault("_size_cache", {})
     hit = cache.get(key)
     if hit is None:
@@ -161,13 +168,13 @@ class SgcLLFunction(torch.autograd.Function):
         Y = torch.empty((plan.rows, ldy), dtype=torch.float32, device=dev)
         res_L = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
-        L_sum = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
+        L_sum = torch.empty(plan.tile_elems if cfg.lsum else 0, dtype=torch.float32, device=dev)
         desc, rbytes, wbytes, _ = _sizes(plan, cfg, ldx, ldy)
         reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         gb = _gbatch(batch, X, L_prev if reslap else None)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
-        out = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr())
+        out = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(out),
                                            reserve.data_ptr(), rbytes, ws.data_ptr(), wbytes, _stream(dev)))
         ctx.batch, ctx.cfg, ctx.has_prev, ctx.has_beta = batch, cfg, (reslap and L_prev is not None), beta is not None
@@ -203,7 +210,7 @@ class SgcLLFunction(torch.autograd.Function):
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         gb = _gbatch(batch, X, L_prev)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
-        fw = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr())
+        fw = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         gr = _ffi.Grads(dX.data_ptr(), dweight.data_ptr(), dbias.data_ptr(), _ptr(dM), dalpha.data_ptr(),
                         _ptr(dbeta), _ptr(dLp))
         _ffi.check(lib.agcn_sgc_ll_backward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(fw),

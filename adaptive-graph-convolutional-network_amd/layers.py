@@ -183,7 +183,7 @@ class SGC_LL(Layer):
         gb, X = _resolve_batch(x)
         self.build(X.device)
         cfg = _Cfg(self.n_atom_feature, self.nb_filter, self.K, self.laplacian_mode, self._variant,
-                   "relu" if self.activation == "relu" else "linear")
+                   "relu" if self.activation == "relu" else "linear", lsum=self._variant == "SGC_LL_Reslap")
         if gb.plan.B != self.batch_size:
             raise ValueError("batch holds %d graphs, layer was built for batch_size=%d" % (gb.plan.B, self.batch_size))
         v = self.vars

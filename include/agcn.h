@@ -366,6 +366,12 @@ void agcn_set_fused_global_b(int32_t mode);
  * order); 0: partial + reduce launches.  Both bit-reproducible. */
 int32_t agcn_get_param_grad_onepass(void);
 void agcn_set_param_grad_onepass(int32_t on);
+/* Shape-specialised fused kernels (csrc/spec_*.hip: SGC_LL, K = 2, layer widths 75->64, 64->128, 128->128, 128->64,
+ * 64->64; 512-thread workgroups, feature widths compiled in).  1 (default): used wherever the fused path would be
+ * taken and the shape is covered; 0: always the general fused kernels.  Bit 0 = forward, bit 1 = backward
+ * (3 = both, the default).  Same results within the last few ulps (hardware sqrt / exp2 in the similarity phase). */
+int32_t agcn_get_spec_mode(void);
+void agcn_set_spec_mode(int32_t mode);
 
 #ifdef __cplusplus
 }

@@ -322,9 +322,14 @@ def backward_graph(c, G, p, K, mode=REFERENCE, variant=SGC_LL, dLa_extra=None):
         dA = -dR                                   # A_ij = s_i S_ij s_j
         ds = (dA * S * s[None, :]).sum(axis=1, dtype=x.dtype) + \
              (dA * S * s[:, None]).sum(axis=0, dtype=x.dtype)
-        dd = dt(-0.5) * s * s * s * ds             # s = d^-1/2  =>  ds/dd = -1/2 d^-3/2
+        # s = d^-1/2  =>  ds/dd = -1/2 d^-3/2.  A node whose similarities all underflow has d = spacing(0),
+        # s^3 = inf and ds = 0: it is cut out of the degree gradient (dd = 0) instead of producing inf * 0 = NaN
+        with np.errstate(over="ignore", invalid="ignore"):
+            s3 = s * s * s
+            dd = np.where(np.isfinite(s3) & (ds != 0), dt(-0.5) * s3 * ds, dt(0)).astype(x.dtype)
         dS = dA * s[:, None] * s[None, :] + dd[None, :]    # d_j = sum_i S_ij
-        dr = -S * dS                               # S = exp(-r); diagonal has S = 0
+        with np.errstate(over="ignore", invalid="ignore"):
+            dr = np.where(S == 0, dt(0), -S * dS).astype(x.dtype)   # S = exp(-r); S == 0 (diagonal, underflow): 0, never inf * 0
         with np.errstate(divide="ignore", invalid="ignore"):
             cij = np.where(r > 0, (dr + dr.T) / r, dt(0)).astype(x.dtype)
         np.fill_diagonal(cij, 0)

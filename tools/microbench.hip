@@ -13,6 +13,7 @@ __global__ __launch_bounds__(1024) void probe(const float* __restrict__ buf, int
   const int tid = threadIdx.x, nthr = blockDim.x;
   unsigned long long t[12];
   int k = 0;
+  const unsigned long long c0 = clock64();
   float acc = 0.f;
   t[k++] = wall_clock64();
   // 1. one dependent global load per thread (distinct lines), then barrier
@@ -65,7 +66,12 @@ __global__ __launch_bounds__(1024) void probe(const float* __restrict__ buf, int
   out[blockIdx.x * nthr + tid] = acc;
   __syncthreads();
   t[k++] = wall_clock64();
-  if (tid == 0) for (int i = 0; i < k; ++i) stamps[blockIdx.x * 12 + i] = t[i];
+  const unsigned long long c1 = clock64();
+  if (tid == 0) {
+    for (int i = 0; i < k; ++i) stamps[blockIdx.x * 12 + i] = t[i];
+    stamps[blockIdx.x * 12 + 10] = c1 - c0;                 // shader-clock ticks over the kernel
+    stamps[blockIdx.x * 12 + 11] = t[k - 1] - t[0];         // 100 MHz ticks over the same span
+  }
 }
 
 int main() {
@@ -79,16 +85,19 @@ int main() {
   const char* names[] = {"1 global load + barrier", "dependent 2nd load + barrier", "8 indep loads + barrier",
                          "10 bare barriers", "lds wr + barrier + 64 dep lds reads + barrier", "16x(sqrt+exp) + barrier",
                          "300 dep fma + barrier", "global store + barrier"};
-  for (int cfg = 0; cfg < 4; ++cfg) {
+  for (int cfg = 0; cfg < 8; ++cfg) {
     const int blocks = (cfg & 1) ? 256 : 1;
     const int threads = (cfg & 2) ? 1024 : 256;
-    for (int rep = 0; rep < 3; ++rep) {
+    const int burst = (cfg & 4) ? 20000 : 3;   // back-to-back launches before the measured one (clock ramp)
+    for (int rep = 0; rep < burst; ++rep) {
       hipLaunchKernelGGL(probe, dim3(blocks), dim3(threads), 4096 * 4, 0, buf, n, out, st, 0);
-      CHECK(hipDeviceSynchronize());
+      if (burst <= 3) CHECK(hipDeviceSynchronize());
     }
+    CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(blocks * 12);
     CHECK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    printf("blocks=%d threads=%d (median over blocks, us):\n", blocks, threads);
+    printf("blocks=%d threads=%d burst=%d  shader clock over the kernel: %.0f MHz (median over blocks, us):\n", blocks, threads, burst,
+           100.0 * (double)h[10] / (double)h[11]);
     for (int p = 0; p < 8; ++p) {
       std::vector<double> d;
       for (int b = 0; b < blocks; ++b) d.push_back((double)(h[b * 12 + p + 1] - h[b * 12 + p]) / 100.0);

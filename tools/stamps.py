@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "lib", "libagcn_hip_stamps.so")
 
 def build():
     src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.cpp")))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17",
            "-DAGCN_STAMPS", "-fgpu-rdc", "-o", LIB] + src
     subprocess.check_call(cmd)
 
@@ -61,6 +61,7 @@ def main():
             continue
         t0 = blk[used, 0].min()
         cols = [c for c in range(16) if (blk[used, c] > 0).any()]
+        cols = sorted(cols, key=lambda c: np.median(blk[used, c]))
         last = max(cols)
         print("%-12s blocks %4d  span %.2f us (first start -> last end)" % (nm, used.sum(), (blk[used, last].max() - t0) / 100.0))
         rel = (blk[used][:, cols] - t0) / 100.0
