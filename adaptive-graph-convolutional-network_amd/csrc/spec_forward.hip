@@ -371,7 +371,7 @@ static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count,
         ensure_dynamic_lds(reinterpret_cast<const void*>(&spec::spec_forward_kernel<FIN, FOUT>), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_fwd): %s", hipGetErrorString(e));
   }
-  prof_begin(PK_FUSED_FWD, s);
+  prof_begin(PK_SPEC_FWD, s);
   hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT>), dim3(count), dim3(spec::NT), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();

@@ -90,15 +90,36 @@ class SgcLLStep(object):
         self.forward()
         self.backward()
 
-    def capture(self):
-        """Capture forward + backward into a HIP graph (torch.cuda.CUDAGraph on ROCm)."""
+    def capture(self, extra=None):
+        """Capture forward + backward into a HIP graph (torch.cuda.CUDAGraph on ROCm).  `extra`, if given, is
+        called behind the step inside the capture (e.g. the RCCL all-reduce of `self.bucket`, so that a
+        data-parallel step is still one graph replay)."""
         self.step()                      # warm-up outside capture (sets function attributes)
+        if extra is not None:
+            extra()
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.step()
+            if extra is not None:
+                extra()
         self._graph = g
         return g
+
+    def kernel_names(self):
+        """Names of the kernels one forward / per-graph backward / parameter-gradient call launches on this
+        batch (three strings), found by running each once under the library's launch profiler."""
+        out = []
+        for fn in (self.forward, lambda: self.backward(1), lambda: self.backward(2)):
+            torch.cuda.synchronize(self.device)
+            self.lib.agcn_profile_enable(1)
+            try:
+                fn()
+                prof = _ffi.profile_collect()
+            finally:
+                self.lib.agcn_profile_enable(0)
+            out.append("+".join(k for k, (ms, c) in prof.items() if c > 0))
+        return out
 
     def replay(self):
         self._graph.replay()

@@ -9,7 +9,7 @@ uses ALL host cores ("CPU-vec", `torch.set_num_threads(os.cpu_count())`).  This 
 ragged batch is zero-padded to [B, n_max, .] and every stage is a batched torch op (bmm / broadcast),
 forward by the formulas of `agcn_oracle.forward_graph` (graphconv.py:163-251), backward by torch
 autograd with the same conventions (d||.||/dz := 0 at r == 0; TF relu gradient 0 at 0).
-It is checked against the per-graph numpy oracle in `tests/test_oracle_golden.py`.
+It is checked against the per-graph numpy oracle in `tests/test_oracle_vec.py`.
 """
 import numpy as np
 import torch
@@ -64,7 +64,8 @@ def forward(bt, p, K, mode):
     I = eye * pair
     if mode == PAPER:
         d = S.sum(1) + float(np.spacing(np.float32(0)))          # :195-196 (column sums)
-        s = torch.where(mask > 0, 1.0 / torch.sqrt(d), torch.zeros_like(d))
+        # (padded nodes: a finite stand-in inside the untaken branch keeps autograd free of 0 * inf)
+        s = torch.where(mask > 0, 1.0 / torch.sqrt(torch.where(mask > 0, d, torch.ones_like(d))), torch.zeros_like(d))
         R = I - (s[:, :, None] * S) * s[:, None, :]
     else:
         R = I                                                    # elementwise D*W*D == 0 (:198-200)

@@ -1,0 +1,74 @@
+"""Data parallelism on real GPUs: N ranks, each with its LPT shard of one global batch, run the real SgcLLStep
+and all-reduce the flat gradient bucket; the result must equal the single-rank run of the whole batch (1e-6).
+  * rccl: one GPU per rank over RCCL -- needs >= 2 GPUs, skipped otherwise;
+  * gloo_shared: two ranks sharing cuda:0 over gloo -- the same code path end to end on a one-GPU box.
+Also: `bench.py --gpus 2` must start its own ranks and report what the process group says."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(backend, shared, world, out):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), backend,
+                                       "1" if shared else "0", out], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+
+
+@pytest.mark.parametrize("flavour", ["gloo_shared", "rccl"])
+def test_dp_step_matches_single_rank(flavour, tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = 2
+    if flavour == "rccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL data-parallel test needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    out = str(tmp_path / "rank0.npz")
+    _run_ranks("nccl" if flavour == "rccl" else "gloo", flavour == "gloo_shared", world, out)
+    got = np.load(out)
+    assert int(got["ranks"]) == world
+    import dist_worker
+    Fin, Fout, K, data, p, G = dist_worker.global_batch()
+    ref = dist_worker.run_shard(np.arange(len(data["n"])), torch.device("cuda", 0))
+    want = ref.bucket.cpu().numpy()
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got["bucket"], want, rtol=1e-6, atol=1e-6 * scale)
+    # every section of the bucket carries signal (dweight | dbias | dM_L | dalpha)
+    for k, g in ref.grads.items():
+        assert float(g.abs().max()) > 0, k
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset) must spawn two ranks and print n_gpus == 2."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["AGCN_BENCH_SELFTEST"] = "1"     # two ranks share cuda:0 over gloo
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline", "--skip-other-mode"], env=env, stdout=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["value"] > 0
