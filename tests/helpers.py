@@ -7,13 +7,23 @@ import torch
 import agcn_oracle as orc
 from conftest import GOLDEN
 
-# Parity tolerance on fp32 features, as stated by BASELINE.json north_star: 1e-5 relative.
-# "Relative" is measured against the largest magnitude of the expected tensor (the tensors
-# contain exact zeros, e.g. relu outputs and pad rows).
+# Parity tolerances.  BASELINE.json north_star: "within 1e-5 rel fp32 on features".  The check is ELEMENT-WISE:
+#     |got - want| <= rtol * |want| + atol_ulps * eps_f32 * scale,   scale[i, j] = max(rowmax_i |want|, colmax_j |want|)
+# rtol is the stated bar (1e-5 on features, 2e-5 on gradients, which reduce over all nodes of the batch in a different
+# fixed order than numpy).  The absolute term exists because the outputs are dot products with cancellation: an
+# element that cancels to ~0 cannot be relatively exact in fp32 -- its error is a few ulp of the TERMS, whose size
+# the largest entry of the element's row or column stands for (row alone fails for one-column outputs such as
+# Fout = 1, where the "row" is the cancelling element itself).  The allowance is calibrated on fp32 arithmetic itself (this oracle run in float32
+# against its float64 run on the test cases: Y <= 5 ulp of the row max, dX / dweight <= 5, dM_L <= 8, and the
+# degenerate Fin = 1 case 17 ulp on dM_L, 120 on dX): 16 ulp for features, 32 for gradients.
+# Tile outputs (res_W, res_L) are products / exponentials without cancellation: pure relative (atol_ulps = 0; values
+# below the smallest normal float may be flushed).
 FEATURE_RTOL = 1e-5
-# Gradients reduce over all nodes of the batch in a different (fixed) order than numpy;
-# 2e-5 relative to the largest expected magnitude.
 GRAD_RTOL = 2e-5
+FEATURE_ULPS = 16
+GRAD_ULPS = 32
+EPS32 = float(np.finfo(np.float32).eps)
+TINY32 = float(np.finfo(np.float32).tiny)
 
 
 def load_golden(name):
@@ -21,19 +31,40 @@ def load_golden(name):
 
 
 def rel_err(a, b):
+    """max |a - b| / max |b| (tensor-level figure, used for reporting only)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     den = max(float(np.abs(b).max()) if b.size else 0.0, 1e-30)
     return float(np.abs(a - b).max() / den) if b.size else 0.0
 
 
-def assert_close(a, b, rtol, what):
+def assert_close(a, b, rtol, what, atol_ulps=None):
+    """Element-wise: |a - b| <= rtol |b| + atol_ulps eps scale (+ the flush-to-zero range), scale = the largest
+    |b| in the element's row (last axis) or column (axis -2); whole-vector max for 1-D.  atol_ulps defaults to
+    FEATURE_ULPS for rtol <= FEATURE_RTOL and GRAD_ULPS otherwise."""
     a = np.asarray(a)
     b = np.asarray(b)
     assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
     assert np.all(np.isfinite(a)), "%s: non-finite values" % what
-    e = rel_err(a, b)
-    assert e <= rtol, "%s: relative error %.3e > %.1e" % (what, e, rtol)
+    assert np.all(np.isfinite(b)), "%s: non-finite values in the expected tensor" % what
+    if b.size == 0:
+        return
+    if atol_ulps is None:
+        atol_ulps = FEATURE_ULPS if rtol <= FEATURE_RTOL else GRAD_ULPS * max(1.0, rtol / GRAD_RTOL)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    if b64.ndim > 1:
+        scale = np.maximum(np.abs(b64).max(axis=-1, keepdims=True), np.abs(b64).max(axis=-2, keepdims=True))
+    else:
+        scale = np.abs(b64).max()
+    bound = rtol * np.abs(b64) + atol_ulps * EPS32 * scale + TINY32
+    err = np.abs(a64 - b64)
+    bad = err > bound
+    if bad.any():
+        k = np.unravel_index(np.argmax(err / bound), err.shape)
+        raise AssertionError("%s: %d of %d elements outside rtol %.1e + %g ulp of the row/column max; worst at %s: got %.9g, "
+                             "want %.9g (|d| = %.3e = %.1f x the bound; rel to tensor max %.2e)"
+                             % (what, int(bad.sum()), b.size, rtol, atol_ulps, k, a64[k], b64[k], err[k],
+                                float(err[k] / bound[k]), rel_err(a, b)))
 
 
 def golden_params(g, prefix):
@@ -147,8 +178,8 @@ def compare_with_oracle(out, caches, tot, variant, mode, K, has_prev):
     B = len(caches)
     assert_close(np.concatenate(out["Y"]), np.concatenate([c["Y"] for c in caches]), FEATURE_RTOL, "Y")
     for b in range(B):
-        assert_close(out["res_W"][b], caches[b]["S"], FEATURE_RTOL, "res_W[%d]" % b)
-        assert_close(out["res_L"][b], caches[b]["R2"], FEATURE_RTOL, "res_L[%d]" % b)
+        assert_close(out["res_W"][b], caches[b]["S"], FEATURE_RTOL, "res_W[%d]" % b, atol_ulps=0)
+        assert_close(out["res_L"][b], caches[b]["R2"], FEATURE_RTOL, "res_L[%d]" % b, atol_ulps=0)
         if variant == orc.SGC_LL_RESLAP:
             assert_close(out["L_sum"][b], caches[b]["La"], FEATURE_RTOL, "L_sum[%d]" % b)
     assert_close(np.concatenate(out["dX"]), np.concatenate(tot["dX"]), GRAD_RTOL, "dX")

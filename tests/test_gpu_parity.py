@@ -9,7 +9,7 @@ import torch
 
 import agcn_oracle as orc
 from conftest import GOLDEN
-from helpers import (FEATURE_RTOL, GRAD_RTOL, assert_close, compare_with_oracle, golden_params, load_golden,
+from helpers import (FEATURE_RTOL, FEATURE_ULPS, GRAD_RTOL, GRAD_ULPS, assert_close, compare_with_oracle, golden_params, load_golden,
                      make_layer, oracle_run, run_packed, synth_case, to_np)
 
 pytestmark = pytest.mark.gpu
@@ -200,7 +200,7 @@ def test_mixed_dispatch_full_batch(amd, fmode):
         b2 = run()
         for x, y, z in zip(ref, a, b2):
             assert torch.equal(y, z), "mixed dispatch must be reproducible"
-            assert_close(to_np(y), to_np(x), 5e-5, "mixed vs fused")
+            assert_close(to_np(y), to_np(x), 2 * GRAD_RTOL, "mixed vs fused", atol_ulps=2 * GRAD_ULPS)   # two fp32 runs
     finally:
         lib.agcn_set_lds_limit(160 * 1024)
         lib.agcn_set_fused_mode(1)
@@ -472,12 +472,12 @@ def test_sgc_ll_upstream_gradient_of_the_combined_laplacian(amd, path):
 def test_random_shapes_on_every_path(amd):
     """Randomised widths / graph sizes / variants / modes / leaky slopes / L_prev / upstream dL_sum, every kernel
     path (auto, fused with LDS parameter images, fused with parameters from global memory, slab, per-graph with the
-    tile in LDS or in global scratch) against the oracle in float64.  (tools/fuzz_paths.py runs more of them;
-    Fin = 1 is left to it: dM_L is then one cancelling sum and sits at 1-2e-4 relative.)"""
+    tile in LDS or in global scratch) against the oracle in float64, Fin = 1 (dM_L is then one cancelling sum)
+    included.  tools/fuzz_paths.py runs more of them."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_paths
-    assert fuzz_paths.run(60, 11, fin_choices=(3, 5, 16, 33, 64, 75, 128), verbose=False) == 0
+    assert fuzz_paths.run(60, 11, fin_choices=(1, 1, 3, 5, 16, 33, 64, 75, 128), verbose=False) == 0
 
 
 def test_hiv_shaped_epoch_properties(amd):
@@ -588,17 +588,37 @@ def test_full_size_properties(amd):
     _, _, _, dXp1, gp1 = run(orc.PAPER, G1)
     _, _, _, dXp2, gp2 = run(orc.PAPER, G2)
     _, _, _, dXp3, gp3 = run(orc.PAPER, G1 + G2)
-    assert_close(to_np(dXp3), to_np(dXp1 + dXp2), 5e-5, "linearity dX")
+    # (three fp32 runs are compared with each other: the allowance of one run against the truth, times three)
+    assert_close(to_np(dXp3), to_np(dXp1 + dXp2), 3 * GRAD_RTOL, "linearity dX", atol_ulps=3 * GRAD_ULPS)
     for a, b, c in zip(gp1[:3], gp2[:3], gp3[:3]):
-        assert_close(to_np(c), to_np(a + b), 5e-5, "linearity param grad")
-    # a sample of graphs against the oracle at full size
-    caches = orc.layer_forward([sb["X"][b] for b in (0, 100, 255)], [sb["L0"][b] for b in (0, 100, 255)],
-                               p, K, orc.PAPER, orc.SGC_LL)
-    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, orc.PAPER, p, DEV)
-    nodes, res_L, res_W = layer({"node_features": gb.X, "graph_batch": gb})
-    for c, b in zip(caches, (0, 100, 255)):
-        assert_close(to_np(nodes[b]), c["Y"], FEATURE_RTOL, "Y full-size")
-        assert_close(to_np(res_L[b]), c["R2"], FEATURE_RTOL, "res_L full-size")
+        assert_close(to_np(c), to_np(a + b), 3 * GRAD_RTOL, "linearity param grad", atol_ulps=3 * GRAD_ULPS)
+
+
+@pytest.mark.parametrize("B", [256, 2048], ids=["b256", "b2048"])
+@pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
+@pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc_ll", "reslap"])
+def test_full_size_every_graph_every_gradient(amd, variant, mode, B):
+    """BASELINE configs[1] and [3] at full size (Tox21-shaped B = 256 on one GPU; B = 2048 = the global batch of the
+    8-GPU config, whose graph sizes reach n = 95): EVERY graph's Y / res_W / res_L (/ L_sum) and EVERY gradient
+    (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) against the float64 oracle, both Laplacian modes, both layer
+    variants (Reslap with a previous Laplacian and an upstream dL_sum)."""
+    if B == 2048 and (variant == orc.SGC_LL_RESLAP or mode == orc.REFERENCE):
+        pytest.skip("the 2048-graph batch is run on the headline configuration (SGC_LL, paper mode)")
+    Fin, Fout, K = 75, 64, 2
+    sb = orc.synth_batch(123, B)
+    ns = [int(v) for v in sb["ns"]]
+    rs = np.random.RandomState(123)
+    p = orc.init_params(rs, Fin, Fout, K, variant)
+    p["alpha"] = np.array([0.8], np.float32)
+    G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
+    Lp = dLs = None
+    if variant == orc.SGC_LL_RESLAP:
+        p["beta"] = np.array([1.2], np.float32)
+        Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
+        dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
+    caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, variant, G, Lp, dLs)
+    out = run_packed(amd, DEV, ns, sb["X"], sb["csr"], p, G, Fin, Fout, K, mode, variant, Lp, dLs)
+    compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
 
 
 def test_errors_are_loud(amd):
@@ -854,14 +874,18 @@ def test_simple_agcn_stack_packed(amd):
         hs = [ci["Y"] for ci in c]
     hd = [orc.dense_mol_forward(x, Wd.astype(np.float64), bd.astype(np.float64)) for x in hs]
     o, pre = orc.graph_gather_forward(hd, "tanh")
-    assert_close(to_np(out), o, 5e-5, "stack output")
+    # six stages deep (4 x SGC_LL, DenseMol, GraphGatherMol): every stage is held to the per-layer bar elsewhere; here
+    # the rounding of each stage feeds the next, so the end-to-end bound is the per-layer one times the depth
+    # (5 x on the forward value, 10 x on gradients that also cross the six backward stages)
+    assert_close(to_np(out), o, 5 * FEATURE_RTOL, "stack output", atol_ulps=5 * FEATURE_ULPS)
     g = orc.graph_gather_backward(o, pre, Gout, ns, "tanh")
     g = [orc.dense_mol_backward(x, Wd.astype(np.float64), gi)[0] for x, gi in zip(hs, g)]
     for c, p in zip(caches[::-1], params[::-1]):
         tot = orc.layer_backward(c, g, f64(p), K, orc.PAPER, orc.SGC_LL)
         g = tot["dX"]
-    assert_close(to_np(Xt.grad), np.concatenate(g, 0), 2e-4, "stack dX")
-    assert_close(to_np(layers[0].vars["M_L"].grad), tot["dM_L"], 2e-4, "stack dM_L (layer 1)")
+    assert_close(to_np(Xt.grad), np.concatenate(g, 0), 10 * GRAD_RTOL, "stack dX", atol_ulps=10 * GRAD_ULPS)
+    assert_close(to_np(layers[0].vars["M_L"].grad), tot["dM_L"], 10 * GRAD_RTOL, "stack dM_L (layer 1)",
+                 atol_ulps=10 * GRAD_ULPS)
 
 
 @pytest.mark.parametrize("symmetric", [True, False], ids=["slab", "globaltile"])
@@ -888,14 +912,18 @@ def test_modelnet_shaped_dense_adjacency(amd, symmetric):
     Xt = gb.X.clone().requires_grad_(True)
     nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
     (nodes.data * torch.from_numpy(G).to(DEV)).sum().backward()
-    caches = orc.layer_forward([pts], [L32], p, K, orc.PAPER, orc.SGC_LL)
-    tot = orc.layer_backward(caches, [G], p, K, orc.PAPER, orc.SGC_LL)
+    caches, tot = oracle_run([pts], [L32], p, K, orc.PAPER, orc.SGC_LL, [G])      # float64 ground truth
     c = caches[0]
-    assert_close(to_np(nodes.data), c["Y"], 2e-5, "Y n=1024")
+    # Same relative bars as everywhere (1e-5 features, 2e-5 gradients).  The absolute allowance (ulps of the row /
+    # column max, helpers.assert_close) is scaled by sqrt(n / 64): every output here is, or depends on, sums over
+    # n = 1024 nodes (X_1 = L X_0, the degree, dM_L = X^T dZ), and the rounding error of an n-term fp32 sum grows like
+    # sqrt(n) eps; 64 nodes is the size the default allowance was calibrated on.
+    k = float(np.sqrt(n / 64.0))
+    assert_close(to_np(nodes.data), c["Y"], FEATURE_RTOL, "Y n=1024", atol_ulps=FEATURE_ULPS * k)
     w = to_np(res_W[0])
-    assert_close(w, c["S"], FEATURE_RTOL, "res_W n=1024")
+    assert_close(w, c["S"], FEATURE_RTOL, "res_W n=1024", atol_ulps=0)
     assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
-    assert_close(to_np(res_L[0]), c["R2"], 2e-5, "res_L n=1024")
-    assert_close(to_np(Xt.grad), tot["dX"][0], 1e-4, "dX n=1024")
-    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], 1e-4, "dweight n=1024")
-    assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], 2e-4, "dM_L n=1024")
+    assert_close(to_np(res_L[0]), c["R2"], FEATURE_RTOL, "res_L n=1024", atol_ulps=FEATURE_ULPS * k)
+    assert_close(to_np(Xt.grad), tot["dX"][0], GRAD_RTOL, "dX n=1024", atol_ulps=GRAD_ULPS * k)
+    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight n=1024", atol_ulps=GRAD_ULPS * k)
+    assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L n=1024", atol_ulps=GRAD_ULPS * k)
