@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import load_reference  # noqa: E402
 import agcn_oracle as orc  # noqa: E402  (only for the synthetic topology / feature generators)
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("AGCN_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # (override: the regeneration test)
 
 
 def _graphs(rs, ns, Fin, gs, atoms):
