@@ -9,6 +9,8 @@ from .batch import GraphBatch, Plan, RowViews, TileViews  # noqa: F401
 from .graph_structure import Graph, MolGraph, laplacian_csr  # noqa: F401
 from .layers import (SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, DenseBlockEnd, GraphPoolMol,  # noqa: F401
                      MultitaskHead, Layer)
+from .graphs import (SequentialGraphMol, ResidualGraphMol, ResidualGraphMolResLap, DenseConnectedGraph,  # noqa: F401
+                     DenseConnectedGraphResLap)
 from .store import GraphStore  # noqa: F401
 from .engine import GraphedStep, SgcLLStep  # noqa: F401
 from . import dist  # noqa: F401

@@ -1,0 +1,176 @@
+"""The graph containers (agcn_amd/graphs.py; reference models/tf_modules/tf_graphs.py): layer lists written the way
+the reference's networks write them (basic_AGCN.py:17-49, ResAGCN.py:13-57, DenseAGCN.py:13-85) run through `add()`
+and give the same results as calling the layers by hand with the reference's input dicts."""
+import numpy as np
+import pytest
+import torch
+
+import agcn_oracle as orc
+from helpers import (FEATURE_RTOL, FEATURE_ULPS, assert_close, golden_params, load_golden, make_layer, synth_case, to_np)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import agcn_amd
+    return agcn_amd
+
+
+def _batch(amd, seed=71, ns=(9, 17, 5, 24, 12), Fin=75):
+    rs, X, L0, csr, _, _ = synth_case(seed, list(ns), Fin, 8, 2, orc.SGC_LL, atoms=True)
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+    return rs, X, L0, gb
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)      # (parameters are drawn on the host, then moved)
+
+
+def test_dispatch_is_by_class_name_and_order_is_checked(amd):
+    m = amd.SequentialGraphMol(75, batch_size=5, max_atom=24)
+    m.add(amd.SGC_LL(8, 75, 5, device=DEV))
+    m.add(amd.GraphGatherMol(5, activation="tanh"))
+    with pytest.raises(AssertionError, match="after a GraphGather"):
+        m.add(amd.SGC_LL(8, 8, 5, device=DEV))
+    assert [type(l).__name__ for l in m.layers] == ["SGC_LL", "GraphGatherMol"]
+
+
+def test_simple_agcn_layer_list(amd):
+    """SimpleAGCN (basic_AGCN.py:33-47) through SequentialGraphMol == the same layers called by hand."""
+    rs, X, L0, gb = _batch(amd)
+    B, K, widths = gb.plan.B, 2, [16, 24, 24, 16]
+    model = amd.SequentialGraphMol(75, B, 24)
+    fin = 75
+    for i, w in enumerate(widths):
+        model.add(amd.SGC_LL(w, fin, B, K=K, activation="relu", laplacian_mode="paper", device=DEV, generator=_gen(i)))
+        fin = w
+    model.add(amd.DenseMol(32, fin, activation="relu", device=DEV, generator=_gen(10)))
+    model.add(amd.GraphGatherMol(B, activation="tanh"))
+    out = model(gb)
+    assert tuple(out.shape) == (B, 32)
+    assert len(model.get_resL_set()) == 4 * B and len(model.get_resW_set()) == 4 * B   # every graph of every SGC layer
+    # by hand, reference-style dicts
+    h = gb.X
+    for lay in model.layers[:4]:
+        h, _, _ = lay({"node_features": h, "graph_batch": gb})
+    h = model.layers[4]({"node_features": h, "graph_batch": gb})
+    ref = model.layers[5]({"node_features": h, "graph_batch": gb})
+    assert torch.equal(out, ref)
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_res_agcn_layer_list(amd):
+    """ResAGCN (ResAGCN.py:31-55): two blocks of two SGC_LL + BlockEnd, against the oracle composed the same way."""
+    rs, X, L0, gb = _batch(amd, seed=72)
+    B, K, w = gb.plan.B, 2, [16, 24, 24, 16]
+    model = amd.ResidualGraphMol(75, B, 24)
+    model.add(amd.SGC_LL(w[0], 75, B, K=K, activation="relu", laplacian_mode="paper", device=DEV, generator=_gen(1)))
+    model.add(amd.SGC_LL(w[1], w[0], B, K=K, activation="relu", laplacian_mode="paper", device=DEV, generator=_gen(2)))
+    model.add(amd.BlockEnd(1, w[0], w[1], "relu", 24, B, device=DEV, generator=_gen(3)))
+    model.add(amd.SGC_LL(w[2], w[1], B, K=K, activation="relu", laplacian_mode="paper", device=DEV, generator=_gen(4)))
+    model.add(amd.SGC_LL(w[3], w[2], B, K=K, activation="relu", laplacian_mode="paper", device=DEV, generator=_gen(5)))
+    model.add(amd.BlockEnd(2, w[2], w[3], "relu", 24, B, device=DEV, generator=_gen(6)))
+    model.add(amd.DenseMol(32, w[3], activation="relu", device=DEV, generator=_gen(7)))
+    model.add(amd.GraphGatherMol(B, activation="tanh"))
+    out = model(gb)
+    assert len(model.block_outputs) == 3          # first SGC_LL output + two block ends (tf_graphs.py:126-143)
+
+    f64 = lambda t: to_np(t).astype(np.float64)   # noqa: E731
+    L64 = [l.astype(np.float64) for l in L0]
+
+    def sgc(hs, lay):
+        p = {k: f64(v) for k, v in lay.vars.items()}
+        return [c["Y"] for c in orc.layer_forward(hs, L64, p, K, orc.PAPER, orc.SGC_LL)]
+
+    hs = [x.astype(np.float64) for x in X]
+    h1 = sgc(hs, model.layers[0])
+    h2 = sgc(h1, model.layers[1])
+    b1 = [orc.block_end_forward(a, r, f64(model.layers[2].vars["weight"]))[0] for a, r in zip(h2, h1)]
+    h3 = sgc(b1, model.layers[3])
+    h4 = sgc(h3, model.layers[4])
+    b2 = [orc.block_end_forward(a, r, f64(model.layers[5].vars["weight"]))[0] for a, r in zip(h4, b1)]
+    hd = [orc.dense_mol_forward(x, f64(model.layers[6].W), f64(model.layers[6].b)) for x in b2]
+    o, _ = orc.graph_gather_forward(hd, "tanh")
+    assert_close(to_np(out), o, 5 * FEATURE_RTOL, "ResAGCN output", atol_ulps=5 * FEATURE_ULPS)   # 8 stages deep
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_dense_agcn_layer_list(amd):
+    """DenseAGCN (DenseAGCN.py:30-83): two dense blocks, save_output=True on every SGC_LL."""
+    rs, X, L0, gb = _batch(amd, seed=73)
+    B, K, w = gb.plan.B, 2, [16, 24, 24, 16]
+    model = amd.DenseConnectedGraph(2, 75, B, 24)
+    mk = lambda o, i, s: amd.SGC_LL(o, i, B, K=K, activation="relu", save_output=True, laplacian_mode="paper",  # noqa: E731
+                                    device=DEV, generator=_gen(s))
+    model.add(mk(w[0], 75, 1))
+    model.add(mk(w[1], w[0], 2))
+    model.add(amd.DenseBlockEnd(0, [w[0], w[1]], w[1], "relu", max_atom=24, batch_size=B, device=DEV, generator=_gen(3)))
+    model.add(mk(w[2], w[1], 4))
+    model.add(mk(w[3], w[2], 5))
+    model.add(amd.DenseBlockEnd(1, [w[2], w[3]], w[3], "relu", max_atom=24, batch_size=B, device=DEV, generator=_gen(6)))
+    model.add(amd.DenseMol(32, w[3], activation="relu", device=DEV, generator=_gen(7)))
+    model.add(amd.GraphGatherMol(B, activation="tanh"))
+    out = model(gb)
+    # bookkeeping of tf_graphs.py:266-294: flat source-major lists, dims per source
+    assert model.inblock_activations_dim == {0: [w[0], w[1]], 1: [w[2], w[3]]}
+    assert len(model.inblock_activations[0]) == 2 * B and len(model.block_outputs) == 2 * B
+    assert model.block_outputs_dim == [w[1], w[3]] and model.current_block_id == 2
+
+    f64 = lambda t: to_np(t).astype(np.float64)   # noqa: E731
+    L64 = [l.astype(np.float64) for l in L0]
+
+    def sgc(hs, lay):
+        p = {k: f64(v) for k, v in lay.vars.items()}
+        return [c["Y"] for c in orc.layer_forward(hs, L64, p, K, orc.PAPER, orc.SGC_LL)]
+
+    def dbe(x, ins, outs, lay):
+        v = lay.vars
+        return [orc.dense_block_end_forward(x[b], [s[b] for s in ins], [f64(t) for t in v["weight_inblock"]],
+                                            [s[b] for s in outs], [f64(t) for t in v["weight_outblock"]],
+                                            float(v["beta_inblock"].detach()), float(v["beta_outblock"].detach()))[0] for b in range(B)]
+
+    hs = [x.astype(np.float64) for x in X]
+    h1 = sgc(hs, model.layers[0])
+    h2 = sgc(h1, model.layers[1])
+    e1 = dbe(h2, [h1, h2], [], model.layers[2])
+    h3 = sgc(e1, model.layers[3])
+    h4 = sgc(h3, model.layers[4])
+    e2 = dbe(h4, [h3, h4], [e1], model.layers[5])
+    hd = [orc.dense_mol_forward(x, f64(model.layers[6].W), f64(model.layers[6].b)) for x in e2]
+    o, _ = orc.graph_gather_forward(hd, "tanh")
+    assert_close(to_np(out), o, 5 * FEATURE_RTOL, "DenseAGCN output", atol_ulps=5 * FEATURE_ULPS)
+    out.sum().backward()
+    # (the first block has no earlier block outputs: its beta_outblock is unused and, as in TF, gets no gradient)
+    unused = model.layers[2].vars["beta_outblock"]
+    assert unused.grad is None
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p is not unused)
+
+
+def test_reslap_container_reference_feed_golden(amd):
+    """ResidualGraphMolResLap on the reference's own padded feed: the 2-layer SGC_LL_Reslap chain of
+    tests/golden/reslap_chain.npz (generated by the reference's classes, first layer save_lap=True) -- the container
+    must hand `stack_laplacians[-batch_size:]` to the second layer (tf_graphs.py:184,193-194)."""
+    g = load_golden("reslap_chain.npz")
+    ns = g["ns"]
+    B, K = len(ns), int(g["K"])
+    Fin, Fout, max_atom = int(g["Fin"]), int(g["Fout"]), int(g["max_atom"])
+    feed = {"node_features": [torch.from_numpy(g["X"][b]).to(DEV) for b in range(B)],
+            "original_laplacian": [torch.from_numpy(g["L"][b]).to(DEV) for b in range(B)],
+            "data_slice": g["data_slice"], "lap_slice": g["lap_slice"]}
+    model = amd.ResidualGraphMolResLap(Fin, B, max_atom)
+    l1 = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, B, K, orc.REFERENCE, golden_params(g, "l1_"), DEV)
+    l2 = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fout, B, K, orc.REFERENCE, golden_params(g, "l2_"), DEV)
+    l1.save_lap = True
+    model.add(l1)
+    model.add(l2)
+    out = model(feed)
+    assert len(model.get_laplacian()) == B and len(model.get_resL_set()) == 2 * B
+    for b, n in enumerate(ns):
+        y = to_np(out[b])
+        assert y.shape == (max_atom, Fout) and np.all(y[n:] == 0)
+        assert_close(y, g["l2_Y"][b], FEATURE_RTOL, "chain Y[%d]" % b)
+        assert_close(to_np(model.get_laplacian()[b]), g["l1_L_sum"][b, :n, :n], FEATURE_RTOL, "saved L[%d]" % b)
