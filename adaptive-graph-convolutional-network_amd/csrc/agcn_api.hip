@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
 
 #include "sgc_kernels.h"
 #include "spec_kernels.h"
@@ -166,14 +169,24 @@ FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   return f;
 }
 
-// Side stream for the mixed dispatch (created once per process; one process drives one GPU).
+// Side stream + fork / join events of the mixed dispatch: one set per DEVICE (created on first use with that device
+// current), and a lock that a mixed-dispatch call holds while it enqueues -- two threads driving the same device
+// would otherwise interleave their fork / join records on the shared events.
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   int ok = 0;
+  std::mutex mu;
 };
 SideStream& side_stream() {
-  static SideStream ss;
+  static std::mutex table_mu;
+  static std::unordered_map<int, std::unique_ptr<SideStream>> table;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(table_mu);
+  std::unique_ptr<SideStream>& p = table[dev];
+  if (!p) p.reset(new SideStream());
+  SideStream& ss = *p;
   if (!ss.ok) {
     if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
         hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
@@ -360,6 +373,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     // stream (row-restricted packed GEMMs + the prefix of the slab table), the rest through the fused kernel
     SideStream& ss = side_stream();
     if (!ss.ok) return fail(AGCN_EDEVICE, "%s: cannot create the side stream", who);
+    std::lock_guard<std::mutex> side_lock(ss.mu);
     hipStream_t main_s = static_cast<hipStream_t>(hip_stream);
     if (hipEventRecord(ss.fork, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess)
       return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
@@ -495,10 +509,12 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     a.ws_Gp = w.Gp;
     a.ws_dA = w.dA; a.ws_dd = w.dd;
     SideStream* ss = nullptr;
+    std::unique_lock<std::mutex> side_lock;
     hipStream_t main_s = static_cast<hipStream_t>(hip_stream);
     if (fs.mode == 2) {
       ss = &side_stream();
       if (!ss->ok) return fail(AGCN_EDEVICE, "%s: cannot create the side stream", who);
+      side_lock = std::unique_lock<std::mutex>(ss->mu);
       if (hipEventRecord(ss->fork, main_s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
         return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
       RowsGemmArgs g;

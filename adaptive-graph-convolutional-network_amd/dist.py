@@ -2,7 +2,12 @@
 parameter gradients couple them.  Each rank packs its own shard; the single exchange step is
 one RCCL all-reduce (SUM) over the flat gradient bucket.  The reference has no multi-GPU code;
 SUM (not mean) is right because its loss divides by the GLOBAL batch size
-(models/tf_modules/multitask_classifier.py:207-208)."""
+(models/tf_modules/multitask_classifier.py:207-208).
+
+Consequence for callers: anything that divides by the batch size -- `MultitaskHead(..., batch_size=...)`, a hand-written
+loss scale -- must be given the GLOBAL batch size (per-rank graphs x world size) on every rank; the SGC layers
+themselves are built with the LOCAL graph count (it is the length of their output lists).  `global_batch_size()`
+returns the number to use."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -51,6 +56,13 @@ def init_from_env(backend=None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def global_batch_size(local_batch_size, group=None):
+    """Batch size the loss must divide by under data parallelism (SUM all-reduce): local x world size."""
+    if dist.is_available() and dist.is_initialized():
+        return int(local_batch_size) * dist.get_world_size(group)
+    return int(local_batch_size)
 
 
 def allreduce_bucket(bucket, group=None):

@@ -2,6 +2,7 @@
 whole batch.  PyTorch is used for device memory, streams and autograd bookkeeping only --
 all arithmetic happens in the HIP library (there is no eager fallback)."""
 import ctypes as C
+import functools
 
 import torch
 
@@ -14,6 +15,20 @@ def _ptr(t):
 
 def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def _on_tensor_device(fn):
+    """Runs an autograd Function's forward / backward with the device of its first GPU tensor made current: the
+    library resolves per-device state (dynamic-LDS caps, the mixed-dispatch side stream) through hipGetDevice(), and
+    a launch on a stream of another device than the current one would fail."""
+    @functools.wraps(fn)
+    def wrapped(ctx, *args):
+        dev = next((a.device for a in args if torch.is_tensor(a) and a.is_cuda), None)
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+    return wrapped
 
 
 def _require_gpu(t, what):
@@ -34,6 +49,7 @@ class CastRowsFunction(torch.autograd.Function):
     """Storage-dtype conversion of a feature matrix (bf16 <-> f32) through the C ABI; the gradient is cast back."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, X, dtype):
         _require_gpu(X, "features")
         if X.dtype not in _DT or dtype not in _DT:
@@ -49,6 +65,7 @@ class CastRowsFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         return CastRowsFunction.apply(g, ctx.src), None
 
@@ -58,6 +75,7 @@ class PackRowsFunction(torch.autograd.Function):
     `batch.plan` is the PACKED plan.  Backward unpacks the gradient (pad rows get 0)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, Xpad, batch, stride):
         _require_gpu(Xpad, "node features")
         Xpad = _f32c(Xpad, "node features")
@@ -71,6 +89,7 @@ class PackRowsFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         return UnpackRowsFunction.apply(g, ctx.batch, ctx.stride, None), None, None
 
@@ -80,6 +99,7 @@ class UnpackRowsFunction(torch.autograd.Function):
     bias lands on pad rows too, dense_layer.py:42-50).  Backward packs the gradient."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, Xp, batch, stride, fill):
         _require_gpu(Xp, "node features")
         Xp = _f32c(Xp, "node features")
@@ -93,6 +113,7 @@ class UnpackRowsFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         return PackRowsFunction.apply(g, ctx.batch, ctx.stride), None, None, None
 
@@ -144,6 +165,7 @@ class SgcLLFunction(torch.autograd.Function):
     """(Y, res_L, res_W, L_sum) = SGC_LL[_Reslap](X; weight, bias, M_L, alpha, beta, L_prev)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, X, weight, bias, M_L, alpha, beta, L_prev, batch, cfg):
         lib = _ffi.lib()
         _require_gpu(X, "node features")
@@ -185,6 +207,7 @@ class SgcLLFunction(torch.autograd.Function):
         return Y, res_L, res_W, L_sum
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dY, _dres_L, _dres_W, dL_sum):
         lib = _ffi.lib()
         X, weight, bias, M_L, alpha, beta, L_prev, Y, res_L, res_W, L_sum, reserve = ctx.saved_tensors
@@ -225,6 +248,7 @@ class GraphGatherFunction(torch.autograd.Function):
     """out[b] = act(sum of graph b's real rows)   (graphgather.py:40-77)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, X, batch, activation):
         lib = _ffi.lib()
         _require_gpu(X, "node features")
@@ -241,6 +265,7 @@ class GraphGatherFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dOut):
         lib = _ffi.lib()
         (out,) = ctx.saved_tensors
@@ -259,6 +284,7 @@ class RowsDenseFunction(torch.autograd.Function):
     (densenet_block.py:113-123)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, A, W, bias, Add, batch, activation, keep_pad_rows, scale=None):
         lib = _ffi.lib()
         _require_gpu(A, "node features")
@@ -291,6 +317,7 @@ class RowsDenseFunction(torch.autograd.Function):
         return Y
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dY):
         lib = _ffi.lib()
         saved = ctx.saved_tensors
@@ -320,6 +347,7 @@ class MultitaskCEFunction(torch.autograd.Function):
     Returns (loss [1], logits [T, B, 2]); the gradient flows through the loss only."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, feat, W, bias, labels, weights, batch_size):
         lib = _ffi.lib()
         _require_gpu(feat, "graph features")
@@ -346,6 +374,7 @@ class MultitaskCEFunction(torch.autograd.Function):
         return loss, logits
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dloss, _dlogits):
         lib = _ffi.lib()
         feat, W, logits, labels, weights = ctx.saved_tensors
@@ -371,6 +400,7 @@ class GraphPoolFunction(torch.autograd.Function):
     grad='argmax': route the gradient to the arg-max rows (extension)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, X, batch, grad):
         lib = _ffi.lib()
         _require_gpu(X, "node features")
@@ -392,6 +422,7 @@ class GraphPoolFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dOut):
         if ctx.grad != "argmax":
             return None, None, None

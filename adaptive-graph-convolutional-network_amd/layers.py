@@ -477,7 +477,10 @@ class MultitaskHead(object):
     """The classifier tail of MultitaskGraphClassifier: `multitask_logits(feat, n_tasks, n_feature=...)`
     (model_operatos.py:792-829: one fully connected 2-class head per task, w ~ truncated_normal(stddev 0.01),
     b = 0, :744-750) and `add_training_loss('cross_entropy', logits)` (multitask_classifier.py:41-44,187-209:
-    per-task weighted sigmoid cross-entropy against one-hot labels, summed, divided by batch_size)."""
+    per-task weighted sigmoid cross-entropy against one-hot labels, summed, divided by batch_size).
+    Under data parallelism (`dist.allreduce_bucket` SUMS the per-rank gradients) `batch_size` must be the GLOBAL batch
+    size, `dist.global_batch_size(local)`: the reference's loss divides by the whole batch
+    (multitask_classifier.py:207-208); the feature matrix a rank passes in holds its local graphs only."""
 
     def __init__(self, n_tasks, n_feature, batch_size, device=None, generator=None, trainable=True):
         self.n_tasks, self.n_feature, self.batch_size = n_tasks, n_feature, batch_size

@@ -4,8 +4,19 @@
  * One call = one layer over a whole ragged batch of graphs (not one call per
  * graph).  Plain pointers and sizes only; the caller (PyTorch host code, via
  * ctypes) owns every buffer including workspace and reserve space; the
- * library allocates nothing on the device, keeps no state between calls, never
- * synchronises, and enqueues all work on the stream it is given.
+ * library allocates no device memory, keeps no per-call state between calls,
+ * never synchronises, and enqueues all work on the stream it is given.
+ *
+ * Threading.  Calls are re-entrant across threads (one stream per thread, disjoint
+ * buffers; tests/test_gpu_parity.py runs two threads concurrently); the error string
+ * is thread-local.  What IS process-wide, by design: the dispatch knobs of the
+ * last section (agcn_set_* / the AGCN_* environment variables: they select
+ * between kernel paths that give the same results, set them before the first
+ * call or while no call is in flight), a per-(device, kernel) cache of the
+ * dynamic-LDS caps already raised, and -- only with the opt-in mixed dispatch,
+ * agcn_set_fused_mode(2 | 3) -- one internal side stream + event pair per device;
+ * a mixed-dispatch call holds that device's lock while it enqueues.  The launch
+ * profiler (agcn_profile_*) is a single-threaded debug facility.
  *
  * What each entry point replaces in the reference (paths relative to the
  * reference repository root):

@@ -327,8 +327,8 @@ def backward_graph(c, G, p, K, mode=REFERENCE, variant=SGC_LL, dLa_extra=None):
         with np.errstate(over="ignore", invalid="ignore"):
             s3 = s * s * s
             dd = np.where(np.isfinite(s3) & (ds != 0), dt(-0.5) * s3 * ds, dt(0)).astype(x.dtype)
-        dS = dA * s[:, None] * s[None, :] + dd[None, :]    # d_j = sum_i S_ij
         with np.errstate(over="ignore", invalid="ignore"):
+            dS = dA * s[:, None] * s[None, :] + dd[None, :]    # d_j = sum_i S_ij (inf where s_i s_j overflows: S = 0 there)
             dr = np.where(S == 0, dt(0), -S * dS).astype(x.dtype)   # S = exp(-r); S == 0 (diagonal, underflow): 0, never inf * 0
         with np.errstate(divide="ignore", invalid="ignore"):
             cij = np.where(r > 0, (dr + dr.T) / r, dt(0)).astype(x.dtype)

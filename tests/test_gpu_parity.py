@@ -927,3 +927,74 @@ def test_modelnet_shaped_dense_adjacency(amd, symmetric):
     assert_close(to_np(Xt.grad), tot["dX"][0], GRAD_RTOL, "dX n=1024", atol_ulps=GRAD_ULPS * k)
     assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight n=1024", atol_ulps=GRAD_ULPS * k)
     assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L n=1024", atol_ulps=GRAD_ULPS * k)
+
+
+def test_two_threads_call_the_library_concurrently(amd):
+    """include/agcn.h "Threading": calls are re-entrant across threads.  Two threads, each with its own stream, batch
+    and buffers, run forward + backward steps at the same time (ctypes drops the GIL inside the library); every
+    result must be bit-identical to the same step run alone."""
+    import threading
+    Fin, Fout, K = 75, 64, 2
+    steps = []
+    for seed, ns in ((41, [18, 7, 33, 12, 25, 9]), (42, [40, 5, 11, 22])):
+        rs, X, L0, csr, p, G = synth_case(seed, ns, Fin, Fout, K, orc.SGC_LL, atoms=True)
+        gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+        layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, orc.PAPER, p, DEV)
+        st = amd.SgcLLStep(layer, gb, dY=torch.from_numpy(np.concatenate(G, 0)).to(DEV))
+        st.step()
+        torch.cuda.synchronize()
+        steps.append((st, [t.clone() for t in (st.Y, st.res_W, st.res_L, st.dX, st.bucket)]))
+    errors = []
+
+    def worker(st):
+        try:
+            stream = torch.cuda.Stream(DEV)
+            with torch.cuda.stream(stream):
+                for _ in range(200):
+                    st.step()
+            stream.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(st,)) for st, _ in steps]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for st, want in steps:
+        for got, w in zip((st.Y, st.res_W, st.res_L, st.dX, st.bucket), want):
+            assert torch.equal(got, w)
+
+
+@pytest.mark.parametrize("path", ["auto", "fused_general", "slab", "pergraph"])
+def test_far_away_nodes_do_not_poison_the_gradients(amd, path):
+    """A node whose similarities all underflow (r > ~104 to everyone) has degree FLT_TRUE_MIN, s ~ 2.7e22 and
+    s^3 = inf: the degree gradient used to come out as inf * 0 = NaN and spread through dM_L to the whole batch.
+    Such nodes are cut out of the degree gradient (agcn_device.h degree_grad; the oracle applies the same rule):
+    every output and gradient must be finite and agree with the oracle -- with one far node, and with two (whose
+    mutual s_i s_j overflows too)."""
+    lib = amd._ffi.lib()
+    fm, sm, spec = {"auto": (1, 1, 3), "fused_general": (1, 1, 0), "slab": (0, 1, 0), "pergraph": (0, 0, 0)}[path]
+    lib.agcn_set_fused_mode(fm)
+    lib.agcn_set_slab_mode(sm)
+    lib.agcn_set_spec_mode(spec)
+    try:
+        ns, Fin, Fout, K = [9, 14, 6], 75, 64, 2
+        rs, X, L0, csr, p, G = synth_case(77, ns, Fin, Fout, K, orc.SGC_LL, atoms=True)
+        X[0][2] *= 3000.0                       # one far-away node in graph 0
+        X[1][4] *= 3000.0                       # two in graph 1
+        X[1][9] *= -2500.0
+        caches, tot = oracle_run(X, L0, p, K, orc.PAPER, orc.SGC_LL, G, dtype=np.float32)
+        assert caches[0]["S"][2].max() == 0 and np.all(np.isfinite(tot["dM_L"]))
+        out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, orc.PAPER, orc.SGC_LL)
+        for k in ("dweight", "dbias", "dM_L", "dalpha"):
+            assert np.all(np.isfinite(out[k])), k
+        assert all(np.all(np.isfinite(d)) for d in out["dX"])
+        assert_close(out["dM_L"], tot["dM_L"], 5 * GRAD_RTOL, "dM_L with far-away nodes")
+        assert_close(out["dweight"], tot["dweight"], 5 * GRAD_RTOL, "dweight with far-away nodes")
+    finally:
+        lib.agcn_set_fused_mode(1)
+        lib.agcn_set_slab_mode(1)
+        lib.agcn_set_spec_mode(3)
