@@ -125,6 +125,109 @@ class SgcLLStep(object):
         self._graph.replay()
 
 
+class SgcLLEpochStep(object):
+    """Forward + backward of one SGC_LL layer over a STREAM of batches (an epoch): every device buffer is allocated
+    once at a capacity and reused, so a batch costs two C-ABI calls and a handful of ctypes fields -- no tensor
+    allocation, no autograd graph (the eager autograd path spends ~200 us of Python per batch).
+    Batches may have any shape; the library picks the kernel path per batch from its plan as usual.  Results of the
+    current batch are views into the capacity buffers (`Y`, `res_L`, `res_W`, `dX`, `bucket` / `grads`), valid until
+    the next `step()`.
+
+        ep = SgcLLEpochStep(layer, rows_cap, tiles_cap, batch_cap)
+        for gb, _, _, _ in store.iterbatches(256, dev, prefetch=2):
+            ep.step(gb, dY=None)           # dY: [rows, Fout] upstream gradient (default: the static ones-filled one)
+    """
+
+    def __init__(self, layer, rows_cap, tiles_cap, batch_cap, device=None):
+        lib = _ffi.lib()
+        self.lib, self.layer = lib, layer
+        dev = torch.device(device if device is not None else layer._device)
+        layer.build(dev)
+        self.device = dev
+        cfg = _Cfg(layer.n_atom_feature, layer.nb_filter, layer.K, layer.laplacian_mode, layer._variant,
+                   "relu" if layer.activation == "relu" else "linear")
+        if cfg.variant != "SGC_LL":
+            raise ValueError("SgcLLEpochStep drives SGC_LL layers")
+        self.cfg = cfg
+        self.paper = cfg.mode == "paper"
+        self.rows_cap, self.tiles_cap, self.batch_cap = int(rows_cap), int(tiles_cap), int(batch_cap)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._Y = torch.zeros((self.rows_cap, cfg.Fout), **f32)
+        self._res_L = torch.zeros(self.tiles_cap, **f32)
+        self._res_W = torch.zeros(self.tiles_cap, **f32)
+        self._dX = torch.zeros((self.rows_cap, cfg.Fin), **f32)
+        self._dY = torch.ones((self.rows_cap, cfg.Fout), **f32)
+        v = layer.vars
+        sizes = [("weight", cfg.Fin * cfg.K * cfg.Fout), ("bias", cfg.Fout)]
+        if self.paper:
+            sizes.append(("M_L", cfg.Fin * cfg.Fin))
+        sizes.append(("alpha", 1))
+        self.bucket = torch.zeros(sum(n for _, n in sizes), **f32)
+        self.grads, o = {}, 0
+        for k, n in sizes:
+            self.grads[k] = self.bucket[o:o + n].view(v[k].shape)
+            o += n
+        self.desc = _desc(cfg, cfg.Fin, cfg.Fout)
+        self.pr = _ffi.Params(v["weight"].data_ptr(), v["bias"].data_ptr(), v["M_L"].data_ptr(),
+                              v["alpha"].data_ptr(), None)
+        self.out = _ffi.Outputs(self._Y.data_ptr(), self._res_L.data_ptr(), self._res_W.data_ptr(), None)
+        g = self.grads
+        self.gr = _ffi.Grads(self._dX.data_ptr(), g["weight"].data_ptr(), g["bias"].data_ptr(), _ptr(g.get("M_L")),
+                             g["alpha"].data_ptr(), None, None)
+        self._reserve = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        self._ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        self.plan = None
+
+    def _fit(self, plan):
+        if plan.rows > self.rows_cap or plan.tile_elems > self.tiles_cap or plan.B > self.batch_cap:
+            raise ValueError("batch (rows %d, tile floats %d, graphs %d) exceeds the capacity (%d, %d, %d)"
+                             % (plan.rows, plan.tile_elems, plan.B, self.rows_cap, self.tiles_cap, self.batch_cap))
+        lib, d, hp = self.lib, C.byref(self.desc), plan.host_ptr
+        rb = lib.agcn_sgc_ll_reserve_bytes(d, hp)
+        wb = max(lib.agcn_sgc_ll_forward_workspace_bytes(d, hp), lib.agcn_sgc_ll_backward_workspace_bytes(d, hp))
+        if rb > self._reserve.numel():            # (grows geometrically: a handful of times per epoch at most)
+            self._reserve = torch.zeros(int(rb * 1.5), dtype=torch.uint8, device=self.device)
+        if wb > self._ws.numel():
+            self._ws = torch.zeros(int(wb * 1.5), dtype=torch.uint8, device=self.device)
+        return rb
+
+    def step(self, batch, dY=None):
+        plan = batch.plan
+        X = batch.X
+        if X.dtype != torch.float32 or not X.is_contiguous() or X.shape[1] != self.cfg.Fin:
+            raise ValueError("node features must be contiguous fp32 [rows, Fin]")
+        rb = self._fit(plan)
+        if dY is not None and (dY.dtype != torch.float32 or not dY.is_contiguous() or dY.shape[1] != self.cfg.Fout):
+            raise ValueError("dY must be contiguous fp32 [rows, Fout]")
+        gb = _gbatch(batch, X, None)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        d, p, o = C.byref(self.desc), C.byref(self.pr), C.byref(self.out)
+        _ffi.check(self.lib.agcn_sgc_ll_forward(d, C.byref(gb), p, o, self._reserve.data_ptr(), rb, self._ws.data_ptr(),
+                                                self._ws.numel(), stream))
+        _ffi.check(self.lib.agcn_sgc_ll_backward(d, C.byref(gb), p, o, (self._dY if dY is None else dY).data_ptr(), None,
+                                                 C.byref(self.gr), self._reserve.data_ptr(), rb, self._ws.data_ptr(),
+                                                 self._ws.numel(), stream))
+        self.plan, self.batch = plan, batch       # (keeps the batch's device tensors alive until the next step)
+        return self
+
+    # views of the current batch's results
+    @property
+    def Y(self):
+        return self._Y[:self.plan.rows]
+
+    @property
+    def dX(self):
+        return self._dX[:self.plan.rows]
+
+    @property
+    def res_L(self):
+        return self._res_L[:self.plan.tile_elems]
+
+    @property
+    def res_W(self):
+        return self._res_W[:self.plan.tile_elems]
+
+
 class GraphedStep(object):
     """A whole training step of layers of this package -- autograd forward + backward over a fixed batch --
     captured into ONE HIP graph (torch.cuda.CUDAGraph on ROCm).

@@ -98,6 +98,9 @@ class GraphStore(object):
                                               C.byref(mx)))
         rows, nnz = rows.value, nnz.value
         st = self._buffers(slot, rows, nnz, B, pin)
+        if st.get("done") is not None:      # the uploads that last read this staging slot must have completed:
+            st["done"].synchronize()        # a fast consumer runs many batches ahead of the GPU
+            st["done"] = None
         sym = C.c_int32()
         _ffi.check(lib.agcn_store_pack_batch(C.byref(self._c), ids.ctypes.data, B, st["n"].ctypes.data,
                                              st["X"].data_ptr(), self.F, st["rowptr"].data_ptr(), st["col"].data_ptr(),
@@ -119,8 +122,13 @@ class GraphStore(object):
             plan.dev, plan.device = st["plan"][:plan.host.size].to(dev, non_blocking=True), dev
         else:
             plan.to(dev)
-        return GraphBatch(plan, up(st["X"], rows), up(st["rowptr"], rows + 1), up(st["col"], nnz), up(st["val"], nnz),
-                          l0_symmetric=pk["sym"])
+        gb = GraphBatch(plan, up(st["X"], rows), up(st["rowptr"], rows + 1), up(st["col"], nnz), up(st["val"], nnz),
+                        l0_symmetric=pk["sym"])
+        if pin:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            st["done"] = ev
+        return gb
 
     def batch(self, graph_ids, device, slot=0, n_threads=1):
         """Packed `GraphBatch` of the graphs `graph_ids` on `device`.  Uploads are asynchronous on the current
@@ -152,7 +160,6 @@ class GraphStore(object):
         import queue
         import threading
         nslots = prefetch + 2
-        done = [None] * nslots          # event recorded after the uploads out of slot k
         q = queue.Queue(maxsize=prefetch)
         stop = threading.Event()
 
@@ -162,9 +169,7 @@ class GraphStore(object):
                     if stop.is_set():
                         break
                     k = j % nslots
-                    if done[k] is not None:
-                        done[k].synchronize()
-                    q.put((j, sel, self._pack(sel, ("it", k), pin, n_threads)))
+                    q.put((j, sel, self._pack(sel, ("it", k), pin, n_threads)))   # (_pack waits for the slot's uploads)
                 q.put(None)
             except BaseException as e:          # surfaced in the consumer
                 q.put(e)
@@ -179,12 +184,7 @@ class GraphStore(object):
                 if isinstance(item, BaseException):
                     raise item
                 j, sel, pk = item
-                gb = self._upload(pk, dev)
-                if pin:
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(dev))
-                    done[j % nslots] = ev
-                yield (gb,) + extra(sel)
+                yield (self._upload(pk, dev),) + extra(sel)
         finally:
             stop.set()
             while th.is_alive():            # unblock a worker waiting on a full queue

@@ -998,3 +998,31 @@ def test_far_away_nodes_do_not_poison_the_gradients(amd, path):
         lib.agcn_set_fused_mode(1)
         lib.agcn_set_slab_mode(1)
         lib.agcn_set_spec_mode(3)
+
+
+def test_epoch_step_static_buffers_match_the_autograd_path(amd):
+    """SgcLLEpochStep (capacity buffers reused across batches of different shapes, two C-ABI calls per batch) gives
+    bit-identical outputs and gradients to the eager autograd path on every batch of an HIV-shaped epoch slice."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(98, 700, mu=np.log(23.0), hi=222)
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    Fin, Fout, K = 75, 64, 2
+    p = orc.init_params(np.random.RandomState(4), Fin, Fout, K)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, 256, K, orc.PAPER, p, DEV)
+    n = data["n"].astype(np.int64)
+    ep = amd.SgcLLEpochStep(layer, rows_cap=int(256 * n.mean() * 1.6 + 4 * n.max()),
+                            tiles_cap=int(256 * (n * n).mean() * 2.5 + 4 * int(n.max()) ** 2), batch_cap=256, device=DEV)
+    seen = 0
+    for gb, _, _, _ in store.iterbatches(256, DEV, deterministic=True, prefetch=2):
+        lay = make_layer(amd, orc.SGC_LL, Fout, Fin, gb.plan.B, K, orc.PAPER, p, DEV)
+        Xt = gb.X.clone().requires_grad_(True)
+        nodes, res_L, res_W = lay({"node_features": Xt, "graph_batch": gb})
+        nodes.data.backward(torch.ones_like(nodes.data))
+        ep.step(gb)
+        torch.cuda.synchronize()
+        assert torch.equal(ep.Y, nodes.data) and torch.equal(ep.res_W, res_W.data) and torch.equal(ep.res_L, res_L.data)
+        assert torch.equal(ep.dX, Xt.grad)
+        for k in ("weight", "bias", "M_L", "alpha"):
+            assert torch.equal(ep.grads[k], lay.vars[k].grad), k
+        seen += gb.plan.B
+    assert seen == 700

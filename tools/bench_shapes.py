@@ -194,16 +194,23 @@ def main():
         layer = amd.SGC_LL(64, 75, 256, K=K, laplacian_mode=args.mode, device=dev)
         layer.load_vars(synth.glorot_params(np.random.RandomState(123), 75, 64, K))
         res = {}
-        for what in ("ingest", "ingest+layer"):
+        n_all = data["n"].astype(np.int64)
+        ep = amd.SgcLLEpochStep(layer, rows_cap=int(1.5 * 256 * n_all.mean() + 4 * n_all.max()),
+                                tiles_cap=int(2.0 * 256 * (n_all * n_all).mean() + 4 * int(n_all.max()) ** 2 + 1024),
+                                batch_cap=256, device=dev)
+        for what in ("ingest", "ingest+layer", "ingest+layer(static buffers)"):
             for pf in (0, 2):
                 for rep in range(2):        # first pass: pinned staging allocation, code-object loading
                     torch.cuda.synchronize(dev)
                     t0 = time.perf_counter()
                     for gb, _, _, _ in store.iterbatches(256, dev, deterministic=True, prefetch=pf):
-                        if what != "ingest":
+                        if what == "ingest+layer(static buffers)":
+                            ep.step(gb)
+                        elif what != "ingest":
                             for q in layer.vars.values():
                                 q.grad = None
                             Xt = gb.X.requires_grad_(True)
+                            layer.batch_size = gb.plan.B      # (np.linspace cuts give batches of 255 / 256 graphs)
                             nodes, _, _ = layer({"node_features": Xt, "graph_batch": gb})
                             nodes.data.backward(torch.ones_like(nodes.data))
                     torch.cuda.synchronize(dev)
