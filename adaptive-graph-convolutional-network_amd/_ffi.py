@@ -78,7 +78,7 @@ SYMBOLS = [
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
     "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
     "agcn_get_fused_global_b", "agcn_set_fused_global_b", "agcn_get_param_grad_onepass", "agcn_set_param_grad_onepass",
-    "agcn_get_spec_mode", "agcn_set_spec_mode",
+    "agcn_get_spec_mode", "agcn_set_spec_mode", "agcn_get_spec_small", "agcn_set_spec_small",
     "agcn_profile_enable", "agcn_profile_kernels", "agcn_profile_kernel_name", "agcn_profile_collect",
 ]
 
@@ -152,10 +152,10 @@ def _declare(lib):
     lib.agcn_get_slab_mode.argtypes = []
     lib.agcn_set_slab_mode.restype = None
     lib.agcn_set_slab_mode.argtypes = [I32]
-    for nm in ("agcn_get_fused_global_b", "agcn_get_param_grad_onepass", "agcn_get_spec_mode"):
+    for nm in ("agcn_get_fused_global_b", "agcn_get_param_grad_onepass", "agcn_get_spec_mode", "agcn_get_spec_small"):
         getattr(lib, nm).restype = I32
         getattr(lib, nm).argtypes = []
-    for nm in ("agcn_set_fused_global_b", "agcn_set_param_grad_onepass", "agcn_set_spec_mode"):
+    for nm in ("agcn_set_fused_global_b", "agcn_set_param_grad_onepass", "agcn_set_spec_mode", "agcn_set_spec_small"):
         getattr(lib, nm).restype = None
         getattr(lib, nm).argtypes = [I32]
     lib.agcn_get_fused_mode.restype = I32

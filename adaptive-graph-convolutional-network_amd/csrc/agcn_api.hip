@@ -78,27 +78,42 @@ struct FusedSplit {
   int gb_fwd, gb_bwd_w, gb_bwd_m;   // backward: W and M_L separately
   // shape-specialised kernels (spec_*.hip) instead of the general fused ones, per direction
   int spec_fwd, spec_bwd;
+  int spec_bwd_first;   // schedule position of the first graph the specialised backward kernel takes
+  int spec_small_first; // schedule position of the first graph of the 8-wave flavour (== B: no such launch)
 };
 
 // The specialised kernels cover the whole batch or nothing (one launch per direction).
-void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnPlanInfo& pi, size_t lim) {
-  f->spec_fwd = f->spec_bwd = 0;
+void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size_t lim) {
+  const AgcnPlanInfo& pi = host.info;
+  f->spec_fwd = f->spec_bwd = f->spec_bwd_first = 0;
+  f->spec_small_first = pi.B;
   if (f->mode != 1 || !spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   const int m = agcn_get_spec_mode();
-  if ((m & 1) && spec_fwd_lds_bytes(pi.max_n, d->Fin, d->Fout) <= lim) f->spec_fwd = 1;
-  if ((m & 2) && spec_bwd_lds_bytes(pi.max_n, d->Fin, d->Fout) <= lim) f->spec_bwd = 1;
+  if ((m & 1) && spec_fwd_lds_bytes(pi.max_n, d->Fin, d->Fout, spec::NW_LARGE) <= lim) f->spec_fwd = 1;
+  if (m & 2) {
+    int first = 0;
+    while (first < pi.B && spec_bwd_lds_bytes(host.n[host.order[first]], d->Fin, d->Fout, spec::NW_LARGE) > lim) ++first;
+    // worth a second launch only when the specialised kernel takes (nearly) the whole batch
+    if (first < pi.B && first <= pi.B / 8) { f->spec_bwd = 1; f->spec_bwd_first = first; }
+  }
+  // Many graphs per CU: the small graphs (a suffix of the largest-first schedule) go to the 8-wave flavour, whose
+  // workgroups share a CU (spec_kernels.h).  With about one graph per CU a second launch only adds a boundary.
+  if ((f->spec_fwd || f->spec_bwd) && pi.B >= 4 * 256 && agcn_get_spec_small() != 0) {
+    int sf = pi.B;
+    while (sf > 0 && host.n[host.order[sf - 1]] <= spec::SMALL_N) --sf;
+    if (pi.B - sf >= 512) f->spec_small_first = sf;
+  }
 }
-
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host);
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
   FusedSplit f = fused_split_general(d, g, host);
   size_t lim = (size_t)agcn_get_lds_limit();
   if (lim > 160 * 1024) lim = 160 * 1024;
-  pick_spec(&f, d, host.info, lim);
+  pick_spec(&f, d, host, lim);
   return f;
 }
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
-  FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
   if (!(d->K == 2 && pi.rows == pi.N1 && (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;
@@ -360,8 +375,15 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   const FusedSplit fs = fused_split(desc, batch, host);
   if (fs.mode == 1) {
     // small graphs: the whole layer forward in one launch, everything staged in LDS once
-    if (fs.spec_fwd)
-      return launch_spec_forward(a, 0, host.info.B, spec_fwd_lds_bytes(fs.thr, desc->Fin, desc->Fout), hip_stream);
+    if (fs.spec_fwd) {
+      const int B = host.info.B, ss = fs.spec_small_first;
+      rc = launch_spec_forward(a, 0, ss, spec_fwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, spec::NW_LARGE),
+                               spec::NW_LARGE, hip_stream);
+      if (rc != AGCN_OK || ss >= B) return rc;
+      return launch_spec_forward(a, ss, B - ss,
+                                 spec_fwd_lds_bytes(host.n[host.order[ss]], desc->Fin, desc->Fout, spec::NW_SMALL),
+                                 spec::NW_SMALL, hip_stream);
+    }
     if (fs.gb_fwd)
       return launch_fused_forward(a, 0, host.info.B, fused_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K), true,
                                   hip_stream);
@@ -544,11 +566,33 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         if (rc != AGCN_OK) return rc;
       }
     }
+    if (fs.spec_bwd) {
+      // graphs are scheduled largest first: the leading fs.spec_bwd_first ones are too large for the specialised
+      // kernel's LDS plan and take the general fused kernel, the rest the specialised one (disjoint graphs)
+      const int sf = fs.spec_bwd_first;
+      if (sf > 0)
+        rc = launch_fused_backward(a, 0, sf,
+                                   fused_bwd_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K, fs.gb_bwd_w != 0,
+                                                          fs.gb_bwd_m != 0),
+                                   fs.gb_bwd_w != 0, fs.gb_bwd_m != 0, hip_stream);
+      if (rc != AGCN_OK) return rc;
+      const int ss = std::max(sf, fs.spec_small_first);
+      rc = launch_spec_backward(a, sf, ss - sf,
+                                spec_bwd_lds_bytes(host.n[host.order[sf]], desc->Fin, desc->Fout, spec::NW_LARGE),
+                                spec::NW_LARGE, hip_stream);
+      if (rc != AGCN_OK) return rc;
+      if (ss < B)
+        rc = launch_spec_backward(a, ss, B - ss,
+                                  spec_bwd_lds_bytes(host.n[host.order[ss]], desc->Fin, desc->Fout, spec::NW_SMALL),
+                                  spec::NW_SMALL, hip_stream);
+      if (rc != AGCN_OK) return rc;
+    } else {
     rc = launch_fused_backward(a, fs.n_big, B - fs.n_big,
                                fused_bwd_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K, fs.gb_bwd_w != 0,
                                                       fs.gb_bwd_m != 0),
                                fs.gb_bwd_w != 0, fs.gb_bwd_m != 0, hip_stream);
     if (rc != AGCN_OK) return rc;
+    }
     if (ss) {
       if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(main_s, ss->join, 0) != hipSuccess)
         return fail(AGCN_EDEVICE, "%s: stream join failed", who);

@@ -56,6 +56,12 @@ std::atomic<int32_t> g_spec_mode{[] {
   return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
 }()};
 extern "C" int32_t agcn_get_spec_mode(void) { return g_spec_mode.load(); }
+std::atomic<int32_t> g_spec_small{[] {
+  const char* e = std::getenv("AGCN_SPEC_SMALL");   // 0: never launch the 8-wave flavour for the small graphs
+  return (e && e[0] == '0') ? 0 : 1;
+}()};
+extern "C" int32_t agcn_get_spec_small(void) { return g_spec_small.load(); }
+extern "C" void agcn_set_spec_small(int32_t on) { g_spec_small.store(on ? 1 : 0); }
 extern "C" void agcn_set_spec_mode(int32_t mode) { g_spec_mode.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
 extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }
 extern "C" void agcn_set_slab_mode(int32_t mode) { g_slab_mode.store(mode ? 1 : 0); }

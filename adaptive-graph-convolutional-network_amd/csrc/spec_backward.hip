@@ -1,6 +1,536 @@
-// (placeholder until the specialised backward lands: never selected)
+// Shape-specialised fused backward of SGC_LL (K = 2): everything local to one graph in one 1024-thread workgroup.
+// Same math and the same hand-off buffers (ws_Gp, ws_dZ, ws_pg -> param_grads.hip) as fused_backward_kernel
+// (fused_kernels.hip); see spec_kernels.h / spec_forward.hip for the design rules.
+//
+//   B0  one bulk round of loads: dY, Y rows -> Gp = dY . act'(Y) image (k-permuted, A operand);  X_0 rows;  r tile
+//       (upper triangle, mirrored into LDS);  s;  CSR rows of L_orig;  first W fragment
+//   B0b L = lrelu(I | I - s S s) + L_orig rebuilt in LDS (S = exp2(-r log2 e): the forward's own instruction, so the
+//       same bits as res_W -- neither res_W nor res_L is read back)
+//   G   [g_0 | g_1] = Gp . W^T            adjoint of graphconv.py:247     MFMA, W rows streamed from L2 (16-byte loads)
+//   B1  dX = g_0 + L^T g_1                adjoint of graphconv.py:231     MFMA
+//   B2  (paper) dL = g_1 X_0^T -> dalpha, dA, ds -> dd;  c_ij = (dr_ij + dr_ji) / r_ij in one pass over the pairs;
+//       dZ = (diag(c 1) - c) Z;  dX += dZ M_L^T
+//   B3  every global store: dX, and the hand-off to the parameter-gradient kernel (Gp, dZ, dalpha)
+// No global store precedes the last global load (one in-order vmcnt for loads and stores on gfx950).
 #include "spec_kernels.h"
+
+#include <float.h>
+
 namespace agcn {
-size_t spec_bwd_lds_bytes(int32_t, int32_t, int32_t) { return ~(size_t)0; }
-int launch_spec_backward(const SgcArgs&, int32_t, int32_t, size_t, void*) { return fail(AGCN_EINVAL, "spec_backward: not built"); }
+namespace spec {
+
+constexpr int MAXTB = 3;   // most MFMA tiles of one phase a wave may own
+
+template <int FIN, int FOUT, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, int first) {
+  constexpr int NT = 64 * NW;
+  using FT = Feat<FIN>;
+  constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
+  constexpr int LDG = FOUT + 2, NKO = FOUT / 16, CPO = (FOUT + 63) / 64;
+  constexpr int RPW = NW == NW_SMALL ? 4 : 8;   // rows of a node-feature matrix one wave may own (n4 <= 32 | 128)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = uni(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const GraphRec g = load_graph(a.graph_desc + first + blockIdx.x);
+  const int n = g.n, row0 = g.row0;
+  const uint32_t toff = g.toff;
+  const BwdLds d = bwd_lds(n, F4, FOUT, NW);
+  const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const bool relu = a.activation == AGCN_ACT_RELU;
+  float* red = smem;
+  float* s_vec = smem + d.o_s;
+  float* ddv = smem + d.o_dd;
+  float* rsv = smem + d.o_rs;
+  float* colp = smem + d.o_colp;     // [NW][n4] per-wave column partials
+  float* tile = smem + d.o_tile;     // L -> dL -> c
+  float* Rt = smem + d.o_rt;         // r_ij, symmetric, diagonal 0 (paper)
+  float* dXimg = smem + d.o_dx;      // [n4][LDX] g_0, then dX
+  float* G1img = smem + d.o_g1;      // [n4][LDX] g_1
+  float* GPimg = smem + d.o_u;       // [n4][LDG] Gp, k-permuted in blocks of 16     (B0 .. G)
+  float* Zimg = smem + d.o_u;        // [n4][LDX] Z rows                              (B2)
+  float* X0img = smem + d.o_x0;      // [n4][LDX] X_0; later dZ
+  const float* Xg = a.X + (int64_t)row0 * a.ldx;
+  const float* Yg = a.Y + (int64_t)row0 * a.ldy;
+  const float* dYg = a.dY + (int64_t)row0 * a.ldy;
+  const float alpha = a.alpha[0];
+
+  AGCN_STAMP(4, 0);
+  // ---- B0 ------------------------------------------------------------------------------------------------
+  // W^T fragments of phase G: output column jr = kk * F4 + f of [g_0 | g_1] is W row f * K + kk, k runs along its
+  // FOUT contiguous floats: one 16-byte load per 16 k (the A image is stored k-permuted to match, perm16)
+  int tga, tgb;
+  tile_range<NW>(ntm * 2 * NCB, wave, tga, tgb);
+  f32x4 wA[NKO], wB[NKO];
+  auto load_wt = [&](f32x4 (&wf)[NKO], int t) {
+    const int jb = t % (2 * NCB);
+    const int kk = jb >= NCB ? 1 : 0, f = min((jb - kk * NCB) * 16 + r, FIN - 1);
+    const f32x4* p = reinterpret_cast<const f32x4*>(a.weight + (f * 2 + kk) * FOUT + 4 * q);
+#pragma unroll
+    for (int v = 0; v < NKO; ++v) wf[v] = p[4 * v];
+  };
+  if (tga < tgb) load_wt(wA, tga);
+
+  int csr_p0 = 0, csr_p1 = 0;
+  if (a.L0_rowptr && tid < n) {
+    csr_p0 = a.L0_rowptr[row0 + tid];
+    csr_p1 = a.L0_rowptr[row0 + tid + 1];
+  }
+  const float s_own = a.sv_s[row0 + min(tid, n - 1)];   // (always issued; stored to LDS behind the bulk loads)
+  // dY, Y rows: wave w takes rows w, w + 16, ..; Gp kept in registers for the hand-off store at the end
+  float gpv[RPW][CPO];
+  {
+    float gy[RPW][CPO], yy[RPW][CPO];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = min(wave + NW * u, n - 1);
+#pragma unroll
+      for (int cp = 0; cp < CPO; ++cp) {
+        const int c = min(lane + 64 * cp, FOUT - 1);
+        gy[u][cp] = 0.f;
+        yy[u][cp] = 0.f;
+        // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
+        if (u < rpw) {
+          gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
+          yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+#pragma unroll
+      for (int cp = 0; cp < CPO; ++cp) {
+        const int c = lane + 64 * cp;
+        const float v = (i < n && c < FOUT && (!relu || yy[u][cp] > 0.f)) ? gy[u][cp] : 0.f;
+        gpv[u][cp] = v;
+        if (i < n4 && c < FOUT) GPimg[i * LDG + perm16(c)] = v;
+      }
+    }
+  }
+  // X_0 rows -> image (zero padded)
+  for (int i0 = wave; i0 < n4; i0 += 4 * NW) {
+    float xr[4][CP];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* rp = Xg + (int64_t)min(i0 + NW * u, n - 1) * a.ldx;
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) xr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + NW * u;
+      if (i < n4) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < F4) X0img[i * LDX + c] = (i < n && c < FIN) ? xr[u][cp] : 0.f;
+        }
+      }
+    }
+  }
+  // r tile: the forward stored r_ij for i < j; mirrored here, diagonal 0.  All of a wave's rows are requested before
+  // the first LDS store (one round trip, not one per row).
+  if (paper) {
+    float rr[RPW][2];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        rr[u][cp] = 0.f;
+        if (u < rpw && 64 * cp < n)     // (uniform bounds, clamped addresses)
+          rr[u][cp] = a.sv_r[toff + (uint32_t)(min(i, n - 1) * n + min(j, n - 1))];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        if (i < n && j < n) {
+          if (j > i) {
+            Rt[i * ldt + j] = rr[u][cp];
+            Rt[j * ldt + i] = rr[u][cp];
+          } else if (j == i) {
+            Rt[i * ldt + i] = 0.f;
+          }
+        }
+      }
+    }
+  }
+  int csr_c[6] = {0, 0, 0, 0, 0, 0};
+  float csr_v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tid < n && csr_p1 > csr_p0) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int pp = min(csr_p0 + u, csr_p1 - 1);
+      csr_c[u] = a.L0_col[pp];
+      csr_v[u] = a.L0_val[pp];
+    }
+  }
+  if (tid < n) s_vec[tid] = paper ? s_own : 0.f;
+  lds_barrier();
+
+  AGCN_STAMP(4, 1);
+  // ---- B0b: L = lrelu(R) (+ L_orig) rebuilt from r and s; the tile's 16-padding zeroed ---------------------
+  {
+    const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+    const float* L0d = !a.L0_dense ? nullptr
+                                   : (a.L0_ld > 0 ? a.L0_dense + (int64_t)g.b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
+    for (int j = lane; j < n4; j += 64) {
+      const bool jv = j < n;
+      const float sj = (paper && jv) ? s_vec[j] : 0.f;
+      for (int i = wave; i < n4; i += NW) {
+        float out = 0.f;
+        if (jv && i < n) {
+          float R = (i == j) ? 1.f : 0.f;
+          if (paper) {
+            const float S = (i == j) ? 0.f : fast_exp_neg(Rt[i * ldt + j]);
+            R = R - (s_vec[i] * S) * sj;
+          }
+          out = lrelu(R, alpha);
+          if (L0d) out += L0d[(int64_t)i * l0ld + j];
+        }
+        tile[i * ldt + j] = out;
+      }
+    }
+  }
+  lds_barrier();
+  if (a.L0_rowptr && tid < n) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
+    for (int p = csr_p0 + 6; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+  }
+
+  AGCN_STAMP(4, 2);
+  // ---- G: [g_0 | g_1] = Gp . W^T -> dX image, g_1 image --------------------------------------------------------
+  {
+    auto tile_g = [&](const f32x4 (&wf)[NKO], int t) {
+      const int rt = t / (2 * NCB), jb = t - rt * (2 * NCB);
+      const int kk = jb >= NCB ? 1 : 0, f = (jb - kk * NCB) * 16 + r;
+      const float* Ap = GPimg + (rt * 16 + r) * LDG + q;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < NKO; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[16 * v + 4 * u], wf[v][u], acc, 0, 0, 0);
+      float* dst = (kk ? G1img : dXimg) + (rt * 16 + 4 * q) * LDX + f;
+      const bool fv = f < FIN;             // image columns FIN .. F4 are zero padding (the W row was clamped)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? acc[i4] : 0.f;
+    };
+#pragma unroll
+    for (int sl = 0; sl < MAXTB; ++sl) {
+      const int t = tga + sl;
+      if (t < tgb) {
+        if (sl & 1) {
+          if (t + 1 < tgb) load_wt(wA, t + 1);
+          tile_g(wB, t);
+        } else {
+          if (t + 1 < tgb) load_wt(wB, t + 1);
+          tile_g(wA, t);
+        }
+      }
+    }
+  }
+  lds_barrier();
+
+  AGCN_STAMP(4, 3);
+  // ---- B1: dX += L^T g_1 --------------------------------------------------------------------------------------
+  // (paper) the Z rows B2 needs are requested now; their round trip overlaps the matrix work
+  float zr[RPW][CP];
+  if (paper) {
+    const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = min(wave + NW * u, n - 1);
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        zr[u][cp] = 0.f;
+        if (u < rpw) zr[u][cp] = Zg[i * FIN + min(lane + 64 * cp, FIN - 1)];
+      }
+    }
+  }
+  int t1a, t1b;
+  tile_range<NW>(ntm * NCB, wave, t1a, t1b);
+  for (int t = t1a; t < t1b; ++t) {
+    const int rt = t / NCB, cb = t - rt * NCB;
+    const float* Ap = tile + q * ldt + rt * 16 + r;          // A[i][k] = L[k][i]
+    const float* Bp = G1img + q * LDX + cb * 16 + r;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < n4; k0 += 16) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = Ap[(k0 + 4 * u) * ldt];
+        bv[u] = Bp[(k0 + 4 * u) * LDX];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    float* dst = dXimg + (rt * 16 + 4 * q) * LDX + cb * 16 + r;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] += acc[i4];
+  }
+  float dalpha_part = 0.f;
+  f32x4 zacc[MAXTB];   // dZ tiles, for the hand-off store
+  if (paper) {
+    // Z rows -> image over the (dead) Gp image
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+      if (i < n4) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < F4) Zimg[i * LDX + c] = (i < n && c < FIN) ? zr[u][cp] : 0.f;
+        }
+      }
+    }
+    lds_barrier();   // L is dead (every wave is past B1)
+    AGCN_STAMP(4, 4);
+    // ---- B2: dL = g_1 X_0^T -> tile --------------------------------------------------------------------------
+    {
+      int ta, tb;
+      tile_range<NW>(ntm * ntm, wave, ta, tb);
+      for (int t = ta; t < tb; ++t) {
+        const int rt = t / ntm, ct = t - rt * ntm;
+        const float* Ap = G1img + (rt * 16 + r) * LDX + q;
+        const float* Bp = X0img + (ct * 16 + r) * LDX + q;   // B[k][j] = X_0[j][k]
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], Bp[4 * u], acc, 0, 0, 0);
+        const int j = ct * 16 + r, i0 = rt * 16 + 4 * q;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          float v = acc[i4];
+          if (a.dL_sum && i0 + i4 < n && j < n) v += a.dL_sum[toff + (uint32_t)((i0 + i4) * n + j)];
+          tile[(i0 + i4) * ldt + j] = v;
+        }
+      }
+    }
+    for (int j = lane; j < n4; j += 64) colp[wave * n4 + j] = 0.f;
+    lds_barrier();
+    AGCN_STAMP(4, 5);
+    // pass 1: dalpha, P = dA . S, row sums  sum_j P_ij s_j  and per-wave column partials  sum_i P_ij s_i
+    for (int i = wave; i < n; i += NW) {
+      float rsum = 0.f;
+      const float si = s_vec[i];
+      for (int j = lane; j < n; j += 64) {
+        const float Sv = (i == j) ? 0.f : fast_exp_neg(Rt[i * ldt + j]);
+        float R = (i == j) ? 1.f : 0.f;
+        R = R - (si * Sv) * s_vec[j];                  // R1 == R (clip scale 1)
+        const float dL = tile[i * ldt + j];
+        dalpha_part += dL * fminf(R, 0.f);
+        const float P = -(dL * lrelu_grad(R, alpha)) * Sv;   // dA_ij S_ij
+        rsum += P * s_vec[j];
+        colp[wave * n4 + j] += P * si;
+      }
+      rsum = wave_sum(rsum);
+      if (lane == 0) rsv[i] = rsum;
+    }
+    lds_barrier();
+    if (tid < n) {
+      float cs = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) cs += colp[w * n4 + tid];
+      ddv[tid] = degree_grad(s_vec[tid], rsv[tid] + cs);   // dd_k = -1/2 s_k^3 ds_k
+    }
+    lds_barrier();
+    AGCN_STAMP(4, 6);
+    // pass 2: c_ij = (dr_ij + dr_ji) / r_ij for i < j, dr_ij = -S_ij (dA_ij s_i s_j + dd_j) (0 where S or r is 0),
+    // mirrored in place: each unordered pair is read and written by exactly one lane
+    for (int i = wave; i < n; i += NW) {
+      const float si = s_vec[i], ddi = ddv[i];
+      for (int j = lane; j < n; j += 64) {
+        if (j > i) {
+          const float rr = Rt[i * ldt + j];
+          const float Sv = fast_exp_neg(rr);
+          const float sj = s_vec[j];
+          const float Rij = -((si * Sv) * sj), Rji = -((sj * Sv) * si);
+          const float dAij = -(tile[i * ldt + j] * lrelu_grad(Rij, alpha));
+          const float dAji = -(tile[j * ldt + i] * lrelu_grad(Rji, alpha));
+          float cij = 0.f;
+          if (Sv != 0.f && rr > 0.f) {
+            const float dr_ij = -Sv * (dAij * si * sj + ddv[j]);
+            const float dr_ji = -Sv * (dAji * sj * si + ddi);
+            cij = (dr_ij + dr_ji) * fast_rcp(rr);
+          }
+          tile[i * ldt + j] = cij;
+          tile[j * ldt + i] = cij;
+        } else if (j == i) {
+          tile[i * ldt + i] = 0.f;
+        }
+      }
+    }
+    lds_barrier();
+    for (int i = wave; i < n; i += NW) {
+      float rsum = 0.f;
+      for (int j = lane; j < n; j += 64) rsum += tile[i * ldt + j];
+      rsum = wave_sum(rsum);
+      if (lane == 0) rsv[i] = rsum;
+    }
+    lds_barrier();
+    AGCN_STAMP(4, 7);
+    // ---- dZ = rowsum(c) Z - c Z -> image over X_0 (A operand of the next product) ------------------------------
+#pragma unroll
+    for (int sl = 0; sl < MAXTB; ++sl) {
+      const int t = t1a + sl;
+      if (t < t1b) {
+        const int rt = t / NCB, cb = t - rt * NCB;
+        const float* Ap = tile + (rt * 16 + r) * ldt + q;
+        const float* Bp = Zimg + q * LDX + cb * 16 + r;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < n4; k0 += 16) {
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = Ap[k0 + 4 * u];
+            bv[u] = Bp[(k0 + 4 * u) * LDX];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        const int f = cb * 16 + r, i0 = rt * 16 + 4 * q;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const int i = i0 + i4;
+          const float v = (i < n) ? rsv[i] * Zimg[i * LDX + f] - acc[i4] : 0.f;
+          X0img[i * LDX + f] = v;
+          zacc[sl][i4] = v;
+        }
+      }
+    }
+  }
+  // M_L^T fragments of the last product: B[k][f] = M_L[f][k], lane (r, q) walks row f = cb * 16 + r of M_L
+  float mA[NKS], mB[NKS];
+  auto load_mt = [&](float (&bf)[NKS], int t) {
+    const int cb = t % NCB;
+    const float* p = a.M_L + min(cb * 16 + r, FIN - 1) * FIN + q;
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      if (4 * u + 3 < FIN) bf[u] = p[4 * u];
+      else bf[u] = p[min(4 * u + q, FIN - 1) - q];
+    }
+  };
+  if (paper && t1a < t1b) load_mt(mA, t1a);
+  lds_barrier();
+
+  AGCN_STAMP(4, 8);
+  // ---- dX += dZ M_L^T, then B3: every global store -------------------------------------------------------------
+  {
+    float* dXg = a.dX + (int64_t)row0 * a.ldx;
+    auto tile_x = [&](const float (&bf)[NKS], int t) {
+      const int rt = t / NCB;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (paper) {
+        const float* Ap = X0img + (rt * 16 + r) * LDX + q;
+#pragma unroll
+        for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
+      }
+      return acc;
+    };
+    f32x4 xacc[MAXTB];
+#pragma unroll
+    for (int sl = 0; sl < MAXTB; ++sl) {
+      const int t = t1a + sl;
+      if (t < t1b) {
+        if (sl & 1) {
+          if (paper && t + 1 < t1b) load_mt(mA, t + 1);
+          xacc[sl] = tile_x(mB, t);
+        } else {
+          if (paper && t + 1 < t1b) load_mt(mB, t + 1);
+          xacc[sl] = tile_x(mA, t);
+        }
+      }
+    }
+    // (no load is issued past this point)
+#pragma unroll
+    for (int sl = 0; sl < MAXTB; ++sl) {
+      const int t = t1a + sl;
+      if (t < t1b) {
+        const int rt = t / NCB, cb = t - rt * NCB;
+        const int f = cb * 16 + r, i0 = rt * 16 + 4 * q;
+        if (f < FIN) {
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) {
+            const int i = i0 + i4;
+            if (i < n) {
+              dXg[(int64_t)i * a.ldx + f] = dXimg[i * LDX + f] + xacc[sl][i4];
+              if (paper) a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[sl][i4];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+#pragma unroll
+      for (int cp = 0; cp < CPO; ++cp) {
+        const int c = lane + 64 * cp;
+        if (i < n && c < FOUT) a.ws_Gp[(int64_t)(row0 + i) * FOUT + c] = gpv[u][cp];
+      }
+    }
+  }
+  const float da = block_sum(dalpha_part, red);
+  if (tid == 0) {
+    a.ws_pg[2 * g.b + 0] = da;
+    a.ws_pg[2 * g.b + 1] = 0.f;
+  }
+  if (blockIdx.x == 0) {   // arrival counters of the parameter-gradient kernel that follows this one
+    for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
+  }
+  AGCN_STAMP(4, 9);
 }
+
+}  // namespace spec
+
+// LDS bytes of the backward kernel for a largest graph of n nodes; SIZE_MAX when a wave would own more tiles (or
+// node-feature rows) than its register arrays hold
+size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw) {
+  const int F4 = (Fin + 15) & ~15, ntm = (n + 15) / 16;
+  const int lim = spec::MAXTB * nw;
+  if (ntm * 2 * (F4 / 16) > lim || ntm * ntm > lim || ntm * 16 > (nw == spec::NW_SMALL ? 4 : 8) * nw) return ~(size_t)0;
+  if (nw == spec::NW_SMALL && n > spec::SMALL_N) return ~(size_t)0;
+  return sizeof(float) * (size_t)spec::bwd_lds(n, F4, Fout, nw).total;
+}
+
+template <int FIN, int FOUT, int NW>
+static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = static_cast<hipError_t>(
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&spec::spec_backward_kernel<FIN, FOUT, NW>), lds_bytes));
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_bwd): %s", hipGetErrorString(e));
+  }
+  prof_begin(PK_SPEC_BWD, s);
+  hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW>), dim3(count), dim3(64 * NW), lds_bytes, s, a, first);
+  prof_end(s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_backward launch: %s", hipGetErrorString(e));
+  return AGCN_OK;
+}
+
+template <int FIN, int FOUT>
+static int launch_spec_backward_w(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, hipStream_t s) {
+  if (nw == spec::NW_SMALL) return launch_spec_backward_t<FIN, FOUT, spec::NW_SMALL>(a, first, count, lds_bytes, s);
+  return launch_spec_backward_t<FIN, FOUT, spec::NW_LARGE>(a, first, count, lds_bytes, s);
+}
+
+int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream) {
+  if (count <= 0) return AGCN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.Fin == 75 && a.Fout == 64) return launch_spec_backward_w<75, 64>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 64 && a.Fout == 128) return launch_spec_backward_w<64, 128>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 128 && a.Fout == 128) return launch_spec_backward_w<128, 128>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 128 && a.Fout == 64) return launch_spec_backward_w<128, 64>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 64 && a.Fout == 64) return launch_spec_backward_w<64, 64>(a, first, count, lds_bytes, nw, s);
+  return fail(AGCN_EINVAL, "spec_backward: unsupported layer shape %d -> %d", a.Fin, a.Fout);
+}
+
+}  // namespace agcn

@@ -26,8 +26,9 @@ namespace spec {
 
 constexpr int MAXT = 3;   // most MFMA tiles of one phase a wave may own (accumulators are held in registers)
 
-template <int FIN, int FOUT>
-__global__ __launch_bounds__(NT) void spec_forward_kernel(SgcArgs a, int first) {
+template <int FIN, int FOUT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_kernel(SgcArgs a, int first) {
+  constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int NOB = FOUT / 16;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(NT) void spec_forward_kernel(SgcArgs a, int first) 
   // ---- F0 ------------------------------------------------------------------------------------------------
   // first M_L fragment of this wave's F1 tiles: requested before anything else (it is consumed last)
   int t1a, t1b;
-  tile_range(ntm * NCB, wave, t1a, t1b);
+  tile_range<NW>(ntm * NCB, wave, t1a, t1b);
   float bA[NKS], bB[NKS];
   const float* mq = a.M_L + q * FIN;
   auto load_m = [&](float (&bf)[NKS], int t) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(NT) void spec_forward_kernel(SgcArgs a, int first) 
   }
   // W fragments of this wave's F5 tiles
   int t5a, t5b;
-  tile_range(ntm * NOB, wave, t5a, t5b);
+  tile_range<NW>(ntm * NOB, wave, t5a, t5b);
   const float* wq = a.weight + q * 2 * FOUT + r;
   auto load_w = [&](float (&bf)[NKS], int t, int h) {
     const int ob = t % NOB;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(NT) void spec_forward_kernel(SgcArgs a, int first) 
   if (t5a < t5b) load_w(bA, t5a, 0);   // first W fragment of F5: its round trip overlaps F4
   {
     int t4a, t4b;
-    tile_range(ntm * NCB, wave, t4a, t4b);
+    tile_range<NW>(ntm * NCB, wave, t4a, t4b);
     for (int t = t4a; t < t4b; ++t) {
       const int rt = t / NCB, cb = t - rt * NCB;
       const float* Ap = tile + (rt * 16 + r) * ldt + q;
@@ -358,35 +359,42 @@ bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant) {
 
 // LDS bytes of the forward kernel for a largest graph of n nodes; SIZE_MAX when a wave would own more than MAXT
 // tiles of an MFMA phase (their accumulators are held in registers until the final store phase)
-size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout) {
+size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw) {
   const int F4 = (Fin + 15) & ~15, ntm = (n + 15) / 16;
-  if (ntm * (F4 / 16) > spec::MAXT * spec::NW || ntm * (Fout / 16) > spec::MAXT * spec::NW) return ~(size_t)0;
+  if (ntm * (F4 / 16) > spec::MAXT * nw || ntm * (Fout / 16) > spec::MAXT * nw) return ~(size_t)0;
+  if (nw == spec::NW_SMALL && n > spec::SMALL_N) return ~(size_t)0;
   return sizeof(float) * (size_t)spec::fwd_lds(n, F4).total;
 }
 
-template <int FIN, int FOUT>
+template <int FIN, int FOUT, int NW>
 static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
     hipError_t e = static_cast<hipError_t>(
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&spec::spec_forward_kernel<FIN, FOUT>), lds_bytes));
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&spec::spec_forward_kernel<FIN, FOUT, NW>), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_fwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_SPEC_FWD, s);
-  hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT>), dim3(count), dim3(spec::NT), lds_bytes, s, a, first);
+  hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT, NW>), dim3(count), dim3(64 * NW), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_forward launch: %s", hipGetErrorString(e));
   return AGCN_OK;
 }
 
-int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream) {
+template <int FIN, int FOUT>
+static int launch_spec_forward_w(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, hipStream_t s) {
+  if (nw == spec::NW_SMALL) return launch_spec_forward_t<FIN, FOUT, spec::NW_SMALL>(a, first, count, lds_bytes, s);
+  return launch_spec_forward_t<FIN, FOUT, spec::NW_LARGE>(a, first, count, lds_bytes, s);
+}
+
+int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream) {
   if (count <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a.Fin == 75 && a.Fout == 64) return launch_spec_forward_t<75, 64>(a, first, count, lds_bytes, s);
-  if (a.Fin == 64 && a.Fout == 128) return launch_spec_forward_t<64, 128>(a, first, count, lds_bytes, s);
-  if (a.Fin == 128 && a.Fout == 128) return launch_spec_forward_t<128, 128>(a, first, count, lds_bytes, s);
-  if (a.Fin == 128 && a.Fout == 64) return launch_spec_forward_t<128, 64>(a, first, count, lds_bytes, s);
-  if (a.Fin == 64 && a.Fout == 64) return launch_spec_forward_t<64, 64>(a, first, count, lds_bytes, s);
+  if (a.Fin == 75 && a.Fout == 64) return launch_spec_forward_w<75, 64>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 64 && a.Fout == 128) return launch_spec_forward_w<64, 128>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 128 && a.Fout == 128) return launch_spec_forward_w<128, 128>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 128 && a.Fout == 64) return launch_spec_forward_w<128, 64>(a, first, count, lds_bytes, nw, s);
+  if (a.Fin == 64 && a.Fout == 64) return launch_spec_forward_w<64, 64>(a, first, count, lds_bytes, nw, s);
   return fail(AGCN_EINVAL, "spec_forward: unsupported layer shape %d -> %d", a.Fin, a.Fout);
 }
 

@@ -19,10 +19,13 @@ namespace spec {
 
 // One wave issues at most one vector instruction every ~5.5 cycles on gfx950 (tools/ubench/valu_rate.hip: v_fma_f32,
 // v_pk_fma_f32, v_sub_f32 and v_add_u32 alike, independent operands), and a SIMD only approaches its issue rate
-// (~1.4 cycles per instruction) with four resident waves.  With one graph per CU, latency is therefore
-// (instructions of the busiest wave) x 5.5 cycles: the graph is spread over the largest workgroup there is.
-constexpr int NT = 1024;  // threads per workgroup
-constexpr int NW = 16;    // waves per workgroup
+// (~1.4 cycles per instruction) with four resident waves.  With one graph per CU (256-graph batches) latency is
+// (instructions of the busiest wave) x 5.5 cycles, so a graph is spread over the largest workgroup there is: 16
+// waves.  With many graphs per CU (2048-graph batches) the small graphs (n <= 32: nine in ten) take 8-wave
+// workgroups instead, two or three of which fit a CU at once, so that one graph's waits (barriers, LDS and memory
+// round trips: ~60 % of a wave's life) are filled by another graph's instructions.
+constexpr int NW_LARGE = 16, NW_SMALL = 8;
+constexpr int SMALL_N = 32;   // largest graph the 8-wave flavour takes
 
 template <int FIN>
 struct Feat {
@@ -55,24 +58,26 @@ AGCN_HD inline FwdLds fwd_lds(int n, int F4) {
 
 // LDS plan of the backward kernel.
 struct BwdLds {
-  int n4, ldt, ldg;
-  int o_s, o_dd, o_rs, o_tile, o_dx, o_g1, o_u, total;   // o_u: Gp image, later X_0 image, later dZ image
+  int n4, ldt;
+  int o_s, o_dd, o_rs, o_colp, o_tile, o_rt, o_dx, o_g1, o_u, o_x0, total;
 };
-AGCN_HD inline BwdLds bwd_lds(int n, int F4, int O4) {
+AGCN_HD inline BwdLds bwd_lds(int n, int F4, int Fout, int NW) {
   BwdLds d;
   d.n4 = (n + 15) & ~15;
   d.ldt = d.n4 + 2;
-  d.ldg = O4 + 2;
-  const int ldx = F4 + 2;
+  const int ldx = F4 + 2, ldg = Fout + 2;
   d.o_s = 32;
   d.o_dd = d.o_s + d.n4;
   d.o_rs = d.o_dd + d.n4;
-  d.o_tile = d.o_rs + d.n4;
-  d.o_dx = d.o_tile + d.n4 * d.ldt;
+  d.o_colp = d.o_rs + d.n4;                 // [NW][n4] per-wave column partials
+  d.o_tile = d.o_colp + NW * d.n4;          // L -> dL -> c
+  d.o_rt = d.o_tile + d.n4 * d.ldt;         // r_ij
+  d.o_dx = d.o_rt + d.n4 * d.ldt;
   d.o_g1 = d.o_dx + d.n4 * ldx;
-  d.o_u = d.o_g1 + d.n4 * ldx;
-  const int gp = d.n4 * d.ldg, x0 = d.n4 * ldx;
-  d.total = d.o_u + (gp > x0 ? gp : x0);
+  d.o_u = d.o_g1 + d.n4 * ldx;              // Gp image, later the Z image
+  const int gp = d.n4 * ldg, z = d.n4 * ldx;
+  d.o_x0 = d.o_u + (gp > z ? gp : z);       // X_0 image, later dZ
+  d.total = d.o_x0 + d.n4 * ldx;
   return d;
 }
 
@@ -125,6 +130,7 @@ struct TriFold19 {
 };
 
 // contiguous, balanced share of T tiles for wave w of NW
+template <int NW>
 __device__ __forceinline__ void tile_range(int T, int w, int& t0, int& t1) {
   const int base = T / NW, rem = T - base * NW;
   t0 = w * base + min(w, rem);
@@ -136,10 +142,11 @@ __device__ __forceinline__ void tile_range(int T, int w, int& t0, int& t1) {
 
 // host-side entry points (agcn_api.hip)
 bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant);
-size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout);
-size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout);
-int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
-int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, void* stream);
+// nw = waves per workgroup: spec::NW_LARGE (16) or spec::NW_SMALL (8, graphs of at most spec::SMALL_N nodes)
+size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw);
+size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw);
+int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream);
+int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream);
 
 }  // namespace agcn
 #endif  // AGCN_SPEC_KERNELS_H_

@@ -34,15 +34,43 @@ class SgcLLStep(object):
         v = layer.vars
         ldx, ldy = self.X.shape[1], cfg.Fout
         f32 = dict(dtype=torch.float32, device=dev)
-        self.Y = torch.zeros((plan.rows, ldy), **f32)
-        self.res_L = torch.zeros(plan.tile_elems, **f32)
-        self.res_W = torch.zeros(plan.tile_elems, **f32)
-        self.L_sum = torch.zeros(plan.tile_elems, **f32) if reslap else None   # SGC_LL has three outputs
-        self.dY = dY if dY is not None else torch.zeros((plan.rows, ldy), **f32)
-        self.dL_sum = dL_sum
-        self.dX = torch.zeros_like(self.X)
+        # Every buffer of the step is carved out of ONE allocation (256-byte aligned pieces): the kernels then touch
+        # a handful of contiguous 2 MB pages instead of a dozen scattered ones (address-translation misses at the
+        # start of each kernel were a measurable part of its first load phase)
+        self.desc = _desc(cfg, ldx, ldy)
+        self.rbytes = lib.agcn_sgc_ll_reserve_bytes(C.byref(self.desc), plan.host_ptr)
+        self.wf = lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
+        self.wb = lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
         has_prev = self.L_prev is not None
-        self.dL_prev = torch.zeros(plan.tile_elems, **f32) if has_prev else None
+        nb = cfg.Fin * cfg.K * cfg.Fout + cfg.Fout + (cfg.Fin * cfg.Fin if paper else 0) + 1 + (1 if has_prev else 0)
+        pieces = [4 * plan.rows * ldy, 4 * plan.tile_elems, 4 * plan.tile_elems, 4 * plan.tile_elems if reslap else 0,
+                  4 * plan.rows * ldy, 4 * self.X.numel(), 4 * self.X.numel(), 4 * plan.tile_elems if has_prev else 0,
+                  4 * nb, self.rbytes, max(self.wf, self.wb)]
+        al = lambda v: (int(v) + 255) // 256 * 256   # noqa: E731
+        arena = torch.zeros(sum(al(v) for v in pieces) + 256, dtype=torch.uint8, device=dev)
+        self._arena, self._arena_off = arena, 0
+
+        def take(nbytes, shape=None, dtype=torch.float32):
+            o = self._arena_off
+            self._arena_off += al(nbytes)
+            t = arena[o:o + int(nbytes)]
+            return t if dtype == torch.uint8 else t.view(dtype).view(shape if shape is not None else -1)
+
+        self.Y = take(4 * plan.rows * ldy, (plan.rows, ldy))
+        self.res_L = take(4 * plan.tile_elems)
+        self.res_W = take(4 * plan.tile_elems)
+        self.L_sum = take(4 * plan.tile_elems) if reslap else None   # SGC_LL has three outputs
+        if dY is not None:
+            self.dY = take(4 * plan.rows * ldy, (plan.rows, ldy))
+            self.dY.copy_(dY)
+        else:
+            self.dY = take(4 * plan.rows * ldy, (plan.rows, ldy))
+        self.dL_sum = dL_sum
+        Xa = take(4 * self.X.numel(), tuple(self.X.shape))
+        Xa.copy_(self.X)
+        self.X = Xa
+        self.dX = take(4 * self.X.numel(), tuple(self.X.shape))
+        self.dL_prev = take(4 * plan.tile_elems) if has_prev else None
         # flat gradient bucket
         sizes = [("weight", cfg.Fin * cfg.K * cfg.Fout), ("bias", cfg.Fout)]
         if paper:
@@ -50,17 +78,14 @@ class SgcLLStep(object):
         sizes.append(("alpha", 1))
         if has_prev:
             sizes.append(("beta", 1))
-        self.bucket = torch.zeros(sum(s for _, s in sizes), **f32)
+        assert sum(s for _, s in sizes) == nb
+        self.bucket = take(4 * nb)
         self.grads, o = {}, 0
         for k, s in sizes:
             self.grads[k] = self.bucket[o:o + s].view(v[k].shape)
             o += s
-        self.desc = _desc(cfg, ldx, ldy)
-        self.rbytes = lib.agcn_sgc_ll_reserve_bytes(C.byref(self.desc), plan.host_ptr)
-        self.wf = lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
-        self.wb = lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
-        self.reserve = torch.zeros(self.rbytes, dtype=torch.uint8, device=dev)
-        self.ws = torch.zeros(max(self.wf, self.wb), dtype=torch.uint8, device=dev)
+        self.reserve = take(self.rbytes, dtype=torch.uint8)
+        self.ws = take(max(self.wf, self.wb), dtype=torch.uint8)
         self.gb = _gbatch(batch, self.X, self.L_prev)
         self.pr = _ffi.Params(v["weight"].data_ptr(), v["bias"].data_ptr(), v["M_L"].data_ptr(),
                               v["alpha"].data_ptr(), _ptr(v.get("beta")))

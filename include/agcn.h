@@ -383,6 +383,10 @@ void agcn_set_param_grad_onepass(int32_t on);
  * (3 = both, the default).  Same results within the last few ulps (hardware sqrt / exp2 in the similarity phase). */
 int32_t agcn_get_spec_mode(void);
 void agcn_set_spec_mode(int32_t mode);
+/* 1 (default): in batches of >= 1024 graphs the graphs of at most 32 nodes take an 8-wave flavour of the
+ * specialised kernels in a launch of their own (two or three such workgroups share a CU); 0: one launch. */
+int32_t agcn_get_spec_small(void);
+void agcn_set_spec_small(int32_t on);
 
 #ifdef __cplusplus
 }
