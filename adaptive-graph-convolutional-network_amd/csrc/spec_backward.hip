@@ -6,8 +6,9 @@
 //       (upper triangle, mirrored into LDS);  s;  CSR rows of L_orig;  first W fragment
 //   B0b L = lrelu(I | I - s S s) + L_orig rebuilt in LDS (S = exp2(-r log2 e): the forward's own instruction, so the
 //       same bits as res_W -- neither res_W nor res_L is read back)
-//   G   [g_0 | g_1] = Gp . W^T            adjoint of graphconv.py:247     MFMA, W rows streamed from L2 (16-byte loads)
-//   B1  dX = g_0 + L^T g_1                adjoint of graphconv.py:231     MFMA
+//   G   [g_0 | g_1] = Gp . W^T            adjoint of graphconv.py:247     MFMA, W rows streamed from L2 (16-byte loads);
+//       g_0 stays in the accumulators of the wave that will also own that dX tile, g_1 -> LDS image
+//   B1  dX = g_0 + L^T g_1                adjoint of graphconv.py:231     MFMA (dX accumulators stay in registers)
 //   B2  (paper) dL = g_1 X_0^T -> dalpha, dA, ds -> dd;  c_ij = (dr_ij + dr_ji) / r_ij in one pass over the pairs;
 //       dZ = (diag(c 1) - c) Z;  dX += dZ M_L^T
 //   B3  every global store: dX, and the hand-off to the parameter-gradient kernel (Gp, dZ, dalpha)
@@ -46,11 +47,11 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
   float* colp = smem + d.o_colp;     // [NW][n4] per-wave column partials
   float* tile = smem + d.o_tile;     // L -> dL -> c
   float* Rt = smem + d.o_rt;         // r_ij, symmetric, diagonal 0 (paper)
-  float* dXimg = smem + d.o_dx;      // [n4][LDX] g_0, then dX
-  float* G1img = smem + d.o_g1;      // [n4][LDX] g_1
+  float* G1img = smem + d.o_g1;      // [n4][LDX] g_1                                 (G .. dL)
+  float* Zimg = smem + d.o_g1;       // [n4][LDX] Z rows                              (dZ)
   float* GPimg = smem + d.o_u;       // [n4][LDG] Gp, k-permuted in blocks of 16     (B0 .. G)
-  float* Zimg = smem + d.o_u;        // [n4][LDX] Z rows                              (B2)
-  float* X0img = smem + d.o_x0;      // [n4][LDX] X_0; later dZ
+  float* X0img = smem + d.o_u;       // [n4][LDX] X_0                                 (B1 .. dL)
+  float* DZimg = smem + d.o_u;       // [n4][LDX] dZ                                  (dZ .. end)
   const float* Xg = a.X + (int64_t)row0 * a.ldx;
   const float* Yg = a.Y + (int64_t)row0 * a.ldy;
   const float* dYg = a.dY + (int64_t)row0 * a.ldy;
@@ -58,19 +59,19 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
 
   AGCN_STAMP(4, 0);
   // ---- B0 ------------------------------------------------------------------------------------------------
-  // W^T fragments of phase G: output column jr = kk * F4 + f of [g_0 | g_1] is W row f * K + kk, k runs along its
-  // FOUT contiguous floats: one 16-byte load per 16 k (the A image is stored k-permuted to match, perm16)
-  int tga, tgb;
-  tile_range<NW>(ntm * 2 * NCB, wave, tga, tgb);
+  // W^T fragments of phase G: column f of g_kk is W row f * K + kk, k runs along its FOUT contiguous floats: one
+  // 16-byte load per 16 k (the A image is stored k-permuted to match, perm16).  Tiles (row tile, 16-column block) are
+  // dealt to the waves once, for every phase that produces a [n x Fin] matrix: a wave keeps its dX tiles in registers.
+  int t1a, t1b;
+  tile_range<NW>(ntm * NCB, wave, t1a, t1b);
   f32x4 wA[NKO], wB[NKO];
-  auto load_wt = [&](f32x4 (&wf)[NKO], int t) {
-    const int jb = t % (2 * NCB);
-    const int kk = jb >= NCB ? 1 : 0, f = min((jb - kk * NCB) * 16 + r, FIN - 1);
+  auto load_wt = [&](f32x4 (&wf)[NKO], int t, int kk) {
+    const int f = min((t % NCB) * 16 + r, FIN - 1);
     const f32x4* p = reinterpret_cast<const f32x4*>(a.weight + (f * 2 + kk) * FOUT + 4 * q);
 #pragma unroll
     for (int v = 0; v < NKO; ++v) wf[v] = p[4 * v];
   };
-  if (tga < tgb) load_wt(wA, tga);
+  if (t1a < t1b) load_wt(wA, t1a, 0);
 
   int csr_p0 = 0, csr_p1 = 0;
   if (a.L0_rowptr && tid < n) {
@@ -106,27 +107,6 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
         const float v = (i < n && c < FOUT && (!relu || yy[u][cp] > 0.f)) ? gy[u][cp] : 0.f;
         gpv[u][cp] = v;
         if (i < n4 && c < FOUT) GPimg[i * LDG + perm16(c)] = v;
-      }
-    }
-  }
-  // X_0 rows -> image (zero padded)
-  for (int i0 = wave; i0 < n4; i0 += 4 * NW) {
-    float xr[4][CP];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* rp = Xg + (int64_t)min(i0 + NW * u, n - 1) * a.ldx;
-#pragma unroll
-      for (int cp = 0; cp < CP; ++cp) xr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + NW * u;
-      if (i < n4) {
-#pragma unroll
-        for (int cp = 0; cp < CP; ++cp) {
-          const int c = lane + 64 * cp;
-          if (c < F4) X0img[i * LDX + c] = (i < n && c < FIN) ? xr[u][cp] : 0.f;
-        }
       }
     }
   }
@@ -208,33 +188,31 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
   }
 
   AGCN_STAMP(4, 2);
-  // ---- G: [g_0 | g_1] = Gp . W^T -> dX image, g_1 image --------------------------------------------------------
+  // ---- G: g_0 = Gp . W_0^T -> registers, g_1 = Gp . W_1^T -> image ------------------------------------------------
+  f32x4 dxacc[MAXTB];
   {
     auto tile_g = [&](const f32x4 (&wf)[NKO], int t) {
-      const int rt = t / (2 * NCB), jb = t - rt * (2 * NCB);
-      const int kk = jb >= NCB ? 1 : 0, f = (jb - kk * NCB) * 16 + r;
-      const float* Ap = GPimg + (rt * 16 + r) * LDG + q;
+      const float* Ap = GPimg + ((t / NCB) * 16 + r) * LDG + q;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < NKO; ++v)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[16 * v + 4 * u], wf[v][u], acc, 0, 0, 0);
-      float* dst = (kk ? G1img : dXimg) + (rt * 16 + 4 * q) * LDX + f;
-      const bool fv = f < FIN;             // image columns FIN .. F4 are zero padding (the W row was clamped)
-#pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? acc[i4] : 0.f;
+      return acc;
     };
 #pragma unroll
     for (int sl = 0; sl < MAXTB; ++sl) {
-      const int t = tga + sl;
-      if (t < tgb) {
-        if (sl & 1) {
-          if (t + 1 < tgb) load_wt(wA, t + 1);
-          tile_g(wB, t);
-        } else {
-          if (t + 1 < tgb) load_wt(wB, t + 1);
-          tile_g(wA, t);
-        }
+      const int t = t1a + sl;
+      if (t < t1b) {
+        load_wt(wB, t, 1);
+        dxacc[sl] = tile_g(wA, t);
+        if (t + 1 < t1b) load_wt(wA, t + 1, 0);
+        const f32x4 g1 = tile_g(wB, t);
+        const int rt = t / NCB, f = (t - rt * NCB) * 16 + r;
+        float* dst = G1img + (rt * 16 + 4 * q) * LDX + f;
+        const bool fv = f < FIN;             // image columns FIN .. F4 are zero padding (the W row was clamped)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? g1[i4] : 0.f;
       }
     }
   }
@@ -242,45 +220,44 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
 
   AGCN_STAMP(4, 3);
   // ---- B1: dX += L^T g_1 --------------------------------------------------------------------------------------
-  // (paper) the Z rows B2 needs are requested now; their round trip overlaps the matrix work
-  float zr[RPW][CP];
+  // (paper) the X_0 rows B2 needs are requested now; their round trip overlaps the matrix work
+  float xzr[RPW][CP];
   if (paper) {
-    const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
-      const int i = min(wave + NW * u, n - 1);
+      const float* rp = Xg + (int64_t)min(wave + NW * u, n - 1) * a.ldx;
 #pragma unroll
       for (int cp = 0; cp < CP; ++cp) {
-        zr[u][cp] = 0.f;
-        if (u < rpw) zr[u][cp] = Zg[i * FIN + min(lane + 64 * cp, FIN - 1)];
+        xzr[u][cp] = 0.f;
+        if (u < rpw) xzr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
       }
     }
   }
-  int t1a, t1b;
-  tile_range<NW>(ntm * NCB, wave, t1a, t1b);
-  for (int t = t1a; t < t1b; ++t) {
-    const int rt = t / NCB, cb = t - rt * NCB;
-    const float* Ap = tile + q * ldt + rt * 16 + r;          // A[i][k] = L[k][i]
-    const float* Bp = G1img + q * LDX + cb * 16 + r;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < n4; k0 += 16) {
-      float av[4], bv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        av[u] = Ap[(k0 + 4 * u) * ldt];
-        bv[u] = Bp[(k0 + 4 * u) * LDX];
+  for (int sl = 0; sl < MAXTB; ++sl) {
+    const int t = t1a + sl;
+    if (t < t1b) {
+      const int rt = t / NCB, cb = t - rt * NCB;
+      const float* Ap = tile + q * ldt + rt * 16 + r;          // A[i][k] = L[k][i]
+      const float* Bp = G1img + q * LDX + cb * 16 + r;
+      f32x4 acc = dxacc[sl];
+      for (int k0 = 0; k0 < n4; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = Ap[(k0 + 4 * u) * ldt];
+          bv[u] = Bp[(k0 + 4 * u) * LDX];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      dxacc[sl] = acc;
     }
-    float* dst = dXimg + (rt * 16 + 4 * q) * LDX + cb * 16 + r;
-#pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] += acc[i4];
   }
   float dalpha_part = 0.f;
   f32x4 zacc[MAXTB];   // dZ tiles, for the hand-off store
   if (paper) {
-    // Z rows -> image over the (dead) Gp image
+    // X_0 rows -> image over the (dead) Gp image
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
       const int i = wave + NW * u;
@@ -288,14 +265,24 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
           const int c = lane + 64 * cp;
-          if (c < F4) Zimg[i * LDX + c] = (i < n && c < FIN) ? zr[u][cp] : 0.f;
+          if (c < F4) X0img[i * LDX + c] = (i < n && c < FIN) ? xzr[u][cp] : 0.f;
         }
       }
     }
     lds_barrier();   // L is dead (every wave is past B1)
     AGCN_STAMP(4, 4);
-    // ---- B2: dL = g_1 X_0^T -> tile --------------------------------------------------------------------------
+    // ---- B2: dL = g_1 X_0^T -> tile; the Z rows of the dZ product are requested meanwhile ---------------------
     {
+      const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        const int i = min(wave + NW * u, n - 1);
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          xzr[u][cp] = 0.f;
+          if (u < rpw) xzr[u][cp] = Zg[i * FIN + min(lane + 64 * cp, FIN - 1)];
+        }
+      }
       int ta, tb;
       tile_range<NW>(ntm * ntm, wave, ta, tb);
       for (int t = ta; t < tb; ++t) {
@@ -317,6 +304,18 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
     for (int j = lane; j < n4; j += 64) colp[wave * n4 + j] = 0.f;
     lds_barrier();
     AGCN_STAMP(4, 5);
+    // Z rows -> image over g_1 (dead: every wave is past dL); read from the dZ product on, behind later barriers
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+      if (i < n4) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < F4) Zimg[i * LDX + c] = (i < n && c < FIN) ? xzr[u][cp] : 0.f;
+        }
+      }
+    }
     // pass 1: dalpha, P = dA . S, row sums  sum_j P_ij s_j  and per-wave column partials  sum_i P_ij s_i
     for (int i = wave; i < n; i += NW) {
       float rsum = 0.f;
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
         for (int i4 = 0; i4 < 4; ++i4) {
           const int i = i0 + i4;
           const float v = (i < n) ? rsv[i] * Zimg[i * LDX + f] - acc[i4] : 0.f;
-          X0img[i * LDX + f] = v;
+          DZimg[i * LDX + f] = v;
           zacc[sl][i4] = v;
         }
       }
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
       const int rt = t / NCB;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (paper) {
-        const float* Ap = X0img + (rt * 16 + r) * LDX + q;
+        const float* Ap = DZimg + (rt * 16 + r) * LDX + q;
 #pragma unroll
         for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
       }
@@ -461,7 +460,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
           for (int i4 = 0; i4 < 4; ++i4) {
             const int i = i0 + i4;
             if (i < n) {
-              dXg[(int64_t)i * a.ldx + f] = dXimg[i * LDX + f] + xacc[sl][i4];
+              dXg[(int64_t)i * a.ldx + f] = dxacc[sl][i4] + xacc[sl][i4];
               if (paper) a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[sl][i4];
             }
           }
@@ -496,7 +495,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
 size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw) {
   const int F4 = (Fin + 15) & ~15, ntm = (n + 15) / 16;
   const int lim = spec::MAXTB * nw;
-  if (ntm * 2 * (F4 / 16) > lim || ntm * ntm > lim || ntm * 16 > (nw == spec::NW_SMALL ? 4 : 8) * nw) return ~(size_t)0;
+  if (ntm * (F4 / 16) > lim || ntm * ntm > lim || ntm * 16 > (nw == spec::NW_SMALL ? 4 : 8) * nw) return ~(size_t)0;
   if (nw == spec::NW_SMALL && n > spec::SMALL_N) return ~(size_t)0;
   return sizeof(float) * (size_t)spec::bwd_lds(n, F4, Fout, nw).total;
 }

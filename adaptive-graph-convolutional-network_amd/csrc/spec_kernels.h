@@ -59,7 +59,7 @@ AGCN_HD inline FwdLds fwd_lds(int n, int F4) {
 // LDS plan of the backward kernel.
 struct BwdLds {
   int n4, ldt;
-  int o_s, o_dd, o_rs, o_colp, o_tile, o_rt, o_dx, o_g1, o_u, o_x0, total;
+  int o_s, o_dd, o_rs, o_colp, o_tile, o_rt, o_g1, o_u, total;
 };
 AGCN_HD inline BwdLds bwd_lds(int n, int F4, int Fout, int NW) {
   BwdLds d;
@@ -72,12 +72,10 @@ AGCN_HD inline BwdLds bwd_lds(int n, int F4, int Fout, int NW) {
   d.o_colp = d.o_rs + d.n4;                 // [NW][n4] per-wave column partials
   d.o_tile = d.o_colp + NW * d.n4;          // L -> dL -> c
   d.o_rt = d.o_tile + d.n4 * d.ldt;         // r_ij
-  d.o_dx = d.o_rt + d.n4 * d.ldt;
-  d.o_g1 = d.o_dx + d.n4 * ldx;
-  d.o_u = d.o_g1 + d.n4 * ldx;              // Gp image, later the Z image
-  const int gp = d.n4 * ldg, z = d.n4 * ldx;
-  d.o_x0 = d.o_u + (gp > z ? gp : z);       // X_0 image, later dZ
-  d.total = d.o_x0 + d.n4 * ldx;
+  d.o_g1 = d.o_rt + d.n4 * d.ldt;           // g_1 image, later the Z image
+  d.o_u = d.o_g1 + d.n4 * ldx;              // Gp image, later the X_0 image, later the dZ image
+  const int gp = d.n4 * ldg, x = d.n4 * ldx;
+  d.total = d.o_u + (gp > x ? gp : x);
   return d;
 }
 
