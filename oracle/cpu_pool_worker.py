@@ -2,8 +2,9 @@
 
 Graphs are independent, so the honest way to use every host core is one process per core, each running the
 per-graph numpy oracle (agcn_oracle.py, 1 BLAS thread) on its share of the batch.  Protocol: load the shard, one
-warm-up pass, print READY, wait for GO on stdin, run `reps` forward+backward passes, print the elapsed seconds.
-usage: cpu_pool_worker.py <batch.npz> <worker> <n_workers> <reps> <mode>"""
+warm-up pass, print READY, then for every "GO <reps>" line on stdin run `reps` forward+backward passes and print the
+elapsed seconds ("QUIT" ends).
+usage: cpu_pool_worker.py <batch.npz> <worker> <n_workers> <mode>"""
 import os
 import sys
 import time
@@ -17,7 +18,7 @@ import agcn_oracle as orc
 
 
 def main():
-    path, w, nw, reps, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    path, w, nw, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     z = np.load(path)
     n = z["n"]
     mine = np.arange(w, len(n), nw)
@@ -36,12 +37,17 @@ def main():
     one()
     sys.stdout.write("READY\n")
     sys.stdout.flush()
-    sys.stdin.readline()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        one()
-    sys.stdout.write("%.6f\n" % (time.perf_counter() - t0))
-    sys.stdout.flush()
+    # rounds: "GO <reps>" -> run -> elapsed seconds; "QUIT" ends (a short pilot round calibrates the timed one)
+    while True:
+        line = sys.stdin.readline().split()
+        if not line or line[0] != "GO":
+            break
+        reps = int(line[1])
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one()
+        sys.stdout.write("%.6f\n" % (time.perf_counter() - t0))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
