@@ -90,7 +90,7 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
   if (f->mode != 1 || !spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   const int m = agcn_get_spec_mode();
   if ((m & 1) && spec_fwd_lds_bytes(pi.max_n, d->Fin, d->Fout, spec::NW_LARGE) <= lim) f->spec_fwd = 1;
-  if (m & 2) {
+  if ((m & 2) && f->spec_fwd) {   // (the specialised forward wrote the transposed parameter copies the backward reads)
     int first = 0;
     while (first < pi.B && spec_bwd_lds_bytes(host.n[host.order[first]], d->Fin, d->Fout, spec::NW_LARGE) > lim) ++first;
     // worth a second launch only when the specialised kernel takes (nearly) the whole batch
@@ -210,7 +210,7 @@ SideStream& side_stream() {
   return ss;
 }
 
-struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, total; };
+struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, MT, WT, total; };
 ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   Carver c(nullptr);
   ReserveLayout r;
@@ -222,6 +222,9 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   // r_ij tiles (fused and slab paths, paper mode): reserved whenever one of them COULD be taken
   r.r = c.off;
   if (d->K == 2 && d->mode == AGCN_MODE_PAPER) c.take((size_t)pi.tile_elems);
+  // transposed parameter copies (specialised kernels)
+  r.MT = c.off; c.take((size_t)d->Fin * d->Fin);
+  r.WT = c.off; c.take((size_t)d->K * d->Fout * d->Fin);
   r.total = c.off;
   return r;
 }
@@ -364,6 +367,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_scal = reinterpret_cast<float*>(rb + rl.scal);
   a.sv_X = reinterpret_cast<float*>(rb + rl.X);
   a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
+  a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
+  a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
 
   Carver c(workspace);
   const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
@@ -506,6 +511,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.sv_scal = reinterpret_cast<float*>(rb + rl.scal);
   a.sv_X = reinterpret_cast<float*>(rb + rl.X);
   a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
+  a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
+  a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
   a.dY = dY; a.dL_sum = dL_sum; a.dX = grads->dX; a.dL_prev = has_prev ? grads->dL_prev : nullptr;
   a.ws_g = w.g; a.ws_dZ = w.dZ; a.ws_pg = w.pg; a.ws_tile = w.tile; a.ws_buf = w.buf;
 

@@ -35,6 +35,10 @@ struct SgcArgs {
   float* sv_scal;  // [B][4]       ssR, scR, ssL, scL
   float* sv_X;     // [K-1][rows][Fin]  Chebyshev terms X_1..X_{K-1}
   float* sv_Lpre;  // [tile_elems] Reslap: L before the second clip
+  // transposed parameter copies written by the specialised forward kernel for the specialised backward one (row-major
+  // with the MFMA k index as the row: a fragment load then touches 4 cache lines instead of 16)
+  float* sv_MT;    // [Fin][Fin]        M_L^T
+  float* sv_WT;    // [K][Fout][Fin]    WT[k][c][f] = W[f*K + k][c]
   // global-tile mode scratch
   float* ws_tile;  // [wtile_off[B]]
   float* ws_buf;   // per-graph image scratch, see graph_scratch_floats()

@@ -2,11 +2,11 @@
 // Same math and the same hand-off buffers (ws_Gp, ws_dZ, ws_pg -> param_grads.hip) as fused_backward_kernel
 // (fused_kernels.hip); see spec_kernels.h / spec_forward.hip for the design rules.
 //
-//   B0  one bulk round of loads: dY, Y rows -> Gp = dY . act'(Y) image (k-permuted, A operand);  X_0 rows;  r tile
+//   B0  one bulk round of loads: dY, Y rows -> Gp = dY . act'(Y) image (A operand);  r tile
 //       (upper triangle, mirrored into LDS);  s;  CSR rows of L_orig;  first W fragment
 //   B0b L = lrelu(I | I - s S s) + L_orig rebuilt in LDS (S = exp2(-r log2 e): the forward's own instruction, so the
 //       same bits as res_W -- neither res_W nor res_L is read back)
-//   G   [g_0 | g_1] = Gp . W^T            adjoint of graphconv.py:247     MFMA, W rows streamed from L2 (16-byte loads);
+//   G   [g_0 | g_1] = Gp . W^T            adjoint of graphconv.py:247     MFMA, W^T streamed from the forward's transposed copy;
 //       g_0 stays in the accumulators of the wave that will also own that dX tile, g_1 -> LDS image
 //   B1  dX = g_0 + L^T g_1                adjoint of graphconv.py:231     MFMA (dX accumulators stay in registers)
 //   B2  (paper) dL = g_1 X_0^T -> dalpha, dA, ds -> dd;  c_ij = (dr_ij + dr_ji) / r_ij in one pass over the pairs;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
-  constexpr int LDG = FOUT + 2, NKO = FOUT / 16, CPO = (FOUT + 63) / 64;
+  constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64;
   constexpr int RPW = NW == NW_SMALL ? 4 : 8;   // rows of a node-feature matrix one wave may own (n4 <= 32 | 128)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
   float* Rt = smem + d.o_rt;         // r_ij, symmetric, diagonal 0 (paper)
   float* G1img = smem + d.o_g1;      // [n4][LDX] g_1                                 (G .. dL)
   float* Zimg = smem + d.o_g1;       // [n4][LDX] Z rows                              (dZ)
-  float* GPimg = smem + d.o_u;       // [n4][LDG] Gp, k-permuted in blocks of 16     (B0 .. G)
+  float* GPimg = smem + d.o_u;       // [n4][LDG] Gp                                  (B0 .. G)
   float* X0img = smem + d.o_u;       // [n4][LDX] X_0                                 (B1 .. dL)
   float* DZimg = smem + d.o_u;       // [n4][LDX] dZ                                  (dZ .. end)
   const float* Xg = a.X + (int64_t)row0 * a.ldx;
@@ -59,72 +59,87 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
 
   AGCN_STAMP(4, 0);
   // ---- B0 ------------------------------------------------------------------------------------------------
-  // W^T fragments of phase G: column f of g_kk is W row f * K + kk, k runs along its FOUT contiguous floats: one
-  // 16-byte load per 16 k (the A image is stored k-permuted to match, perm16).  Tiles (row tile, 16-column block) are
-  // dealt to the waves once, for every phase that produces a [n x Fin] matrix: a wave keeps its dX tiles in registers.
+  // W^T fragments of phase G from the transposed copy the forward left in the reserve: WT[kk][c][f] = W[f*K + kk][c],
+  // so that B[k = c][col = f] is row-major (lane (r, q) reads row 4u + q, column cb * 16 + r: four 64-byte runs per
+  // load).  Tiles (row tile, 16-column block) are dealt to the waves once, for every phase that produces a [n x Fin]
+  // matrix: a wave keeps its dX tiles in registers.
+  // Fragments are streamed in chunks of at most 16 / 20 k-steps through two register buffers (the next chunk is in
+  // flight while the current one feeds the matrix cores), whatever the layer width.
+  constexpr int NKW = FOUT / 4;            // k-steps over the output features
+  constexpr int CHW = 16, NCHW = NKW / CHW;
   int t1a, t1b;
   tile_range<NW>(ntm * NCB, wave, t1a, t1b);
-  f32x4 wA[NKO], wB[NKO];
-  auto load_wt = [&](f32x4 (&wf)[NKO], int t, int kk) {
-    const int f = min((t % NCB) * 16 + r, FIN - 1);
-    const f32x4* p = reinterpret_cast<const f32x4*>(a.weight + (f * 2 + kk) * FOUT + 4 * q);
+  float wb0[CHW], wb1[CHW];
+  auto load_wc = [&](float (&wf)[CHW], int t, int kk, int ch) {
+    const float* p = a.sv_WT + kk * (FOUT * FIN) + (q + 4 * CHW * ch) * FIN + min((t % NCB) * 16 + r, FIN - 1);
 #pragma unroll
-    for (int v = 0; v < NKO; ++v) wf[v] = p[4 * v];
+    for (int u = 0; u < CHW; ++u) wf[u] = p[4 * u * FIN];
   };
-  if (t1a < t1b) load_wt(wA, t1a, 0);
-
+  // One memory round trip for the whole phase: every independent load is requested before the first LDS store (loads
+  // return in order, so a store that waits for its data also waits for every older load), the row pointers first --
+  // the only dependent loads, the CSR entries, follow the bulk requests and ride the same round trip.
   int csr_p0 = 0, csr_p1 = 0;
   if (a.L0_rowptr && tid < n) {
     csr_p0 = a.L0_rowptr[row0 + tid];
     csr_p1 = a.L0_rowptr[row0 + tid + 1];
   }
-  const float s_own = a.sv_s[row0 + min(tid, n - 1)];   // (always issued; stored to LDS behind the bulk loads)
-  // dY, Y rows: wave w takes rows w, w + 16, ..; Gp kept in registers for the hand-off store at the end
-  float gpv[RPW][CPO];
-  {
-    float gy[RPW][CPO], yy[RPW][CPO];
+  // dY, Y rows: wave w takes rows w, w + NW, ..
+  float gy[RPW][CPO], yy[RPW][CPO];
 #pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-      const int i = min(wave + NW * u, n - 1);
+  for (int u = 0; u < RPW; ++u) {
+    const int i = min(wave + NW * u, n - 1);
 #pragma unroll
-      for (int cp = 0; cp < CPO; ++cp) {
-        const int c = min(lane + 64 * cp, FOUT - 1);
-        gy[u][cp] = 0.f;
-        yy[u][cp] = 0.f;
-        // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
-        if (u < rpw) {
-          gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
-          yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-      const int i = wave + NW * u;
-#pragma unroll
-      for (int cp = 0; cp < CPO; ++cp) {
-        const int c = lane + 64 * cp;
-        const float v = (i < n && c < FOUT && (!relu || yy[u][cp] > 0.f)) ? gy[u][cp] : 0.f;
-        gpv[u][cp] = v;
-        if (i < n4 && c < FOUT) GPimg[i * LDG + perm16(c)] = v;
+    for (int cp = 0; cp < CPO; ++cp) {
+      const int c = min(lane + 64 * cp, FOUT - 1);
+      gy[u][cp] = 0.f;
+      yy[u][cp] = 0.f;
+      // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
+      if (u < rpw) {
+        gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
+        yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
       }
     }
   }
-  // r tile: the forward stored r_ij for i < j; mirrored here, diagonal 0.  All of a wave's rows are requested before
-  // the first LDS store (one round trip, not one per row).
-  if (paper) {
-    float rr[RPW][2];
+  if (t1a < t1b) load_wc(wb0, t1a, 0, 0);
+  // r tile rows (the forward stored r_ij for i < j)
+  float rr[RPW][2];
 #pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-      const int i = wave + NW * u;
+  for (int u = 0; u < RPW; ++u) {
+    const int i = wave + NW * u;
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
-        const int j = lane + 64 * cp;
-        rr[u][cp] = 0.f;
-        if (u < rpw && 64 * cp < n)     // (uniform bounds, clamped addresses)
-          rr[u][cp] = a.sv_r[toff + (uint32_t)(min(i, n - 1) * n + min(j, n - 1))];
-      }
+    for (int cp = 0; cp < 2; ++cp) {
+      const int j = lane + 64 * cp;
+      rr[u][cp] = 0.f;
+      if (paper && u < rpw && 64 * cp < n)     // (uniform bounds, clamped addresses)
+        rr[u][cp] = a.sv_r[toff + (uint32_t)(min(i, n - 1) * n + min(j, n - 1))];
     }
+  }
+  const float s_own = a.sv_s[row0 + min(tid, n - 1)];
+  int csr_c[6] = {0, 0, 0, 0, 0, 0};
+  float csr_v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tid < n && csr_p1 > csr_p0) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int pp = min(csr_p0 + u, csr_p1 - 1);
+      csr_c[u] = a.L0_col[pp];
+      csr_v[u] = a.L0_val[pp];
+    }
+  }
+  // Gp = dY . act'(Y) -> image (A operand of phase G); kept in registers for the hand-off store at the end
+  float gpv[RPW][CPO];
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int i = wave + NW * u;
+#pragma unroll
+    for (int cp = 0; cp < CPO; ++cp) {
+      const int c = lane + 64 * cp;
+      const float v = (i < n && c < FOUT && (!relu || yy[u][cp] > 0.f)) ? gy[u][cp] : 0.f;
+      gpv[u][cp] = v;
+      if (i < n4 && c < FOUT) GPimg[i * LDG + c] = v;
+    }
+  }
+  // r tile: mirrored, diagonal 0
+  if (paper) {
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
       const int i = wave + NW * u;
@@ -140,16 +155,6 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
           }
         }
       }
-    }
-  }
-  int csr_c[6] = {0, 0, 0, 0, 0, 0};
-  float csr_v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (tid < n && csr_p1 > csr_p0) {
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int pp = min(csr_p0 + u, csr_p1 - 1);
-      csr_c[u] = a.L0_col[pp];
-      csr_v[u] = a.L0_val[pp];
     }
   }
   if (tid < n) s_vec[tid] = paper ? s_own : 0.f;
@@ -191,28 +196,37 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
   // ---- G: g_0 = Gp . W_0^T -> registers, g_1 = Gp . W_1^T -> image ------------------------------------------------
   f32x4 dxacc[MAXTB];
   {
-    auto tile_g = [&](const f32x4 (&wf)[NKO], int t) {
-      const float* Ap = GPimg + ((t / NCB) * 16 + r) * LDG + q;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma_wc = [&](f32x4 acc, const float (&wf)[CHW], int t, int ch) {
+      const float* Ap = GPimg + ((t / NCB) * 16 + r) * LDG + q + 4 * CHW * ch;
 #pragma unroll
-      for (int v = 0; v < NKO; ++v)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[16 * v + 4 * u], wf[v][u], acc, 0, 0, 0);
+      for (int u = 0; u < CHW; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], wf[u], acc, 0, 0, 0);
       return acc;
     };
 #pragma unroll
     for (int sl = 0; sl < MAXTB; ++sl) {
       const int t = t1a + sl;
       if (t < t1b) {
-        load_wt(wB, t, 1);
-        dxacc[sl] = tile_g(wA, t);
-        if (t + 1 < t1b) load_wt(wA, t + 1, 0);
-        const f32x4 g1 = tile_g(wB, t);
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int st = 0; st < 2 * NCHW; ++st) {
+          const int kk = st / NCHW, ch = st - kk * NCHW;
+          const bool odd = ((sl * 2 * NCHW + st) & 1) != 0;      // compile-time: which buffer holds this chunk
+          // request the next chunk (same tile, or the first one of the next tile) into the other buffer
+          if (st + 1 < 2 * NCHW) {
+            if (odd) load_wc(wb0, t, (st + 1) / NCHW, (st + 1) % NCHW);
+            else load_wc(wb1, t, (st + 1) / NCHW, (st + 1) % NCHW);
+          } else if (t + 1 < t1b) {
+            if (odd) load_wc(wb0, t + 1, 0, 0);
+            else load_wc(wb1, t + 1, 0, 0);
+          }
+          acc[kk] = odd ? mma_wc(acc[kk], wb1, t, ch) : mma_wc(acc[kk], wb0, t, ch);
+        }
+        dxacc[sl] = acc[0];
         const int rt = t / NCB, f = (t - rt * NCB) * 16 + r;
         float* dst = G1img + (rt * 16 + 4 * q) * LDX + f;
         const bool fv = f < FIN;             // image columns FIN .. F4 are zero padding (the W row was clamped)
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? g1[i4] : 0.f;
+        for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? acc[1][i4] : 0.f;
       }
     }
   }
@@ -406,31 +420,33 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
       }
     }
   }
-  // M_L^T fragments of the last product: B[k][f] = M_L[f][k], lane (r, q) walks row f = cb * 16 + r of M_L
-  float mA[NKS], mB[NKS];
-  auto load_mt = [&](float (&bf)[NKS], int t) {
-    const int cb = t % NCB;
-    const float* p = a.M_L + min(cb * 16 + r, FIN - 1) * FIN + q;
+  // M_L^T fragments of the last product from the transposed copy: B[k][f] = MT[k][f] row-major
+  constexpr int CHM = 20, NCHM = (NKS + CHM - 1) / CHM;
+  float mb0[CHM], mb1[CHM];
+  auto load_mc = [&](float (&bf)[CHM], int t, int ch) {
+    const float* p = a.sv_MT + q * FIN + min((t % NCB) * 16 + r, FIN - 1);
 #pragma unroll
-    for (int u = 0; u < NKS; ++u) {
-      if (4 * u + 3 < FIN) bf[u] = p[4 * u];
-      else bf[u] = p[min(4 * u + q, FIN - 1) - q];
+    for (int uu = 0; uu < CHM; ++uu) {
+      const int u = ch * CHM + uu;       // (compile-time after unrolling)
+      if (u < NKS) {
+        if (4 * u + 3 < FIN) bf[uu] = p[4 * u * FIN];
+        else bf[uu] = p[(min(4 * u + q, FIN - 1) - q) * FIN];
+      }
     }
   };
-  if (paper && t1a < t1b) load_mt(mA, t1a);
+  if (paper && t1a < t1b) load_mc(mb0, t1a, 0);
   lds_barrier();
 
   AGCN_STAMP(4, 8);
   // ---- dX += dZ M_L^T, then B3: every global store -------------------------------------------------------------
   {
     float* dXg = a.dX + (int64_t)row0 * a.ldx;
-    auto tile_x = [&](const float (&bf)[NKS], int t) {
-      const int rt = t / NCB;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (paper) {
-        const float* Ap = DZimg + (rt * 16 + r) * LDX + q;
+    auto mma_mc = [&](f32x4 acc, const float (&bf)[CHM], int t, int ch) {
+      const float* Ap = DZimg + ((t / NCB) * 16 + r) * LDX + q;
 #pragma unroll
-        for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
+      for (int uu = 0; uu < CHM; ++uu) {
+        const int u = ch * CHM + uu;
+        if (u < NKS) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[uu], acc, 0, 0, 0);
       }
       return acc;
     };
@@ -439,13 +455,22 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
     for (int sl = 0; sl < MAXTB; ++sl) {
       const int t = t1a + sl;
       if (t < t1b) {
-        if (sl & 1) {
-          if (paper && t + 1 < t1b) load_mt(mA, t + 1);
-          xacc[sl] = tile_x(mB, t);
-        } else {
-          if (paper && t + 1 < t1b) load_mt(mB, t + 1);
-          xacc[sl] = tile_x(mA, t);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (paper) {
+#pragma unroll
+          for (int ch = 0; ch < NCHM; ++ch) {
+            const bool odd = ((sl * NCHM + ch) & 1) != 0;
+            if (ch + 1 < NCHM) {
+              if (odd) load_mc(mb0, t, ch + 1);
+              else load_mc(mb1, t, ch + 1);
+            } else if (t + 1 < t1b) {
+              if (odd) load_mc(mb0, t + 1, 0);
+              else load_mc(mb1, t + 1, 0);
+            }
+            acc = odd ? mma_mc(acc, mb1, t, ch) : mma_mc(acc, mb0, t, ch);
+          }
         }
+        xacc[sl] = acc;
       }
     }
     // (no load is issued past this point)

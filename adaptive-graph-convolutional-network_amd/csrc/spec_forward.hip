@@ -346,6 +346,20 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_
         if (c < FIN) Xo[i * FIN + c] = X1img[i * LDX + c];
       }
   }
+  // The block of the last (smallest) graph of the batch also leaves transposed copies of the parameters in the reserve
+  // for the backward kernel (its B operands W^T and M_L^T then load row-major: 4 cache lines per fragment load
+  // instead of 16).  Stores only, behind every load of this block.
+  if (first + (int)blockIdx.x == a.B - 1) {
+    for (int e = tid; e < FIN * FIN; e += NT) {
+      const int k = e / FIN, f = e - k * FIN;
+      a.sv_MT[e] = a.M_L[f * FIN + k];
+    }
+    for (int e = tid; e < 2 * FOUT * FIN; e += NT) {
+      const int kk = e / (FOUT * FIN), rem = e - kk * (FOUT * FIN);
+      const int c = rem / FIN, f = rem - c * FIN;
+      a.sv_WT[e] = a.weight[(f * 2 + kk) * FOUT + c];
+    }
+  }
   AGCN_STAMP(1, 8);
 }
 
