@@ -98,10 +98,12 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
   }
   // Many graphs per CU: the small graphs (a suffix of the largest-first schedule) go to the 8-wave flavour, whose
   // workgroups share a CU (spec_kernels.h).  With about one graph per CU a second launch only adds a boundary.
-  if ((f->spec_fwd || f->spec_bwd) && pi.B >= 4 * 256 && agcn_get_spec_small() != 0) {
+  // (measured, Tox21-shaped batches, graphs/s with one launch | two launches in a row | side by side:
+  //  512: 5.6 | 3.9 | 4.8 M;  1024: 6.9 | 5.4 | 6.7 M;  2048: 8.0 | 7.8 | 9.2 M;  4096: 7.3 | 8.3 | 8.9 M)
+  if ((f->spec_fwd || f->spec_bwd) && pi.B >= 6 * 256 && agcn_get_spec_small() != 0) {
     int sf = pi.B;
     while (sf > 0 && host.n[host.order[sf - 1]] <= spec::SMALL_N) --sf;
-    if (pi.B - sf >= 512) f->spec_small_first = sf;
+    if (pi.B - sf >= 1024) f->spec_small_first = sf;
   }
 }
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host);
@@ -381,13 +383,33 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   if (fs.mode == 1) {
     // small graphs: the whole layer forward in one launch, everything staged in LDS once
     if (fs.spec_fwd) {
+      // Two bins: the few large graphs (16-wave workgroups, one per CU, as long as the largest graph takes) and the
+      // many small ones (8-wave workgroups sharing CUs).  Run one after the other the first launch leaves most of the
+      // chip idle behind its longest graph, so it goes to a side stream and the two launches overlap (they touch
+      // disjoint graphs; the transposed parameter copies are written by the block of the last graph only).
       const int B = host.info.B, ss = fs.spec_small_first;
+      const bool two = ss > 0 && ss < B, conc = two && agcn_get_spec_small() >= 2;
+      hipStream_t main_s = static_cast<hipStream_t>(hip_stream);
+      SideStream* side = nullptr;
+      std::unique_lock<std::mutex> side_lock;
+      if (conc) {
+        side = &side_stream();
+        if (!side->ok) return fail(AGCN_EDEVICE, "%s: cannot create the side stream", who);
+        side_lock = std::unique_lock<std::mutex>(side->mu);
+        if (hipEventRecord(side->fork, main_s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
+          return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
+      }
       rc = launch_spec_forward(a, 0, ss, spec_fwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, spec::NW_LARGE),
-                               spec::NW_LARGE, hip_stream);
-      if (rc != AGCN_OK || ss >= B) return rc;
-      return launch_spec_forward(a, ss, B - ss,
+                               spec::NW_LARGE, conc ? side->s : main_s);
+      if (rc != AGCN_OK) return rc;
+      if (ss < B)
+        rc = launch_spec_forward(a, ss, B - ss,
                                  spec_fwd_lds_bytes(host.n[host.order[ss]], desc->Fin, desc->Fout, spec::NW_SMALL),
-                                 spec::NW_SMALL, hip_stream);
+                                 spec::NW_SMALL, main_s);
+      if (rc != AGCN_OK) return rc;
+      if (conc && (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(main_s, side->join, 0) != hipSuccess))
+        return fail(AGCN_EDEVICE, "%s: stream join failed", who);
+      return AGCN_OK;
     }
     if (fs.gb_fwd)
       return launch_fused_forward(a, 0, host.info.B, fused_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K), true,
@@ -584,15 +606,27 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
                                    fs.gb_bwd_w != 0, fs.gb_bwd_m != 0, hip_stream);
       if (rc != AGCN_OK) return rc;
       const int ss = std::max(sf, fs.spec_small_first);
+      const bool two = ss > sf && ss < B, conc = two && sf == 0 && agcn_get_spec_small() >= 2 && fs.mode == 1;
+      SideStream* side = nullptr;
+      std::unique_lock<std::mutex> side_lock2;
+      if (conc) {   // large graphs beside the small ones, as in the forward
+        side = &side_stream();
+        if (!side->ok) return fail(AGCN_EDEVICE, "%s: cannot create the side stream", who);
+        side_lock2 = std::unique_lock<std::mutex>(side->mu);
+        if (hipEventRecord(side->fork, main_s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
+          return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
+      }
       rc = launch_spec_backward(a, sf, ss - sf,
                                 spec_bwd_lds_bytes(host.n[host.order[sf]], desc->Fin, desc->Fout, spec::NW_LARGE),
-                                spec::NW_LARGE, hip_stream);
+                                spec::NW_LARGE, conc ? side->s : main_s);
       if (rc != AGCN_OK) return rc;
       if (ss < B)
         rc = launch_spec_backward(a, ss, B - ss,
                                   spec_bwd_lds_bytes(host.n[host.order[ss]], desc->Fin, desc->Fout, spec::NW_SMALL),
-                                  spec::NW_SMALL, hip_stream);
+                                  spec::NW_SMALL, main_s);
       if (rc != AGCN_OK) return rc;
+      if (conc && (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(main_s, side->join, 0) != hipSuccess))
+        return fail(AGCN_EDEVICE, "%s: stream join failed", who);
     } else {
     rc = launch_fused_backward(a, fs.n_big, B - fs.n_big,
                                fused_bwd_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K, fs.gb_bwd_w != 0,

@@ -57,11 +57,12 @@ std::atomic<int32_t> g_spec_mode{[] {
 }()};
 extern "C" int32_t agcn_get_spec_mode(void) { return g_spec_mode.load(); }
 std::atomic<int32_t> g_spec_small{[] {
-  const char* e = std::getenv("AGCN_SPEC_SMALL");   // 0: never launch the 8-wave flavour for the small graphs
-  return (e && e[0] == '0') ? 0 : 1;
+  // 0: never launch the 8-wave flavour for the small graphs; 1: after the large graphs' launch; 2: beside it
+  const char* e = std::getenv("AGCN_SPEC_SMALL");
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
 }()};
 extern "C" int32_t agcn_get_spec_small(void) { return g_spec_small.load(); }
-extern "C" void agcn_set_spec_small(int32_t on) { g_spec_small.store(on ? 1 : 0); }
+extern "C" void agcn_set_spec_small(int32_t on) { g_spec_small.store(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 extern "C" void agcn_set_spec_mode(int32_t mode) { g_spec_mode.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
 extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }
 extern "C" void agcn_set_slab_mode(int32_t mode) { g_slab_mode.store(mode ? 1 : 0); }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64;
-  constexpr int RPW = NW == NW_SMALL ? 4 : 8;   // rows of a node-feature matrix one wave may own (n4 <= 32 | 128)
+  constexpr int RPW = NW == NW_SMALL ? 6 : 8;   // rows of a node-feature matrix one wave may own (n4 <= 48 | 128)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
 size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw) {
   const int F4 = (Fin + 15) & ~15, ntm = (n + 15) / 16;
   const int lim = spec::MAXTB * nw;
-  if (ntm * (F4 / 16) > lim || ntm * ntm > lim || ntm * 16 > (nw == spec::NW_SMALL ? 4 : 8) * nw) return ~(size_t)0;
+  if (ntm * (F4 / 16) > lim || ntm * ntm > lim || ntm * 16 > (nw == spec::NW_SMALL ? 6 : 8) * nw) return ~(size_t)0;
   if (nw == spec::NW_SMALL && n > spec::SMALL_N) return ~(size_t)0;
   return sizeof(float) * (size_t)spec::bwd_lds(n, F4, Fout, nw).total;
 }

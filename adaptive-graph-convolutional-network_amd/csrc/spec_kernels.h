@@ -21,11 +21,12 @@ namespace spec {
 // v_pk_fma_f32, v_sub_f32 and v_add_u32 alike, independent operands), and a SIMD only approaches its issue rate
 // (~1.4 cycles per instruction) with four resident waves.  With one graph per CU (256-graph batches) latency is
 // (instructions of the busiest wave) x 5.5 cycles, so a graph is spread over the largest workgroup there is: 16
-// waves.  With many graphs per CU (2048-graph batches) the small graphs (n <= 32: nine in ten) take 8-wave
-// workgroups instead, two or three of which fit a CU at once, so that one graph's waits (barriers, LDS and memory
-// round trips: ~60 % of a wave's life) are filled by another graph's instructions.
+// waves.  With many graphs per CU (batches of 1536 graphs and up) the small graphs (n <= 48: all but one or two in a
+// hundred) take 8-wave workgroups instead, two or three of which fit a CU at once, so that one graph's waits
+// (barriers, LDS and memory round trips: ~60 % of a wave's life) are filled by another graph's instructions; the
+// few large graphs run in a launch of their own on a side stream, beside them (agcn_api.hip).
 constexpr int NW_LARGE = 16, NW_SMALL = 8;
-constexpr int SMALL_N = 32;   // largest graph the 8-wave flavour takes
+constexpr int SMALL_N = 48;   // largest graph the 8-wave flavour takes
 
 template <int FIN>
 struct Feat {

@@ -139,7 +139,7 @@ def test_new_entry_points_validate_before_launching(amd):
                                    (lib.agcn_set_param_grad_onepass, lib.agcn_get_param_grad_onepass, (0, 1)),
                                    (lib.agcn_set_fused_mode, lib.agcn_get_fused_mode, (0, 2, 3, 1)),
                                    (lib.agcn_set_spec_mode, lib.agcn_get_spec_mode, (0, 1, 2, 3)),
-                                   (lib.agcn_set_spec_small, lib.agcn_get_spec_small, (0, 1))):
+                                   (lib.agcn_set_spec_small, lib.agcn_get_spec_small, (0, 1, 2))):
         for v in values:
             setter(v)
             assert getter() == v
