@@ -131,7 +131,12 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(ParamGradArgs a)
 // (An XCD-aware workgroup order -- every workgroup of one row split on the same XCD, AGCN_PG_XCD=1 -- cuts this
 // kernel's HBM fetch from 22 MB to 6 MB but makes it SLOWER, 9.4 -> 12.0 us eager / -1.7 % graphs/s on the whole
 // step: the splits' rows then come out of one L2 instead of eight.  Measured; off by default.)
+// TF = 16 | 32 output rows per tile.  32 (two A fragments per wave, four accumulators) halves the number of tiles that
+// re-read every row of X / Gp / dZ: at >= 16k rows the kernel is bound by that L2 traffic (Tox21-shaped B = 2048:
+// 49 -> 3x us), below it by the latency chain of the hand-off, where the smaller tile has more workgroups in flight.
+template <int TF>
 __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs a) {
+  constexpr int NA = TF / 16, TE = TF * 32;   // A fragments per wave, floats per tile
   __shared__ float wsum[16][512 + 16];
   __shared__ int last_flag;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -144,8 +149,8 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   const int S8 = a.xcd ? ((S + 7) & ~7) : S;
   const int t = blockIdx.x / S8, s = blockIdx.x - t * S8;
   if (s >= S) return;
-  const int tfW = (Fin * K + 15) >> 4, tcW = (Fout + 31) >> 5;
-  const int tfM = (Fin + 15) >> 4, tcM = (Fin + 31) >> 5;
+  const int tfW = (Fin * K + TF - 1) / TF, tcW = (Fout + 31) >> 5;
+  const int tfM = (Fin + TF - 1) / TF;
   int p, rem;                               // problem, tile index inside it
   if (t < tfW * tcW) { p = 0; rem = t; }
   else if (t < tfW * tcW + tcW) { p = 1; rem = t - tfW * tcW; }
@@ -153,60 +158,82 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   const int Fa = p == 0 ? Fin * K : (p == 1 ? 1 : Fin), Fb = p == 2 ? Fin : Fout;
   const int tf = p == 0 ? tfW : (p == 1 ? 1 : tfM);
   const int itc = rem / tf, itf = rem - itc * tf;
-  const int f0 = itf * 16, c0 = itc * 32;
+  const int f0 = itf * TF, c0 = itc * 32;
   const int last_row = a.rows - 1;
   const int r_begin = s * a.chunk_rows + wave * a.wgs_per_chunk;   // chunk_rows: rows per split, wgs_per_chunk: rows per wave
   const int r_end = min(min(a.rows, (s + 1) * a.chunk_rows), r_begin + a.wgs_per_chunk);
 
-  const int j = min(f0 + r, Fa - 1);
-  const bool jv = (f0 + r) < Fa;
-  const float* Ap;
-  int64_t lda;
-  if (p == 0) {
-    const int f = j / K, kx = j - f * K;
-    if (kx == 0) { Ap = a.X + f; lda = a.ldx; }
-    else { Ap = a.sv_X + (int64_t)(kx - 1) * a.rows * Fin + f; lda = Fin; }
-  } else if (p == 2) { Ap = a.X + j; lda = a.ldx; }
-  else { Ap = a.X; lda = 0; }
+  const float* Ap[NA];
+  int64_t lda = 0;
+  bool jv[NA];
+#pragma unroll
+  for (int x = 0; x < NA; ++x) {
+    const int j = min(f0 + 16 * x + r, Fa - 1);
+    jv[x] = (f0 + 16 * x + r) < Fa;
+    if (p == 0) {
+      const int f = j / K, kx = j - f * K;
+      if (kx == 0) { Ap[x] = a.X + f; lda = a.ldx; }
+      else { Ap[x] = a.sv_X + (int64_t)(kx - 1) * a.rows * Fin + f; lda = Fin; }
+    } else if (p == 2) { Ap[x] = a.X + j; lda = a.ldx; }
+    else { Ap[x] = a.X; lda = 0; }
+  }
+  // (K == 2 alternates X / sv_X columns with different strides: keep one stride per fragment)
+  int64_t ldax[NA];
+#pragma unroll
+  for (int x = 0; x < NA; ++x) {
+    const int j = min(f0 + 16 * x + r, Fa - 1);
+    ldax[x] = (p == 0) ? ((j % K) == 0 ? (int64_t)a.ldx : (int64_t)Fin) : lda;
+  }
   const float* Bp = (p == 2) ? a.dZ : a.Gp;
   const int ldb = (p == 2) ? Fin : Fout;
   const int cA = min(c0 + r, Fb - 1), cB = min(c0 + 16 + r, Fb - 1);
   const bool cAv = (c0 + r) < Fb, cBv = (c0 + 16 + r) < Fb;
 
-  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  f32x4 acc[NA][2];
+#pragma unroll
+  for (int x = 0; x < NA; ++x) acc[x][0] = acc[x][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int rr = r_begin; rr < r_end; rr += 32) {
-    float av[8], b0[8], b1[8];
+    float av[NA][8], b0[8], b1[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int row = min(rr + 4 * u + q, last_row);
-      av[u] = (p == 1) ? 1.0f : Ap[(int64_t)row * lda];
+#pragma unroll
+      for (int x = 0; x < NA; ++x) av[x][u] = (p == 1) ? 1.0f : Ap[x][(int64_t)row * ldax[x]];
       b0[u] = Bp[(int64_t)row * ldb + cA];
       b1[u] = Bp[(int64_t)row * ldb + cB];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const bool rv = (rr + 4 * u + q) < r_end;
-      const float x = (rv && jv) ? av[u] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, (rv && cAv) ? b0[u] : 0.f, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, (rv && cBv) ? b1[u] : 0.f, acc1, 0, 0, 0);
+      const float y0 = (rv && cAv) ? b0[u] : 0.f, y1 = (rv && cBv) ? b1[u] : 0.f;
+#pragma unroll
+      for (int x = 0; x < NA; ++x) {
+        const float xv = (rv && jv[x]) ? av[x][u] : 0.f;
+        acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, y0, acc[x][0], 0, 0, 0);
+        acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, y1, acc[x][1], 0, 0, 0);
+      }
     }
   }
-  // element e = ff * 32 + c of the 16 x 32 tile; lane holds rows 4q .. 4q+3 of columns r and 16 + r
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    wsum[wave][(4 * q + i) * 32 + r] = acc0[i];
-    wsum[wave][(4 * q + i) * 32 + 16 + r] = acc1[i];
-  }
-  __syncthreads();
   // The hand-off to the tile's last workgroup uses agent-scope (sc1) stores and loads of exactly the bytes
   // handed off -- no release / acquire fence: an agent-scope release would write back the whole L2, which
   // holds megabytes of this step's outputs (measured: 158 us for this kernel with __threadfence()).
-  float* mine = a.part + ((int64_t)t * S + s) * 512;
-  if (tid < 512) {
-    float v = 0.f;
+  float* mine = a.part + ((int64_t)t * S + s) * TE;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) v += wsum[w][tid];
-    __hip_atomic_store(mine + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int x = 0; x < NA; ++x) {
+    // element e = ff * 32 + c of the 16 x 32 half tile x; lane holds rows 4q .. 4q+3 of columns r and 16 + r
+    if (x > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wsum[wave][(4 * q + i) * 32 + r] = acc[x][0][i];
+      wsum[wave][(4 * q + i) * 32 + 16 + r] = acc[x][1][i];
+    }
+    __syncthreads();
+    if (tid < 512) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) v += wsum[w][tid];
+      __hip_atomic_store(mine + 512 * x + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   // Every storing wave drains its sc1 stores BEFORE the barrier that precedes the arrival count: a workgroup-scope
   // barrier alone emits no vmcnt wait on gfx950, and the relaxed counter add could then overtake the partial tile
@@ -219,19 +246,19 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   }
   __syncthreads();
   if (last_flag) {
-    if (tid < 512) {
-      const float* base = a.part + (int64_t)t * S * 512 + tid;
+    for (int e = tid; e < TE; e += 1024) {
+      const float* base = a.part + (int64_t)t * S * TE + e;
       float v = 0.f;
       for (int s0 = 0; s0 < S; s0 += 8) {   // eight loads in flight, added in split order
         float l[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          l[u] = __hip_atomic_load(base + (int64_t)min(s0 + u, S - 1) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          l[u] = __hip_atomic_load(base + (int64_t)min(s0 + u, S - 1) * TE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (s0 + u < S) v += l[u];
       }
-      const int ff = f0 + (tid >> 5), c = c0 + (tid & 31);
+      const int ff = f0 + (e >> 5), c = c0 + (e & 31);
       if (ff < Fa && c < Fb) {
         if (p == 0) a.dweight[(int64_t)ff * Fout + c] = v;
         else if (p == 1) a.dbias[c] = v;
@@ -252,15 +279,23 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
 }
 
 namespace {
-int pg_tiles(int Fin, int Fout, int K, bool paper) {
-  const int tfW = (Fin * K + 15) / 16, tcW = (Fout + 31) / 32;
-  const int tfM = (Fin + 15) / 16, tcM = (Fin + 31) / 32;
+// output rows per tile of the one-pass kernel: 32 when the row count makes the kernel bandwidth-bound
+int pg_tf(int rows) {
+  static const int force = [] { const char* e = std::getenv("AGCN_PG_TF"); return e ? std::atoi(e) : 0; }();
+  if (force == 16 || force == 32) return force;
+  return rows >= 49152 ? 32 : 16;   // measured: 18k rows 28.8 | 34.4 us (16 | 32), 36k: 49 | 48.5, 73k: 165 | 110
+}
+int pg_tiles(int Fin, int Fout, int K, bool paper, int TF) {
+  const int tfW = (Fin * K + TF - 1) / TF, tcW = (Fout + 31) / 32;
+  const int tfM = (Fin + TF - 1) / TF, tcM = (Fin + 31) / 32;
   return tfW * tcW + tcW + (paper ? tfM * tcM : 0);
 }
 // rows per wave (multiple of 32) and number of row splits
 void pg_split(int rows, int* rows_per_wave, int* S) {
+  static const int force = [] { const char* e = std::getenv("AGCN_PG_RPW"); return e ? std::atoi(e) : 0; }();
   int rpw = 32;   // measured: 32 / 64 / 96 rows per wave are within 5 %, 128 is 30 % slower
   while ((rows + 16 * rpw - 1) / (16 * rpw) > 64) rpw += 32;
+  if (force >= 32) rpw = force / 32 * 32;
   *rows_per_wave = rpw;
   *S = std::max(1, (rows + 16 * rpw - 1) / (16 * rpw));
 }
@@ -271,8 +306,9 @@ int pg_mode() { return agcn_get_param_grad_onepass(); }
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper) {
   int rpw, S;
   pg_split(rows, &rpw, &S);
-  const size_t nt = (size_t)pg_tiles(Fin, Fout, K, paper != 0);
-  return nt * S * 512 + ((nt + 63) / 64) * 64;
+  const int TF = pg_tf(rows);
+  const size_t nt = (size_t)pg_tiles(Fin, Fout, K, paper != 0, TF);
+  return nt * S * (TF * 32) + ((nt + 63) / 64) * 64;
 }
 
 int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int32_t Fin, int32_t Fout, int32_t K,
@@ -281,9 +317,10 @@ int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int3
   if (pg_mode() != 1 || !part || part_floats < param_grad_onepass_floats(rows, Fin, Fout, K, paper)) return nullptr;
   int rpw, S;
   pg_split(rows, &rpw, &S);
-  const int nt = pg_tiles(Fin, Fout, K, paper != 0);
+  const int TF = pg_tf(rows);
+  const int nt = pg_tiles(Fin, Fout, K, paper != 0, TF);
   *count = nt;
-  return reinterpret_cast<int32_t*>(part + (size_t)nt * S * 512);
+  return reinterpret_cast<int32_t*>(part + (size_t)nt * S * (TF * 32));
 }
 
 int launch_param_grads(const ParamGradArgs& a, void* stream) {
@@ -292,9 +329,10 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
     ParamGradArgs aa = a;
     int rpw, S;
     pg_split(a.rows, &rpw, &S);
-    const int nt = pg_tiles(a.Fin, a.Fout, a.K, a.paper != 0);
+    const int TF = pg_tf(a.rows);
+    const int nt = pg_tiles(a.Fin, a.Fout, a.K, a.paper != 0, TF);
     aa.n_chunks = S; aa.wgs_per_chunk = rpw; aa.chunk_rows = 16 * rpw;
-    aa.counters = reinterpret_cast<int32_t*>(a.part + (size_t)nt * S * 512);
+    aa.counters = reinterpret_cast<int32_t*>(a.part + (size_t)nt * S * (TF * 32));
     if (!a.counters_zeroed) {
       hipError_t e = hipMemsetAsync(aa.counters, 0, sizeof(int32_t) * (size_t)nt, s);
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad counters memset: %s", hipGetErrorString(e));
@@ -302,7 +340,9 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
     prof_begin(PK_PARAM_ONEPASS, stream);
     static const int xcd = [] { const char* e = std::getenv("AGCN_PG_XCD"); return (e && e[0] == '1') ? 1 : 0; }();
     aa.xcd = xcd;
-    hipLaunchKernelGGL(param_grad_onepass_kernel, dim3((unsigned)(nt * (xcd ? ((S + 7) & ~7) : S))), dim3(1024), 0, s, aa);
+    const dim3 grid((unsigned)(nt * (xcd ? ((S + 7) & ~7) : S)));
+    if (TF == 32) hipLaunchKernelGGL(param_grad_onepass_kernel<32>, grid, dim3(1024), 0, s, aa);
+    else hipLaunchKernelGGL(param_grad_onepass_kernel<16>, grid, dim3(1024), 0, s, aa);
     prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_onepass launch: %s", hipGetErrorString(e));
