@@ -11,8 +11,8 @@ from .layers import (SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, 
                      MultitaskHead, Layer)
 from .graphs import (SequentialGraphMol, ResidualGraphMol, ResidualGraphMolResLap, DenseConnectedGraph,  # noqa: F401
                      DenseConnectedGraphResLap)
-from .store import GraphStore  # noqa: F401
-from .engine import GraphedStep, SgcLLEpochStep, SgcLLStep  # noqa: F401
+from .store import GraphStore, ResidentStore  # noqa: F401
+from .engine import GraphedStep, SgcLLEpochLanes, SgcLLEpochStep, SgcLLStep  # noqa: F401
 from . import dist  # noqa: F401
 
 __version__ = "0.1.0"

@@ -60,6 +60,16 @@ class GraphStoreC(C.Structure):
                 ("val", C.c_void_p), ("symmetric", C.c_void_p)]
 
 
+class ResidentStoreC(C.Structure):
+    _fields_ = [("host", GraphStoreC), ("X_dev", C.c_void_p), ("rowptr_dev", C.c_void_p), ("col_dev", C.c_void_p),
+                ("val_dev", C.c_void_p)]
+
+
+class StagedBatch(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("max_n", C.c_int32), ("symmetric", C.c_int32),
+                ("stage_bytes", C.c_int64), ("plan", PlanInfo)]
+
+
 MODE = {"reference": 0, "paper": 1}
 VARIANT = {"SGC_LL": 0, "SGC_LL_Reslap": 1}
 ACT = {None: 0, "linear": 0, "relu": 1, "tanh": 2}
@@ -74,7 +84,8 @@ SYMBOLS = [
     "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
     "agcn_multitask_ce_workspace_bytes", "agcn_multitask_ce_forward", "agcn_multitask_ce_backward",
     "agcn_graph_pool_forward", "agcn_graph_pool_backward",
-    "agcn_store_batch_sizes", "agcn_store_pack_batch", "agcn_cast_rows", "agcn_rows_pack", "agcn_rows_unpack",
+    "agcn_store_batch_sizes", "agcn_store_pack_batch", "agcn_store_stage_bytes", "agcn_store_stage_batch",
+    "agcn_cast_rows", "agcn_rows_pack", "agcn_rows_unpack",
     "agcn_version", "agcn_last_error", "agcn_get_lds_limit", "agcn_set_lds_limit",
     "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
     "agcn_get_fused_global_b", "agcn_set_fused_global_b", "agcn_get_param_grad_onepass", "agcn_set_param_grad_onepass",
@@ -136,6 +147,11 @@ def _declare(lib):
     lib.agcn_store_batch_sizes.argtypes = [C.POINTER(GraphStoreC), P, I32, P, P, P]
     lib.agcn_store_pack_batch.restype = C.c_int
     lib.agcn_store_pack_batch.argtypes = [C.POINTER(GraphStoreC), P, I32, P, P, I32, P, P, P, P, I32]
+    lib.agcn_store_stage_bytes.restype = SZ
+    lib.agcn_store_stage_bytes.argtypes = [I32, C.c_int64]
+    lib.agcn_store_stage_batch.restype = C.c_int
+    lib.agcn_store_stage_batch.argtypes = [C.POINTER(ResidentStoreC), P, I32, P, P, SZ, P, I32, C.c_int64, P, P, P,
+                                           C.c_int64, C.POINTER(StagedBatch), P]
     lib.agcn_graph_pool_forward.restype = C.c_int
     lib.agcn_graph_pool_forward.argtypes = [P, P, C.POINTER(GraphBatch), P, I32, I32, P, P, P]
     lib.agcn_graph_pool_backward.restype = C.c_int

@@ -72,13 +72,20 @@ class Plan(object):
         _ffi.check(lib.agcn_plan_build(n.ctypes.data, B, int(row_stride), self.host.ctypes.data, nbytes))
         info = _ffi.PlanInfo()
         _ffi.check(lib.agcn_plan_info(self.host.ctypes.data, C.byref(info)))
+        self._adopt(info, row_stride)
+        if device is not None:
+            self.to(device)
+
+    def _adopt(self, info, row_stride):
+        B = info.B
         self.info = info
         self.B, self.N1, self.rows, self.max_n = info.B, info.N1, info.rows, info.max_n
         self.N2, self.tile_elems = info.N2, info.tile_elems
         self.row_stride = int(row_stride)
+        host = self.host
 
         def view(off, dtype, count):
-            return self.host[off:off + count * np.dtype(dtype).itemsize].view(dtype)
+            return host[off:off + count * np.dtype(dtype).itemsize].view(dtype)
 
         self.n = view(info.off_n, np.int32, B)
         self.row_off = view(info.off_row_off, np.int32, B + 1)
@@ -89,8 +96,18 @@ class Plan(object):
         self.slab_row = view(info.off_slab_row, np.int32, info.n_slabs)
         self.dev = None
         self.device = None
-        if device is not None:
-            self.to(device)
+
+    @classmethod
+    def from_blob(cls, host, info, dev, device, host_ptr=None):
+        """A packed plan that already exists as a host blob (numpy uint8 view, e.g. of pinned memory) with its
+        device copy `dev` (what agcn_store_stage_batch leaves behind); `info` is its AgcnPlanInfo."""
+        self = cls.__new__(cls)
+        self.host = host
+        self._adopt(info, 0)
+        self.dev, self.device = dev, device
+        if host_ptr is not None:
+            self.__dict__["_host_ptr"] = host_ptr
+        return self
 
     def to(self, device):
         device = torch.device(device)

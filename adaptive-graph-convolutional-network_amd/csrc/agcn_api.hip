@@ -106,12 +106,37 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
     if (pi.B - sf >= 1024) f->spec_small_first = sf;
   }
 }
+// A batch whose few largest graphs exceed the specialised kernels' LDS plan (n > 96: HIV-shaped batches have one or two
+// such molecules in 40 % of the batches): those graphs take the slab-parallel pipeline on the side stream, everything
+// else the specialised kernels beside it.
+void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host, size_t lim) {
+  const AgcnPlanInfo& pi = host.info;
+  // opt-in (agcn_set_fused_mode(3)): measured SLOWER than the whole batch on the slab path -- the side chain's six
+  // launches each wait for CUs the specialised workgroups hold (HIV-shaped epoch: 1.58 M graphs/s mixed, 1.78 M all-slab)
+  if (agcn_get_fused_mode() < 3 || agcn_get_spec_mode() != 3) return;
+  if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
+  if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || !use_slabs(d, g, pi)) return;
+  int nb = 0, ns = 0;
+  while (nb < pi.B) {
+    const int n = host.n[host.order[nb]];
+    if (std::max(spec_fwd_lds_bytes(n, d->Fin, d->Fout, spec::NW_LARGE),
+                 spec_bwd_lds_bytes(n, d->Fin, d->Fout, spec::NW_LARGE)) <= lim) break;
+    ns += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
+    ++nb;
+  }
+  if (nb == 0 || nb == pi.B || nb > std::max(2, pi.B / 16)) return;
+  FusedSplit m{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  m.mode = 2; m.n_big = nb; m.n_big_slabs = ns; m.thr = host.n[host.order[nb]]; m.big_pg = 0;
+  m.spec_fwd = m.spec_bwd = 1; m.spec_bwd_first = nb; m.spec_small_first = pi.B;
+  *f = m;
+}
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host);
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
   FusedSplit f = fused_split_general(d, g, host);
   size_t lim = (size_t)agcn_get_lds_limit();
   if (lim > 160 * 1024) lim = 160 * 1024;
   pick_spec(&f, d, host, lim);
+  if (!(f.mode == 1 && f.spec_fwd && f.spec_bwd)) mixed_spec(&f, d, g, host, lim);
   return f;
 }
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
@@ -450,8 +475,12 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
       rc = launch_rows_gemm(g, RG_FILTER, ss.s);
       if (rc != AGCN_OK) return rc;
     }
-    rc = launch_fused_forward(a, fs.n_big, host.info.B - fs.n_big,
-                              fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), false, hip_stream);
+    if (fs.spec_fwd)
+      rc = launch_spec_forward(a, fs.n_big, host.info.B - fs.n_big,
+                               spec_fwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, spec::NW_LARGE), spec::NW_LARGE, main_s);
+    else
+      rc = launch_fused_forward(a, fs.n_big, host.info.B - fs.n_big,
+                                fused_lds_bytes(fs.thr, desc->Fin, desc->Fout, desc->K), false, hip_stream);
     if (rc != AGCN_OK) return rc;
     if (hipEventRecord(ss.join, ss.s) != hipSuccess || hipStreamWaitEvent(main_s, ss.join, 0) != hipSuccess)
       return fail(AGCN_EDEVICE, "%s: stream join failed", who);
@@ -599,7 +628,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       // graphs are scheduled largest first: the leading fs.spec_bwd_first ones are too large for the specialised
       // kernel's LDS plan and take the general fused kernel, the rest the specialised one (disjoint graphs)
       const int sf = fs.spec_bwd_first;
-      if (sf > 0)
+      if (sf > 0 && fs.mode == 1)
         rc = launch_fused_backward(a, 0, sf,
                                    fused_bwd_lds_bytes_gb(fs.thr, desc->Fin, desc->Fout, desc->K, fs.gb_bwd_w != 0,
                                                           fs.gb_bwd_m != 0),

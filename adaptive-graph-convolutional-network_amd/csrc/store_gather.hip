@@ -1,0 +1,144 @@
+// Batches out of a graph store that is RESIDENT in HBM (include/agcn.h, "graph store resident in HBM").
+// The reference re-reads its dataset shards from disk and rebuilds the feed on the host every step
+// (utils/dataset/diskdataset.py:239-295 -> models/tf_modules/graph_topology.py:84-135); with 288 GB of HBM the
+// whole dataset lives on the device, and a batch is one small table upload + one gather launch.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "agcn_internal.h"
+
+namespace agcn {
+namespace {
+
+struct GatherRec {      // one per graph of the batch, behind the plan in the stage blob
+  int64_t src_row;      // first row of the graph in the store
+  int64_t src_nnz;      // rowptr[src_row]
+  int32_t dst_nnz;      // first CSR entry of the graph in the batch
+  int32_t pad;
+};
+
+struct GatherArgs {
+  const int32_t* n;         // plan arrays (device)
+  const int32_t* row_off;
+  const GatherRec* rec;
+  const float* X;
+  const int64_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  float* X_out;
+  int32_t* rowptr_out;
+  int32_t* col_out;
+  float* val_out;
+  int32_t F, ldx_out;
+};
+
+// one workgroup per graph: contiguous segments in, contiguous segments out
+__global__ __launch_bounds__(256) void store_gather_kernel(GatherArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = a.n[b], r0 = a.row_off[b];
+  const GatherRec rc = a.rec[b];
+  const int F = a.F;
+  const float* xs = a.X + rc.src_row * F;
+  if (a.ldx_out == F) {
+    float* xd = a.X_out + (int64_t)r0 * F;
+    for (int i = tid; i < n * F; i += 256) xd[i] = xs[i];
+  } else {
+    for (int i = tid; i < n * F; i += 256) {
+      const int r = i / F, f = i - r * F;
+      a.X_out[(int64_t)(r0 + r) * a.ldx_out + f] = xs[i];
+    }
+  }
+  const int64_t shift = (int64_t)rc.dst_nnz - rc.src_nnz;
+  // entry r0 + n is the next graph's first (same value from both) or the batch's total
+  for (int i = tid; i <= n; i += 256) a.rowptr_out[r0 + i] = (int32_t)(a.rowptr[rc.src_row + i] + shift);
+  const int nz = (int)(a.rowptr[rc.src_row + n] - rc.src_nnz);
+  for (int i = tid; i < nz; i += 256) {
+    a.col_out[rc.dst_nnz + i] = a.col[rc.src_nnz + i];
+    a.val_out[rc.dst_nnz + i] = a.val[rc.src_nnz + i];
+  }
+}
+
+inline size_t align16(size_t v) { return (v + 15) / 16 * 16; }
+
+}  // namespace
+}  // namespace agcn
+
+extern "C" size_t agcn_store_stage_bytes(int32_t B, int64_t rows) {
+  if (B < 1 || rows < B) return 0;
+  // plan of B graphs over `rows` packed rows: slabs <= rows / 16 + B; sized through the plan's own layout function
+  // with the worst split of the rows (every graph one slab more than its share)
+  std::vector<int32_t> n((size_t)B, (int32_t)(rows / B));
+  n[0] += (int32_t)(rows - (rows / B) * B);
+  size_t plan = agcn_plan_bytes_for(n.data(), B, 0);
+  // slab tables: 8 bytes per slab; uneven graphs have at most B more slabs than the even split
+  plan += 8 * (size_t)B + 64;
+  return agcn::align16(plan) + sizeof(agcn::GatherRec) * (size_t)B;
+}
+
+extern "C" int agcn_store_stage_batch(const AgcnResidentStore* st, const int64_t* ids, int32_t B, void* stage_host,
+                                      void* stage_dev, size_t stage_cap, float* X_out, int32_t ldx_out,
+                                      int64_t rows_cap, int32_t* rowptr_out, int32_t* col_out, float* val_out,
+                                      int64_t nnz_cap, AgcnStagedBatch* info, void* hip_stream) {
+  using agcn::fail;
+  const char* who = "agcn_store_stage_batch";
+  if (!st || !ids || B < 1 || !stage_host || !stage_dev || !X_out || !rowptr_out || !col_out || !val_out || !info)
+    return fail(AGCN_EINVAL, "%s: null argument", who);
+  const AgcnGraphStore& h = st->host;
+  if (h.n_graphs < 1 || h.F < 1 || !h.n || !h.row_off || !h.rowptr)
+    return fail(AGCN_EINVAL, "%s: incomplete host index", who);
+  if (!st->X_dev || !st->rowptr_dev || !st->col_dev || !st->val_dev)
+    return fail(AGCN_EINVAL, "%s: store is not resident (null device array)", who);
+  if (ldx_out < h.F) return fail(AGCN_EINVAL, "%s: ldx_out smaller than F", who);
+  static thread_local std::vector<int32_t> n;
+  n.resize((size_t)B);
+  int64_t rows = 0, nnz = 0;
+  int32_t mx = 0, sym = h.symmetric ? 1 : 0;
+  for (int32_t b = 0; b < B; ++b) {
+    const int64_t g = ids[b];
+    if (g < 0 || g >= h.n_graphs) return fail(AGCN_EINVAL, "%s: graph id %lld out of range", who, (long long)g);
+    n[b] = h.n[g];
+    rows += h.n[g];
+    nnz += h.rowptr[h.row_off[g + 1]] - h.rowptr[h.row_off[g]];
+    mx = n[b] > mx ? n[b] : mx;
+    if (h.symmetric && !h.symmetric[g]) sym = 0;
+  }
+  if (rows > rows_cap || nnz > nnz_cap)
+    return fail(AGCN_ENOSPACE, "%s: batch (%lld rows, %lld entries) exceeds the output buffers (%lld, %lld)", who,
+                (long long)rows, (long long)nnz, (long long)rows_cap, (long long)nnz_cap);
+  if (nnz > INT32_MAX) return fail(AGCN_EINVAL, "%s: batch too large for int32 offsets", who);
+  const size_t pbytes = agcn_plan_bytes_for(n.data(), B, 0);
+  const size_t tab_off = agcn::align16(pbytes);
+  const size_t total = tab_off + sizeof(agcn::GatherRec) * (size_t)B;
+  if (total > stage_cap) return fail(AGCN_ENOSPACE, "%s: stage blob needs %zu bytes, %zu given", who, total, stage_cap);
+  int rc = agcn_plan_build(n.data(), B, 0, stage_host, pbytes);
+  if (rc != AGCN_OK) return rc;
+  agcn::GatherRec* rec = reinterpret_cast<agcn::GatherRec*>(static_cast<char*>(stage_host) + tab_off);
+  int64_t z = 0;
+  for (int32_t b = 0; b < B; ++b) {
+    const int64_t g = ids[b], r0 = h.row_off[g];
+    rec[b].src_row = r0;
+    rec[b].src_nnz = h.rowptr[r0];
+    rec[b].dst_nnz = (int32_t)z;
+    rec[b].pad = 0;
+    z += h.rowptr[h.row_off[g + 1]] - h.rowptr[r0];
+  }
+  rc = agcn_plan_info(stage_host, &info->plan);
+  if (rc != AGCN_OK) return rc;
+  info->rows = rows; info->nnz = nnz; info->max_n = mx; info->symmetric = sym; info->stage_bytes = (int64_t)total;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  hipError_t e = hipMemcpyAsync(stage_dev, stage_host, total, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: blob upload: %s", who, hipGetErrorString(e));
+  agcn::GatherArgs a;
+  const char* d = static_cast<const char*>(stage_dev);
+  a.n = reinterpret_cast<const int32_t*>(d + info->plan.off_n);
+  a.row_off = reinterpret_cast<const int32_t*>(d + info->plan.off_row_off);
+  a.rec = reinterpret_cast<const agcn::GatherRec*>(d + tab_off);
+  a.X = st->X_dev; a.rowptr = st->rowptr_dev; a.col = st->col_dev; a.val = st->val_dev;
+  a.X_out = X_out; a.rowptr_out = rowptr_out; a.col_out = col_out; a.val_out = val_out;
+  a.F = h.F; a.ldx_out = ldx_out;
+  hipLaunchKernelGGL(agcn::store_gather_kernel, dim3((unsigned)B), dim3(256), 0, s, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: gather launch: %s", who, hipGetErrorString(e));
+  return AGCN_OK;
+}

@@ -216,7 +216,8 @@ class SgcLLEpochStep(object):
             self._ws = torch.zeros(int(wb * 1.5), dtype=torch.uint8, device=self.device)
         return rb
 
-    def step(self, batch, dY=None):
+    def step(self, batch, dY=None, stream=None):
+        """Forward + backward of `batch` on `stream` (a torch stream; default: the current one)."""
         plan = batch.plan
         X = batch.X
         if X.dtype != torch.float32 or not X.is_contiguous() or X.shape[1] != self.cfg.Fin:
@@ -225,7 +226,7 @@ class SgcLLEpochStep(object):
         if dY is not None and (dY.dtype != torch.float32 or not dY.is_contiguous() or dY.shape[1] != self.cfg.Fout):
             raise ValueError("dY must be contiguous fp32 [rows, Fout]")
         gb = _gbatch(batch, X, None)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = (torch.cuda.current_stream(self.device) if stream is None else stream).cuda_stream
         d, p, o = C.byref(self.desc), C.byref(self.pr), C.byref(self.out)
         _ffi.check(self.lib.agcn_sgc_ll_forward(d, C.byref(gb), p, o, self._reserve.data_ptr(), rb, self._ws.data_ptr(),
                                                 self._ws.numel(), stream))
@@ -251,6 +252,43 @@ class SgcLLEpochStep(object):
     @property
     def res_W(self):
         return self._res_W[:self.plan.tile_elems]
+
+
+class SgcLLEpochLanes(object):
+    """`lanes` independent `SgcLLEpochStep`s, each on its own stream with its own buffers, fed round-robin from a
+    `ResidentStore`: consecutive batches overlap on the GPU.  A step of one 256-graph batch is as long as the dependent
+    chain of its largest graph (one workgroup per graph) and leaves most CUs idle behind it; a second batch in flight
+    fills them.  Each batch is computed exactly as by a lone `SgcLLEpochStep` (same kernels, same bits).
+
+    Valid wherever consecutive batches do not depend on each other: evaluation / prediction passes and gradient
+    accumulation over `lanes` micro-batches (sum the lanes' `bucket`s; SUM semantics as in dist.py).  Plain SGD with a
+    parameter update after every batch has that dependency: use one lane.
+
+        rs = store.to_device(dev, 256, lanes=2)
+        ep = SgcLLEpochLanes(layer, rs, lanes=2)
+        for j, sel in enumerate(selections):
+            step = ep.step(sel)            # the SgcLLEpochStep that holds this batch's results (on ep.streams[j % 2])
+        ep.synchronize()
+    """
+
+    def __init__(self, layer, rstore, lanes=2):
+        if len(rstore.lanes) < lanes:
+            raise ValueError("the resident store was built with %d lane(s)" % len(rstore.lanes))
+        self.rstore, self.device = rstore, rstore.device
+        self.steps = [SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device)
+                      for _ in range(lanes)]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(lanes)]
+        self._j = 0
+
+    def step(self, graph_ids, dY=None):
+        k = self._j % len(self.steps)
+        self._j += 1
+        s = self.streams[k]
+        return self.steps[k].step(self.rstore.stage(graph_ids, lane=k, stream=s), dY, stream=s)
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
 
 
 class GraphedStep(object):

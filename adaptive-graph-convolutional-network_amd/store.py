@@ -137,6 +137,16 @@ class GraphStore(object):
         dev = torch.device(device)
         return self._upload(self._pack(graph_ids, slot, dev.type == "cuda", n_threads), dev)
 
+    def to_device(self, device, batch_cap, slots=4, lanes=1):
+        """The store resident in HBM (`ResidentStore`): arrays uploaded once, batches gathered on the device."""
+        return ResidentStore(self, device, batch_cap, slots, lanes)
+
+    def _selections(self, batch_size, deterministic, rng):
+        N = len(self)
+        perm = np.arange(N) if deterministic else (rng if rng is not None else np.random).permutation(N)
+        pts = np.linspace(0, N, int(np.ceil(float(N) / batch_size)) + 1, dtype=int)
+        return [perm[pts[j]:pts[j + 1]] for j in range(len(pts) - 1)]
+
     def iterbatches(self, batch_size, device, deterministic=False, rng=None, n_threads=1, prefetch=0):
         """Same batching rule as DiskDataset.iterbatches (diskdataset.py:263-283): a permutation of the samples
         (identity when `deterministic`), cut at np.linspace(0, N, ceil(N / batch_size) + 1, dtype=int).
@@ -145,12 +155,9 @@ class GraphStore(object):
         only after the uploads that read it have completed.  (Measured on MI355X, 256-graph HIV-shaped batches:
         ingest alone 2.2 M graphs/s without and 2.6 M graphs/s with prefetch; with an eager autograd layer step
         per batch the Python side is the bottleneck either way, hence off by default.)"""
-        N = len(self)
         dev = torch.device(device)
         pin = dev.type == "cuda"
-        perm = np.arange(N) if deterministic else (rng if rng is not None else np.random).permutation(N)
-        pts = np.linspace(0, N, int(np.ceil(float(N) / batch_size)) + 1, dtype=int)
-        sels = [perm[pts[j]:pts[j + 1]] for j in range(len(pts) - 1)]
+        sels = self._selections(batch_size, deterministic, rng)
         extra = lambda sel: (None if self.y is None else self.y[sel], None if self.w is None else self.w[sel],  # noqa: E731
                              self.ids[sel])
         if prefetch <= 0:
@@ -193,3 +200,96 @@ class GraphStore(object):
                 except queue.Empty:
                     pass
                 th.join(timeout=0.01)
+
+
+class ResidentStore(object):
+    """A `GraphStore` whose arrays live in HBM (288 GB hold whole datasets: the HIV-sized store is 0.3 GB).
+
+    The reference reads its shards from disk and rebuilds the padded feed on the host every step
+    (diskdataset.py:239-295 -> graph_topology.py:84-135).  Here X / CSR of ALL graphs are uploaded once; a batch is
+    ONE C-ABI call (`agcn_store_stage_batch`): plan + gather table built into a pinned blob (tens of KB), one
+    asynchronous copy of that blob, one gather launch into capacity-sized device buffers.  No per-batch feature
+    bytes cross PCIe and no per-batch device memory is allocated.
+
+    `stage(ids)` returns a `GraphBatch` whose tensors are VIEWS of the capacity buffers and whose plan lives in one
+    of `slots` pinned blobs: it is valid until the next `stage()` on the same lane on the device side (stream
+    order) and until `slots` further batches on the host side.  `lanes` > 1 keeps that many independent sets of
+    capacity buffers, so that batches staged on different streams can be in flight together (`SgcLLEpochLanes`)."""
+
+    def __init__(self, store, device, batch_cap, slots=4, lanes=1):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _ffi.AgcnError("a resident store lives on the GPU: there is no CPU fallback")
+        self.store, self.device = store, dev
+        self.batch_cap = int(batch_cap)
+        self.F = store.F
+        up = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
+        self.X, self.rowptr = up(store.X), up(store.rowptr)
+        self.col = up(store.col if store.col.size else np.zeros(1, np.int32))
+        self.val = up(store.val if store.val.size else np.zeros(1, np.float32))
+        # capacity of any batch of <= batch_cap graphs: the batch_cap largest graphs / Laplacians of the store
+        k = min(self.batch_cap, len(store))
+        nnz_g = store.rowptr[store.row_off[1:]] - store.rowptr[store.row_off[:-1]]
+        self.rows_cap = int(np.sort(store.n)[-k:].sum())
+        self.nnz_cap = max(1, int(np.sort(nnz_g)[-k:].sum()))
+        self.tiles_cap = int(((np.sort(store.n.astype(np.int64))[-k:] ** 2 + 3) // 4 * 4).sum())
+        lib = _ffi.lib()
+        self.stage_cap = int(lib.agcn_store_stage_bytes(k, max(self.rows_cap, k)))
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.lanes = []
+        for _ in range(max(1, int(lanes))):
+            ln = {"X": torch.zeros((self.rows_cap, self.F), dtype=torch.float32, device=dev),
+                  "rowptr": torch.zeros(self.rows_cap + 1, **i32), "col": torch.zeros(self.nnz_cap, **i32),
+                  "val": torch.zeros(self.nnz_cap, dtype=torch.float32, device=dev),
+                  "stage": torch.zeros(self.stage_cap, dtype=torch.uint8, device=dev)}
+            ln["args"] = (ln["stage"].data_ptr(), self.stage_cap, ln["X"].data_ptr(), self.F, self.rows_cap,
+                          ln["rowptr"].data_ptr(), ln["col"].data_ptr(), ln["val"].data_ptr(), self.nnz_cap)
+            self.lanes.append(ln)
+        self._slots = []
+        for _ in range(max(2, int(slots)) * len(self.lanes)):
+            t = torch.zeros(self.stage_cap, dtype=torch.uint8, pin_memory=True)
+            self._slots.append({"t": t, "np": t.numpy(), "ptr": t.data_ptr(), "done": None})
+        self._k = 0
+        h = store._c
+        self._c = _ffi.ResidentStoreC(h, self.X.data_ptr(), self.rowptr.data_ptr(), self.col.data_ptr(),
+                                      self.val.data_ptr())
+        self._info = _ffi.StagedBatch()
+
+    def __len__(self):
+        return len(self.store)
+
+    def stage(self, graph_ids, lane=0, stream=None):
+        """Batch `graph_ids` gathered into lane `lane`'s buffers on `stream` (a torch stream; default: the current
+        one)."""
+        ids = np.ascontiguousarray(graph_ids, dtype=np.int64)
+        B = int(ids.size)
+        if B > self.batch_cap:
+            raise ValueError("batch of %d graphs exceeds the capacity %d" % (B, self.batch_cap))
+        sl = self._slots[self._k]
+        self._k = (self._k + 1) % len(self._slots)
+        if sl["done"] is not None:              # the copy that last read this pinned blob must have executed
+            sl["done"].synchronize()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        info = self._info
+        ln = self.lanes[lane]
+        a = ln["args"]
+        _ffi.check(_ffi.lib().agcn_store_stage_batch(C.byref(self._c), ids.ctypes.data, B, sl["ptr"], a[0], a[1], a[2],
+                                                     a[3], a[4], a[5], a[6], a[7], a[8], C.byref(info),
+                                                     stream.cuda_stream))
+        if sl["done"] is None:
+            sl["done"] = torch.cuda.Event()
+        sl["done"].record(stream)
+        pinfo = _ffi.PlanInfo.from_buffer_copy(info.plan)
+        plan = Plan.from_blob(sl["np"][:pinfo.plan_bytes], pinfo, ln["stage"], self.device, host_ptr=sl["ptr"])
+        rows, nnz = info.rows, info.nnz
+        return GraphBatch(plan, ln["X"][:rows], ln["rowptr"][:rows + 1], ln["col"][:max(nnz, 1)],
+                          ln["val"][:max(nnz, 1)], l0_symmetric=bool(info.symmetric))
+
+    def iterbatches(self, batch_size, deterministic=False, rng=None):
+        """Same batching rule as `GraphStore.iterbatches` / DiskDataset.iterbatches (diskdataset.py:263-283).
+        Yields (GraphBatch, y_batch, w_batch, ids_batch); the batch is valid until the next one is staged."""
+        st = self.store
+        for sel in st._selections(batch_size, deterministic, rng):
+            yield (self.stage(sel), None if st.y is None else st.y[sel], None if st.w is None else st.w[sel],
+                   st.ids[sel])

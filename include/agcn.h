@@ -341,6 +341,34 @@ int agcn_store_pack_batch(const AgcnGraphStore* store, const int64_t* ids, int32
                           float* X_out, int32_t ldx_out, int32_t* rowptr_out, int32_t* col_out, float* val_out,
                           int32_t* symmetric_out, int32_t n_threads);
 
+/* ---- graph store resident in HBM ---------------------------------------------------------------------
+ * 288 GB of HBM hold whole datasets (HIV: 41 127 graphs = 0.3 GB), so the store's X / CSR arrays are uploaded ONCE
+ * and a batch never crosses PCIe again: agcn_store_stage_batch builds the plan of the batch `ids` plus a per-graph
+ * gather table into caller-owned PINNED host memory (`stage_host`), enqueues ONE host-to-device copy of that blob
+ * (tens of KB) and ONE gather launch that writes the packed batch (X rows, batch-global rowptr, col, val) into
+ * caller-owned device buffers -- what agcn_store_pack_batch + five uploads do through the host.  The plan sits at
+ * offset 0 of the blob: `stage_host` / `stage_dev` are the AgcnGraphBatch's plan_host / plan_dev.  The caller keeps
+ * `stage_host` untouched until the copy has executed (an event on `hip_stream`); everything else is stream-ordered. */
+typedef struct AgcnResidentStore {
+  AgcnGraphStore host;       /* host index of the store: n, row_off, rowptr, symmetric are read (X / col / val may be NULL) */
+  const float* X_dev;        /* [R][F]  device copies of the store's arrays */
+  const int64_t* rowptr_dev; /* [R+1] */
+  const int32_t* col_dev;
+  const float* val_dev;
+} AgcnResidentStore;
+typedef struct AgcnStagedBatch {
+  int64_t rows, nnz;
+  int32_t max_n, symmetric;
+  int64_t stage_bytes;       /* bytes of the blob that were written / copied */
+  AgcnPlanInfo plan;         /* what agcn_plan_info would return for the staged plan */
+} AgcnStagedBatch;
+/* upper bound of the blob size for a batch of B graphs with `rows` rows in total */
+size_t agcn_store_stage_bytes(int32_t B, int64_t rows);
+int agcn_store_stage_batch(const AgcnResidentStore* store, const int64_t* ids, int32_t B, void* stage_host,
+                           void* stage_dev, size_t stage_cap, float* X_out, int32_t ldx_out, int64_t rows_cap,
+                           int32_t* rowptr_out, int32_t* col_out, float* val_out, int64_t nnz_cap,
+                           AgcnStagedBatch* info, void* hip_stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel of
  * the path).  Off by default.  agcn_profile_collect waits for the events recorded since the last
  * collect and returns, per kernel id < agcn_profile_kernels(), the total milliseconds and the

@@ -621,6 +621,43 @@ def test_full_size_every_graph_every_gradient(amd, variant, mode, B):
     compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
 
 
+@pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
+def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode):
+    """BASELINE configs[4]'s batch shape (HIV-like sizes, mu = ln 23, up to 222 atoms): a 256-graph batch with a few
+    molecules beyond the specialised kernels' 96-node LDS plan.  By default the whole batch takes the slab kernels;
+    with agcn_set_fused_mode(3) the oversized molecules take the slab kernels on the side stream beside the
+    specialised kernels ("mixed" dispatch).  The launches must be exactly that, and EVERY graph and EVERY gradient
+    must match the float64 oracle either way."""
+    Fin, Fout, K = 75, 64, 2
+    for seed in range(40, 80):
+        sb = orc.synth_batch(seed, 256, mu=np.log(23.0), hi=222)
+        big = int((np.asarray(sb["ns"]) > 96).sum())
+        if 1 <= big <= 4:
+            break
+    else:
+        pytest.fail("no seed gives a batch with 1-4 oversized molecules")
+    ns = [int(v) for v in sb["ns"]]
+    rs = np.random.RandomState(seed)
+    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL)
+    p["alpha"] = np.array([0.8], np.float32)
+    G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
+    caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, orc.SGC_LL, G, None, None)
+    lib = amd._ffi.lib()
+    for fused_mode in (1, 3):      # 1 (default): the whole batch on the slab kernels; 3: mixed dispatch
+        lib.agcn_set_fused_mode(fused_mode)
+        try:
+            out = run_packed(amd, DEV, ns, sb["X"], sb["csr"], p, G, Fin, Fout, K, mode, orc.SGC_LL, None, None)
+            compare_with_oracle(out, caches, tot, orc.SGC_LL, mode, K, has_prev=False)
+            gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(sb["X"], 0), sb["csr"], DEV)
+            layer = make_layer(amd, orc.SGC_LL, Fout, Fin, 256, K, mode, p, DEV)
+            names = amd.SgcLLStep(layer, gb).kernel_names()
+        finally:
+            lib.agcn_set_fused_mode(1)
+        assert "slab_sim_kernel" in names[0] and "slab_bwd1_kernel" in names[1], names
+        assert ("spec_forward_kernel" in names[0]) == (fused_mode == 3), names
+        assert ("spec_backward_kernel" in names[1]) == (fused_mode == 3), names
+
+
 def test_errors_are_loud(amd):
     gb = amd.GraphBatch.from_arrays(np.array([4], np.int32), np.zeros((4, 5), np.float32),
                                     [orc.graph_laplacian([[1], [0, 2], [1, 3], [2]])[:3]], DEV)
@@ -1026,3 +1063,82 @@ def test_epoch_step_static_buffers_match_the_autograd_path(amd):
             assert torch.equal(ep.grads[k], lay.vars[k].grad), k
         seen += gb.plan.B
     assert seen == 700
+
+
+def test_resident_store_batches_are_the_host_packed_batches(amd):
+    """A batch gathered on the device out of the HBM-resident store (one C-ABI call: plan + gather table upload, one
+    gather launch) is bit-identical -- features, CSR, plan blob, symmetry flag -- to the batch the host-side pack
+    produces, for shuffled selections of different sizes (ragged last batch, a single graph, repeated ids), and the
+    layer's outputs and gradients on it are the same bits."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(77, 900, mu=np.log(23.0), hi=222)
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    rs = store.to_device(DEV, 256, slots=2)
+    assert rs.rows_cap >= int(np.sort(data["n"])[-256:].sum())
+    rng = np.random.RandomState(5)
+    sels = [rng.permutation(900)[:256], np.arange(700, 900), np.array([17]), np.array([5, 5, 9, 5]),
+            np.argsort(-data["n"].astype(np.int64))[:256]]         # the 256 largest graphs: exactly at capacity
+    Fin, Fout, K = 75, 64, 2
+    p = orc.init_params(np.random.RandomState(4), Fin, Fout, K)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, 256, K, orc.PAPER, p, DEV)
+    ep_a = amd.SgcLLEpochStep(layer, rows_cap=rs.rows_cap, tiles_cap=rs.tiles_cap, batch_cap=256, device=DEV)
+    ep_b = amd.SgcLLEpochStep(layer, rows_cap=rs.rows_cap, tiles_cap=rs.tiles_cap, batch_cap=256, device=DEV)
+    for sel in sels:
+        ref = store.batch(sel, DEV)
+        gb = rs.stage(sel)
+        torch.cuda.synchronize()
+        assert gb.plan.B == ref.plan.B and gb.plan.rows == ref.plan.rows and gb.plan.tile_elems == ref.plan.tile_elems
+        assert np.array_equal(gb.plan.host, ref.plan.host)
+        assert torch.equal(gb.plan.dev[:ref.plan.host.size].cpu(), torch.from_numpy(ref.plan.host))
+        assert torch.equal(gb.X, ref.X) and torch.equal(gb.l0_rowptr, ref.l0_rowptr)
+        assert torch.equal(gb.l0_col, ref.l0_col) and torch.equal(gb.l0_val, ref.l0_val)
+        assert gb.l0_symmetric == ref.l0_symmetric
+        ep_a.step(ref)
+        ep_b.step(gb)
+        torch.cuda.synchronize()
+        assert torch.equal(ep_a.Y, ep_b.Y) and torch.equal(ep_a.dX, ep_b.dX) and torch.equal(ep_a.res_W, ep_b.res_W)
+        assert torch.equal(ep_a.bucket, ep_b.bucket)
+    with pytest.raises(ValueError):
+        rs.stage(np.arange(257))
+    with pytest.raises(amd.AgcnError):
+        rs.stage(np.array([900]))
+    # a whole epoch through the iterator: every graph exactly once, same cuts as the host-side iterator
+    seen = []
+    for (gb, _, _, ids), (ref, _, _, ids2) in zip(rs.iterbatches(256, deterministic=True),
+                                                  store.iterbatches(256, DEV, deterministic=True)):
+        assert np.array_equal(ids, ids2) and torch.equal(gb.X, ref.X)
+        seen.append(ids)
+    assert np.array_equal(np.concatenate(seen), np.arange(900))
+
+
+def test_epoch_lanes_give_the_single_lane_results(amd):
+    """Batches overlapped on two streams (SgcLLEpochLanes: own buffers per lane) are computed exactly as one after
+    the other on one stream: outputs and gradient buckets of every batch bit-identical."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(55, 1100, mu=np.log(23.0), hi=222)
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    p = orc.init_params(np.random.RandomState(4), 75, 64, 2)
+    layer = make_layer(amd, orc.SGC_LL, 64, 75, 256, 2, orc.PAPER, p, DEV)
+    sels = store._selections(256, False, np.random.RandomState(1))
+    r1 = store.to_device(DEV, 256)
+    ep = amd.SgcLLEpochStep(layer, r1.rows_cap, r1.tiles_cap, 256, device=DEV)
+    want = []
+    for sel in sels:
+        ep.step(r1.stage(sel))
+        torch.cuda.synchronize()
+        want.append((ep.Y.clone(), ep.dX.clone(), ep.bucket.clone()))
+    r2 = store.to_device(DEV, 256, lanes=2)
+    lanes = amd.SgcLLEpochLanes(layer, r2, lanes=2)
+    got = []
+    for j, sel in enumerate(sels):
+        st = lanes.step(sel)
+        if j >= 1:                          # the previous batch (other lane) is still intact while this one runs
+            k = (j - 1) % 2
+            lanes.streams[k].synchronize()
+            prev = lanes.steps[k]
+            got.append((prev.Y.clone(), prev.dX.clone(), prev.bucket.clone()))
+    lanes.synchronize()
+    got.append((st.Y.clone(), st.dX.clone(), st.bucket.clone()))
+    assert len(got) == len(want)
+    for (a, b, c), (x, y, z) in zip(got, want):
+        assert torch.equal(a, x) and torch.equal(b, y) and torch.equal(c, z)

@@ -215,6 +215,34 @@ def main():
                             nodes.data.backward(torch.ones_like(nodes.data))
                     torch.cuda.synchronize(dev)
                     res["%s prefetch=%d" % (what, pf)] = round(G / (time.perf_counter() - t0), 1)
+        # the store RESIDENT in HBM: one upload per dataset, a batch = one table upload + one gather launch
+        t0 = time.perf_counter()
+        rstore = store.to_device(dev, 256)
+        torch.cuda.synchronize(dev)
+        res["resident store upload_s"] = round(time.perf_counter() - t0, 3)
+        ep2 = amd.SgcLLEpochStep(layer, rows_cap=rstore.rows_cap, tiles_cap=rstore.tiles_cap, batch_cap=256, device=dev)
+        for what in ("resident stage", "resident stage+layer(static buffers)"):
+            for rep in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for gb, _, _, _ in rstore.iterbatches(256, deterministic=True):
+                    if what != "resident stage":
+                        ep2.step(gb)
+                torch.cuda.synchronize(dev)
+                res[what] = round(G / (time.perf_counter() - t0), 1)
+        # consecutive batches overlapped on 2 / 3 streams (evaluation passes, gradient accumulation: SgcLLEpochLanes)
+        sels = store._selections(256, True, None)
+        for lanes in (2, 3):
+            rl = store.to_device(dev, 256, lanes=lanes)
+            epl = amd.SgcLLEpochLanes(layer, rl, lanes=lanes)
+            for rep in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for sel in sels:
+                    epl.step(sel)
+                epl.synchronize()
+                res["resident stage+layer, %d lanes" % lanes] = round(G / (time.perf_counter() - t0), 1)
+            del rl, epl
         print(json.dumps({"workload": "epoch over %d HIV-shaped graphs, batches of 256" % G, "mode": args.mode,
                           "store_build_s": round(t_store, 3), "graphs_per_s": res}), flush=True)
 
