@@ -132,9 +132,11 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(ParamGradArgs a)
 // kernel's HBM fetch from 22 MB to 6 MB but makes it SLOWER, 9.4 -> 12.0 us eager / -1.7 % graphs/s on the whole
 // step: the splits' rows then come out of one L2 instead of eight.  Measured; off by default.)
 // TF = 16 | 32 output rows per tile.  32 (two A fragments per wave, four accumulators) halves the number of tiles that
-// re-read every row of X / Gp / dZ: at >= 16k rows the kernel is bound by that L2 traffic (Tox21-shaped B = 2048:
-// 49 -> 3x us), below it by the latency chain of the hand-off, where the smaller tile has more workgroups in flight.
-template <int TF>
+// re-read every row of X / Gp / dZ; it paid only while the large-batch kernel was bound by HBM re-fetches (plain
+// workgroup order) and is kept for diagnostics (AGCN_PG_TF=32).
+// KS = MFMA k-steps (of 4 rows) whose operand loads a wave issues in one go.  8; 16 (both round trips of a 64-row slice
+// in flight together) was measured SLOWER -- B = 2048: 51 vs 38 us -- the registers cost the second resident workgroup.
+template <int TF, int KS>
 __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs a) {
   constexpr int NA = TF / 16, TE = TF * 32;   // A fragments per wave, floats per tile
   __shared__ float wsum[16][512 + 16];
@@ -147,10 +149,22 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   // index running fastest over a multiple of 8 slots every workgroup of split s lands on XCD s % 8 and a row
   // range of X / Gp / dZ is fetched into ONE L2
   const int S8 = a.xcd ? ((S + 7) & ~7) : S;
-  const int t = blockIdx.x / S8, s = blockIdx.x - t * S8;
-  if (s >= S) return;
   const int tfW = (Fin * K + TF - 1) / TF, tcW = (Fout + 31) >> 5;
   const int tfM = (Fin + TF - 1) / TF;
+  int t, s;
+  if (a.xcd == 2) {
+    // split-major inside an XCD: the workgroups an XCD runs at any one time belong to ONE row split (all its output
+    // tiles), so that split's rows of X / Gp / dZ are fetched from HBM once and re-read from that XCD's L2
+    const int nt = tfW * tcW + tcW + (a.paper ? tfM * ((Fin + 31) >> 5) : 0);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int sl = j / nt;
+    t = j - sl * nt;
+    s = sl * 8 + xcd;
+  } else {
+    t = blockIdx.x / S8;
+    s = blockIdx.x - t * S8;
+  }
+  if (s >= S) return;
   int p, rem;                               // problem, tile index inside it
   if (t < tfW * tcW) { p = 0; rem = t; }
   else if (t < tfW * tcW + tcW) { p = 1; rem = t - tfW * tcW; }
@@ -192,10 +206,10 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   f32x4 acc[NA][2];
 #pragma unroll
   for (int x = 0; x < NA; ++x) acc[x][0] = acc[x][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int rr = r_begin; rr < r_end; rr += 32) {
-    float av[NA][8], b0[8], b1[8];
+  for (int rr = r_begin; rr < r_end; rr += 4 * KS) {
+    float av[NA][KS], b0[KS], b1[KS];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < KS; ++u) {
       const int row = min(rr + 4 * u + q, last_row);
 #pragma unroll
       for (int x = 0; x < NA; ++x) av[x][u] = (p == 1) ? 1.0f : Ap[x][(int64_t)row * ldax[x]];
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
       b1[u] = Bp[(int64_t)row * ldb + cB];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < KS; ++u) {
       const bool rv = (rr + 4 * u + q) < r_end;
       const float y0 = (rv && cAv) ? b0[u] : 0.f, y1 = (rv && cBv) ? b1[u] : 0.f;
 #pragma unroll
@@ -283,7 +297,10 @@ namespace {
 int pg_tf(int rows) {
   static const int force = [] { const char* e = std::getenv("AGCN_PG_TF"); return e ? std::atoi(e) : 0; }();
   if (force == 16 || force == 32) return force;
-  return rows >= 49152 ? 32 : 16;   // measured: 18k rows 28.8 | 34.4 us (16 | 32), 36k: 49 | 48.5, 73k: 165 | 110
+  // 16 | 32-row tiles, plain workgroup order: 18k rows 28.8 | 34.4 us, 36k: 49 | 48.5, 73k: 165 | 110; with the
+  // split-major XCD order (the default from 8k rows on) the 16-row tile wins everywhere: 73k rows 62.8 | 74.5 us
+  (void)rows;
+  return 16;
 }
 int pg_tiles(int Fin, int Fout, int K, bool paper, int TF) {
   const int tfW = (Fin * K + TF - 1) / TF, tcW = (Fout + 31) / 32;
@@ -338,11 +355,15 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad counters memset: %s", hipGetErrorString(e));
     }
     prof_begin(PK_PARAM_ONEPASS, stream);
-    static const int xcd = [] { const char* e = std::getenv("AGCN_PG_XCD"); return (e && e[0] == '1') ? 1 : 0; }();
+    // XCD-aware order: off for small batches (the rows fit every L2; the plain order has the shorter tail:
+    // B = 256: 13.6 vs 15.4 us), split-major from ~8k rows on (512 / 1024 / 2048 / 4096 graphs: 19.5 / 26.3 / 38.3 /
+    // 74.6 us against 19.9 / 29.7 / 47.7 / 111 us)
+    static const int xcd_force = [] { const char* e = std::getenv("AGCN_PG_XCD"); return e ? std::atoi(e) : -1; }();
+    const int xcd = xcd_force >= 0 ? xcd_force : (a.rows >= 8192 ? 2 : 0);
     aa.xcd = xcd;
     const dim3 grid((unsigned)(nt * (xcd ? ((S + 7) & ~7) : S)));
-    if (TF == 32) hipLaunchKernelGGL(param_grad_onepass_kernel<32>, grid, dim3(1024), 0, s, aa);
-    else hipLaunchKernelGGL(param_grad_onepass_kernel<16>, grid, dim3(1024), 0, s, aa);
+    if (TF == 32) hipLaunchKernelGGL((param_grad_onepass_kernel<32, 8>), grid, dim3(1024), 0, s, aa);
+    else hipLaunchKernelGGL((param_grad_onepass_kernel<16, 8>), grid, dim3(1024), 0, s, aa);
     prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_onepass launch: %s", hipGetErrorString(e));

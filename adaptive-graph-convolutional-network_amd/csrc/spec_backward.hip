@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * NW, 4) void spec_backward_kernel(SgcArgs a, in
           for (int i4 = 0; i4 < 4; ++i4) {
             const int i = i0 + i4;
             if (i < n) {
-              dXg[(int64_t)i * a.ldx + f] = dxacc[sl][i4] + xacc[sl][i4];
+              AGCN_ST(8, &dXg[(int64_t)i * a.ldx + f], dxacc[sl][i4] + xacc[sl][i4]);
               if (paper) a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[sl][i4];
             }
           }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_
         *reinterpret_cast<f32x4*>(Zt + c * ldz + i0) = acc;   // rows >= n come out 0 (zero rows of the X image)
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4)
-          if (i0 + i4 < n) Zg[(i0 + i4) * FIN + c] = acc[i4];
+          if (i0 + i4 < n) AGCN_ST(2, &Zg[(i0 + i4) * FIN + c], acc[i4]);
       }
     };
     for (int t = t1a; t < t1b; t += 2) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_
           const float sv = (i == j) ? 0.f : fast_exp_neg(rr);   // graphconv.py:171-177
           tile[i * ldt + j] = sv;
           tile[j * ldt + i] = sv;   // bit-symmetric by construction
-          if (paper && i < j) a.sv_r[toff + (uint32_t)(i * n + j)] = rr;   // the backward reads r_ij for i < j only
+          if (paper && i < j) AGCN_ST(2, &a.sv_r[toff + (uint32_t)(i * n + j)], rr);   // the backward reads r_ij for i < j only
         }
       }
     }
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_
           if (paper) R = R - (s_vec[i] * S) * sj;
           const float R2 = lrelu(R, alpha);   // (clip_by_average_norm never clips for SGC_LL: scale exactly 1)
           const uint32_t o = toff + (uint32_t)(i * n + j);
-          a.res_W[o] = S;
-          a.res_L[o] = R2;
+          AGCN_ST(1, &a.res_W[o], S);
+          AGCN_ST(1, &a.res_L[o], R2);
           out = R2 + l0;
         }
         tile[i * ldt + j] = out;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_
           if (i0 + i4 < n) {
             float v = yacc[sl][i4] + ybias[sl];
             if (relu) v = fmaxf(v, 0.f);
-            Yg[(int64_t)(i0 + i4) * a.ldy + c] = v;
+            AGCN_ST(4, &Yg[(int64_t)(i0 + i4) * a.ldy + c], v);
           }
         }
       }
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_
 #pragma unroll
       for (int cp = 0; cp < CP; ++cp) {
         const int c = lane + 64 * cp;
-        if (c < FIN) Xo[i * FIN + c] = X1img[i * LDX + c];
+        if (c < FIN) AGCN_ST(2, &Xo[i * FIN + c], X1img[i * LDX + c]);
       }
   }
   // The block of the last (smallest) graph of the batch also leaves transposed copies of the parameters in the reserve

@@ -14,6 +14,17 @@
 #include "agcn_device.h"
 #include "sgc_kernels.h"
 
+// Store policy of the bulk outputs (diagnostic A/B switch, -DAGCN_NT=<bits>): bit 0 res_W / res_L, bit 1 the reserve
+// (r, Z, X_1), bit 2 Y, bit 3 dX -- nontemporal (streaming) stores leave no dirty lines for the end-of-kernel write-back
+#ifndef AGCN_NT
+#define AGCN_NT 0
+#endif
+#define AGCN_ST(bit, ptr, val)                                          \
+  do {                                                                  \
+    if ((AGCN_NT) & (bit)) __builtin_nontemporal_store((val), (ptr));   \
+    else *(ptr) = (val);                                                \
+  } while (0)
+
 namespace agcn {
 namespace spec {
 

@@ -210,10 +210,16 @@ class SgcLLEpochStep(object):
         lib, d, hp = self.lib, C.byref(self.desc), plan.host_ptr
         rb = lib.agcn_sgc_ll_reserve_bytes(d, hp)
         wb = max(lib.agcn_sgc_ll_forward_workspace_bytes(d, hp), lib.agcn_sgc_ll_backward_workspace_bytes(d, hp))
-        if rb > self._reserve.numel():            # (grows geometrically: a handful of times per epoch at most)
-            self._reserve = torch.zeros(int(rb * 1.5), dtype=torch.uint8, device=self.device)
-        if wb > self._ws.numel():
-            self._ws = torch.zeros(int(wb * 1.5), dtype=torch.uint8, device=self.device)
+        if rb > self._reserve.numel() or wb > self._ws.numel():
+            # grows geometrically: a handful of times per epoch at most.  The step may be running on a stream other
+            # than the allocator's: nothing may still be using the old buffers when they go back to the pool, and the
+            # new ones must be zero-filled before a kernel on that stream touches them
+            torch.cuda.synchronize(self.device)
+            if rb > self._reserve.numel():
+                self._reserve = torch.zeros(int(rb * 1.5), dtype=torch.uint8, device=self.device)
+            if wb > self._ws.numel():
+                self._ws = torch.zeros(int(wb * 1.5), dtype=torch.uint8, device=self.device)
+            torch.cuda.synchronize(self.device)
         return rb
 
     def step(self, batch, dY=None, stream=None):
@@ -279,6 +285,7 @@ class SgcLLEpochLanes(object):
                       for _ in range(lanes)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(lanes)]
         self._j = 0
+        torch.cuda.synchronize(self.device)      # buffers, parameters and the store were filled on other streams
 
     def step(self, graph_ids, dY=None):
         k = self._j % len(self.steps)
