@@ -312,7 +312,7 @@ void pg_split(int rows, int* rows_per_wave, int* S) {
   static const int force = [] { const char* e = std::getenv("AGCN_PG_RPW"); return e ? std::atoi(e) : 0; }();
   int rpw = 32;   // measured: 32 / 64 / 96 rows per wave are within 5 %, 128 is 30 % slower
   while ((rows + 16 * rpw - 1) / (16 * rpw) > 64) rpw += 32;
-  if (force >= 32) rpw = force / 32 * 32;
+  if (force >= 4) rpw = force / 4 * 4;
   *rows_per_wave = rpw;
   *S = std::max(1, (rows + 16 * rpw - 1) / (16 * rpw));
 }

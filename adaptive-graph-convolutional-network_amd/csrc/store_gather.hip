@@ -22,7 +22,7 @@ struct GatherArgs {
   const int32_t* n;         // plan arrays (device)
   const int32_t* row_off;
   const GatherRec* rec;
-  const float* X;
+  const void* X;            // float or bf16 (x_bf16) rows of the store
   const int64_t* rowptr;
   const int32_t* col;
   const float* val;
@@ -30,8 +30,10 @@ struct GatherArgs {
   int32_t* rowptr_out;
   int32_t* col_out;
   float* val_out;
-  int32_t F, ldx_out;
+  int32_t F, ldx_out, x_bf16;
 };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 // one workgroup per graph: contiguous segments in, contiguous segments out
 __global__ __launch_bounds__(256) void store_gather_kernel(GatherArgs a) {
@@ -39,14 +41,17 @@ __global__ __launch_bounds__(256) void store_gather_kernel(GatherArgs a) {
   const int n = a.n[b], r0 = a.row_off[b];
   const GatherRec rc = a.rec[b];
   const int F = a.F;
-  const float* xs = a.X + rc.src_row * F;
+  // (features kept in bf16 at rest are widened here: the layer computes in fp32, include/agcn.h agcn_cast_rows)
+  const float* xs = static_cast<const float*>(a.X) + rc.src_row * F;
+  const uint16_t* xh = static_cast<const uint16_t*>(a.X) + rc.src_row * F;
+  const bool h = a.x_bf16 != 0;   // (uniform)
   if (a.ldx_out == F) {
     float* xd = a.X_out + (int64_t)r0 * F;
-    for (int i = tid; i < n * F; i += 256) xd[i] = xs[i];
+    for (int i = tid; i < n * F; i += 256) xd[i] = h ? bf16_to_f32(xh[i]) : xs[i];
   } else {
     for (int i = tid; i < n * F; i += 256) {
       const int r = i / F, f = i - r * F;
-      a.X_out[(int64_t)(r0 + r) * a.ldx_out + f] = xs[i];
+      a.X_out[(int64_t)(r0 + r) * a.ldx_out + f] = h ? bf16_to_f32(xh[i]) : xs[i];
     }
   }
   const int64_t shift = (int64_t)rc.dst_nnz - rc.src_nnz;
@@ -136,7 +141,7 @@ extern "C" int agcn_store_stage_batch(const AgcnResidentStore* st, const int64_t
   a.rec = reinterpret_cast<const agcn::GatherRec*>(d + tab_off);
   a.X = st->X_dev; a.rowptr = st->rowptr_dev; a.col = st->col_dev; a.val = st->val_dev;
   a.X_out = X_out; a.rowptr_out = rowptr_out; a.col_out = col_out; a.val_out = val_out;
-  a.F = h.F; a.ldx_out = ldx_out;
+  a.F = h.F; a.ldx_out = ldx_out; a.x_bf16 = st->x_bf16 != 0 ? 1 : 0;
   hipLaunchKernelGGL(agcn::store_gather_kernel, dim3((unsigned)B), dim3(256), 0, s, a);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: gather launch: %s", who, hipGetErrorString(e));

@@ -137,9 +137,10 @@ class GraphStore(object):
         dev = torch.device(device)
         return self._upload(self._pack(graph_ids, slot, dev.type == "cuda", n_threads), dev)
 
-    def to_device(self, device, batch_cap, slots=4, lanes=1):
-        """The store resident in HBM (`ResidentStore`): arrays uploaded once, batches gathered on the device."""
-        return ResidentStore(self, device, batch_cap, slots, lanes)
+    def to_device(self, device, batch_cap, slots=4, lanes=1, dtype=torch.float32):
+        """The store resident in HBM (`ResidentStore`): arrays uploaded once, batches gathered on the device.
+        dtype=torch.bfloat16 keeps the node features in bf16 at rest (rounded once, nearest-even)."""
+        return ResidentStore(self, device, batch_cap, slots, lanes, dtype)
 
     def _selections(self, batch_size, deterministic, rng):
         N = len(self)
@@ -216,15 +217,20 @@ class ResidentStore(object):
     order) and until `slots` further batches on the host side.  `lanes` > 1 keeps that many independent sets of
     capacity buffers, so that batches staged on different streams can be in flight together (`SgcLLEpochLanes`)."""
 
-    def __init__(self, store, device, batch_cap, slots=4, lanes=1):
+    def __init__(self, store, device, batch_cap, slots=4, lanes=1, dtype=torch.float32):
         dev = torch.device(device)
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("node features are kept in float32 or bfloat16")
         if dev.type != "cuda":
             raise _ffi.AgcnError("a resident store lives on the GPU: there is no CPU fallback")
         self.store, self.device = store, dev
         self.batch_cap = int(batch_cap)
         self.F = store.F
         up = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
-        self.X, self.rowptr = up(store.X), up(store.rowptr)
+        # bf16 at rest ("bf16 features + fp32 Laplacian", DESIGN.md 7): rounded once here, widened by the gather;
+        # every batch then carries float32(bf16(x)) and the layer computes in fp32
+        self.X, self.rowptr = up(store.X).to(dtype), up(store.rowptr)
+        self.dtype = dtype
         self.col = up(store.col if store.col.size else np.zeros(1, np.int32))
         self.val = up(store.val if store.val.size else np.zeros(1, np.float32))
         # capacity of any batch of <= batch_cap graphs: the batch_cap largest graphs / Laplacians of the store
@@ -252,7 +258,7 @@ class ResidentStore(object):
         self._k = 0
         h = store._c
         self._c = _ffi.ResidentStoreC(h, self.X.data_ptr(), self.rowptr.data_ptr(), self.col.data_ptr(),
-                                      self.val.data_ptr())
+                                      self.val.data_ptr(), 1 if dtype == torch.bfloat16 else 0, 0)
         self._info = _ffi.StagedBatch()
 
     def __len__(self):

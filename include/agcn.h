@@ -351,10 +351,13 @@ int agcn_store_pack_batch(const AgcnGraphStore* store, const int64_t* ids, int32
  * `stage_host` untouched until the copy has executed (an event on `hip_stream`); everything else is stream-ordered. */
 typedef struct AgcnResidentStore {
   AgcnGraphStore host;       /* host index of the store: n, row_off, rowptr, symmetric are read (X / col / val may be NULL) */
-  const float* X_dev;        /* [R][F]  device copies of the store's arrays */
-  const int64_t* rowptr_dev; /* [R+1] */
+  const void* X_dev;         /* [R][F]  device copy of the node features: float32, or bfloat16 if x_bf16 */
+  const int64_t* rowptr_dev; /* [R+1]   device copies of the CSR arrays */
   const int32_t* col_dev;
   const float* val_dev;
+  int32_t x_bf16;            /* 1: X_dev holds bfloat16 (features at rest in bf16, "bf16 features + fp32 Laplacian");
+                              * the gather widens them, X_out is always float32 */
+  int32_t reserved;
 } AgcnResidentStore;
 typedef struct AgcnStagedBatch {
   int64_t rows, nnz;

@@ -1098,6 +1098,14 @@ def test_resident_store_batches_are_the_host_packed_batches(amd):
         torch.cuda.synchronize()
         assert torch.equal(ep_a.Y, ep_b.Y) and torch.equal(ep_a.dX, ep_b.dX) and torch.equal(ep_a.res_W, ep_b.res_W)
         assert torch.equal(ep_a.bucket, ep_b.bucket)
+    # features kept in bf16 at rest: every batch carries float32(bf16(x)) exactly (rounded once, nearest-even)
+    rh = store.to_device(DEV, 256, dtype=torch.bfloat16)
+    for sel in sels[:2]:
+        ref = store.batch(sel, DEV)
+        gb = rh.stage(sel)
+        torch.cuda.synchronize()
+        assert torch.equal(gb.X, ref.X.to(torch.bfloat16).to(torch.float32))
+        assert torch.equal(gb.l0_val, ref.l0_val) and torch.equal(gb.l0_rowptr, ref.l0_rowptr)
     with pytest.raises(ValueError):
         rs.stage(np.arange(257))
     with pytest.raises(amd.AgcnError):

@@ -230,6 +230,16 @@ def main():
                         ep2.step(gb)
                 torch.cuda.synchronize(dev)
                 res[what] = round(G / (time.perf_counter() - t0), 1)
+        # BASELINE configs[4]: features at rest in bf16, Laplacian and all arithmetic fp32
+        rh = store.to_device(dev, 256, dtype=torch.bfloat16)
+        for rep in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for gb, _, _, _ in rh.iterbatches(256, deterministic=True):
+                ep2.step(gb)
+            torch.cuda.synchronize(dev)
+            res["resident stage+layer(static buffers), bf16 features at rest"] = round(G / (time.perf_counter() - t0), 1)
+        del rh
         # consecutive batches overlapped on 2 / 3 streams (evaluation passes, gradient accumulation: SgcLLEpochLanes)
         sels = store._selections(256, True, None)
         for lanes in (2, 3):
