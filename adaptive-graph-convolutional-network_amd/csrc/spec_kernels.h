@@ -37,7 +37,10 @@ namespace spec {
 // (barriers, LDS and memory round trips: ~60 % of a wave's life) are filled by another graph's instructions; the
 // few large graphs run in a launch of their own on a side stream, beside them (agcn_api.hip).
 constexpr int NW_LARGE = 16, NW_SMALL = 8;
-constexpr int SMALL_N = 48;   // largest graph the 8-wave flavour takes
+#ifndef AGCN_SMALL_N
+#define AGCN_SMALL_N 48
+#endif
+constexpr int SMALL_N = AGCN_SMALL_N;   // largest graph the 8-wave flavour takes (<= 48: six rows per wave)
 
 template <int FIN>
 struct Feat {
