@@ -367,6 +367,44 @@ __device__ __forceinline__ void strip_gemm_transposed(float* out, const float* A
   for (int i = 0; i < 4; ++i) out[(4 * q + i) * CHP + 16 * wave + r] = acc[i];
 }
 
+// Backward chunk of the learned Laplacian: of the forward's n x n data only r (paper mode) and L_orig are read.
+// S = exp(-r) and R = I - s S s are recomputed with the forward's own instructions (slab_sim: expf(-r); slab_lap:
+// R - (s_i S) s_j), so L and S carry the same bits as res_L + L_orig and res_W -- neither output is read again.
+struct BChunkRegs { float rv[4], l0[4], sj; };
+
+__device__ __forceinline__ BChunkRegs load_B_chunk(const SgcArgs& a, const SlabCtx& c, int c0, bool want_l0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = c.n, jc = min(c0 + lane, n - 1);
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  BChunkRegs g;
+  g.sj = paper ? a.sv_s[c.row0 + jc] : 0.f;
+  const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+  const float* L0d = (!a.L0_dense || !want_l0)
+                         ? nullptr
+                         : (a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff);
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int i = min(c.i0 + 4 * wave + di, n - 1);
+    g.rv[di] = paper ? a.sv_r[c.toff + (int64_t)i * n + jc] : 0.f;
+    g.l0[di] = L0d ? L0d[(int64_t)i * l0ld + jc] : 0.f;
+  }
+  return g;
+}
+
+// S_ij and R_ij of the chunk element (4 * wave + di, lane) from the chunk registers
+__device__ __forceinline__ void chunk_SR(const SlabCtx& c, const BChunkRegs& g, int c0, const float (&si)[4], bool paper,
+                                         float (&S)[4], float (&R)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = c0 + lane;
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int i = c.i0 + 4 * wave + di;
+    S[di] = (!paper || i == j) ? 0.f : expf(-g.rv[di]);        // slab_sim's instruction
+    R[di] = (i == j) ? 1.f : 0.f;
+    if (paper) R[di] = R[di] - (si[di] * S[di]) * g.sj;        // slab_lap's instruction (R1 == R: clip scale 1)
+  }
+}
+
 __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SlabCtx c = slab_ctx(a);
@@ -412,13 +450,41 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
   acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float ds[4] = {0.f, 0.f, 0.f, 0.f};
   float dalpha_part = 0.f;
-  LChunkRegs cur = load_L_chunk<false>(a, c, 0);
+  const bool dense_l0 = a.L0_dense != nullptr;
+  BChunkRegs cur = load_B_chunk(a, c, 0, true);
   for (int c0 = 0; c0 < n; c0 += CH) {
     const int nc = min(CH, n - c0);
     if (c0 > 0) __syncthreads();
-    const LChunkRegs nxt = (c0 + CH < n) ? load_L_chunk<false>(a, c, c0 + CH) : cur;   // next chunk's loads in flight
-    build_L_chunk<false>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1, cur);
+    const BChunkRegs nxt = (c0 + CH < n) ? load_B_chunk(a, c, c0 + CH, true) : cur;   // next chunk's loads in flight
+    float Sv[4], Rv[4];
+    chunk_SR(c, cur, c0, si, paper, Sv, Rv);
+    {
+      const bool cv = lane < nc;
+#pragma unroll
+      for (int di = 0; di < 4; ++di) {
+        const int il = 4 * wave + di;
+        Ls[il * CHP + lane] = (cv && il < c.nr) ? lrelu(Rv[di], alpha) + cur.l0[di] : 0.f;
+      }
+    }
+    const float sj = cur.sj;
     cur = nxt;
+    __syncthreads();
+    // + L_orig rows of the slab (CSR, one thread per row)
+    if (!dense_l0 && tid < c.nr) {
+      for (int p = csr_p0; p < csr_p1; p += 4) {
+        int cc[4];
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pp = min(p + u, csr_p1 - 1);
+          cc[u] = a.L0_col[pp];
+          vv[u] = a.L0_val[pp];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (p + u < csr_p1 && cc[u] >= c0 && cc[u] < c0 + CH) Ls[tid * CHP + cc[u] - c0] += vv[u];
+      }
+    }
     stage_rows_img(G1s, ldf, g1 + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
     if (paper) {
       stage_rows_img(X0s, ldf, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
@@ -437,29 +503,25 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
       __syncthreads();
       const int j = c0 + lane;
       const bool cv = lane < nc;
-      const float sj = a.sv_s[c.row0 + min(j, n - 1)];
-      float Sv[4], up[4] = {0.f, 0.f, 0.f, 0.f}, upt[4] = {0.f, 0.f, 0.f, 0.f};
+      float up[4] = {0.f, 0.f, 0.f, 0.f}, upt[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.dL_sum) {   // upstream gradient of the 4th output (the combined Laplacian), both orientations
 #pragma unroll
-      for (int di = 0; di < 4; ++di) {
-        const int i = c.i0 + min(4 * wave + di, c.nr - 1), jc = min(j, n - 1);
-        Sv[di] = a.res_W[c.toff + (int64_t)i * n + jc];
-        if (a.dL_sum) {   // upstream gradient of the 4th output (the combined Laplacian), both orientations
+        for (int di = 0; di < 4; ++di) {
+          const int i = c.i0 + min(4 * wave + di, c.nr - 1), jc = min(j, n - 1);
           up[di] = a.dL_sum[c.toff + (int64_t)i * n + jc];
           upt[di] = a.dL_sum[c.toff + (int64_t)jc * n + i];
         }
       }
 #pragma unroll
       for (int di = 0; di < 4; ++di) {
-        const int il = 4 * wave + di, i = c.i0 + il;
+        const int il = 4 * wave + di;
         if (cv && il < c.nr) {
-          float R = (i == j) ? 1.f : 0.f;
-          R = R - (si[di] * Sv[di]) * sj;                 // R1 == R (clip scale 1)
-          const float lg = lrelu_grad(R, alpha);
+          const float lg = lrelu_grad(Rv[di], alpha);
           const float dL = T[il * CHP + lane] + up[di];
-          dalpha_part += dL * fminf(R, 0.f);
+          dalpha_part += dL * fminf(Rv[di], 0.f);
           const float dA = -(dL * lg);                     // dA_ij = -dR_ij
           const float dAt = -((Cc[il * CHP + lane] + upt[di]) * lg);   // dA_ji (R symmetric)
-          a.ws_dA[c.toff + (int64_t)i * n + j] = dA;
+          a.ws_dA[c.toff + (int64_t)(c.i0 + il) * n + j] = dA;
           // ds_i = sum_j dA_ij S_ij s_j + sum_j dA_ji S_ij s_j
           ds[di] += (dA * Sv[di]) * sj + (dAt * Sv[di]) * sj;
         }
