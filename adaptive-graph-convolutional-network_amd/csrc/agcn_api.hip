@@ -101,11 +101,10 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
   // (measured, Tox21-shaped batches, graphs/s with one launch | two launches in a row | side by side:
   //  512: 5.6 | 3.9 | 4.8 M;  1024: 6.9 | 5.4 | 6.7 M;  2048: 8.0 | 7.8 | 9.2 M;  4096: 7.3 | 8.3 | 8.9 M)
   if ((f->spec_fwd || f->spec_bwd) && pi.B >= 6 * 256 && agcn_get_spec_small() != 0) {
-    // the 8-wave launch's LDS per workgroup is that of its largest graph: a lower cut lets four such workgroups
-    // share a CU (measured, 2048 graphs: cut at 48 / 32 / 24 nodes: 9.7 / 9.7 / 10.0 M graphs/s)
+    // the 8-wave launch's LDS per workgroup is that of its largest graph and its registers allow three workgroups per
+    // CU: a lower cut keeps three of them resident (measured, 2048 graphs: cut at 40 / 32 / 24 nodes: 9.9 / 10.5 /
+    // 10.6 M graphs/s; 4096 graphs: 12.7 / 13.0 / 12.2 M)
     static const int cut_force = [] { const char* e = std::getenv("AGCN_SMALL_CUT"); return e ? std::atoi(e) : 0; }();
-    // (cut 20 / 24 / 28 / 32 / 48: 1536 graphs 8.85 / 8.93 / 8.98 / 8.90 / 8.82 M, 2048: 9.73 / 10.02 / 9.92 / 9.89 / 9.77 M,
-    //  4096: 11.0 / 11.3 / 11.7 / 11.8 / 11.6 M)
     const int cut = cut_force > 0 ? std::min(cut_force, spec::SMALL_N) : (pi.B < 3072 ? 24 : 32);
     int sf = pi.B;
     while (sf > 0 && host.n[host.order[sf - 1]] <= cut) --sf;

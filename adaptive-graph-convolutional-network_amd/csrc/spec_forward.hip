@@ -27,7 +27,7 @@ namespace spec {
 constexpr int MAXT = 3;   // most MFMA tiles of one phase a wave may own (accumulators are held in registers)
 
 template <int FIN, int FOUT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? 4 : 4) void spec_forward_kernel(SgcArgs a, int first) {
+__global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void spec_forward_kernel(SgcArgs a, int first) {
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;

@@ -37,6 +37,13 @@ namespace spec {
 // (barriers, LDS and memory round trips: ~60 % of a wave's life) are filled by another graph's instructions; the
 // few large graphs run in a launch of their own on a side stream, beside them (agcn_api.hip).
 constexpr int NW_LARGE = 16, NW_SMALL = 8;
+// Waves per SIMD the 8-wave flavour's register allocation is held to.  Two of its waves sit on each SIMD per workgroup,
+// so 6 (<= 80 VGPRs; the backward spills 16-48 bytes per lane) lets THREE workgroups share a CU instead of two.
+// Measured, 1536 / 2048 / 4096 graphs: 4 (93 VGPRs, no spill): 8.8 / 10.0 / 11.9 M graphs/s; 6: 9.2 / 10.6 / 13.0 M;
+// 7: 8.9 / 10.3 / 12.6 M; 8 (64 VGPRs, 90-1050 bytes spilled): 8.9 / 10.2 / 12.4 M.
+#ifndef AGCN_SMALL_OCC
+#define AGCN_SMALL_OCC 6
+#endif
 #ifndef AGCN_SMALL_N
 #define AGCN_SMALL_N 48
 #endif
