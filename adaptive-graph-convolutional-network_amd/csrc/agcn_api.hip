@@ -98,9 +98,10 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
   }
   // Many graphs per CU: the small graphs (a suffix of the largest-first schedule) go to the 8-wave flavour, whose
   // workgroups share a CU (spec_kernels.h).  With about one graph per CU a second launch only adds a boundary.
-  // (measured, Tox21-shaped batches, graphs/s with one launch | two launches in a row | side by side:
-  //  512: 5.6 | 3.9 | 4.8 M;  1024: 6.9 | 5.4 | 6.7 M;  2048: 8.0 | 7.8 | 9.2 M;  4096: 7.3 | 8.3 | 8.9 M)
-  if ((f->spec_fwd || f->spec_bwd) && pi.B >= 6 * 256 && agcn_get_spec_small() != 0) {
+  // (measured, Tox21-shaped batches, graphs/s with one launch | two launches side by side:
+  //  512: 5.7 | 5.1 M;  768: 6.6 | 6.0 M;  1024: 7.2 | 7.4 M;  1280: 7.5 | 8.5 M;  2048: 8.0 | 10.6 M;  4096: 7.3 | 13.0 M)
+  static const int min_b = [] { const char* e = std::getenv("AGCN_SMALL_MIN_B"); return e ? std::atoi(e) : 1024; }();
+  if ((f->spec_fwd || f->spec_bwd) && pi.B >= min_b && agcn_get_spec_small() != 0) {
     // the 8-wave launch's LDS per workgroup is that of its largest graph and its registers allow three workgroups per
     // CU: a lower cut keeps three of them resident (measured, 2048 graphs: cut at 40 / 32 / 24 nodes: 9.9 / 10.5 /
     // 10.6 M graphs/s; 4096 graphs: 12.7 / 13.0 / 12.2 M)
@@ -108,7 +109,7 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
     const int cut = cut_force > 0 ? std::min(cut_force, spec::SMALL_N) : (pi.B < 3072 ? 24 : 32);
     int sf = pi.B;
     while (sf > 0 && host.n[host.order[sf - 1]] <= cut) --sf;
-    if (pi.B - sf >= 1024) f->spec_small_first = sf;
+    if (pi.B - sf >= std::min(1024, min_b / 2)) f->spec_small_first = sf;
   }
 }
 // A batch whose few largest graphs exceed the specialised kernels' LDS plan (n > 96: HIV-shaped batches have one or two

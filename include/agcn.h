@@ -414,8 +414,8 @@ void agcn_set_param_grad_onepass(int32_t on);
  * (3 = both, the default).  Same results within the last few ulps (hardware sqrt / exp2 in the similarity phase). */
 int32_t agcn_get_spec_mode(void);
 void agcn_set_spec_mode(int32_t mode);
-/* In batches of >= 1536 graphs the graphs of at most 48 nodes take an 8-wave flavour of the specialised kernels in
- * a launch of their own (two or three such workgroups share a CU).  2 (default): the launch of the few larger
+/* In batches of >= 1024 graphs the graphs of at most 24 nodes (32 from 3072 graphs on) take an 8-wave flavour of the
+ * specialised kernels in a launch of their own (three such workgroups share a CU).  2 (default): the launch of the few larger
  * graphs runs beside it on the library's per-device side stream (fork / join with events, capturable into a HIP
  * graph); 1: before it on the caller's stream; 0: one launch for all graphs. */
 int32_t agcn_get_spec_small(void);
