@@ -260,6 +260,45 @@ class SgcLLEpochStep(object):
         return self._res_W[:self.plan.tile_elems]
 
 
+def _overlapping_streams(device, k, candidates=12, spin=400000):
+    """`k` streams of `device` whose work really runs side by side.  ROCm multiplexes streams onto a few hardware queues
+    and which queue a (pooled) torch stream lands on is not under the caller's control: two streams on one queue run
+    their kernels strictly one after the other (measured: 2 lanes at 1.9 instead of 3.1 M graphs/s).  So candidates are
+    TESTED: a single-thread spin kernel on each of two streams takes one spin if they overlap, two if they do not."""
+    if k <= 1:
+        return [torch.cuda.current_stream(device)]
+    sleep = getattr(torch.cuda, "_sleep", None)
+    pool = [torch.cuda.Stream(device) for _ in range(candidates)]
+    if sleep is None:                                   # cannot test: take what the pool hands out
+        return pool[:k]
+
+    def side_by_side(a, b):
+        torch.cuda.synchronize(device)
+        t = []
+        for pair in ((a,), (a, b)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cur = torch.cuda.current_stream(device)
+            e0.record(cur)
+            for s in pair:
+                s.wait_event(e0)
+                with torch.cuda.stream(s):
+                    sleep(spin)
+            for s in pair:
+                cur.wait_stream(s)
+            e1.record(cur)
+            torch.cuda.synchronize(device)
+            t.append(e0.elapsed_time(e1))
+        return t[1] < 1.5 * t[0]
+
+    chosen = []
+    for s in pool:
+        if all(side_by_side(c, s) for c in chosen):
+            chosen.append(s)
+            if len(chosen) == k:
+                return chosen
+    return (chosen + [s for s in pool if s not in chosen])[:k]     # fewer independent queues than lanes
+
+
 class SgcLLEpochLanes(object):
     """`lanes` independent `SgcLLEpochStep`s, each on its own stream with its own buffers, fed round-robin from a
     `ResidentStore`: consecutive batches overlap on the GPU.  A step of one 256-graph batch is as long as the dependent
@@ -283,7 +322,7 @@ class SgcLLEpochLanes(object):
         self.rstore, self.device = rstore, rstore.device
         self.steps = [SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device)
                       for _ in range(lanes)]
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(lanes)]
+        self.streams = _overlapping_streams(self.device, lanes)
         self._j = 0
         torch.cuda.synchronize(self.device)      # buffers, parameters and the store were filled on other streams
 
