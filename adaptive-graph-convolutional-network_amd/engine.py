@@ -115,20 +115,24 @@ class SgcLLStep(object):
         self.forward()
         self.backward()
 
-    def capture(self, extra=None):
+    def capture(self, extra=None, steps=1):
         """Capture forward + backward into a HIP graph (torch.cuda.CUDAGraph on ROCm).  `extra`, if given, is
         called behind the step inside the capture (e.g. the RCCL all-reduce of `self.bucket`, so that a
-        data-parallel step is still one graph replay)."""
+        data-parallel step is still one graph replay).  `steps` > 1 captures that many consecutive steps into the ONE
+        graph: kernels inside a graph follow each other without a gap, while two graph launches are ~5 us apart on
+        MI355X (end-of-graph release + start-of-graph acquire), 9 % of a 256-graph step."""
         self.step()                      # warm-up outside capture (sets function attributes)
         if extra is not None:
             extra()
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.step()
-            if extra is not None:
-                extra()
+            for _ in range(max(1, int(steps))):
+                self.step()
+                if extra is not None:
+                    extra()
         self._graph = g
+        self.steps_per_replay = max(1, int(steps))
         return g
 
     def kernel_names(self):
