@@ -268,7 +268,9 @@ def _overlapping_streams(device, k, candidates=12, spin=400000):
     """`k` streams of `device` whose work really runs side by side.  ROCm multiplexes streams onto a few hardware queues
     and which queue a (pooled) torch stream lands on is not under the caller's control: two streams on one queue run
     their kernels strictly one after the other (measured: 2 lanes at 1.9 instead of 3.1 M graphs/s).  So candidates are
-    TESTED: a single-thread spin kernel on each of two streams takes one spin if they overlap, two if they do not."""
+    TESTED: a single-thread spin kernel on each of two streams takes one spin if they overlap, two if they do not.
+    (The runtime may still re-map streams to queues later; a process that keeps more than ~3 streams busy should raise
+    the number of hardware queues: GPU_MAX_HW_QUEUES=8 in the environment, before the first HIP call.)"""
     if k <= 1:
         return [torch.cuda.current_stream(device)]
     sleep = getattr(torch.cuda, "_sleep", None)

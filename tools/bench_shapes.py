@@ -11,6 +11,10 @@
 
 One JSON line per workload; `--prof` adds the library's per-kernel HIP-event averages.
 Not part of the driver contract (bench.py is); results are copied into profiles/."""
+import os
+# more hardware queues than the default four: this process keeps several streams alive (the library's side streams,
+# the epoch lanes), and streams that share a queue run strictly in turn (2 lanes: 1.9 instead of 3.1 M graphs/s)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os
