@@ -167,3 +167,25 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "agcn_oracle" not in src and "oracle/" not in src, f
+
+
+def test_stage_blob_bound_covers_every_split_of_the_rows(amd):
+    """agcn_store_stage_bytes(B, rows) -- the size the resident store allocates its pinned / device blobs with -- must
+    cover the plan + gather table of ANY batch of at most B graphs and `rows` rows, however unevenly the rows are
+    split (the slab tables grow with sum(ceil(n / 16)))."""
+    lib = amd._ffi.lib()
+    rng = np.random.RandomState(0)
+    for B, rows in ((1, 1), (1, 1600), (7, 7), (256, 4617), (256, 25000), (64, 64 * 1600)):
+        cap = lib.agcn_store_stage_bytes(B, rows)
+        assert cap > 0
+        for trial in range(20):
+            b = int(rng.randint(1, B + 1))
+            # a random split of at most `rows` rows into b graphs of 1..1600 nodes
+            n = np.ones(b, dtype=np.int64)
+            budget = min(rows, 1600 * b) - b
+            extra = rng.multinomial(budget, rng.dirichlet(np.full(b, 0.3))) if budget > 0 else np.zeros(b, np.int64)
+            n = np.minimum(n + extra, 1600).astype(np.int32)
+            need = lib.agcn_plan_bytes_for(n.ctypes.data, b, 0)
+            assert need > 0
+            assert (need + 15) // 16 * 16 + 24 * b <= cap, (B, rows, b, int(n.sum()))
+    assert lib.agcn_store_stage_bytes(0, 10) == 0 and lib.agcn_store_stage_bytes(4, 3) == 0
