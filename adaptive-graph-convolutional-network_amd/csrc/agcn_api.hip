@@ -10,6 +10,7 @@
 #include <unordered_map>
 
 #include "sgc_kernels.h"
+#include "spec_backward_coop.h"
 #include "spec_kernels.h"
 
 namespace agcn {
@@ -119,7 +120,7 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   const AgcnPlanInfo& pi = host.info;
   // opt-in (agcn_set_fused_mode(3)): measured SLOWER than the whole batch on the slab path -- the side chain's six
   // launches each wait for CUs the specialised workgroups hold (HIV-shaped epoch: 1.58 M graphs/s mixed, 1.78 M all-slab)
-  if (agcn_get_fused_mode() < 3 || agcn_get_spec_mode() != 3) return;
+  if (agcn_get_fused_mode() < 3 || (agcn_get_spec_mode() & 3) != 3) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || !use_slabs(d, g, pi)) return;
   int nb = 0, ns = 0;
@@ -243,7 +244,7 @@ SideStream& side_stream() {
   return ss;
 }
 
-struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, MT, WT, total; };
+struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, MT, WT, xch, total; };
 ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   Carver c(nullptr);
   ReserveLayout r;
@@ -258,6 +259,8 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   // transposed parameter copies (specialised kernels)
   r.MT = c.off; c.take((size_t)d->Fin * d->Fin);
   r.WT = c.off; c.take((size_t)d->K * d->Fout * d->Fin);
+  // exchange words of the cooperative backward: 97 64-bit words per graph (spec_backward_coop.h)
+  r.xch = c.off; c.take((size_t)2 * spec::COOP_XCH_WORDS * pi.B);
   r.total = c.off;
   return r;
 }
@@ -402,6 +405,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
+  a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
+  a.coop_slabs = 0;
 
   Carver c(workspace);
   const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
@@ -570,6 +575,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
+  a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
+  a.coop_slabs = 0;
   a.dY = dY; a.dL_sum = dL_sum; a.dX = grads->dX; a.dL_prev = has_prev ? grads->dL_prev : nullptr;
   a.ws_g = w.g; a.ws_dZ = w.dZ; a.ws_pg = w.pg; a.ws_tile = w.tile; a.ws_buf = w.buf;
 
@@ -589,6 +596,38 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   int32_t* counters = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, desc->K,
                                           paper ? 1 : 0, &n_counters);
   a.zero_ptr = counters; a.zero_count = n_counters;
+  // cooperative backward (spec_backward_coop.h): paper mode, every graph in ONE 16-wave launch
+  int coop_graphs = 0, coop_slabs = 0;
+  if (paper && fs.mode == 1 && fs.spec_bwd && fs.spec_bwd_first == 0 && fs.spec_small_first >= B &&
+      (agcn_get_spec_mode() & 4) != 0) {
+    // Members are whole-CU workgroups like every other one.  While the launch still fits the chip (graphs + extra
+    // members <= CUs) every graph of three tiles and up is spread out (B = 128: backward 27.2 -> 17.8 us).  Beyond
+    // that an extra workgroup starts only when another one has finished -- 12 us even for the smallest graph -- and
+    // runs 12 us itself, so only graphs whose own chain is much longer than that 24 us pay: five tiles and up
+    // (the n = 95 graph of an 8-GPU shard: backward 46.2 -> 26.3 us; B = 256 with n <= 59: nothing to gain, measured).
+    static const int min_force = [] { const char* e = std::getenv("AGCN_COOP_MIN_N"); return e ? std::atoi(e) : 0; }();
+    static const int n_cus = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+      return v > 0 ? v : 256;
+    }();
+    int extra = 0;
+    for (int k = 0; k < B; ++k) {
+      const int n = host.n[host.order[k]];
+      if (n < spec::COOP_MIN_N) break;
+      extra += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS - 1;
+    }
+    const int min_n = min_force > 0 ? std::max(spec::COOP_MIN_N, min_force)
+                                    : (B + extra <= n_cus ? spec::COOP_MIN_N : spec::COOP_MIN_N_FULL);
+    while (coop_graphs < B) {
+      const int n = host.n[host.order[coop_graphs]];
+      const int sl = (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
+      if (n < min_n || coop_slabs + sl > spec::COOP_MAX_MEMBERS) break;
+      coop_slabs += sl;
+      ++coop_graphs;
+    }
+  }
   if ((stages & 1) && fused) {
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
@@ -642,6 +681,10 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       if (rc != AGCN_OK) return rc;
       const int ss = std::max(sf, fs.spec_small_first);
       const bool two = ss > sf && ss < B, conc = two && sf == 0 && agcn_get_spec_small() >= 2 && fs.mode == 1;
+      // one launch for every graph: the largest graphs are spread over one workgroup per 16-row tile (members: the
+      // leading slabs of the slab table, which is in the same largest-first order), spec_backward_coop.h
+      const int first_plain = coop_graphs;
+      a.coop_slabs = coop_slabs;
       SideStream* side = nullptr;
       std::unique_lock<std::mutex> side_lock2;
       if (conc) {   // large graphs beside the small ones, as in the forward
@@ -651,9 +694,12 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         if (hipEventRecord(side->fork, main_s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
           return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
       }
-      rc = launch_spec_backward(a, sf, ss - sf,
-                                spec_bwd_lds_bytes(host.n[host.order[sf]], desc->Fin, desc->Fout, spec::NW_LARGE),
-                                spec::NW_LARGE, conc ? side->s : main_s);
+      {
+        const int f0 = std::max(sf, first_plain);
+        size_t lds = f0 < B ? spec_bwd_lds_bytes(host.n[host.order[f0]], desc->Fin, desc->Fout, spec::NW_LARGE) : 0;
+        if (coop_slabs > 0) lds = std::max(lds, spec_coop_lds_bytes(host.n[host.order[0]], desc->Fin, desc->Fout));
+        rc = launch_spec_backward(a, f0, ss - f0, lds, spec::NW_LARGE, conc ? side->s : main_s);
+      }
       if (rc != AGCN_OK) return rc;
       if (ss < B)
         rc = launch_spec_backward(a, ss, B - ss,
@@ -719,7 +765,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
-  pa.B = fused ? B + fs.n_big_slabs : (slabs ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
+  pa.B = fused ? B + fs.n_big_slabs + coop_slabs : (slabs ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
   pa.counters_zeroed = (stages & 1) ? 1 : 0;

@@ -52,8 +52,9 @@ std::atomic<int32_t> g_pg_onepass{[] {
 extern "C" int32_t agcn_get_param_grad_onepass(void) { return g_pg_onepass.load(); }
 extern "C" void agcn_set_param_grad_onepass(int32_t on) { g_pg_onepass.store(on ? 1 : 0); }
 std::atomic<int32_t> g_spec_mode{[] {
-  const char* e = std::getenv("AGCN_SPEC");   // bit 0: specialised forward, bit 1: specialised backward
-  return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
+  // bit 0: specialised forward, bit 1: specialised backward, bit 2: large graphs' backward spread over several workgroups
+  const char* e = std::getenv("AGCN_SPEC");
+  return (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 7;
 }()};
 extern "C" int32_t agcn_get_spec_mode(void) { return g_spec_mode.load(); }
 std::atomic<int32_t> g_spec_small{[] {
@@ -63,7 +64,7 @@ std::atomic<int32_t> g_spec_small{[] {
 }()};
 extern "C" int32_t agcn_get_spec_small(void) { return g_spec_small.load(); }
 extern "C" void agcn_set_spec_small(int32_t on) { g_spec_small.store(on < 0 ? 0 : (on > 2 ? 2 : on)); }
-extern "C" void agcn_set_spec_mode(int32_t mode) { g_spec_mode.store(mode < 0 ? 0 : (mode > 3 ? 3 : mode)); }
+extern "C" void agcn_set_spec_mode(int32_t mode) { g_spec_mode.store(mode < 0 ? 0 : (mode > 7 ? 7 : mode)); }
 extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }
 extern "C" void agcn_set_slab_mode(int32_t mode) { g_slab_mode.store(mode ? 1 : 0); }
 extern "C" void agcn_set_lds_limit(int32_t bytes) {

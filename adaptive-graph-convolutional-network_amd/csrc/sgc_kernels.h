@@ -39,6 +39,11 @@ struct SgcArgs {
   // with the MFMA k index as the row: a fragment load then touches 4 cache lines instead of 16)
   float* sv_MT;    // [Fin][Fin]        M_L^T
   float* sv_WT;    // [K][Fout][Fin]    WT[k][c][f] = W[f*K + k][c]
+  // exchange words of the cooperative backward (spec_backward_coop.h): [B][97] 64-bit words, zeroed per graph by the
+  // specialised forward kernel
+  uint64_t* sv_xch;
+  int32_t coop_slabs;   // backward launch: its first coop_slabs workgroups are members (slabs of the plan's slab table)
+  int32_t coop_pad;
   // global-tile mode scratch
   float* ws_tile;  // [wtile_off[B]]
   float* ws_buf;   // per-graph image scratch, see graph_scratch_floats()

@@ -13,6 +13,7 @@
 //       dZ = (diag(c 1) - c) Z;  dX += dZ M_L^T
 //   B3  every global store: dX, and the hand-off to the parameter-gradient kernel (Gp, dZ, dalpha)
 // No global store precedes the last global load (one in-order vmcnt for loads and stores on gfx950).
+#include "spec_backward_coop.h"
 #include "spec_kernels.h"
 
 #include <float.h>
@@ -30,10 +31,19 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
   constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64;
   constexpr int RPW = NW == NW_SMALL ? 6 : 8;   // rows of a node-feature matrix one wave may own (n4 <= 48 | 128)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  int gpos = first + (int)blockIdx.x;
+  if constexpr (NW == NW_LARGE) {
+    // the first coop_slabs workgroups are the members of the cooperative graphs (positions 0 .. first - 1 of the schedule)
+    if ((int)blockIdx.x < a.coop_slabs) {
+      coop_backward_member<FIN, FOUT>(a, (int)blockIdx.x, smem);
+      return;
+    }
+    gpos -= a.coop_slabs;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const GraphRec g = load_graph(a.graph_desc + first + blockIdx.x);
+  const GraphRec g = load_graph(a.graph_desc + gpos);
   const int n = g.n, row0 = g.row0;
   const uint32_t toff = g.toff;
   const BwdLds d = bwd_lds(n, F4, FOUT, NW);
@@ -525,6 +535,11 @@ size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw) {
   return sizeof(float) * (size_t)spec::bwd_lds(n, F4, Fout, nw).total;
 }
 
+// LDS bytes of a member of the cooperative backward for a graph of n nodes
+size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout) {
+  return sizeof(float) * (size_t)spec::coop_lds(n, (Fin + 15) & ~15, Fout).total;
+}
+
 template <int FIN, int FOUT, int NW>
 static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
@@ -533,7 +548,8 @@ static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_SPEC_BWD, s);
-  hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW>), dim3(count), dim3(64 * NW), lds_bytes, s, a, first);
+  const unsigned members = NW == spec::NW_LARGE ? (unsigned)a.coop_slabs : 0u;
+  hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW>), dim3(members + count), dim3(64 * NW), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_backward launch: %s", hipGetErrorString(e));
@@ -547,7 +563,7 @@ static int launch_spec_backward_w(const SgcArgs& a, int32_t first, int32_t count
 }
 
 int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream) {
-  if (count <= 0) return AGCN_OK;
+  if (count <= 0 && a.coop_slabs <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a.Fin == 75 && a.Fout == 64) return launch_spec_backward_w<75, 64>(a, first, count, lds_bytes, nw, s);
   if (a.Fin == 64 && a.Fout == 128) return launch_spec_backward_w<64, 128>(a, first, count, lds_bytes, nw, s);

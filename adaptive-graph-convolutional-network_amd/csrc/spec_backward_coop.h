@@ -1,0 +1,496 @@
+// A large graph's backward spread over SEVERAL workgroups of the specialised backward launch (spec_backward.hip).
+//
+// With one workgroup per graph a 256-graph step is as long as the dependent chain of its largest graph on ONE CU
+// (n = 59: 26 us, while the median graph is done after 14 us and its CU idles).  Here every 16-row tile of a large
+// graph (n >= COOP_MIN_N) gets a workgroup of its own -- a "member", one per slab of the plan's slab table, so the
+// table's (graph, first row) pairs are the member list -- which computes everything that belongs to its 16 rows:
+//   dX[I], dZ[I], the rows I of Gp, and its share of dalpha.
+// What a member needs from the other rows it recomputes (g_1 = Gp W_1^T for all rows: the rows of dY / Y are read by
+// every member) -- except ONE vector that depends on whole columns of the tile: dd_k = -1/2 s_k^3 ds_k (the degree
+// gradient), needed for every k by the pair pass.  The members exchange it through global memory: each publishes its
+// 16 values as (value, epoch + 1) 64-bit words with agent-scope stores and polls the others' words until their flag
+// matches (one store-to-load latency, no separate flag).  The epoch word of the graph (zeroed, with the slots, by the
+// forward kernel's workgroup of that graph) is read by every member when it starts and bumped by member 0 when it is
+// done, so a second backward on the same forward does not see the first one's words.  Members are the FIRST
+// workgroups of the launch (dispatched before any other), at most COOP_MAX_MEMBERS of them, so all members of a
+// graph are resident while they wait for each other; the waits are bounded all the same.
+#ifndef AGCN_SPEC_BACKWARD_COOP_H_
+#define AGCN_SPEC_BACKWARD_COOP_H_
+
+#include "spec_kernels.h"
+
+namespace agcn {
+namespace spec {
+
+constexpr int COOP_MIN_N = 33;         // graphs of at least three 16-row tiles (while the launch fits the chip)
+constexpr int COOP_MIN_N_FULL = 65;    // ... of at least five, when every extra workgroup has to wait for a CU
+constexpr int COOP_MAX_MEMBERS = 192;  // of 256 CUs
+constexpr int COOP_XCH_WORDS = 97;     // per graph: 96 (value, flag) slots + the epoch word
+constexpr int COOP_SPIN_LIMIT = 1 << 22;
+
+struct CoopLds {
+  int n4, ldt;
+  int o_s, o_dd, o_rs, o_lt, o_r, o_dlr, o_dlc, o_g0, o_g1, o_u, total;
+};
+AGCN_HD inline CoopLds coop_lds(int n, int F4, int Fout) {
+  CoopLds d;
+  d.n4 = (n + 15) & ~15;
+  d.ldt = d.n4 + 2;
+  const int ldx = F4 + 2, ldg = Fout + 2;
+  d.o_s = 32;
+  d.o_dd = d.o_s + d.n4;
+  d.o_rs = d.o_dd + d.n4;
+  d.o_lt = d.o_rs + 16;                  // [16][ldt]  L^T strip: LT[il][k] = L[k][i0 + il]
+  d.o_r = d.o_lt + 16 * d.ldt;           // [16][ldt]  r rows of the strip
+  d.o_dlr = d.o_r + 16 * d.ldt;          // [16][ldt]  dL[i0 + il][j]   -> c strip
+  d.o_dlc = d.o_dlr + 16 * d.ldt;        // [16][ldt]  dL[j][i0 + il]
+  d.o_g0 = d.o_dlc + 16 * d.ldt;         // [16][ldx]  g_0 rows of the strip, later the dZ rows
+  d.o_g1 = d.o_g0 + 16 * ldx;            // [n4][ldx]  g_1 (all rows), later Z (all rows)
+  d.o_u = d.o_g1 + d.n4 * ldx;           // [n4][ldg]  Gp (all rows), later [n4][ldx] X_0 (all rows)
+  const int gp = d.n4 * ldg, x = d.n4 * ldx;
+  d.total = d.o_u + (gp > x ? gp : x);
+  return d;
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint64_t coop_pack(float v, uint32_t flag) {
+  return ((uint64_t)flag << 32) | (uint64_t)__float_as_uint(v);
+}
+
+// One member: slab `sl` of the plan's slab table.  1024 threads.
+template <int FIN, int FOUT>
+__device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int sl, float* smem) {
+  constexpr int NW = 16, NT = 1024;
+  using FT = Feat<FIN>;
+  constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
+  constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64, NKW = FOUT / 4;
+  constexpr int RPW = 6;                       // rows of an [n x F] matrix one wave may own (n4 <= 96)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = uni(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int b = uni(a.slab_graph[sl]), i0 = uni(a.slab_row[sl]);
+  const int n = uni(a.n[b]), row0 = uni(a.row_off[b]);
+  const uint32_t toff = (uint32_t)a.tile_off[b];
+  const CoopLds d = coop_lds(n, F4, FOUT);
+  const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
+  const int me = i0 >> 4;                      // member index == this strip's row tile
+  const bool relu = a.activation == AGCN_ACT_RELU;
+  float* red = smem;
+  float* s_vec = smem + d.o_s;
+  float* ddv = smem + d.o_dd;
+  float* rsv = smem + d.o_rs;
+  float* LT = smem + d.o_lt;
+  float* RS = smem + d.o_r;
+  float* DLr = smem + d.o_dlr;
+  float* DLc = smem + d.o_dlc;
+  float* G0img = smem + d.o_g0;
+  float* DZimg = smem + d.o_g0;
+  float* G1img = smem + d.o_g1;
+  float* Zimg = smem + d.o_g1;
+  float* GPimg = smem + d.o_u;
+  float* X0img = smem + d.o_u;
+  const float* Xg = a.X + (int64_t)row0 * a.ldx;
+  const float* Yg = a.Y + (int64_t)row0 * a.ldy;
+  const float* dYg = a.dY + (int64_t)row0 * a.ldy;
+  const float alpha = a.alpha[0];
+  uint64_t* xch = a.sv_xch + (int64_t)b * COOP_XCH_WORDS;
+  // the epoch of this backward: read before anything is published (member 0 bumps it only after it has every member's
+  // words, i.e. after every member has got here)
+  const uint32_t want = (uint32_t)__hip_atomic_load(xch + 96, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+
+  AGCN_STAMP(5, 0);
+  // ---- M0: one round of loads ---------------------------------------------------------------------------------
+  int csr_p0 = 0, csr_p1 = 0;
+  if (a.L0_rowptr && tid < n) {
+    csr_p0 = a.L0_rowptr[row0 + tid];
+    csr_p1 = a.L0_rowptr[row0 + tid + 1];
+  }
+  float gy[RPW][CPO], yy[RPW][CPO];
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int i = min(wave + NW * u, n - 1);
+#pragma unroll
+    for (int cp = 0; cp < CPO; ++cp) {
+      const int c = min(lane + 64 * cp, FOUT - 1);
+      gy[u][cp] = 0.f;
+      yy[u][cp] = 0.f;
+      if (u < rpw) {
+        gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
+        yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
+      }
+    }
+  }
+  // r rows of the strip: wave il owns row i0 + il (the forward stored both triangles for these graphs)
+  float rr[2];
+  {
+    const int i = min(i0 + wave, n - 1);
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      rr[cp] = 0.f;
+      if (64 * cp < n) rr[cp] = a.sv_r[toff + (uint32_t)(i * n + min(lane + 64 * cp, n - 1))];
+    }
+  }
+  const float s_own = a.sv_s[row0 + min(tid, n - 1)];
+  int csr_c[6] = {0, 0, 0, 0, 0, 0};
+  float csr_v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tid < n && csr_p1 > csr_p0) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int pp = min(csr_p0 + u, csr_p1 - 1);
+      csr_c[u] = a.L0_col[pp];
+      csr_v[u] = a.L0_val[pp];
+    }
+  }
+  float gpown[CPO];   // Gp row i0 + wave (this wave loaded it: rows wave, wave + 16, ..), for the hand-off store
+#pragma unroll
+  for (int cp = 0; cp < CPO; ++cp) gpown[cp] = 0.f;
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int i = wave + NW * u;
+#pragma unroll
+    for (int cp = 0; cp < CPO; ++cp) {
+      const int c = lane + 64 * cp;
+      const float v = (i < n && c < FOUT && (!relu || yy[u][cp] > 0.f)) ? gy[u][cp] : 0.f;
+      if (u == me) gpown[cp] = v;
+      if (i < n4 && c < FOUT) GPimg[i * LDG + c] = v;
+    }
+  }
+  {
+    const int i = i0 + wave;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int j = lane + 64 * cp;
+      if (j < n4) RS[wave * ldt + j] = (i < n && j < n && j != i) ? rr[cp] : 0.f;
+    }
+  }
+  if (tid < n4) s_vec[tid] = tid < n ? s_own : 0.f;
+  lds_barrier();
+  AGCN_STAMP(5, 1);
+
+  // ---- M1: L^T strip  LT[il][k] = lrelu(R_k,i) + L_orig[k][i],  R_ki = delta - (s_k S) s_i  (the forward's operand order)
+  {
+    const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+    const float* L0d = !a.L0_dense ? nullptr
+                                   : (a.L0_ld > 0 ? a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
+    const int i = i0 + wave;
+    const float si = s_vec[min(i, n4 - 1)];
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int k = lane + 64 * cp;
+      if (k < n4) {
+        float out = 0.f;
+        if (i < n && k < n) {
+          const float S = (i == k) ? 0.f : fast_exp_neg(RS[wave * ldt + k]);
+          float R = (i == k) ? 1.f : 0.f;
+          R = R - (s_vec[k] * S) * si;
+          out = lrelu(R, alpha);
+          if (L0d) out += L0d[(int64_t)k * l0ld + i];
+        }
+        LT[wave * ldt + k] = out;
+      }
+    }
+  }
+  lds_barrier();
+  if (a.L0_rowptr && tid < n) {      // CSR row tid: its entries in the columns of the strip
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (csr_p0 + u < csr_p1 && csr_c[u] >= i0 && csr_c[u] < i0 + 16) LT[(csr_c[u] - i0) * ldt + tid] += csr_v[u];
+    for (int p = csr_p0 + 6; p < csr_p1; ++p) {
+      const int c = a.L0_col[p];
+      if (c >= i0 && c < i0 + 16) LT[(c - i0) * ldt + tid] += a.L0_val[p];
+    }
+  }
+
+  AGCN_STAMP(5, 2);
+  // ---- M2: g_1 = Gp W_1^T for ALL rows -> image;  g_0 = Gp[I] W_0^T -> image -------------------------------------
+  {
+    constexpr int CHW = 16, NCHW = NKW / CHW;
+    int ta, tb;
+    tile_range<NW>((ntm + 1) * NCB, wave, ta, tb);
+    for (int t = ta; t < tb; ++t) {
+      const bool own = t >= ntm * NCB;            // a g_0 tile of the strip
+      const int rt = own ? me : t / NCB, cb = own ? t - ntm * NCB : t - rt * NCB;
+      const int kk = own ? 0 : 1;
+      const float* Ap = GPimg + (rt * 16 + r) * LDG + q;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < NCHW; ++ch) {
+        const float* p = a.sv_WT + kk * (FOUT * FIN) + (q + 4 * CHW * ch) * FIN + min(cb * 16 + r, FIN - 1);
+        float wf[CHW];
+#pragma unroll
+        for (int u = 0; u < CHW; ++u) wf[u] = p[4 * u * FIN];
+#pragma unroll
+        for (int u = 0; u < CHW; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * (CHW * ch + u)], wf[u], acc, 0, 0, 0);
+      }
+      const int f = cb * 16 + r;
+      const bool fv = f < FIN;
+      float* dst = own ? G0img + (4 * q) * LDX + f : G1img + (rt * 16 + 4 * q) * LDX + f;
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? acc[i4] : 0.f;
+    }
+  }
+  lds_barrier();
+  AGCN_STAMP(5, 3);
+
+  // ---- M3: dX[I] = g_0[I] + L^T[I, :] g_1 (waves < NCB keep their tile);  X_0 rows requested meanwhile ------------
+  float xzr[RPW][CP];
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const float* rp = Xg + (int64_t)min(wave + NW * u, n - 1) * a.ldx;
+#pragma unroll
+    for (int cp = 0; cp < CP; ++cp) {
+      xzr[u][cp] = 0.f;
+      if (u < rpw) xzr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
+    }
+  }
+  f32x4 dxacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (wave < NCB) {
+    const int cb = wave;
+    const float* Ap = LT + r * ldt + q;
+    const float* Bp = G1img + q * LDX + cb * 16 + r;
+    const int f = cb * 16 + r;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) dxacc[i4] = G0img[(4 * q + i4) * LDX + f];
+    for (int k0 = 0; k0 < n4; k0 += 16) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = Ap[k0 + 4 * u];
+        bv[u] = Bp[(k0 + 4 * u) * LDX];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dxacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], dxacc, 0, 0, 0);
+    }
+  }
+  // X_0 rows -> image over the (dead) Gp image
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int i = wave + NW * u;
+    if (i < n4) {
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        const int c = lane + 64 * cp;
+        if (c < F4) X0img[i * LDX + c] = (i < n && c < FIN) ? xzr[u][cp] : 0.f;
+      }
+    }
+  }
+  lds_barrier();
+  AGCN_STAMP(5, 4);
+
+  // ---- M4: dL row strip (g_1[I] X_0^T) and column strip ((g_1 X_0[I]^T)^T = X_0[I] g_1^T);  Z rows requested --------
+  {
+    const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = min(wave + NW * u, n - 1);
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        xzr[u][cp] = 0.f;
+        if (u < rpw) xzr[u][cp] = Zg[i * FIN + min(lane + 64 * cp, FIN - 1)];
+      }
+    }
+    int ta, tb;
+    tile_range<NW>(2 * ntm, wave, ta, tb);
+    for (int t = ta; t < tb; ++t) {
+      const bool col = t >= ntm;
+      const int ct = col ? t - ntm : t;
+      const float* Ap = (col ? X0img : G1img) + (me * 16 + r) * LDX + q;
+      const float* Bp = (col ? G1img : X0img) + (ct * 16 + r) * LDX + q;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], Bp[4 * u], acc, 0, 0, 0);
+      float* dst = (col ? DLc : DLr) + (4 * q) * ldt + ct * 16 + r;
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) dst[i4 * ldt] = acc[i4];
+    }
+  }
+  lds_barrier();
+  // Z rows -> image over g_1 (dead)
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int i = wave + NW * u;
+    if (i < n4) {
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        const int c = lane + 64 * cp;
+        if (c < F4) Zimg[i * LDX + c] = (i < n && c < FIN) ? xzr[u][cp] : 0.f;
+      }
+    }
+  }
+
+  AGCN_STAMP(5, 5);
+  // ---- M5: pass 1 over the strip's rows (wave il = row i0 + il): dalpha, ds_i -> dd_i, published to the other members
+  float dalpha_part = 0.f;
+  {
+    const int i = i0 + wave;
+    float dsum = 0.f;
+    if (i < n) {   // (uniform)
+      const float si = s_vec[i];
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        if (j < n) {
+          const float sj = s_vec[j];
+          const float Sv = (i == j) ? 0.f : fast_exp_neg(RS[wave * ldt + j]);
+          const float dlt = (i == j) ? 1.f : 0.f;
+          const float Rij = dlt - (si * Sv) * sj, Rji = dlt - (sj * Sv) * si;
+          const float dLij = DLr[wave * ldt + j], dLji = DLc[wave * ldt + j];
+          dalpha_part += dLij * fminf(Rij, 0.f);
+          const float Pij = -(dLij * lrelu_grad(Rij, alpha)) * Sv;   // dA_ij S_ij
+          const float Pji = -(dLji * lrelu_grad(Rji, alpha)) * Sv;   // dA_ji S_ji
+          dsum += Pij * sj + Pji * sj;
+        }
+      }
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0 && i < n) {
+      const float ddk = degree_grad(s_vec[i], dsum);   // dd_k = -1/2 s_k^3 ds_k
+      ddv[i] = ddk;
+      __hip_atomic_store(xch + i, coop_pack(ddk, want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // the other members' dd: poll their words until the flag is this backward's
+  if (tid < n && (tid < i0 || tid >= i0 + 16)) {
+    uint64_t w = 0;
+    int it = 0;
+    do {
+      w = __hip_atomic_load(xch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(w >> 32) == want) break;
+      __builtin_amdgcn_s_sleep(2);
+    } while (++it < COOP_SPIN_LIMIT);
+    ddv[tid] = (it < COOP_SPIN_LIMIT) ? __uint_as_float((uint32_t)w) : __builtin_nanf("");   // (a wait that ran out is loud)
+  }
+  lds_barrier();
+  AGCN_STAMP(5, 6);
+
+  // ---- M6: pass 2: c_ij = (dr_ij + dr_ji) / r_ij over the strip's rows, in place over the dL row strip; row sums -----
+  {
+    const int i = i0 + wave;
+    float rsum = 0.f;
+    if (i < n) {
+      const float si = s_vec[i], ddi = ddv[i];
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        if (j < n4) {
+          float cij = 0.f;
+          if (j < n && j != i) {
+            const float rv = RS[wave * ldt + j];
+            const float Sv = fast_exp_neg(rv);
+            const float sj = s_vec[j];
+            const float Rij = -((si * Sv) * sj), Rji = -((sj * Sv) * si);
+            const float dAij = -(DLr[wave * ldt + j] * lrelu_grad(Rij, alpha));
+            const float dAji = -(DLc[wave * ldt + j] * lrelu_grad(Rji, alpha));
+            if (Sv != 0.f && rv > 0.f) {
+              const float dr_ij = -Sv * (dAij * si * sj + ddv[j]);
+              const float dr_ji = -Sv * (dAji * sj * si + ddi);
+              cij = (dr_ij + dr_ji) * fast_rcp(rv);
+            }
+          }
+          DLr[wave * ldt + j] = cij;
+          rsum += cij;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp)
+        if (lane + 64 * cp < n4) DLr[wave * ldt + lane + 64 * cp] = 0.f;
+    }
+    rsum = wave_sum(rsum);
+    if (lane == 0) rsv[wave] = rsum;
+  }
+  lds_barrier();
+  AGCN_STAMP(5, 7);
+
+  // ---- M7: dZ[I] = rowsum(c) Z[I] - c[I, :] Z  -> image + registers ------------------------------------------------
+  f32x4 zacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (wave < NCB) {
+    const int cb = wave;
+    const float* Ap = DLr + r * ldt + q;
+    const float* Bp = Zimg + q * LDX + cb * 16 + r;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < n4; k0 += 16) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = Ap[k0 + 4 * u];
+        bv[u] = Bp[(k0 + 4 * u) * LDX];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    const int f = cb * 16 + r;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int il = 4 * q + i4;
+      const float v = (i0 + il < n) ? rsv[il] * Zimg[(i0 + il) * LDX + f] - acc[i4] : 0.f;
+      DZimg[il * LDX + f] = v;
+      zacc[i4] = v;
+    }
+  }
+  lds_barrier();
+  AGCN_STAMP(5, 8);
+
+  // ---- M8: dX[I] += dZ[I] M_L^T, then every global store ------------------------------------------------------------
+  if (wave < NCB) {
+    const int cb = wave;
+    const float* Ap = DZimg + r * LDX + q;
+    const float* p = a.sv_MT + q * FIN + min(cb * 16 + r, FIN - 1);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int CHM = 16;
+#pragma unroll
+    for (int u0 = 0; u0 < NKS; u0 += CHM) {
+      float bf[CHM];
+#pragma unroll
+      for (int uu = 0; uu < CHM; ++uu) {
+        const int u = u0 + uu;
+        if (u < NKS) bf[uu] = (4 * u + 3 < FIN) ? p[4 * u * FIN] : p[(min(4 * u + q, FIN - 1) - q) * FIN];
+      }
+#pragma unroll
+      for (int uu = 0; uu < CHM; ++uu) {
+        const int u = u0 + uu;
+        if (u < NKS) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[uu], acc, 0, 0, 0);
+      }
+    }
+    const int f = cb * 16 + r;
+    if (f < FIN) {
+      float* dXg = a.dX + (int64_t)row0 * a.ldx;
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int i = i0 + 4 * q + i4;
+        if (i < n) {
+          dXg[(int64_t)i * a.ldx + f] = dxacc[i4] + acc[i4];
+          a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[i4];
+        }
+      }
+    }
+  }
+  if (i0 + wave < n) {
+#pragma unroll
+    for (int cp = 0; cp < CPO; ++cp) {
+      const int c = lane + 64 * cp;
+      if (c < FOUT) a.ws_Gp[(int64_t)(row0 + i0 + wave) * FOUT + c] = gpown[cp];
+    }
+  }
+  const float da = block_sum(dalpha_part, red);
+  if (tid == 0) {
+    a.ws_pg[2 * (a.B + sl) + 0] = da;
+    a.ws_pg[2 * (a.B + sl) + 1] = 0.f;
+    if (i0 == 0) {
+      a.ws_pg[2 * b + 0] = 0.f;
+      a.ws_pg[2 * b + 1] = 0.f;
+      // member 0 holds every member's words by now: the next backward on this forward gets a new epoch
+      __hip_atomic_store(xch + 96, (uint64_t)want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  AGCN_STAMP(5, 9);
+  if (sl == 0) {   // arrival counters of the parameter-gradient kernel that follows
+    for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
+  }
+}
+#endif
+
+}  // namespace spec
+}  // namespace agcn
+
+#endif  // AGCN_SPEC_BACKWARD_COOP_H_

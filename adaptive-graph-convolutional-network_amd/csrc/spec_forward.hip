@@ -17,6 +17,7 @@
 // requested at the start of F4) is waited for; the outputs of F4 / F5 (X_1, Y) are stored after the last W fragment
 // has been requested (the Y accumulators wait in registers).  Fragments are requested one phase ahead at most: held
 // longer, the register allocator moves them around and has to wait for them on the spot (measured).
+#include "spec_backward_coop.h"
 #include "spec_kernels.h"
 
 #include <float.h>
@@ -199,7 +200,11 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
           const float sv = (i == j) ? 0.f : fast_exp_neg(rr);   // graphconv.py:171-177
           tile[i * ldt + j] = sv;
           tile[j * ldt + i] = sv;   // bit-symmetric by construction
-          if (paper && i < j) AGCN_ST(2, &a.sv_r[toff + (uint32_t)(i * n + j)], rr);   // the backward reads r_ij for i < j only
+          if (paper && i < j) {   // the backward reads r_ij for i < j only ...
+            AGCN_ST(2, &a.sv_r[toff + (uint32_t)(i * n + j)], rr);
+            // ... unless the graph's backward is spread over several workgroups, each of which reads whole rows
+            if (n >= COOP_MIN_N) AGCN_ST(2, &a.sv_r[toff + (uint32_t)(j * n + i)], rr);
+          }
         }
       }
     }
@@ -337,6 +342,8 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
         }
       }
     }
+    // exchange words of a cooperative backward of this graph: all invalid, epoch 0
+    if (n >= COOP_MIN_N && tid < COOP_XCH_WORDS) a.sv_xch[(int64_t)g.b * COOP_XCH_WORDS + tid] = 0ull;
     // X_1 rows (reserve: the parameter gradients read them)
     float* Xo = a.sv_X + (int64_t)row0 * FIN;
     for (int i = wave; i < n; i += NW)

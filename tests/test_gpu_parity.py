@@ -1013,7 +1013,7 @@ def test_far_away_nodes_do_not_poison_the_gradients(amd, path):
     every output and gradient must be finite and agree with the oracle -- with one far node, and with two (whose
     mutual s_i s_j overflows too)."""
     lib = amd._ffi.lib()
-    fm, sm, spec = {"auto": (1, 1, 3), "fused_general": (1, 1, 0), "slab": (0, 1, 0), "pergraph": (0, 0, 0)}[path]
+    fm, sm, spec = {"auto": (1, 1, 7), "fused_general": (1, 1, 0), "slab": (0, 1, 0), "pergraph": (0, 0, 0)}[path]
     lib.agcn_set_fused_mode(fm)
     lib.agcn_set_slab_mode(sm)
     lib.agcn_set_spec_mode(spec)
@@ -1034,7 +1034,7 @@ def test_far_away_nodes_do_not_poison_the_gradients(amd, path):
     finally:
         lib.agcn_set_fused_mode(1)
         lib.agcn_set_slab_mode(1)
-        lib.agcn_set_spec_mode(3)
+        lib.agcn_set_spec_mode(7)
 
 
 def test_epoch_step_static_buffers_match_the_autograd_path(amd):
@@ -1150,3 +1150,48 @@ def test_epoch_lanes_give_the_single_lane_results(amd):
     assert len(got) == len(want)
     for (a, b, c), (x, y, z) in zip(got, want):
         assert torch.equal(a, x) and torch.equal(b, y) and torch.equal(c, z)
+
+
+@pytest.mark.parametrize("Fin,Fout", [(75, 64), (64, 128), (128, 128), (128, 64), (64, 64)])
+def test_large_graphs_spread_over_several_workgroups(amd, Fin, Fout):
+    """Paper-mode backward with the graphs of >= 33 nodes spread over one workgroup per 16-row tile (members exchange
+    the degree gradients through global memory, spec_backward_coop.h) against the one-workgroup-per-graph kernel
+    (agcn_set_spec_mode(3)): every gradient within the gradient tolerance of each other (different summation orders),
+    repeated backward calls on one forward and HIP-graph replays bit-identical to the first call, and all of it
+    against the float64 oracle.  Sizes cover 3 .. 6 tiles, ragged last tiles (33, 49, 81) and exact multiples."""
+    ns = [96, 81, 80, 64, 59, 49, 48, 33, 32, 17, 5, 40, 95, 70]
+    K = 2
+    rs, X, L0, csr, p, G = synth_case(5, ns, Fin, Fout, K, orc.SGC_LL, atoms=(Fin == 75))
+    p["alpha"] = np.array([0.8], np.float32)
+    caches, tot = oracle_run(X, L0, p, K, orc.PAPER, orc.SGC_LL, G, None, None)
+    lib = amd._ffi.lib()
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, orc.PAPER, p, DEV)
+    dY = torch.from_numpy(np.concatenate(G, 0)).to(DEV)
+    res = {}
+    try:
+        for mode in (3, 7):
+            lib.agcn_set_spec_mode(mode)
+            out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, orc.PAPER, orc.SGC_LL, None, None)
+            compare_with_oracle(out, caches, tot, orc.SGC_LL, orc.PAPER, K, has_prev=False)
+            st = amd.SgcLLStep(layer, gb, dY=dY)
+            st.step()
+            torch.cuda.synchronize()
+            first = (st.bucket.clone(), st.dX.clone())
+            for _ in range(3):                       # backward again on the same forward: a new exchange epoch
+                st.bucket.fill_(float("nan"))
+                st.dX.fill_(float("nan"))
+                st.backward()
+                torch.cuda.synchronize()
+                assert torch.equal(st.bucket, first[0]) and torch.equal(st.dX, first[1])
+            st.capture()
+            for _ in range(3):
+                st.bucket.fill_(float("nan"))
+                st.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(st.bucket, first[0]) and torch.equal(st.dX, first[1])
+            res[mode] = first
+    finally:
+        lib.agcn_set_spec_mode(7)
+    assert_close(to_np(res[7][1]), to_np(res[3][1]), 2 * GRAD_RTOL, "dX coop vs plain", atol_ulps=2 * GRAD_ULPS)
+    assert_close(to_np(res[7][0]), to_np(res[3][0]), 2 * GRAD_RTOL, "bucket coop vs plain", atol_ulps=2 * GRAD_ULPS)
