@@ -137,6 +137,45 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   m.spec_fwd = m.spec_bwd = 1; m.spec_bwd_first = nb; m.spec_small_first = pi.B;
   *f = m;
 }
+// Cooperative kernels (spec_backward_coop.h): how many of the largest graphs (a prefix of the schedule) are spread over
+// one workgroup per 16-row tile, and how many members (slabs) that makes.  The same answer for the forward and the
+// backward of a batch.
+void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, int* graphs, int* slabs) {
+  *graphs = *slabs = 0;
+  const int B = host.info.B;
+  if (d->mode != AGCN_MODE_PAPER || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
+      fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
+    return;
+  // Members are whole-CU workgroups like every other one.  While the launch still fits the chip (graphs + extra
+  // members <= CUs) every graph of three tiles and up is spread out (B = 128: backward 27.2 -> 17.8 us).  Beyond
+  // that an extra workgroup starts only when another one has finished -- 12 us even for the smallest graph -- and
+  // runs 12 us itself, so only graphs whose own chain is much longer than that 24 us pay: five tiles and up
+  // (the n = 95 graph of an 8-GPU shard: backward 46.2 -> 26.3 us; B = 256 with n <= 59: nothing to gain, measured).
+  static const int min_force = [] { const char* e = std::getenv("AGCN_COOP_MIN_N"); return e ? std::atoi(e) : 0; }();
+  static const int n_cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+    return v > 0 ? v : 256;
+  }();
+  int extra = 0;
+  for (int k = 0; k < B; ++k) {
+    const int n = host.n[host.order[k]];
+    if (n < spec::COOP_MIN_N) break;
+    extra += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS - 1;
+  }
+  const int min_n = min_force > 0 ? std::max(spec::COOP_MIN_N, min_force)
+                                  : (B + extra <= n_cus ? spec::COOP_MIN_N : spec::COOP_MIN_N_FULL);
+  int g = 0, s = 0;
+  while (g < B - 1) {   // (the last graph of the schedule stays a plain workgroup: it writes the transposed parameters)
+    const int n = host.n[host.order[g]];
+    const int sl = (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
+    if (n < min_n || s + sl > spec::COOP_MAX_MEMBERS) break;
+    s += sl;
+    ++g;
+  }
+  *graphs = g; *slabs = s;
+}
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host);
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
   FusedSplit f = fused_split_general(d, g, host);
@@ -248,6 +287,9 @@ struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, MT, WT, xch, total; };
 ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   Carver c(nullptr);
   ReserveLayout r;
+  // exchange header of the cooperative kernels (spec_backward_coop.h): fixed size, at offset 0 whatever the batch, zero
+  // when the reserve is first used (include/agcn.h) and self-maintaining afterwards
+  r.xch = c.off; c.take((size_t)2 * spec::COOP_HEADER_WORDS);
   r.Z = c.off; c.take((size_t)pi.rows * d->Fin);
   r.s = c.off; c.take((size_t)pi.rows);
   r.scal = c.off; c.take((size_t)4 * pi.B);
@@ -259,8 +301,6 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   // transposed parameter copies (specialised kernels)
   r.MT = c.off; c.take((size_t)d->Fin * d->Fin);
   r.WT = c.off; c.take((size_t)d->K * d->Fout * d->Fin);
-  // exchange words of the cooperative backward: 97 64-bit words per graph (spec_backward_coop.h)
-  r.xch = c.off; c.take((size_t)2 * spec::COOP_XCH_WORDS * pi.B);
   r.total = c.off;
   return r;
 }
@@ -435,8 +475,14 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
         if (hipEventRecord(side->fork, main_s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
           return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
       }
-      rc = launch_spec_forward(a, 0, ss, spec_fwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, spec::NW_LARGE),
-                               spec::NW_LARGE, conc ? side->s : main_s);
+      {
+        int cg = 0, cs = 0;
+        coop_plan(desc, host, fs, &cg, &cs);
+        a.coop_slabs = cs;
+        size_t lds = spec_fwd_lds_bytes(host.n[host.order[cg]], desc->Fin, desc->Fout, spec::NW_LARGE);
+        if (cs > 0) lds = std::max(lds, spec_coop_fwd_lds_bytes(host.n[host.order[0]], desc->Fin));
+        rc = launch_spec_forward(a, cg, ss - cg, lds, spec::NW_LARGE, conc ? side->s : main_s);
+      }
       if (rc != AGCN_OK) return rc;
       if (ss < B)
         rc = launch_spec_forward(a, ss, B - ss,
@@ -596,38 +642,9 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   int32_t* counters = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, desc->K,
                                           paper ? 1 : 0, &n_counters);
   a.zero_ptr = counters; a.zero_count = n_counters;
-  // cooperative backward (spec_backward_coop.h): paper mode, every graph in ONE 16-wave launch
+  // cooperative backward (spec_backward_coop.h)
   int coop_graphs = 0, coop_slabs = 0;
-  if (paper && fs.mode == 1 && fs.spec_bwd && fs.spec_bwd_first == 0 && fs.spec_small_first >= B &&
-      (agcn_get_spec_mode() & 4) != 0) {
-    // Members are whole-CU workgroups like every other one.  While the launch still fits the chip (graphs + extra
-    // members <= CUs) every graph of three tiles and up is spread out (B = 128: backward 27.2 -> 17.8 us).  Beyond
-    // that an extra workgroup starts only when another one has finished -- 12 us even for the smallest graph -- and
-    // runs 12 us itself, so only graphs whose own chain is much longer than that 24 us pay: five tiles and up
-    // (the n = 95 graph of an 8-GPU shard: backward 46.2 -> 26.3 us; B = 256 with n <= 59: nothing to gain, measured).
-    static const int min_force = [] { const char* e = std::getenv("AGCN_COOP_MIN_N"); return e ? std::atoi(e) : 0; }();
-    static const int n_cus = [] {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-      return v > 0 ? v : 256;
-    }();
-    int extra = 0;
-    for (int k = 0; k < B; ++k) {
-      const int n = host.n[host.order[k]];
-      if (n < spec::COOP_MIN_N) break;
-      extra += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS - 1;
-    }
-    const int min_n = min_force > 0 ? std::max(spec::COOP_MIN_N, min_force)
-                                    : (B + extra <= n_cus ? spec::COOP_MIN_N : spec::COOP_MIN_N_FULL);
-    while (coop_graphs < B) {
-      const int n = host.n[host.order[coop_graphs]];
-      const int sl = (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
-      if (n < min_n || coop_slabs + sl > spec::COOP_MAX_MEMBERS) break;
-      coop_slabs += sl;
-      ++coop_graphs;
-    }
-  }
+  coop_plan(desc, host, fs, &coop_graphs, &coop_slabs);
   if ((stages & 1) && fused) {
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);

@@ -9,13 +9,19 @@
 // every member) -- except ONE vector that depends on whole columns of the tile: dd_k = -1/2 s_k^3 ds_k (the degree
 // gradient), needed for every k by the pair pass.  The members exchange it through global memory: each publishes its
 // 16 values as (value, epoch + 1) 64-bit words with agent-scope stores and polls the others' words until their flag
-// matches (one store-to-load latency, no separate flag).  The epoch word of the graph (zeroed, with the slots, by the
-// forward kernel's workgroup of that graph) is read by every member when it starts and bumped by member 0 when it is
-// done, so a second backward on the same forward does not see the first one's words.  Members are the FIRST
-// workgroups of the launch (dispatched before any other), at most COOP_MAX_MEMBERS of them, so all members of a
-// graph are resident while they wait for each other; the waits are bounded all the same.
+// matches (one store-to-load latency, no separate flag).  The words live in a fixed-size HEADER at the start of the
+// reserve (COOP_HEADER_WORDS 64-bit words: per direction one slot per member row and one epoch word per member, keyed
+// by the graph's first slab).  The header is zero when a reserve is first used -- the caller's only obligation -- and
+// only ever holds (value, epoch) words afterwards: a graph's epoch word is read by every member when it starts and
+// bumped by member 0 when it is done, so words of earlier launches, whatever batch they belonged to, never match.
+// Members are the FIRST workgroups of the launch (dispatched before any other), at most COOP_MAX_MEMBERS of them, so
+// all members of a graph are resident while they wait for each other; the waits are bounded all the same.
+// The forward is spread the same way (coop_forward_member): a member computes Z for all rows, the rows I of the
+// similarity tile and their degrees -- and the members exchange s = d^-1/2.
 #ifndef AGCN_SPEC_BACKWARD_COOP_H_
 #define AGCN_SPEC_BACKWARD_COOP_H_
+
+#include <float.h>
 
 #include "spec_kernels.h"
 
@@ -25,7 +31,10 @@ namespace spec {
 constexpr int COOP_MIN_N = 33;         // graphs of at least three 16-row tiles (while the launch fits the chip)
 constexpr int COOP_MIN_N_FULL = 65;    // ... of at least five, when every extra workgroup has to wait for a CU
 constexpr int COOP_MAX_MEMBERS = 192;  // of 256 CUs
-constexpr int COOP_XCH_WORDS = 97;     // per graph: 96 (value, flag) slots + the epoch word
+// exchange header at the start of the reserve, per direction (0 backward, 1 forward): one slot per member row, one
+// epoch word per member (a graph uses the rows / the epoch of its first slab)
+constexpr int COOP_DIR_WORDS = COOP_MAX_MEMBERS * 16 + COOP_MAX_MEMBERS;
+constexpr int COOP_HEADER_WORDS = 2 * COOP_DIR_WORDS;
 constexpr int COOP_SPIN_LIMIT = 1 << 22;
 
 struct CoopLds {
@@ -93,10 +102,15 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const float* Yg = a.Y + (int64_t)row0 * a.ldy;
   const float* dYg = a.dY + (int64_t)row0 * a.ldy;
   const float alpha = a.alpha[0];
-  uint64_t* xch = a.sv_xch + (int64_t)b * COOP_XCH_WORDS;
-  // the epoch of this backward: read before anything is published (member 0 bumps it only after it has every member's
-  // words, i.e. after every member has got here)
-  const uint32_t want = (uint32_t)__hip_atomic_load(xch + 96, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  uint64_t* xch = a.sv_xch + (sl - me) * 16;                        // this graph's slots (direction 0): row i at xch + i
+  uint64_t* xep = a.sv_xch + COOP_MAX_MEMBERS * 16 + (sl - me);     // ... and its members' epoch words
+  // Every member has an epoch word of its own (keyed by ITS slab index, like its 16 slots: a slot is only ever written
+  // under one epoch counter, whatever graphs of whatever batches use it over time).  A member reads the epochs of all
+  // members of its graph before it publishes anything and bumps its own when it is done -- by then it holds every
+  // sibling's words, so every sibling has read the epochs.
+  uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [8] in the (otherwise unused) tail of the `red` area
+  if (tid < ntm)
+    wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 
   AGCN_STAMP(5, 0);
   // ---- M0: one round of loads ---------------------------------------------------------------------------------
@@ -346,11 +360,12 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     if (lane == 0 && i < n) {
       const float ddk = degree_grad(s_vec[i], dsum);   // dd_k = -1/2 s_k^3 ds_k
       ddv[i] = ddk;
-      __hip_atomic_store(xch + i, coop_pack(ddk, want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(xch + i, coop_pack(ddk, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   // the other members' dd: poll their words until the flag is this backward's
   if (tid < n && (tid < i0 || tid >= i0 + 16)) {
+    const uint32_t want = wants[tid >> 4];
     uint64_t w = 0;
     int it = 0;
     do {
@@ -479,14 +494,304 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     if (i0 == 0) {
       a.ws_pg[2 * b + 0] = 0.f;
       a.ws_pg[2 * b + 1] = 0.f;
-      // member 0 holds every member's words by now: the next backward on this forward gets a new epoch
-      __hip_atomic_store(xch + 96, (uint64_t)want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // this member holds every sibling's words by now: its next launch gets a new epoch
+    __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   AGCN_STAMP(5, 9);
   if (sl == 0) {   // arrival counters of the parameter-gradient kernel that follows
     for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
   }
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+struct CoopFwdLds {
+  int n4, ldt, ldz;
+  int o_s, o_st, o_x, o_z, o_x1, total;
+};
+AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4) {
+  CoopFwdLds d;
+  d.n4 = (n + 15) & ~15;
+  d.ldt = d.n4 + 2;
+  d.ldz = d.n4 + 4;
+  const int ldx = F4 + 2;
+  d.o_s = 32;
+  d.o_st = d.o_s + d.n4;              // [16][ldt]  S rows of the strip, then L rows
+  d.o_x = d.o_st + 16 * d.ldt;        // [n4][ldx]  X_0 (all rows)
+  d.o_z = d.o_x + d.n4 * ldx;         // [F4][ldz]  Z^T (all rows)
+  d.o_x1 = d.o_z + F4 * d.ldz;        // [16][ldx]  X_1 rows of the strip
+  d.total = d.o_x1 + 16 * ldx;
+  return d;
+}
+
+// One forward member: slab `sl`.  Same math as spec_forward_kernel, restricted to the 16 rows of the strip:
+//   Z (all rows, recomputed by every member) -> S[I, :], r[I, :], d[I] -> s[I] published, s of the other rows polled
+//   -> res_L[I, :], L[I, :] -> X_1[I] = L[I, :] X_0 -> Y[I].
+// The distance sums run over the features in index order for both (i, j) and (j, i), so S stays bit-symmetric across
+// members; degrees are wave sums (not the serial column sums of the one-workgroup kernel: last-ulp differences).
+template <int FIN, int FOUT>
+__device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int sl, float* smem) {
+  constexpr int NW = 16;
+  using FT = Feat<FIN>;
+  constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
+  constexpr int NOB = FOUT / 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = uni(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int b = uni(a.slab_graph[sl]), i0 = uni(a.slab_row[sl]);
+  const int n = uni(a.n[b]), row0 = uni(a.row_off[b]);
+  const uint32_t toff = (uint32_t)a.tile_off[b];
+  const CoopFwdLds d = coop_fwd_lds(n, F4);
+  const int n4 = d.n4, ldt = d.ldt, ldz = d.ldz, ntm = n4 >> 4;
+  const int me = i0 >> 4;
+  const bool relu = a.activation == AGCN_ACT_RELU;
+  float* s_vec = smem + d.o_s;
+  float* St = smem + d.o_st;
+  float* Ximg = smem + d.o_x;
+  float* Zt = smem + d.o_z;
+  float* X1s = smem + d.o_x1;
+  const float* Xg = a.X + (int64_t)row0 * a.ldx;
+  const float alpha = a.alpha[0];
+  uint64_t* xch = a.sv_xch + COOP_DIR_WORDS + (sl - me) * 16;                     // direction 1
+  uint64_t* xep = a.sv_xch + COOP_DIR_WORDS + COOP_MAX_MEMBERS * 16 + (sl - me);
+  uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [8], see coop_backward_member
+  if (tid < ntm)
+    wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+
+  // ---- P0: X rows (all), CSR rows of the strip ----------------------------------------------------------------------
+  int csr_p0 = 0, csr_p1 = 0;
+  if (a.L0_rowptr && tid < 16 && i0 + tid < n) {
+    csr_p0 = a.L0_rowptr[row0 + i0 + tid];
+    csr_p1 = a.L0_rowptr[row0 + i0 + tid + 1];
+  }
+  for (int ib = wave; ib < n4; ib += 4 * NW) {
+    float xr[4][CP];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* rp = Xg + (int64_t)min(ib + NW * u, n - 1) * a.ldx;
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) xr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = ib + NW * u;
+      if (i < n4) {
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < F4) Ximg[i * LDX + c] = (i < n && c < FIN) ? xr[u][cp] : 0.f;
+        }
+      }
+    }
+  }
+  int csr_c[6] = {0, 0, 0, 0, 0, 0};
+  float csr_v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tid < 16 && csr_p1 > csr_p0) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int pp = min(csr_p0 + u, csr_p1 - 1);
+      csr_c[u] = a.L0_col[pp];
+      csr_v[u] = a.L0_val[pp];
+    }
+  }
+  lds_barrier();
+
+  // ---- P1: Z = X M_L for all rows -> Z^T image; the strip's rows also go to the reserve -----------------------------
+  {
+    float* Zg = a.sv_Z + (int64_t)row0 * FIN;
+    const float* mq = a.M_L + q * FIN;
+    int ta, tb;
+    tile_range<NW>(ntm * NCB, wave, ta, tb);
+    for (int t = ta; t < tb; ++t) {
+      const int rt = t / NCB, cb = t - rt * NCB;
+      const float* p = mq + min(cb * 16 + r, FIN - 1);
+      float bf[NKS];
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) bf[u] = (4 * u + 3 < FIN) ? p[4 * u * FIN] : p[(min(4 * u + q, FIN - 1) - q) * FIN];
+      const float* Ap = Ximg + (rt * 16 + r) * LDX + q;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
+      const int c = cb * 16 + r, ib = rt * 16 + 4 * q;
+      if (c < FIN) {
+        *reinterpret_cast<f32x4*>(Zt + c * ldz + ib) = acc;
+        if (rt == me) {
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4)
+            if (ib + i4 < n) Zg[(ib + i4) * FIN + c] = acc[i4];
+        }
+      }
+    }
+  }
+  lds_barrier();
+
+  // ---- P2: S[I, :], r[I, :], degree of the strip's rows (wave il = row i0 + il) -> s published -----------------------
+  {
+    const int i = i0 + wave;
+    float dsum = 0.f;
+    if (i < n) {   // (uniform)
+      float acc[2] = {0.f, 0.f};
+      const int j0 = min(lane, n - 1), j1 = min(lane + 64, n - 1);
+      const float* zi = Zt + i;
+      for (int f = 0; f < FIN; ++f) {
+        const float zv = zi[f * ldz];
+        const float d0 = zv - Zt[f * ldz + j0], d1 = zv - Zt[f * ldz + j1];
+        acc[0] = fmaf(d0, d0, acc[0]);
+        acc[1] = fmaf(d1, d1, acc[1]);
+      }
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        if (j < n4) {
+          float sv = 0.f;
+          if (j < n) {
+            const float rr = fast_sqrt(acc[cp]);
+            sv = (i == j) ? 0.f : fast_exp_neg(rr);
+            const uint32_t o = toff + (uint32_t)(i * n + j);
+            a.res_W[o] = sv;
+            a.sv_r[o] = (i == j) ? 0.f : rr;
+          }
+          St[wave * ldt + j] = sv;
+          dsum += sv;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp)
+        if (lane + 64 * cp < n4) St[wave * ldt + lane + 64 * cp] = 0.f;
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0 && i < n) {
+      const float sd = 1.0f / sqrtf(dsum + FLT_TRUE_MIN);
+      s_vec[i] = sd;
+      a.sv_s[row0 + i] = sd;
+      __hip_atomic_store(xch + i, coop_pack(sd, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tid < n4 && tid >= n) s_vec[tid] = 0.f;
+  if (tid < n && (tid < i0 || tid >= i0 + 16)) {
+    const uint32_t want = wants[tid >> 4];
+    uint64_t w = 0;
+    int it = 0;
+    do {
+      w = __hip_atomic_load(xch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(w >> 32) == want) break;
+      __builtin_amdgcn_s_sleep(2);
+    } while (++it < COOP_SPIN_LIMIT);
+    s_vec[tid] = (it < COOP_SPIN_LIMIT) ? __uint_as_float((uint32_t)w) : __builtin_nanf("");
+  }
+  lds_barrier();
+
+  // ---- P3: res_L[I, :], L[I, :] = lrelu(R) + L_orig ----------------------------------------------------------------
+  {
+    const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+    const float* L0d = !a.L0_dense ? nullptr
+                                   : (a.L0_ld > 0 ? a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
+    const int i = i0 + wave;
+    if (i < n) {
+      const float si = s_vec[i];
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        if (j < n) {
+          const float S = St[wave * ldt + j];
+          float R = (i == j) ? 1.f : 0.f;
+          R = R - (si * S) * s_vec[j];
+          const float R2 = lrelu(R, alpha);
+          a.res_L[toff + (uint32_t)(i * n + j)] = R2;
+          St[wave * ldt + j] = R2 + (L0d ? L0d[(int64_t)i * l0ld + j] : 0.f);
+        }
+      }
+    }
+  }
+  lds_barrier();
+  if (a.L0_rowptr && tid < 16 && i0 + tid < n) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (csr_p0 + u < csr_p1) St[tid * ldt + csr_c[u]] += csr_v[u];
+    for (int p = csr_p0 + 6; p < csr_p1; ++p) St[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+  }
+  lds_barrier();
+  if (a.L_sum) {
+    const int i = i0 + wave;
+    if (i < n)
+      for (int j = lane; j < n; j += 64) a.L_sum[toff + (uint32_t)(i * n + j)] = St[wave * ldt + j];
+  }
+
+  // ---- P4: X_1[I] = L[I, :] X_0 ------------------------------------------------------------------------------------
+  if (wave < NCB) {
+    const int cb = wave;
+    const float* Ap = St + r * ldt + q;
+    const float* Bp = Ximg + q * LDX + cb * 16 + r;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < n4; k0 += 16) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = Ap[k0 + 4 * u];
+        bv[u] = Bp[(k0 + 4 * u) * LDX];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    const int c = cb * 16 + r;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) X1s[(4 * q + i4) * LDX + c] = acc[i4];
+  }
+  lds_barrier();
+
+  // ---- P5: Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b), then the stores -------------------------------------------------
+  if (wave < NOB) {
+    const int ob = wave;
+    const float* wq = a.weight + q * 2 * FOUT + r + ob * 16;
+    float w0[NKS], w1[NKS];
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      const int off = (4 * u + 3 < FIN) ? 4 * u * 2 * FOUT : (min(4 * u + q, FIN - 1) - q) * 2 * FOUT;
+      w0[u] = wq[off];
+      w1[u] = wq[off + FOUT];
+    }
+    const float bias = a.bias[ob * 16 + r];
+    const float* A0 = Ximg + (me * 16 + r) * LDX + q;
+    const float* A1 = X1s + r * LDX + q;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], w0[u], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * u], w1[u], acc, 0, 0, 0);
+    float* Yg = a.Y + (int64_t)row0 * a.ldy;
+    const int c = ob * 16 + r;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int i = i0 + 4 * q + i4;
+      if (i < n) {
+        float v = acc[i4] + bias;
+        if (relu) v = fmaxf(v, 0.f);
+        Yg[(int64_t)i * a.ldy + c] = v;
+      }
+    }
+  }
+  if (i0 + wave < n) {   // X_1 rows of the strip (reserve: the parameter gradients read them)
+    float* Xo = a.sv_X + (int64_t)(row0 + i0 + wave) * FIN;
+#pragma unroll
+    for (int cp = 0; cp < CP; ++cp) {
+      const int c = lane + 64 * cp;
+      if (c < FIN) Xo[c] = X1s[wave * LDX + c];
+    }
+  }
+  if (i0 == 0) {
+    const uint32_t npad = (uint32_t)(a.tile_off[b + 1] - a.tile_off[b]) - (uint32_t)(n * n);
+    if (tid < (int)npad) {   // alignment floats behind the tile
+      a.res_W[toff + (uint32_t)(n * n) + tid] = 0.f;
+      a.res_L[toff + (uint32_t)(n * n) + tid] = 0.f;
+      if (a.L_sum) a.L_sum[toff + (uint32_t)(n * n) + tid] = 0.f;
+    }
+    if (tid == 0) {
+      float* sc = a.sv_scal + 4 * b;
+      sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
+    }
+  }
+  if (tid == 0) __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 

@@ -34,10 +34,19 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int NOB = FOUT / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  int gpos = first + (int)blockIdx.x;
+  if constexpr (NW == NW_LARGE) {
+    // the first coop_slabs workgroups are the members of the cooperative graphs (spec_backward_coop.h)
+    if ((int)blockIdx.x < a.coop_slabs) {
+      coop_forward_member<FIN, FOUT>(a, (int)blockIdx.x, smem);
+      return;
+    }
+    gpos -= a.coop_slabs;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const GraphRec g = load_graph(a.graph_desc + first + blockIdx.x);
+  const GraphRec g = load_graph(a.graph_desc + gpos);
   const int n = g.n, row0 = g.row0;
   const uint32_t toff = g.toff;
   const FwdLds d = fwd_lds(n, F4);
@@ -342,8 +351,6 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
         }
       }
     }
-    // exchange words of a cooperative backward of this graph: all invalid, epoch 0
-    if (n >= COOP_MIN_N && tid < COOP_XCH_WORDS) a.sv_xch[(int64_t)g.b * COOP_XCH_WORDS + tid] = 0ull;
     // X_1 rows (reserve: the parameter gradients read them)
     float* Xo = a.sv_X + (int64_t)row0 * FIN;
     for (int i = wave; i < n; i += NW)
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
   // The block of the last (smallest) graph of the batch also leaves transposed copies of the parameters in the reserve
   // for the backward kernel (its B operands W^T and M_L^T then load row-major: 4 cache lines per fragment load
   // instead of 16).  Stores only, behind every load of this block.
-  if (first + (int)blockIdx.x == a.B - 1) {
+  if (gpos == a.B - 1) {
     for (int e = tid; e < FIN * FIN; e += NT) {
       const int k = e / FIN, f = e - k * FIN;
       a.sv_MT[e] = a.M_L[f * FIN + k];
@@ -387,6 +394,11 @@ size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw) {
   return sizeof(float) * (size_t)spec::fwd_lds(n, F4).total;
 }
 
+// LDS bytes of a member of the cooperative forward for a graph of n nodes
+size_t spec_coop_fwd_lds_bytes(int32_t n, int32_t Fin) {
+  return sizeof(float) * (size_t)spec::coop_fwd_lds(n, (Fin + 15) & ~15).total;
+}
+
 template <int FIN, int FOUT, int NW>
 static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (lds_bytes > 64 * 1024) {
@@ -395,7 +407,8 @@ static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count,
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_fwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_SPEC_FWD, s);
-  hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT, NW>), dim3(count), dim3(64 * NW), lds_bytes, s, a, first);
+  const unsigned members = NW == spec::NW_LARGE ? (unsigned)a.coop_slabs : 0u;
+  hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT, NW>), dim3(members + count), dim3(64 * NW), lds_bytes, s, a, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_forward launch: %s", hipGetErrorString(e));

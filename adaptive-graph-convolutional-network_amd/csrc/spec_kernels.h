@@ -166,6 +166,7 @@ bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant);
 size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw);
 size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw);
 size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout);
+size_t spec_coop_fwd_lds_bytes(int32_t n, int32_t Fin);
 int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream);
 int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream);
 

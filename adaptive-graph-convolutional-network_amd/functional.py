@@ -193,7 +193,9 @@ class SgcLLFunction(torch.autograd.Function):
         res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         L_sum = torch.empty(plan.tile_elems if cfg.lsum else 0, dtype=torch.float32, device=dev)
         desc, rbytes, wbytes, _ = _sizes(plan, cfg, ldx, ldy)
-        reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
+        # (zero-filled: the reserve starts with the exchange header of the cooperative kernels, which must be zero when a
+        # reserve is first used -- include/agcn.h)
+        reserve = torch.zeros(rbytes, dtype=torch.uint8, device=dev)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         gb = _gbatch(batch, X, L_prev if reslap else None)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))

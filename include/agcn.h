@@ -189,7 +189,12 @@ typedef struct AgcnGrads {
 } AgcnGrads;
 
 /* Reserve space: intermediates the forward keeps for the backward (opaque
- * layout).  Workspace: scratch for one call. */
+ * layout).  Workspace: scratch for one call.
+ * The first AGCN_RESERVE_HEADER_BYTES of a reserve buffer must be ZERO when the buffer is first handed to the
+ * library (hipMemset once after allocating it); the library keeps that header consistent from then on, also when
+ * the buffer is reused for other batches.  (It holds the words through which the workgroups that share one large
+ * graph exchange a vector inside a launch; csrc/spec_backward_coop.h.) */
+#define AGCN_RESERVE_HEADER_BYTES 65536
 size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
@@ -411,7 +416,9 @@ void agcn_set_param_grad_onepass(int32_t on);
 /* Shape-specialised fused kernels (csrc/spec_*.hip: SGC_LL, K = 2, layer widths 75->64, 64->128, 128->128, 128->64,
  * 64->64; 512-thread workgroups, feature widths compiled in).  1 (default): used wherever the fused path would be
  * taken and the shape is covered; 0: always the general fused kernels.  Bit 0 = forward, bit 1 = backward
- * (3 = both, the default).  Same results within the last few ulps (hardware sqrt / exp2 in the similarity phase). */
+ * bit 2 = graphs of three (five, when the launch does not fit the chip any more) 16-row tiles and up spread over one
+ * workgroup per tile in the same launch, paper mode (7 = all, the default).  Same results within the last few ulps
+ * (hardware sqrt / exp2 in the similarity phase; summation orders). */
 int32_t agcn_get_spec_mode(void);
 void agcn_set_spec_mode(int32_t mode);
 /* In batches of >= 1024 graphs the graphs of at most 24 nodes (32 from 3072 graphs on) take an 8-wave flavour of the
