@@ -140,8 +140,9 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
 // Cooperative kernels (spec_backward_coop.h): how many of the largest graphs (a prefix of the schedule) are spread over
 // one workgroup per 16-row tile, and how many members (slabs) that makes.  The same answer for the forward and the
 // backward of a batch.
-void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, int* graphs, int* slabs) {
-  *graphs = *slabs = 0;
+void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, int* graphs, int* slabs,
+               int* dual_graphs) {
+  *graphs = *slabs = *dual_graphs = 0;
   const int B = host.info.B;
   if (d->mode != AGCN_MODE_PAPER || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
       fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
@@ -158,16 +159,28 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
         hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
     return v > 0 ? v : 256;
   }();
+  // (with two and more rounds of workgroups per CU the tail graph matters less than the extra workgroups cost:
+  //  512 graphs: 6.0 M graphs/s without, 5.7 M with members for its one 70-node graph)
+  if (B > n_cus + n_cus / 2) return;
   int extra = 0;
   for (int k = 0; k < B; ++k) {
     const int n = host.n[host.order[k]];
     if (n < spec::COOP_MIN_N) break;
     extra += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS - 1;
   }
+  // When the launch would not fit the chip, room is made by packing the SMALLEST graphs (at most DUAL_MAX_N nodes: a
+  // suffix of the schedule) two to a workgroup (8 waves each, spec_forward.hip): a pair frees one CU.
+  static const int dual_on = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
+  int tiny = 0;
+  while (tiny < B - 1 && host.n[host.order[B - 1 - tiny]] <= spec::DUAL_MAX_N) ++tiny;
+  int pairs = 0;
+  if (dual_on && B + extra > n_cus) pairs = std::min(tiny / 2, B + extra - n_cus);
   const int min_n = min_force > 0 ? std::max(spec::COOP_MIN_N, min_force)
-                                  : (B + extra <= n_cus ? spec::COOP_MIN_N : spec::COOP_MIN_N_FULL);
+                                  : (B + extra - pairs <= n_cus ? spec::COOP_MIN_N : spec::COOP_MIN_N_FULL);
+  if (min_n != spec::COOP_MIN_N && min_force <= 0) pairs = 0;   // (no room to be made: nothing is paired)
+  *dual_graphs = 2 * pairs;
   int g = 0, s = 0;
-  while (g < B - 1) {   // (the last graph of the schedule stays a plain workgroup: it writes the transposed parameters)
+  while (g < B - 1 - 2 * pairs) {   // (never every graph: the last one of the schedule writes the transposed parameters)
     const int n = host.n[host.order[g]];
     const int sl = (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
     if (n < min_n || s + sl > spec::COOP_MAX_MEMBERS) break;
@@ -446,7 +459,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
-  a.coop_slabs = 0;
+  a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
 
   Carver c(workspace);
   const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
@@ -476,12 +489,18 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
           return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
       }
       {
-        int cg = 0, cs = 0;
-        coop_plan(desc, host, fs, &cg, &cs);
+        int cg = 0, cs = 0, dg = 0;
+        coop_plan(desc, host, fs, &cg, &cs, &dg);
         a.coop_slabs = cs;
         size_t lds = spec_fwd_lds_bytes(host.n[host.order[cg]], desc->Fin, desc->Fout, spec::NW_LARGE);
         if (cs > 0) lds = std::max(lds, spec_coop_fwd_lds_bytes(host.n[host.order[0]], desc->Fin));
-        rc = launch_spec_forward(a, cg, ss - cg, lds, spec::NW_LARGE, conc ? side->s : main_s);
+        if (dg > 0) {   // the dg smallest graphs, two to a workgroup
+          const size_t half = spec_fwd_lds_bytes(host.n[host.order[B - dg]], desc->Fin, desc->Fout, spec::NW_SMALL);
+          a.dual_pairs = dg / 2;
+          a.dual_stride = (int32_t)(half / sizeof(float));
+          lds = std::max(lds, 2 * half);
+        }
+        rc = launch_spec_forward(a, cg, ss - cg - dg, lds, spec::NW_LARGE, conc ? side->s : main_s);
       }
       if (rc != AGCN_OK) return rc;
       if (ss < B)
@@ -622,7 +641,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
-  a.coop_slabs = 0;
+  a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
   a.dY = dY; a.dL_sum = dL_sum; a.dX = grads->dX; a.dL_prev = has_prev ? grads->dL_prev : nullptr;
   a.ws_g = w.g; a.ws_dZ = w.dZ; a.ws_pg = w.pg; a.ws_tile = w.tile; a.ws_buf = w.buf;
 
@@ -643,8 +662,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
                                           paper ? 1 : 0, &n_counters);
   a.zero_ptr = counters; a.zero_count = n_counters;
   // cooperative backward (spec_backward_coop.h)
-  int coop_graphs = 0, coop_slabs = 0;
-  coop_plan(desc, host, fs, &coop_graphs, &coop_slabs);
+  int coop_graphs = 0, coop_slabs = 0, dual_graphs = 0;
+  coop_plan(desc, host, fs, &coop_graphs, &coop_slabs, &dual_graphs);
   if ((stages & 1) && fused) {
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
@@ -715,7 +734,13 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         const int f0 = std::max(sf, first_plain);
         size_t lds = f0 < B ? spec_bwd_lds_bytes(host.n[host.order[f0]], desc->Fin, desc->Fout, spec::NW_LARGE) : 0;
         if (coop_slabs > 0) lds = std::max(lds, spec_coop_lds_bytes(host.n[host.order[0]], desc->Fin, desc->Fout));
-        rc = launch_spec_backward(a, f0, ss - f0, lds, spec::NW_LARGE, conc ? side->s : main_s);
+        if (dual_graphs > 0) {
+          const size_t half = spec_bwd_lds_bytes(host.n[host.order[B - dual_graphs]], desc->Fin, desc->Fout, spec::NW_SMALL);
+          a.dual_pairs = dual_graphs / 2;
+          a.dual_stride = (int32_t)(half / sizeof(float));
+          lds = std::max(lds, 2 * half);
+        }
+        rc = launch_spec_backward(a, f0, ss - f0 - dual_graphs, lds, spec::NW_LARGE, conc ? side->s : main_s);
       }
       if (rc != AGCN_OK) return rc;
       if (ss < B)

@@ -42,8 +42,10 @@ struct SgcArgs {
   // exchange words of the cooperative backward (spec_backward_coop.h): [B][97] 64-bit words, zeroed per graph by the
   // specialised forward kernel
   uint64_t* sv_xch;
-  int32_t coop_slabs;   // backward launch: its first coop_slabs workgroups are members (slabs of the plan's slab table)
-  int32_t coop_pad;
+  int32_t coop_slabs;   // 16-wave launch: its first coop_slabs workgroups are members (slabs of the plan's slab table),
+  int32_t plain_count;  // the next plain_count one graph each, the rest TWO small graphs each (spec_forward.hip)
+  int32_t dual_stride;  // floats of LDS between the two halves of such a workgroup
+  int32_t dual_pairs;   // number of such workgroups (set by the caller; plain_count is set by the launcher)
   // global-tile mode scratch
   float* ws_tile;  // [wtile_off[B]]
   float* ws_buf;   // per-graph image scratch, see graph_scratch_floats()

@@ -23,24 +23,33 @@ namespace spec {
 
 constexpr int MAXTB = 3;   // most MFMA tiles of one phase a wave may own
 
-template <int FIN, int FOUT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void spec_backward_kernel(SgcArgs a, int first) {
+// deterministic sum over the NW waves of one body (block_sum of agcn_device.h for a body that may be half a workgroup)
+template <int NW>
+__device__ __forceinline__ float body_sum(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    red[31] = t;
+  }
+  __syncthreads();
+  return red[31];
+}
+
+// The body for ONE graph; DUAL as in spec_forward.hip.
+template <int FIN, int FOUT, int NW, bool DUAL>
+__device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int gpos, float* smem_) {
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64;
   constexpr int RPW = NW == NW_SMALL ? 6 : 8;   // rows of a node-feature matrix one wave may own (n4 <= 48 | 128)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int gpos = first + (int)blockIdx.x;
-  if constexpr (NW == NW_LARGE) {
-    // the first coop_slabs workgroups are the members of the cooperative graphs (positions 0 .. first - 1 of the schedule)
-    if ((int)blockIdx.x < a.coop_slabs) {
-      coop_backward_member<FIN, FOUT>(a, (int)blockIdx.x, smem);
-      return;
-    }
-    gpos -= a.coop_slabs;
-  }
-  const int tid = threadIdx.x;
+  const int tid = DUAL ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;
+  float* smem = smem_ + ((DUAL && (int)threadIdx.x >= NT) ? a.dual_stride : 0);
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const GraphRec g = load_graph(a.graph_desc + gpos);
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
       }
     }
   }
-  const float da = block_sum(dalpha_part, red);
+  const float da = body_sum<NW>(dalpha_part, red, tid);
   if (tid == 0) {
     a.ws_pg[2 * g.b + 0] = da;
     a.ws_pg[2 * g.b + 1] = 0.f;
@@ -521,6 +530,30 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
     for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
   }
   AGCN_STAMP(4, 9);
+}
+
+// FULL: the launch may carry members of cooperative graphs and workgroups of two small graphs (16-wave flavour only; a
+// variant of its own so that launches without them keep the plain kernel's register allocation).
+// 8-wave flavour: held to AGCN_SMALL_OCC waves per SIMD where that does not spill much (feature widths up to 80).
+template <int FIN, int FOUT, int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMALL_OCC) : 4) void spec_backward_kernel(SgcArgs a, int first) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (FULL) {
+    // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
+    int blk = (int)blockIdx.x;
+    if (blk < a.coop_slabs) {   // (spec_backward_coop.h)
+      coop_backward_member<FIN, FOUT>(a, blk, smem);
+      return;
+    }
+    blk -= a.coop_slabs;
+    if (blk >= a.plain_count) {
+      spec_backward_body<FIN, FOUT, NW_SMALL, true>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
+      return;
+    }
+    spec_backward_body<FIN, FOUT, NW_LARGE, false>(a, first + blk, smem);
+  } else {
+    spec_backward_body<FIN, FOUT, NW, false>(a, first + (int)blockIdx.x, smem);
+  }
 }
 
 }  // namespace spec
@@ -542,14 +575,19 @@ size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout) {
 
 template <int FIN, int FOUT, int NW>
 static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
+  const bool full = NW == spec::NW_LARGE && (a.coop_slabs > 0 || a.dual_pairs > 0);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = static_cast<hipError_t>(
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&spec::spec_backward_kernel<FIN, FOUT, NW>), lds_bytes));
+        ensure_dynamic_lds(full ? reinterpret_cast<const void*>(&spec::spec_backward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>)
+                                : reinterpret_cast<const void*>(&spec::spec_backward_kernel<FIN, FOUT, NW, false>), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_SPEC_BWD, s);
-  const unsigned members = NW == spec::NW_LARGE ? (unsigned)a.coop_slabs : 0u;
-  hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW>), dim3(members + count), dim3(64 * NW), lds_bytes, s, a, first);
+  const unsigned members = NW == spec::NW_LARGE ? (unsigned)(a.coop_slabs + a.dual_pairs) : 0u;
+  SgcArgs aa = a;
+  aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
+  if (full) hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>), dim3(members + count), dim3(64 * NW), lds_bytes, s, aa, first);
+  else hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, false>), dim3(members + count), dim3(64 * NW), lds_bytes, s, aa, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_backward launch: %s", hipGetErrorString(e));
@@ -563,7 +601,7 @@ static int launch_spec_backward_w(const SgcArgs& a, int32_t first, int32_t count
 }
 
 int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream) {
-  if (count <= 0 && a.coop_slabs <= 0) return AGCN_OK;
+  if (count <= 0 && a.coop_slabs <= 0 && a.dual_pairs <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a.Fin == 75 && a.Fout == 64) return launch_spec_backward_w<75, 64>(a, first, count, lds_bytes, nw, s);
   if (a.Fin == 64 && a.Fout == 128) return launch_spec_backward_w<64, 128>(a, first, count, lds_bytes, nw, s);

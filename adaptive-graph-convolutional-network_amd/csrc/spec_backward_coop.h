@@ -31,6 +31,7 @@ namespace spec {
 constexpr int COOP_MIN_N = 33;         // graphs of at least three 16-row tiles (while the launch fits the chip)
 constexpr int COOP_MIN_N_FULL = 65;    // ... of at least five, when every extra workgroup has to wait for a CU
 constexpr int COOP_MAX_MEMBERS = 192;  // of 256 CUs
+constexpr int DUAL_MAX_N = 16;         // graphs that may be packed two to a workgroup (8 waves each)
 // exchange header at the start of the reserve, per direction (0 backward, 1 forward): one slot per member row, one
 // epoch word per member (a graph uses the rows / the epoch of its first slab)
 constexpr int COOP_DIR_WORDS = COOP_MAX_MEMBERS * 16 + COOP_MAX_MEMBERS;
@@ -633,6 +634,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       float acc[2] = {0.f, 0.f};
       const int j0 = min(lane, n - 1), j1 = min(lane + 64, n - 1);
       const float* zi = Zt + i;
+#pragma unroll 4
       for (int f = 0; f < FIN; ++f) {
         const float zv = zi[f * ldz];
         const float d0 = zv - Zt[f * ldz + j0], d1 = zv - Zt[f * ldz + j1];

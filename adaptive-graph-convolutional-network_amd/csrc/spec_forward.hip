@@ -27,23 +27,18 @@ namespace spec {
 
 constexpr int MAXT = 3;   // most MFMA tiles of one phase a wave may own (accumulators are held in registers)
 
-template <int FIN, int FOUT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void spec_forward_kernel(SgcArgs a, int first) {
+// The body for ONE graph (schedule position gpos), run by NT = 64 * NW threads.  DUAL: the workgroup has 1024 threads
+// and runs TWO such bodies side by side, threads 0-511 and 512-1023 each on a graph of their own with their own half of
+// the LDS (smem_ + dual_stride); the barriers are workgroup-wide, which is fine because both halves run the same
+// sequence of them (every barrier of the body is in control flow that depends on the launch arguments only).
+template <int FIN, int FOUT, int NW, bool DUAL>
+__device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gpos, float* smem_) {
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int NOB = FOUT / 16;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int gpos = first + (int)blockIdx.x;
-  if constexpr (NW == NW_LARGE) {
-    // the first coop_slabs workgroups are the members of the cooperative graphs (spec_backward_coop.h)
-    if ((int)blockIdx.x < a.coop_slabs) {
-      coop_forward_member<FIN, FOUT>(a, (int)blockIdx.x, smem);
-      return;
-    }
-    gpos -= a.coop_slabs;
-  }
-  const int tid = threadIdx.x;
+  const int tid = DUAL ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;
+  float* smem = smem_ + ((DUAL && (int)threadIdx.x >= NT) ? a.dual_stride : 0);
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const GraphRec g = load_graph(a.graph_desc + gpos);
@@ -377,6 +372,31 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? AGCN_SMALL_OCC : 4) void 
   AGCN_STAMP(1, 8);
 }
 
+// grid: [members of the cooperative graphs][one workgroup per graph: plain_count of them][two small graphs per workgroup]
+// FULL: the launch may carry members of cooperative graphs and workgroups of two small graphs (16-wave flavour only; a
+// variant of its own so that launches without them keep the plain kernel's register allocation).
+// 8-wave flavour: held to AGCN_SMALL_OCC waves per SIMD where that does not spill much (feature widths up to 80).
+template <int FIN, int FOUT, int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMALL_OCC) : 4) void spec_forward_kernel(SgcArgs a, int first) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (FULL) {
+    // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
+    int blk = (int)blockIdx.x;
+    if (blk < a.coop_slabs) {   // (spec_backward_coop.h)
+      coop_forward_member<FIN, FOUT>(a, blk, smem);
+      return;
+    }
+    blk -= a.coop_slabs;
+    if (blk >= a.plain_count) {
+      spec_forward_body<FIN, FOUT, NW_SMALL, true>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
+      return;
+    }
+    spec_forward_body<FIN, FOUT, NW_LARGE, false>(a, first + blk, smem);
+  } else {
+    spec_forward_body<FIN, FOUT, NW, false>(a, first + (int)blockIdx.x, smem);
+  }
+}
+
 }  // namespace spec
 
 bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant) {
@@ -401,14 +421,21 @@ size_t spec_coop_fwd_lds_bytes(int32_t n, int32_t Fin) {
 
 template <int FIN, int FOUT, int NW>
 static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
+  const bool full = NW == spec::NW_LARGE && (a.coop_slabs > 0 || a.dual_pairs > 0);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = static_cast<hipError_t>(
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&spec::spec_forward_kernel<FIN, FOUT, NW>), lds_bytes));
+        ensure_dynamic_lds(full ? reinterpret_cast<const void*>(&spec::spec_forward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>)
+                                : reinterpret_cast<const void*>(&spec::spec_forward_kernel<FIN, FOUT, NW, false>), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_fwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_SPEC_FWD, s);
-  const unsigned members = NW == spec::NW_LARGE ? (unsigned)a.coop_slabs : 0u;
-  hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT, NW>), dim3(members + count), dim3(64 * NW), lds_bytes, s, a, first);
+  const unsigned members = NW == spec::NW_LARGE ? (unsigned)(a.coop_slabs + a.dual_pairs) : 0u;
+  SgcArgs aa = a;
+  aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
+  // count = plain workgroups + workgroups of two small graphs each (a.plain_count is set by the caller for the 16-wave
+  // launch; the 8-wave launch has one graph per workgroup throughout)
+  if (full) hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>), dim3(members + count), dim3(64 * NW), lds_bytes, s, aa, first);
+  else hipLaunchKernelGGL((spec::spec_forward_kernel<FIN, FOUT, NW, false>), dim3(members + count), dim3(64 * NW), lds_bytes, s, aa, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_forward launch: %s", hipGetErrorString(e));
@@ -422,7 +449,7 @@ static int launch_spec_forward_w(const SgcArgs& a, int32_t first, int32_t count,
 }
 
 int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream) {
-  if (count <= 0) return AGCN_OK;
+  if (count <= 0 && a.coop_slabs <= 0 && a.dual_pairs <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a.Fin == 75 && a.Fout == 64) return launch_spec_forward_w<75, 64>(a, first, count, lds_bytes, nw, s);
   if (a.Fin == 64 && a.Fout == 128) return launch_spec_forward_w<64, 128>(a, first, count, lds_bytes, nw, s);
