@@ -162,22 +162,23 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   // (with two and more rounds of workgroups per CU the tail graph matters less than the extra workgroups cost:
   //  512 graphs: 6.0 M graphs/s without, 5.7 M with members for its one 70-node graph)
   if (B > n_cus + n_cus / 2) return;
+  const int base_min = min_force >= 17 ? min_force : spec::COOP_MIN_N;
   int extra = 0;
   for (int k = 0; k < B; ++k) {
     const int n = host.n[host.order[k]];
-    if (n < spec::COOP_MIN_N) break;
+    if (n < base_min) break;
     extra += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS - 1;
   }
   // When the launch would not fit the chip, room is made by packing the SMALLEST graphs (at most DUAL_MAX_N nodes: a
   // suffix of the schedule) two to a workgroup (8 waves each, spec_forward.hip): a pair frees one CU.
   static const int dual_on = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
   int tiny = 0;
-  while (tiny < B - 1 && host.n[host.order[B - 1 - tiny]] <= spec::DUAL_MAX_N) ++tiny;
+  static const int dual_max = [] { const char* e = std::getenv("AGCN_DUAL_MAX_N"); return e ? std::atoi(e) : spec::DUAL_MAX_N; }();
+  while (tiny < B - 1 && host.n[host.order[B - 1 - tiny]] <= dual_max) ++tiny;
   int pairs = 0;
   if (dual_on && B + extra > n_cus) pairs = std::min(tiny / 2, B + extra - n_cus);
-  const int min_n = min_force > 0 ? std::max(spec::COOP_MIN_N, min_force)
-                                  : (B + extra - pairs <= n_cus ? spec::COOP_MIN_N : spec::COOP_MIN_N_FULL);
-  if (min_n != spec::COOP_MIN_N && min_force <= 0) pairs = 0;   // (no room to be made: nothing is paired)
+  const int min_n = B + extra - pairs <= n_cus ? base_min : std::max(base_min, spec::COOP_MIN_N_FULL);
+  if (min_n != base_min) pairs = 0;   // (no room to be made: nothing is paired)
   *dual_graphs = 2 * pairs;
   int g = 0, s = 0;
   while (g < B - 1 - 2 * pairs) {   // (never every graph: the last one of the schedule writes the transposed parameters)

@@ -559,6 +559,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   if (tid < ntm)
     wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 
+  AGCN_STAMP(0, 0);
   // ---- P0: X rows (all), CSR rows of the strip ----------------------------------------------------------------------
   int csr_p0 = 0, csr_p1 = 0;
   if (a.L0_rowptr && tid < 16 && i0 + tid < n) {
@@ -597,6 +598,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   }
   lds_barrier();
 
+  AGCN_STAMP(0, 1);
   // ---- P1: Z = X M_L for all rows -> Z^T image; the strip's rows also go to the reserve -----------------------------
   {
     float* Zg = a.sv_Z + (int64_t)row0 * FIN;
@@ -626,7 +628,9 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   }
   lds_barrier();
 
+  AGCN_STAMP(0, 2);
   // ---- P2: S[I, :], r[I, :], degree of the strip's rows (wave il = row i0 + il) -> s published -----------------------
+  float rkeep[2] = {0.f, 0.f}, skeep[2] = {0.f, 0.f}, sd_keep = 0.f;
   {
     const int i = i0 + wave;
     float dsum = 0.f;
@@ -634,12 +638,20 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       float acc[2] = {0.f, 0.f};
       const int j0 = min(lane, n - 1), j1 = min(lane + 64, n - 1);
       const float* zi = Zt + i;
+      if (n > 64) {   // (uniform)
 #pragma unroll 4
-      for (int f = 0; f < FIN; ++f) {
-        const float zv = zi[f * ldz];
-        const float d0 = zv - Zt[f * ldz + j0], d1 = zv - Zt[f * ldz + j1];
-        acc[0] = fmaf(d0, d0, acc[0]);
-        acc[1] = fmaf(d1, d1, acc[1]);
+        for (int f = 0; f < FIN; ++f) {
+          const float zv = zi[f * ldz];
+          const float d0 = zv - Zt[f * ldz + j0], d1 = zv - Zt[f * ldz + j1];
+          acc[0] = fmaf(d0, d0, acc[0]);
+          acc[1] = fmaf(d1, d1, acc[1]);
+        }
+      } else {
+#pragma unroll 5
+        for (int f = 0; f < FIN; ++f) {
+          const float d0 = zi[f * ldz] - Zt[f * ldz + j0];
+          acc[0] = fmaf(d0, d0, acc[0]);
+        }
       }
 #pragma unroll
       for (int cp = 0; cp < 2; ++cp) {
@@ -647,12 +659,10 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         if (j < n4) {
           float sv = 0.f;
           if (j < n) {
-            const float rr = fast_sqrt(acc[cp]);
-            sv = (i == j) ? 0.f : fast_exp_neg(rr);
-            const uint32_t o = toff + (uint32_t)(i * n + j);
-            a.res_W[o] = sv;
-            a.sv_r[o] = (i == j) ? 0.f : rr;
+            rkeep[cp] = (i == j) ? 0.f : fast_sqrt(acc[cp]);
+            sv = (i == j) ? 0.f : fast_exp_neg(rkeep[cp]);
           }
+          skeep[cp] = sv;
           St[wave * ldt + j] = sv;
           dsum += sv;
         }
@@ -666,7 +676,9 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     if (lane == 0 && i < n) {
       const float sd = 1.0f / sqrtf(dsum + FLT_TRUE_MIN);
       s_vec[i] = sd;
-      a.sv_s[row0 + i] = sd;
+      sd_keep = sd;
+      // (published before any other store of this phase: the siblings' polls -- and this workgroup's own, which queue
+      // behind its stores in the one in-order memory counter -- then see it a store round trip earlier)
       __hip_atomic_store(xch + i, coop_pack(sd, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -682,8 +694,24 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     } while (++it < COOP_SPIN_LIMIT);
     s_vec[tid] = (it < COOP_SPIN_LIMIT) ? __uint_as_float((uint32_t)w) : __builtin_nanf("");
   }
+  {   // the strip's rows of res_W and r, and s: out behind the exchange
+    const int i = i0 + wave;
+    if (i < n) {
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        if (j < n) {
+          const uint32_t o = toff + (uint32_t)(i * n + j);
+          a.res_W[o] = skeep[cp];
+          a.sv_r[o] = rkeep[cp];
+        }
+      }
+      if (lane == 0) a.sv_s[row0 + i] = sd_keep;
+    }
+  }
   lds_barrier();
 
+  AGCN_STAMP(0, 3);
   // ---- P3: res_L[I, :], L[I, :] = lrelu(R) + L_orig ----------------------------------------------------------------
   {
     const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
@@ -720,6 +748,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       for (int j = lane; j < n; j += 64) a.L_sum[toff + (uint32_t)(i * n + j)] = St[wave * ldt + j];
   }
 
+  AGCN_STAMP(0, 4);
   // ---- P4: X_1[I] = L[I, :] X_0 ------------------------------------------------------------------------------------
   if (wave < NCB) {
     const int cb = wave;
@@ -742,6 +771,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   }
   lds_barrier();
 
+  AGCN_STAMP(0, 5);
   // ---- P5: Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b), then the stores -------------------------------------------------
   if (wave < NOB) {
     const int ob = wave;
@@ -794,6 +824,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     }
   }
   if (tid == 0) __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  AGCN_STAMP(0, 6);
 }
 #endif
 

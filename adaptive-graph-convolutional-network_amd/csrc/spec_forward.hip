@@ -207,7 +207,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
           if (paper && i < j) {   // the backward reads r_ij for i < j only ...
             AGCN_ST(2, &a.sv_r[toff + (uint32_t)(i * n + j)], rr);
             // ... unless the graph's backward is spread over several workgroups, each of which reads whole rows
-            if (n >= COOP_MIN_N) AGCN_ST(2, &a.sv_r[toff + (uint32_t)(j * n + i)], rr);
+            if (n > 16) AGCN_ST(2, &a.sv_r[toff + (uint32_t)(j * n + i)], rr);
           }
         }
       }
