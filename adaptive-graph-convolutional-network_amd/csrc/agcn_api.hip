@@ -140,11 +140,12 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
 // Cooperative kernels (spec_backward_coop.h): how many of the largest graphs (a prefix of the schedule) are spread over
 // one workgroup per 16-row tile, and how many members (slabs) that makes.  The same answer for the forward and the
 // backward of a batch.
-void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, int* graphs, int* slabs,
-               int* dual_graphs) {
+void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, bool backward, int* graphs,
+               int* slabs, int* dual_graphs) {
   *graphs = *slabs = *dual_graphs = 0;
   const int B = host.info.B;
-  if (d->mode != AGCN_MODE_PAPER || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
+  // (reference mode: the backward has no n x n work to spread; the forward still has the similarity tile)
+  if ((d->mode != AGCN_MODE_PAPER && backward) || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
       fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
     return;
   // Members are whole-CU workgroups like every other one.  While the launch still fits the chip (graphs + extra
@@ -491,7 +492,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
       }
       {
         int cg = 0, cs = 0, dg = 0;
-        coop_plan(desc, host, fs, &cg, &cs, &dg);
+        coop_plan(desc, host, fs, false, &cg, &cs, &dg);
         a.coop_slabs = cs;
         size_t lds = spec_fwd_lds_bytes(host.n[host.order[cg]], desc->Fin, desc->Fout, spec::NW_LARGE);
         if (cs > 0) lds = std::max(lds, spec_coop_fwd_lds_bytes(host.n[host.order[0]], desc->Fin));
@@ -664,7 +665,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.zero_ptr = counters; a.zero_count = n_counters;
   // cooperative backward (spec_backward_coop.h)
   int coop_graphs = 0, coop_slabs = 0, dual_graphs = 0;
-  coop_plan(desc, host, fs, &coop_graphs, &coop_slabs, &dual_graphs);
+  coop_plan(desc, host, fs, true, &coop_graphs, &coop_slabs, &dual_graphs);
   if ((stages & 1) && fused) {
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);

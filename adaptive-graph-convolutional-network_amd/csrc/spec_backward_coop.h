@@ -546,6 +546,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   const int n4 = d.n4, ldt = d.ldt, ldz = d.ldz, ntm = n4 >> 4;
   const int me = i0 >> 4;
   const bool relu = a.activation == AGCN_ACT_RELU;
+  const bool paper = a.mode == AGCN_MODE_PAPER;   // (reference mode: R = I, nothing to exchange)
   float* s_vec = smem + d.o_s;
   float* St = smem + d.o_st;
   float* Ximg = smem + d.o_x;
@@ -556,7 +557,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   uint64_t* xch = a.sv_xch + COOP_DIR_WORDS + (sl - me) * 16;                     // direction 1
   uint64_t* xep = a.sv_xch + COOP_DIR_WORDS + COOP_MAX_MEMBERS * 16 + (sl - me);
   uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [8], see coop_backward_member
-  if (tid < ntm)
+  if (paper && tid < ntm)
     wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 
   AGCN_STAMP(0, 0);
@@ -673,7 +674,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         if (lane + 64 * cp < n4) St[wave * ldt + lane + 64 * cp] = 0.f;
     }
     dsum = wave_sum(dsum);
-    if (lane == 0 && i < n) {
+    if (paper && lane == 0 && i < n) {
       const float sd = 1.0f / sqrtf(dsum + FLT_TRUE_MIN);
       s_vec[i] = sd;
       sd_keep = sd;
@@ -682,8 +683,8 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       __hip_atomic_store(xch + i, coop_pack(sd, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (tid < n4 && tid >= n) s_vec[tid] = 0.f;
-  if (tid < n && (tid < i0 || tid >= i0 + 16)) {
+  if (tid < n4 && (!paper || tid >= n)) s_vec[tid] = 0.f;
+  if (paper && tid < n && (tid < i0 || tid >= i0 + 16)) {
     const uint32_t want = wants[tid >> 4];
     uint64_t w = 0;
     int it = 0;
@@ -703,10 +704,10 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         if (j < n) {
           const uint32_t o = toff + (uint32_t)(i * n + j);
           a.res_W[o] = skeep[cp];
-          a.sv_r[o] = rkeep[cp];
+          if (paper) a.sv_r[o] = rkeep[cp];
         }
       }
-      if (lane == 0) a.sv_s[row0 + i] = sd_keep;
+      if (lane == 0) a.sv_s[row0 + i] = paper ? sd_keep : 0.f;
     }
   }
   lds_barrier();
@@ -726,7 +727,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         if (j < n) {
           const float S = St[wave * ldt + j];
           float R = (i == j) ? 1.f : 0.f;
-          R = R - (si * S) * s_vec[j];
+          if (paper) R = R - (si * S) * s_vec[j];
           const float R2 = lrelu(R, alpha);
           a.res_L[toff + (uint32_t)(i * n + j)] = R2;
           St[wave * ldt + j] = R2 + (L0d ? L0d[(int64_t)i * l0ld + j] : 0.f);
@@ -823,7 +824,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
     }
   }
-  if (tid == 0) __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (paper && tid == 0) __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   AGCN_STAMP(0, 6);
 }
 #endif
