@@ -30,7 +30,10 @@ namespace spec {
 
 constexpr int COOP_MIN_N = 33;         // graphs of at least three 16-row tiles (while the launch fits the chip)
 constexpr int COOP_MIN_N_FULL = 65;    // ... of at least five, when every extra workgroup has to wait for a CU
-constexpr int COOP_MAX_MEMBERS = 192;  // of 256 CUs
+// At most this many members per launch: all members of a graph must be resident together.  In ONE launch they are (first
+// workgroups of the grid, fewer than the CUs); 120 keeps that true when TWO launches with members run side by side on
+// different streams (epoch lanes): 240 members still fit 256 CUs.  (Beyond that a wait can run out: bounded, loud.)
+constexpr int COOP_MAX_MEMBERS = 120;
 constexpr int DUAL_MAX_N = 16;         // graphs that may be packed two to a workgroup (8 waves each)
 // exchange header at the start of the reserve, per direction (0 backward, 1 forward): one slot per member row, one
 // epoch word per member (a graph uses the rows / the epoch of its first slab)
