@@ -594,16 +594,17 @@ def test_full_size_properties(amd):
         assert_close(to_np(c), to_np(a + b), 3 * GRAD_RTOL, "linearity param grad", atol_ulps=3 * GRAD_ULPS)
 
 
-@pytest.mark.parametrize("B", [256, 2048], ids=["b256", "b2048"])
+@pytest.mark.parametrize("B", [256, 600, 2048], ids=["b256", "b600", "b2048"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 @pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc_ll", "reslap"])
 def test_full_size_every_graph_every_gradient(amd, variant, mode, B):
-    """BASELINE configs[1] and [3] at full size (Tox21-shaped B = 256 on one GPU; B = 2048 = the global batch of the
-    8-GPU config, whose graph sizes reach n = 95): EVERY graph's Y / res_W / res_L (/ L_sum) and EVERY gradient
+    """BASELINE configs[1] and [3] at full size (Tox21-shaped B = 256 on one GPU: large graphs spread over member
+    workgroups, small ones paired; B = 600: one launch, small graphs paired; B = 2048 = the global batch of the 8-GPU
+    config, whose graph sizes reach n = 95: 8- and 16-wave launches side by side): EVERY graph's Y / res_W / res_L (/ L_sum) and EVERY gradient
     (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) against the float64 oracle, both Laplacian modes, both layer
     variants (Reslap with a previous Laplacian and an upstream dL_sum)."""
-    if B == 2048 and (variant == orc.SGC_LL_RESLAP or mode == orc.REFERENCE):
-        pytest.skip("the 2048-graph batch is run on the headline configuration (SGC_LL, paper mode)")
+    if B != 256 and (variant == orc.SGC_LL_RESLAP or mode == orc.REFERENCE):
+        pytest.skip("the 600- and 2048-graph batches are run on the headline configuration (SGC_LL, paper mode)")
     Fin, Fout, K = 75, 64, 2
     sb = orc.synth_batch(123, B)
     ns = [int(v) for v in sb["ns"]]
