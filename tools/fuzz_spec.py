@@ -1,0 +1,52 @@
+"""Randomised check of the specialised kernels' dispatch (plain workgroups, cooperative members, paired small graphs,
+8-/16-wave launches side by side) against the float64 oracle: random batch sizes around the thresholds, graph sizes up
+to 96 nodes, the five covered layer shapes, both Laplacian modes.
+usage: python tools/fuzz_spec.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for extra in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if extra not in sys.path:
+        sys.path.insert(0, extra)
+import agcn_oracle as orc  # noqa: E402
+from helpers import compare_with_oracle, oracle_run, run_packed, synth_case  # noqa: E402
+
+DEV = "cuda:0"
+SHAPES = ((75, 64), (64, 128), (128, 128), (128, 64), (64, 64))
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import agcn_amd as amd
+    rs0 = np.random.RandomState(seed)
+    fails = 0
+    for case in range(n_cases):
+        B = int(rs0.choice([1, 2, 3, 7, 16, 33, 64, 120, 200, 255, 256, 257, 300, 390, 520, 1030]))
+        mu = np.log(rs0.choice([6, 12, 16, 24, 40]))
+        ns = [int(v) for v in np.clip(np.rint(rs0.lognormal(mu, 0.6, size=B)), 1, 96)]
+        if rs0.rand() < 0.3:
+            ns[int(rs0.randint(B))] = int(rs0.choice([96, 95, 81, 80, 65, 64, 49, 48, 33]))
+        Fin, Fout = SHAPES[int(rs0.randint(len(SHAPES)))]
+        mode = orc.PAPER if rs0.rand() < 0.7 else orc.REFERENCE
+        rs, X, L0, csr, p, G = synth_case(20_000 + case, ns, Fin, Fout, 2, orc.SGC_LL, atoms=(Fin == 75))
+        p["alpha"] = np.array([rs0.choice([1.0, 0.7, 0.2])], np.float32)
+        caches, tot = oracle_run(X, L0, p, 2, mode, orc.SGC_LL, G, None, None)
+        try:
+            out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, 2, mode, orc.SGC_LL, None, None)
+            compare_with_oracle(out, caches, tot, orc.SGC_LL, mode, 2, has_prev=False)
+            print("ok   case %d: B=%d max_n=%d n>=33: %d n<=16: %d %d->%d mode=%d" % (
+                case, B, max(ns), sum(v >= 33 for v in ns), sum(v <= 16 for v in ns), Fin, Fout, mode), flush=True)
+        except Exception as e:      # noqa: BLE001
+            fails += 1
+            print("FAIL case %d: B=%d max_n=%d %d->%d mode=%d -> %s" % (case, B, max(ns), Fin, Fout, mode, str(e)[:300]),
+                  flush=True)
+    print("failures:", fails)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
