@@ -79,6 +79,7 @@ SYMBOLS = [
     "agcn_plan_bytes", "agcn_plan_bytes_for", "agcn_plan_build", "agcn_plan_info",
     "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
+    "agcn_sgc_ll_dispatch_info",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
     "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
@@ -147,6 +148,8 @@ def _declare(lib):
     lib.agcn_store_batch_sizes.argtypes = [C.POINTER(GraphStoreC), P, I32, P, P, P]
     lib.agcn_store_pack_batch.restype = C.c_int
     lib.agcn_store_pack_batch.argtypes = [C.POINTER(GraphStoreC), P, I32, P, P, I32, P, P, P, P, I32]
+    lib.agcn_sgc_ll_dispatch_info.restype = C.c_int
+    lib.agcn_sgc_ll_dispatch_info.argtypes = [C.POINTER(LayerDesc), C.POINTER(GraphBatch), P, I32]
     lib.agcn_store_stage_bytes.restype = SZ
     lib.agcn_store_stage_bytes.argtypes = [I32, C.c_int64]
     lib.agcn_store_stage_batch.restype = C.c_int

@@ -375,6 +375,27 @@ int check_batch(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnParam
 
 using namespace agcn;
 
+// Which kernels a forward / backward call on this batch would launch (host logic only: nothing is launched, no device
+// pointer is dereferenced).  For tests and diagnostics.
+extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out) {
+  const char* who = "agcn_sgc_ll_dispatch_info";
+  int rc = check_desc(desc, who);
+  if (rc != AGCN_OK) return rc;
+  if (!batch || !batch->plan_host || !out || n_out < AGCN_DISPATCH_INFO_INTS) return fail(AGCN_EINVAL, "%s: bad argument", who);
+  PlanView host;
+  rc = plan_view(batch->plan_host, batch->plan_host, &host);
+  if (rc != AGCN_OK) return rc;
+  const FusedSplit fs = fused_split(desc, batch, host);
+  int cg = 0, cs = 0, dg = 0, cgb = 0, csb = 0, dgb = 0;
+  coop_plan(desc, host, fs, false, &cg, &cs, &dg);
+  coop_plan(desc, host, fs, true, &cgb, &csb, &dgb);
+  const int path = fs.mode == 1 ? ((fs.spec_fwd ? 1 : 0) | (fs.spec_bwd ? 2 : 0) | 4)      // fused (+ specialised bits)
+                                : (fs.mode == 2 ? 8 : (use_slabs(desc, batch, host.info) ? 16 : 32));
+  const int32_t v[AGCN_DISPATCH_INFO_INTS] = {path, fs.spec_small_first, cg, cs, dg, cgb, csb, dgb};
+  for (int i = 0; i < AGCN_DISPATCH_INFO_INTS; ++i) out[i] = v[i];
+  return AGCN_OK;
+}
+
 extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
   AgcnPlanInfo pi;
   if (check_desc(desc, "agcn_sgc_ll_reserve_bytes") != AGCN_OK || agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;

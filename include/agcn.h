@@ -199,6 +199,14 @@ size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_hos
 size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 
+/* Which kernels a forward / backward call on this batch would launch: host logic only (nothing is launched, device
+ * pointers of `batch` are only tested for NULL).  out[0] = path: 4 fused one-launch-per-direction kernels (| 1 / | 2:
+ * the specialised forward / backward), 8 mixed, 16 slab kernels, 32 per-graph kernels; out[1] = schedule position of
+ * the first graph of the 8-wave launch (== B: none); out[2..4] = forward: graphs spread over member workgroups,
+ * members, graphs packed two to a workgroup; out[5..7] = the same for the backward. */
+#define AGCN_DISPATCH_INFO_INTS 8
+int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out);
+
 int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
                         const AgcnOutputs* out, void* reserve, size_t reserve_bytes,
                         void* workspace, size_t workspace_bytes, void* hip_stream);

@@ -189,3 +189,63 @@ def test_stage_blob_bound_covers_every_split_of_the_rows(amd):
             assert need > 0
             assert (need + 15) // 16 * 16 + 24 * b <= cap, (B, rows, b, int(n.sum()))
     assert lib.agcn_store_stage_bytes(0, 10) == 0 and lib.agcn_store_stage_bytes(4, 3) == 0
+
+
+def _dispatch(amd, n, Fin, Fout, mode, variant=0, K=2, symmetric=1, csr=True):
+    """agcn_sgc_ll_dispatch_info on a packed plan of the node counts `n` (host logic: no GPU needed)."""
+    import ctypes as C
+    lib = amd._ffi.lib()
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    nbytes = lib.agcn_plan_bytes_for(n.ctypes.data, n.size, 0)
+    plan = np.zeros(nbytes, np.uint8)
+    assert lib.agcn_plan_build(n.ctypes.data, n.size, 0, plan.ctypes.data, nbytes) == 0
+    desc = amd._ffi.LayerDesc(Fin, Fout, K, mode, variant, 1, Fin, Fout)
+    one = 1   # any non-NULL "device" pointer: the call only tests them for NULL
+    gb = amd._ffi.GraphBatch(plan.ctypes.data, one, one, None, 0, symmetric, one if csr else None, one if csr else None,
+                             one if csr else None, None)
+    out = (C.c_int32 * 8)()
+    assert lib.agcn_sgc_ll_dispatch_info(C.byref(desc), C.byref(gb), out, 8) == 0, lib.agcn_last_error()
+    return dict(zip(("path", "small_first", "f_graphs", "f_members", "f_paired", "b_graphs", "b_members", "b_paired"),
+                    list(out)))
+
+
+def test_dispatch_table(amd):
+    """Which kernels a batch takes, decided on the host: checked without a GPU on the batch shapes the
+    benchmarks use."""
+    from agcn_amd import synth
+    rs = np.random.RandomState(0)
+    tox = lambda B: synth.node_counts(np.random.RandomState(123), B)   # noqa: E731
+    n256 = tox(256)
+    big, tiny = int((n256 >= 33).sum()), int((n256 <= 16).sum())
+    members = int(np.ceil(n256[n256 >= 33] / 16.0).sum())
+    # the headline batch: specialised kernels, every graph >= 33 nodes spread over members, exactly enough pairs of
+    # small graphs for the launch to fit 256 CUs, the same plan for the forward and the backward
+    d = _dispatch(amd, n256, 75, 64, 1)
+    assert d["path"] == 7 and d["small_first"] == 256
+    assert (d["f_graphs"], d["f_members"]) == (big, members) == (d["b_graphs"], d["b_members"])
+    assert d["f_paired"] == d["b_paired"] == 2 * (256 + members - big - 256) and d["f_paired"] <= tiny
+    # reference mode: members in the forward only
+    d = _dispatch(amd, n256, 75, 64, 0)
+    assert d["path"] == 7 and d["f_members"] == members and d["b_members"] == 0 and d["b_paired"] == 0
+    # half a chip of graphs: members, nobody paired
+    d = _dispatch(amd, tox(128), 75, 64, 1)
+    assert d["path"] == 7 and d["f_members"] > 0 and d["f_paired"] == 0
+    # two rounds of workgroups per CU: no members, small graphs in pairs
+    d = _dispatch(amd, tox(600), 75, 64, 1)
+    assert d["path"] == 7 and d["small_first"] == 600 and d["f_members"] == 0 and d["f_paired"] > 0
+    # 1024 graphs and up: 8-wave launch beside the 16-wave one, nothing else
+    d = _dispatch(amd, tox(2048), 75, 64, 1)
+    assert d["path"] == 7 and 0 < d["small_first"] < 2048 and d["f_members"] == d["f_paired"] == 0
+    # a full batch without enough small graphs: only graphs of five tiles and up are spread
+    n = np.concatenate([np.full(250, 40), [96, 80, 64, 40, 40, 40]]).astype(np.int32)
+    d = _dispatch(amd, n, 75, 64, 1)
+    assert d["path"] == 7 and d["f_graphs"] == 2 and d["f_members"] == 6 + 5 and d["f_paired"] == 0
+    # a molecule beyond the specialised kernels' 96 nodes: the whole batch on the slab kernels (general fused kernels
+    # when it is small enough for them); other layer widths / Reslap: general fused kernels
+    n = n256.copy()
+    n[3] = 150
+    assert _dispatch(amd, n, 75, 64, 1)["path"] == 16
+    assert _dispatch(amd, n256, 80, 64, 1)["path"] == 4
+    assert _dispatch(amd, n256, 64, 64, 1, variant=1)["path"] == 4
+    assert _dispatch(amd, n256, 75, 64, 1, K=3)["path"] == 32
+    del rs
