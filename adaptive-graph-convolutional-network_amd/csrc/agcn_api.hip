@@ -81,6 +81,7 @@ struct FusedSplit {
   int spec_fwd, spec_bwd;
   int spec_bwd_first;   // schedule position of the first graph the specialised backward kernel takes
   int spec_small_first; // schedule position of the first graph of the 8-wave flavour (== B: no such launch)
+  int coop_forced;      // leading graphs that only the cooperative members can take (96 < n <= 128)
 };
 
 // The specialised kernels cover the whole batch or nothing (one launch per direction).
@@ -132,7 +133,7 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
     ++nb;
   }
   if (nb == 0 || nb == pi.B || nb > std::max(2, pi.B / 16)) return;
-  FusedSplit m{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  FusedSplit m{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   m.mode = 2; m.n_big = nb; m.n_big_slabs = ns; m.thr = host.n[host.order[nb]]; m.big_pg = 0;
   m.spec_fwd = m.spec_bwd = 1; m.spec_bwd_first = nb; m.spec_small_first = pi.B;
   *f = m;
@@ -185,6 +186,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   if (dual_on && B + extra > n_cus) pairs = std::min(tiny / 2, B + extra - n_cus);
   const int min_n = B + extra - pairs <= n_cus ? base_min : std::max(base_min, spec::COOP_MIN_N_FULL);
   if (min_n != base_min) pairs = 0;   // (no room to be made: nothing is paired)
+  // (graphs only the members can take -- fs.coop_forced leading ones, n > 96 -- are above either threshold)
   *dual_graphs = 2 * pairs;
   int g = 0, s = 0;
   while (g < B - 1 - 2 * pairs) {   // (never every graph: the last one of the schedule writes the transposed parameters)
@@ -196,17 +198,45 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   }
   *graphs = g; *slabs = s;
 }
+// Batches whose few largest graphs are beyond the one-workgroup kernels (n > 96) but within the members' reach
+// (n <= COOP_MAX_N and their LDS plan fits): the specialised kernels take the batch with those graphs spread over
+// members -- instead of the whole batch on the slab kernels (HIV-shaped epoch: 36 % of the batches).  Paper mode (the
+// reference-mode backward has no members), one 16-wave launch.
+void coop_reach(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host, size_t lim) {
+  const AgcnPlanInfo& pi = host.info;
+  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 || d->mode != AGCN_MODE_PAPER) return;
+  if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
+  if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || pi.B >= 1024 || pi.B < 2) return;
+  int k = 0;
+  while (k < pi.B - 1) {
+    const int n = host.n[host.order[k]];
+    if (std::max(spec_fwd_lds_bytes(n, d->Fin, d->Fout, spec::NW_LARGE),
+                 spec_bwd_lds_bytes(n, d->Fin, d->Fout, spec::NW_LARGE)) <= lim) break;
+    if (n > spec::COOP_MAX_N || spec_coop_lds_bytes(n, d->Fin, d->Fout) > lim || spec_coop_fwd_lds_bytes(n, d->Fin) > lim)
+      return;
+    ++k;
+  }
+  if (k == 0 || k >= pi.B - 1) return;
+  FusedSplit m{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  m.mode = 1; m.thr = host.n[host.order[k]];
+  m.spec_fwd = m.spec_bwd = 1; m.spec_bwd_first = 0; m.spec_small_first = pi.B; m.coop_forced = k;
+  int cg = 0, cs = 0, dg = 0;
+  coop_plan(d, host, m, true, &cg, &cs, &dg);
+  if (cg < k) return;   // (the planner would not spread all of them: member budget, batch too large)
+  *f = m;
+}
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host);
 FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
   FusedSplit f = fused_split_general(d, g, host);
   size_t lim = (size_t)agcn_get_lds_limit();
   if (lim > 160 * 1024) lim = 160 * 1024;
   pick_spec(&f, d, host, lim);
+  if (!(f.mode == 1 && f.spec_fwd && f.spec_bwd && f.spec_bwd_first == 0)) coop_reach(&f, d, g, host, lim);
   if (!(f.mode == 1 && f.spec_fwd && f.spec_bwd)) mixed_spec(&f, d, g, host, lim);
   return f;
 }
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
-  FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
   if (agcn_get_fused_mode() == 0) return f;
   if (!(d->K == 2 && pi.rows == pi.N1 && (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;

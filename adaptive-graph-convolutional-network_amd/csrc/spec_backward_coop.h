@@ -35,6 +35,10 @@ constexpr int COOP_MIN_N_FULL = 65;    // ... of at least five, when every extra
 // different streams (epoch lanes): 240 members still fit 256 CUs.  (Beyond that a wait can run out: bounded, loud.)
 constexpr int COOP_MAX_MEMBERS = 120;
 constexpr int DUAL_MAX_N = 16;         // graphs that may be packed two to a workgroup (8 waves each)
+// Largest graph the members can take: a member holds [n x F] images and 16-row strips, not n x n tiles, so it reaches
+// beyond the 96 nodes of the one-workgroup kernels (whose backward keeps two n x n tiles) as far as its LDS plan fits
+// (spec_coop_lds_bytes): lanes cover 128 columns, a wave 8 rows of an image, the epoch table 8 members.
+constexpr int COOP_MAX_N = 128;
 // exchange header at the start of the reserve, per direction (0 backward, 1 forward): one slot per member row, one
 // epoch word per member (a graph uses the rows / the epoch of its first slab)
 constexpr int COOP_DIR_WORDS = COOP_MAX_MEMBERS * 16 + COOP_MAX_MEMBERS;
@@ -77,7 +81,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64, NKW = FOUT / 4;
-  constexpr int RPW = 6;                       // rows of an [n x F] matrix one wave may own (n4 <= 96)
+  constexpr int RPW = 8;                       // rows of an [n x F] matrix one wave may own (n4 <= 128 = COOP_MAX_N)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;

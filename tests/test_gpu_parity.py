@@ -622,21 +622,26 @@ def test_full_size_every_graph_every_gradient(amd, variant, mode, B):
     compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
 
 
+@pytest.mark.parametrize("reach", ["beyond_members", "within_members"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
-def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode):
+def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach):
     """BASELINE configs[4]'s batch shape (HIV-like sizes, mu = ln 23, up to 222 atoms): a 256-graph batch with a few
-    molecules beyond the specialised kernels' 96-node LDS plan.  By default the whole batch takes the slab kernels;
-    with agcn_set_fused_mode(3) the oversized molecules take the slab kernels on the side stream beside the
-    specialised kernels ("mixed" dispatch).  The launches must be exactly that, and EVERY graph and EVERY gradient
-    must match the float64 oracle either way."""
+    molecules beyond the one-workgroup kernels' 96-node LDS plan.
+    within_members (largest molecule <= 128 atoms, paper mode): the specialised kernels take the batch, the oversized
+    molecules spread over member workgroups.  beyond_members (a molecule > 128 atoms; or reference mode): the whole
+    batch takes the slab kernels by default; with agcn_set_fused_mode(3) the oversized molecules take the slab kernels
+    on the side stream beside the specialised kernels ("mixed" dispatch).  The launches must be exactly that, and
+    EVERY graph and EVERY gradient must match the float64 oracle either way."""
     Fin, Fout, K = 75, 64, 2
-    for seed in range(40, 80):
-        sb = orc.synth_batch(seed, 256, mu=np.log(23.0), hi=222)
-        big = int((np.asarray(sb["ns"]) > 96).sum())
-        if 1 <= big <= 4:
+    for seed in range(40, 400):      # (the node counts are the first thing synth_batch draws from its seed)
+        nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
+        big = int((nsa > 96).sum())
+        if 1 <= big <= 4 and ((nsa.max() > 128) == (reach == "beyond_members")):
             break
     else:
-        pytest.fail("no seed gives a batch with 1-4 oversized molecules")
+        pytest.fail("no seed gives such a batch")
+    sb = orc.synth_batch(seed, 256, mu=np.log(23.0), hi=222)
+    assert np.array_equal(np.asarray(sb["ns"]), nsa)
     ns = [int(v) for v in sb["ns"]]
     rs = np.random.RandomState(seed)
     p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL)
@@ -644,7 +649,8 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode):
     G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
     caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, orc.SGC_LL, G, None, None)
     lib = amd._ffi.lib()
-    for fused_mode in (1, 3):      # 1 (default): the whole batch on the slab kernels; 3: mixed dispatch
+    members_take_it = reach == "within_members" and mode == orc.PAPER
+    for fused_mode in (1, 3):      # 1 (default); 3: mixed dispatch allowed
         lib.agcn_set_fused_mode(fused_mode)
         try:
             out = run_packed(amd, DEV, ns, sb["X"], sb["csr"], p, G, Fin, Fout, K, mode, orc.SGC_LL, None, None)
@@ -654,9 +660,12 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode):
             names = amd.SgcLLStep(layer, gb).kernel_names()
         finally:
             lib.agcn_set_fused_mode(1)
-        assert "slab_sim_kernel" in names[0] and "slab_bwd1_kernel" in names[1], names
-        assert ("spec_forward_kernel" in names[0]) == (fused_mode == 3), names
-        assert ("spec_backward_kernel" in names[1]) == (fused_mode == 3), names
+        if members_take_it:
+            assert names[0] == "spec_forward_kernel" and names[1] == "spec_backward_kernel", names
+        else:
+            assert "slab_sim_kernel" in names[0] and "slab_bwd1_kernel" in names[1], names
+            assert ("spec_forward_kernel" in names[0]) == (fused_mode == 3), names
+            assert ("spec_backward_kernel" in names[1]) == (fused_mode == 3), names
 
 
 def test_errors_are_loud(amd):

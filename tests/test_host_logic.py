@@ -245,6 +245,12 @@ def test_dispatch_table(amd):
     n = n256.copy()
     n[3] = 150
     assert _dispatch(amd, n, 75, 64, 1)["path"] == 16
+    # ... unless it is within the members' reach (<= 128 nodes, paper mode): specialised kernels, that graph on 8 members
+    n[3] = 120
+    d = _dispatch(amd, n, 75, 64, 1)
+    assert d["path"] == 7 and d["f_graphs"] >= 1 and d["f_members"] >= 8 and d["b_members"] == d["f_members"]
+    assert _dispatch(amd, n, 75, 64, 0)["path"] == 16          # (reference mode: no members in the backward)
+    assert _dispatch(amd, n, 128, 128, 1)["path"] == 16        # (the members' LDS plan does not fit at this width)
     assert _dispatch(amd, n256, 80, 64, 1)["path"] == 4
     assert _dispatch(amd, n256, 64, 64, 1, variant=1)["path"] == 4
     assert _dispatch(amd, n256, 75, 64, 1, K=3)["path"] == 32

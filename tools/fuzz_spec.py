@@ -1,6 +1,6 @@
 """Randomised check of the specialised kernels' dispatch (plain workgroups, cooperative members, paired small graphs,
 8-/16-wave launches side by side) against the float64 oracle: random batch sizes around the thresholds, graph sizes up
-to 96 nodes, the five covered layer shapes, both Laplacian modes.
+to 128 nodes, the five covered layer shapes, both Laplacian modes.
 usage: python tools/fuzz_spec.py [n_cases] [seed]"""
 import os
 import sys
@@ -28,8 +28,8 @@ def main():
         B = int(rs0.choice([1, 2, 3, 7, 16, 33, 64, 120, 200, 255, 256, 257, 300, 390, 520, 1030]))
         mu = np.log(rs0.choice([6, 12, 16, 24, 40]))
         ns = [int(v) for v in np.clip(np.rint(rs0.lognormal(mu, 0.6, size=B)), 1, 96)]
-        if rs0.rand() < 0.3:
-            ns[int(rs0.randint(B))] = int(rs0.choice([96, 95, 81, 80, 65, 64, 49, 48, 33]))
+        if rs0.rand() < 0.4:      # thresholds of the dispatch, incl. graphs only the members can take (97 .. 128)
+            ns[int(rs0.randint(B))] = int(rs0.choice([128, 127, 113, 112, 97, 96, 95, 81, 80, 65, 64, 49, 48, 33]))
         Fin, Fout = SHAPES[int(rs0.randint(len(SHAPES)))]
         mode = orc.PAPER if rs0.rand() < 0.7 else orc.REFERENCE
         rs, X, L0, csr, p, G = synth_case(20_000 + case, ns, Fin, Fout, 2, orc.SGC_LL, atoms=(Fin == 75))
