@@ -422,10 +422,11 @@ void agcn_set_fused_global_b(int32_t mode);
 int32_t agcn_get_param_grad_onepass(void);
 void agcn_set_param_grad_onepass(int32_t on);
 /* Shape-specialised fused kernels (csrc/spec_*.hip: SGC_LL, K = 2, layer widths 75->64, 64->128, 128->128, 128->64,
- * 64->64; 512-thread workgroups, feature widths compiled in).  1 (default): used wherever the fused path would be
- * taken and the shape is covered; 0: always the general fused kernels.  Bit 0 = forward, bit 1 = backward
- * bit 2 = graphs of three (five, when the launch does not fit the chip any more) 16-row tiles and up spread over one
- * workgroup per tile in the same launch, paper mode (7 = all, the default).  Same results within the last few ulps
+ * 64->64; 1024-thread workgroups, feature widths compiled in).  A bit mask, default 7: bit 0 = forward, bit 1 =
+ * backward (used wherever the fused path would be taken and the shape is covered; 0: always the general fused
+ * kernels), bit 2 = the cooperative launch layout (csrc/spec_backward_coop.h): graphs of three 16-row tiles and up
+ * (five, when the launch does not fit the chip any more; up to 128 nodes) spread over one workgroup per tile of the
+ * same launch, the smallest graphs packed two to a workgroup to make room.  Same results within the last few ulps
  * (hardware sqrt / exp2 in the similarity phase; summation orders). */
 int32_t agcn_get_spec_mode(void);
 void agcn_set_spec_mode(int32_t mode);
