@@ -22,6 +22,7 @@
 #include <float.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace agcn {
 
@@ -679,6 +680,223 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Point-cloud first layer (Fin <= 4: xyz coordinates, dense L_orig, n = 1024): the feature contractions of the
+// backward have 3 terms -- staging 64-row images in LDS and running 16-wide MFMA k-steps (12 of 16 lanes of k padding)
+// between three barriers per 64-column chunk is what the general kernels above spend their time on.  These two
+// variants keep the slab rows' g_1 / X_0 / Z values in registers, take the chunk column's rows of g_1 / X_0 / Z with
+// plain coalesced loads, accumulate per lane and reduce ONCE at the end: no LDS image, no barrier inside the chunk
+// loop, and dA_ij / dA_ji (three-term dot products) are recomputed by the second kernel instead of being written
+// and read back: the only n x n traffic of the backward is r (twice) and L_orig (once).
+constexpr int SF = 4;   // padded small feature count
+
+struct SmallRegs { float rv[4], l0[4], sj, gj[SF], xj[SF]; };
+
+__global__ __launch_bounds__(256) void slab_bwd1_small_kernel(SgcArgs a) {
+  __shared__ float red[32];
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Fin = a.Fin, n = c.n;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * Fin;
+  const float* L0d = a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff;
+  const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+  float si[4], gI[4][SF], xI[4][SF];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = min(4 * wave + di, c.nr - 1);
+    si[di] = paper ? a.sv_s[c.row0 + c.i0 + il] : 0.f;
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      gI[di][f] = f < Fin ? g1[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
+      xI[di][f] = (paper && f < Fin) ? Xg[(int64_t)(c.i0 + il) * a.ldx + f] : 0.f;
+    }
+  }
+  auto load_chunk = [&](int c0) {
+    SmallRegs g;
+    const int jc = min(c0 + lane, n - 1);
+    g.sj = paper ? a.sv_s[c.row0 + jc] : 0.f;
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      g.gj[f] = f < Fin ? g1[(int64_t)jc * Fin + f] : 0.f;
+      g.xj[f] = (paper && f < Fin) ? Xg[(int64_t)jc * a.ldx + f] : 0.f;
+    }
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int i = min(c.i0 + 4 * wave + di, n - 1);
+      g.rv[di] = paper ? a.sv_r[c.toff + (int64_t)i * n + jc] : 0.f;
+      g.l0[di] = L0d[(int64_t)i * l0ld + jc];
+    }
+    return g;
+  };
+  float accL[4][SF], ds[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int di = 0; di < 4; ++di)
+#pragma unroll
+    for (int f = 0; f < SF; ++f) accL[di][f] = 0.f;
+  float dalpha_part = 0.f;
+  SmallRegs cur = load_chunk(0);
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const SmallRegs nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;   // next chunk's loads in flight
+    const int j = c0 + lane;
+    const bool cv = j < n;
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int il = 4 * wave + di, i = c.i0 + il;
+      if (cv && il < c.nr) {
+        const float S = (!paper || i == j) ? 0.f : expf(-cur.rv[di]);      // slab_sim's instruction
+        float R = (i == j) ? 1.f : 0.f;
+        if (paper) R = R - (si[di] * S) * cur.sj;                            // slab_lap's instruction
+        const float L = lrelu(R, alpha) + cur.l0[di];
+        float dL = 0.f, dLt = 0.f;
+#pragma unroll
+        for (int f = 0; f < SF; ++f) {
+          accL[di][f] += L * cur.gj[f];                                      // dX[I] += L[I, :] g_1
+          dL += gI[di][f] * cur.xj[f];                                       // dL[i][j] = g_1[i] . X_0[j]
+          dLt += xI[di][f] * cur.gj[f];                                      // dL[j][i] = g_1[j] . X_0[i]
+        }
+        if (paper) {
+          const float lg = lrelu_grad(R, alpha);
+          dalpha_part += dL * fminf(R, 0.f);
+          const float dA = -(dL * lg), dAt = -(dLt * lg);                    // dA_ij, dA_ji (R symmetric)
+          ds[di] += (dA * S) * cur.sj + (dAt * S) * cur.sj;     // (nothing n x n is stored: slab_bwd2_small recomputes dA)
+        }
+      }
+    }
+    cur = nxt;
+  }
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = 4 * wave + di;
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      const float t = wave_allsum(accL[di][f]);
+      if (lane == 0 && il < c.nr && f < Fin) dXg[(int64_t)il * a.ldx + f] += t;   // (g_0 is there already)
+    }
+    if (paper) {
+      const float t = wave_allsum(ds[di]);
+      if (lane == 0 && il < c.nr) a.ws_dd[c.row0 + c.i0 + il] = degree_grad(si[di], t);
+    }
+  }
+  const float da = block_sum(dalpha_part, red);
+  if (tid == 0) {
+    a.ws_pg[2 * (a.pg_slab_base + blockIdx.x) + 0] = da;
+    a.ws_pg[2 * (a.pg_slab_base + blockIdx.x) + 1] = 0.f;
+    if (a.pg_slab_base > 0 && c.i0 == 0) {
+      a.ws_pg[2 * c.b + 0] = 0.f;
+      a.ws_pg[2 * c.b + 1] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_bwd2_small_kernel(SgcArgs a) {
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Fin = a.Fin, n = c.n;
+  const float alpha = a.alpha[0];
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * Fin;
+  float si[4], ddi[4], gI[4][SF], xI[4][SF];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = min(4 * wave + di, c.nr - 1);
+    const int row = c.row0 + c.i0 + il;
+    si[di] = a.sv_s[row];
+    ddi[di] = a.ws_dd[row];
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      gI[di][f] = f < Fin ? g1[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
+      xI[di][f] = f < Fin ? Xg[(int64_t)(c.i0 + il) * a.ldx + f] : 0.f;
+    }
+  }
+  // dA_ij / dA_ji are recomputed exactly as slab_bwd1_small computed them (three-term dot products, the same
+  // expressions: the same bits): the only n x n read is r
+  struct Regs { float sj, ddj, rv[4], zj[SF], gj[SF], xj[SF]; };
+  auto load_chunk = [&](int c0) {
+    Regs g;
+    const int jc = min(c0 + lane, n - 1);
+    g.sj = a.sv_s[c.row0 + jc];
+    g.ddj = a.ws_dd[c.row0 + jc];
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      g.zj[f] = f < Fin ? Zg[(int64_t)jc * Fin + f] : 0.f;
+      g.gj[f] = f < Fin ? g1[(int64_t)jc * Fin + f] : 0.f;
+      g.xj[f] = f < Fin ? Xg[(int64_t)jc * a.ldx + f] : 0.f;
+    }
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int i = c.i0 + min(4 * wave + di, c.nr - 1);
+      g.rv[di] = a.sv_r[c.toff + (int64_t)i * n + jc];
+    }
+    return g;
+  };
+  float accZ[4][SF], cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int di = 0; di < 4; ++di)
+#pragma unroll
+    for (int f = 0; f < SF; ++f) accZ[di][f] = 0.f;
+  Regs cur = load_chunk(0);
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const Regs nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;
+    const int j = c0 + lane;
+    const bool cv = j < n;
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int il = 4 * wave + di, i = c.i0 + il;
+      if (cv && il < c.nr && i != j && cur.rv[di] > 0.f) {
+        const float S = expf(-cur.rv[di]);
+        if (S != 0.f) {                                                      // S == 0 (underflow): dr = 0, never inf * 0
+          const float R = -((si[di] * S) * cur.sj);                         // (i != j)
+          const float lg = lrelu_grad(R, alpha);
+          float dL = 0.f, dLt = 0.f;
+#pragma unroll
+          for (int f = 0; f < SF; ++f) {
+            dL += gI[di][f] * cur.xj[f];
+            dLt += xI[di][f] * cur.gj[f];
+          }
+          const float dA = -(dL * lg), dAt = -(dLt * lg);
+          const float dr_ij = -S * (dA * si[di] * cur.sj + cur.ddj);
+          const float dr_ji = -S * (dAt * cur.sj * si[di] + ddi[di]);
+          const float cij = (dr_ij + dr_ji) / cur.rv[di];
+          cs[di] += cij;
+#pragma unroll
+          for (int f = 0; f < SF; ++f) accZ[di][f] += cij * cur.zj[f];
+        }
+      }
+    }
+    cur = nxt;
+  }
+  // dZ_i = rowsum(c)_i Z_i - (c Z)_i;  dX_i += dZ_i M_L^T
+  float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * Fin;
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = 4 * wave + di;
+    const float csum = wave_allsum(cs[di]);
+    float dz[SF];
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      const float t = wave_allsum(accZ[di][f]);
+      const float zi = (il < c.nr && f < Fin) ? Zg[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
+      dz[f] = (il < c.nr && f < Fin) ? csum * zi - t : 0.f;
+    }
+    if (il < c.nr && lane < Fin) {
+      float dzl = 0.f, dx = 0.f;
+#pragma unroll
+      for (int f = 0; f < SF; ++f) {
+        if (f == lane) dzl = dz[f];
+        if (f < Fin) dx += dz[f] * a.M_L[(int64_t)lane * Fin + f];           // (dZ M_L^T)[lane] = sum_f dZ[f] M_L[lane][f]
+      }
+      dZg[(int64_t)il * Fin + lane] = dzl;
+      dXg[(int64_t)il * a.ldx + lane] += dx;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 namespace {
 size_t lds_sim(int Fin) { return sizeof(float) * ((size_t)Fin * SH + (size_t)Fin * CH1P); }
 size_t lds_lap(int Fin) {
@@ -724,8 +942,18 @@ int launch_slab_forward(const SgcArgs& a, void* stream) {
   return launch_slab(slab_lap_kernel, a, lds_lap(a.Fin), PK_SLAB_LAP, "slab_lap", stream);
 }
 
+bool slab_small_features(const SgcArgs& a) {
+  static const int off = [] { const char* e = std::getenv("AGCN_SLAB_SMALL"); return (e && e[0] == '0') ? 1 : 0; }();
+  return !off && a.Fin <= SF && a.L0_dense != nullptr && a.dL_sum == nullptr;
+}
+
 int launch_slab_backward(const SgcArgs& a, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
+  if (slab_small_features(a)) {   // point-cloud first layer: streaming variants (no LDS images, no chunk barriers)
+    int rc = launch_slab(slab_bwd1_small_kernel, a, 0, PK_SLAB_BWD1, "slab_bwd1_small", stream);
+    if (rc != AGCN_OK || !paper) return rc;
+    return launch_slab(slab_bwd2_small_kernel, a, 0, PK_SLAB_BWD2, "slab_bwd2_small", stream);
+  }
   int rc = launch_slab(slab_bwd1_kernel, a, lds_bwd1(a.Fin, paper), PK_SLAB_BWD1, "slab_bwd1", stream);
   if (rc != AGCN_OK || !paper) return rc;
   return launch_slab(slab_bwd2_kernel, a, lds_bwd2(a.Fin), PK_SLAB_BWD2, "slab_bwd2", stream);
