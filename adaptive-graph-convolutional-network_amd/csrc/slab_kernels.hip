@@ -691,6 +691,110 @@ constexpr int SF = 4;   // padded small feature count
 
 struct SmallRegs { float rv[4], l0[4], sj, gj[SF], xj[SF]; };
 
+// forward: R, res_L, L strip, X_1[I] = L[I, :] X_0 (three columns: per-lane partial sums, one reduction at the end) and
+// the filter product of the slab's rows
+__global__ __launch_bounds__(256) void slab_lap_small_kernel(SgcArgs a) {
+  constexpr int LDA = 18;                 // ld_frag(16)
+  __shared__ float X0s[SH * LDA], X1s[SH * LDA];
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int Fin = a.Fin, n = c.n;
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* L0d = a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff;
+  const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+  float si[4];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) si[di] = a.sv_s[c.row0 + c.i0 + min(4 * wave + di, c.nr - 1)];
+  for (int e = tid; e < SH * LDA; e += 256) {
+    const int ii = e / LDA, f = e - ii * LDA;
+    X0s[e] = (ii < c.nr && f < Fin) ? Xg[(int64_t)(c.i0 + ii) * a.ldx + f] : 0.f;
+    X1s[e] = 0.f;
+  }
+  struct Regs { float v[4], l0[4], sj, xj[SF]; };
+  auto load_chunk = [&](int c0) {
+    Regs g;
+    const int jc = min(c0 + lane, n - 1);
+    g.sj = paper ? a.sv_s[c.row0 + jc] : 0.f;
+#pragma unroll
+    for (int f = 0; f < SF; ++f) g.xj[f] = f < Fin ? Xg[(int64_t)jc * a.ldx + f] : 0.f;
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int i = min(c.i0 + 4 * wave + di, n - 1);
+      g.v[di] = paper ? a.res_W[c.toff + (int64_t)i * n + jc] : 0.f;
+      g.l0[di] = L0d[(int64_t)i * l0ld + jc];
+    }
+    return g;
+  };
+  float accX[4][SF];
+#pragma unroll
+  for (int di = 0; di < 4; ++di)
+#pragma unroll
+    for (int f = 0; f < SF; ++f) accX[di][f] = 0.f;
+  Regs cur = load_chunk(0);
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const Regs nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;   // next chunk's loads in flight
+    const int j = c0 + lane;
+    const bool cv = j < n;
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int il = 4 * wave + di, i = c.i0 + il;
+      if (cv && il < c.nr) {
+        float R = (i == j) ? 1.f : 0.f;                    // reference: I - D*W*D elementwise == I
+        if (paper) R = R - (si[di] * cur.v[di]) * cur.sj;   // paper: I - s S s
+        const float L = lrelu(R, alpha);                    // (R * 1.0f: the clip scale is exactly 1)
+        const int64_t o = c.toff + (int64_t)i * n + j;
+        a.res_L[o] = L;
+        const float Lt = L + cur.l0[di];
+        if (a.L_sum) a.L_sum[o] = Lt;
+#pragma unroll
+        for (int f = 0; f < SF; ++f) accX[di][f] += Lt * cur.xj[f];
+      }
+    }
+    cur = nxt;
+  }
+  __syncthreads();   // (the images' zero fill)
+  float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * Fin;
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = 4 * wave + di;
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      const float t = wave_allsum(accX[di][f]);
+      if (lane == 0 && il < c.nr && f < Fin) {
+        X1s[il * LDA + f] = t;
+        Xo[(int64_t)il * Fin + f] = t;
+      }
+    }
+  }
+  __syncthreads();
+  // Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b), as slab_lap_kernel
+  {
+    const int Fout = a.Fout, K = a.K;
+    const bool relu = a.activation == AGCN_ACT_RELU;
+    float* Yg = a.Y + (int64_t)(c.row0 + c.i0) * a.ldy;
+    for (int tcol = wave; tcol < ((Fout + 15) >> 4); tcol += 4) {
+      f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+      tile_gemm_gb(y, X0s, LDA, 0, a.weight, K * Fout, Fin, 16 * tcol, Fout, 16);
+      tile_gemm_gb(y, X1s, LDA, 0, a.weight + Fout, K * Fout, Fin, 16 * tcol, Fout, 16);
+      const int col = 16 * tcol + r;
+      if (col < Fout) {
+        const float bc = a.bias[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (4 * q + i < c.nr) {
+            float v = y[i] + bc;
+            if (relu) v = fmaxf(v, 0.f);
+            Yg[(int64_t)(4 * q + i) * a.ldy + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void slab_bwd1_small_kernel(SgcArgs a) {
   __shared__ float red[32];
   const SlabCtx c = slab_ctx(a);
@@ -936,15 +1040,20 @@ bool slab_path_fits(int32_t Fin) {
   return lds_sim(Fin) <= lim && lds_lap(Fin) <= lim && lds_bwd1(Fin, true) <= lim && lds_bwd2(Fin) <= lim;
 }
 
+static bool slab_small_env() {
+  static const int off = [] { const char* e = std::getenv("AGCN_SLAB_SMALL"); return (e && e[0] == '0') ? 1 : 0; }();
+  return !off;
+}
 int launch_slab_forward(const SgcArgs& a, void* stream) {
   int rc = launch_slab(slab_sim_kernel, a, lds_sim(a.Fin), PK_SLAB_SIM, "slab_sim", stream);
   if (rc != AGCN_OK) return rc;
+  if (a.Fin <= SF && a.L0_dense != nullptr && a.K == 2 && slab_small_env())
+    return launch_slab(slab_lap_small_kernel, a, 0, PK_SLAB_LAP, "slab_lap_small", stream);
   return launch_slab(slab_lap_kernel, a, lds_lap(a.Fin), PK_SLAB_LAP, "slab_lap", stream);
 }
 
 bool slab_small_features(const SgcArgs& a) {
-  static const int off = [] { const char* e = std::getenv("AGCN_SLAB_SMALL"); return (e && e[0] == '0') ? 1 : 0; }();
-  return !off && a.Fin <= SF && a.L0_dense != nullptr && a.dL_sum == nullptr;
+  return slab_small_env() && a.Fin <= SF && a.L0_dense != nullptr && a.dL_sum == nullptr;
 }
 
 int launch_slab_backward(const SgcArgs& a, void* stream) {
