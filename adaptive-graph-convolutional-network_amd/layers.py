@@ -128,13 +128,14 @@ class SGC_LL(Layer):
                  save_lap=False, save_output=False, laplacian_mode="reference", device=None,
                  generator=None, **kwargs):
         super(SGC_LL, self).__init__(**kwargs)
-        if dropout is not None:
-            raise NotImplementedError("dropout is never enabled by the reference networks")
+        if dropout is not None and not (0.0 <= float(dropout) < 1.0):
+            raise ValueError("dropout is the fraction of activations to drop, in [0, 1)")
         if activation not in ("relu", "linear", None):
             raise ValueError("Invalid activation function: %s" % (activation,))
         if laplacian_mode not in ("reference", "paper"):
             raise ValueError("laplacian_mode must be 'reference' or 'paper'")
         self.dropout = dropout
+        self.training = True        # the learning phase of the reference (model_operatos.in_train_phase): dropout only
         self.activation = activation
         self.batch_size = batch_size
         self.nb_filter = output_dim
@@ -189,6 +190,11 @@ class SGC_LL(Layer):
         v = self.vars
         Y, res_L, res_W, L_sum = SgcLLFunction.apply(_in32(X), v["weight"], v["bias"], v["M_L"], v["alpha"],
                                                      v.get("beta"), L_prev, gb, cfg)
+        if self.dropout and self.training:
+            # graphconv.py:121-122 / dropout.py:34-41: Dropout(p) on the activated nodes in the training phase, i.e.
+            # tf.nn.dropout(x, keep_prob = 1 - p): kept entries scaled by 1 / (1 - p).  (No reference network enables it;
+            # an element-wise torch op behind the layer, differentiable, not part of the fused kernels.)
+            Y = torch.nn.functional.dropout(Y, p=float(self.dropout), training=True)
         nodes = RowViews(_out_as(Y, X.dtype), gb.plan, gb)
         return gb, nodes, TileViews(res_L, gb.plan), TileViews(res_W, gb.plan), TileViews(L_sum, gb.plan)
 

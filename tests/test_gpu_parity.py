@@ -1205,3 +1205,30 @@ def test_large_graphs_spread_over_several_workgroups(amd, Fin, Fout):
         lib.agcn_set_spec_mode(7)
     assert_close(to_np(res[7][1]), to_np(res[3][1]), 2 * GRAD_RTOL, "dX coop vs plain", atol_ulps=2 * GRAD_ULPS)
     assert_close(to_np(res[7][0]), to_np(res[3][0]), 2 * GRAD_RTOL, "bucket coop vs plain", atol_ulps=2 * GRAD_ULPS)
+
+
+def test_dropout_on_the_activated_nodes(amd):
+    """SGC_LL(dropout=p) (graphconv.py:121-122 -> dropout.py:34-41, tf.nn.dropout(x, 1 - p) in the training phase): kept
+    entries are the layer's own outputs scaled by 1 / (1 - p), about a fraction p is dropped, the gradient flows through
+    the kept ones only; outside the training phase the layer is unchanged."""
+    ns, Fin, Fout, K = [18, 7, 33, 4, 12], 75, 64, 2
+    rs, X, L0, csr, p, G = synth_case(31, ns, Fin, Fout, K, orc.SGC_LL, atoms=True)
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+    plain = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, orc.PAPER, p, DEV)
+    drop = amd.SGC_LL(Fout, Fin, len(ns), K=K, laplacian_mode="paper", dropout=0.3, device=DEV)
+    drop.load_vars(p)
+    y0 = plain({"node_features": gb.X, "graph_batch": gb})[0].data
+    torch.manual_seed(0)
+    Xt = gb.X.clone().requires_grad_(True)
+    y1 = drop({"node_features": Xt, "graph_batch": gb})[0].data
+    kept = y1 != 0
+    assert torch.allclose(y1[kept], (y0 / 0.7)[kept], rtol=1e-6, atol=0)
+    live = y0 != 0
+    frac = 1.0 - float((kept & live).sum()) / float(live.sum())
+    assert 0.2 < frac < 0.4, frac
+    y1.sum().backward()
+    assert torch.isfinite(Xt.grad).all() and float(Xt.grad.abs().sum()) > 0
+    drop.training = False
+    assert torch.equal(drop({"node_features": gb.X, "graph_batch": gb})[0].data, y0)
+    with pytest.raises(ValueError):
+        amd.SGC_LL(Fout, Fin, len(ns), dropout=1.5, device=DEV)
