@@ -372,6 +372,13 @@ void fill_rows(RowsGemmArgs& g, const AgcnLayerDesc* d, const PlanView& host, co
   g.n = dev.n;
 }
 
+// every graph a multiple of 64 rows: four consecutive slabs always belong to one graph (slab_kernels.hip, Q = 4)
+static int slab_quad_ok(const PlanView& host) {
+  for (int b = 0; b < host.info.B; ++b)
+    if (host.n[b] % 64 != 0) return 0;
+  return 1;
+}
+
 void fill_common(SgcArgs& a, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnParams* p,
                  const AgcnOutputs* o, const PlanView& dev) {
   std::memset(&a, 0, sizeof(a));
@@ -525,6 +532,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, c.off);
 
   a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.slab_quad = slab_quad_ok(host);
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
   const FusedSplit fs = fused_split(desc, batch, host);
   if (fs.mode == 1) {
@@ -597,6 +605,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     } else {
       SgcArgs ab = a;
       ab.n_slabs = fs.n_big_slabs;
+      ab.slab_quad = 0;
       rc = launch_slab_forward(ab, ss.s);
     }
     if (rc != AGCN_OK) return rc;
@@ -631,6 +640,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   // 2. graph-local stages (similarity tile, learned Laplacian, Chebyshev terms)
   const int B = host.info.B;
   a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.slab_quad = slab_quad_ok(host);
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
   if (use_slabs(desc, batch, host.info)) {
     // slab_lap also applies the filter to its rows (Y = act([X_0|X_1] . W + b)): no packed FILTER launch
@@ -724,6 +734,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   coop_plan(desc, host, fs, true, &coop_graphs, &coop_slabs, &dual_graphs);
   if ((stages & 1) && fused) {
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.slab_quad = slab_quad_ok(host);
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_Gp = w.Gp;
     a.ws_dA = w.dA; a.ws_dd = w.dd;
@@ -751,6 +762,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         SgcArgs ab = a;
         ab.n_slabs = fs.n_big_slabs;
         ab.pg_slab_base = B;
+        ab.slab_quad = 0;
         rc = launch_slab_backward(ab, ss->s);
       }
       if (rc != AGCN_OK) return rc;
@@ -831,6 +843,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     if (rc != AGCN_OK) return rc;
     // 2. graph-local adjoints
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.slab_quad = slab_quad_ok(host);
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_dA = w.dA; a.ws_dd = w.dd;
     if (slabs) {

@@ -65,6 +65,7 @@ struct SgcArgs {
   float* ws_dA;    // [tile_elems]  dA = -dR               (paper mode, bwd1 -> bwd2)
   float* ws_dd;    // [rows]        dd_j                   (paper mode, bwd1 -> bwd2)
   int32_t pg_slab_base;  // mixed dispatch: slab s writes its partials at ws_pg[2 * (pg_slab_base + s)]
+  int32_t slab_quad;     // 1: every graph has a multiple of 64 rows (four consecutive slabs always share a graph)
   // arrival counters of the one-pass parameter-gradient kernel that follows: zeroed by workgroup 0 of the
   // fused backward kernel (saves a memset node in front of it)
   int32_t* zero_ptr;

@@ -38,9 +38,8 @@ struct SlabCtx {
   int64_t toff;
 };
 
-__device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a) {
+__device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a, int s) {
   SlabCtx c;
-  const int s = blockIdx.x;
   c.b = a.slab_graph[s];
   c.i0 = a.slab_row[s];
   c.n = a.n[c.b];
@@ -49,6 +48,7 @@ __device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a) {
   c.toff = a.tile_off[c.b];
   return c;
 }
+__device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a) { return slab_ctx(a, (int)blockIdx.x); }
 
 // wave-wide sum, result in every lane (fixed xor tree)
 __device__ __forceinline__ float wave_allsum(float v) {
@@ -229,7 +229,7 @@ __device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c
 // column tiles w and w + 4
 __device__ __forceinline__ void strip_gemm_rowmajor(f32x4 (&acc)[2], const float* A, int lda, const float* B,
                                                     int ldb, int kdim, int ntiles) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
   const int r = lane & 15, q = lane >> 4;
   const bool t1 = wave + 4 < ntiles;
   if (wave >= ntiles) return;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
 // tile[16 x 64] = A[16 x Fin] . T^T, T = row image [64][ldf] of the chunk's nodes (B[f][j] = T[j][f]);
 // wave w owns column tile w.  Result written to the LDS strip `out` [16][CHP].
 __device__ __forceinline__ void strip_gemm_transposed(float* out, const float* A, const float* T, int ldf, int F16) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
   const int r = lane & 15, q = lane >> 4;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < F16; k0 += 16) {
@@ -374,7 +374,7 @@ __device__ __forceinline__ void strip_gemm_transposed(float* out, const float* A
 struct BChunkRegs { float rv[4], l0[4], sj; };
 
 __device__ __forceinline__ BChunkRegs load_B_chunk(const SgcArgs& a, const SlabCtx& c, int c0, bool want_l0) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // (strip-local: a workgroup may hold four strips)
   const int n = c.n, jc = min(c0 + lane, n - 1);
   const bool paper = a.mode == AGCN_MODE_PAPER;
   BChunkRegs g;
@@ -395,7 +395,7 @@ __device__ __forceinline__ BChunkRegs load_B_chunk(const SgcArgs& a, const SlabC
 // S_ij and R_ij of the chunk element (4 * wave + di, lane) from the chunk registers
 __device__ __forceinline__ void chunk_SR(const SlabCtx& c, const BChunkRegs& g, int c0, const float (&si)[4], bool paper,
                                          float (&S)[4], float (&R)[4]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
   const int j = c0 + lane;
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
@@ -406,24 +406,36 @@ __device__ __forceinline__ void chunk_SR(const SlabCtx& c, const BChunkRegs& g, 
   }
 }
 
-__global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const SlabCtx c = slab_ctx(a);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Q strips per workgroup (Q = 1 | 2 | 4; Q x 256 threads).  The chunk rows of g_1 and X_0 are staged ONCE per workgroup
+// and shared by its Q strips: with one strip per workgroup every strip re-stages all of g_1 and X_0 (2 x n x Fin
+// floats), which at n = 1024, Fin = 64 is 1 GB of L2 traffic per launch and 70 % of the kernel's time (stamps: 5.8 of
+// 8.5 us per chunk).  Q > 1 needs the strips of a workgroup to belong to one graph (every graph a multiple of 64 rows:
+// the point clouds) and a dense L_orig.  Measured, 32 clouds of 1024 points, 64 -> 128: Q = 1: 560 us, Q = 2: 480 us
+// (185 VGPRs, one workgroup per CU), Q = 4: 564 us (held to 128 VGPRs by its 1024 threads: 200 bytes spilled).
+template <int Q>
+__global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  const int sub = Q == 1 ? 0 : (int)(threadIdx.x >> 8);
+  const int slab = (int)blockIdx.x * Q + sub;
+  const SlabCtx c = slab_ctx(a, slab);
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int Fin = a.Fin, n = c.n;
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const int ldf = ld_frag((Fin + 15) & ~15);   // images are read in k-steps of 16: pad columns are zero
   const int F16 = (Fin + 15) & ~15;
   const int ntiles = (Fin + 15) >> 4;
+  // shared by the workgroup: the chunk images;  per strip: everything else
+  float* G1s = smem_all;                // [CH][ldf]  g_1 rows of the chunk
+  float* X0s = G1s + CH * ldf;          // [CH][ldf]  X_0 rows of the chunk (paper)
+  const int strip_floats = 3 * SH * CHP + 2 * SH * ldf + 32;
+  float* smem = X0s + CH * ldf + sub * strip_floats;
   float* Ls = smem;                     // [16][CHP]  L chunk
-  float* G1s = Ls + SH * CHP;           // [CH][ldf]  g_1 rows of the chunk
-  float* red = G1s + CH * ldf;          // 32
+  float* red = Ls + SH * CHP;           // 32
   float* T = red + 32;                  // [16][CHP]  dL row strip        (paper)
   float* Cc = T + SH * CHP;             // [16][CHP]  dL column strip^T   (paper)
   float* gI = Cc + SH * CHP;            // [16][ldf]  g_1 rows of the slab (paper)
   float* xI = gI + SH * ldf;            // [16][ldf]  X_0 rows of the slab (paper)
-  float* X0s = xI + SH * ldf;           // [CH][ldf]  X_0 rows of the chunk (paper)
   const float alpha = a.alpha[0];
   const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
   const float* g1 = a.ws_g + (int64_t)c.row0 * Fin;   // adjoint of X_1 (K = 2: plane 0)
@@ -437,8 +449,13 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
     csr_p1 = a.L0_rowptr[c.row0 + c.i0 + tid + 1];
   }
   if (paper) {
-    stage_rows_img(gI, ldf, g1 + (int64_t)c.i0 * Fin, Fin, c.nr, SH, F16 <= Fin ? Fin : Fin);
-    stage_rows_img(xI, ldf, Xg + (int64_t)c.i0 * a.ldx, a.ldx, c.nr, SH, Fin);
+    // (stage_rows_img works with every thread of the workgroup: one strip's images after the other)
+    for (int sb = 0; sb < Q; ++sb) {
+      const SlabCtx cs = Q == 1 ? c : slab_ctx(a, (int)blockIdx.x * Q + sb);
+      float* base = X0s + CH * ldf + sb * strip_floats + 3 * SH * CHP + 32;
+      stage_rows_img(base, ldf, g1 + (int64_t)cs.i0 * Fin, Fin, cs.nr, SH, Fin);
+      stage_rows_img(base + SH * ldf, ldf, Xg + (int64_t)cs.i0 * a.ldx, a.ldx, cs.nr, SH, Fin);
+    }
     // columns round4(Fin)..F16 of the A images must be zero as well
     for (int idx = tid; idx < SH * (F16 - round4(Fin)); idx += 256) {
       const int w = F16 - round4(Fin), i = idx / w, f = round4(Fin) + idx - i * w;
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
     stage_rows_img(G1s, ldf, g1 + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
     if (paper) {
       stage_rows_img(X0s, ldf, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
-      for (int idx = tid; idx < CH * (F16 - round4(Fin)); idx += 256) {
+      for (int idx = threadIdx.x; idx < CH * (F16 - round4(Fin)); idx += 256 * Q) {
         const int w = F16 - round4(Fin), i = idx / w, f = round4(Fin) + idx - i * w;
         G1s[i * ldf + f] = 0.f;
         X0s[i * ldf + f] = 0.f;
@@ -553,10 +570,14 @@ __global__ __launch_bounds__(256) void slab_bwd1_kernel(SgcArgs a) {
       }
     }
   }
-  const float da = block_sum(dalpha_part, red);
+  float da = wave_allsum(dalpha_part);      // the strip's four waves, in wave order
+  __syncthreads();
+  if (lane == 0) red[wave] = da;
+  __syncthreads();
+  da = (red[0] + red[1]) + (red[2] + red[3]);
   if (tid == 0) {
-    a.ws_pg[2 * (a.pg_slab_base + blockIdx.x) + 0] = da;
-    a.ws_pg[2 * (a.pg_slab_base + blockIdx.x) + 1] = 0.f;
+    a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = da;
+    a.ws_pg[2 * (a.pg_slab_base + slab) + 1] = 0.f;
     if (a.pg_slab_base > 0 && c.i0 == 0) {   // mixed dispatch: this graph's per-graph slot stays 0
       a.ws_pg[2 * c.b + 0] = 0.f;
       a.ws_pg[2 * c.b + 1] = 0.f;
@@ -1007,11 +1028,10 @@ size_t lds_lap(int Fin) {
   const size_t strips = 2 * (size_t)SH * ld_frag((Fin + 15) & ~15);   // X_0 / X_1 images of the fused filter product
   return sizeof(float) * std::max((size_t)SH * CHP + (size_t)CH * ld_b(Fin), strips);
 }
-size_t lds_bwd1(int Fin, bool paper) {
+size_t lds_bwd1(int Fin, bool paper, int Q = 1) {
+  (void)paper;
   const size_t ldf = ld_frag((Fin + 15) & ~15);
-  size_t f = (size_t)SH * CHP + (size_t)CH * ldf + 32;
-  if (paper) f += 2 * (size_t)SH * CHP + 2 * (size_t)SH * ldf + (size_t)CH * ldf;
-  return sizeof(float) * f;
+  return sizeof(float) * (2 * (size_t)CH * ldf + (size_t)Q * (3 * (size_t)SH * CHP + 2 * (size_t)SH * ldf + 32));
 }
 size_t lds_bwd2(int Fin) {
   const size_t img = std::max((size_t)CH * ld_b(Fin), (size_t)SH * ld_frag((Fin + 15) & ~15));   // chunk rows / dZ image
@@ -1019,7 +1039,7 @@ size_t lds_bwd2(int Fin) {
 }
 
 template <class K>
-int launch_slab(K kernel, const SgcArgs& a, size_t lds, int prof_id, const char* what, void* stream) {
+int launch_slab(K kernel, const SgcArgs& a, size_t lds, int prof_id, const char* what, void* stream, int Q = 1) {
   if (a.n_slabs <= 0) return AGCN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (lds > 64 * 1024) {
@@ -1027,7 +1047,7 @@ int launch_slab(K kernel, const SgcArgs& a, size_t lds, int prof_id, const char*
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
   }
   prof_begin(prof_id, stream);
-  hipLaunchKernelGGL(kernel, dim3(a.n_slabs), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kernel, dim3(a.n_slabs / Q), dim3(256 * Q), lds, s, a);
   prof_end(stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s launch: %s", what, hipGetErrorString(e));
@@ -1063,7 +1083,15 @@ int launch_slab_backward(const SgcArgs& a, void* stream) {
     if (rc != AGCN_OK || !paper) return rc;
     return launch_slab(slab_bwd2_small_kernel, a, 0, PK_SLAB_BWD2, "slab_bwd2_small", stream);
   }
-  int rc = launch_slab(slab_bwd1_kernel, a, lds_bwd1(a.Fin, paper), PK_SLAB_BWD1, "slab_bwd1", stream);
+  // four strips per workgroup where every graph is a multiple of 64 rows (the point clouds): the chunk rows of g_1 / X_0
+  // are staged once for the four
+  static const int q_env = [] { const char* e = std::getenv("AGCN_SLAB_QUAD"); return e ? std::atoi(e) : 2; }();
+  int Q = (a.slab_quad != 0 && a.L0_dense != nullptr) ? q_env : 1;
+  if (Q != 2 && Q != 4) Q = 1;
+  if (a.n_slabs % Q != 0 || lds_bwd1(a.Fin, paper, Q) > 160 * 1024) Q = 1;
+  int rc = Q == 4 ? launch_slab(slab_bwd1_kernel_t<4>, a, lds_bwd1(a.Fin, paper, 4), PK_SLAB_BWD1, "slab_bwd1 x4", stream, 4)
+         : Q == 2 ? launch_slab(slab_bwd1_kernel_t<2>, a, lds_bwd1(a.Fin, paper, 2), PK_SLAB_BWD1, "slab_bwd1 x2", stream, 2)
+                  : launch_slab(slab_bwd1_kernel_t<1>, a, lds_bwd1(a.Fin, paper), PK_SLAB_BWD1, "slab_bwd1", stream);
   if (rc != AGCN_OK || !paper) return rc;
   return launch_slab(slab_bwd2_kernel, a, lds_bwd2(a.Fin), PK_SLAB_BWD2, "slab_bwd2", stream);
 }
