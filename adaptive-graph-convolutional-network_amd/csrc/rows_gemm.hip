@@ -269,7 +269,13 @@ static int launch_ntw(RowsGemmArgs a, int gy, int nt, int threads, hipStream_t s
 
 template <int MODE>
 static int launch_mode(const RowsGemmArgs& a, hipStream_t s) {
-  const int threads = NTHR;
+  // 16 waves stage the operands fastest, but only 4 * (column tiles) of them have an output tile: a product of many
+  // rows with one or two column tiles (the point-cloud layers: N = K * Fin = 6, Fin = 3) runs as more, smaller workgroups
+  const int nt_all = (a.N + 15) / 16;
+  static const int thr_env = [] { const char* e = std::getenv("AGCN_RG_THREADS"); return e ? std::atoi(e) : 0; }();
+  int threads = NTHR;
+  if (a.rows >= 16384 && nt_all <= 2) threads = 512;
+  if (thr_env == 256 || thr_env == 512 || thr_env == 1024) threads = thr_env;
   const int ncg = threads / 256;
   // split N into gy column blocks: at most 3 tiles per wave, and enough blocks that the grid
   // covers the chip (few rows => narrow blocks; the A image is then re-staged from L2 by each)

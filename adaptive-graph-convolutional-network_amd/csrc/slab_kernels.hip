@@ -50,6 +50,19 @@ __device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a, int s) {
 }
 __device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a) { return slab_ctx(a, (int)blockIdx.x); }
 
+// Per-pair transcendental functions of the general slab kernels.  AGCN_SLAB_FAST (default 1): the hardware
+// sqrt / exp2 / rcp instructions (1 ulp each, as the specialised per-graph kernels, spec_kernels.h) instead of the
+// ~45-instruction library sequences -- the pairwise phases are bound by instruction issue.  The backward rebuilds S
+// from r with the SAME function the forward used.
+#ifndef AGCN_SLAB_FAST
+#define AGCN_SLAB_FAST 1
+#endif
+__device__ __forceinline__ float slab_sqrt(float x) { return AGCN_SLAB_FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+__device__ __forceinline__ float slab_exp_neg(float r) {
+  return AGCN_SLAB_FAST ? __builtin_amdgcn_exp2f(r * -1.44269504088896341f) : expf(-r);
+}
+__device__ __forceinline__ float slab_div(float x, float r) { return AGCN_SLAB_FAST ? x * __builtin_amdgcn_rcpf(r) : x / r; }
+
 // wave-wide sum, result in every lane (fixed xor tree)
 __device__ __forceinline__ float wave_allsum(float v) {
 #pragma unroll
@@ -122,9 +135,9 @@ __global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
       for (int dj = 0; dj < 2; ++dj) {
         const int jj = 2 * lane + dj, j = c0 + jj;
         if (il < c.nr && jj < nc) {
-          const float r = sqrtf(acc[di][dj]);
+          const float r = slab_sqrt(acc[di][dj]);
           // S_ii = 0 (graphconv.py:171-173); exp(-1 * norm) otherwise (:176-177)
-          const float sv = (i == j) ? 0.f : expf(-r);
+          const float sv = (i == j) ? 0.f : slab_exp_neg(r);
           a.res_W[c.toff + (int64_t)i * n + j] = sv;
           if (paper) a.sv_r[c.toff + (int64_t)i * n + j] = r;
           rs[di] += sv;
@@ -400,7 +413,7 @@ __device__ __forceinline__ void chunk_SR(const SlabCtx& c, const BChunkRegs& g, 
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
     const int i = c.i0 + 4 * wave + di;
-    S[di] = (!paper || i == j) ? 0.f : expf(-g.rv[di]);        // slab_sim's instruction
+    S[di] = (!paper || i == j) ? 0.f : slab_exp_neg(g.rv[di]);   // slab_sim's instruction
     R[di] = (i == j) ? 1.f : 0.f;
     if (paper) R[di] = R[di] - (si[di] * S[di]) * g.sj;        // slab_lap's instruction (R1 == R: clip scale 1)
   }
@@ -646,7 +659,7 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
         // dS_ij = dA_ij s_i s_j + dd_j ; dr_ij = -S_ij dS_ij  (and the transposed pair)
         const float dr_ij = -Sv[di] * (dA[di] * si[di] * sj + ddj);
         const float dr_ji = -Sv[di] * (dAt[di] * sj * si[di] + ddi[di]);
-        cij = (dr_ij + dr_ji) / rv[di];   // defined 0 where r_ij == 0 (duplicate atoms)
+        cij = slab_div(dr_ij + dr_ji, rv[di]);   // defined 0 where r_ij == 0 (duplicate atoms)
       }
       Cs[il * CHP + lane] = cij;
       cs[di] += cij;
@@ -701,50 +714,156 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Point-cloud first layer (Fin <= 4: xyz coordinates, dense L_orig, n = 1024): the feature contractions of the
-// backward have 3 terms -- staging 64-row images in LDS and running 16-wide MFMA k-steps (12 of 16 lanes of k padding)
-// between three barriers per 64-column chunk is what the general kernels above spend their time on.  These two
-// variants keep the slab rows' g_1 / X_0 / Z values in registers, take the chunk column's rows of g_1 / X_0 / Z with
-// plain coalesced loads, accumulate per lane and reduce ONCE at the end: no LDS image, no barrier inside the chunk
-// loop, and dA_ij / dA_ji (three-term dot products) are recomputed by the second kernel instead of being written
-// and read back: the only n x n traffic of the backward is r (twice) and L_orig (once).
-constexpr int SF = 4;   // padded small feature count
+// Point-cloud first layer (Fin <= 4: xyz coordinates, dense L_orig, n = 1024): the feature contractions have 3 terms --
+// staging 64-row images in LDS and running 16-wide MFMA k-steps (12 of 16 lanes of k padding) between three barriers
+// per 64-column chunk is what the general kernels above spend their time on.  These variants keep the slab rows'
+// g_1 / X_0 / Z values in registers, take the chunk column's rows of g_1 / X_0 / Z with plain coalesced loads, accumulate
+// per lane and reduce ONCE at the end: no LDS image, no barrier inside the chunk loop.  Nothing n x n crosses from the
+// forward to the backward and nothing from the first backward kernel to the second: r_ij, S_ij, R_ij and dA_ij / dA_ji
+// are REBUILT from the Z / g_1 / X_0 rows wherever they are needed, by the same helper functions (the same
+// instructions in the same order: the same bits in all four kernels, and S bit-symmetric).  The n x n traffic is what
+// the layer's interface demands: res_W written once, res_L written once, L_orig read once per direction.
+// The kernels are bound by instruction issue after that (stamps + ISA counts), so the per-pair arithmetic
+// uses fused multiply-adds and the hardware sqrt / exp2 / rcp instructions (1 ulp each, as the specialised per-graph
+// kernels; exp(-r) = exp2(-r log2 e) carries a relative error of r * 6e-8) instead of the ~45-instruction library
+// sequences.  The feature count is a template constant (1..4): the dot products have exactly Fin terms and the
+// per-lane arrays exactly Fin registers.
+constexpr int SF_MAX = 4;
+#ifdef AGCN_SMALL_WAVES
+#define AGCN_SMALL_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(AGCN_SMALL_WAVES, AGCN_SMALL_WAVES)))
+#else
+#define AGCN_SMALL_WAVES_ATTR
+#endif
 
-struct SmallRegs { float rv[4], l0[4], sj, gj[SF], xj[SF]; };
+// r_ij: acc = fma(z_i[f] - z_j[f], z_i[f] - z_j[f], acc) for f = 0 .. Fin-1 (symmetric in i, j bit for bit)
+template <int SF>
+__device__ __forceinline__ float small_dist(const float (&zi)[SF], const float (&zj)[SF]) {
+  float acc = 0.f;
+#pragma unroll
+  for (int f = 0; f < SF; ++f) {
+    const float d = zi[f] - zj[f];
+    acc = __builtin_fmaf(d, d, acc);
+  }
+  return __builtin_amdgcn_sqrtf(acc);
+}
+// S_ij = exp(-r_ij) off the diagonal (graphconv.py:171-177)
+__device__ __forceinline__ float small_sim(float r, bool diag) {
+  return diag ? 0.f : __builtin_amdgcn_exp2f(r * -1.44269504088896341f);
+}
+template <int SF>
+__device__ __forceinline__ float small_dot(const float (&u)[SF], const float (&v)[SF]) {
+  float acc = u[0] * v[0];
+#pragma unroll
+  for (int f = 1; f < SF; ++f) acc = __builtin_fmaf(u[f], v[f], acc);
+  return acc;
+}
 
-// forward: R, res_L, L strip, X_1[I] = L[I, :] X_0 (three columns: per-lane partial sums, one reduction at the end) and
+template <int SF>
+struct SmallCol { float z[SF]; };
+
+// forward, first kernel: S strip -> res_W, degree -> s_i
+template <int SF>
+__global__ __launch_bounds__(256) void slab_sim_small_kernel(SgcArgs a) {
+  const SlabCtx c = slab_ctx(a);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int Fin = SF;
+  const int n = c.n;
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
+  float zI[4][SF];
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const int il = min(4 * wave + di, c.nr - 1);
+#pragma unroll
+    for (int f = 0; f < SF; ++f) zI[di][f] = Zg[(int64_t)(c.i0 + il) * Fin + f];
+  }
+  auto load_chunk = [&](int c0) {
+    SmallCol<SF> g;
+    const int jc = min(c0 + lane, n - 1);
+#pragma unroll
+    for (int f = 0; f < SF; ++f) g.z[f] = Zg[(int64_t)jc * Fin + f];
+    return g;
+  };
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  SmallCol<SF> cur = load_chunk(0);
+  for (int c0 = 0; c0 < n; c0 += CH) {
+    const SmallCol<SF> nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;
+    const int j = c0 + lane;
+    const bool cv = j < n;
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int il = 4 * wave + di, i = c.i0 + il;
+      const float S = small_sim(small_dist<SF>(zI[di], cur.z), i == j);
+      if (cv && il < c.nr) {
+        a.res_W[c.toff + (int64_t)i * n + j] = S;
+        rs[di] += S;
+      }
+    }
+    cur = nxt;
+  }
+  // degree of the slab's rows (S is bit-symmetric, so row sums == column sums), s = d^-1/2
+#pragma unroll
+  for (int di = 0; di < 4; ++di) {
+    const float d = wave_allsum(rs[di]) + FLT_TRUE_MIN;   // np.spacing(0), graphconv.py:196
+    const int il = 4 * wave + di;
+    if (lane == 0 && il < c.nr) a.sv_s[c.row0 + c.i0 + il] = 1.0f / sqrtf(d);
+  }
+  if (c.i0 + SH >= n) {   // alignment floats behind the tile stay 0; clip scale exactly 1 (as slab_sim_kernel)
+    const int nn = n * n, npadt = (int)(a.tile_off[c.b + 1] - c.toff) - nn;
+    if (tid < npadt) {
+      a.res_W[c.toff + nn + tid] = 0.f;
+      a.res_L[c.toff + nn + tid] = 0.f;
+      if (a.L_sum) a.L_sum[c.toff + nn + tid] = 0.f;
+    }
+    if (tid == 0) {
+      float* sc = a.sv_scal + 4 * c.b;
+      sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
+    }
+  }
+}
+
+// forward, second kernel: R, res_L, L strip, X_1[I] = L[I, :] X_0 (per-lane partial sums, one reduction at the end) and
 // the filter product of the slab's rows
+template <int SF>
 __global__ __launch_bounds__(256) void slab_lap_small_kernel(SgcArgs a) {
   constexpr int LDA = 18;                 // ld_frag(16)
   __shared__ float X0s[SH * LDA], X1s[SH * LDA];
   const SlabCtx c = slab_ctx(a);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int Fin = a.Fin, n = c.n;
+  constexpr int Fin = SF;
+  const int n = c.n;
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const float alpha = a.alpha[0];
   const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
   const float* L0d = a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff;
   const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
-  float si[4];
+  float si[4], zI[4][SF];
 #pragma unroll
-  for (int di = 0; di < 4; ++di) si[di] = a.sv_s[c.row0 + c.i0 + min(4 * wave + di, c.nr - 1)];
+  for (int di = 0; di < 4; ++di) {
+    const int il = min(4 * wave + di, c.nr - 1);
+    si[di] = a.sv_s[c.row0 + c.i0 + il];
+#pragma unroll
+    for (int f = 0; f < SF; ++f) zI[di][f] = paper ? Zg[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
+  }
   for (int e = tid; e < SH * LDA; e += 256) {
     const int ii = e / LDA, f = e - ii * LDA;
     X0s[e] = (ii < c.nr && f < Fin) ? Xg[(int64_t)(c.i0 + ii) * a.ldx + f] : 0.f;
     X1s[e] = 0.f;
   }
-  struct Regs { float v[4], l0[4], sj, xj[SF]; };
+  struct Regs { float l0[4], sj, xj[SF], zj[SF]; };
   auto load_chunk = [&](int c0) {
     Regs g;
     const int jc = min(c0 + lane, n - 1);
     g.sj = paper ? a.sv_s[c.row0 + jc] : 0.f;
 #pragma unroll
-    for (int f = 0; f < SF; ++f) g.xj[f] = f < Fin ? Xg[(int64_t)jc * a.ldx + f] : 0.f;
+    for (int f = 0; f < SF; ++f) {
+      g.xj[f] = Xg[(int64_t)jc * a.ldx + f];
+      g.zj[f] = paper ? Zg[(int64_t)jc * Fin + f] : 0.f;
+    }
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int i = min(c.i0 + 4 * wave + di, n - 1);
-      g.v[di] = paper ? a.res_W[c.toff + (int64_t)i * n + jc] : 0.f;
       g.l0[di] = L0d[(int64_t)i * l0ld + jc];
     }
     return g;
@@ -762,16 +881,16 @@ __global__ __launch_bounds__(256) void slab_lap_small_kernel(SgcArgs a) {
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int il = 4 * wave + di, i = c.i0 + il;
+      float R = (i == j) ? 1.f : 0.f;                               // reference: I - D*W*D elementwise == I
+      if (paper) R = R - (si[di] * small_sim(small_dist<SF>(zI[di], cur.zj), i == j)) * cur.sj;   // paper: I - s S s
+      const float L = lrelu(R, alpha);                               // (R * 1.0f: the clip scale is exactly 1)
+      const float Lt = L + cur.l0[di];
       if (cv && il < c.nr) {
-        float R = (i == j) ? 1.f : 0.f;                    // reference: I - D*W*D elementwise == I
-        if (paper) R = R - (si[di] * cur.v[di]) * cur.sj;   // paper: I - s S s
-        const float L = lrelu(R, alpha);                    // (R * 1.0f: the clip scale is exactly 1)
         const int64_t o = c.toff + (int64_t)i * n + j;
         a.res_L[o] = L;
-        const float Lt = L + cur.l0[di];
         if (a.L_sum) a.L_sum[o] = Lt;
 #pragma unroll
-        for (int f = 0; f < SF; ++f) accX[di][f] += Lt * cur.xj[f];
+        for (int f = 0; f < SF; ++f) accX[di][f] = __builtin_fmaf(Lt, cur.xj[f], accX[di][f]);
       }
     }
     cur = nxt;
@@ -784,7 +903,7 @@ __global__ __launch_bounds__(256) void slab_lap_small_kernel(SgcArgs a) {
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
       const float t = wave_allsum(accX[di][f]);
-      if (lane == 0 && il < c.nr && f < Fin) {
+      if (lane == 0 && il < c.nr) {
         X1s[il * LDA + f] = t;
         Xo[(int64_t)il * Fin + f] = t;
       }
@@ -816,41 +935,66 @@ __global__ __launch_bounds__(256) void slab_lap_small_kernel(SgcArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void slab_bwd1_small_kernel(SgcArgs a) {
+// The pair (i, j) of the backward, rebuilt: S, R and the two entries dA_ij, dA_ji of dA = -dR (R symmetric).
+struct SmallPair { float S, R, dL, dA, dAt; };
+template <int SF>
+__device__ __forceinline__ SmallPair small_pair(const float (&zi)[SF], const float (&gi)[SF], const float (&xi)[SF],
+                                                const float (&zj)[SF], const float (&gj)[SF], const float (&xj)[SF],
+                                                float si, float sj, float alpha, bool diag) {
+  SmallPair p;
+  p.S = small_sim(small_dist<SF>(zi, zj), diag);
+  p.R = (diag ? 1.f : 0.f) - (si * p.S) * sj;         // slab_lap_small's expression
+  p.dL = small_dot<SF>(gi, xj);                        // dL[i][j] = g_1[i] . X_0[j]
+  const float dLt = small_dot<SF>(xi, gj);             // dL[j][i] = g_1[j] . X_0[i]
+  const float nlg = -lrelu_grad(p.R, alpha);
+  p.dA = p.dL * nlg;
+  p.dAt = dLt * nlg;
+  return p;
+}
+
+template <int SF>
+struct SmallRegs { float l0[4], sj, gj[SF], xj[SF], zj[SF]; };
+
+// backward, first kernel: dX[I] += L[I, :] g_1, ds -> dd_i, dalpha partial
+template <int SF>
+__global__ __launch_bounds__(256) AGCN_SMALL_WAVES_ATTR void slab_bwd1_small_kernel(SgcArgs a) {
   __shared__ float red[32];
   const SlabCtx c = slab_ctx(a);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Fin = a.Fin, n = c.n;
+  constexpr int Fin = SF;
+  const int n = c.n;
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const float alpha = a.alpha[0];
   const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
   const float* g1 = a.ws_g + (int64_t)c.row0 * Fin;
   const float* L0d = a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff;
   const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
-  float si[4], gI[4][SF], xI[4][SF];
+  float si[4], gI[4][SF], xI[4][SF], zI[4][SF];
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
     const int il = min(4 * wave + di, c.nr - 1);
     si[di] = paper ? a.sv_s[c.row0 + c.i0 + il] : 0.f;
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
-      gI[di][f] = f < Fin ? g1[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
-      xI[di][f] = (paper && f < Fin) ? Xg[(int64_t)(c.i0 + il) * a.ldx + f] : 0.f;
+      gI[di][f] = g1[(int64_t)(c.i0 + il) * Fin + f];
+      xI[di][f] = paper ? Xg[(int64_t)(c.i0 + il) * a.ldx + f] : 0.f;
+      zI[di][f] = paper ? Zg[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
     }
   }
   auto load_chunk = [&](int c0) {
-    SmallRegs g;
+    SmallRegs<SF> g;
     const int jc = min(c0 + lane, n - 1);
     g.sj = paper ? a.sv_s[c.row0 + jc] : 0.f;
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
-      g.gj[f] = f < Fin ? g1[(int64_t)jc * Fin + f] : 0.f;
-      g.xj[f] = (paper && f < Fin) ? Xg[(int64_t)jc * a.ldx + f] : 0.f;
+      g.gj[f] = g1[(int64_t)jc * Fin + f];
+      g.xj[f] = paper ? Xg[(int64_t)jc * a.ldx + f] : 0.f;
+      g.zj[f] = paper ? Zg[(int64_t)jc * Fin + f] : 0.f;
     }
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int i = min(c.i0 + 4 * wave + di, n - 1);
-      g.rv[di] = paper ? a.sv_r[c.toff + (int64_t)i * n + jc] : 0.f;
       g.l0[di] = L0d[(int64_t)i * l0ld + jc];
     }
     return g;
@@ -861,32 +1005,28 @@ __global__ __launch_bounds__(256) void slab_bwd1_small_kernel(SgcArgs a) {
 #pragma unroll
     for (int f = 0; f < SF; ++f) accL[di][f] = 0.f;
   float dalpha_part = 0.f;
-  SmallRegs cur = load_chunk(0);
+  SmallRegs<SF> cur = load_chunk(0);
   for (int c0 = 0; c0 < n; c0 += CH) {
-    const SmallRegs nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;   // next chunk's loads in flight
+    const SmallRegs<SF> nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;   // next chunk's loads in flight
     const int j = c0 + lane;
     const bool cv = j < n;
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int il = 4 * wave + di, i = c.i0 + il;
-      if (cv && il < c.nr) {
-        const float S = (!paper || i == j) ? 0.f : expf(-cur.rv[di]);      // slab_sim's instruction
-        float R = (i == j) ? 1.f : 0.f;
-        if (paper) R = R - (si[di] * S) * cur.sj;                            // slab_lap's instruction
-        const float L = lrelu(R, alpha) + cur.l0[di];
-        float dL = 0.f, dLt = 0.f;
+      const bool ok = cv && il < c.nr;
+      if (paper) {
+        const SmallPair p = small_pair<SF>(zI[di], gI[di], xI[di], cur.zj, cur.gj, cur.xj, si[di], cur.sj, alpha, i == j);
+        const float L = ok ? lrelu(p.R, alpha) + cur.l0[di] : 0.f;
 #pragma unroll
-        for (int f = 0; f < SF; ++f) {
-          accL[di][f] += L * cur.gj[f];                                      // dX[I] += L[I, :] g_1
-          dL += gI[di][f] * cur.xj[f];                                       // dL[i][j] = g_1[i] . X_0[j]
-          dLt += xI[di][f] * cur.gj[f];                                      // dL[j][i] = g_1[j] . X_0[i]
+        for (int f = 0; f < SF; ++f) accL[di][f] = __builtin_fmaf(L, cur.gj[f], accL[di][f]);   // dX[I] += L[I, :] g_1
+        if (ok) {
+          dalpha_part = __builtin_fmaf(p.dL, fminf(p.R, 0.f), dalpha_part);
+          ds[di] = __builtin_fmaf((p.dA + p.dAt) * p.S, cur.sj, ds[di]);
         }
-        if (paper) {
-          const float lg = lrelu_grad(R, alpha);
-          dalpha_part += dL * fminf(R, 0.f);
-          const float dA = -(dL * lg), dAt = -(dLt * lg);                    // dA_ij, dA_ji (R symmetric)
-          ds[di] += (dA * S) * cur.sj + (dAt * S) * cur.sj;     // (nothing n x n is stored: slab_bwd2_small recomputes dA)
-        }
+      } else {
+        const float L = ok ? ((i == j) ? 1.f : 0.f) + cur.l0[di] : 0.f;   // lrelu(I) = I
+#pragma unroll
+        for (int f = 0; f < SF; ++f) accL[di][f] = __builtin_fmaf(L, cur.gj[f], accL[di][f]);
       }
     }
     cur = nxt;
@@ -898,7 +1038,7 @@ __global__ __launch_bounds__(256) void slab_bwd1_small_kernel(SgcArgs a) {
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
       const float t = wave_allsum(accL[di][f]);
-      if (lane == 0 && il < c.nr && f < Fin) dXg[(int64_t)il * a.ldx + f] += t;   // (g_0 is there already)
+      if (lane == 0 && il < c.nr) dXg[(int64_t)il * a.ldx + f] += t;   // (g_0 is there already)
     }
     if (paper) {
       const float t = wave_allsum(ds[di]);
@@ -916,15 +1056,19 @@ __global__ __launch_bounds__(256) void slab_bwd1_small_kernel(SgcArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void slab_bwd2_small_kernel(SgcArgs a) {
+// backward, second kernel (paper mode): c strip = (dr_ij + dr_ji) / r_ij, dZ[I] = rowsum(c) Z[I] - c Z,
+// dX[I] += dZ[I] M_L^T
+template <int SF>
+__global__ __launch_bounds__(256) AGCN_SMALL_WAVES_ATTR void slab_bwd2_small_kernel(SgcArgs a) {
   const SlabCtx c = slab_ctx(a);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Fin = a.Fin, n = c.n;
+  constexpr int Fin = SF;
+  const int n = c.n;
   const float alpha = a.alpha[0];
   const float* Zg = a.sv_Z + (int64_t)c.row0 * Fin;
   const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
   const float* g1 = a.ws_g + (int64_t)c.row0 * Fin;
-  float si[4], ddi[4], gI[4][SF], xI[4][SF];
+  float si[4], ddi[4], gI[4][SF], xI[4][SF], zI[4][SF];
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
     const int il = min(4 * wave + di, c.nr - 1);
@@ -933,13 +1077,12 @@ __global__ __launch_bounds__(256) void slab_bwd2_small_kernel(SgcArgs a) {
     ddi[di] = a.ws_dd[row];
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
-      gI[di][f] = f < Fin ? g1[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
-      xI[di][f] = f < Fin ? Xg[(int64_t)(c.i0 + il) * a.ldx + f] : 0.f;
+      gI[di][f] = g1[(int64_t)(c.i0 + il) * Fin + f];
+      xI[di][f] = Xg[(int64_t)(c.i0 + il) * a.ldx + f];
+      zI[di][f] = Zg[(int64_t)(c.i0 + il) * Fin + f];
     }
   }
-  // dA_ij / dA_ji are recomputed exactly as slab_bwd1_small computed them (three-term dot products, the same
-  // expressions: the same bits): the only n x n read is r
-  struct Regs { float sj, ddj, rv[4], zj[SF], gj[SF], xj[SF]; };
+  struct Regs { float sj, ddj, zj[SF], gj[SF], xj[SF]; };
   auto load_chunk = [&](int c0) {
     Regs g;
     const int jc = min(c0 + lane, n - 1);
@@ -947,14 +1090,9 @@ __global__ __launch_bounds__(256) void slab_bwd2_small_kernel(SgcArgs a) {
     g.ddj = a.ws_dd[c.row0 + jc];
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
-      g.zj[f] = f < Fin ? Zg[(int64_t)jc * Fin + f] : 0.f;
-      g.gj[f] = f < Fin ? g1[(int64_t)jc * Fin + f] : 0.f;
-      g.xj[f] = f < Fin ? Xg[(int64_t)jc * a.ldx + f] : 0.f;
-    }
-#pragma unroll
-    for (int di = 0; di < 4; ++di) {
-      const int i = c.i0 + min(4 * wave + di, c.nr - 1);
-      g.rv[di] = a.sv_r[c.toff + (int64_t)i * n + jc];
+      g.zj[f] = Zg[(int64_t)jc * Fin + f];
+      g.gj[f] = g1[(int64_t)jc * Fin + f];
+      g.xj[f] = Xg[(int64_t)jc * a.ldx + f];
     }
     return g;
   };
@@ -971,26 +1109,16 @@ __global__ __launch_bounds__(256) void slab_bwd2_small_kernel(SgcArgs a) {
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int il = 4 * wave + di, i = c.i0 + il;
-      if (cv && il < c.nr && i != j && cur.rv[di] > 0.f) {
-        const float S = expf(-cur.rv[di]);
-        if (S != 0.f) {                                                      // S == 0 (underflow): dr = 0, never inf * 0
-          const float R = -((si[di] * S) * cur.sj);                         // (i != j)
-          const float lg = lrelu_grad(R, alpha);
-          float dL = 0.f, dLt = 0.f;
+      const float rij = small_dist<SF>(zI[di], cur.zj);
+      const SmallPair p = small_pair<SF>(zI[di], gI[di], xI[di], cur.zj, cur.gj, cur.xj, si[di], cur.sj, alpha, i == j);
+      const float dr_ij = -p.S * __builtin_fmaf(p.dA * si[di], cur.sj, cur.ddj);
+      const float dr_ji = -p.S * __builtin_fmaf(p.dAt * cur.sj, si[di], ddi[di]);
+      // r == 0 (coincident points): the term is defined as 0; S == 0 (underflow): dr = 0, never inf * 0
+      const bool ok = cv && il < c.nr && i != j && rij > 0.f && p.S != 0.f;
+      const float cij = ok ? (dr_ij + dr_ji) * __builtin_amdgcn_rcpf(rij) : 0.f;
+      cs[di] += cij;
 #pragma unroll
-          for (int f = 0; f < SF; ++f) {
-            dL += gI[di][f] * cur.xj[f];
-            dLt += xI[di][f] * cur.gj[f];
-          }
-          const float dA = -(dL * lg), dAt = -(dLt * lg);
-          const float dr_ij = -S * (dA * si[di] * cur.sj + cur.ddj);
-          const float dr_ji = -S * (dAt * cur.sj * si[di] + ddi[di]);
-          const float cij = (dr_ij + dr_ji) / cur.rv[di];
-          cs[di] += cij;
-#pragma unroll
-          for (int f = 0; f < SF; ++f) accZ[di][f] += cij * cur.zj[f];
-        }
-      }
+      for (int f = 0; f < SF; ++f) accZ[di][f] = __builtin_fmaf(cij, cur.zj[f], accZ[di][f]);
     }
     cur = nxt;
   }
@@ -1005,15 +1133,14 @@ __global__ __launch_bounds__(256) void slab_bwd2_small_kernel(SgcArgs a) {
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
       const float t = wave_allsum(accZ[di][f]);
-      const float zi = (il < c.nr && f < Fin) ? Zg[(int64_t)(c.i0 + il) * Fin + f] : 0.f;
-      dz[f] = (il < c.nr && f < Fin) ? csum * zi - t : 0.f;
+      dz[f] = il < c.nr ? csum * zI[di][f] - t : 0.f;
     }
     if (il < c.nr && lane < Fin) {
       float dzl = 0.f, dx = 0.f;
 #pragma unroll
       for (int f = 0; f < SF; ++f) {
         if (f == lane) dzl = dz[f];
-        if (f < Fin) dx += dz[f] * a.M_L[(int64_t)lane * Fin + f];           // (dZ M_L^T)[lane] = sum_f dZ[f] M_L[lane][f]
+        dx += dz[f] * a.M_L[(int64_t)lane * Fin + f];           // (dZ M_L^T)[lane] = sum_f dZ[f] M_L[lane][f]
       }
       dZg[(int64_t)il * Fin + lane] = dzl;
       dXg[(int64_t)il * a.ldx + lane] += dx;
@@ -1064,24 +1191,52 @@ static bool slab_small_env() {
   static const int off = [] { const char* e = std::getenv("AGCN_SLAB_SMALL"); return (e && e[0] == '0') ? 1 : 0; }();
   return !off;
 }
+// the forward and the backward must agree on this (the small-feature forward leaves no r tiles behind)
+bool slab_small_features(const SgcArgs& a) {
+  return slab_small_env() && a.Fin <= SF_MAX && a.L0_dense != nullptr && a.K == 2;
+}
+
 int launch_slab_forward(const SgcArgs& a, void* stream) {
+  if (slab_small_features(a)) {   // point-cloud first layer: streaming variants, nothing n x n left for the backward
+    int rc;
+    switch (a.Fin) {
+      case 1: rc = launch_slab(slab_sim_small_kernel<1>, a, 0, PK_SLAB_SIM, "slab_sim_small", stream); break;
+      case 2: rc = launch_slab(slab_sim_small_kernel<2>, a, 0, PK_SLAB_SIM, "slab_sim_small", stream); break;
+      case 3: rc = launch_slab(slab_sim_small_kernel<3>, a, 0, PK_SLAB_SIM, "slab_sim_small", stream); break;
+      default: rc = launch_slab(slab_sim_small_kernel<4>, a, 0, PK_SLAB_SIM, "slab_sim_small", stream); break;
+    }
+    if (rc != AGCN_OK) return rc;
+    switch (a.Fin) {
+      case 1: return launch_slab(slab_lap_small_kernel<1>, a, 0, PK_SLAB_LAP, "slab_lap_small", stream);
+      case 2: return launch_slab(slab_lap_small_kernel<2>, a, 0, PK_SLAB_LAP, "slab_lap_small", stream);
+      case 3: return launch_slab(slab_lap_small_kernel<3>, a, 0, PK_SLAB_LAP, "slab_lap_small", stream);
+      default: return launch_slab(slab_lap_small_kernel<4>, a, 0, PK_SLAB_LAP, "slab_lap_small", stream);
+    }
+  }
   int rc = launch_slab(slab_sim_kernel, a, lds_sim(a.Fin), PK_SLAB_SIM, "slab_sim", stream);
   if (rc != AGCN_OK) return rc;
-  if (a.Fin <= SF && a.L0_dense != nullptr && a.K == 2 && slab_small_env())
-    return launch_slab(slab_lap_small_kernel, a, 0, PK_SLAB_LAP, "slab_lap_small", stream);
   return launch_slab(slab_lap_kernel, a, lds_lap(a.Fin), PK_SLAB_LAP, "slab_lap", stream);
 }
 
-bool slab_small_features(const SgcArgs& a) {
-  return slab_small_env() && a.Fin <= SF && a.L0_dense != nullptr && a.dL_sum == nullptr;
-}
 
 int launch_slab_backward(const SgcArgs& a, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
   if (slab_small_features(a)) {   // point-cloud first layer: streaming variants (no LDS images, no chunk barriers)
-    int rc = launch_slab(slab_bwd1_small_kernel, a, 0, PK_SLAB_BWD1, "slab_bwd1_small", stream);
+    if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "slab path: a gradient of L_sum is not supported (SGC_LL only)");
+    int rc;
+    switch (a.Fin) {
+      case 1: rc = launch_slab(slab_bwd1_small_kernel<1>, a, 0, PK_SLAB_BWD1, "slab_bwd1_small", stream); break;
+      case 2: rc = launch_slab(slab_bwd1_small_kernel<2>, a, 0, PK_SLAB_BWD1, "slab_bwd1_small", stream); break;
+      case 3: rc = launch_slab(slab_bwd1_small_kernel<3>, a, 0, PK_SLAB_BWD1, "slab_bwd1_small", stream); break;
+      default: rc = launch_slab(slab_bwd1_small_kernel<4>, a, 0, PK_SLAB_BWD1, "slab_bwd1_small", stream); break;
+    }
     if (rc != AGCN_OK || !paper) return rc;
-    return launch_slab(slab_bwd2_small_kernel, a, 0, PK_SLAB_BWD2, "slab_bwd2_small", stream);
+    switch (a.Fin) {
+      case 1: return launch_slab(slab_bwd2_small_kernel<1>, a, 0, PK_SLAB_BWD2, "slab_bwd2_small", stream);
+      case 2: return launch_slab(slab_bwd2_small_kernel<2>, a, 0, PK_SLAB_BWD2, "slab_bwd2_small", stream);
+      case 3: return launch_slab(slab_bwd2_small_kernel<3>, a, 0, PK_SLAB_BWD2, "slab_bwd2_small", stream);
+      default: return launch_slab(slab_bwd2_small_kernel<4>, a, 0, PK_SLAB_BWD2, "slab_bwd2_small", stream);
+    }
   }
   // four strips per workgroup where every graph is a multiple of 64 rows (the point clouds): the chunk rows of g_1 / X_0
   // are staged once for the four
