@@ -17,6 +17,8 @@
 // (16 rows) and the column tiles cg, cg+4, cg+8.  A image ld = 2|14 mod 16, B image ld = 16 mod 32:
 // conflict-free fragment reads.
 // v_mfma_f32_16x16x4_f32 keeps exact fp32 fmaf-chain semantics.
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "agcn_device.h"
@@ -293,8 +295,151 @@ static int launch_mode(const RowsGemmArgs& a, hipStream_t s) {
   return launch_ntw<MODE, 3>(a, gy, nt, threads, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Narrow products of MANY rows (the point-cloud first layer: Fin = 3, K * Fin = 6 columns, 32 x 1024 rows).  The
+// 64-row MFMA workgroups above spend their time staging a [64 x Fout] image for one sixteen-wide column tile of which
+// six columns are real; these two kernels stream the rows instead (one pass over dY / Y / Gp resp. X at full width).
+
+// RG_FILTER_BWD with N = K * Fin <= 8, packed rows: sixteen lanes per row (four rows per wave instruction), each lane
+// four consecutive k of a 64-wide pass (float4 loads of dY and Y, float4 store of Gp), the W^T rows in registers,
+// partial dot products reduced over the sixteen lanes by a fixed xor tree.
+template <int NC, int PASSES>
+__global__ __launch_bounds__(256) void rows_filter_bwd_narrow_kernel(RowsGemmArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l16 = lane & 15, sub = lane >> 4;
+  const int Fout = a.Fout, K = a.K, Fin = a.Fin;
+  const bool relu = a.activation == AGCN_ACT_RELU;
+  if (blockIdx.x == 0)
+    for (int e = tid; e < a.zero_count; e += 256) a.zero_ptr[e] = 0;
+  f32x4 w[PASSES][NC];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int k = 64 * p + 4 * l16;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      w[p][c] = (k < Fout && c < a.N) ? *reinterpret_cast<const f32x4*>(a.Bm + (int64_t)c * Fout + k)
+                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float scale = a.scale ? a.scale[0] : 1.f;
+  const int rows_per_wg = 16, wave = tid >> 6;
+  for (int base = blockIdx.x * rows_per_wg; base < a.rows; base += gridDim.x * rows_per_wg) {
+    const int row = base + 4 * wave + sub;
+    const int rc = min(row, a.rows - 1);
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int k = 64 * p + 4 * l16;
+      if (k < Fout) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.A0 + (int64_t)rc * a.lda0 + k);
+        f32x4 v = g;
+        if (relu) {
+          const f32x4 y = *reinterpret_cast<const f32x4*>(a.Yact + (int64_t)rc * a.ldy + k);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = y[u] > 0.f ? g[u] : 0.f;
+        }
+        if (row < a.rows) *reinterpret_cast<f32x4*>(a.Gp + (int64_t)row * Fout + k) = v;   // masked upstream gradient
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[c] = __builtin_fmaf(v[u], w[p][c][u], acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+    // lane c of the sixteen writes column c = f * K + k: the adjoint of X_k[:, f]
+    float mine = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) mine = (l16 == c) ? acc[c] : mine;
+    if (row < a.rows && l16 < a.N) {
+      const int f = l16 / K, kx = l16 - f * K;
+      const float v = mine * scale;
+      if (kx == 0) a.Out0[(int64_t)row * a.ldo0 + f] = v;
+      else a.Out1[(int64_t)(kx - 1) * a.o1_plane + (int64_t)row * Fin + f] = v;
+    }
+  }
+}
+
+// RG_PROJECT with Fin <= 4, packed rows: one thread per row, M_L in registers
+template <int FIN>
+__global__ __launch_bounds__(256) void rows_project_narrow_kernel(RowsGemmArgs a) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  float m[FIN][FIN];
+#pragma unroll
+  for (int k = 0; k < FIN; ++k)
+#pragma unroll
+    for (int c = 0; c < FIN; ++c) m[k][c] = a.Bm[k * FIN + c];
+  if (row >= a.rows) return;
+  float x[FIN];
+#pragma unroll
+  for (int k = 0; k < FIN; ++k) x[k] = a.A0[(int64_t)row * a.lda0 + k];
+#pragma unroll
+  for (int c = 0; c < FIN; ++c) {
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < FIN; ++k) z = __builtin_fmaf(x[k], m[k][c], z);   // the MFMA's k-ascending fmaf chain
+    a.Out0[(int64_t)row * a.ldo0 + c] = z;
+  }
+}
+
+static bool narrow_env() {
+  static const int off = [] { const char* e = std::getenv("AGCN_ROWS_NARROW"); return (e && e[0] == '0') ? 1 : 0; }();
+  return !off;
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <class Kern>
+static int launch_narrow(Kern kernel, const RowsGemmArgs& a, int grid, int prof_id, hipStream_t s) {
+  prof_begin(prof_id, s);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, a);
+  prof_end(s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "rows_gemm (narrow) launch: %s", hipGetErrorString(e));
+  return AGCN_OK;
+}
+
+// returns 1 if the product was launched by a narrow kernel, 0 if the general kernel must take it, < 0 on error
+static int try_narrow(const RowsGemmArgs& a, int mode, hipStream_t s) {
+  if (!narrow_env() || a.row_stride != 0 || a.big_n != 0 || a.rows < 1024) return 0;
+  if (mode == RG_PROJECT && a.Kd == a.N && a.N == a.Fin && a.Fin <= 4) {
+    const int grid = (a.rows + 255) / 256;
+    int rc;
+    switch (a.Fin) {
+      case 1: rc = launch_narrow(rows_project_narrow_kernel<1>, a, grid, PK_PROJECT, s); break;
+      case 2: rc = launch_narrow(rows_project_narrow_kernel<2>, a, grid, PK_PROJECT, s); break;
+      case 3: rc = launch_narrow(rows_project_narrow_kernel<3>, a, grid, PK_PROJECT, s); break;
+      default: rc = launch_narrow(rows_project_narrow_kernel<4>, a, grid, PK_PROJECT, s); break;
+    }
+    return rc == AGCN_OK ? 1 : rc;
+  }
+  if (mode == RG_FILTER_BWD && a.N <= 8 && a.Kd == a.Fout && (a.Fout & 3) == 0 && a.Fout <= 256 && (a.lda0 & 3) == 0 &&
+      (a.ldy & 3) == 0 && aligned16(a.A0) && aligned16(a.Yact) && aligned16(a.Gp) && aligned16(a.Bm) && a.Gp != nullptr) {
+    const int grid = std::min((a.rows + 15) / 16, 2048);
+    const int passes = (a.Fout + 63) / 64;
+    int rc;
+    if (a.N <= 4) {
+      rc = passes == 1 ? launch_narrow(rows_filter_bwd_narrow_kernel<4, 1>, a, grid, PK_FILTER_BWD, s)
+         : passes == 2 ? launch_narrow(rows_filter_bwd_narrow_kernel<4, 2>, a, grid, PK_FILTER_BWD, s)
+                       : launch_narrow(rows_filter_bwd_narrow_kernel<4, 4>, a, grid, PK_FILTER_BWD, s);
+    } else {
+      rc = passes == 1 ? launch_narrow(rows_filter_bwd_narrow_kernel<8, 1>, a, grid, PK_FILTER_BWD, s)
+         : passes == 2 ? launch_narrow(rows_filter_bwd_narrow_kernel<8, 2>, a, grid, PK_FILTER_BWD, s)
+                       : launch_narrow(rows_filter_bwd_narrow_kernel<8, 4>, a, grid, PK_FILTER_BWD, s);
+    }
+    return rc == AGCN_OK ? 1 : rc;
+  }
+  return 0;
+}
+
 int launch_rows_gemm(const RowsGemmArgs& a, int mode, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    const int nr = try_narrow(a, mode, s);
+    if (nr != 0) return nr > 0 ? AGCN_OK : nr;
+  }
   switch (mode) {
     case RG_PROJECT: return launch_mode<RG_PROJECT>(a, s);
     case RG_FILTER: return launch_mode<RG_FILTER>(a, s);

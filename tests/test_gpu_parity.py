@@ -976,6 +976,62 @@ def test_modelnet_shaped_dense_adjacency(amd, symmetric):
     assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L n=1024", atol_ulps=GRAD_ULPS * k)
 
 
+@pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
+@pytest.mark.parametrize("Fin,Fout", [(3, 64), (2, 32), (4, 128), (1, 16)])
+def test_point_cloud_batch_streaming_kernels(amd, mode, Fin, Fout):
+    """A ragged batch of point clouds (Fin <= 4, dense symmetric L_orig): the streaming small-feature slab kernels
+    (slab_kernels.hip: nothing n x n kept for the backward, r / S / R / dA rebuilt from the Z rows) and, from 1024
+    packed rows on, the narrow row kernels (rows_gemm.hip).  Sizes are not multiples of the 16-row strips or the
+    64-column chunks.  Every output and gradient against the float64 oracle."""
+    K = 2
+    sizes = [300, 257, 519, 131]
+    rs = np.random.RandomState(100 + Fin)
+    Xs, Ls, Gs = [], [], []
+    for n in sizes:
+        pts = rs.uniform(-1, 1, size=(n, Fin)).astype(np.float32)
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        A = (d < 0.6 * d.mean()).astype(np.float64)
+        np.fill_diagonal(A, 0)
+        adj = [list(np.nonzero(A[i])[0]) for i in range(n)]
+        _, _, _, L = orc.graph_laplacian(adj)
+        Xs.append(pts); Ls.append(L.astype(np.float32)); Gs.append(rs.randn(n, Fout).astype(np.float32))
+    Xs[1][5] = Xs[1][4]                                      # coincident points: r_ij = 0 off the diagonal
+    p = orc.init_params(rs, Fin, Fout, K)
+    plan = amd.Plan(sizes, 0, DEV)
+    tile_off = plan.tile_off                                 # tiles are padded to the plan's alignment
+    l0_host = np.zeros(int(tile_off[-1]), np.float32)
+    for b, L in enumerate(Ls):
+        l0_host[int(tile_off[b]):int(tile_off[b]) + L.size] = L.reshape(-1)
+    l0 = torch.from_numpy(l0_host).to(DEV)
+    gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=l0, l0_ld=0, l0_symmetric=True)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(sizes), K, mode, p, DEV)
+    Xt = gb.X.clone().requires_grad_(True)
+    nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+    (nodes.data * torch.from_numpy(np.concatenate(Gs)).to(DEV)).sum().backward()
+    caches, tot = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL, Gs)
+    # absolute allowance scaled by sqrt(n / 64) as in test_modelnet_shaped_dense_adjacency; the gradients of the
+    # degenerate one-feature case ((z_i - z_j) / r_ij = +-1: dZ and dX are sums of signed terms that cancel) get the
+    # allowance fp32 arithmetic itself needs there (helpers.py: 120 ulp on dX against 5 in the other cases)
+    k = float(np.sqrt(max(sizes) / 64.0))
+    kg = k * (4.0 if Fin == 1 else 1.0)
+    Y = to_np(nodes.data)
+    dX = to_np(Xt.grad)
+    r0 = 0
+    for b, n in enumerate(sizes):
+        c = caches[b]
+        assert_close(Y[r0:r0 + n], c["Y"], FEATURE_RTOL, f"Y[{b}]", atol_ulps=FEATURE_ULPS * k)
+        w = to_np(res_W[b])
+        assert_close(w, c["S"], FEATURE_RTOL, f"res_W[{b}]", atol_ulps=0)
+        assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
+        assert_close(to_np(res_L[b]), c["R2"], FEATURE_RTOL, f"res_L[{b}]", atol_ulps=FEATURE_ULPS * k)
+        assert_close(dX[r0:r0 + n], tot["dX"][b], GRAD_RTOL, f"dX[{b}]", atol_ulps=GRAD_ULPS * kg)
+        r0 += n
+    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight", atol_ulps=GRAD_ULPS * kg)
+    assert_close(to_np(layer.vars["bias"].grad), tot["dbias"], GRAD_RTOL, "dbias", atol_ulps=GRAD_ULPS * kg)
+    if mode == orc.PAPER:
+        assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L", atol_ulps=GRAD_ULPS * kg)
+
+
 def test_two_threads_call_the_library_concurrently(amd):
     """include/agcn.h "Threading": calls are re-entrant across threads.  Two threads, each with its own stream, batch
     and buffers, run forward + backward steps at the same time (ctypes drops the GIL inside the library); every
