@@ -437,6 +437,12 @@ void agcn_set_spec_mode(int32_t mode);
 int32_t agcn_get_spec_small(void);
 void agcn_set_spec_small(int32_t on);
 
+/* Environment switches of the point-cloud kernels, read once per process (A/B measurements; results within the same
+ * tolerances either way): AGCN_SLAB_SMALL=0 -- slab batches with Fin <= 4 and a dense L_orig take the general slab
+ * kernels instead of the streaming small-feature ones (which keep nothing n x n for the backward: r, S, R and dA are
+ * rebuilt from the Z / g_1 / X_0 rows); AGCN_ROWS_NARROW=0 -- the projection (Fin <= 4) and the filter adjoint
+ * (K * Fin <= 8 columns) of >= 1024 packed rows take the 64-row MFMA workgroups instead of the streaming row kernels. */
+
 #ifdef __cplusplus
 }
 #endif
