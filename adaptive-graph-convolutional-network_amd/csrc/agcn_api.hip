@@ -525,6 +525,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
   a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
+  a.tp_first = host.info.B - 1;
 
   Carver c(workspace);
   const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
@@ -558,6 +559,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
         int cg = 0, cs = 0, dg = 0;
         coop_plan(desc, host, fs, false, &cg, &cs, &dg);
         a.coop_slabs = cs;
+        a.tp_first = std::max(cg, B - 32);   // (cg < B: the last graph of the schedule is never spread over members)
         size_t lds = spec_fwd_lds_bytes(host.n[host.order[cg]], desc->Fin, desc->Fout, spec::NW_LARGE);
         if (cs > 0) lds = std::max(lds, spec_coop_fwd_lds_bytes(host.n[host.order[0]], desc->Fin));
         if (dg > 0) {   // the dg smallest graphs, two to a workgroup
@@ -618,6 +620,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
       rc = launch_rows_gemm(g, RG_FILTER, ss.s);
       if (rc != AGCN_OK) return rc;
     }
+    if (fs.spec_fwd) a.tp_first = std::max(fs.n_big, host.info.B - 32);
     if (fs.spec_fwd)
       rc = launch_spec_forward(a, fs.n_big, host.info.B - fs.n_big,
                                spec_fwd_lds_bytes(fs.thr, desc->Fin, desc->Fout, spec::NW_LARGE), spec::NW_LARGE, main_s);
@@ -710,6 +713,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
   a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
+  a.tp_first = host.info.B - 1;
   a.dY = dY; a.dL_sum = dL_sum; a.dX = grads->dX; a.dL_prev = has_prev ? grads->dL_prev : nullptr;
   a.ws_g = w.g; a.ws_dZ = w.dZ; a.ws_pg = w.pg; a.ws_tile = w.tile; a.ws_buf = w.buf;
 

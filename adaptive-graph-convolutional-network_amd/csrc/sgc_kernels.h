@@ -39,6 +39,7 @@ struct SgcArgs {
   // with the MFMA k index as the row: a fragment load then touches 4 cache lines instead of 16)
   float* sv_MT;    // [Fin][Fin]        M_L^T
   float* sv_WT;    // [K][Fout][Fin]    WT[k][c][f] = W[f*K + k][c]
+  int32_t tp_first; // specialised forward: the graphs at schedule positions tp_first .. B-1 write sv_MT / sv_WT
   // exchange words of the cooperative backward (spec_backward_coop.h): [B][97] 64-bit words, zeroed per graph by the
   // specialised forward kernel
   uint64_t* sv_xch;

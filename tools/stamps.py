@@ -38,11 +38,15 @@ def main():
         big = synth.tox21_batch(123, B * N)
         mine = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(big["n"], 75, 64, 2), N)[0]
         data = {"n": big["n"][mine], "X": [big["X"][i] for i in mine], "csr": [big["csr"][i] for i in mine]}
-    p = synth.glorot_params(np.random.RandomState(123), 75, 64, 2)
-    gb = agcn_amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], "cuda:0")
-    layer = agcn_amd.SGC_LL(64, 75, B, K=2, laplacian_mode=mode, device="cuda:0")
+    Fin, Fout = int(os.environ.get("AGCN_STAMP_FIN", 75)), int(os.environ.get("AGCN_STAMP_FOUT", 64))   # layer shape
+    p = synth.glorot_params(np.random.RandomState(123), Fin, Fout, 2)
+    X = np.concatenate(data["X"], 0)
+    if Fin != 75:
+        X = np.maximum(np.random.RandomState(5).randn(X.shape[0], Fin), 0).astype(np.float32)   # deeper layer: relu(N(0,1))
+    gb = agcn_amd.GraphBatch.from_arrays(data["n"], X, data["csr"], "cuda:0")
+    layer = agcn_amd.SGC_LL(Fout, Fin, B, K=2, laplacian_mode=mode, device="cuda:0")
     layer.load_vars(p)
-    st = agcn_amd.SgcLLStep(layer, gb, dY=torch.randn(gb.plan.rows, 64, device="cuda:0"))
+    st = agcn_amd.SgcLLStep(layer, gb, dY=torch.randn(gb.plan.rows, Fout, device="cuda:0"))
     lib = agcn_amd._ffi.lib()
     lib.agcn_debug_read_stamps.restype = C.c_int
     lib.agcn_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
