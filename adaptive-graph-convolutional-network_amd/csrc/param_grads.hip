@@ -307,10 +307,13 @@ int pg_tiles(int Fin, int Fout, int K, bool paper, int TF) {
   const int tfM = (Fin + TF - 1) / TF, tcM = (Fin + 31) / 32;
   return tfW * tcW + tcW + (paper ? tfM * tcM : 0);
 }
-// rows per wave (multiple of 32) and number of row splits
-void pg_split(int rows, int* rows_per_wave, int* S) {
+// rows per wave (multiple of 32) and number of row splits, for `nt` output tiles
+void pg_split(int rows, int nt, int* rows_per_wave, int* S) {
   static const int force = [] { const char* e = std::getenv("AGCN_PG_RPW"); return e ? std::atoi(e) : 0; }();
   int rpw = 32;   // measured: 32 / 64 / 96 rows per wave are within 5 %, 128 is 30 % slower
+  // wide layers have many tiles: beyond ~800 workgroups (three rounds of 1024 threads per CU) twice the rows per
+  // wave win -- 256 graphs, 128 -> 128 (100 tiles): 20.5 -> 17.1 us; 75 -> 64 (37 tiles): 12.7 -> 13.0 us
+  if (rows < 8192 && nt * ((rows + 16 * rpw - 1) / (16 * rpw)) > 800) rpw = 64;   // (larger batches: measured with 32)
   while ((rows + 16 * rpw - 1) / (16 * rpw) > 64) rpw += 32;
   if (force >= 4) rpw = force / 4 * 4;
   *rows_per_wave = rpw;
@@ -322,9 +325,9 @@ int pg_mode() { return agcn_get_param_grad_onepass(); }
 // floats of `part` the one-pass kernel needs: S partial tiles per output tile + the arrival counters
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper) {
   int rpw, S;
-  pg_split(rows, &rpw, &S);
   const int TF = pg_tf(rows);
   const size_t nt = (size_t)pg_tiles(Fin, Fout, K, paper != 0, TF);
+  pg_split(rows, (int)nt, &rpw, &S);
   return nt * S * (TF * 32) + ((nt + 63) / 64) * 64;
 }
 
@@ -333,9 +336,9 @@ int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int3
   *count = 0;
   if (pg_mode() != 1 || !part || part_floats < param_grad_onepass_floats(rows, Fin, Fout, K, paper)) return nullptr;
   int rpw, S;
-  pg_split(rows, &rpw, &S);
   const int TF = pg_tf(rows);
   const int nt = pg_tiles(Fin, Fout, K, paper != 0, TF);
+  pg_split(rows, nt, &rpw, &S);
   *count = nt;
   return reinterpret_cast<int32_t*>(part + (size_t)nt * S * (TF * 32));
 }
@@ -345,9 +348,9 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
   if (pg_mode() == 1 && a.part_floats >= param_grad_onepass_floats(a.rows, a.Fin, a.Fout, a.K, a.paper)) {
     ParamGradArgs aa = a;
     int rpw, S;
-    pg_split(a.rows, &rpw, &S);
     const int TF = pg_tf(a.rows);
     const int nt = pg_tiles(a.Fin, a.Fout, a.K, a.paper != 0, TF);
+    pg_split(a.rows, nt, &rpw, &S);
     aa.n_chunks = S; aa.wgs_per_chunk = rpw; aa.chunk_rows = 16 * rpw;
     aa.counters = reinterpret_cast<int32_t*>(a.part + (size_t)nt * S * (TF * 32));
     if (!a.counters_zeroed) {
