@@ -41,6 +41,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
   float* smem = smem_ + ((DUAL && (int)threadIdx.x >= NT) ? a.dual_stride : 0);
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
+  AGCN_STAMP(1, 9);   // (workgroup start; sorts first in tools/stamps.py)
   const GraphRec g = load_graph(a.graph_desc + gpos);
   const int n = g.n, row0 = g.row0;
   const uint32_t toff = g.toff;

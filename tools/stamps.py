@@ -54,7 +54,12 @@ def main():
         st.step()
     buf = np.zeros(8 * 1024 * 16, dtype=np.uint64)
     lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
-    st.step()
+    seq = os.environ.get("AGCN_STAMP_SEQ", "")     # e.g. "ff": two forwards in a row, "bf": backward then forward
+    if seq:
+        for ch in seq:
+            st.forward() if ch == "f" else st.backward()
+    else:
+        st.step()
     lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
     s = buf.reshape(8, 1024, 16).astype(np.int64)
     names = ["PROJECT", "graph_fwd/slab_sim", "FILTER", "FILTER_BWD", "graph_bwd", "PROJECT_BWD", "slab_lap/DENSE", "slot7"]
