@@ -54,6 +54,12 @@ __device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a) { return slab_ctx(
 // sqrt / exp2 / rcp instructions (1 ulp each, as the specialised per-graph kernels, spec_kernels.h) instead of the
 // ~45-instruction library sequences -- the pairwise phases are bound by instruction issue.  The backward rebuilds S
 // from r with the SAME function the forward used.
+#ifndef AGCN_LAP_GB
+#define AGCN_LAP_GB 1
+#endif
+#ifndef AGCN_BWD_GB
+#define AGCN_BWD_GB 1
+#endif
 #ifndef AGCN_SLAB_FAST
 #define AGCN_SLAB_FAST 1
 #endif
@@ -297,8 +303,12 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
     build_L_chunk<true>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1, cur);
     cur = nxt;
     if (c0 == 0) AGCN_STAMP(6, 2);
-    stage_rows_img(Xs, ldbx, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
-    __syncthreads();
+    if (!AGCN_LAP_GB) {
+      stage_rows_img(Xs, ldbx, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
+      __syncthreads();
+    } else if (a.L0_dense == nullptr) {
+      __syncthreads();   // (the CSR scatter into the strip)
+    }
     if (c0 == 0) AGCN_STAMP(6, 3);
     if (a.L_sum) {   // optional 4th output of SGC_LL: the combined Laplacian
 #pragma unroll
@@ -307,7 +317,15 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
         if (il < c.nr && lane < nc) a.L_sum[c.toff + (int64_t)(c.i0 + il) * n + c0 + lane] = Ls[il * CHP + lane];
       }
     }
-    strip_gemm_rowmajor(acc, Ls, CHP, Xs, ldbx, (nc + 15) & ~15, ntiles);
+    if (!AGCN_LAP_GB) {
+      strip_gemm_rowmajor(acc, Ls, CHP, Xs, ldbx, (nc + 15) & ~15, ntiles);
+    } else if (wave < ntiles) {
+      // the chunk's X_0 rows as the MFMA B operand straight from L2 (a graph's rows are re-read by all its strips:
+      // they stay there): no LDS image, no staging barrier
+      const float* Xc = Xg + (int64_t)c0 * a.ldx;
+      tile_gemm_gb(acc[0], Ls, CHP, 0, Xc, a.ldx, nc, 16 * wave, Fin, (nc + 15) & ~15);
+      if (wave + 4 < ntiles) tile_gemm_gb(acc[1], Ls, CHP, 0, Xc, a.ldx, nc, 16 * (wave + 4), Fin, (nc + 15) & ~15);
+    }
   }
   AGCN_STAMP(6, 4);
   // X_1[I] = L[I, :] X_0   (graphconv.py:231) -> reserve, and as an A image for the filter product below
@@ -381,6 +399,18 @@ __device__ __forceinline__ void strip_gemm_transposed(float* out, const float* A
   for (int i = 0; i < 4; ++i) out[(4 * q + i) * CHP + 16 * wave + r] = acc[i];
 }
 
+// The same with the chunk's rows read straight from global memory (L2): B[f][j] = rows[j * ldr + f], row index
+// clamped to rlast (the columns of a partial chunk beyond it are never used).  A: k-permuted image (perm16).
+__device__ __forceinline__ void strip_gemm_transposed_gb(float* out, const float* A, int ldf, const float* rows, int ldr,
+                                                         int rlast, int Fin, int F16) {
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+  const int r = lane & 15, q = lane >> 4;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  tile_gemm_gbt4(acc, A, ldf, 0, rows + (int64_t)min(16 * wave + r, rlast) * ldr, Fin, F16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[(4 * q + i) * CHP + 16 * wave + r] = acc[i];
+}
+
 // Backward chunk of the learned Laplacian: of the forward's n x n data only r (paper mode) and L_orig are read.
 // S = exp(-r) and R = I - s S s are recomputed with the forward's own instructions (slab_sim: expf(-r); slab_lap:
 // R - (s_i S) s_j), so L and S carry the same bits as res_L + L_orig and res_W -- neither output is read again.
@@ -439,10 +469,11 @@ __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
   const int F16 = (Fin + 15) & ~15;
   const int ntiles = (Fin + 15) >> 4;
   // shared by the workgroup: the chunk images;  per strip: everything else
+  const int img_floats = (AGCN_BWD_GB && Q == 1) ? 0 : CH * ldf;   // (no chunk images when the B operands come from L2)
   float* G1s = smem_all;                // [CH][ldf]  g_1 rows of the chunk
-  float* X0s = G1s + CH * ldf;          // [CH][ldf]  X_0 rows of the chunk (paper)
+  float* X0s = G1s + img_floats;        // [CH][ldf]  X_0 rows of the chunk (paper)
   const int strip_floats = 3 * SH * CHP + 2 * SH * ldf + 32;
-  float* smem = X0s + CH * ldf + sub * strip_floats;
+  float* smem = X0s + img_floats + sub * strip_floats;
   float* Ls = smem;                     // [16][CHP]  L chunk
   float* red = Ls + SH * CHP;           // 32
   float* T = red + 32;                  // [16][CHP]  dL row strip        (paper)
@@ -461,11 +492,22 @@ __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
     csr_p0 = a.L0_rowptr[c.row0 + c.i0 + tid];
     csr_p1 = a.L0_rowptr[c.row0 + c.i0 + tid + 1];
   }
-  if (paper) {
+  if (paper && AGCN_BWD_GB && Q == 1) {
+    // A images of the two transposed products, k-permuted inside every 16-block (tile_gemm_gbt4: the chunk rows are
+    // fetched with one 16-byte load per lane and 16-k block); zero beyond the slab's rows and Fin
+    for (int idx = tid; idx < SH * F16; idx += 256) {
+      const int i = idx / F16, f = idx - i * F16;
+      const bool ok = i < c.nr && f < Fin;
+      const int ic = c.i0 + min(i, c.nr - 1), fc = min(f, Fin - 1);
+      const float gv = g1[(int64_t)ic * Fin + fc], xv = Xg[(int64_t)ic * a.ldx + fc];
+      gI[i * ldf + perm16(f)] = ok ? gv : 0.f;
+      xI[i * ldf + perm16(f)] = ok ? xv : 0.f;
+    }
+  } else if (paper) {
     // (stage_rows_img works with every thread of the workgroup: one strip's images after the other)
     for (int sb = 0; sb < Q; ++sb) {
       const SlabCtx cs = Q == 1 ? c : slab_ctx(a, (int)blockIdx.x * Q + sb);
-      float* base = X0s + CH * ldf + sb * strip_floats + 3 * SH * CHP + 32;
+      float* base = X0s + img_floats + sb * strip_floats + 3 * SH * CHP + 32;
       stage_rows_img(base, ldf, g1 + (int64_t)cs.i0 * Fin, Fin, cs.nr, SH, Fin);
       stage_rows_img(base + SH * ldf, ldf, Xg + (int64_t)cs.i0 * a.ldx, a.ldx, cs.nr, SH, Fin);
     }
@@ -516,21 +558,38 @@ __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
           if (p + u < csr_p1 && cc[u] >= c0 && cc[u] < c0 + CH) Ls[tid * CHP + cc[u] - c0] += vv[u];
       }
     }
-    stage_rows_img(G1s, ldf, g1 + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
-    if (paper) {
-      stage_rows_img(X0s, ldf, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
-      for (int idx = threadIdx.x; idx < CH * (F16 - round4(Fin)); idx += 256 * Q) {
-        const int w = F16 - round4(Fin), i = idx / w, f = round4(Fin) + idx - i * w;
-        G1s[i * ldf + f] = 0.f;
-        X0s[i * ldf + f] = 0.f;
+    if (!(AGCN_BWD_GB && Q == 1)) {
+      stage_rows_img(G1s, ldf, g1 + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
+      if (paper) {
+        stage_rows_img(X0s, ldf, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, CH, Fin);
+        for (int idx = threadIdx.x; idx < CH * (F16 - round4(Fin)); idx += 256 * Q) {
+          const int w = F16 - round4(Fin), i = idx / w, f = round4(Fin) + idx - i * w;
+          G1s[i * ldf + f] = 0.f;
+          X0s[i * ldf + f] = 0.f;
+        }
       }
+      __syncthreads();
+    } else if (!dense_l0) {
+      __syncthreads();   // (the CSR scatter into the strip)
     }
-    __syncthreads();
     // dX[I] += L[I, :] g_1   (== (L^T g_1)[I]: L is symmetric)
-    strip_gemm_rowmajor(acc, Ls, CHP, G1s, ldf, (nc + 15) & ~15, ntiles);
+    if (!(AGCN_BWD_GB && Q == 1)) {
+      strip_gemm_rowmajor(acc, Ls, CHP, G1s, ldf, (nc + 15) & ~15, ntiles);
+    } else if (wave < ntiles) {
+      // the chunk's g_1 / X_0 rows as the MFMA B operands straight from L2 (a graph's rows are re-read by all its
+      // strips: they stay there): no chunk images, no staging barrier (as slab_lap)
+      const float* gc = g1 + (int64_t)c0 * Fin;
+      tile_gemm_gb(acc[0], Ls, CHP, 0, gc, Fin, nc, 16 * wave, Fin, (nc + 15) & ~15);
+      if (wave + 4 < ntiles) tile_gemm_gb(acc[1], Ls, CHP, 0, gc, Fin, nc, 16 * (wave + 4), Fin, (nc + 15) & ~15);
+    }
     if (paper) {
-      strip_gemm_transposed(T, gI, X0s, ldf, F16);    // dL[I, chunk]   = g_1[I] . X_0[chunk]^T
-      strip_gemm_transposed(Cc, xI, G1s, ldf, F16);   // dL[chunk, I]^T = X_0[I] . g_1[chunk]^T
+      if (!(AGCN_BWD_GB && Q == 1)) {
+        strip_gemm_transposed(T, gI, X0s, ldf, F16);    // dL[I, chunk]   = g_1[I] . X_0[chunk]^T
+        strip_gemm_transposed(Cc, xI, G1s, ldf, F16);   // dL[chunk, I]^T = X_0[I] . g_1[chunk]^T
+      } else {
+        strip_gemm_transposed_gb(T, gI, ldf, Xg + (int64_t)c0 * a.ldx, a.ldx, n - 1 - c0, Fin, F16);
+        strip_gemm_transposed_gb(Cc, xI, ldf, g1 + (int64_t)c0 * Fin, Fin, n - 1 - c0, Fin, F16);
+      }
       __syncthreads();
       const int j = c0 + lane;
       const bool cv = lane < nc;
@@ -664,9 +723,18 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
       Cs[il * CHP + lane] = cij;
       cs[di] += cij;
     }
-    stage_rows_img(Zs, ldbx, Zg + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
-    __syncthreads();
-    strip_gemm_rowmajor(acc, Cs, CHP, Zs, ldbx, (nc + 15) & ~15, ntiles);
+    if (!AGCN_BWD_GB) {
+      stage_rows_img(Zs, ldbx, Zg + (int64_t)c0 * Fin, Fin, nc, CH, Fin);
+      __syncthreads();
+      strip_gemm_rowmajor(acc, Cs, CHP, Zs, ldbx, (nc + 15) & ~15, ntiles);
+    } else {
+      __syncthreads();   // the c strip chunk
+      if (wave < ntiles) {   // the chunk's Z rows as the B operand straight from L2 (as slab_lap)
+        const float* Zc = Zg + (int64_t)c0 * Fin;
+        tile_gemm_gb(acc[0], Cs, CHP, 0, Zc, Fin, nc, 16 * wave, Fin, (nc + 15) & ~15);
+        if (wave + 4 < ntiles) tile_gemm_gb(acc[1], Cs, CHP, 0, Zc, Fin, nc, 16 * (wave + 4), Fin, (nc + 15) & ~15);
+      }
+    }
   }
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
@@ -1158,7 +1226,8 @@ size_t lds_lap(int Fin) {
 size_t lds_bwd1(int Fin, bool paper, int Q = 1) {
   (void)paper;
   const size_t ldf = ld_frag((Fin + 15) & ~15);
-  return sizeof(float) * (2 * (size_t)CH * ldf + (size_t)Q * (3 * (size_t)SH * CHP + 2 * (size_t)SH * ldf + 32));
+  const size_t img = (AGCN_BWD_GB && Q == 1) ? 0 : (size_t)CH * ldf;
+  return sizeof(float) * (2 * img + (size_t)Q * (3 * (size_t)SH * CHP + 2 * (size_t)SH * ldf + 32));
 }
 size_t lds_bwd2(int Fin) {
   const size_t img = std::max((size_t)CH * ld_b(Fin), (size_t)SH * ld_frag((Fin + 15) & ~15));   // chunk rows / dZ image
@@ -1241,7 +1310,7 @@ int launch_slab_backward(const SgcArgs& a, void* stream) {
   // four strips per workgroup where every graph is a multiple of 64 rows (the point clouds): the chunk rows of g_1 / X_0
   // are staged once for the four
   static const int q_env = [] { const char* e = std::getenv("AGCN_SLAB_QUAD"); return e ? std::atoi(e) : 2; }();
-  int Q = (a.slab_quad != 0 && a.L0_dense != nullptr) ? q_env : 1;
+  int Q = (a.slab_quad != 0 && a.L0_dense != nullptr && !AGCN_BWD_GB) ? q_env : 1;   // (B operands from L2: nothing to share)
   if (Q != 2 && Q != 4) Q = 1;
   if (a.n_slabs % Q != 0 || lds_bwd1(a.Fin, paper, Q) > 160 * 1024) Q = 1;
   int rc = Q == 4 ? launch_slab(slab_bwd1_kernel_t<4>, a, lds_bwd1(a.Fin, paper, 4), PK_SLAB_BWD1, "slab_bwd1 x4", stream, 4)
