@@ -455,6 +455,9 @@ __device__ __forceinline__ void chunk_SR(const SlabCtx& c, const BChunkRegs& g, 
 // 8.5 us per chunk).  Q > 1 needs the strips of a workgroup to belong to one graph (every graph a multiple of 64 rows:
 // the point clouds) and a dense L_orig.  Measured, 32 clouds of 1024 points, 64 -> 128: Q = 1: 560 us, Q = 2: 480 us
 // (185 VGPRs, one workgroup per CU), Q = 4: 564 us (held to 128 VGPRs by its 1024 threads: 200 bytes spilled).
+// AGCN_BWD_GB (default 1) supersedes the staging altogether: with Q = 1 the chunk rows are the MFMA B operands straight
+// from L2 (row-major product: tile_gemm_gb; transposed products: tile_gemm_gbt4 against k-permuted A images), no chunk
+// images, no staging barrier: 355 us.  The Q > 1 code remains for -DAGCN_BWD_GB=0.
 template <int Q>
 __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
