@@ -165,6 +165,7 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
     s = blockIdx.x - t * S8;
   }
   if (s >= S) return;
+  AGCN_STAMP(7, 0);
   int p, rem;                               // problem, tile index inside it
   if (t < tfW * tcW) { p = 0; rem = t; }
   else if (t < tfW * tcW + tcW) { p = 1; rem = t - tfW * tcW; }
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
       }
     }
   }
+  AGCN_STAMP(7, 1);
   // The hand-off to the tile's last workgroup uses agent-scope (sc1) stores and loads of exactly the bytes
   // handed off -- no release / acquire fence: an agent-scope release would write back the whole L2, which
   // holds megabytes of this step's outputs (measured: 158 us for this kernel with __threadfence()).
@@ -253,12 +255,14 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   // barrier alone emits no vmcnt wait on gfx950, and the relaxed counter add could then overtake the partial tile
   // (MI355X_MICROARCH.md, inter-workgroup visibility, condition (3)).  Inline asm: invisible to the waitcnt pass.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AGCN_STAMP(7, 2);
   __syncthreads();
   if (tid == 0) {
     const int old = __hip_atomic_fetch_add(a.counters + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_flag = (old == S - 1) ? 1 : 0;
   }
   __syncthreads();
+  AGCN_STAMP(7, 3);
   if (last_flag) {
     for (int e = tid; e < TE; e += 1024) {
       const float* base = a.part + (int64_t)t * S * TE + e;
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
       }
     }
   }
+  AGCN_STAMP(7, 4);
   // scalars: one wave each of workgroup 0, fixed order (the per-graph partials come from the previous kernel)
   if (blockIdx.x == 0 && wave < 2) {
     float* dst = wave == 0 ? a.dalpha : a.dbeta;

@@ -62,7 +62,7 @@ def main():
         st.step()
     lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
     s = buf.reshape(8, 1024, 16).astype(np.int64)
-    names = ["PROJECT", "graph_fwd/slab_sim", "FILTER", "FILTER_BWD", "graph_bwd", "PROJECT_BWD", "slab_lap/DENSE", "slot7"]
+    names = ["PROJECT", "graph_fwd/slab_sim", "FILTER", "FILTER_BWD", "graph_bwd", "PROJECT_BWD", "slab_lap/DENSE", "param_grad"]
     for k, nm in enumerate(names):
         blk = s[k]
         used = blk[:, 0] > 0
