@@ -461,7 +461,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dd; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -471,9 +471,10 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
   w->dZ = paper ? c.take((size_t)pi.rows * d->Fin) : nullptr;
   w->Gp = c.take((size_t)pi.rows * d->Fout);
   w->pg = c.take((size_t)2 * ((size_t)pi.n_slabs + pi.B));
-  w->dA = w->dd = nullptr;
+  w->dA = w->dAt = w->dd = nullptr;
   if (d->variant == AGCN_SGC_LL && d->K == 2 && paper) {   // slab path scratch
     w->dA = c.take((size_t)pi.tile_elems);
+    w->dAt = c.take((size_t)pi.tile_elems);
     w->dd = c.take((size_t)pi.rows);
   }
   w->n_chunks = n_chunks_for(pi.rows);
@@ -741,7 +742,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     a.slab_quad = slab_quad_ok(host);
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_Gp = w.Gp;
-    a.ws_dA = w.dA; a.ws_dd = w.dd;
+    a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd;
     SideStream* ss = nullptr;
     std::unique_lock<std::mutex> side_lock;
     hipStream_t main_s = static_cast<hipStream_t>(hip_stream);
@@ -849,7 +850,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
     a.slab_quad = slab_quad_ok(host);
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
-    a.ws_dA = w.dA; a.ws_dd = w.dd;
+    a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd;
     if (slabs) {
       rc = launch_slab_backward(a, hip_stream);
       if (rc != AGCN_OK) return rc;

@@ -64,6 +64,7 @@ struct SgcArgs {
   int32_t n_slabs;
   float* sv_r;     // [tile_elems]  r_ij = ||Z_i - Z_j||  (paper mode, forward -> backward)
   float* ws_dA;    // [tile_elems]  dA = -dR               (paper mode, bwd1 -> bwd2)
+  float* ws_dAt;   // [tile_elems]  dAt[i][j] = dA[j][i], written by the strip that owns row i (bwd2 then reads rows only)
   float* ws_dd;    // [rows]        dd_j                   (paper mode, bwd1 -> bwd2)
   int32_t pg_slab_base;  // mixed dispatch: slab s writes its partials at ws_pg[2 * (pg_slab_base + s)]
   int32_t slab_quad;     // 1: every graph has a multiple of 64 rows (four consecutive slabs always share a graph)

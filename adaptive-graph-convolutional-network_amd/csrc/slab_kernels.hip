@@ -615,6 +615,7 @@ __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
           const float dA = -(dL * lg);                     // dA_ij = -dR_ij
           const float dAt = -((Cc[il * CHP + lane] + upt[di]) * lg);   // dA_ji (R symmetric)
           a.ws_dA[c.toff + (int64_t)(c.i0 + il) * n + j] = dA;
+          a.ws_dAt[c.toff + (int64_t)(c.i0 + il) * n + j] = dAt;   // (dA_ji, kept row-wise: slab_bwd2 reads no columns)
           // ds_i = sum_j dA_ij S_ij s_j + sum_j dA_ji S_ij s_j
           ds[di] += (dA * Sv[di]) * sj + (dAt * Sv[di]) * sj;
         }
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
       const int i = c.i0 + min(4 * wave + di, c.nr - 1);
       const int64_t o = c.toff + (int64_t)i * n + jc;
       g.dA[di] = a.ws_dA[o];
-      g.dAt[di] = a.ws_dA[c.toff + (int64_t)jc * n + i];
+      g.dAt[di] = a.ws_dAt[o];
       g.Sv[di] = a.res_W[o];
       g.rv[di] = a.sv_r[o];
     }
