@@ -244,6 +244,35 @@ __device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c
   }
 }
 
+// One 16-column tile of a strip x chunk product with the chunk's rows as the B operand straight from L2, in two
+// halves: gb_chunk_load issues ALL of the chunk's B loads (64 rows: 16 registers) -- they do not depend on the strip
+// image, so the caller issues them BEFORE it builds the image and waits at the barrier --, gb_chunk_mma consumes them.
+struct GbChunk { float b[4][4]; };
+__device__ __forceinline__ GbChunk gb_chunk_load(const float* Bg, int krow, int kvalid, int col0, int cvalid) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* Bp = Bg + min(col0 + r, cvalid - 1);
+  GbChunk g;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g.b[blk][u] = Bp[(int64_t)min(16 * blk + 4 * u + q, kvalid - 1) * krow];
+  return g;
+}
+__device__ __forceinline__ void gb_chunk_mma(f32x4& acc, const float* A, int lda, const GbChunk& g, int kdim) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* Ap = A + r * lda + q;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    if (16 * blk < kdim) {
+      float av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[u] = Ap[16 * blk + 4 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], g.b[blk][u], acc, 0, 0, 0);
+    }
+  }
+}
+
 // acc[j] += A[16 x kdim] (LDS image, ld lda) . B[kdim x Fin] (LDS row-major image, ld ldb), this wave's
 // column tiles w and w + 4
 __device__ __forceinline__ void strip_gemm_rowmajor(f32x4 (&acc)[2], const float* A, int lda, const float* B,
@@ -300,6 +329,9 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
     if (c0 > 0) __syncthreads();
     if (c0 == 0) AGCN_STAMP(6, 1);
     const LChunkRegs nxt = (c0 + CH < n) ? load_L_chunk<true>(a, c, c0 + CH) : cur;   // next chunk's loads in flight
+    GbChunk gb0;
+    if (AGCN_LAP_GB && wave < ntiles)   // this chunk's X_0 rows (the B operand): in flight while the strip is built
+      gb0 = gb_chunk_load(Xg + (int64_t)c0 * a.ldx, a.ldx, nc, 16 * wave, Fin);
     build_L_chunk<true>(a, c, Ls, c0, nc, si, alpha, csr_p0, csr_p1, cur);
     cur = nxt;
     if (c0 == 0) AGCN_STAMP(6, 2);
@@ -322,9 +354,9 @@ __global__ __launch_bounds__(256) void slab_lap_kernel(SgcArgs a) {
     } else if (wave < ntiles) {
       // the chunk's X_0 rows as the MFMA B operand straight from L2 (a graph's rows are re-read by all its strips:
       // they stay there): no LDS image, no staging barrier
-      const float* Xc = Xg + (int64_t)c0 * a.ldx;
-      tile_gemm_gb(acc[0], Ls, CHP, 0, Xc, a.ldx, nc, 16 * wave, Fin, (nc + 15) & ~15);
-      if (wave + 4 < ntiles) tile_gemm_gb(acc[1], Ls, CHP, 0, Xc, a.ldx, nc, 16 * (wave + 4), Fin, (nc + 15) & ~15);
+      gb_chunk_mma(acc[0], Ls, CHP, gb0, (nc + 15) & ~15);
+      if (wave + 4 < ntiles)   // (a second column tile, Fin > 64: loaded on the spot)
+        tile_gemm_gb(acc[1], Ls, CHP, 0, Xg + (int64_t)c0 * a.ldx, a.ldx, nc, 16 * (wave + 4), Fin, (nc + 15) & ~15);
     }
   }
   AGCN_STAMP(6, 4);
@@ -532,6 +564,9 @@ __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
     const int nc = min(CH, n - c0);
     if (c0 > 0) __syncthreads();
     const BChunkRegs nxt = (c0 + CH < n) ? load_B_chunk(a, c, c0 + CH, true) : cur;   // next chunk's loads in flight
+    GbChunk gb0;
+    if (AGCN_BWD_GB && Q == 1 && wave < ntiles)   // this chunk's g_1 rows (B operand of dX[I] += L g_1): in flight early
+      gb0 = gb_chunk_load(g1 + (int64_t)c0 * Fin, Fin, nc, 16 * wave, Fin);
     float Sv[4], Rv[4];
     chunk_SR(c, cur, c0, si, paper, Sv, Rv);
     {
@@ -582,7 +617,7 @@ __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
       // the chunk's g_1 / X_0 rows as the MFMA B operands straight from L2 (a graph's rows are re-read by all its
       // strips: they stay there): no chunk images, no staging barrier (as slab_lap)
       const float* gc = g1 + (int64_t)c0 * Fin;
-      tile_gemm_gb(acc[0], Ls, CHP, 0, gc, Fin, nc, 16 * wave, Fin, (nc + 15) & ~15);
+      gb_chunk_mma(acc[0], Ls, CHP, gb0, (nc + 15) & ~15);
       if (wave + 4 < ntiles) tile_gemm_gb(acc[1], Ls, CHP, 0, gc, Fin, nc, 16 * (wave + 4), Fin, (nc + 15) & ~15);
     }
     if (paper) {
@@ -709,6 +744,9 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
     const int j = c0 + lane;
     const bool cv = lane < nc;
     const Regs nxt = (c0 + CH < n) ? load_chunk(c0 + CH) : cur;   // next chunk's loads in flight
+    GbChunk gb0;
+    if (AGCN_BWD_GB && wave < ntiles)   // this chunk's Z rows (the B operand): in flight while the c strip is built
+      gb0 = gb_chunk_load(Zg + (int64_t)c0 * Fin, Fin, nc, 16 * wave, Fin);
     const float sj = cur.sj, ddj = cur.ddj;
     float dA[4], dAt[4], Sv[4], rv[4];
 #pragma unroll
@@ -735,7 +773,7 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
       __syncthreads();   // the c strip chunk
       if (wave < ntiles) {   // the chunk's Z rows as the B operand straight from L2 (as slab_lap)
         const float* Zc = Zg + (int64_t)c0 * Fin;
-        tile_gemm_gb(acc[0], Cs, CHP, 0, Zc, Fin, nc, 16 * wave, Fin, (nc + 15) & ~15);
+        gb_chunk_mma(acc[0], Cs, CHP, gb0, (nc + 15) & ~15);
         if (wave + 4 < ntiles) tile_gemm_gb(acc[1], Cs, CHP, 0, Zc, Fin, nc, 16 * (wave + 4), Fin, (nc + 15) & ~15);
       }
     }
