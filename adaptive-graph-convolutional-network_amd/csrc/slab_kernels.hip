@@ -54,6 +54,9 @@ __device__ __forceinline__ SlabCtx slab_ctx(const SgcArgs& a) { return slab_ctx(
 // sqrt / exp2 / rcp instructions (1 ulp each, as the specialised per-graph kernels, spec_kernels.h) instead of the
 // ~45-instruction library sequences -- the pairwise phases are bound by instruction issue.  The backward rebuilds S
 // from r with the SAME function the forward used.
+#ifndef AGCN_SMALL_NT
+#define AGCN_SMALL_NT 45
+#endif
 #ifndef AGCN_LAP_GB
 #define AGCN_LAP_GB 1
 #endif
@@ -144,8 +147,13 @@ __global__ __launch_bounds__(256) void slab_sim_kernel(SgcArgs a) {
           const float r = slab_sqrt(acc[di][dj]);
           // S_ii = 0 (graphconv.py:171-173); exp(-1 * norm) otherwise (:176-177)
           const float sv = (i == j) ? 0.f : slab_exp_neg(r);
-          a.res_W[c.toff + (int64_t)i * n + j] = sv;
-          if (paper) a.sv_r[c.toff + (int64_t)i * n + j] = r;
+          if (AGCN_SMALL_NT & 16) {
+            __builtin_nontemporal_store(sv, &a.res_W[c.toff + (int64_t)i * n + j]);
+            if (paper) __builtin_nontemporal_store(r, &a.sv_r[c.toff + (int64_t)i * n + j]);
+          } else {
+            a.res_W[c.toff + (int64_t)i * n + j] = sv;
+            if (paper) a.sv_r[c.toff + (int64_t)i * n + j] = r;
+          }
           rs[di] += sv;
         }
       }
@@ -221,7 +229,10 @@ __device__ __forceinline__ void build_L_chunk(const SgcArgs& a, const SlabCtx& c
       float R = (i == j) ? 1.f : 0.f;              // reference: I - D*W*D elementwise == I
       if (paper) R = R - (si[di] * g.v[di]) * g.sj;  // paper: I - s S s
       L = lrelu(R, alpha);                         // (R * 1.0f: the clip scale is exactly 1)
-      if (ok) a.res_L[c.toff + (int64_t)i * n + j] = L;
+      if (ok) {
+        if (AGCN_SMALL_NT & 8) __builtin_nontemporal_store(L, &a.res_L[c.toff + (int64_t)i * n + j]);
+        else a.res_L[c.toff + (int64_t)i * n + j] = L;
+      }
     }
     Ls[il * CHP + lane] = ok ? L + g.l0[di] : 0.f;
   }
@@ -649,8 +660,13 @@ __global__ __launch_bounds__(256 * Q) void slab_bwd1_kernel_t(SgcArgs a) {
           dalpha_part += dL * fminf(Rv[di], 0.f);
           const float dA = -(dL * lg);                     // dA_ij = -dR_ij
           const float dAt = -((Cc[il * CHP + lane] + upt[di]) * lg);   // dA_ji (R symmetric)
-          a.ws_dA[c.toff + (int64_t)(c.i0 + il) * n + j] = dA;
-          a.ws_dAt[c.toff + (int64_t)(c.i0 + il) * n + j] = dAt;   // (dA_ji, kept row-wise: slab_bwd2 reads no columns)
+          if (AGCN_SMALL_NT & 32) {
+            __builtin_nontemporal_store(dA, &a.ws_dA[c.toff + (int64_t)(c.i0 + il) * n + j]);
+            __builtin_nontemporal_store(dAt, &a.ws_dAt[c.toff + (int64_t)(c.i0 + il) * n + j]);
+          } else {
+            a.ws_dA[c.toff + (int64_t)(c.i0 + il) * n + j] = dA;
+            a.ws_dAt[c.toff + (int64_t)(c.i0 + il) * n + j] = dAt;   // (dA_ji, kept row-wise: slab_bwd2 reads no columns)
+          }
           // ds_i = sum_j dA_ij S_ij s_j + sum_j dA_ji S_ij s_j
           ds[di] += (dA * Sv[di]) * sj + (dAt * Sv[di]) * sj;
         }
@@ -904,7 +920,8 @@ __global__ __launch_bounds__(256) void slab_sim_small_kernel(SgcArgs a) {
       const int il = 4 * wave + di, i = c.i0 + il;
       const float S = small_sim(small_dist<SF>(zI[di], cur.z), i == j);
       if (cv && il < c.nr) {
-        a.res_W[c.toff + (int64_t)i * n + j] = S;
+        if (AGCN_SMALL_NT & 1) __builtin_nontemporal_store(S, &a.res_W[c.toff + (int64_t)i * n + j]);
+        else a.res_W[c.toff + (int64_t)i * n + j] = S;
         rs[di] += S;
       }
     }
@@ -974,7 +991,7 @@ __global__ __launch_bounds__(256) void slab_lap_small_kernel(SgcArgs a) {
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int i = min(c.i0 + 4 * wave + di, n - 1);
-      g.l0[di] = L0d[(int64_t)i * l0ld + jc];
+      g.l0[di] = (AGCN_SMALL_NT & 2) ? __builtin_nontemporal_load(&L0d[(int64_t)i * l0ld + jc]) : L0d[(int64_t)i * l0ld + jc];
     }
     return g;
   };
@@ -997,7 +1014,8 @@ __global__ __launch_bounds__(256) void slab_lap_small_kernel(SgcArgs a) {
       const float Lt = L + cur.l0[di];
       if (cv && il < c.nr) {
         const int64_t o = c.toff + (int64_t)i * n + j;
-        a.res_L[o] = L;
+        if (AGCN_SMALL_NT & 4) __builtin_nontemporal_store(L, &a.res_L[o]);
+        else a.res_L[o] = L;
         if (a.L_sum) a.L_sum[o] = Lt;
 #pragma unroll
         for (int f = 0; f < SF; ++f) accX[di][f] = __builtin_fmaf(Lt, cur.xj[f], accX[di][f]);
