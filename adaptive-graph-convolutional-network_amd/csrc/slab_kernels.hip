@@ -748,8 +748,8 @@ __global__ __launch_bounds__(256) void slab_bwd2_kernel(SgcArgs a) {
       const int64_t o = c.toff + (int64_t)i * n + jc;
       g.dA[di] = a.ws_dA[o];
       g.dAt[di] = a.ws_dAt[o];
-      g.Sv[di] = a.res_W[o];
       g.rv[di] = a.sv_r[o];
+      g.Sv[di] = (i == jc) ? 0.f : slab_exp_neg(g.rv[di]);   // slab_sim's instruction: the same bits as res_W, 4 bytes per pair less to read
     }
     return g;
   };
