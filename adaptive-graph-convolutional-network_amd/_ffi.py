@@ -213,6 +213,19 @@ def check(rc):
         raise AgcnError("agcn error %d: %s" % (rc, lib().agcn_last_error().decode()))
 
 
+def dispatch_info(layer, batch):
+    """agcn_sgc_ll_dispatch_info for `layer` on `batch` (host logic only): list of AGCN_DISPATCH_INFO_INTS ints;
+    [0] = path bits (4 fused | 1 / 2 specialised fwd / bwd, 8 mixed, 16 slab, 32 per-graph, 64 cloud kernels)."""
+    from .functional import _Cfg, _desc, _gbatch
+    cfg = _Cfg(layer.n_atom_feature, layer.nb_filter, layer.K, layer.laplacian_mode, layer._variant,
+               "relu" if layer.activation == "relu" else "linear")
+    desc = _desc(cfg, batch.X.shape[1], cfg.Fout)
+    gb = _gbatch(batch, batch.X, None)
+    out = (C.c_int32 * 8)()
+    check(lib().agcn_sgc_ll_dispatch_info(C.byref(desc), C.byref(gb), out, 8))
+    return list(out)
+
+
 def profile_collect():
     """{kernel name: (total_ms, launches)} since the last collect (needs agcn_profile_enable(1))."""
     import numpy as np

@@ -976,6 +976,101 @@ def test_modelnet_shaped_dense_adjacency(amd, symmetric):
     assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L n=1024", atol_ulps=GRAD_ULPS * k)
 
 
+def _cloud_case(rs, n, Fin, Fout, thresh=1.0):
+    """One point cloud: xyz in the unit cube -> mean-distance-threshold adjacency (meshloader.py:264-285) -> the
+    graph_structure Laplacian; hidden-layer features relu(N(0, 1)) when Fin != 3."""
+    pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+    A = (d < thresh * d.mean()).astype(np.float64)
+    np.fill_diagonal(A, 0)
+    adj = [list(np.nonzero(A[i])[0]) for i in range(n)]
+    _, _, _, L = orc.graph_laplacian(adj)
+    X = pts if Fin == 3 else np.maximum(rs.randn(n, Fin), 0).astype(np.float32)
+    return X, L.astype(np.float32), rs.randn(n, Fout).astype(np.float32)
+
+
+def _run_dense_clouds(amd, sizes, Xs, Ls, Gs, p, Fin, Fout, K, mode):
+    plan = amd.Plan(sizes, 0, DEV)
+    tile_off = plan.tile_off
+    l0_host = np.zeros(int(tile_off[-1]), np.float32)
+    for b, L in enumerate(Ls):
+        l0_host[int(tile_off[b]):int(tile_off[b]) + L.size] = L.reshape(-1)
+    gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0_host).to(DEV),
+                        l0_ld=0, l0_symmetric=True)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(sizes), K, mode, p, DEV)
+    Xt = gb.X.clone().requires_grad_(True)
+    nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+    (nodes.data * torch.from_numpy(np.concatenate(Gs)).to(DEV)).sum().backward()
+    return layer, gb, Xt, nodes, res_L, res_W
+
+
+def _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, kg):
+    Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
+    for b, n in enumerate(sizes):
+        c = caches[b]
+        assert_close(Y[r0:r0 + n], c["Y"], FEATURE_RTOL, f"Y[{b}]", atol_ulps=FEATURE_ULPS * k)
+        w = to_np(res_W[b])
+        assert_close(w, c["S"], FEATURE_RTOL, f"res_W[{b}]", atol_ulps=0)
+        assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
+        if mode == orc.REFERENCE:
+            assert np.array_equal(to_np(res_L[b]), np.eye(n, dtype=np.float32))
+        else:
+            assert_close(to_np(res_L[b]), c["R2"], FEATURE_RTOL, f"res_L[{b}]", atol_ulps=FEATURE_ULPS * k)
+        assert_close(dX[r0:r0 + n], tot["dX"][b], GRAD_RTOL, f"dX[{b}]", atol_ulps=GRAD_ULPS * kg)
+        r0 += n
+    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight", atol_ulps=GRAD_ULPS * kg)
+    assert_close(to_np(layer.vars["bias"].grad), tot["dbias"], GRAD_RTOL, "dbias", atol_ulps=GRAD_ULPS * kg)
+    if mode == orc.PAPER:
+        assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L", atol_ulps=GRAD_ULPS * kg)
+        da = float(np.asarray(tot["dalpha"]).reshape(-1)[0])
+        scale = max(abs(da), float(np.abs(tot["dweight"]).max()))
+        assert abs(float(to_np(layer.vars["alpha"].grad).reshape(-1)[0]) - da) <= GRAD_RTOL * 10 * scale, "dalpha"
+    else:
+        assert layer.vars["M_L"].grad is None
+
+
+@pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
+def test_modelnet_hidden_layer_at_size(amd, mode):
+    """BASELINE config[2], the HIDDEN layer shape whose time the bench quotes: one cloud of n = 1024 points, dense
+    symmetric L_orig, 64 -> 128 (the "MFMA A.X path"; widths: hyper_parameters.py l_n_filters, cloud size:
+    meshloader.py:34-39,264-285).  Every output and every gradient against the float64 oracle on the full tensors,
+    res_W bit-symmetric with a zero diagonal, res_L == I bit for bit in reference mode.  alpha != 1 so that the
+    leaky branch of the learned Laplacian and its gradient are live."""
+    n, Fin, Fout, K = 1024, 64, 128, 2
+    rs = np.random.RandomState(64128)
+    X, L, G = _cloud_case(rs, n, Fin, Fout)
+    X[7] = X[3]                                               # duplicate rows: r_ij = 0 off the diagonal
+    p = orc.init_params(rs, Fin, Fout, K)
+    p["alpha"] = np.array([0.7], dtype=np.float32)
+    p["bias"] = (0.1 * rs.randn(Fout)).astype(np.float32)
+    layer, gb, Xt, nodes, res_L, res_W = _run_dense_clouds(amd, [n], [X], [L], [G], p, Fin, Fout, K, mode)
+    assert (amd._ffi.dispatch_info(layer, gb)[0] & 16) != 0, "n = 1024 must take the slab-parallel kernels"
+    caches, tot = oracle_run([X], [L], p, K, mode, orc.SGC_LL, [G])
+    k = float(np.sqrt(n / 64.0))                              # n-term sums: see test_modelnet_shaped_dense_adjacency
+    _check_dense_clouds([n], caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k)
+
+
+@pytest.mark.parametrize("sizes", [[512, 256, 320, 64], [300, 257, 519, 131]], ids=["multiples_of_64", "ragged"])
+@pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
+def test_point_cloud_batch_hidden_features(amd, mode, sizes):
+    """A multi-cloud batch at the hidden width (Fin = 64, dense symmetric L_orig): clouds that are multiples of the
+    64-column chunks and clouds that are multiples of nothing (partial strips, partial chunks), coincident rows.
+    Every output and gradient against the float64 oracle."""
+    Fin, Fout, K = 64, 128, 2
+    rs = np.random.RandomState(6400 + sizes[0])
+    Xs, Ls, Gs = [], [], []
+    for n in sizes:
+        X, L, G = _cloud_case(rs, n, Fin, Fout, thresh=0.6)
+        Xs.append(X); Ls.append(L); Gs.append(G)
+    Xs[1][5] = Xs[1][4]
+    p = orc.init_params(rs, Fin, Fout, K)
+    p["alpha"] = np.array([1.2], dtype=np.float32)
+    layer, gb, Xt, nodes, res_L, res_W = _run_dense_clouds(amd, sizes, Xs, Ls, Gs, p, Fin, Fout, K, mode)
+    caches, tot = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL, Gs)
+    k = float(np.sqrt(max(sizes) / 64.0))
+    _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k)
+
+
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
 @pytest.mark.parametrize("Fin,Fout", [(3, 64), (2, 32), (4, 128), (1, 16)])
 def test_point_cloud_batch_streaming_kernels(amd, mode, Fin, Fout):

@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--only", default="", help="comma list of workload names")
     ap.add_argument("--modelnet-batch", type=int, default=8)
     ap.add_argument("--prof", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="eager launches instead of HIP-graph replay (profiler runs)")
     ap.add_argument("--epoch-graphs", type=int, default=8192)
     args = ap.parse_args()
     import agcn_amd as amd
@@ -122,8 +123,11 @@ def main():
         layer.load_vars(p)
         dY = torch.from_numpy(np.random.RandomState(7).randn(gb.plan.rows, Fout).astype(np.float32)).to(dev)
         st = amd.SgcLLStep(layer, gb, dY=dY)
-        st.capture()
-        t = timed(st.replay, args.steps, args.warmup, dev)
+        if args.eager:
+            t = timed(st.step, args.steps, args.warmup, dev)
+        else:
+            st.capture()
+            t = timed(st.replay, args.steps, args.warmup, dev)
         fl = flops_layer(n, Fin, Fout, K, args.mode == "paper")
         by = bytes_layer(n, nnz, Fin, Fout, K, dense)
         out = {"workload": name, "mode": args.mode, "graphs": int(len(n)), "N1": int(np.sum(n)),
