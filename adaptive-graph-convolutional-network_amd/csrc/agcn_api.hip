@@ -426,8 +426,12 @@ extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGr
   int cg = 0, cs = 0, dg = 0, cgb = 0, csb = 0, dgb = 0;
   coop_plan(desc, host, fs, false, &cg, &cs, &dg);
   coop_plan(desc, host, fs, true, &cgb, &csb, &dgb);
-  const int path = fs.mode == 1 ? ((fs.spec_fwd ? 1 : 0) | (fs.spec_bwd ? 2 : 0) | 4)      // fused (+ specialised bits)
-                                : (fs.mode == 2 ? 8 : (use_slabs(desc, batch, host.info) ? 16 : 32));
+  int path = fs.mode == 1 ? ((fs.spec_fwd ? 1 : 0) | (fs.spec_bwd ? 2 : 0) | 4)      // fused (+ specialised bits)
+                          : (fs.mode == 2 ? 8 : (use_slabs(desc, batch, host.info) ? 16 : 32));
+  // 64: the slab batch has the shape the point-cloud kernels take (pointer alignment is checked at the call)
+  if (path == 16 && desc->Fin == 64 && batch->L0_dense != nullptr && slab_quad_ok(host) && (desc->ldx & 3) == 0 &&
+      (desc->Fout & 3) == 0 && (desc->ldy & 3) == 0)
+    path |= 64;
   const int32_t v[AGCN_DISPATCH_INFO_INTS] = {path, fs.spec_small_first, cg, cs, dg, cgb, csb, dgb};
   for (int i = 0; i < AGCN_DISPATCH_INFO_INTS; ++i) out[i] = v[i];
   return AGCN_OK;
@@ -438,6 +442,9 @@ extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const voi
   if (check_desc(desc, "agcn_sgc_ll_reserve_bytes") != AGCN_OK || agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;
   return reserve_layout(desc, pi).total + 256;
 }
+
+// layer shapes the point-cloud kernels (cloud_kernels.hip) are compiled for: their forward needs partial-degree scratch
+static bool cloud_shape(const AgcnLayerDesc* d) { return d->variant == AGCN_SGC_LL && d->K == 2 && d->Fin == 64; }
 
 static size_t global_scratch_floats(const AgcnLayerDesc* d, const PlanView& host, bool bwd, Carver* c,
                                     float** tile, float** buf) {
@@ -458,6 +465,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   Carver c(nullptr);
   float *t, *b;
   global_scratch_floats(desc, host, false, &c, &t, &b);
+  if (cloud_shape(desc)) c.take(cloud_dpart_floats(host.info.tile_elems));
   return c.off + 256;
 }
 
@@ -530,7 +538,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
 
   Carver c(workspace);
   const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
-  if (c.off > workspace_bytes || (n_glb > 0 && !workspace))
+  float* dpart = cloud_shape(desc) ? c.take(cloud_dpart_floats(host.info.tile_elems)) : nullptr;
+  if (c.off > workspace_bytes || ((n_glb > 0 || dpart) && !workspace))
     return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, c.off);
 
   a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
@@ -648,6 +657,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
   if (use_slabs(desc, batch, host.info)) {
     // slab_lap also applies the filter to its rows (Y = act([X_0|X_1] . W + b)): no packed FILTER launch
+    if (dpart && cloud_path(a, a.slab_quad != 0) && (reinterpret_cast<uintptr_t>(out->Y) & 15) == 0)
+      return launch_cloud_forward(a, dpart, host.info.max_n, hip_stream);
     return launch_slab_forward(a, hip_stream);
   } else {
   if (n_glb > 0) {
@@ -852,7 +863,11 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd;
     if (slabs) {
-      rc = launch_slab_backward(a, hip_stream);
+      // (either backward works behind either forward: both forwards leave Z, X_1, s and the r tiles)
+      if (cloud_path(a, a.slab_quad != 0) && dL_sum == nullptr && (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0)
+        rc = launch_cloud_backward(a, hip_stream);
+      else
+        rc = launch_slab_backward(a, hip_stream);
       if (rc != AGCN_OK) return rc;
     } else {
     if (w.n_glb > 0) {

@@ -1,0 +1,648 @@
+// Point-cloud ("cloud") kernels: SGC_LL, K = 2, hidden-layer width Fin = 64, DENSE symmetric L_orig, every graph a
+// multiple of 64 nodes (ModelNet-shaped batches, n = 1024: BASELINE config 3, the "MFMA A.X path").  Same math as
+// slab_kernels.hip (graphconv.py:163-236 and its TF autodiff) -- the n x n work of a graph cut into row strips walked
+// in 64-column chunks -- rebuilt around what the general slab kernels measured as their limits at this size
+// (profiles/r03a_modelnet_baseline_*: bwd1 358 us at 23 % matrix-pipe utilisation and 700 MB of traffic):
+//
+//  * 64-row strips, one wave per 16 rows.  The chunk's 64 rows of X_0 / g_1 / Z (the B operands of every product) are
+//    staged in LDS ONCE per workgroup and chunk with fully coalesced 16-byte loads and serve four waves (the 16-row
+//    strips fetched them from L2 once per strip, as 16-rows-by-64-bytes gathers for the transposed products).
+//  * every n x n element is touched in the MFMA accumulator layout (lane (r, q) <-> rows 4q..4q+3, column r of a 16 x 16
+//    tile): tiles are loaded / stored as 4 rows x 64 bytes per instruction, the element-wise math runs on the
+//    accumulator registers of the products it belongs to, and only L (the A operand of the next product) goes through a
+//    WAVE-PRIVATE LDS strip -- no workgroup barrier besides the two around the staging.
+//  * all fragment reads are 16 bytes wide: images have a leading dimension of 72 floats (conflict-free ds_read_b128 for
+//    "row r, columns 16 blk + 4q .. + 3"), the k index of every product is permuted inside 16-blocks accordingly, and
+//    the row-major products take their B operand as B[k][4r .. 4r + 3], which makes lane r own the output columns
+//    4r .. 4r + 3 (a 16-byte store).
+//  * the backward keeps ONE n x n tile between its two kernels instead of two: only Q_ij = dA_ij + dA_ji is ever used
+//    (ds_i = sum_j Q_ij S_ij s_j, c_ij = -S_ij (Q_ij s_i s_j + dd_i + dd_j) / r_ij, dalpha = 1/2 sum P_ij min(R_ij, 0)
+//    with P = dL + dL^T: R and S are symmetric), and P is ONE product of depth 2 Fin: [g_1 | X_0][I] . [X_0 | g_1][J]^T.
+//  * the similarity kernel keeps a column's Z row in 64 registers and reads the row operand through the SCALAR cache
+//    (uniform address, constant address space -> s_load): two vector instructions per pair and feature, no LDS at all
+//    (the LDS-staged 4 x 2 register blocks of slab_sim are bound by LDS bandwidth: 198 us against 58 us of issue time).
+//    Column sums over a wave's 64 rows are complete per (row block, column) and go out as partial degrees; a tiny
+//    kernel adds the n / 64 partials of a node in fixed order (S is bit-symmetric: column sums == row sums).
+// Reductions are per-lane sequential + fixed shuffle trees: bit-reproducible.  No floating-point atomics.
+#include "agcn_device.h"
+#include "sgc_kernels.h"
+
+#include <float.h>
+
+#include <cstdlib>
+
+namespace agcn {
+
+namespace {
+constexpr int FIN = 64;     // feature width these kernels are compiled for
+constexpr int CS = 64;      // rows per workgroup (4 waves x 16)
+constexpr int CC = 64;      // columns per chunk
+constexpr int LD = 72;      // leading dimension of every LDS image (floats): 72 mod 64 = 8 -> conflict-free b128 rows
+constexpr float NLOG2E = -1.44269504088896341f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// sixteen consecutive floats at a wave-uniform address -> SGPRs (scalar cache); SWAIT2 = s_waitcnt lgkmcnt(0), tied to the
+// registers it guards so that no use of them is scheduled above it
+#define SLOAD16(dst, ptr, off) asm volatile("s_load_dwordx16 %0, %1, " off : "=s"(dst) : "s"(ptr))
+// the same, ordered BEFORE every later use of `keep` (a fake read-modify-write of it): the arithmetic on the buffer in
+// use cannot be scheduled in front of the request for the other buffer
+#define SLOAD16_BEFORE(dst, ptr, off, keep) asm volatile("s_load_dwordx16 %0, %2, " off : "=&s"(dst), "+s"(keep) : "s"(ptr))
+// ... and ordered AFTER the arithmetic that produced `dep` (a vector register)
+#define SWAIT2(x, y, dep) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y), "+v"(dep))
+
+struct WaveCtx { int b, i0, n, row0; int64_t toff; };
+// wave `slab` of the plan's 16-row slab table (uniform per wave: everything lands in scalar registers)
+__device__ __forceinline__ WaveCtx wave_ctx(const SgcArgs& a, int slab) {
+  WaveCtx c;
+  c.b = a.slab_graph[slab];
+  c.i0 = a.slab_row[slab];
+  c.n = a.n[c.b];
+  c.row0 = a.row_off[c.b];
+  c.toff = a.tile_off[c.b];
+  return c;
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// sum over the 16 lanes that share q (= the 16 columns of a tile row), result in each of them
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// acc[e] (rows 4q + i, column 4r + e) += A[16 x 64] . B[64 x 64]
+//   A: wave-private image [16][LD], k = image column;  B: image [k][c] (the chunk's rows), both read 16 bytes wide.
+//   MFMA step j of block blk pairs A[r][16 blk + 4q + j] with B[16 blk + 4q + j][4r + e].
+__device__ __forceinline__ void strip_mma(f32x4 (&acc)[4], const float* A, const float* B, int r, int q) {
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(A + r * LD + 16 * blk + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(B + (16 * blk + 4 * q + j) * LD + 4 * r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = mfma4(av[j], bv[e], acc[e]);
+    }
+  }
+}
+
+// The chunk's 64 rows of a [rows][ld] matrix -> registers (four coalesced 16-byte loads per thread: a wave-load covers
+// 4 rows x 256 bytes) -> LDS image [64][LD].
+struct StageRegs { f32x4 v[4]; };
+__device__ __forceinline__ StageRegs stage_load(const float* src, int ld, int c0) {
+  const int tid = threadIdx.x;
+  StageRegs s;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    s.v[m] = *reinterpret_cast<const f32x4*>(src + (int64_t)(c0 + (tid >> 4) + 16 * m) * ld + 4 * (tid & 15));
+  return s;
+}
+// Chunk row rho lands in image row 16 (rho % 4) + rho / 4: tile t of the accumulator layout then stands for the chunk
+// columns 4r + t (lane r), i.e. a lane's four tiles are four CONSECUTIVE columns of the n x n matrices -- every tile
+// access to global memory is one 16-byte load / store per row -- while the images are still indexed 16 t + r.
+__device__ __forceinline__ void stage_store(float* img, const StageRegs& s) {
+  const int tid = threadIdx.x, rho = tid >> 4;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    *reinterpret_cast<f32x4*>(img + (16 * (rho & 3) + (rho >> 2) + 4 * m) * LD + 4 * (tid & 15)) = s.v[m];
+}
+
+__device__ __forceinline__ const float* dense_l0(const SgcArgs& a, const WaveCtx& c, int* ld) {
+  *ld = a.L0_ld > 0 ? a.L0_ld : c.n;
+  return a.L0_ld > 0 ? a.L0_dense + (int64_t)c.b * a.L0_ld * a.L0_ld : a.L0_dense + c.toff;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// forward 1: S = exp(-||Z_i - Z_j||) (graphconv.py:163-180) -> res_W, r -> reserve (paper mode), partial degrees.
+// Workgroup = one 64-row block of a graph x a quarter of its column blocks; a wave = one column per lane.
+__global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int slab0 = 4 * (int)blockIdx.x;
+  const int b = a.slab_graph[slab0], r0 = a.slab_row[slab0];
+  const int n = a.n[b], row0 = a.row_off[b];
+  const int64_t toff = a.tile_off[b];
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
+  float* dp = dpart + (toff >> 6) + (int64_t)(r0 >> 6) * n;   // partial degrees of this row block: [n / 64][n] per graph
+  const int ncb = n >> 6;
+  __shared__ __attribute__((aligned(16))) float trbuf[4][2][4 * 64];
+  float* trS = trbuf[wave][0];
+  float* trR = trbuf[wave][1];
+  for (int jb = wave + 4 * (int)blockIdx.y; jb < ncb; jb += 4 * (int)gridDim.y) {
+    const int j = 64 * jb + lane;
+    float zj[FIN];
+    {
+      const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)j * FIN);
+#pragma unroll
+      for (int f4 = 0; f4 < FIN / 4; ++f4) {
+        const f32x4 t = zp[f4];
+        zj[4 * f4 + 0] = t.x; zj[4 * f4 + 1] = t.y; zj[4 * f4 + 2] = t.z; zj[4 * f4 + 3] = t.w;
+      }
+    }
+    float cs = 0.f;
+    // 16-byte stores: a lane holds ONE column, so four rows of S (and r) are turned through a wave-private LDS patch
+    // [4][64] and leave as one dwordx4 per lane (row lane / 16, columns 4 (lane % 16) ..): dword-per-lane stores are
+    // bound by store ISSUE at ~2.4 TB/s on this chip (measured here: 110 us for 268 MB), 16-byte ones are not
+    float* wout = a.res_W + toff + (int64_t)(r0 + (lane >> 4)) * n + 64 * jb + 4 * (lane & 15);
+    float* rout = a.sv_r + toff + (int64_t)(r0 + (lane >> 4)) * n + 64 * jb + 4 * (lane & 15);
+    // The row operand z_i comes through the scalar cache into SGPRs (uniform address), half a row (32 features = two
+    // s_load_dwordx16) at a time into one of two buffers: the half after the one being consumed is requested right
+    // behind the wait for the current one -- scalar loads return out of order, so the only usable wait is
+    // lgkmcnt(0), and a request has the 64 vector instructions of a half row to arrive (the compiler's own schedule
+    // put 8 instructions between request and wait: 175 us for this kernel against 58 us of issue time).
+    const float* zrow = Zg + (int64_t)r0 * FIN;
+    f32x16 A0, A1, B0, B1;
+    SLOAD16(A0, zrow, "0x0");
+    SLOAD16(A1, zrow, "0x40");
+#pragma unroll 1
+    for (int i4 = 0; i4 < CS; i4 += 4) {
+#pragma unroll 1
+      for (int u = 0; u < 4; ++u) {
+        const int ii = i4 + u;
+        float acc = 0.f;
+        SWAIT2(A0, A1, cs);
+        SLOAD16_BEFORE(B0, zrow, "0x80", A0);
+        SLOAD16_BEFORE(B1, zrow, "0xc0", A1);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { const float d = A0[f] - zj[f]; acc = __builtin_fmaf(d, d, acc); }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { const float d = A1[f] - zj[16 + f]; acc = __builtin_fmaf(d, d, acc); }
+        SWAIT2(B0, B1, acc);
+        zrow += (ii + 1 < CS) ? FIN : 0;      // (the last request re-reads the last row: never used)
+        SLOAD16_BEFORE(A0, zrow, "0x0", B0);
+        SLOAD16_BEFORE(A1, zrow, "0x40", B1);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { const float d = B0[f] - zj[32 + f]; acc = __builtin_fmaf(d, d, acc); }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { const float d = B1[f] - zj[48 + f]; acc = __builtin_fmaf(d, d, acc); }
+        // ((z_i - z_j)^2 == (z_j - z_i)^2 and the same f order for both orientations of a pair: S bit-symmetric)
+        const float rr = __builtin_amdgcn_sqrtf(acc);
+        // S_ii = 0 (graphconv.py:171-173); exp(-1 * norm) otherwise (:176-177)
+        const float S = (r0 + ii == j) ? 0.f : __builtin_amdgcn_exp2f(rr * NLOG2E);
+        trS[u * 64 + lane] = S;
+        if (paper) trR[u * 64 + lane] = rr;
+        cs += S;
+      }
+      __builtin_amdgcn_wave_barrier();
+      *reinterpret_cast<f32x4*>(wout + (int64_t)i4 * n) = *reinterpret_cast<const f32x4*>(trS + 4 * lane);
+      if (paper) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(trR + 4 * lane), reinterpret_cast<f32x4*>(rout + (int64_t)i4 * n));
+      __builtin_amdgcn_wave_barrier();
+    }
+    SWAIT2(A0, A1, cs);                      // (nothing of this column block's requests is left in flight)
+    dp[j] = cs;
+  }
+}
+
+// forward 2: d_j = sum of the n / 64 partial column sums in row-block order + np.spacing(0) (graphconv.py:195-196),
+// s = d^-1/2 (:197).  One 64-thread workgroup per 64-row block.
+__global__ __launch_bounds__(64) void cloud_degree_kernel(SgcArgs a, const float* dpart) {
+  const int slab0 = 4 * (int)blockIdx.x;
+  const int b = a.slab_graph[slab0], r0 = a.slab_row[slab0];
+  const int n = a.n[b], row0 = a.row_off[b];
+  const int64_t toff = a.tile_off[b];
+  const int j = r0 + (int)threadIdx.x;
+  const float* dp = dpart + (toff >> 6) + j;
+  float d = 0.f;
+  for (int rb = 0; rb < (n >> 6); ++rb) d += dp[(int64_t)rb * n];
+  a.sv_s[row0 + j] = 1.0f / sqrtf(d + FLT_TRUE_MIN);
+  if (r0 == 0 && threadIdx.x == 0) {   // clip_by_average_norm(R, 1) never clips for SGC_LL: scale exactly 1
+    float* sc = a.sv_scal + 4 * b;
+    sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile convention of the three strip kernels below: a wave owns 16 rows; of a 64-column chunk lane (r, q) holds, for
+// its rows 4q + i (i = 0..3), the four columns c0 + 4r + t (t = 0..3) as ONE f32x4 -- component t is the lane's element
+// of accumulator tile t, whose image index (column of the L / c strips, row of the staged chunk images) is 16 t + r.
+
+// forward 3: R = I - s S s (paper) | I (reference), res_L = lrelu(R), L = res_L + L_orig, X_1[I] = L[I, :] X_0
+// (graphconv.py:198-231) and the filter product Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b) (:238-251, 117-123).
+template <bool PAPER>
+__global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WaveCtx c = wave_ctx(a, 4 * (int)blockIdx.x + wave);
+  const int n = c.n;
+  float* Bs = smem;                             // [64][LD]  the chunk's rows of X_0
+  float* Ls = smem + CC * LD + wave * (16 * LD);   // [16][LD]  this wave's strip of L
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  int l0ld;
+  const float* L0d = dense_l0(a, c, &l0ld);
+  const float* Wt = a.res_W + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  float* RLt = a.res_L + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  float* LSt = a.L_sum ? a.L_sum + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r : nullptr;
+  const float* L0t = L0d + (int64_t)(c.i0 + 4 * q) * l0ld + 4 * r;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  float si[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) si[i] = PAPER ? a.sv_s[c.row0 + c.i0 + 4 * q + i] : 0.f;
+
+  struct Tiles { f32x4 s[4], l0[4], sj; };
+  auto load_tiles = [&](int c0) {
+    Tiles g;
+    g.sj = PAPER ? *reinterpret_cast<const f32x4*>(sjp + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.s[i] = PAPER ? *reinterpret_cast<const f32x4*>(Wt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
+    }
+    return g;
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  StageRegs pre = stage_load(Xg, a.ldx, 0);
+  Tiles cur = load_tiles(0);
+#pragma unroll 1
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    __syncthreads();                  // every wave is done with the previous chunk's rows
+    stage_store(Bs, pre);
+    __syncthreads();
+    Tiles nxt = cur;
+    if (c0 + CC < n) {                // the next chunk's loads in flight behind this chunk's arithmetic
+      pre = stage_load(Xg, a.ldx, c0 + CC);
+      nxt = load_tiles(c0 + CC);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+      f32x4 Lv, Ltv;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float R = (row == c0 + 4 * r + t) ? 1.f : 0.f;                // reference: I - D*W*D elementwise == I
+        if (PAPER) R = R - (si[i] * cur.s[i][t]) * cur.sj[t];          // paper: I - s S s
+        Lv[t] = lrelu(R, alpha);                                      // (R * 1.0f: the clip scale is exactly 1)
+        Ltv[t] = Lv[t] + cur.l0[i][t];
+        Ls[(4 * q + i) * LD + 16 * t + r] = Ltv[t];
+      }
+      __builtin_nontemporal_store(Lv, reinterpret_cast<f32x4*>(RLt + (int64_t)i * n + c0));
+      if (LSt) *reinterpret_cast<f32x4*>(LSt + (int64_t)i * n + c0) = Ltv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    strip_mma(acc, Ls, Bs, r, q);
+    cur = nxt;
+  }
+  // X_1[I] = L[I, :] X_0 -> reserve; and, with X_0[I], the A images of the filter product
+  __syncthreads();                    // the chunk image is dead: its space holds the X_0[I] images now
+  float* X0s = smem + wave * (16 * LD);   // (inside Bs: 4 x 16 rows)
+  float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * FIN;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 v = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+    *reinterpret_cast<f32x4*>(Xo + (int64_t)(4 * q + i) * FIN + 4 * r) = v;
+    *reinterpret_cast<f32x4*>(Ls + (4 * q + i) * LD + 4 * r) = v;
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = q + 4 * m;
+    *reinterpret_cast<f32x4*>(X0s + row * LD + 4 * r) =
+        *reinterpret_cast<const f32x4*>(Xg + (int64_t)(c.i0 + row) * a.ldx + 4 * r);
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int Fout = a.Fout, K = a.K;
+    const bool relu = a.activation == AGCN_ACT_RELU;
+    float* Yg = a.Y + (int64_t)(c.row0 + c.i0) * a.ldy;
+    for (int h = 0; 64 * h < Fout; ++h) {
+      const int col = 64 * h + 4 * r;
+      const bool cok = col < Fout;                       // (Fout is a multiple of 4: a 16-byte group is whole or absent)
+      const int cc = cok ? col : Fout - 4;
+      f32x4 y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const float* A = kk == 0 ? X0s : Ls;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(A + r * LD + 16 * blk + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int f = 16 * blk + 4 * q + j;          // weight row f * K + k (graphconv.py:243: column f*K + k)
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.weight + (int64_t)(f * K + kk) * Fout + cc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mfma4(av[j], bv[e], y[e]);
+          }
+        }
+      }
+      if (cok) {
+        const f32x4 bc = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v = (f32x4){y[0][i] + bc.x, y[1][i] + bc.y, y[2][i] + bc.z, y[3][i] + bc.w};
+          if (relu) v = (f32x4){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+          *reinterpret_cast<f32x4*>(Yg + (int64_t)(4 * q + i) * a.ldy + col) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 1: dX[I] += L[I, :] g_1 (L symmetric);  paper: P = dL + dL^T = [g_1 | X_0][I] . [X_0 | g_1][J]^T,
+// Q = -lrelu'(R) P -> workspace, ds_i = sum_j Q_ij S_ij s_j -> dd_i, dalpha = 1/2 sum P_ij min(R_ij, 0).
+template <bool PAPER>
+__global__ __launch_bounds__(256) void cloud_bwd1_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slab = 4 * (int)blockIdx.x + wave;
+  const WaveCtx c = wave_ctx(a, slab);
+  const int n = c.n;
+  float* Gs = smem;                                  // [64][LD]  g_1 rows of the chunk
+  float* Xs = smem + CC * LD;                        // [64][LD]  X_0 rows of the chunk (paper)
+  float* Ls = smem + (PAPER ? 2 : 1) * CC * LD + wave * (16 * LD);   // [16][LD] this wave's strip of L
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * FIN;   // adjoint of X_1 (K = 2: plane 0)
+  int l0ld;
+  const float* L0d = dense_l0(a, c, &l0ld);
+  const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* L0t = L0d + (int64_t)(c.i0 + 4 * q) * l0ld + 4 * r;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  float si[4];
+  f32x4 gIf[4], xIf[4];   // A fragments of the wave's own rows: lane (r, q) holds [row r][16 kb + 4q .. + 3]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) si[i] = PAPER ? a.sv_s[c.row0 + c.i0 + 4 * q + i] : 0.f;
+  if (PAPER) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      gIf[kb] = *reinterpret_cast<const f32x4*>(g1 + (int64_t)(c.i0 + r) * FIN + 16 * kb + 4 * q);
+      xIf[kb] = *reinterpret_cast<const f32x4*>(Xg + (int64_t)(c.i0 + r) * a.ldx + 16 * kb + 4 * q);
+    }
+  }
+  struct Tiles { f32x4 rv[4], l0[4], sj; };
+  auto load_tiles = [&](int c0) {
+    Tiles g;
+    g.sj = PAPER ? *reinterpret_cast<const f32x4*>(sjp + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.rv[i] = PAPER ? *reinterpret_cast<const f32x4*>(Rt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
+    }
+    return g;
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ds[4] = {0.f, 0.f, 0.f, 0.f};
+  float dalpha_part = 0.f;
+  StageRegs preG = stage_load(g1, FIN, 0), preX;
+  if (PAPER) preX = stage_load(Xg, a.ldx, 0);
+  Tiles cur = load_tiles(0);
+#pragma unroll 1
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    __syncthreads();
+    stage_store(Gs, preG);
+    if (PAPER) stage_store(Xs, preX);
+    __syncthreads();
+    Tiles nxt = cur;
+    if (c0 + CC < n) {
+      preG = stage_load(g1, FIN, c0 + CC);
+      if (PAPER) preX = stage_load(Xg, a.ldx, c0 + CC);
+      nxt = load_tiles(c0 + CC);
+    }
+    f32x4 S[4], R[4];     // [i][t]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool diag = row == c0 + 4 * r + t;
+        S[i][t] = (!PAPER || diag) ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);   // cloud_sim's instruction
+        R[i][t] = diag ? 1.f : 0.f;
+        if (PAPER) R[i][t] = R[i][t] - (si[i] * S[i][t]) * cur.sj[t];                         // cloud_lap's instruction
+        Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(R[i][t], alpha) + cur.l0[i][t];
+      }
+    }
+    if (PAPER) {
+      f32x4 Qv[4];         // [i][t]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        // P[I, tile] = g_1[I] . X_0[tile]^T + X_0[I] . g_1[tile]^T   (two independent accumulation chains)
+        f32x4 Pa = (f32x4){0.f, 0.f, 0.f, 0.f}, Pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const f32x4 bx = *reinterpret_cast<const f32x4*>(Xs + (16 * t + r) * LD + 16 * kb + 4 * q);
+          const f32x4 bg = *reinterpret_cast<const f32x4*>(Gs + (16 * t + r) * LD + 16 * kb + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            Pa = mfma4(gIf[kb][j], bx[j], Pa);
+            Pb = mfma4(xIf[kb][j], bg[j], Pb);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float P = Pa[i] + Pb[i];
+          dalpha_part = __builtin_fmaf(P, fminf(R[i][t], 0.f), dalpha_part);
+          const float Q = -(P * lrelu_grad(R[i][t], alpha));     // dA_ij + dA_ji, dA = -dR
+          Qv[i][t] = Q;
+          ds[i] = __builtin_fmaf(Q * S[i][t], cur.sj[t], ds[i]);  // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = Qv[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
+    cur = nxt;
+  }
+  // dX rows of the strip (g_0 already there from the packed filter adjoint)
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4* p = reinterpret_cast<f32x4*>(dXg + (int64_t)(4 * q + i) * a.ldx + 4 * r);
+    f32x4 v = *p;
+    v.x += acc[0][i]; v.y += acc[1][i]; v.z += acc[2][i]; v.w += acc[3][i];
+    *p = v;
+  }
+  if (PAPER) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = row16_sum(ds[i]);
+      if (r == 0) a.ws_dd[c.row0 + c.i0 + 4 * q + i] = degree_grad(si[i], t);   // dd_k = -1/2 s_k^3 ds_k
+    }
+  }
+  const float da = wave_sum_all(dalpha_part);
+  if (lane == 0) {
+    a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = 0.5f * da;
+    a.ws_pg[2 * (a.pg_slab_base + slab) + 1] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 2 (paper mode): c_ij = -S_ij (Q_ij s_i s_j + dd_i + dd_j) / r_ij (0 where r_ij = 0 or S_ij = 0),
+// dZ[I] = rowsum(c) Z[I] - c Z, dX[I] += dZ[I] M_L^T.
+__global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WaveCtx c = wave_ctx(a, 4 * (int)blockIdx.x + wave);
+  const int n = c.n;
+  float* Zs = smem;                                  // [64][LD]  Z rows of the chunk
+  float* Cs = smem + CC * LD + wave * (16 * LD);     // [16][LD]  this wave's strip of c
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * FIN;
+  const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  const float* ddp = a.ws_dd + c.row0 + 4 * r;
+  float si[4], ddi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    si[i] = a.sv_s[c.row0 + c.i0 + 4 * q + i];
+    ddi[i] = a.ws_dd[c.row0 + c.i0 + 4 * q + i];
+  }
+  struct Tiles { f32x4 rv[4], qv[4], sj, ddj; };
+  auto load_tiles = [&](int c0) {
+    Tiles g;
+    g.sj = *reinterpret_cast<const f32x4*>(sjp + c0);
+    g.ddj = *reinterpret_cast<const f32x4*>(ddp + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.rv[i] = *reinterpret_cast<const f32x4*>(Rt + (int64_t)i * n + c0);
+      g.qv[i] = *reinterpret_cast<const f32x4*>(Qt + (int64_t)i * n + c0);
+    }
+    return g;
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  StageRegs pre = stage_load(Zg, FIN, 0);
+  Tiles cur = load_tiles(0);
+#pragma unroll 1
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    __syncthreads();
+    stage_store(Zs, pre);
+    __syncthreads();
+    Tiles nxt = cur;
+    if (c0 + CC < n) {
+      pre = stage_load(Zg, FIN, c0 + CC);
+      nxt = load_tiles(c0 + CC);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float rr = cur.rv[i][t];
+        const float S = __builtin_amdgcn_exp2f(rr * NLOG2E);      // cloud_sim's instruction
+        // dS_ij = dA_ij s_i s_j + dd_j, dr_ij = -S_ij dS_ij; the pair (i, j) contributes dr_ij + dr_ji
+        const float dr = -(S * __builtin_fmaf(cur.qv[i][t] * si[i], cur.sj[t], ddi[i] + cur.ddj[t]));
+        // r == 0 (coincident rows): the term is defined as 0; S == 0 (underflow): dr = 0, never inf * 0
+        const bool ok = row != c0 + 4 * r + t && rr > 0.f && S != 0.f;
+        const float cij = ok ? dr * __builtin_amdgcn_rcpf(rr) : 0.f;
+        cs[i] += cij;
+        Cs[(4 * q + i) * LD + 16 * t + r] = cij;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    strip_mma(acc, Cs, Zs, r, q);
+    cur = nxt;
+  }
+  // dZ_i = rowsum(c)_i Z_i - (c Z)_i -> workspace (for dM_L) and the A image of the product below
+  float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * FIN;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float csum = row16_sum(cs[i]);
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Zg + (int64_t)(c.i0 + 4 * q + i) * FIN + 4 * r);
+    const f32x4 v = (f32x4){csum * z.x - acc[0][i], csum * z.y - acc[1][i], csum * z.z - acc[2][i], csum * z.w - acc[3][i]};
+    *reinterpret_cast<f32x4*>(dZg + (int64_t)(4 * q + i) * FIN + 4 * r) = v;
+    *reinterpret_cast<f32x4*>(Cs + (4 * q + i) * LD + 4 * r) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // dX[I] += dZ[I] M_L^T   (adjoint of graphconv.py:164): B[k][f] = M_L[f][k], the lane's M_L rows read along k; tile t
+  // stands for the output columns 4r + t, so a lane's four results of a row are one 16-byte read-modify-write
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+  f32x4 d[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(Cs + r * LD + 16 * blk + 4 * q);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.M_L + (int64_t)(4 * r + t) * FIN + 16 * blk + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[t] = mfma4(av[j], bv[j], d[t]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4* p = reinterpret_cast<f32x4*>(dXg + (int64_t)(4 * q + i) * a.ldx + 4 * r);
+    f32x4 v = *p;
+    v.x += d[0][i]; v.y += d[1][i]; v.z += d[2][i]; v.w += d[3][i];
+    *p = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+bool cloud_env() {
+  static const int off = [] { const char* e = std::getenv("AGCN_CLOUD"); return (e && e[0] == '0') ? 1 : 0; }();
+  return !off;
+}
+template <class K, class... A>
+int launch_cloud(K kernel, dim3 grid, int threads, size_t lds, int prof_id, const char* what, void* stream, A... args) {
+  if (grid.x == 0) return AGCN_OK;
+  prof_begin(prof_id, stream);
+  hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, static_cast<hipStream_t>(stream), args...);
+  prof_end(stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s launch: %s", what, hipGetErrorString(e));
+  return AGCN_OK;
+}
+}  // namespace
+
+// Which slab batches these kernels take: the forward and the backward of a call pair must agree (same answer from the
+// same arguments).  `quad` = every graph a multiple of 64 nodes.
+bool cloud_path(const SgcArgs& a, bool quad) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return cloud_env() && quad && a.Fin == FIN && a.K == 2 && a.variant == AGCN_SGC_LL && a.L0_dense != nullptr &&
+         (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 3) == 0 && al16(a.X) && al16(a.weight) && al16(a.bias) &&
+         al16(a.M_L) && (a.n_slabs & 3) == 0;
+}
+size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / 64 + 64); }
+
+int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* stream) {
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const unsigned strips = (unsigned)(a.n_slabs / 4);
+  // column blocks are dealt to 4 waves x gridDim.y workgroups: enough waves to fill the chip, at least one column block each
+  const unsigned ys = (unsigned)std::max(1, std::min(4, max_n / 256));
+  int rc = launch_cloud(cloud_sim_kernel, dim3(strips, ys), 256, 0, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart);
+  if (rc != AGCN_OK) return rc;
+  rc = launch_cloud(cloud_degree_kernel, dim3(strips), 64, 0, PK_CLOUD_DEG, "cloud_degree", stream, a, (const float*)dpart);
+  if (rc != AGCN_OK) return rc;
+  const size_t lds = sizeof(float) * (CC * LD + 4 * 16 * LD);
+  return paper ? launch_cloud(cloud_lap_kernel<true>, dim3(strips), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a)
+               : launch_cloud(cloud_lap_kernel<false>, dim3(strips), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a);
+}
+
+int launch_cloud_backward(const SgcArgs& a, void* stream) {
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const unsigned strips = (unsigned)(a.n_slabs / 4);
+  if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "cloud kernels: a gradient of L_sum is not supported");
+  if (!paper)
+    return launch_cloud(cloud_bwd1_kernel<false>, dim3(strips), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
+                        "cloud_bwd1", stream, a);
+  int rc = launch_cloud(cloud_bwd1_kernel<true>, dim3(strips), 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
+                        "cloud_bwd1", stream, a);
+  if (rc != AGCN_OK) return rc;
+  return launch_cloud(cloud_bwd2_kernel, dim3(strips), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2",
+                      stream, a);
+}
+
+}  // namespace agcn

@@ -122,7 +122,8 @@ struct ParamGradArgs {
 // profiling ids (profile.hip)
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
        PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD,
-       PK_PARAM_ONEPASS, PK_SPEC_FWD, PK_SPEC_BWD, PK_COUNT };
+       PK_PARAM_ONEPASS, PK_SPEC_FWD, PK_SPEC_BWD, PK_CLOUD_SIM, PK_CLOUD_DEG, PK_CLOUD_LAP, PK_CLOUD_BWD1,
+       PK_CLOUD_BWD2, PK_COUNT };
 // Raises a kernel's dynamic-LDS cap (hipFuncAttributeMaxDynamicSharedMemorySize) once per kernel and size: the
 // driver call is skipped when the cap already covers `bytes` (it costs several microseconds per launch otherwise).
 // Tracked per (device, kernel).  Returns hipSuccess (0) or the HIP error code.
@@ -160,6 +161,11 @@ int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t
 bool slab_path_fits(int32_t Fin);
 int launch_slab_forward(const SgcArgs& a, void* stream);
 int launch_slab_backward(const SgcArgs& a, void* stream);
+// point-cloud kernels (cloud_kernels.hip): slab batches with Fin = 64, dense L_orig, every graph a multiple of 64 nodes
+bool cloud_path(const SgcArgs& a, bool quad);
+size_t cloud_dpart_floats(int64_t tile_elems);   // forward workspace: partial degrees
+int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* stream);
+int launch_cloud_backward(const SgcArgs& a, void* stream);
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper);
 // the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number
