@@ -469,7 +469,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -492,6 +492,7 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
                             param_grad_onepass_floats(pi.rows, d->Fin, d->Fout, d->K, paper ? 1 : 0));
   w->part = c.take(w->part_floats);
   w->n_glb = (int)global_scratch_floats(d, host, true, &c, &w->tile, &w->buf);
+  w->WT = cloud_shape(d) ? c.take((size_t)d->K * d->Fout * d->Fin) : nullptr;   // cloud kernels: W^T for the filter adjoint
   return c.off;
 }
 
@@ -642,6 +643,10 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
       return fail(AGCN_EDEVICE, "%s: stream join failed", who);
     return AGCN_OK;
   }
+  // point clouds (cloud_kernels.hip): projection, similarity, degree, Laplacian + Chebyshev + filter in four launches
+  if (use_slabs(desc, batch, host.info) && dpart && cloud_path(a, a.slab_quad != 0) &&
+      (reinterpret_cast<uintptr_t>(out->Y) & 15) == 0)
+    return launch_cloud_forward(a, dpart, host.info.max_n, hip_stream);
   // 1. Z = X . M_L over the packed rows (graphconv.py:164)
   RowsGemmArgs g;
   fill_rows(g, desc, host, dev);
@@ -657,8 +662,6 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
   if (use_slabs(desc, batch, host.info)) {
     // slab_lap also applies the filter to its rows (Y = act([X_0|X_1] . W + b)): no packed FILTER launch
-    if (dpart && cloud_path(a, a.slab_quad != 0) && (reinterpret_cast<uintptr_t>(out->Y) & 15) == 0)
-      return launch_cloud_forward(a, dpart, host.info.max_n, hip_stream);
     return launch_slab_forward(a, hip_stream);
   } else {
   if (n_glb > 0) {
@@ -740,6 +743,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   const bool slabs = use_slabs(desc, batch, host.info);
   const FusedSplit fs = fused_split(desc, batch, host);
   const bool fused = fs.mode != 0;
+  bool cloud_bwd = false;
   // arrival counters of the one-pass parameter-gradient kernel: zeroed by the first kernel of this call
   int32_t n_counters = 0;
   int32_t* counters = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, desc->K,
@@ -848,8 +852,19 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         return fail(AGCN_EDEVICE, "%s: stream join failed", who);
     }
   } else if (stages & 1) {
-    // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace
+    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.slab_quad = slab_quad_ok(host);
+    a.sv_r = reinterpret_cast<float*>(rb + rl.r);
+    a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd; a.ws_Gp = w.Gp;
+    // point clouds: either backward works behind either forward (both forwards leave Z, X_1, s and the r tiles)
+    cloud_bwd = slabs && w.WT && cloud_path(a, a.slab_quad != 0) && dL_sum == nullptr &&
+                (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
     RowsGemmArgs g;
+    if (cloud_bwd) {
+      rc = launch_cloud_backward(a, w.WT, hip_stream);
+      if (rc != AGCN_OK) return rc;
+    } else {
+    // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace
     fill_rows(g, desc, host, dev);
     g.Kd = desc->Fout; g.N = desc->Fin * desc->K;
     g.A0 = dY; g.lda0 = desc->ldy; g.Yact = fwd->Y; g.ldy = desc->ldy; g.Bm = params->weight;
@@ -858,16 +873,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
     if (rc != AGCN_OK) return rc;
     // 2. graph-local adjoints
-    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
-    a.slab_quad = slab_quad_ok(host);
-    a.sv_r = reinterpret_cast<float*>(rb + rl.r);
-    a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd;
     if (slabs) {
-      // (either backward works behind either forward: both forwards leave Z, X_1, s and the r tiles)
-      if (cloud_path(a, a.slab_quad != 0) && dL_sum == nullptr && (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0)
-        rc = launch_cloud_backward(a, hip_stream);
-      else
-        rc = launch_slab_backward(a, hip_stream);
+      rc = launch_slab_backward(a, hip_stream);
       if (rc != AGCN_OK) return rc;
     } else {
     if (w.n_glb > 0) {
@@ -889,6 +896,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       rc = launch_rows_gemm(g, RG_PROJECT_BWD, hip_stream);
       if (rc != AGCN_OK) return rc;
     }
+    }
   }
   if (!(stages & 2)) return AGCN_OK;
 
@@ -901,9 +909,17 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.B = fused ? B + fs.n_big_slabs + coop_slabs : (slabs ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
-  pa.counters_zeroed = (stages & 1) ? 1 : 0;
+  pa.counters_zeroed = ((stages & 1) && !cloud_bwd) ? 1 : 0;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
+  // point-cloud sizes: row-chunk partials with 16-byte operand loads + the fixed-order reduce (cloud_kernels.hip)
+  static const int cloud_pg = [] { const char* e = std::getenv("AGCN_CLOUD_PG"); return e ? std::atoi(e) : 0; }();
+  if (cloud_pg && !fused && slabs && w.WT && cloud_param_grads_ok(pa) && (size_t)pa.n_chunks * pa.part_stride <= w.part_floats &&
+      (reinterpret_cast<uintptr_t>(batch->X) & 15) == 0) {
+    rc = launch_cloud_param_partials(pa, hip_stream);
+    if (rc != AGCN_OK) return rc;
+    return launch_param_grad_reduce(pa, hip_stream);
+  }
   return launch_param_grads(pa, hip_stream);
 }
 

@@ -62,6 +62,27 @@ __device__ __forceinline__ WaveCtx wave_ctx(const SgcArgs& a, int slab) {
   return c;
 }
 
+// XCD-aware order of the 64-row strips: workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 share one L2), the
+// strip table is sorted by graph, so XCD x takes the x-th EIGHTH of the table -- the strips of one cloud run on one XCD and
+// its rows of X_0 / g_1 / Z / s (re-read by every strip of the cloud) come out of ONE L2 instead of being fetched into all
+// eight (placement is a speed matter only).  Returns -1 for the padding workgroups of the rounded-up grid.
+#ifndef AGCN_CLOUD_XCD
+#define AGCN_CLOUD_XCD 1
+#endif
+// AGCN_CLOUD_SYM=1: only the blocks on and above the block diagonal of S / r are computed and each is also written
+// mirrored, a lane's four consecutive rows of its column as 16 bytes of the mirrored row.  Measured: 264 us against
+// 100 us -- 64 scattered 16-byte pieces per store instruction are partial-line writes all the way to memory, and the
+// three kernels behind it slow down as well (lap 101 -> 119 us).  Off; kept as the record of the experiment.
+#ifndef AGCN_CLOUD_SYM
+#define AGCN_CLOUD_SYM 0
+#endif
+__device__ __forceinline__ int xcd_strip(int n_strips) {
+  const int per = (n_strips + 7) >> 3, g = (int)blockIdx.x;
+  const int s = AGCN_CLOUD_XCD ? (g & 7) * per + (g >> 3) : g;
+  return s < n_strips ? s : -1;
+}
+__host__ inline unsigned xcd_grid(int n_strips) { return (unsigned)(8 * ((n_strips + 7) >> 3)); }
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // sum over the 16 lanes that share q (= the 16 columns of a tile row), result in each of them
@@ -121,11 +142,16 @@ __device__ __forceinline__ const float* dense_l0(const SgcArgs& a, const WaveCtx
 
 // ------------------------------------------------------------------------------------------------
 // forward 1: S = exp(-||Z_i - Z_j||) (graphconv.py:163-180) -> res_W, r -> reserve (paper mode), partial degrees.
-// Workgroup = one 64-row block of a graph x a quarter of its column blocks; a wave = one column per lane.
+// Workgroup = one 64-row block of a graph x a quarter of its column blocks; a wave = one 64 x 64 block, one column per lane.
+// S and r are symmetric bit for bit, so only the blocks on and above the block diagonal are computed; a block above it is
+// also written transposed (a lane's four consecutive rows of its column = 16 contiguous bytes of the mirrored row) and
+// contributes its ROW sums as the partial degrees of the mirrored block.
 __global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int slab0 = 4 * (int)blockIdx.x;
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const int slab0 = 4 * strip;
   const int b = a.slab_graph[slab0], r0 = a.slab_row[slab0];
   const int n = a.n[b], row0 = a.row_off[b];
   const int64_t toff = a.tile_off[b];
@@ -136,8 +162,10 @@ __global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart)
   __shared__ __attribute__((aligned(16))) float trbuf[4][2][4 * 64];
   float* trS = trbuf[wave][0];
   float* trR = trbuf[wave][1];
-  for (int jb = wave + 4 * (int)blockIdx.y; jb < ncb; jb += 4 * (int)gridDim.y) {
+  const int rb = r0 >> 6;
+  for (int jb = (AGCN_CLOUD_SYM ? rb : 0) + wave + 4 * (int)blockIdx.y; jb < ncb; jb += 4 * (int)gridDim.y) {
     const int j = 64 * jb + lane;
+    const bool mirror = AGCN_CLOUD_SYM && jb > rb;
     float zj[FIN];
     {
       const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)j * FIN);
@@ -153,6 +181,9 @@ __global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart)
     // bound by store ISSUE at ~2.4 TB/s on this chip (measured here: 110 us for 268 MB), 16-byte ones are not
     float* wout = a.res_W + toff + (int64_t)(r0 + (lane >> 4)) * n + 64 * jb + 4 * (lane & 15);
     float* rout = a.sv_r + toff + (int64_t)(r0 + (lane >> 4)) * n + 64 * jb + 4 * (lane & 15);
+    float* woutT = a.res_W + toff + (int64_t)j * n + r0;     // the mirrored block: row j, columns r0 ..
+    float* routT = a.sv_r + toff + (int64_t)j * n + r0;
+    float* dpT = dpart + (toff >> 6) + (int64_t)jb * n + r0 + (lane >> 4);
     // The row operand z_i comes through the scalar cache into SGPRs (uniform address), half a row (32 features = two
     // s_load_dwordx16) at a time into one of two buffers: the half after the one being consumed is requested right
     // behind the wait for the current one -- scalar loads return out of order, so the only usable wait is
@@ -192,8 +223,20 @@ __global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart)
         cs += S;
       }
       __builtin_amdgcn_wave_barrier();
-      *reinterpret_cast<f32x4*>(wout + (int64_t)i4 * n) = *reinterpret_cast<const f32x4*>(trS + 4 * lane);
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(trS + 4 * lane);
+      *reinterpret_cast<f32x4*>(wout + (int64_t)i4 * n) = sv;
       if (paper) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(trR + 4 * lane), reinterpret_cast<f32x4*>(rout + (int64_t)i4 * n));
+      if (mirror) {
+        *reinterpret_cast<f32x4*>(woutT + i4) = (f32x4){trS[lane], trS[64 + lane], trS[128 + lane], trS[192 + lane]};
+        if (paper)
+          __builtin_nontemporal_store((f32x4){trR[lane], trR[64 + lane], trR[128 + lane], trR[192 + lane]},
+                                      reinterpret_cast<f32x4*>(routT + i4));
+        // row sums of the four rows (a row = 16 lanes' 4 columns each): the mirrored block's column sums
+        float t = (sv.x + sv.y) + (sv.z + sv.w);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+        if ((lane & 15) == 0) dpT[i4] = t;
+      }
       __builtin_amdgcn_wave_barrier();
     }
     SWAIT2(A0, A1, cs);                      // (nothing of this column block's requests is left in flight)
@@ -211,7 +254,14 @@ __global__ __launch_bounds__(64) void cloud_degree_kernel(SgcArgs a, const float
   const int j = r0 + (int)threadIdx.x;
   const float* dp = dpart + (toff >> 6) + j;
   float d = 0.f;
-  for (int rb = 0; rb < (n >> 6); ++rb) d += dp[(int64_t)rb * n];
+  const int nrb = n >> 6;
+  for (int rb = 0; rb < nrb; rb += 8) {   // eight loads in flight, added in row-block order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = dp[(int64_t)min(rb + u, nrb - 1) * n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d += (rb + u < nrb) ? v[u] : 0.f;
+  }
   a.sv_s[row0 + j] = 1.0f / sqrtf(d + FLT_TRUE_MIN);
   if (r0 == 0 && threadIdx.x == 0) {   // clip_by_average_norm(R, 1) never clips for SGC_LL: scale exactly 1
     float* sc = a.sv_scal + 4 * b;
@@ -231,7 +281,9 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WaveCtx c = wave_ctx(a, 4 * (int)blockIdx.x + wave);
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const WaveCtx c = wave_ctx(a, 4 * strip + wave);
   const int n = c.n;
   float* Bs = smem;                             // [64][LD]  the chunk's rows of X_0
   float* Ls = smem + CC * LD + wave * (16 * LD);   // [16][LD]  this wave's strip of L
@@ -358,7 +410,9 @@ __global__ __launch_bounds__(256) void cloud_bwd1_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slab = 4 * (int)blockIdx.x + wave;
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const int slab = 4 * strip + wave;
   const WaveCtx c = wave_ctx(a, slab);
   const int n = c.n;
   float* Gs = smem;                                  // [64][LD]  g_1 rows of the chunk
@@ -491,7 +545,9 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WaveCtx c = wave_ctx(a, 4 * (int)blockIdx.x + wave);
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const WaveCtx c = wave_ctx(a, 4 * strip + wave);
   const int n = c.n;
   float* Zs = smem;                                  // [64][LD]  Z rows of the chunk
   float* Cs = smem + CC * LD + wave * (16 * LD);     // [16][LD]  this wave's strip of c
@@ -590,6 +646,186 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The packed-row products of the layer at point-cloud sizes (tens of thousands of rows).  The general rows_gemm /
+// param_grad kernels are built for a few thousand rows (1024-thread workgroups that stage whole operands, one round of
+// loads): at 32768 rows they ran at 22 TFLOP/s (projection 16 us, filter adjoint 49 us, parameter gradients 44 us of a
+// 550 us step).  Here a wave owns 16 rows, its A rows sit in a wave-private LDS image read 16 bytes wide, and the small B
+// matrix (M_L, W^T: L1 / L2 resident) comes row-major straight from memory as B[k][4r .. 4r + 3] (lane r owns the output
+// columns 4r .. 4r + 3: 16-byte stores).
+
+// Z = X . M_L   (graphconv.py:164)
+__global__ __launch_bounds__(256) void cloud_project_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ M,
+                                                            float* __restrict__ Z) {
+  __shared__ __attribute__((aligned(16))) float As_all[4][16 * LD];
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t row0 = (int64_t)blockIdx.x * CS + 16 * wave;
+  float* As = As_all[wave];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    *reinterpret_cast<f32x4*>(As + (q + 4 * m) * LD + 4 * r) = *reinterpret_cast<const f32x4*>(X + (row0 + q + 4 * m) * ldx + 4 * r);
+  __builtin_amdgcn_wave_barrier();
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(As + r * LD + 16 * blk + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(M + (16 * blk + 4 * q + j) * FIN + 4 * r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = mfma4(av[j], bv[e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<f32x4*>(Z + (row0 + 4 * q + i) * FIN + 4 * r) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+}
+
+// WT[k][c][f] = W[f * K + k][c]  (the filter adjoint's B operand, row-major in its contraction index c)
+__global__ __launch_bounds__(256) void cloud_prep_kernel(const float* __restrict__ W, float* __restrict__ WT, int Fout, int K) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < K * Fout * FIN) {
+    const int f = e % FIN, kc = e / FIN, c = kc % Fout, k = kc / Fout;
+    WT[e] = W[(int64_t)(f * K + k) * Fout + c];
+  }
+}
+
+// Gp = dY . act'(Y) -> workspace;  g_0 = Gp . W_0^T -> dX,  g_1 = Gp . W_1^T -> workspace   (adjoint of graphconv.py:238-251)
+__global__ __launch_bounds__(256) void cloud_filter_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                               int ldy, int Fout, int relu, const float* __restrict__ WT,
+                                                               float* __restrict__ Gp, float* __restrict__ dX, int ldx,
+                                                               float* __restrict__ g1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lda = Fout + 8;
+  float* As = smem + wave * (16 * lda);
+  const int64_t row0 = (int64_t)blockIdx.x * CS + 16 * wave;
+  const int f4 = Fout >> 2;                                  // 16-byte groups per row
+  for (int idx = lane; idx < 16 * f4; idx += 64) {
+    const int row = idx / f4, c4 = idx - row * f4;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dY + (row0 + row) * ldy + 4 * c4);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (row0 + row) * ldy + 4 * c4);
+    f32x4 g = d;
+    if (relu) g = (f32x4){y.x > 0.f ? d.x : 0.f, y.y > 0.f ? d.y : 0.f, y.z > 0.f ? d.z : 0.f, y.w > 0.f ? d.w : 0.f};
+    *reinterpret_cast<f32x4*>(Gp + (row0 + row) * Fout + 4 * c4) = g;
+    *reinterpret_cast<f32x4*>(As + row * lda + 4 * c4) = g;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* Bk = WT + (int64_t)k * Fout * FIN + 4 * r;
+#pragma unroll 2
+    for (int cb = 0; cb < Fout; cb += 16) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(As + r * lda + cb + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(Bk + (int64_t)(cb + 4 * q + j) * FIN);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = mfma4(av[j], bv[e], acc[e]);
+      }
+    }
+    float* out = k == 0 ? dX : g1;
+    const int ldo = k == 0 ? ldx : FIN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(out + (row0 + 4 * q + i) * ldo + 4 * r) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+  }
+}
+
+// Row-chunk partials of the parameter gradients (param_grads.hip's layout: [chunk][dweight | dbias | dM_L]; the
+// existing fixed-order reduce kernel adds the chunks):  dweight[f*K + k][c] = sum_rows X_k[row][f] Gp[row][c],
+// dbias[c] = sum_rows Gp[row][c], dM_L[f][g] = sum_rows X[row][f] dZ[row][g]  -- A^T B with the row index as the MFMA
+// k dimension, both operands as 16-byte loads: A tile (k, e) <-> f = 4r + e, B tile (h, e') <-> c = 64 h + 4r + e'.
+// Wave w of a workgroup takes the A tiles (k = w / 2, e = 2 (w % 2) + {0, 1}) against every B tile, and the dM_L tiles of
+// e = w.
+template <int FOUT>
+__global__ __launch_bounds__(256) void cloud_param_partial_kernel(ParamGradArgs a) {
+  constexpr int NH = FOUT / 64;
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int chunk = blockIdx.x;
+  const int r_begin = chunk * a.chunk_rows, r_end = min(a.rows, r_begin + a.chunk_rows);
+  const int kx = wave >> 1, e0 = 2 * (wave & 1);
+  const float* Ak = kx == 0 ? a.X : a.sv_X;            // X_0 rows (ld ldx) / X_1 rows (ld Fin)
+  const int lda = kx == 0 ? a.ldx : FIN;
+  f32x4 accW[2][NH][4], accM[4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accW[u][h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) accM[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) bsum[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool paper = a.paper != 0;
+#pragma unroll 2
+  for (int rr = r_begin; rr < r_end; rr += 4) {
+    const int64_t row = rr + q;
+    const f32x4 xa = *reinterpret_cast<const f32x4*>(Ak + row * lda + 4 * r);
+    f32x4 gp[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) gp[h] = *reinterpret_cast<const f32x4*>(a.Gp + row * FOUT + 64 * h + 4 * r);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accW[u][h][e] = mfma4(xa[e0 + u], gp[h][e], accW[u][h][e]);
+    if (wave == 0) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) bsum[h] += gp[h];
+    }
+    if (paper) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.X + row * a.ldx + 4 * r);
+      const f32x4 dz = *reinterpret_cast<const f32x4*>(a.dZ + row * FIN + 4 * r);
+      const float xw = wave == 0 ? x0.x : wave == 1 ? x0.y : wave == 2 ? x0.z : x0.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accM[e] = mfma4(xw, dz[e], accM[e]);
+    }
+  }
+  float* out = a.part + (int64_t)chunk * a.part_stride;
+  // accumulator element i of tile (A tile e, B tile (h, e')): f = 4 (4q + i) + e, c = 64 h + 4r + e'
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = 16 * q + 4 * i + e0 + u;
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        *reinterpret_cast<f32x4*>(out + (int64_t)(f * 2 + kx) * FOUT + 64 * h + 4 * r) =
+            (f32x4){accW[u][h][0][i], accW[u][h][1][i], accW[u][h][2][i], accW[u][h][3][i]};
+    }
+  if (wave == 0) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      f32x4 t = bsum[h];
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+      }
+      if (q == 0) *reinterpret_cast<f32x4*>(out + (int64_t)2 * FIN * FOUT + 64 * h + 4 * r) = t;
+    }
+  }
+  if (paper) {
+    float* outM = out + (int64_t)2 * FIN * FOUT + FOUT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = 16 * q + 4 * i + wave;
+      *reinterpret_cast<f32x4*>(outM + (int64_t)f * FIN + 4 * r) = (f32x4){accM[0][i], accM[1][i], accM[2][i], accM[3][i]};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 namespace {
 bool cloud_env() {
   static const int off = [] { const char* e = std::getenv("AGCN_CLOUD"); return (e && e[0] == '0') ? 1 : 0; }();
@@ -612,7 +848,7 @@ int launch_cloud(K kernel, dim3 grid, int threads, size_t lds, int prof_id, cons
 bool cloud_path(const SgcArgs& a, bool quad) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   return cloud_env() && quad && a.Fin == FIN && a.K == 2 && a.variant == AGCN_SGC_LL && a.L0_dense != nullptr &&
-         (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 3) == 0 && al16(a.X) && al16(a.weight) && al16(a.bias) &&
+         (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 15) == 0 && al16(a.X) && al16(a.weight) && al16(a.bias) &&
          al16(a.M_L) && (a.n_slabs & 3) == 0;
 }
 size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / 64 + 64); }
@@ -620,28 +856,52 @@ size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / 64 
 int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const unsigned strips = (unsigned)(a.n_slabs / 4);
+  {
+    int rc0 = launch_cloud(cloud_project_kernel, dim3(strips), 256, 0, PK_PROJECT, "cloud_project", stream, a.X, a.ldx, a.M_L, a.sv_Z);
+    if (rc0 != AGCN_OK) return rc0;
+  }
   // column blocks are dealt to 4 waves x gridDim.y workgroups: enough waves to fill the chip, at least one column block each
   const unsigned ys = (unsigned)std::max(1, std::min(4, max_n / 256));
-  int rc = launch_cloud(cloud_sim_kernel, dim3(strips, ys), 256, 0, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart);
+  int rc = launch_cloud(cloud_sim_kernel, dim3(xcd_grid((int)strips), ys), 256, 0, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart);
   if (rc != AGCN_OK) return rc;
   rc = launch_cloud(cloud_degree_kernel, dim3(strips), 64, 0, PK_CLOUD_DEG, "cloud_degree", stream, a, (const float*)dpart);
   if (rc != AGCN_OK) return rc;
   const size_t lds = sizeof(float) * (CC * LD + 4 * 16 * LD);
-  return paper ? launch_cloud(cloud_lap_kernel<true>, dim3(strips), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a)
-               : launch_cloud(cloud_lap_kernel<false>, dim3(strips), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a);
+  return paper ? launch_cloud(cloud_lap_kernel<true>, dim3(xcd_grid((int)strips)), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a)
+               : launch_cloud(cloud_lap_kernel<false>, dim3(xcd_grid((int)strips)), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a);
 }
 
-int launch_cloud_backward(const SgcArgs& a, void* stream) {
+// The row-chunk partials of the parameter gradients (the caller runs param_grads.hip's reduce kernel behind it).
+bool cloud_param_grads_ok(const ParamGradArgs& a) { return cloud_env() && a.Fin == FIN && a.K == 2 && (a.Fout == 64 || a.Fout == 128) &&
+                                                           (a.rows & 63) == 0 && (a.ldx & 3) == 0 && (a.chunk_rows & 3) == 0; }
+int launch_cloud_param_partials(const ParamGradArgs& a, void* stream) {
+  return a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks), 256, 0, PK_PARAM_PARTIAL,
+                                      "cloud_param_partial", stream, a)
+                       : launch_cloud(cloud_param_partial_kernel<64>, dim3((unsigned)a.n_chunks), 256, 0, PK_PARAM_PARTIAL,
+                                      "cloud_param_partial", stream, a);
+}
+
+// Gp, g_0 -> dX, g_1 (the packed filter adjoint), then the strip kernels.  `WT`: K * Fout * 64 floats of workspace.
+int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const unsigned strips = (unsigned)(a.n_slabs / 4);
   if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "cloud kernels: a gradient of L_sum is not supported");
+  {
+    int rc0 = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep",
+                           stream, a.weight, WT, a.Fout, 2);
+    if (rc0 != AGCN_OK) return rc0;
+    rc0 = launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD,
+                       "cloud_filter_bwd", stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0,
+                       (const float*)WT, a.ws_Gp, a.dX, a.ldx, a.ws_g);
+    if (rc0 != AGCN_OK) return rc0;
+  }
   if (!paper)
-    return launch_cloud(cloud_bwd1_kernel<false>, dim3(strips), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
+    return launch_cloud(cloud_bwd1_kernel<false>, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
                         "cloud_bwd1", stream, a);
-  int rc = launch_cloud(cloud_bwd1_kernel<true>, dim3(strips), 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
+  int rc = launch_cloud(cloud_bwd1_kernel<true>, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
                         "cloud_bwd1", stream, a);
   if (rc != AGCN_OK) return rc;
-  return launch_cloud(cloud_bwd2_kernel, dim3(strips), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2",
+  return launch_cloud(cloud_bwd2_kernel, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2",
                       stream, a);
 }
 
