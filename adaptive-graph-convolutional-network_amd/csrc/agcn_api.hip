@@ -913,12 +913,10 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
   // point-cloud sizes: row-chunk partials with 16-byte operand loads + the fixed-order reduce (cloud_kernels.hip)
-  static const int cloud_pg = [] { const char* e = std::getenv("AGCN_CLOUD_PG"); return e ? std::atoi(e) : 0; }();
+  static const int cloud_pg = [] { const char* e = std::getenv("AGCN_CLOUD_PG"); return e ? std::atoi(e) : 1; }();
   if (cloud_pg && !fused && slabs && w.WT && cloud_param_grads_ok(pa) && (size_t)pa.n_chunks * pa.part_stride <= w.part_floats &&
       (reinterpret_cast<uintptr_t>(batch->X) & 15) == 0) {
-    rc = launch_cloud_param_partials(pa, hip_stream);
-    if (rc != AGCN_OK) return rc;
-    return launch_param_grad_reduce(pa, hip_stream);
+    return launch_cloud_param_partials(pa, hip_stream);   // (partials + the fixed-order reduce)
   }
   return launch_param_grads(pa, hip_stream);
 }

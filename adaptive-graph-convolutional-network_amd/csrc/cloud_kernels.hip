@@ -738,73 +738,107 @@ __global__ __launch_bounds__(256) void cloud_filter_bwd_kernel(const float* __re
   }
 }
 
-// Row-chunk partials of the parameter gradients (param_grads.hip's layout: [chunk][dweight | dbias | dM_L]; the
-// existing fixed-order reduce kernel adds the chunks):  dweight[f*K + k][c] = sum_rows X_k[row][f] Gp[row][c],
-// dbias[c] = sum_rows Gp[row][c], dM_L[f][g] = sum_rows X[row][f] dZ[row][g]  -- A^T B with the row index as the MFMA
-// k dimension, both operands as 16-byte loads: A tile (k, e) <-> f = 4r + e, B tile (h, e') <-> c = 64 h + 4r + e'.
-// Wave w of a workgroup takes the A tiles (k = w / 2, e = 2 (w % 2) + {0, 1}) against every B tile, and the dM_L tiles of
-// e = w.
+// Row-chunk partials of the parameter gradients (param_grads.hip's layout: [chunk][dweight | dbias | dM_L]):
+//   dweight[f*K + k][c] = sum_rows X_k[row][f] Gp[row][c], dbias[c] = sum_rows Gp[row][c], dM_L[f][g] = sum_rows X[row][f] dZ[row][g]
+// -- A^T B with the row index as the MFMA k dimension.  A workgroup owns a chunk of rows and the WHOLE output; the chunk is
+// walked in pieces of 32 rows whose X_0 / X_1 / Gp / dZ rows are staged in LDS with coalesced 16-byte loads (the next
+// piece's loads in flight in registers behind the current piece's 160 MFMAs per wave: with operands fetched straight into
+// the MFMA registers, one wave per SIMD and 20 MFMAs per round trip, the first version of this kernel took 46 us).
+// A tile (k, e) <-> f = 4r + e, B tile (h, e') <-> c = 64 h + 4r + e': both operands are 16-byte LDS reads of "row 4u + q".
+// Workgroup (chunk, k) takes the A tiles of X_k, wave w of it the tile e = w against every B tile (k = 0: also the dM_L tiles of
+// e = w and the bias): two workgroups per chunk and CU overlap one's staging with the other's products.
 template <int FOUT>
 __global__ __launch_bounds__(256) void cloud_param_partial_kernel(ParamGradArgs a) {
-  constexpr int NH = FOUT / 64;
-  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int NH = FOUT / 64, PR = 32;   // rows per piece
+  __shared__ __attribute__((aligned(16))) float Xs[PR * FIN], dZs[PR * FIN], Gps[PR * FOUT];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunk = blockIdx.x;
   const int r_begin = chunk * a.chunk_rows, r_end = min(a.rows, r_begin + a.chunk_rows);
-  const int kx = wave >> 1, e0 = 2 * (wave & 1);
-  const float* Ak = kx == 0 ? a.X : a.sv_X;            // X_0 rows (ld ldx) / X_1 rows (ld Fin)
-  const int lda = kx == 0 ? a.ldx : FIN;
-  f32x4 accW[2][NH][4], accM[4];
+  const int kx = blockIdx.y;
+  const bool paper = a.paper != 0 && kx == 0;    // (dM_L rides with the X_0 workgroup)
+  f32x4 accW[NH][4], accM[4];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) accW[u][h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e) accW[h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; ++e) accM[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 bsum[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) bsum[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool paper = a.paper != 0;
-#pragma unroll 2
-  for (int rr = r_begin; rr < r_end; rr += 4) {
-    const int64_t row = rr + q;
-    const f32x4 xa = *reinterpret_cast<const f32x4*>(Ak + row * lda + 4 * r);
-    f32x4 gp[NH];
+
+  struct Piece { f32x4 xa[2], dz[2], gp[2 * NH]; };
+  const float* Asrc = kx == 0 ? a.X : a.sv_X;
+  const int lda = kx == 0 ? a.ldx : FIN;
+  auto load_piece = [&](int p0) {        // rows p0 .. p0 + 31 (clamped to the batch: chunks are multiples of 32 rows)
+    Piece g;
 #pragma unroll
-    for (int h = 0; h < NH; ++h) gp[h] = *reinterpret_cast<const f32x4*>(a.Gp + row * FOUT + 64 * h + 4 * r);
+    for (int m = 0; m < 2; ++m) {
+      const int id = tid + 256 * m;
+      const int64_t row = min(p0 + (id >> 4), a.rows - 1);
+      g.xa[m] = *reinterpret_cast<const f32x4*>(Asrc + row * lda + 4 * (id & 15));
+      g.dz[m] = paper ? *reinterpret_cast<const f32x4*>(a.dZ + row * FIN + 4 * (id & 15)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int m = 0; m < 2 * NH; ++m) {
+      const int id = tid + 256 * m;
+      const int64_t row = min(p0 + id / (FOUT / 4), a.rows - 1);
+      g.gp[m] = *reinterpret_cast<const f32x4*>(a.Gp + row * FOUT + 4 * (id % (FOUT / 4)));
+    }
+    return g;
+  };
+  auto store_piece = [&](const Piece& g) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int id = tid + 256 * m;
+      *reinterpret_cast<f32x4*>(Xs + 4 * id) = g.xa[m];
+      if (paper) *reinterpret_cast<f32x4*>(dZs + 4 * id) = g.dz[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 2 * NH; ++m) *reinterpret_cast<f32x4*>(Gps + 4 * (tid + 256 * m)) = g.gp[m];
+  };
+  Piece pre = load_piece(r_begin);
+#pragma unroll 1
+  for (int p0 = r_begin; p0 < r_end; p0 += PR) {
+    __syncthreads();
+    store_piece(pre);
+    __syncthreads();
+    if (p0 + PR < r_end) pre = load_piece(p0 + PR);
+    const int nk = min(PR, r_end - p0) >> 2;       // k-steps of 4 rows in this piece
+    for (int u = 0; u < nk; ++u) {
+      const int row = 4 * u + q;
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(Xs + row * FIN + 4 * r);
+      const float xw = wave == 0 ? xa.x : wave == 1 ? xa.y : wave == 2 ? xa.z : xa.w;
+      f32x4 gp[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) gp[h] = *reinterpret_cast<const f32x4*>(Gps + row * FOUT + 64 * h + 4 * r);
 #pragma unroll
       for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) accW[u][h][e] = mfma4(xa[e0 + u], gp[h][e], accW[u][h][e]);
-    if (wave == 0) {
+        for (int e = 0; e < 4; ++e) accW[h][e] = mfma4(xw, gp[h][e], accW[h][e]);
+      if (wave == 0 && kx == 0) {
 #pragma unroll
-      for (int h = 0; h < NH; ++h) bsum[h] += gp[h];
-    }
-    if (paper) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.X + row * a.ldx + 4 * r);
-      const f32x4 dz = *reinterpret_cast<const f32x4*>(a.dZ + row * FIN + 4 * r);
-      const float xw = wave == 0 ? x0.x : wave == 1 ? x0.y : wave == 2 ? x0.z : x0.w;
+        for (int h = 0; h < NH; ++h) bsum[h] += gp[h];
+      }
+      if (paper) {
+        const f32x4 dz = *reinterpret_cast<const f32x4*>(dZs + row * FIN + 4 * r);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) accM[e] = mfma4(xw, dz[e], accM[e]);
+        for (int e = 0; e < 4; ++e) accM[e] = mfma4(xw, dz[e], accM[e]);
+      }
     }
   }
   float* out = a.part + (int64_t)chunk * a.part_stride;
   // accumulator element i of tile (A tile e, B tile (h, e')): f = 4 (4q + i) + e, c = 64 h + 4r + e'
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int i = 0; i < 4; ++i) {
+    const int f = 16 * q + 4 * i + wave;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = 16 * q + 4 * i + e0 + u;
-#pragma unroll
-      for (int h = 0; h < NH; ++h)
-        *reinterpret_cast<f32x4*>(out + (int64_t)(f * 2 + kx) * FOUT + 64 * h + 4 * r) =
-            (f32x4){accW[u][h][0][i], accW[u][h][1][i], accW[u][h][2][i], accW[u][h][3][i]};
-    }
-  if (wave == 0) {
+    for (int h = 0; h < NH; ++h)
+      *reinterpret_cast<f32x4*>(out + (int64_t)(f * 2 + kx) * FOUT + 64 * h + 4 * r) =
+          (f32x4){accW[h][0][i], accW[h][1][i], accW[h][2][i], accW[h][3][i]};
+  }
+  if (wave == 0 && kx == 0) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       f32x4 t = bsum[h];
@@ -821,6 +855,46 @@ __global__ __launch_bounds__(256) void cloud_param_partial_kernel(ParamGradArgs 
     for (int i = 0; i < 4; ++i) {
       const int f = 16 * q + 4 * i + wave;
       *reinterpret_cast<f32x4*>(outM + (int64_t)f * FIN + 4 * r) = (f32x4){accM[0][i], accM[1][i], accM[2][i], accM[3][i]};
+    }
+  }
+}
+
+// Fixed-order sum of the chunk partials: element e of [dweight | dbias | dM_L] = sum over four quarters of the chunk range
+// (one quarter per wave, 32 loads in flight, added in chunk order), the quarters added in order; and the scalars
+// (dalpha, dbeta: the per-slab partials in index order).  64 elements per workgroup.
+__global__ __launch_bounds__(256) void cloud_param_reduce_kernel(ParamGradArgs a) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nW = (int64_t)a.K * a.Fin * a.Fout, nB = a.Fout, nM = a.paper ? (int64_t)a.Fin * a.Fin : 0;
+  const int64_t total = nW + nB + nM;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  const int per = (a.n_chunks + 3) >> 2, c_begin = wave * per, c_end = min(a.n_chunks, c_begin + per);
+  float s = 0.f;
+  if (e < total) {
+    const float* p = a.part + e;
+    for (int c = c_begin; c < c_end; c += 32) {
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = p[(int64_t)min(c + u, c_end - 1) * a.part_stride];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) s += (c + u < c_end) ? v[u] : 0.f;
+    }
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && e < total) {
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (e < nW) a.dweight[e] = t;
+    else if (e < nW + nB) a.dbias[e - nW] = t;
+    else a.dM_L[e - nW - nB] = t;
+  }
+  if (blockIdx.x == 0 && wave >= 2) {   // scalars: one wave each, fixed order
+    float* dst = wave == 2 ? a.dalpha : a.dbeta;
+    if (dst != nullptr && a.pg != nullptr) {
+      float t = 0.f;
+      for (int b = lane; b < a.B; b += 64) t += a.pg[2 * b + (wave - 2)];
+      t = wave_sum(t);
+      if (lane == 0) dst[0] = t;
     }
   }
 }
@@ -875,10 +949,14 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* st
 bool cloud_param_grads_ok(const ParamGradArgs& a) { return cloud_env() && a.Fin == FIN && a.K == 2 && (a.Fout == 64 || a.Fout == 128) &&
                                                            (a.rows & 63) == 0 && (a.ldx & 3) == 0 && (a.chunk_rows & 3) == 0; }
 int launch_cloud_param_partials(const ParamGradArgs& a, void* stream) {
-  return a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks), 256, 0, PK_PARAM_PARTIAL,
+  int rc = a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks, 2), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a)
-                       : launch_cloud(cloud_param_partial_kernel<64>, dim3((unsigned)a.n_chunks), 256, 0, PK_PARAM_PARTIAL,
+                       : launch_cloud(cloud_param_partial_kernel<64>, dim3((unsigned)a.n_chunks, 2), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a);
+  if (rc != AGCN_OK) return rc;
+  const int64_t total = (int64_t)a.K * a.Fin * a.Fout + a.Fout + (a.paper ? (int64_t)a.Fin * a.Fin : 0);
+  return launch_cloud(cloud_param_reduce_kernel, dim3((unsigned)((total + 63) / 64)), 256, 0, PK_PARAM_REDUCE, "cloud_param_reduce",
+                      stream, a);
 }
 
 // Gp, g_0 -> dX, g_1 (the packed filter adjoint), then the strip kernels.  `WT`: K * Fout * 64 floats of workspace.

@@ -348,16 +348,6 @@ int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int3
   return reinterpret_cast<int32_t*>(part + (size_t)nt * S * (TF * 32));
 }
 
-int launch_param_grad_reduce(const ParamGradArgs& a, void* stream) {
-  const int64_t total = (int64_t)a.K * a.Fin * a.Fout + a.Fout + (a.paper ? (int64_t)a.Fin * a.Fin : 0);
-  prof_begin(PK_PARAM_REDUCE, stream);
-  hipLaunchKernelGGL(param_grad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  prof_end(stream);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_reduce launch: %s", hipGetErrorString(e));
-  return AGCN_OK;
-}
-
 int launch_param_grads(const ParamGradArgs& a, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (pg_mode() == 1 && a.part_floats >= param_grad_onepass_floats(a.rows, a.Fin, a.Fout, a.K, a.paper)) {

@@ -167,8 +167,7 @@ size_t cloud_dpart_floats(int64_t tile_elems);   // forward workspace: partial d
 int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* stream);
 int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream);   // (incl. the packed filter adjoint)
 bool cloud_param_grads_ok(const ParamGradArgs& a);
-int launch_cloud_param_partials(const ParamGradArgs& a, void* stream);
-int launch_param_grad_reduce(const ParamGradArgs& a, void* stream);   // param_grads.hip: fixed-order sum of the chunk partials
+int launch_cloud_param_partials(const ParamGradArgs& a, void* stream);   // row-chunk partials + their fixed-order sum
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper);
 // the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number

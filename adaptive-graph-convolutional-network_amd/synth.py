@@ -82,3 +82,39 @@ def glorot_params(rs, Fin, Fout, K, reslap=False):
     if reslap:
         p["beta"] = np.ones(1, np.float32)
     return p
+
+
+def modelnet_clouds(seed, B, n=1024, Fin=3):
+    """ModelNet-shaped point clouds (BASELINE.json config 3): B clouds of n unit-cube points
+    (utils/data_loader/meshloader.py:34), adjacency by the mean-distance threshold rule (:264-285, ~50 % dense -> the
+    original Laplacian is fed DENSE), features = xyz for the first layer (Fin = 3) or relu(N(0, 1)) for a hidden one.
+    Returns (X [B, n, Fin] f32, L [B, n, n] f32)."""
+    rs = np.random.RandomState(seed)
+    Xs, Ls = [], []
+    for _ in range(B):
+        pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        A = d < d.mean()
+        np.fill_diagonal(A, False)
+        adj = [np.nonzero(A[i])[0].tolist() for i in range(n)]
+        ip, ix, val = laplacian_csr(adj)
+        L = np.zeros((n, n), np.float32)
+        L[np.repeat(np.arange(n), np.diff(ip)), ix] = val.astype(np.float32)
+        Ls.append(L)
+        Xs.append(pts if Fin == 3 else np.maximum(rs.randn(n, Fin), 0).astype(np.float32))
+    return np.stack(Xs), np.stack(Ls)
+
+
+def layer_work(n, nnz, Fin, Fout, K, paper, dense_l0=False, reslap=False):
+    """algorithmic HBM bytes and flops of one layer call, (fwd_bytes, bwd_bytes, fwd_flops,
+    bwd_flops).  L_bytes = 4 N2 (dense original Laplacian) or 8 nnz + 4 (N1 + B) (CSR); Reslap adds the L_sum write and
+    the L_prev read."""
+    n = np.asarray(n, np.int64)
+    N1, N2, B = int(n.sum()), int((n * n).sum()), len(n)
+    P = Fin * Fin + K * Fin * Fout + Fout + 1
+    Lb = 4 * N2 if dense_l0 else 8 * int(nnz) + 4 * (N1 + B)
+    fwd_b = 4 * N1 * Fin + Lb + 4 * N1 * Fout + 8 * N2 + 4 * P + (8 * N2 if reslap else 0)
+    bwd_b = 4 * N1 * Fout + 8 * N1 * Fin + Lb + 8 * P
+    fwd_f = 2 * N1 * Fin * Fin + (3 * Fin + 10) * N2 + 2 * (K - 1) * N2 * Fin + 2 * N1 * K * Fin * Fout
+    bwd_f = 2 * (2 * N1 * K * Fin * Fout) + 2 * (2 * (K - 1) * N2 * Fin) + ((4 * N2 * Fin + 4 * N1 * Fin * Fin) if paper else 0)
+    return fwd_b, bwd_b, fwd_f, bwd_f

@@ -75,24 +75,10 @@ def bytes_layer(n, nnz, Fin, Fout, K, dense_l0):
 
 def modelnet_batch(amd, B, n, Fin, dev, seed=10):
     """Unit-cube point clouds, mean-distance-threshold adjacency (utils/meshloader.py:264-285), dense feed."""
-    rs = np.random.RandomState(seed)
-    Xs, Ls = [], []
-    for _ in range(B):
-        pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
-        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
-        A = d < d.mean()
-        np.fill_diagonal(A, False)
-        adj = [np.nonzero(A[i])[0].tolist() for i in range(n)]
-        ip, ix, val = amd.laplacian_csr(adj)
-        L = np.zeros((n, n), np.float32)
-        rows = np.repeat(np.arange(n), np.diff(ip))
-        L[rows, ix] = val.astype(np.float32)
-        Ls.append(L)
-        Xs.append(pts if Fin == 3 else np.maximum(rs.randn(n, Fin), 0).astype(np.float32))
+    from agcn_amd import synth
+    X, L = synth.modelnet_clouds(seed, B, n, Fin)
     ds = np.stack([np.full(B, n), np.full(B, -1)], 1).astype(np.int32)
-    X3 = torch.from_numpy(np.stack(Xs)).to(dev)
-    L3 = torch.from_numpy(np.stack(Ls)).to(dev)
-    return amd.GraphBatch.from_padded(X3, L3, ds, dev), np.full(B, n, np.int32)
+    return amd.GraphBatch.from_padded(torch.from_numpy(X).to(dev), torch.from_numpy(L).to(dev), ds, dev), np.full(B, n, np.int32)
 
 
 def main():

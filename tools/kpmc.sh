@@ -4,7 +4,7 @@ tag=$1; ctr=$2
 out=$GRAFT_REPO_ROOT/gpurun_out/kpmc/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --skip-other-mode --mode ${AGCN_BENCH_MODE:-paper} --steps 20 --warmup 2 > $out/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --no-secondary --repeats 1 --skip-other-mode --mode ${AGCN_BENCH_MODE:-paper} --steps 20 --warmup 2 > $out/log.txt 2>&1
 python3 - <<PY
 import csv,glob,collections
 fs=glob.glob("$out/*/*counter_collection.csv")

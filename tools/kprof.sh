@@ -5,7 +5,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/kprof/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --skip-other-mode --mode ${AGCN_BENCH_MODE:-paper} --steps 100 > $out/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --no-secondary --repeats 1 --skip-other-mode --mode ${AGCN_BENCH_MODE:-paper} --steps 100 > $out/log.txt 2>&1
 echo "== $tag $@"
 python3 - <<PY
 import csv,glob

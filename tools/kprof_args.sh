@@ -4,7 +4,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/kprof/$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --skip-other-mode --steps 50 "$@" > $out/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --repeats 1 --skip-other-mode --steps 50 "$@" > $out/log.txt 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("$out/*/*kernel_stats.csv")[0]

@@ -7,7 +7,7 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/mfma
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --skip-other-mode --steps 20 --warmup 2 "$@" > $out/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --no-secondary --repeats 1 --skip-other-mode --steps 20 --warmup 2 "$@" > $out/log.txt 2>&1
 python3 - <<PY
 import csv,glob,collections,json
 fs=glob.glob("$out/p/*/*counter_collection.csv")

@@ -6,7 +6,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/traffic
 rm -rf $out/FETCH_SIZE $out/WRITE_SIZE; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --skip-other-mode --mode ${AGCN_BENCH_MODE:-paper} --steps 20 --warmup 2 > $out/$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --no-cpu-baseline --no-secondary --repeats 1 --skip-other-mode --mode ${AGCN_BENCH_MODE:-paper} --steps 20 --warmup 2 > $out/$c.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json
