@@ -13,6 +13,7 @@ from .graphs import (SequentialGraphMol, ResidualGraphMol, ResidualGraphMolResLa
                      DenseConnectedGraphResLap)
 from .store import GraphStore, ResidentStore  # noqa: F401
 from .engine import GraphedStep, SgcLLEpochLanes, SgcLLEpochStep, SgcLLStep  # noqa: F401
+from .functional import check_device_status  # noqa: F401
 from . import dist  # noqa: F401
 
 __version__ = "0.1.0"

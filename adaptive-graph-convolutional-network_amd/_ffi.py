@@ -79,7 +79,7 @@ SYMBOLS = [
     "agcn_plan_bytes", "agcn_plan_bytes_for", "agcn_plan_build", "agcn_plan_info",
     "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
-    "agcn_sgc_ll_dispatch_info",
+    "agcn_sgc_ll_dispatch_info", "agcn_sgc_ll_reserve_status",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
     "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
@@ -91,6 +91,7 @@ SYMBOLS = [
     "agcn_get_slab_mode", "agcn_set_slab_mode", "agcn_get_fused_mode", "agcn_set_fused_mode",
     "agcn_get_fused_global_b", "agcn_set_fused_global_b", "agcn_get_param_grad_onepass", "agcn_set_param_grad_onepass",
     "agcn_get_spec_mode", "agcn_set_spec_mode", "agcn_get_spec_small", "agcn_set_spec_small",
+    "agcn_get_coop_members", "agcn_set_coop_members",
     "agcn_profile_enable", "agcn_profile_kernels", "agcn_profile_kernel_name", "agcn_profile_collect",
 ]
 
@@ -171,10 +172,14 @@ def _declare(lib):
     lib.agcn_get_slab_mode.argtypes = []
     lib.agcn_set_slab_mode.restype = None
     lib.agcn_set_slab_mode.argtypes = [I32]
-    for nm in ("agcn_get_fused_global_b", "agcn_get_param_grad_onepass", "agcn_get_spec_mode", "agcn_get_spec_small"):
+    lib.agcn_sgc_ll_reserve_status.restype = C.c_int
+    lib.agcn_sgc_ll_reserve_status.argtypes = [P, SZ, P, C.POINTER(C.c_int32)]
+    for nm in ("agcn_get_fused_global_b", "agcn_get_param_grad_onepass", "agcn_get_spec_mode", "agcn_get_spec_small",
+               "agcn_get_coop_members"):
         getattr(lib, nm).restype = I32
         getattr(lib, nm).argtypes = []
-    for nm in ("agcn_set_fused_global_b", "agcn_set_param_grad_onepass", "agcn_set_spec_mode", "agcn_set_spec_small"):
+    for nm in ("agcn_set_fused_global_b", "agcn_set_param_grad_onepass", "agcn_set_spec_mode", "agcn_set_spec_small",
+               "agcn_set_coop_members"):
         getattr(lib, nm).restype = None
         getattr(lib, nm).argtypes = [I32]
     lib.agcn_get_fused_mode.restype = I32
@@ -211,6 +216,17 @@ def lib():
 def check(rc):
     if rc != 0:
         raise AgcnError("agcn error %d: %s" % (rc, lib().agcn_last_error().decode()))
+
+
+def reserve_status(reserve, stream=None):
+    """Waits for `stream` (default: the current one of the reserve's device) and raises AgcnError if a cooperative wait of
+    any step that used this reserve tensor ran out (include/agcn.h: agcn_sgc_ll_reserve_status).  Returns 0 otherwise."""
+    import torch
+    with torch.cuda.device(reserve.device):
+        st = (torch.cuda.current_stream(reserve.device) if stream is None else stream).cuda_stream
+        n = C.c_int32(0)
+        check(lib().agcn_sgc_ll_reserve_status(reserve.data_ptr(), reserve.numel() * reserve.element_size(), st, C.byref(n)))
+    return n.value
 
 
 def dispatch_info(layer, batch):

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -155,16 +156,29 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   // runs 12 us itself, so only graphs whose own chain is much longer than that 24 us pay: five tiles and up
   // (the n = 95 graph of an 8-GPU shard: backward 46.2 -> 26.3 us; B = 256 with n <= 59: nothing to gain, measured).
   static const int min_force = [] { const char* e = std::getenv("AGCN_COOP_MIN_N"); return e ? std::atoi(e) : 0; }();
-  static const int n_cus = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-    return v > 0 ? v : 256;
-  }();
+  // CU count of the CURRENT device (the thresholds below rest on "members fit the chip"): cached per device id
+  int n_cus = 256;
+  {
+    static std::atomic<int> cus_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      int v = cus_of[dev].load(std::memory_order_relaxed);
+      if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus_of[dev].store(v, std::memory_order_relaxed);
+      }
+      n_cus = v;
+    }
+  }
+  const int member_budget = std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members());
   // (with two and more rounds of workgroups per CU the tail graph matters less than the extra workgroups cost:
   //  512 graphs: 6.0 M graphs/s without, 5.7 M with members for its one 70-node graph)
   static const int dual_on = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
-  static const int dual_max = [] { const char* e = std::getenv("AGCN_DUAL_MAX_N"); return e ? std::atoi(e) : spec::DUAL_MAX_N; }();
+  // (never beyond DUAL_MAX_N: both halves of a paired workgroup must run the same barrier sequence, spec_forward.hip)
+  static const int dual_max = [] {
+    const char* e = std::getenv("AGCN_DUAL_MAX_N");
+    return std::max(1, std::min(e ? std::atoi(e) : (int)spec::DUAL_MAX_N, (int)spec::DUAL_MAX_N));
+  }();
   int tiny = 0;   // graphs that may be packed two to a workgroup: a suffix of the schedule
   while (tiny < B - 1 && host.n[host.order[B - 1 - tiny]] <= dual_max) ++tiny;
   if (B > n_cus + n_cus / 2) {
@@ -192,7 +206,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   while (g < B - 1 - 2 * pairs) {   // (never every graph: the last one of the schedule writes the transposed parameters)
     const int n = host.n[host.order[g]];
     const int sl = (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
-    if (n < min_n || s + sl > spec::COOP_MAX_MEMBERS) break;
+    if (n < min_n || s + sl > member_budget) break;
     s += sl;
     ++g;
   }
@@ -434,6 +448,23 @@ extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGr
     path |= 64;
   const int32_t v[AGCN_DISPATCH_INFO_INTS] = {path, fs.spec_small_first, cg, cs, dg, cgb, csb, dgb};
   for (int i = 0; i < AGCN_DISPATCH_INFO_INTS; ++i) out[i] = v[i];
+  return AGCN_OK;
+}
+
+extern "C" int agcn_sgc_ll_reserve_status(const void* reserve, size_t reserve_bytes, void* hip_stream, int32_t* timeouts) {
+  const char* who = "agcn_sgc_ll_reserve_status";
+  if (!reserve || !timeouts || reserve_bytes < sizeof(uint64_t) * ((size_t)spec::COOP_STATUS_WORD + 1)) return fail(AGCN_EINVAL, "%s: bad argument", who);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  uint32_t v = 0;
+  const char* word = static_cast<const char*>(reserve) + sizeof(uint64_t) * (size_t)spec::COOP_STATUS_WORD;
+  hipError_t e = hipMemcpyAsync(&v, word, sizeof(v), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: %s", who, hipGetErrorString(e));
+  *timeouts = (int32_t)v;
+  if (v != 0)
+    return fail(AGCN_EDEVICE, "%s: %u wait(s) between the workgroups that share a large graph ran out (members not co-resident: "
+                "too many concurrent launches for the chip, see agcn_set_coop_members); the results of those steps are NaN",
+                who, v);
   return AGCN_OK;
 }
 

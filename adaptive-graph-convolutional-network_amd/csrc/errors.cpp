@@ -63,6 +63,13 @@ std::atomic<int32_t> g_spec_small{[] {
   return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
 }()};
 extern "C" int32_t agcn_get_spec_small(void) { return g_spec_small.load(); }
+std::atomic<int32_t> g_coop_members{[] {
+  const char* e = std::getenv("AGCN_COOP_MEMBERS");
+  const int v = e ? std::atoi(e) : 120;
+  return v < 0 ? 0 : (v > 120 ? 120 : v);
+}()};
+extern "C" int32_t agcn_get_coop_members(void) { return g_coop_members.load(); }
+extern "C" void agcn_set_coop_members(int32_t m) { g_coop_members.store(m < 0 ? 0 : (m > 120 ? 120 : m)); }
 extern "C" void agcn_set_spec_small(int32_t on) { g_spec_small.store(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 extern "C" void agcn_set_spec_mode(int32_t mode) { g_spec_mode.store(mode < 0 ? 0 : (mode > 7 ? 7 : mode)); }
 extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }

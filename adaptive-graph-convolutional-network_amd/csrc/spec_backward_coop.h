@@ -15,7 +15,8 @@
 // only ever holds (value, epoch) words afterwards: a graph's epoch word is read by every member when it starts and
 // bumped by member 0 when it is done, so words of earlier launches, whatever batch they belonged to, never match.
 // Members are the FIRST workgroups of the launch (dispatched before any other), at most COOP_MAX_MEMBERS of them, so
-// all members of a graph are resident while they wait for each other; the waits are bounded all the same.
+// all members of a graph are resident while they wait for each other; the waits are bounded all the same (10 ms of wall
+// time), and a wait that runs out is reported: status word + NaN, see coop_wait_word.
 // The forward is spread the same way (coop_forward_member): a member computes Z for all rows, the rows I of the
 // similarity tile and their degrees -- and the members exchange s = d^-1/2.
 #ifndef AGCN_SPEC_BACKWARD_COOP_H_
@@ -43,7 +44,25 @@ constexpr int COOP_MAX_N = 128;
 // epoch word per member (a graph uses the rows / the epoch of its first slab)
 constexpr int COOP_DIR_WORDS = COOP_MAX_MEMBERS * 16 + COOP_MAX_MEMBERS;
 constexpr int COOP_HEADER_WORDS = 2 * COOP_DIR_WORDS;
-constexpr int COOP_SPIN_LIMIT = 1 << 22;
+// A member's wait for a sibling's word is bounded in WALL time (the 100 MHz constant clock): 10 ms, three orders of
+// magnitude beyond a step.  A wait that runs out counts itself in the STATUS word behind the exchange words (sticky: the
+// library never clears it; agcn_sgc_ll_reserve_status reads it) and poisons the value it was waiting for with NaN: a
+// timed-out step is wrong loudly, in the gradients AND in the return code of the next status check, never silently.
+constexpr int COOP_STATUS_WORD = COOP_HEADER_WORDS;     // 64-bit word index inside the reserve header
+constexpr unsigned long long COOP_TIMEOUT_TICKS = 1000000ull;   // 10 ms at 100 MHz
+__device__ __forceinline__ uint64_t coop_wait_word(uint64_t* status, const uint64_t* word, uint32_t want, bool* ok) {
+  const unsigned long long t0 = wall_clock64();
+  uint64_t w;
+  for (;;) {
+    w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(w >> 32) == want) { *ok = true; return w; }
+    if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *ok = false;
+  return w;
+}
 
 struct CoopLds {
   int n4, ldt;
@@ -373,15 +392,9 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   }
   // the other members' dd: poll their words until the flag is this backward's
   if (tid < n && (tid < i0 || tid >= i0 + 16)) {
-    const uint32_t want = wants[tid >> 4];
-    uint64_t w = 0;
-    int it = 0;
-    do {
-      w = __hip_atomic_load(xch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(w >> 32) == want) break;
-      __builtin_amdgcn_s_sleep(2);
-    } while (++it < COOP_SPIN_LIMIT);
-    ddv[tid] = (it < COOP_SPIN_LIMIT) ? __uint_as_float((uint32_t)w) : __builtin_nanf("");   // (a wait that ran out is loud)
+    bool got;
+    const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, xch + tid, wants[tid >> 4], &got);
+    ddv[tid] = got ? __uint_as_float((uint32_t)w) : __builtin_nanf("");   // (a wait that ran out is loud: NaN + status word)
   }
   lds_barrier();
   AGCN_STAMP(5, 6);
@@ -692,15 +705,9 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   }
   if (tid < n4 && (!paper || tid >= n)) s_vec[tid] = 0.f;
   if (paper && tid < n && (tid < i0 || tid >= i0 + 16)) {
-    const uint32_t want = wants[tid >> 4];
-    uint64_t w = 0;
-    int it = 0;
-    do {
-      w = __hip_atomic_load(xch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(w >> 32) == want) break;
-      __builtin_amdgcn_s_sleep(2);
-    } while (++it < COOP_SPIN_LIMIT);
-    s_vec[tid] = (it < COOP_SPIN_LIMIT) ? __uint_as_float((uint32_t)w) : __builtin_nanf("");
+    bool got;
+    const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, xch + tid, wants[tid >> 4], &got);
+    s_vec[tid] = got ? __uint_as_float((uint32_t)w) : __builtin_nanf("");
   }
   {   // the strip's rows of res_W and r, and s: out behind the exchange
     const int i = i0 + wave;

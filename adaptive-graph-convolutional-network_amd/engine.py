@@ -153,6 +153,12 @@ class SgcLLStep(object):
     def replay(self):
         self._graph.replay()
 
+    def check(self):
+        """Waits for the current stream and raises AgcnError if a wait between the workgroups that share a large graph ran
+        out in any step of this object (include/agcn.h: agcn_sgc_ll_reserve_status).  Call it where the host synchronises
+        anyway."""
+        return _ffi.reserve_status(self.reserve)
+
 
 class SgcLLEpochStep(object):
     """Forward + backward of one SGC_LL layer over a STREAM of batches (an epoch): every device buffer is allocated
@@ -230,11 +236,13 @@ class SgcLLEpochStep(object):
         """Forward + backward of `batch` on `stream` (a torch stream; default: the current one)."""
         plan = batch.plan
         X = batch.X
-        if X.dtype != torch.float32 or not X.is_contiguous() or X.shape[1] != self.cfg.Fin:
-            raise ValueError("node features must be contiguous fp32 [rows, Fin]")
+        if (X.dtype != torch.float32 or not X.is_contiguous() or X.dim() != 2 or X.shape[1] != self.cfg.Fin
+                or X.shape[0] < plan.rows):
+            raise ValueError("node features must be contiguous fp32 [>= %d rows, Fin]" % plan.rows)
         rb = self._fit(plan)
-        if dY is not None and (dY.dtype != torch.float32 or not dY.is_contiguous() or dY.shape[1] != self.cfg.Fout):
-            raise ValueError("dY must be contiguous fp32 [rows, Fout]")
+        if dY is not None and (dY.dtype != torch.float32 or not dY.is_contiguous() or dY.dim() != 2
+                               or dY.shape[1] != self.cfg.Fout or dY.shape[0] < plan.rows):
+            raise ValueError("dY must be contiguous fp32 [>= %d rows, Fout]" % plan.rows)
         gb = _gbatch(batch, X, None)
         stream = (torch.cuda.current_stream(self.device) if stream is None else stream).cuda_stream
         d, p, o = C.byref(self.desc), C.byref(self.pr), C.byref(self.out)
@@ -244,7 +252,17 @@ class SgcLLEpochStep(object):
                                                  C.byref(self.gr), self._reserve.data_ptr(), rb, self._ws.data_ptr(),
                                                  self._ws.numel(), stream))
         self.plan, self.batch = plan, batch       # (keeps the batch's device tensors alive until the next step)
+        self._stream = stream
         return self
+
+    def check(self):
+        """Waits for the stream of the last step and raises AgcnError if a cooperative wait ran out in any step since the
+        reserve was (re)allocated (include/agcn.h: agcn_sgc_ll_reserve_status)."""
+        n = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            st = getattr(self, "_stream", None) or torch.cuda.current_stream(self.device).cuda_stream
+            _ffi.check(self.lib.agcn_sgc_ll_reserve_status(self._reserve.data_ptr(), self._reserve.numel(), st, C.byref(n)))
+        return n.value
 
     # views of the current batch's results
     @property
@@ -328,6 +346,11 @@ class SgcLLEpochLanes(object):
         self.rstore, self.device = rstore, rstore.device
         self.steps = [SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device)
                       for _ in range(lanes)]
+        # All member workgroups of the launches in flight must be resident together (csrc/spec_backward_coop.h): the
+        # library's budget of 120 per launch is sized for two concurrent launches; with more lanes it is divided
+        # (process-wide knob, include/agcn.h agcn_set_coop_members).
+        if lanes > 2:
+            _ffi.lib().agcn_set_coop_members(min(_ffi.lib().agcn_get_coop_members(), 240 // lanes))
         self.streams = _overlapping_streams(self.device, lanes)
         self._j = 0
         torch.cuda.synchronize(self.device)      # buffers, parameters and the store were filled on other streams
@@ -338,9 +361,13 @@ class SgcLLEpochLanes(object):
         s = self.streams[k]
         return self.steps[k].step(self.rstore.stage(graph_ids, lane=k, stream=s), dY, stream=s)
 
-    def synchronize(self):
+    def synchronize(self, check=True):
+        """Waits for every lane and (check=True) raises AgcnError if a cooperative wait ran out on any of them."""
         for s in self.streams:
             s.synchronize()
+        if check:
+            for st in self.steps:
+                st.check()
 
 
 class GraphedStep(object):

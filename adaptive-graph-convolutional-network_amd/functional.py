@@ -1,8 +1,10 @@
 """torch.autograd bridge to the C ABI: one forward / one backward call per layer for the
 whole batch.  PyTorch is used for device memory, streams and autograd bookkeeping only --
 all arithmetic happens in the HIP library (there is no eager fallback)."""
+import collections
 import ctypes as C
 import functools
+import weakref
 
 import torch
 
@@ -162,6 +164,24 @@ def _sizes(plan, cfg, ldx, ldy):
     return hit
 
 
+# Reserves of recent autograd calls (weak: a reserve dies with its autograd graph): check_device_status() reads their
+# status words.  Bounded: a training loop that never checks does not grow it.
+_recent_reserves = collections.deque(maxlen=256)
+
+
+def check_device_status():
+    """Synchronises the devices of the recent SGC_LL autograd calls and raises AgcnError if a wait between the workgroups
+    that share a large graph ran out in any of them (include/agcn.h: agcn_sgc_ll_reserve_status) -- their gradients are NaN
+    then.  Call it where the training loop synchronises anyway (reading the loss).  Returns the number of reserves checked."""
+    n = 0
+    while _recent_reserves:
+        r = _recent_reserves.popleft()()
+        if r is not None:
+            _ffi.reserve_status(r)
+            n += 1
+    return n
+
+
 class SgcLLFunction(torch.autograd.Function):
     """(Y, res_L, res_W, L_sum) = SGC_LL[_Reslap](X; weight, bias, M_L, alpha, beta, L_prev)."""
 
@@ -202,6 +222,7 @@ class SgcLLFunction(torch.autograd.Function):
         out = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(out),
                                            reserve.data_ptr(), rbytes, ws.data_ptr(), wbytes, _stream(dev)))
+        _recent_reserves.append(weakref.ref(reserve))
         ctx.batch, ctx.cfg, ctx.has_prev, ctx.has_beta = batch, cfg, (reslap and L_prev is not None), beta is not None
         ctx.save_for_backward(X, weight, bias, M_L, alpha, beta, L_prev if reslap else None,
                               Y, res_L, res_W, L_sum, reserve)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AGCN_VERSION 100 /* 0.1.0 */
+#define AGCN_VERSION 101 /* 0.1.1: reserve header carries the cooperative kernels' status word */
 
 enum {
   AGCN_OK = 0,
@@ -196,6 +196,15 @@ typedef struct AgcnGrads {
  * graph exchange a vector inside a launch; csrc/spec_backward_coop.h.) */
 #define AGCN_RESERVE_HEADER_BYTES 65536
 size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host);
+/* Device-side status of the calls that used `reserve`.  The workgroups that share one large graph wait for each other's
+ * words inside a launch; such a wait is bounded (10 ms of wall time) and can only run out when the members are not
+ * co-resident -- more concurrent launches with members than the chip holds (see agcn_set_coop_members), or other work
+ * keeping the CUs.  A wait that ran out poisons its step with NaN AND counts itself in a sticky word of the header.
+ * This call copies that word to the host on `hip_stream` and WAITS for it (the one entry point that synchronises: call it
+ * where the host synchronises anyway -- reading a loss, the end of an epoch); *timeouts = the count.  Returns AGCN_OK
+ * when it is 0, AGCN_EDEVICE otherwise (every result computed with this reserve since the header was last zeroed is
+ * suspect; zero the header to re-arm). */
+int agcn_sgc_ll_reserve_status(const void* reserve, size_t reserve_bytes, void* hip_stream, int32_t* timeouts);
 size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 
@@ -436,6 +445,12 @@ void agcn_set_spec_mode(int32_t mode);
  * graph); 1: before it on the caller's stream; 0: one launch for all graphs. */
 int32_t agcn_get_spec_small(void);
 void agcn_set_spec_small(int32_t on);
+/* Member workgroups per launch of the cooperative layout (spec_mode bit 2): all members of a graph must be RESIDENT
+ * together, so concurrent member launches on one device have to fit the chip.  Default 120 (two concurrent launches on
+ * 256 CUs: two epoch lanes, or two ranks sharing a GPU); with L launches in flight set 240 / L (0: no members).  Clamped
+ * to [0, 120].  Process-wide, like the other knobs. */
+int32_t agcn_get_coop_members(void);
+void agcn_set_coop_members(int32_t members);
 
 /* Environment switches of the point-cloud kernels, read once per process (A/B measurements; results within the same
  * tolerances either way): AGCN_SLAB_SMALL=0 -- slab batches with Fin <= 4 and a dense L_orig take the general slab

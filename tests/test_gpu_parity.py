@@ -1313,6 +1313,67 @@ def test_epoch_lanes_give_the_single_lane_results(amd):
         assert torch.equal(a, x) and torch.equal(b, y) and torch.equal(c, z)
 
 
+def test_cooperative_waits_are_never_silent(amd):
+    """The workgroups that share a large graph wait for each other inside a launch (csrc/spec_backward_coop.h); the wait
+    is bounded and, when it runs out, reported: NaN in the step's results AND a sticky status word that
+    agcn_sgc_ll_reserve_status / .check() turn into AgcnError.  Stress: member launches from TWO lanes while a third
+    stream keeps every CU busy with unrelated work.  Accepted outcomes: every batch bit-identical to the single-lane run,
+    or an AgcnError from the status check -- never a NaN (or any difference) without the error.  The reporting path itself
+    is exercised by planting a count in the status word."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(77, 1536, mu=np.log(30.0), hi=128)          # many molecules of 33..128 nodes: members everywhere
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    p = synth.glorot_params(np.random.RandomState(3), 75, 64, 2)
+    layer = make_layer(amd, orc.SGC_LL, 64, 75, 256, 2, orc.PAPER, p, DEV)
+    sels = store._selections(256, False, np.random.RandomState(1))
+    r1 = store.to_device(DEV, 256)
+    ep = amd.SgcLLEpochStep(layer, r1.rows_cap, r1.tiles_cap, 256, device=DEV)
+    want, members = [], 0
+    for sel in sels:
+        gb = r1.stage(sel)
+        members += amd._ffi.dispatch_info(layer, gb)[6]
+        ep.step(gb)
+        torch.cuda.synchronize()
+        want.append((ep.Y.clone(), ep.dX.clone(), ep.bucket.clone()))
+    assert ep.check() == 0
+    assert members > 0, "the stress needs batches that use member workgroups"
+    r2 = store.to_device(DEV, 256, lanes=2)
+    lanes = amd.SgcLLEpochLanes(layer, r2, lanes=2)
+    hog_stream = torch.cuda.Stream(DEV)
+    A = torch.randn(4096, 4096, device=DEV)
+    got = []
+    with torch.cuda.stream(hog_stream):
+        for _ in range(60):                      # ~50 ms of matrix products on every CU, beside the lanes
+            A = torch.mm(A, A) * 1e-4
+    for j, sel in enumerate(sels):
+        st = lanes.step(sel)
+        if j >= 1:
+            k = (j - 1) % 2
+            lanes.streams[k].synchronize()
+            prev = lanes.steps[k]
+            got.append((prev.Y.clone(), prev.dX.clone(), prev.bucket.clone()))
+    lanes.synchronize(check=False)
+    got.append((st.Y.clone(), st.dX.clone(), st.bucket.clone()))
+    hog_stream.synchronize()
+    raised = False
+    for stp in lanes.steps:
+        try:
+            stp.check()
+        except amd.AgcnError:
+            raised = True
+    same = all(torch.equal(a, x) and torch.equal(b, y) and torch.equal(c, z) for (a, b, c), (x, y, z) in zip(got, want))
+    finite = all(bool(torch.isfinite(t).all()) for trip in got for t in trip)
+    assert raised or same, "results differ from the single-lane run and no device error was reported"
+    assert raised or finite, "NaN without a reported device error"
+    # the reporting path: a planted count in the status word of a reserve is an AgcnError at the next check
+    word = ep._reserve[8 * 4080:8 * 4080 + 4].view(torch.int32)          # 64-bit word COOP_STATUS_WORD of the header
+    word.fill_(3)
+    with pytest.raises(amd.AgcnError, match="ran out"):
+        ep.check()
+    word.zero_()
+    assert ep.check() == 0
+
+
 @pytest.mark.parametrize("Fin,Fout", [(75, 64), (64, 128), (128, 128), (128, 64), (64, 64)])
 def test_large_graphs_spread_over_several_workgroups(amd, Fin, Fout):
     """Paper-mode backward with the graphs of >= 33 nodes spread over one workgroup per 16-row tile (members exchange

@@ -255,3 +255,47 @@ def test_dispatch_table(amd):
     assert _dispatch(amd, n256, 64, 64, 1, variant=1)["path"] == 4
     assert _dispatch(amd, n256, 75, 64, 1, K=3)["path"] == 32
     del rs
+
+
+def test_member_budget_knob_and_cloud_dispatch(amd):
+    """agcn_set_coop_members: the member workgroups of a launch never exceed the budget (all members of the launches in
+    flight must be co-resident: epoch lanes divide it), clamped to [0, 120]; and point-cloud batches (Fin = 64, dense
+    symmetric L_orig, every graph a multiple of 64 nodes) report the cloud kernels (path bit 64)."""
+    from agcn_amd import synth
+    lib = amd._ffi.lib()
+    n256 = synth.node_counts(np.random.RandomState(123), 256)
+    old = lib.agcn_get_coop_members()
+    try:
+        assert old == 120
+        full = _dispatch(amd, n256, 75, 64, 1)["f_members"]
+        assert 40 < full <= 120
+        lib.agcn_set_coop_members(40)
+        d = _dispatch(amd, n256, 75, 64, 1)
+        assert d["path"] == 7 and 0 < d["f_members"] <= 40 and d["b_members"] <= 40
+        lib.agcn_set_coop_members(0)
+        d = _dispatch(amd, n256, 75, 64, 1)
+        assert d["path"] == 7 and d["f_members"] == 0 and d["b_members"] == 0
+        lib.agcn_set_coop_members(100000)
+        assert lib.agcn_get_coop_members() == 120
+        lib.agcn_set_coop_members(-5)
+        assert lib.agcn_get_coop_members() == 0
+    finally:
+        lib.agcn_set_coop_members(old)
+    clouds = np.full(4, 1024, np.int32)
+    assert _dispatch(amd, clouds, 64, 128, 1)["path"] == 16          # CSR L_orig: the general slab kernels
+    import ctypes as C
+
+    def path(n_arr, Fin, Fout):
+        n_arr = np.ascontiguousarray(n_arr, np.int32)
+        nb = lib.agcn_plan_bytes_for(n_arr.ctypes.data, n_arr.size, 0)
+        pl = np.zeros(nb, np.uint8)
+        assert lib.agcn_plan_build(n_arr.ctypes.data, n_arr.size, 0, pl.ctypes.data, nb) == 0
+        desc = amd._ffi.LayerDesc(Fin, Fout, 2, 1, 0, 1, Fin, Fout)
+        gb = amd._ffi.GraphBatch(pl.ctypes.data, 1, 1, 1, 0, 1, None, None, None, None)      # dense L_orig, symmetric
+        out = (C.c_int32 * 8)()
+        assert lib.agcn_sgc_ll_dispatch_info(C.byref(desc), C.byref(gb), out, 8) == 0
+        return out[0]
+    assert path(clouds, 64, 128) == 16 | 64
+    assert path([512, 256, 320, 64], 64, 128) == 16 | 64
+    assert path([300, 257, 519, 131], 64, 128) == 16          # not multiples of 64: general slab kernels
+    assert path(clouds, 3, 64) == 16                             # the first layer has kernels of its own (Fin <= 4)
