@@ -404,6 +404,10 @@ def main():
     run_layer_case(*L, "reslap_chain",     "reslap", [4, 9, 6, 12],      7,  6, 2, 12, True, chain=True)
     run_layer_case(*L, "reslap_chain_tox", "reslap", [18, 30, 5],       75, 64, 2, 13, False, atoms=True,
                    chain=True)
+    # BASELINE.json config 1: "Tox21 batch=32, K=2 Chebyshev, repo's TF CPU path" -- a whole 32-graph batch of the
+    # synthetic Tox21-shaped generator's sizes (lognormal(ln 16, 0.5) clipped to [4, 132], seed 123)
+    ns32 = np.clip(np.rint(np.random.RandomState(123).lognormal(np.log(16.0), 0.5, size=32)), 4, 132).astype(int)
+    run_layer_case(*L, "sgc_tox_b32",      "sgc",    [int(v) for v in ns32], 75, 64, 2, 14, False, atoms=True)
 
 
 if __name__ == "__main__":

@@ -16,6 +16,10 @@ from conftest import GOLDEN
 # Fout = 1, where the "row" is the cancelling element itself).  The allowance is calibrated on fp32 arithmetic itself (this oracle run in float32
 # against its float64 run on the test cases: Y <= 5 ulp of the row max, dX / dweight <= 5, dM_L <= 8, and the
 # degenerate Fin = 1 case 17 ulp on dM_L, 120 on dX): 16 ulp for features, 32 for gradients.
+# Parameter gradients that reduce over every pair of every graph (dM_L, dalpha, dbeta) carry NO extra multiplier: the
+# main parametrised tests run the oracle a second time in float32 and print its error next to the HIP path's
+# (assert_close ref32 / _scalar_close): the HIP results sit at 0.0-0.4 of the plain gradient bound, where the fp32
+# oracle itself sits (0.0-0.5; once 2.7 on a scalar).
 # Tile outputs (res_W, res_L) are products / exponentials without cancellation: pure relative (atol_ulps = 0; values
 # below the smallest normal float may be flushed).
 FEATURE_RTOL = 1e-5
@@ -38,10 +42,14 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / den) if b.size else 0.0
 
 
-def assert_close(a, b, rtol, what, atol_ulps=None):
+def assert_close(a, b, rtol, what, atol_ulps=None, ref32=None):
     """Element-wise: |a - b| <= rtol |b| + atol_ulps eps scale (+ the flush-to-zero range), scale = the largest
     |b| in the element's row (last axis) or column (axis -2); whole-vector max for 1-D.  atol_ulps defaults to
-    FEATURE_ULPS for rtol <= FEATURE_RTOL and GRAD_ULPS otherwise."""
+    FEATURE_ULPS for rtol <= FEATURE_RTOL and GRAD_ULPS otherwise.
+    ref32: the SAME quantity from the oracle run in float32.  The bound is then calibrated per case on what fp32
+    arithmetic of the reference algorithm itself achieves: with k32 = the worst fp32-oracle error in units of the
+    bound, the HIP result may be max(1, 2 k32) bounds away -- never looser than twice the oracle's own fp32 error,
+    never tighter than the stated bar -- and both figures are printed (pytest -s / on failure)."""
     a = np.asarray(a)
     b = np.asarray(b)
     assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
@@ -58,6 +66,11 @@ def assert_close(a, b, rtol, what, atol_ulps=None):
         scale = np.abs(b64).max()
     bound = rtol * np.abs(b64) + atol_ulps * EPS32 * scale + TINY32
     err = np.abs(a64 - b64)
+    if ref32 is not None:
+        k32 = float((np.abs(np.asarray(ref32, dtype=np.float64) - b64) / bound).max())
+        kgpu = float((err / bound).max())
+        print("%-12s fp32 oracle %.2f x the bound, HIP %.2f x the bound (rtol %.0e + %g ulp)" % (what, k32, kgpu, rtol, atol_ulps))
+        bound = bound * max(1.0, 2.0 * k32)
     bad = err > bound
     if bad.any():
         k = np.unravel_index(np.argmax(err / bound), err.shape)
@@ -174,7 +187,21 @@ def run_packed(agcn_amd, device, ns, X, csr, p, G, Fin, Fout, K, mode, variant, 
     return out
 
 
-def compare_with_oracle(out, caches, tot, variant, mode, K, has_prev):
+def _scalar_close(got, want, want32, scale, what):
+    """Scalar gradients (dalpha, dbeta: sums over every pair of every graph): GRAD_RTOL of the weight-gradient scale, or
+    twice the error the fp32 oracle itself makes on this case, whichever is larger (printed)."""
+    got, want = float(np.asarray(got).reshape(-1)[0]), float(np.asarray(want).reshape(-1)[0])
+    bar = GRAD_RTOL * max(abs(want), scale)
+    e32 = abs(float(np.asarray(want32).reshape(-1)[0]) - want) if want32 is not None else None
+    print("%-12s fp32 oracle %s, HIP %.2f x the bar (%.1e of the gradient scale)"
+          % (what, "n/a" if e32 is None else "%.2f x the bar" % (e32 / bar), abs(got - want) / bar, GRAD_RTOL))
+    allowed = max(bar, 2.0 * e32) if e32 is not None else 2.0 * bar
+    assert abs(got - want) <= allowed, "%s %r vs %r (allowed %.3e)" % (what, got, want, allowed)
+
+
+def compare_with_oracle(out, caches, tot, variant, mode, K, has_prev, tot32=None):
+    """tot32: the oracle's gradients from a float32 run of the same case (oracle_run(..., dtype=np.float32)[1]): the
+    parameter-gradient bounds are then calibrated on it (assert_close, ref32)."""
     B = len(caches)
     assert_close(np.concatenate(out["Y"]), np.concatenate([c["Y"] for c in caches]), FEATURE_RTOL, "Y")
     for b in range(B):
@@ -185,18 +212,18 @@ def compare_with_oracle(out, caches, tot, variant, mode, K, has_prev):
     assert_close(np.concatenate(out["dX"]), np.concatenate(tot["dX"]), GRAD_RTOL, "dX")
     assert_close(out["dweight"], tot["dweight"], GRAD_RTOL, "dweight")
     assert_close(out["dbias"], tot["dbias"], GRAD_RTOL, "dbias")
-    da = float(np.asarray(tot["dalpha"]).reshape(-1)[0])
-    scale = max(abs(da), float(np.abs(tot["dweight"]).max()))
-    assert abs(float(out["dalpha"][0]) - da) <= GRAD_RTOL * 10 * scale, "dalpha %r vs %r" % (out["dalpha"], da)
+    scale = float(np.abs(tot["dweight"]).max())
+    _scalar_close(out["dalpha"], tot["dalpha"], None if tot32 is None else tot32["dalpha"], scale, "dalpha")
     if mode == orc.PAPER:
         if tot["dM_L"] is None:
             assert out["dM_L"] is None or np.all(out["dM_L"] == 0)
+        elif tot32 is not None:
+            assert_close(out["dM_L"], tot["dM_L"], GRAD_RTOL, "dM_L", ref32=tot32["dM_L"])
         else:
-            assert_close(out["dM_L"], tot["dM_L"], 5 * GRAD_RTOL, "dM_L")
+            assert_close(out["dM_L"], tot["dM_L"], GRAD_RTOL, "dM_L")
     else:
         assert out["dM_L"] is None
     if has_prev:
-        db = float(np.asarray(tot["dbeta"]).reshape(-1)[0])
-        assert abs(float(out["dbeta"][0]) - db) <= GRAD_RTOL * 10 * max(abs(db), scale), "dbeta"
+        _scalar_close(out["dbeta"], tot["dbeta"], None if tot32 is None else tot32["dbeta"], scale, "dbeta")
         for b in range(B):
             assert_close(out["dLp"][b], tot["dLp"][b], GRAD_RTOL, "dL_prev[%d]" % b)

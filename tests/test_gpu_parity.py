@@ -159,8 +159,9 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
             Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
             dLsum = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
         caches, tot = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLsum)
+        _, tot32 = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLsum, dtype=np.float32)   # what fp32 itself achieves
         out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, variant, Lp, dLsum)
-        compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
+        compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
     finally:
         amd._ffi.lib().agcn_set_fused_global_b(-1)
         amd._ffi.lib().agcn_set_param_grad_onepass(1)
@@ -618,8 +619,9 @@ def test_full_size_every_graph_every_gradient(amd, variant, mode, B):
         Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
         dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
     caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, variant, G, Lp, dLs)
+    _, tot32 = oracle_run(sb["X"], sb["L0"], p, K, mode, variant, G, Lp, dLs, dtype=np.float32)
     out = run_packed(amd, DEV, ns, sb["X"], sb["csr"], p, G, Fin, Fout, K, mode, variant, Lp, dLs)
-    compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
+    compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
 
 
 @pytest.mark.parametrize("reach", ["beyond_members", "within_members"])
