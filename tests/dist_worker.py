@@ -35,7 +35,38 @@ def run_shard(idx, dev, mode="paper"):
     return st
 
 
+def capture_main(out):
+    """bench.py --graph-allreduce's code path on ONE GPU: a one-rank RCCL group (a real ncclAllReduce launch, identity in
+    value), the all-reduce of the flat bucket captured into the step's HIP graph BEHIND the step, replays compared with the
+    eager bucket bit for bit.  Proves on this stack that RCCL initialises with device_id, that its collective is
+    capturable, and that SgcLLStep.capture(extra=...) orders it behind the parameter-gradient kernel."""
+    import torch
+    import torch.distributed as dist
+    import agcn_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    Fin, Fout, K, data, p, G = global_batch()
+    st = run_shard(np.arange(len(data["n"])), dev)
+    torch.cuda.synchronize(dev)
+    want = st.bucket.clone()
+    warm = torch.ones(4, device=dev)
+    dist.all_reduce(warm)                                  # communicator set-up outside the capture
+    torch.cuda.synchronize(dev)
+    st.capture(extra=lambda: dist.all_reduce(st.bucket, op=dist.ReduceOp.SUM), steps=2)
+    ok = True
+    for _ in range(3):
+        st.bucket.zero_()
+        st.replay()
+        torch.cuda.synchronize(dev)
+        ok = ok and bool(torch.equal(st.bucket, want))
+    np.savez(out, ok=int(ok), ranks=dist.get_world_size(), bucket=st.bucket.cpu().numpy(), want=want.cpu().numpy())
+    dist.destroy_process_group()
+
+
 def main():
+    if sys.argv[1] == "capture":
+        return capture_main(sys.argv[2])
     backend, shared, out = sys.argv[1], sys.argv[2] == "1", sys.argv[3]
     import torch
     import torch.distributed as dist

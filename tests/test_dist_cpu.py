@@ -82,6 +82,73 @@ def test_bucket_allreduce_world2(amd):
     assert float(g2[0]) == float(n.sum())                                           # integers: exact
 
 
+def _oracle_worker(rank, world, port, out_q):
+    """One rank of the 8-way data-parallel run of the B = 2048 global batch (BASELINE config 4) with the ORACLE as the
+    per-rank compute: LPT shard -> forward + backward -> flat bucket [dweight | dbias | dM_L | dalpha] -> SUM all-reduce."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "oracle"))
+    import agcn_amd
+    import agcn_oracle as orc
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    agcn_amd.dist.init_from_env("gloo")
+    X, L0, p, G, ns = _dp_case(orc)
+    shards = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(ns, 75, 64, 2), world)
+    mine = shards[rank]
+    flat = _oracle_bucket(orc, [X[i] for i in mine], [L0[i] for i in mine], p, [G[i] for i in mine])
+    agcn_amd.dist.allreduce_bucket(flat)
+    if rank == 0:
+        out_q.put((flat.numpy().copy(), [len(s) for s in shards]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_case(orc):
+    sb = orc.synth_batch(123, 2048)
+    rs = np.random.RandomState(9)
+    p = {k: v.astype(np.float64) for k, v in orc.init_params(rs, 75, 64, 2).items()}
+    ns = np.asarray(sb["ns"])
+    G = [np.random.RandomState(1000 + b).randn(int(n), 64) for b, n in enumerate(ns)]
+    X = [x.astype(np.float64) for x in sb["X"]]
+    L0 = [l.astype(np.float64) for l in sb["L0"]]
+    return X, L0, p, G, ns
+
+
+def _oracle_bucket(orc, X, L0, p, G):
+    caches = orc.layer_forward(X, L0, p, 2, orc.PAPER, orc.SGC_LL)
+    tot = orc.layer_backward(caches, G, p, 2, orc.PAPER, orc.SGC_LL)
+    parts = [tot["dweight"], tot["dbias"], tot["dM_L"], np.asarray(tot["dalpha"]).reshape(-1)]
+    return torch.from_numpy(np.concatenate([np.asarray(t, np.float64).reshape(-1) for t in parts]))
+
+
+def test_bucket_equality_world8_full_global_batch(amd):
+    """BASELINE config 4 (Tox21 batch = 2048 over 8 GPUs) with everything but the GPU: 8 gloo ranks, each with its LPT
+    shard (256 graphs) of the 2048-graph global batch, the oracle as the per-rank compute, ONE SUM all-reduce of the flat
+    bucket == the single-process gradients of the whole batch (float64: 1e-9 of the bucket's scale: the order of
+    summation is the only difference)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import agcn_oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oracle_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p_ in procs:
+        p_.start()
+    got, counts = q.get(timeout=600)
+    for p_ in procs:
+        p_.join(timeout=600)
+        assert p_.exitcode == 0
+    assert counts == [256] * 8
+    X, L0, p, G, ns = _dp_case(orc)
+    want = _oracle_bucket(orc, X, L0, p, G).numpy()
+    assert got.shape == want.shape == (75 * 2 * 64 + 64 + 75 * 75 + 1,)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9 * np.abs(want).max())
+
+
 def test_single_process_is_noop(amd):
     t = torch.arange(4, dtype=torch.float32)
     assert torch.equal(amd.dist.allreduce_bucket(t.clone()), t)

@@ -60,6 +60,22 @@ def test_dp_step_matches_single_rank(flavour, tmp_path):
         assert float(g.abs().max()) > 0, k
 
 
+def test_allreduce_captured_into_the_step_graph(tmp_path):
+    """`bench.py --graph-allreduce` on one GPU: a one-rank RCCL group, the bucket all-reduce captured into the HIP graph
+    behind the step (tests/dist_worker.py capture_main), three replays bit-identical to the eager bucket."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = str(tmp_path / "capture.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "capture", out], env=env, timeout=600)
+    assert res.returncode == 0
+    got = np.load(out)
+    assert int(got["ranks"]) == 1 and int(got["ok"]) == 1
+    assert np.array_equal(got["bucket"], got["want"]) and float(np.abs(got["want"]).max()) > 0
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset) must spawn two ranks and print n_gpus == 2."""
     env = dict(os.environ)
