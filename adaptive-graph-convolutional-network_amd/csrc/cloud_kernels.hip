@@ -69,13 +69,6 @@ __device__ __forceinline__ WaveCtx wave_ctx(const SgcArgs& a, int slab) {
 #ifndef AGCN_CLOUD_XCD
 #define AGCN_CLOUD_XCD 1
 #endif
-// AGCN_CLOUD_SYM=1: only the blocks on and above the block diagonal of S / r are computed and each is also written
-// mirrored, a lane's four consecutive rows of its column as 16 bytes of the mirrored row.  Measured: 264 us against
-// 100 us -- 64 scattered 16-byte pieces per store instruction are partial-line writes all the way to memory, and the
-// three kernels behind it slow down as well (lap 101 -> 119 us).  Off; kept as the record of the experiment.
-#ifndef AGCN_CLOUD_SYM
-#define AGCN_CLOUD_SYM 0
-#endif
 __device__ __forceinline__ int xcd_strip(int n_strips) {
   const int per = (n_strips + 7) >> 3, g = (int)blockIdx.x;
   const int s = AGCN_CLOUD_XCD ? (g & 7) * per + (g >> 3) : g;
@@ -101,15 +94,29 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 //   A: wave-private image [16][LD], k = image column;  B: image [k][c] (the chunk's rows), both read 16 bytes wide.
 //   MFMA step j of block blk pairs A[r][16 blk + 4q + j] with B[16 blk + 4q + j][4r + e].
 __device__ __forceinline__ void strip_mma(f32x4 (&acc)[4], const float* A, const float* B, int r, int q) {
+  // the fragment reads run ONE 4-MFMA step ahead of their use (the compiler, left alone, puts each ds_read right in front
+  // of its MFMAs behind an lgkmcnt(0): ~100 cycles of LDS latency exposed per 128 cycles of matrix work)
+  f32x4 av = *reinterpret_cast<const f32x4*>(A + r * LD + 4 * q);
+  f32x4 bv = *reinterpret_cast<const f32x4*>(B + (4 * q) * LD + 4 * r);
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
-    const f32x4 av = *reinterpret_cast<const f32x4*>(A + r * LD + 16 * blk + 4 * q);
+    f32x4 av_next = av;
+    if (blk < 3) av_next = *reinterpret_cast<const f32x4*>(A + r * LD + 16 * (blk + 1) + 4 * q);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(B + (16 * blk + 4 * q + j) * LD + 4 * r);
+      const int step = 4 * blk + j;
+      f32x4 bv_next = bv;
+      if (step < 15) {
+        const int nb = (step + 1) >> 2, nj = (step + 1) & 3;
+        bv_next = *reinterpret_cast<const f32x4*>(B + (16 * nb + 4 * q + nj) * LD + 4 * r);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] = mfma4(av[j], bv[e], acc[e]);
+      __builtin_amdgcn_sched_barrier(0);
+      bv = bv_next;
     }
+    av = av_next;
   }
 }
 
@@ -142,11 +149,25 @@ __device__ __forceinline__ const float* dense_l0(const SgcArgs& a, const WaveCtx
 
 // ------------------------------------------------------------------------------------------------
 // forward 1: S = exp(-||Z_i - Z_j||) (graphconv.py:163-180) -> res_W, r -> reserve (paper mode), partial degrees.
-// Workgroup = one 64-row block of a graph x a quarter of its column blocks; a wave = one 64 x 64 block, one column per lane.
-// S and r are symmetric bit for bit, so only the blocks on and above the block diagonal are computed; a block above it is
-// also written transposed (a lane's four consecutive rows of its column = 16 contiguous bytes of the mirrored row) and
-// contributes its ROW sums as the partial degrees of the mirrored block.
-__global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart) {
+// Workgroup = one 64-row block of a graph; a wave = NB 64 x 64 blocks at a time (one column of each per lane, the
+// columns' Z rows in 64 NB registers) against the block's rows, which come through the scalar cache into SGPRs
+// (uniform address: s_load_dwordx16), half a row at a time into one of two buffers: the half after the one being consumed
+// is requested right behind the wait for the current one -- scalar loads return out of order, so the only usable wait is
+// lgkmcnt(0) -- and has the 64 NB vector instructions of a half row to arrive.  Measured (32 clouds of 1024 points):
+//   the compiler's own schedule (8 instructions between request and wait)              175 us
+//   explicit double buffering, NB = 1 (64 instructions of cover, 5 waves per SIMD)      100 us
+//   two accumulation chains; 16 waves of a row block in one workgroup (shared rows)      100 us (neither binds)
+//   NB = 2 (128 instructions of cover, half the scalar requests per pair)               110 us
+// against 58 us of pure issue time (2 instructions per pair and feature); LDS-staged register blocks (slab_sim): 198 us.
+// 16-byte stores: a lane holds ONE column, so four rows of S (and r) are turned through a wave-private LDS patch [4][64]
+// and leave as one dwordx4 per lane (row lane / 16, columns 4 (lane % 16) ..); dword-per-lane stores are bound by store
+// issue.  Computing only the blocks on or above the diagonal and writing each also mirrored (a lane's four rows of its
+// column = 16 bytes of the mirrored row) was measured and rejected: 264 us -- 64 scattered 16-byte pieces per store
+// instruction are partial-line writes all the way to memory, and the kernels behind it slowed down as well.
+template <int NB>
+__global__ __launch_bounds__(64 * (NB == 1 ? 16 : 8)) void cloud_sim_kernel(SgcArgs a, float* dpart) {
+  extern __shared__ __attribute__((aligned(16))) float trbuf[];   // [waves][NB][2][4 * 64]
+  const int nw = (int)(blockDim.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int strip = xcd_strip(a.n_slabs >> 2);
@@ -159,36 +180,22 @@ __global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart)
   const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
   float* dp = dpart + (toff >> 6) + (int64_t)(r0 >> 6) * n;   // partial degrees of this row block: [n / 64][n] per graph
   const int ncb = n >> 6;
-  __shared__ __attribute__((aligned(16))) float trbuf[4][2][4 * 64];
-  float* trS = trbuf[wave][0];
-  float* trR = trbuf[wave][1];
-  const int rb = r0 >> 6;
-  for (int jb = (AGCN_CLOUD_SYM ? rb : 0) + wave + 4 * (int)blockIdx.y; jb < ncb; jb += 4 * (int)gridDim.y) {
-    const int j = 64 * jb + lane;
-    const bool mirror = AGCN_CLOUD_SYM && jb > rb;
-    float zj[FIN];
-    {
+  float* tr = trbuf + wave * (NB * 512);
+  for (int jb = NB * wave; jb < ncb; jb += NB * nw) {
+    float zj[NB][FIN];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const int j = 64 * min(jb + c, ncb - 1) + lane;          // (a column block beyond the graph: recomputed, not stored)
       const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)j * FIN);
 #pragma unroll
       for (int f4 = 0; f4 < FIN / 4; ++f4) {
         const f32x4 t = zp[f4];
-        zj[4 * f4 + 0] = t.x; zj[4 * f4 + 1] = t.y; zj[4 * f4 + 2] = t.z; zj[4 * f4 + 3] = t.w;
+        zj[c][4 * f4 + 0] = t.x; zj[c][4 * f4 + 1] = t.y; zj[c][4 * f4 + 2] = t.z; zj[c][4 * f4 + 3] = t.w;
       }
     }
-    float cs = 0.f;
-    // 16-byte stores: a lane holds ONE column, so four rows of S (and r) are turned through a wave-private LDS patch
-    // [4][64] and leave as one dwordx4 per lane (row lane / 16, columns 4 (lane % 16) ..): dword-per-lane stores are
-    // bound by store ISSUE at ~2.4 TB/s on this chip (measured here: 110 us for 268 MB), 16-byte ones are not
-    float* wout = a.res_W + toff + (int64_t)(r0 + (lane >> 4)) * n + 64 * jb + 4 * (lane & 15);
-    float* rout = a.sv_r + toff + (int64_t)(r0 + (lane >> 4)) * n + 64 * jb + 4 * (lane & 15);
-    float* woutT = a.res_W + toff + (int64_t)j * n + r0;     // the mirrored block: row j, columns r0 ..
-    float* routT = a.sv_r + toff + (int64_t)j * n + r0;
-    float* dpT = dpart + (toff >> 6) + (int64_t)jb * n + r0 + (lane >> 4);
-    // The row operand z_i comes through the scalar cache into SGPRs (uniform address), half a row (32 features = two
-    // s_load_dwordx16) at a time into one of two buffers: the half after the one being consumed is requested right
-    // behind the wait for the current one -- scalar loads return out of order, so the only usable wait is
-    // lgkmcnt(0), and a request has the 64 vector instructions of a half row to arrive (the compiler's own schedule
-    // put 8 instructions between request and wait: 175 us for this kernel against 58 us of issue time).
+    float cs[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) cs[c] = 0.f;
     const float* zrow = Zg + (int64_t)r0 * FIN;
     f32x16 A0, A1, B0, B1;
     SLOAD16(A0, zrow, "0x0");
@@ -198,49 +205,60 @@ __global__ __launch_bounds__(256) void cloud_sim_kernel(SgcArgs a, float* dpart)
 #pragma unroll 1
       for (int u = 0; u < 4; ++u) {
         const int ii = i4 + u;
-        float acc = 0.f;
-        SWAIT2(A0, A1, cs);
+        float acc[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) acc[c] = 0.f;
+        SWAIT2(A0, A1, cs[0]);
         SLOAD16_BEFORE(B0, zrow, "0x80", A0);
         SLOAD16_BEFORE(B1, zrow, "0xc0", A1);
 #pragma unroll
-        for (int f = 0; f < 16; ++f) { const float d = A0[f] - zj[f]; acc = __builtin_fmaf(d, d, acc); }
+        for (int f = 0; f < 16; ++f)
 #pragma unroll
-        for (int f = 0; f < 16; ++f) { const float d = A1[f] - zj[16 + f]; acc = __builtin_fmaf(d, d, acc); }
-        SWAIT2(B0, B1, acc);
+          for (int c = 0; c < NB; ++c) { const float d = A0[f] - zj[c][f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+          for (int c = 0; c < NB; ++c) { const float d = A1[f] - zj[c][16 + f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
+        SWAIT2(B0, B1, acc[NB - 1]);
         zrow += (ii + 1 < CS) ? FIN : 0;      // (the last request re-reads the last row: never used)
         SLOAD16_BEFORE(A0, zrow, "0x0", B0);
         SLOAD16_BEFORE(A1, zrow, "0x40", B1);
 #pragma unroll
-        for (int f = 0; f < 16; ++f) { const float d = B0[f] - zj[32 + f]; acc = __builtin_fmaf(d, d, acc); }
+        for (int f = 0; f < 16; ++f)
 #pragma unroll
-        for (int f = 0; f < 16; ++f) { const float d = B1[f] - zj[48 + f]; acc = __builtin_fmaf(d, d, acc); }
+          for (int c = 0; c < NB; ++c) { const float d = B0[f] - zj[c][32 + f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+          for (int c = 0; c < NB; ++c) { const float d = B1[f] - zj[c][48 + f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
         // ((z_i - z_j)^2 == (z_j - z_i)^2 and the same f order for both orientations of a pair: S bit-symmetric)
-        const float rr = __builtin_amdgcn_sqrtf(acc);
-        // S_ii = 0 (graphconv.py:171-173); exp(-1 * norm) otherwise (:176-177)
-        const float S = (r0 + ii == j) ? 0.f : __builtin_amdgcn_exp2f(rr * NLOG2E);
-        trS[u * 64 + lane] = S;
-        if (paper) trR[u * 64 + lane] = rr;
-        cs += S;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          const float rr = __builtin_amdgcn_sqrtf(acc[c]);
+          // S_ii = 0 (graphconv.py:171-173); exp(-1 * norm) otherwise (:176-177)
+          const float S = (r0 + ii == 64 * (jb + c) + lane) ? 0.f : __builtin_amdgcn_exp2f(rr * NLOG2E);
+          tr[c * 512 + u * 64 + lane] = S;
+          if (paper) tr[c * 512 + 256 + u * 64 + lane] = rr;
+          cs[c] += S;
+        }
       }
       __builtin_amdgcn_wave_barrier();
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(trS + 4 * lane);
-      *reinterpret_cast<f32x4*>(wout + (int64_t)i4 * n) = sv;
-      if (paper) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(trR + 4 * lane), reinterpret_cast<f32x4*>(rout + (int64_t)i4 * n));
-      if (mirror) {
-        *reinterpret_cast<f32x4*>(woutT + i4) = (f32x4){trS[lane], trS[64 + lane], trS[128 + lane], trS[192 + lane]};
-        if (paper)
-          __builtin_nontemporal_store((f32x4){trR[lane], trR[64 + lane], trR[128 + lane], trR[192 + lane]},
-                                      reinterpret_cast<f32x4*>(routT + i4));
-        // row sums of the four rows (a row = 16 lanes' 4 columns each): the mirrored block's column sums
-        float t = (sv.x + sv.y) + (sv.z + sv.w);
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
-        if ((lane & 15) == 0) dpT[i4] = t;
+      for (int c = 0; c < NB; ++c) {
+        if (jb + c < ncb) {
+          const int64_t o = toff + (int64_t)(r0 + i4 + (lane >> 4)) * n + 64 * (jb + c) + 4 * (lane & 15);
+          *reinterpret_cast<f32x4*>(a.res_W + o) = *reinterpret_cast<const f32x4*>(tr + c * 512 + 4 * lane);
+          if (paper)
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(tr + c * 512 + 256 + 4 * lane),
+                                        reinterpret_cast<f32x4*>(a.sv_r + o));
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
-    SWAIT2(A0, A1, cs);                      // (nothing of this column block's requests is left in flight)
-    dp[j] = cs;
+    SWAIT2(A0, A1, cs[0]);                   // (nothing of these column blocks' requests is left in flight)
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (jb + c < ncb) dp[64 * (jb + c) + lane] = cs[c];
   }
 }
 
@@ -322,11 +340,7 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
     __syncthreads();                  // every wave is done with the previous chunk's rows
     stage_store(Bs, pre);
     __syncthreads();
-    Tiles nxt = cur;
-    if (c0 + CC < n) {                // the next chunk's loads in flight behind this chunk's arithmetic
-      pre = stage_load(Xg, a.ldx, c0 + CC);
-      nxt = load_tiles(c0 + CC);
-    }
+    if (c0 + CC < n) pre = stage_load(Xg, a.ldx, c0 + CC);   // the next chunk's rows in flight behind this chunk's arithmetic
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
@@ -342,9 +356,10 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
       __builtin_nontemporal_store(Lv, reinterpret_cast<f32x4*>(RLt + (int64_t)i * n + c0));
       if (LSt) *reinterpret_cast<f32x4*>(LSt + (int64_t)i * n + c0) = Ltv;
     }
+    // the next chunk's tiles: requested once this chunk's are consumed (into the same registers), in flight behind the product
+    if (c0 + CC < n) cur = load_tiles(c0 + CC);
     __builtin_amdgcn_wave_barrier();
     strip_mma(acc, Ls, Bs, r, q);
-    cur = nxt;
   }
   // X_1[I] = L[I, :] X_0 -> reserve; and, with X_0[I], the A images of the filter product
   __syncthreads();                    // the chunk image is dead: its space holds the X_0[I] images now
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
 // backward 1: dX[I] += L[I, :] g_1 (L symmetric);  paper: P = dL + dL^T = [g_1 | X_0][I] . [X_0 | g_1][J]^T,
 // Q = -lrelu'(R) P -> workspace, ds_i = sum_j Q_ij S_ij s_j -> dd_i, dalpha = 1/2 sum P_ij min(R_ij, 0).
 template <bool PAPER>
-__global__ __launch_bounds__(256) void cloud_bwd1_kernel(SgcArgs a) {
+__global__ __launch_bounds__(256, 2) void cloud_bwd1_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -464,56 +479,61 @@ __global__ __launch_bounds__(256) void cloud_bwd1_kernel(SgcArgs a) {
     stage_store(Gs, preG);
     if (PAPER) stage_store(Xs, preX);
     __syncthreads();
-    Tiles nxt = cur;
     if (c0 + CC < n) {
       preG = stage_load(g1, FIN, c0 + CC);
       if (PAPER) preX = stage_load(Xg, a.ldx, c0 + CC);
-      nxt = load_tiles(c0 + CC);
     }
-    f32x4 S[4], R[4];     // [i][t]
+    f32x4 S[4], R[4];     // [i][t]: S_ij s_j and R_ij
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const bool diag = row == c0 + 4 * r + t;
-        S[i][t] = (!PAPER || diag) ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);   // cloud_sim's instruction
+        const float Sv = (!PAPER || diag) ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);   // cloud_sim's instruction
         R[i][t] = diag ? 1.f : 0.f;
-        if (PAPER) R[i][t] = R[i][t] - (si[i] * S[i][t]) * cur.sj[t];                         // cloud_lap's instruction
+        if (PAPER) R[i][t] = R[i][t] - (si[i] * Sv) * cur.sj[t];                                   // cloud_lap's instruction
+        S[i][t] = Sv * cur.sj[t];
         Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(R[i][t], alpha) + cur.l0[i][t];
       }
     }
+    // the next chunk's tiles: requested once this chunk's are consumed (into the same registers), in flight behind the products
+    if (c0 + CC < n) cur = load_tiles(c0 + CC);
+    __builtin_amdgcn_wave_barrier();
     if (PAPER) {
+      // P[I, tile] = g_1[I] . X_0[tile]^T + X_0[I] . g_1[tile]^T (two independent accumulation chains per tile), then the
+      // tile's element-wise epilogue.  (Software-pipelined orders -- the next tile's MFMAs issued before this tile's
+      // epilogue, fragments read a tile ahead, sched_group_barrier interleaving -- were measured: no gain at 2 waves per
+      // SIMD, and 280-300 VGPRs without the launch bound; profiles/EXPERIMENTS.md.)
       f32x4 Qv[4];         // [i][t]
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        // P[I, tile] = g_1[I] . X_0[tile]^T + X_0[I] . g_1[tile]^T   (two independent accumulation chains)
-        f32x4 Pa = (f32x4){0.f, 0.f, 0.f, 0.f}, Pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           const f32x4 bx = *reinterpret_cast<const f32x4*>(Xs + (16 * t + r) * LD + 16 * kb + 4 * q);
           const f32x4 bg = *reinterpret_cast<const f32x4*>(Gs + (16 * t + r) * LD + 16 * kb + 4 * q);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            Pa = mfma4(gIf[kb][j], bx[j], Pa);
-            Pb = mfma4(xIf[kb][j], bg[j], Pb);
+            pa = mfma4(gIf[kb][j], bx[j], pa);
+            pb = mfma4(xIf[kb][j], bg[j], pb);
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float P = Pa[i] + Pb[i];
+          const float P = pa[i] + pb[i];
           dalpha_part = __builtin_fmaf(P, fminf(R[i][t], 0.f), dalpha_part);
           const float Q = -(P * lrelu_grad(R[i][t], alpha));     // dA_ij + dA_ji, dA = -dR
           Qv[i][t] = Q;
-          ds[i] = __builtin_fmaf(Q * S[i][t], cur.sj[t], ds[i]);  // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
+          ds[i] = __builtin_fmaf(Q, S[i][t], ds[i]);              // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
         }
       }
+      strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = Qv[i];
+    } else {
+      strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
     }
-    __builtin_amdgcn_wave_barrier();
-    strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
-    cur = nxt;
   }
   // dX rows of the strip (g_0 already there from the packed filter adjoint)
   float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
@@ -585,11 +605,7 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
     __syncthreads();
     stage_store(Zs, pre);
     __syncthreads();
-    Tiles nxt = cur;
-    if (c0 + CC < n) {
-      pre = stage_load(Zg, FIN, c0 + CC);
-      nxt = load_tiles(c0 + CC);
-    }
+    if (c0 + CC < n) pre = stage_load(Zg, FIN, c0 + CC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
@@ -606,9 +622,9 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
         Cs[(4 * q + i) * LD + 16 * t + r] = cij;
       }
     }
+    if (c0 + CC < n) cur = load_tiles(c0 + CC);   // (into the registers just consumed; in flight behind the product)
     __builtin_amdgcn_wave_barrier();
     strip_mma(acc, Cs, Zs, r, q);
-    cur = nxt;
   }
   // dZ_i = rowsum(c)_i Z_i - (c Z)_i -> workspace (for dM_L) and the A image of the product below
   float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * FIN;
@@ -934,9 +950,21 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* st
     int rc0 = launch_cloud(cloud_project_kernel, dim3(strips), 256, 0, PK_PROJECT, "cloud_project", stream, a.X, a.ldx, a.M_L, a.sv_Z);
     if (rc0 != AGCN_OK) return rc0;
   }
-  // column blocks are dealt to 4 waves x gridDim.y workgroups: enough waves to fill the chip, at least one column block each
-  const unsigned ys = (unsigned)std::max(1, std::min(4, max_n / 256));
-  int rc = launch_cloud(cloud_sim_kernel, dim3(xcd_grid((int)strips), ys), 256, 0, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart);
+  // one wave per NB column blocks of the largest graph, up to 16 / NB per workgroup (larger graphs: the waves loop)
+  // (NB = 2 measured 110 us against 104 us: the kernel is bound by vector issue itself -- SQ counters: waves active 67 % of
+  //  their cycles at 3 waves per SIMD, 7.2e7 vector instructions = the 2 per pair and feature -- not by the scalar requests)
+  static const int nb_env = [] { const char* e = std::getenv("AGCN_CLOUD_SIM_NB"); return e ? std::atoi(e) : 1; }();
+  const int ncb = std::max(1, max_n / 64);
+  int rc;
+  if (nb_env == 2 && ncb >= 2) {
+    const int nw = std::max(1, std::min(8, (ncb + 1) / 2));
+    rc = launch_cloud(cloud_sim_kernel<2>, dim3(xcd_grid((int)strips)), 64 * nw, sizeof(float) * 1024 * nw, PK_CLOUD_SIM, "cloud_sim",
+                      stream, a, dpart);
+  } else {
+    const int nw = std::min(16, ncb);
+    rc = launch_cloud(cloud_sim_kernel<1>, dim3(xcd_grid((int)strips)), 64 * nw, sizeof(float) * 512 * nw, PK_CLOUD_SIM, "cloud_sim",
+                      stream, a, dpart);
+  }
   if (rc != AGCN_OK) return rc;
   rc = launch_cloud(cloud_degree_kernel, dim3(strips), 64, 0, PK_CLOUD_DEG, "cloud_degree", stream, a, (const float*)dpart);
   if (rc != AGCN_OK) return rc;
