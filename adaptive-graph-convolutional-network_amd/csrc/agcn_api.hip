@@ -147,6 +147,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   *graphs = *slabs = *dual_graphs = 0;
   const int B = host.info.B;
   // (reference mode: the backward has no n x n work to spread; the forward still has the similarity tile)
+  if (d->variant != AGCN_SGC_LL) return;   // (the Reslap flavour of the specialised kernels: one workgroup per graph)
   if ((d->mode != AGCN_MODE_PAPER && backward) || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
       fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
     return;
@@ -218,7 +219,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
 // reference-mode backward has no members), one 16-wave launch.
 void coop_reach(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host, size_t lim) {
   const AgcnPlanInfo& pi = host.info;
-  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 || d->mode != AGCN_MODE_PAPER) return;
+  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 || d->mode != AGCN_MODE_PAPER || d->variant != AGCN_SGC_LL) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || pi.B >= 1024 || pi.B < 2) return;
   int k = 0;

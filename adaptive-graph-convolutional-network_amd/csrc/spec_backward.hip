@@ -23,25 +23,10 @@ namespace spec {
 
 constexpr int MAXTB = 3;   // most MFMA tiles of one phase a wave may own
 
-// deterministic sum over the NW waves of one body (block_sum of agcn_device.h for a body that may be half a workgroup)
-template <int NW>
-__device__ __forceinline__ float body_sum(float v, float* red, int tid) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) t += red[i];
-    red[31] = t;
-  }
-  __syncthreads();
-  return red[31];
-}
-
-// The body for ONE graph; DUAL as in spec_forward.hip.
-template <int FIN, int FOUT, int NW, bool DUAL>
+// The body for ONE graph; DUAL as in spec_forward.hip.  RESLAP: SGC_LL_Reslap (graphconv_reslap.py:184-198 under autodiff):
+// L is the saved, twice clipped L_sum; between dL = g_1 X_0^T and the pair passes sit the adjoints of the two
+// clip_by_norm + leaky-ReLU stages (two graph-wide inner products), dbeta and dL_prev.
+template <int FIN, int FOUT, int NW, bool DUAL, bool RESLAP>
 __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int gpos, float* smem_) {
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
@@ -98,7 +83,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   // return in order, so a store that waits for its data also waits for every older load), the row pointers first --
   // the only dependent loads, the CSR entries, follow the bulk requests and ride the same round trip.
   int csr_p0 = 0, csr_p1 = 0;
-  if (a.L0_rowptr && tid < n) {
+  if (!RESLAP && a.L0_rowptr && tid < n) {
     csr_p0 = a.L0_rowptr[row0 + tid];
     csr_p1 = a.L0_rowptr[row0 + tid + 1];
   }
@@ -131,6 +116,20 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       rr[u][cp] = 0.f;
       if (paper && u < rpw && 64 * cp < n)     // (uniform bounds, clamped addresses)
         rr[u][cp] = a.sv_r[toff + (uint32_t)(min(i, n - 1) * n + min(j, n - 1))];
+    }
+  }
+  // Reslap: the combined Laplacian is the forward's 4th output (it already holds L_orig and beta L_prev)
+  float lsr[RESLAP ? RPW : 1][2];
+  if constexpr (RESLAP) {
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const int j = lane + 64 * cp;
+        lsr[u][cp] = 0.f;
+        if (u < rpw && 64 * cp < n) lsr[u][cp] = a.L_sum[toff + (uint32_t)(min(i, n - 1) * n + min(j, n - 1))];
+      }
     }
   }
   const float s_own = a.sv_s[row0 + min(tid, n - 1)];
@@ -181,7 +180,19 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
 
   AGCN_STAMP(4, 1);
   // ---- B0b: L = lrelu(R) (+ L_orig) rebuilt from r and s; the tile's 16-padding zeroed ---------------------
-  {
+  if constexpr (RESLAP) {
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+      if (i < n4) {
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const int j = lane + 64 * cp;
+          if (j < n4) tile[i * ldt + j] = (i < n && j < n) ? lsr[u][cp] : 0.f;
+        }
+      }
+    }
+  } else {
     const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
     const float* L0d = !a.L0_dense ? nullptr
                                    : (a.L0_ld > 0 ? a.L0_dense + (int64_t)g.b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
@@ -204,7 +215,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }
   }
   lds_barrier();
-  if (a.L0_rowptr && tid < n) {
+  if (!RESLAP && a.L0_rowptr && tid < n) {
 #pragma unroll
     for (int u = 0; u < 6; ++u)
       if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
@@ -255,7 +266,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   // ---- B1: dX += L^T g_1 --------------------------------------------------------------------------------------
   // (paper) the X_0 rows B2 needs are requested now; their round trip overlaps the matrix work
   float xzr[RPW][CP];
-  if (paper) {
+  if (paper || RESLAP) {
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
       const float* rp = Xg + (int64_t)min(wave + NW * u, n - 1) * a.ldx;
@@ -287,9 +298,9 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       dxacc[sl] = acc;
     }
   }
-  float dalpha_part = 0.f;
+  float dalpha_part = 0.f, dbeta_part = 0.f;
   f32x4 zacc[MAXTB];   // dZ tiles, for the hand-off store
-  if (paper) {
+  if (paper || RESLAP) {
     // X_0 rows -> image over the (dead) Gp image
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
@@ -313,7 +324,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
           xzr[u][cp] = 0.f;
-          if (u < rpw) xzr[u][cp] = Zg[i * FIN + min(lane + 64 * cp, FIN - 1)];
+          if (paper && u < rpw) xzr[u][cp] = Zg[i * FIN + min(lane + 64 * cp, FIN - 1)];
         }
       }
       int ta, tb;
@@ -337,6 +348,101 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     for (int j = lane; j < n4; j += 64) colp[wave * n4 + j] = 0.f;
     lds_barrier();
     AGCN_STAMP(4, 5);
+    if constexpr (RESLAP) {
+      // adjoint of  La = lrelu(cn(Lpre)),  Lpre = R2 + L_orig + beta L_prev   (graphconv_reslap.py:188-198); the tile
+      // holds dLa and becomes dLpre == dR2 (reference mode ends here), then -- paper -- dR through the first clip + leaky-ReLU
+      const float* sc = a.sv_scal + 4 * g.b;
+      const bool has_prev = a.L_prev != nullptr && a.dL_prev != nullptr;
+      if (a.dL_prev && tid < (int)g.npad) a.dL_prev[toff + (uint32_t)(n * n) + tid] = 0.f;   // alignment floats behind the tile
+      {
+        const float ssL = sc[2], scL = sc[3];
+        const float invL = 1.0f / sqrtf(ssL);
+        const bool clipped = invL <= 1.0f;   // TF MinimumGrad: ties take the norm branch
+        // this thread's elements of L_pre and L_prev (rows wave + NW u, columns lane + 64 cp): ONE round of loads, kept in
+        // registers for the second pass -- which then only stores (dL_prev): a load behind a store waits for the store
+        float lpre[RPW][2], lprv[RPW][2];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u)
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            const uint32_t o = toff + (uint32_t)(min(wave + NW * u, n - 1) * n + min(lane + 64 * cp, n - 1));
+            lpre[u][cp] = 0.f;
+            lprv[u][cp] = 0.f;
+            if (u < rpw && 64 * cp < n) {
+              lpre[u][cp] = a.sv_Lpre[o];
+              if (has_prev) lprv[u][cp] = a.L_prev[o];
+            }
+          }
+        float dot_part = 0.f;
+#pragma unroll
+        for (int u = 0; u < RPW; ++u)
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            const int i = wave + NW * u, j = lane + 64 * cp;
+            if (i < n && j < n) {
+              const float Lpre = lpre[u][cp];
+              const float Lc = Lpre * scL;
+              const float dLa = tile[i * ldt + j];
+              dalpha_part += dLa * fminf(Lc, 0.f);
+              const float dLc = dLa * lrelu_grad(Lc, alpha);
+              tile[i * ldt + j] = dLc;
+              dot_part += dLc * Lpre;
+            }
+          }
+        const float dot = body_sum<NW>(dot_part, red, tid);   // (each lane re-reads only its own tile elements below)
+        const float beta = has_prev ? a.beta[0] : 0.f;
+        const float k3 = clipped ? dot * invL * invL * invL : 0.f;
+        // second pass: dLpre == dR2 (-> dbeta, dL_prev) and, in the same sweep (paper), the adjoint of
+        // R2 = lrelu(cn(R)), R = I - s S s (clip_by_norm, q = 1): the tile becomes dR1, then dR
+        const float scR = sc[1];
+        float dotR_part = 0.f;
+#pragma unroll
+        for (int u = 0; u < RPW; ++u)
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            const int i = wave + NW * u, j = lane + 64 * cp;
+            if (i < n && j < n) {
+              float dv = tile[i * ldt + j];
+              if (clipped) dv = dv * invL - lpre[u][cp] * k3;
+              if (has_prev) {
+                dbeta_part += dv * lprv[u][cp];
+                a.dL_prev[toff + (uint32_t)(i * n + j)] = dv * beta;
+              }
+              if (paper) {
+                const float Sv = (i == j) ? 0.f : fast_exp_neg(Rt[i * ldt + j]);
+                const float R = ((i == j) ? 1.f : 0.f) - (s_vec[i] * Sv) * s_vec[j];
+                const float R1 = R * scR;
+                dalpha_part += dv * fminf(R1, 0.f);
+                dv = dv * lrelu_grad(R1, alpha);          // dR1
+                dotR_part += dv * R;
+              }
+              tile[i * ldt + j] = dv;
+            }
+          }
+        if (paper) {
+          const float ssR = sc[0];
+          const float invR = 1.0f / sqrtf(ssR);
+          const bool clippedR = invR <= 1.0f;
+          const float dotR = body_sum<NW>(dotR_part, red, tid);
+          if (clippedR) {
+            const float k3R = dotR * invR * invR * invR;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u)
+#pragma unroll
+              for (int cp = 0; cp < 2; ++cp) {
+                const int i = wave + NW * u, j = lane + 64 * cp;
+                if (i < n && j < n) {
+                  const float Sv = (i == j) ? 0.f : fast_exp_neg(Rt[i * ldt + j]);
+                  const float R = ((i == j) ? 1.f : 0.f) - (s_vec[i] * Sv) * s_vec[j];
+                  tile[i * ldt + j] = tile[i * ldt + j] * invR - R * k3R;
+                }
+              }
+          }
+        }
+      }
+      lds_barrier();
+    }
+    if (paper) {
     // Z rows -> image over g_1 (dead: every wave is past dL); read from the dZ product on, behind later barriers
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
@@ -358,8 +464,8 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         float R = (i == j) ? 1.f : 0.f;
         R = R - (si * Sv) * s_vec[j];                  // R1 == R (clip scale 1)
         const float dL = tile[i * ldt + j];
-        dalpha_part += dL * fminf(R, 0.f);
-        const float P = -(dL * lrelu_grad(R, alpha)) * Sv;   // dA_ij S_ij
+        if (!RESLAP) dalpha_part += dL * fminf(R, 0.f);
+        const float P = -(RESLAP ? dL : dL * lrelu_grad(R, alpha)) * Sv;   // dA_ij S_ij (Reslap: the tile is dR already)
         rsum += P * s_vec[j];
         colp[wave * n4 + j] += P * si;
       }
@@ -385,8 +491,8 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
           const float Sv = fast_exp_neg(rr);
           const float sj = s_vec[j];
           const float Rij = -((si * Sv) * sj), Rji = -((sj * Sv) * si);
-          const float dAij = -(tile[i * ldt + j] * lrelu_grad(Rij, alpha));
-          const float dAji = -(tile[j * ldt + i] * lrelu_grad(Rji, alpha));
+          const float dAij = -(RESLAP ? tile[i * ldt + j] : tile[i * ldt + j] * lrelu_grad(Rij, alpha));
+          const float dAji = -(RESLAP ? tile[j * ldt + i] : tile[j * ldt + i] * lrelu_grad(Rji, alpha));
           float cij = 0.f;
           if (Sv != 0.f && rr > 0.f) {
             const float dr_ij = -Sv * (dAij * si * sj + ddv[j]);
@@ -438,6 +544,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         }
       }
     }
+    }   // paper
   }
   // M_L^T fragments of the last product from the transposed copy: B[k][f] = MT[k][f] row-major
   constexpr int CHM = 20, NCHM = (NKS + CHM - 1) / CHM;
@@ -522,9 +629,10 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }
   }
   const float da = body_sum<NW>(dalpha_part, red, tid);
+  const float db = RESLAP ? body_sum<NW>(dbeta_part, red, tid) : 0.f;
   if (tid == 0) {
     a.ws_pg[2 * g.b + 0] = da;
-    a.ws_pg[2 * g.b + 1] = 0.f;
+    a.ws_pg[2 * g.b + 1] = db;
   }
   if (blockIdx.x == 0) {   // arrival counters of the parameter-gradient kernel that follows this one
     for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
@@ -535,10 +643,12 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
 // FULL: the launch may carry members of cooperative graphs and workgroups of two small graphs (16-wave flavour only; a
 // variant of its own so that launches without them keep the plain kernel's register allocation).
 // 8-wave flavour: held to AGCN_SMALL_OCC waves per SIMD where that does not spill much (feature widths up to 80).
-template <int FIN, int FOUT, int NW, bool FULL>
+template <int FIN, int FOUT, int NW, bool FULL, bool RESLAP = false>
 __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMALL_OCC) : 4) void spec_backward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if constexpr (FULL) {
+  if constexpr (RESLAP) {   // (no members, no paired graphs: one workgroup per graph)
+    spec_backward_body<FIN, FOUT, NW, false, true>(a, first + (int)blockIdx.x, smem);
+  } else if constexpr (FULL) {
     // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
     int blk = (int)blockIdx.x;
     if (blk < a.coop_slabs) {   // (spec_backward_coop.h)
@@ -547,12 +657,12 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     }
     blk -= a.coop_slabs;
     if (blk >= a.plain_count) {
-      spec_backward_body<FIN, FOUT, NW_SMALL, true>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
+      spec_backward_body<FIN, FOUT, NW_SMALL, true, false>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
       return;
     }
-    spec_backward_body<FIN, FOUT, NW_LARGE, false>(a, first + blk, smem);
+    spec_backward_body<FIN, FOUT, NW_LARGE, false, false>(a, first + blk, smem);
   } else {
-    spec_backward_body<FIN, FOUT, NW, false>(a, first + (int)blockIdx.x, smem);
+    spec_backward_body<FIN, FOUT, NW, false, false>(a, first + (int)blockIdx.x, smem);
   }
 }
 
@@ -575,6 +685,20 @@ size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout) {
 
 template <int FIN, int FOUT, int NW>
 static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
+  if (a.variant == AGCN_SGC_LL_RESLAP) {
+    if (a.coop_slabs > 0 || a.dual_pairs > 0) return fail(AGCN_EINVAL, "spec_backward: no cooperative layout for SGC_LL_Reslap");
+    auto kern = &spec::spec_backward_kernel<FIN, FOUT, NW, false, true>;
+    if (lds_bytes > 64 * 1024) {
+      hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes));
+      if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_bwd): %s", hipGetErrorString(e));
+    }
+    prof_begin(PK_SPEC_BWD, s);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(64 * NW), lds_bytes, s, a, first);
+    prof_end(s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_backward launch: %s", hipGetErrorString(e));
+    return AGCN_OK;
+  }
   const bool full = NW == spec::NW_LARGE && (a.coop_slabs > 0 || a.dual_pairs > 0);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = static_cast<hipError_t>(

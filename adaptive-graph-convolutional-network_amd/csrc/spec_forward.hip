@@ -31,7 +31,9 @@ constexpr int MAXT = 3;   // most MFMA tiles of one phase a wave may own (accumu
 // and runs TWO such bodies side by side, threads 0-511 and 512-1023 each on a graph of their own with their own half of
 // the LDS (smem_ + dual_stride); the barriers are workgroup-wide, which is fine because both halves run the same
 // sequence of them (every barrier of the body is in control flow that depends on the launch arguments only).
-template <int FIN, int FOUT, int NW, bool DUAL>
+// RESLAP: SGC_LL_Reslap (graphconv_reslap.py:184-198): clip_by_norm on R and on the combined Laplacian (two graph-wide
+// Frobenius norms), + beta L_prev, the pre-clip Laplacian kept for the backward, L_sum = the 4th output.
+template <int FIN, int FOUT, int NW, bool DUAL, bool RESLAP = false>
 __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gpos, float* smem_) {
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
@@ -101,6 +103,20 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         }
       }
     }
+  }
+  // Reslap: this thread's elements of L_prev (rows wave + NW u, columns lane + 64 cp), requested with the first round of
+  // loads: in F3 they would sit behind the res_W / res_L stores (one in-order counter for loads and stores)
+  constexpr int RPWF = NW == NW_SMALL ? 6 : 8;
+  float lprv[RESLAP ? RPWF : 1][2];
+  if constexpr (RESLAP) {
+#pragma unroll
+    for (int u = 0; u < RPWF; ++u)
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        lprv[u][cp] = 0.f;
+        if (a.L_prev != nullptr && wave + NW * u < n4 && 64 * cp < n)
+          lprv[u][cp] = a.L_prev[toff + (uint32_t)(min(wave + NW * u, n - 1) * n + min(lane + 64 * cp, n - 1))];
+      }
   }
   // (a molecule row has at most 5 entries: the diagonal + 4 bonds; longer rows take the dependent tail loop)
   int csr_c[6] = {0, 0, 0, 0, 0, 0};
@@ -231,7 +247,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
     a.res_L[toff + (uint32_t)(n * n) + tid] = 0.f;
     if (a.L_sum) a.L_sum[toff + (uint32_t)(n * n) + tid] = 0.f;
   }
-  if (tid == 0) {   // clip_by_average_norm never clips for SGC_LL: scale exactly 1 (see slab_kernels.hip)
+  if (!RESLAP && tid == 0) {   // clip_by_average_norm never clips for SGC_LL: scale exactly 1 (see slab_kernels.hip)
     float* sc = a.sv_scal + 4 * g.b;
     sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
   }
@@ -243,37 +259,120 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
     const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
     const float* L0d = !a.L0_dense ? nullptr
                                    : (a.L0_ld > 0 ? a.L0_dense + (int64_t)g.b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
-    for (int j = lane; j < n4; j += 64) {
-      const bool jv = j < n;
-      const float sj = (paper && jv) ? s_vec[j] : 0.f;
-      for (int i = wave; i < n4; i += NW) {
-        float out = 0.f;
-        if (jv && i < n) {
-          const float l0 = L0d ? L0d[(int64_t)i * l0ld + j] : 0.f;
-          const float S = tile[i * ldt + j];
-          float R = (i == j) ? 1.f : 0.f;
-          if (paper) R = R - (s_vec[i] * S) * sj;
-          const float R2 = lrelu(R, alpha);   // (clip_by_average_norm never clips for SGC_LL: scale exactly 1)
-          const uint32_t o = toff + (uint32_t)(i * n + j);
-          AGCN_ST(1, &a.res_W[o], S);
-          AGCN_ST(1, &a.res_L[o], R2);
-          out = R2 + l0;
+    float scR = 1.f, ssR = 1.f;
+    if constexpr (RESLAP) {
+      // clip_by_norm(R, 1) needs ||R||_F of the whole tile first (graphconv_reslap.py:185): res_W out, R -> tile
+      float part = 0.f;
+      for (int j = lane; j < n4; j += 64) {
+        const bool jv = j < n;
+        const float sj = (paper && jv) ? s_vec[j] : 0.f;
+        for (int i = wave; i < n4; i += NW) {
+          float R = 0.f;
+          if (jv && i < n) {
+            const float S = tile[i * ldt + j];
+            R = (i == j) ? 1.f : 0.f;
+            if (paper) R = R - (s_vec[i] * S) * sj;
+            AGCN_ST(1, &a.res_W[toff + (uint32_t)(i * n + j)], S);
+            part += R * R;
+          }
+          tile[i * ldt + j] = R;
         }
-        tile[i * ldt + j] = out;
+      }
+      ssR = body_sum<NW>(part, smem, tid);   // (a lane re-reads only the tile elements it wrote itself)
+      scR = clip_scale(ssR, 1.0f);
+    }
+    if constexpr (RESLAP) {
+      // R2 = lrelu(cn(R)) -> res_L; L_pre = R2 + L_orig + beta L_prev (graphconv_reslap.py:188-190) -> tile, and the sum
+      // of its squares on the way: the dense L_orig is added here, the CSR entries (a handful per row) by the scatter
+      // below, which corrects the sum of squares by 2 v l0 + l0^2 per entry instead of costing another sweep of the tile
+      const bool has_prev = a.L_prev != nullptr;
+      const float beta = has_prev ? a.beta[0] : 0.f;
+      float part = 0.f;
+#pragma unroll
+      for (int u = 0; u < RPWF; ++u)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const int i = wave + NW * u, j = lane + 64 * cp;
+          if (i < n4 && j < n4) {
+            float v = 0.f;
+            if (i < n && j < n) {
+              const float R2 = lrelu(tile[i * ldt + j] * scR, alpha);
+              AGCN_ST(1, &a.res_L[toff + (uint32_t)(i * n + j)], R2);
+              v = R2;
+              if (L0d) v += L0d[(int64_t)i * l0ld + j];
+              if (has_prev) v = v + lprv[u][cp] * beta;
+              part += v * v;
+            }
+            tile[i * ldt + j] = v;
+          }
+        }
+      lds_barrier();
+      if (a.L0_rowptr && tid < n) {
+        auto add = [&](int c, float l0) {
+          const float v = tile[tid * ldt + c];
+          part += (2.f * v + l0) * l0;          // (v + l0)^2 - v^2
+          tile[tid * ldt + c] = v + l0;
+        };
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+          if (csr_p0 + u < csr_p1) add(csr_c[u], csr_v[u]);
+        for (int p = csr_p0 + 6; p < csr_p1; ++p) add(a.L0_col[p], a.L0_val[p]);
+      }
+      const float ssL = body_sum<NW>(part, smem, tid);
+      const float scL = clip_scale(ssL, 1.0f);
+      // second clip + leaky-ReLU (:194-198): L_pre out (reserve), La -> tile and the 4th output
+#pragma unroll
+      for (int u = 0; u < RPWF; ++u)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const int i = wave + NW * u, j = lane + 64 * cp;
+          if (i < n && j < n) {
+            const float v = tile[i * ldt + j];
+            const float La = lrelu(v * scL, alpha);
+            const uint32_t o = toff + (uint32_t)(i * n + j);
+            a.sv_Lpre[o] = v;
+            a.L_sum[o] = La;
+            tile[i * ldt + j] = La;
+          }
+        }
+      if (tid == 0) {   // norms / scales for the backward projections
+        float* sc = a.sv_scal + 4 * g.b;
+        sc[0] = ssR; sc[1] = scR; sc[2] = ssL; sc[3] = scL;
+      }
+      lds_barrier();
+    } else {
+      for (int j = lane; j < n4; j += 64) {
+        const bool jv = j < n;
+        const float sj = (paper && jv) ? s_vec[j] : 0.f;
+        for (int i = wave; i < n4; i += NW) {
+          float out = 0.f;
+          if (jv && i < n) {
+            const float l0 = L0d ? L0d[(int64_t)i * l0ld + j] : 0.f;
+            const float S = tile[i * ldt + j];
+            float R = (i == j) ? 1.f : 0.f;
+            if (paper) R = R - (s_vec[i] * S) * sj;
+            const float R2 = lrelu(R, alpha);   // (clip_by_average_norm never clips for SGC_LL: scale exactly 1)
+            const uint32_t o = toff + (uint32_t)(i * n + j);
+            AGCN_ST(1, &a.res_W[o], S);
+            AGCN_ST(1, &a.res_L[o], R2);
+            out = R2 + l0;
+          }
+          tile[i * ldt + j] = out;
+        }
+      }
+      lds_barrier();
+      if (a.L0_rowptr && tid < n) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+          if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
+        for (int p = csr_p0 + 6; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+      }
+      lds_barrier();
+      if (a.L_sum) {   // SGC_LL with the combined Laplacian requested
+        for (int i = wave; i < n; i += NW)
+          for (int j = lane; j < n; j += 64) a.L_sum[toff + (uint32_t)(i * n + j)] = tile[i * ldt + j];
       }
     }
-  }
-  lds_barrier();
-  if (a.L0_rowptr && tid < n) {
-#pragma unroll
-    for (int u = 0; u < 6; ++u)
-      if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
-    for (int p = csr_p0 + 6; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
-  }
-  lds_barrier();
-  if (a.L_sum) {   // SGC_LL with the combined Laplacian requested
-    for (int i = wave; i < n; i += NW)
-      for (int j = lane; j < n; j += 64) a.L_sum[toff + (uint32_t)(i * n + j)] = tile[i * ldt + j];
   }
 
   AGCN_STAMP(1, 5);
@@ -382,10 +481,12 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
 // FULL: the launch may carry members of cooperative graphs and workgroups of two small graphs (16-wave flavour only; a
 // variant of its own so that launches without them keep the plain kernel's register allocation).
 // 8-wave flavour: held to AGCN_SMALL_OCC waves per SIMD where that does not spill much (feature widths up to 80).
-template <int FIN, int FOUT, int NW, bool FULL>
+template <int FIN, int FOUT, int NW, bool FULL, bool RESLAP = false>
 __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMALL_OCC) : 4) void spec_forward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if constexpr (FULL) {
+  if constexpr (RESLAP) {   // (no members, no paired graphs: one workgroup per graph)
+    spec_forward_body<FIN, FOUT, NW, false, true>(a, first + (int)blockIdx.x, smem);
+  } else if constexpr (FULL) {
     // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
     int blk = (int)blockIdx.x;
     if (blk < a.coop_slabs) {   // (spec_backward_coop.h)
@@ -406,7 +507,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
 }  // namespace spec
 
 bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant) {
-  if (K != 2 || variant != AGCN_SGC_LL) return false;
+  if (K != 2 || (variant != AGCN_SGC_LL && variant != AGCN_SGC_LL_RESLAP)) return false;
   return (Fin == 75 && Fout == 64) || (Fin == 64 && Fout == 128) || (Fin == 128 && Fout == 128) ||
          (Fin == 128 && Fout == 64) || (Fin == 64 && Fout == 64);
 }
@@ -427,6 +528,20 @@ size_t spec_coop_fwd_lds_bytes(int32_t n, int32_t Fin) {
 
 template <int FIN, int FOUT, int NW>
 static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
+  if (a.variant == AGCN_SGC_LL_RESLAP) {
+    if (a.coop_slabs > 0 || a.dual_pairs > 0) return fail(AGCN_EINVAL, "spec_forward: no cooperative layout for SGC_LL_Reslap");
+    auto kern = &spec::spec_forward_kernel<FIN, FOUT, NW, false, true>;
+    if (lds_bytes > 64 * 1024) {
+      hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes));
+      if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_fwd): %s", hipGetErrorString(e));
+    }
+    prof_begin(PK_SPEC_FWD, s);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(64 * NW), lds_bytes, s, a, first);
+    prof_end(s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_forward launch: %s", hipGetErrorString(e));
+    return AGCN_OK;
+  }
   const bool full = NW == spec::NW_LARGE && (a.coop_slabs > 0 || a.dual_pairs > 0);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = static_cast<hipError_t>(

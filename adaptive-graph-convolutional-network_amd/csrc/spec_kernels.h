@@ -149,6 +149,24 @@ struct TriFold19 {
   }
 };
 
+// deterministic sum over the NW waves of one body (block_sum of agcn_device.h for a body that may be half a workgroup);
+// red: 32 floats of the body's LDS; contains barriers: uniform control flow only
+template <int NW>
+__device__ __forceinline__ float body_sum(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    red[31] = t;
+  }
+  __syncthreads();
+  return red[31];
+}
+
 // contiguous, balanced share of T tiles for wave w of NW
 template <int NW>
 __device__ __forceinline__ void tile_range(int T, int w, int& t0, int& t1) {

@@ -1315,6 +1315,38 @@ def test_epoch_lanes_give_the_single_lane_results(amd):
         assert torch.equal(a, x) and torch.equal(b, y) and torch.equal(c, z)
 
 
+@pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
+@pytest.mark.parametrize("Fin,Fout", [(64, 64), (128, 64)])
+def test_reslap_takes_the_specialised_kernels(amd, mode, Fin, Fout):
+    """SGC_LL_Reslap at the ResLap networks' widths (ResAGCN.py:79-92, Point_AGCN.py:37-71: 64 -> 64, 128 -> 64, ...): a
+    256-graph Tox21-shaped batch with a previous Laplacian and an upstream gradient of L_sum must run on the specialised
+    kernels' Reslap flavour (kernel names asserted) and match the float64 oracle on every graph and every gradient
+    (dbeta, dL_prev included)."""
+    K, B = 2, 256
+    sb = orc.synth_batch(321, B)
+    ns = [int(v) for v in sb["ns"]]
+    rs = np.random.RandomState(17)
+    X = [np.maximum(rs.randn(n, Fin), 0).astype(np.float32) for n in ns]
+    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL_RESLAP)
+    p["alpha"] = np.array([0.8], np.float32)
+    p["beta"] = np.array([1.2], np.float32)
+    G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
+    Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
+    dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), sb["csr"], DEV)
+    layer = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, B, K, mode, p, DEV)
+    from helpers import pack_tiles_np
+    st = amd.SgcLLStep(layer, gb, L_prev=torch.from_numpy(pack_tiles_np(Lp, gb.plan)).to(DEV),
+                       dY=torch.from_numpy(np.concatenate(G, 0)).to(DEV),
+                       dL_sum=torch.from_numpy(pack_tiles_np(dLs, gb.plan)).to(DEV))
+    names = st.kernel_names()
+    assert "spec_forward_kernel" in names[0] and "spec_backward_kernel" in names[1], names
+    caches, tot = oracle_run(X, sb["L0"], p, K, mode, orc.SGC_LL_RESLAP, G, Lp, dLs)
+    _, tot32 = oracle_run(X, sb["L0"], p, K, mode, orc.SGC_LL_RESLAP, G, Lp, dLs, dtype=np.float32)
+    out = run_packed(amd, DEV, ns, X, sb["csr"], p, G, Fin, Fout, K, mode, orc.SGC_LL_RESLAP, Lp, dLs)
+    compare_with_oracle(out, caches, tot, orc.SGC_LL_RESLAP, mode, K, has_prev=True, tot32=tot32)
+
+
 def test_cooperative_waits_are_never_silent(amd):
     """The workgroups that share a large graph wait for each other inside a launch (csrc/spec_backward_coop.h); the wait
     is bounded and, when it runs out, reported: NaN in the step's results AND a sticky status word that

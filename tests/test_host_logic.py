@@ -252,7 +252,11 @@ def test_dispatch_table(amd):
     assert _dispatch(amd, n, 75, 64, 0)["path"] == 16          # (reference mode: no members in the backward)
     assert _dispatch(amd, n, 128, 128, 1)["path"] == 16        # (the members' LDS plan does not fit at this width)
     assert _dispatch(amd, n256, 80, 64, 1)["path"] == 4
-    assert _dispatch(amd, n256, 64, 64, 1, variant=1)["path"] == 4
+    # SGC_LL_Reslap at the specialised widths: the specialised kernels' Reslap flavour, one workgroup per graph (no members,
+    # no pairs); other widths: the general fused kernels
+    d = _dispatch(amd, n256, 64, 64, 1, variant=1)
+    assert d["path"] == 7 and d["f_members"] == d["b_members"] == d["f_paired"] == d["b_paired"] == 0
+    assert _dispatch(amd, n256, 80, 64, 1, variant=1)["path"] == 4
     assert _dispatch(amd, n256, 75, 64, 1, K=3)["path"] == 32
     del rs
 
