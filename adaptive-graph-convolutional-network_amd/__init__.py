@@ -12,7 +12,7 @@ from .layers import (SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, 
 from .graphs import (SequentialGraphMol, ResidualGraphMol, ResidualGraphMolResLap, DenseConnectedGraph,  # noqa: F401
                      DenseConnectedGraphResLap)
 from .store import GraphStore, ResidentStore  # noqa: F401
-from .engine import GraphedStep, SgcLLEpochLanes, SgcLLEpochStep, SgcLLStep  # noqa: F401
+from .engine import GraphedStep, SgcLLEpochLanes, SgcLLEpochPipeline, SgcLLEpochStep, SgcLLStep  # noqa: F401
 from .functional import check_device_status  # noqa: F401
 from . import dist  # noqa: F401
 

@@ -4,6 +4,7 @@
 // whole dataset lives on the device, and a batch is one small table upload + one gather launch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include "agcn_internal.h"
@@ -19,9 +20,12 @@ struct GatherRec {      // one per graph of the batch, behind the plan in the st
 };
 
 struct GatherArgs {
-  const int32_t* n;         // plan arrays (device)
-  const int32_t* row_off;
+  const int32_t* n;         // plan arrays and gather table: in the DEVICE blob, or -- zero-copy staging -- in the pinned
+  const int32_t* row_off;   // host blob, read over the host link by the gather workgroups themselves
   const GatherRec* rec;
+  const uint2* blob_src;    // zero-copy staging: the pinned host blob (device-visible address) ...
+  uint2* blob_dst;          // ... copied into the device blob by this launch (a slice per workgroup); else null
+  int32_t blob_vec;         // 8-byte words of the blob (plan 16-byte aligned + 24-byte records: a multiple of 8 bytes)
   const void* X;            // float or bf16 (x_bf16) rows of the store
   const int64_t* rowptr;
   const int32_t* col;
@@ -41,6 +45,10 @@ __global__ __launch_bounds__(256) void store_gather_kernel(GatherArgs a) {
   const int n = a.n[b], r0 = a.row_off[b];
   const GatherRec rc = a.rec[b];
   const int F = a.F;
+  if (a.blob_dst) {   // this workgroup's slice of the plan blob: host -> device (the layer kernels read the device copy)
+    const int per = (a.blob_vec + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int i = b * per + tid; i < min((b + 1) * per, a.blob_vec); i += 256) a.blob_dst[i] = a.blob_src[i];
+  }
   // (features kept in bf16 at rest are widened here: the layer computes in fp32, include/agcn.h agcn_cast_rows)
   const float* xs = static_cast<const float*>(a.X) + rc.src_row * F;
   const uint16_t* xh = static_cast<const uint16_t*>(a.X) + rc.src_row * F;
@@ -132,10 +140,29 @@ extern "C" int agcn_store_stage_batch(const AgcnResidentStore* st, const int64_t
   if (rc != AGCN_OK) return rc;
   info->rows = rows; info->nnz = nnz; info->max_n = mx; info->symmetric = sym; info->stage_bytes = (int64_t)total;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
-  hipError_t e = hipMemcpyAsync(stage_dev, stage_host, total, hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: blob upload: %s", who, hipGetErrorString(e));
+  // Zero-copy staging: when the pinned blob is visible to the device (hipHostMalloc'ed / registered memory: torch's pinned
+  // tensors are), the gather launch reads plan + table over the host link itself and copies the blob into the device
+  // buffer on the way -- ONE launch per batch instead of a copy-engine transfer (whose hand-over to the compute queue cost
+  // ~25 us of stream time per batch) plus a launch.  Otherwise: the asynchronous copy as before.
+  static const int zc_env = [] { const char* v = std::getenv("AGCN_STAGE_ZEROCOPY"); return v ? std::atoi(v) : 1; }();
+  const char* hd = nullptr;
+  if (zc_env) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, stage_host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr)
+      hd = static_cast<const char*>(at.devicePointer);
+    else
+      (void)hipGetLastError();   // (plain pageable memory: not an error, the copy path takes it)
+  }
+  hipError_t e = hipSuccess;
+  if (!hd) {
+    e = hipMemcpyAsync(stage_dev, stage_host, total, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: blob upload: %s", who, hipGetErrorString(e));
+  }
   agcn::GatherArgs a;
-  const char* d = static_cast<const char*>(stage_dev);
+  const char* d = hd ? hd : static_cast<const char*>(stage_dev);
+  a.blob_src = reinterpret_cast<const uint2*>(hd);
+  a.blob_dst = hd ? static_cast<uint2*>(stage_dev) : nullptr;
+  a.blob_vec = (int32_t)(total / 8);
   a.n = reinterpret_cast<const int32_t*>(d + info->plan.off_n);
   a.row_off = reinterpret_cast<const int32_t*>(d + info->plan.off_row_off);
   a.rec = reinterpret_cast<const agcn::GatherRec*>(d + tab_off);

@@ -370,6 +370,61 @@ class SgcLLEpochLanes(object):
                 st.check()
 
 
+class SgcLLEpochPipeline(object):
+    """ONE lane of `SgcLLEpochStep` (batches strictly one after the other on the compute stream: plain SGD order) fed by a
+    `ResidentStore` whose staging runs ONE BATCH AHEAD on a side stream: while batch k computes, the plan / gather table of
+    batch k + 1 is copied and its rows are gathered into the other of two buffer sets.  A batch's data does not depend on
+    the parameters, so this is prefetching, not batch overlap: results are those of the plain loop, bit for bit.
+
+        rs = store.to_device(dev, 256, lanes=2)          # two buffer sets
+        pipe = SgcLLEpochPipeline(layer, rs)
+        for step in pipe.run(selections):                # step = the SgcLLEpochStep holding that batch's results
+            ...                                          # (valid until the next iteration; enqueue an optimiser step here)
+        pipe.synchronize()
+    """
+
+    def __init__(self, layer, rstore):
+        if len(rstore.lanes) < 2:
+            raise ValueError("the pipeline needs a resident store with lanes >= 2 (two buffer sets)")
+        self.rstore, self.device = rstore, rstore.device
+        self.step_obj = SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device)
+        self.side = _overlapping_streams(self.device, 2)[1]
+        self._staged = [torch.cuda.Event(), torch.cuda.Event()]     # staging of buffer set b has executed
+        self._freed = [None, None]                                  # last compute that read buffer set b has executed
+        torch.cuda.synchronize(self.device)
+
+    def _stage(self, sel, b, main):
+        if self._freed[b] is not None:
+            self.side.wait_event(self._freed[b])                    # the step that last used these buffers is done
+        gb = self.rstore.stage(sel, lane=b, stream=self.side)
+        self._staged[b].record(self.side)
+        return gb
+
+    def run(self, selections, dY=None):
+        main = torch.cuda.current_stream(self.device)
+        sels = list(selections)
+        if not sels:
+            return
+        nxt = self._stage(sels[0], 0, main)
+        for k in range(len(sels)):
+            b = k & 1
+            gb = nxt
+            if k + 1 < len(sels):
+                nxt = self._stage(sels[k + 1], b ^ 1, main)          # one batch ahead, on the side stream
+            main.wait_event(self._staged[b])
+            st = self.step_obj.step(gb, dY, stream=main)
+            if self._freed[b] is None:
+                self._freed[b] = torch.cuda.Event()
+            self._freed[b].record(main)
+            yield st
+
+    def synchronize(self, check=True):
+        torch.cuda.current_stream(self.device).synchronize()
+        self.side.synchronize()
+        if check:
+            self.step_obj.check()
+
+
 class GraphedStep(object):
     """A whole training step of layers of this package -- autograd forward + backward over a fixed batch --
     captured into ONE HIP graph (torch.cuda.CUDAGraph on ROCm).

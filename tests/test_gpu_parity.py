@@ -1315,6 +1315,39 @@ def test_epoch_lanes_give_the_single_lane_results(amd):
         assert torch.equal(a, x) and torch.equal(b, y) and torch.equal(c, z)
 
 
+def test_epoch_pipeline_gives_the_plain_loop_results(amd):
+    """`SgcLLEpochPipeline`: one lane, staging one batch ahead on a side stream (two buffer sets) -- prefetching, not batch
+    overlap: every batch bit-identical to the plain stage -> step loop; and zero-copy staging (the gather launch reads the
+    pinned plan blob itself) bit-identical to the copy-engine path (AGCN_STAGE_ZEROCOPY is read once per process, so the
+    comparison is against the host-packed batch instead)."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(55, 1100, mu=np.log(23.0), hi=222)
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    p = synth.glorot_params(np.random.RandomState(3), 75, 64, 2)
+    layer = make_layer(amd, orc.SGC_LL, 64, 75, 256, 2, orc.PAPER, p, DEV)
+    sels = store._selections(256, False, np.random.RandomState(2))
+    r1 = store.to_device(DEV, 256)
+    ep = amd.SgcLLEpochStep(layer, r1.rows_cap, r1.tiles_cap, 256, device=DEV)
+    want = []
+    for sel in sels:
+        gb = r1.stage(sel)
+        hb = store.batch(sel, DEV)                       # the same batch packed on the host and uploaded
+        assert torch.equal(gb.X, hb.X) and torch.equal(gb.l0_rowptr, hb.l0_rowptr) and torch.equal(gb.l0_val, hb.l0_val)
+        ep.step(gb)
+        torch.cuda.synchronize()
+        want.append((ep.Y.clone(), ep.dX.clone(), ep.bucket.clone()))
+    r2 = store.to_device(DEV, 256, lanes=2)
+    pipe = amd.SgcLLEpochPipeline(layer, r2)
+    got = []
+    for st in pipe.run(sels):
+        torch.cuda.current_stream().synchronize()
+        got.append((st.Y.clone(), st.dX.clone(), st.bucket.clone()))
+    pipe.synchronize()
+    assert len(got) == len(want)
+    for (a, b, c), (x, y, z) in zip(got, want):
+        assert torch.equal(a, x) and torch.equal(b, y) and torch.equal(c, z)
+
+
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
 @pytest.mark.parametrize("Fin,Fout", [(64, 64), (128, 64)])
 def test_reslap_takes_the_specialised_kernels(amd, mode, Fin, Fout):
