@@ -10,7 +10,7 @@ from .graph_structure import Graph, MolGraph, laplacian_csr  # noqa: F401
 from .layers import (SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, DenseBlockEnd, GraphPoolMol,  # noqa: F401
                      MultitaskHead, Layer)
 from .graphs import (SequentialGraphMol, ResidualGraphMol, ResidualGraphMolResLap, DenseConnectedGraph,  # noqa: F401
-                     DenseConnectedGraphResLap)
+                     DenseConnectedGraphResLap, SegmentationGraph)
 from .store import GraphStore, ResidentStore  # noqa: F401
 from .engine import GraphedStep, SgcLLEpochLanes, SgcLLEpochPipeline, SgcLLEpochStep, SgcLLStep  # noqa: F401
 from .functional import check_device_status  # noqa: F401

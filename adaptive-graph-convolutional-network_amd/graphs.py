@@ -233,3 +233,89 @@ class DenseConnectedGraphResLap(DenseConnectedGraph):
 
     def get_laplacian(self):
         return self.stack_laplacians
+
+
+class SegmentationGraph(SequentialGraphMol):
+    """models/tf_modules/seg_graph.py:9-125: a shared BACKBONE followed by two heads that both start from the backbone's
+    output -- a CLASSIFIER head (`add(layer, classifer=True)`, sic) and a SEGMENTATION head (`add(layer, segmentation=True)`).
+    The only caller of `GraphPoolMol` in the reference (Seg_AGCN.py:79-81).  Per-type dispatch as there: in the backbone
+    `SGC_LL` gets the full topology dict and returns three values, `MLP` gets `node_features` + `data_slice`, everything
+    else the full dict; in the classifier head `FCL` gets `node_features` only; in the segmentation head `Merge` is called
+    on the raw tensor list (seg_graph.py:67-68).  `FCL` / `MLP` / `Merge` are dispatched by class name like every layer
+    (any callable of that name), this package does not ship them (they belong to the trainers).
+
+    Calling the container on a batch returns (classification_outputs, segmentation_outputs)."""
+
+    allowed = ("MLP", "GraphGatherMol", "GraphPoolMol", "SGC_LL", "DenseMol", "FCL", "Merge")
+
+    def __init__(self, n_feat, batch_size=50, num_point=128):
+        super(SegmentationGraph, self).__init__(n_feat, batch_size, num_point)
+        self.num_point = num_point
+        self.backbone_layers, self.classifier_layer, self.segmentation_layer = [], [], []
+        self.classifier_output = None
+        self.segmentation_output = None
+
+    def add(self, layer, classifer=False, segmentation=False):
+        """seg_graph.py:34-109 (the keyword is spelt `classifer` there)."""
+        assert type(layer).__name__ in self.allowed
+        if classifer:
+            assert len(self.backbone_layers) > 0
+            self.classifier_layer.append(layer)
+        elif segmentation:
+            assert len(self.backbone_layers) > 0
+            self.segmentation_layer.append(layer)
+        else:
+            self.backbone_layers.append(layer)
+        self.layers = self.backbone_layers + self.classifier_layer + self.segmentation_layer
+
+    def _full(self, topo, feats):
+        x = {"node_features": feats, "data_slice": topo["data_slice"], "original_laplacian": topo["original_laplacian"],
+             "lap_slice": topo["lap_slice"]}
+        if topo.get("graph_batch") is not None:
+            x["graph_batch"] = topo["graph_batch"]
+        return x
+
+    def __call__(self, batch):
+        self._reset()
+        topo, self.output = self._topology(batch)
+        for layer in self.backbone_layers:                               # seg_graph.py:79-106
+            name = type(layer).__name__
+            if name == "SGC_LL":
+                self.output, res_L, res_W = layer(self._full(topo, self.output))
+                self.res_L_set.extend(res_L)
+                self.res_W_set.extend(res_W)
+                self._adopt_batch(topo, self.output)
+            elif name == "MLP":
+                x = {"node_features": self.output, "data_slice": topo["data_slice"]}
+                if topo.get("graph_batch") is not None:
+                    x["graph_batch"] = topo["graph_batch"]
+                self.output = layer(x)
+            else:
+                self.output = layer(self._full(topo, self.output))
+        self.classifier_output = self.segmentation_output = self.output
+        for layer in self.classifier_layer:                              # seg_graph.py:40-55
+            if type(layer).__name__ == "FCL":
+                self.classifier_output = layer({"node_features": self.classifier_output})
+            else:
+                self.classifier_output = layer(self._full(topo, self.classifier_output))
+        for layer in self.segmentation_layer:                            # seg_graph.py:57-77
+            name = type(layer).__name__
+            if name == "SGC_LL":
+                self.segmentation_output, res_L, res_W = layer(self._full(topo, self.segmentation_output))
+            elif name == "Merge":
+                self.segmentation_output = layer(self.segmentation_output)
+            else:
+                self.segmentation_output = layer(self._full(topo, self.segmentation_output))
+        return self.classifier_output, self.segmentation_output
+
+    def get_graph_topology(self):
+        raise NotImplementedError("define-by-run containers hold no placeholders: pass the batch to the call")
+
+    def backbone_outputs(self):
+        return self.output
+
+    def classification_outputs(self):
+        return self.classifier_output
+
+    def segmentation_outputs(self):
+        return self.segmentation_output

@@ -174,3 +174,62 @@ def test_reslap_container_reference_feed_golden(amd):
         assert y.shape == (max_atom, Fout) and np.all(y[n:] == 0)
         assert_close(y, g["l2_Y"][b], FEATURE_RTOL, "chain Y[%d]" % b)
         assert_close(to_np(model.get_laplacian()[b]), g["l1_L_sum"][b, :n, :n], FEATURE_RTOL, "saved L[%d]" % b)
+
+
+def test_segmentation_graph_backbone_and_two_heads(amd):
+    """SegmentationGraph (seg_graph.py:9-125) with Seg_AGCN's layer list shape (Seg_AGCN.py:75-121: SGC_LL, SGC_LL,
+    GraphPoolMol backbone; DenseMol -> GraphGatherMol -> FCL classifier head; SGC_LL, SGC_LL -> Merge segmentation head):
+    both heads start from the backbone output, FCL sees `node_features` only, Merge the raw output, and the results equal
+    the same layers called by hand."""
+    rs, X, L0, gb = _batch(amd, Fin=75)
+    B = gb.plan.B
+
+    class FCL(object):                       # dispatched by class name; the trainers' layer itself is out of scope
+        def __init__(self):
+            self.keys = None
+
+        def __call__(self, x):
+            self.keys = sorted(x.keys())
+            return x["node_features"] * 2.0
+
+    class Merge(object):
+        def __call__(self, x):
+            assert not isinstance(x, dict)
+            return ("merged", x)
+
+    m = amd.SegmentationGraph(75, batch_size=B, num_point=24)
+    with pytest.raises(AssertionError):
+        m.add(amd.DenseMol(8, 8, device=DEV), classifer=True)          # no backbone yet
+    with pytest.raises(AssertionError):
+        m.add(object())                                                 # not a segmentation-graph layer
+    bb = [amd.SGC_LL(16, 75, B, K=2, laplacian_mode="paper", device=DEV, generator=_gen(1)),
+          amd.SGC_LL(24, 16, B, K=2, laplacian_mode="paper", device=DEV, generator=_gen(2)),
+          amd.GraphPoolMol(B)]
+    for lay in bb:
+        m.add(lay)
+    cl = [amd.DenseMol(12, 24, activation="relu", device=DEV, generator=_gen(3)), amd.GraphGatherMol(B, activation="tanh"), FCL()]
+    for lay in cl:
+        m.add(lay, classifer=True)
+    sg = [amd.SGC_LL(16, 24, B, K=2, laplacian_mode="paper", device=DEV, generator=_gen(4)),
+          amd.SGC_LL(6, 16, B, K=2, laplacian_mode="paper", device=DEV, generator=_gen(5)), Merge()]
+    for lay in sg:
+        m.add(lay, segmentation=True)
+    cls_out, seg_out = m(gb)
+    assert len(m.get_resL_set()) == 2 * B            # the backbone's SGC layers (the head's are not collected: seg_graph.py:66)
+    # by hand
+    h = gb.X
+    for lay in bb[:2]:
+        h, _, _ = lay({"node_features": h, "graph_batch": gb})
+    h = bb[2]({"node_features": h, "graph_batch": gb})
+    assert torch.equal(to_np_t(m.backbone_outputs()), to_np_t(h))
+    c = cl[0]({"node_features": h, "graph_batch": gb})
+    c = cl[1]({"node_features": c, "graph_batch": gb})
+    assert torch.equal(cls_out, c * 2.0) and cl[2].keys == ["node_features"]
+    s1, _, _ = sg[0]({"node_features": h, "graph_batch": gb})
+    s2, _, _ = sg[1]({"node_features": s1, "graph_batch": gb})
+    assert seg_out[0] == "merged" and torch.equal(to_np_t(seg_out[1]), to_np_t(s2))
+    assert m.classification_outputs() is cls_out and m.segmentation_outputs() is seg_out
+
+
+def to_np_t(v):
+    return v.data if hasattr(v, "data") and not torch.is_tensor(v) else v
