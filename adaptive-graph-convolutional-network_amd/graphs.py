@@ -123,6 +123,23 @@ class SequentialGraphMol(object):
                 ps += list(layer.parameters())
         return ps
 
+    def train(self, mode=True):
+        """The learning phase of every layer (the reference's global in_train_phase, model_operatos.py:46-61): dropout is
+        active in training only.  `eval()` before predicting."""
+        for layer in self.layers:
+            if hasattr(layer, "train"):
+                layer.train(mode)
+            else:
+                layer.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    @property
+    def uses_learning_phase(self):
+        return any(getattr(layer, "uses_learning_phase", False) for layer in self.layers)
+
 
 class ResidualGraphMol(SequentialGraphMol):
     """tf_graphs.py:107-156: ResNet-style blocks; `BlockEnd` adds the saved output of the previous block."""

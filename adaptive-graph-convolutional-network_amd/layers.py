@@ -69,6 +69,15 @@ class Layer(object):
     def __call__(self, x):
         return self.call(x)
 
+    # the reference's learning phase is a global switch (model_operatos.py:46-61, in_train_phase); here it is a flag on
+    # every layer, flipped per layer or -- containers -- for a whole network
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
 
 def glorot(shape, generator=None, device=None):
     """graphconv.py:19-23: U(-r, r), r = sqrt(6 / (fan_in + fan_out))."""
@@ -136,6 +145,8 @@ class SGC_LL(Layer):
             raise ValueError("laplacian_mode must be 'reference' or 'paper'")
         self.dropout = dropout
         self.training = True        # the learning phase of the reference (model_operatos.in_train_phase): dropout only
+        # (model_operatos.py:46-61, dropout.py:34-41: a layer with 0 < p < 1 depends on the learning phase)
+        self.uses_learning_phase = bool(dropout) and 0.0 < float(dropout) < 1.0
         self.activation = activation
         self.batch_size = batch_size
         self.nb_filter = output_dim

@@ -233,3 +233,23 @@ def test_segmentation_graph_backbone_and_two_heads(amd):
 
 def to_np_t(v):
     return v.data if hasattr(v, "data") and not torch.is_tensor(v) else v
+
+
+def test_learning_phase_switches_dropout_for_the_whole_container(amd):
+    """dropout=p layers depend on the learning phase (dropout.py:34-41, model_operatos.py:46-61): `model.eval()` makes the
+    predictions deterministic, `model.train()` brings the dropout back; `uses_learning_phase` says so."""
+    rs, X, L0, gb = _batch(amd)
+    B = gb.plan.B
+    m = amd.SequentialGraphMol(75, B, 24)
+    m.add(amd.SGC_LL(16, 75, B, K=2, dropout=0.5, laplacian_mode="paper", device=DEV, generator=_gen(1)))
+    m.add(amd.SGC_LL(8, 16, B, K=2, laplacian_mode="paper", device=DEV, generator=_gen(2)))
+    assert m.uses_learning_phase and m.layers[0].uses_learning_phase and not m.layers[1].uses_learning_phase
+    m.eval()
+    a, b = m(gb).data.clone(), m(gb).data.clone()
+    assert torch.equal(a, b)
+    m.train()
+    torch.manual_seed(0)
+    c = m(gb).data.clone()
+    torch.manual_seed(1)
+    d = m(gb).data.clone()
+    assert not torch.equal(c, d) and not torch.equal(a, c)
