@@ -893,7 +893,9 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
                 (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
     RowsGemmArgs g;
     if (cloud_bwd) {
-      rc = launch_cloud_backward(a, w.WT, hip_stream);
+      // the same predicate as the forward's: the cloud forward left W^T in the reserve (else it is built here, in workspace)
+      const bool fwd_cloud = (reinterpret_cast<uintptr_t>(fwd->Y) & 15) == 0;
+      rc = launch_cloud_backward(a, fwd_cloud ? nullptr : w.WT, hip_stream);
       if (rc != AGCN_OK) return rc;
     } else {
     // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace

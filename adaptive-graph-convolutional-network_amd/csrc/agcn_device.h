@@ -47,6 +47,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;  // lane 0 holds the total
 }
 
+// Sum over the B per-graph (or per-slab) scalar partials pg[2 b + which] by ONE wave, in a fixed order: 16 loads in flight per
+// round (a plain strided loop waits out one memory round trip per 64 entries: ~16 us at 2048 slabs).
+__device__ __forceinline__ float pg_wave_sum(const float* pg, int B, int which, int lane) {
+  float t = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 64 * 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int b = b0 + 64 * u + lane;
+      v[u] = b < B ? pg[2 * b + which] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += v[u];
+  }
+  return wave_sum(t);
+}
+
 // Deterministic block-wide sum, result broadcast to every thread.
 // red: >= 32 floats of LDS.  Contains barriers: call from uniform control flow.
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -285,6 +285,11 @@ __global__ __launch_bounds__(64) void cloud_degree_kernel(SgcArgs a, const float
     float* sc = a.sv_scal + 4 * b;
     sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
   }
+  // W^T for the backward's filter adjoint (WT[k][c][f] = W[f * K + k][c]) -> reserve, a slice per workgroup
+  for (int e = (int)blockIdx.x * 64 + (int)threadIdx.x; e < 2 * a.Fout * FIN; e += (int)gridDim.x * 64) {
+    const int f = e % FIN, kc = e / FIN, c = kc % a.Fout, k = kc / a.Fout;
+    a.sv_WT[e] = a.weight[(int64_t)(f * 2 + k) * a.Fout + c];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,89 +735,89 @@ __global__ __launch_bounds__(256) void cloud_filter_bwd_kernel(const float* __re
     *reinterpret_cast<f32x4*>(As + row * lda + 4 * c4) = g;
   }
   __builtin_amdgcn_wave_barrier();
+  // both products at once (the A fragment serves g_0 and g_1), the W^T fragments one 8-MFMA step ahead of their use
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[k][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* B0 = WT + 4 * r + (int64_t)(4 * q) * FIN;
+  const float* B1 = B0 + (int64_t)Fout * FIN;
+  f32x4 b0 = *reinterpret_cast<const f32x4*>(B0), b1 = *reinterpret_cast<const f32x4*>(B1);
+  const int nsteps = Fout >> 2;            // (cb, j) steps of 4 contraction indices per lane group
 #pragma unroll 1
-  for (int k = 0; k < 2; ++k) {
-    f32x4 acc[4];
+  for (int cb = 0; cb < Fout; cb += 16) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(As + r * lda + cb + 4 * q);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* Bk = WT + (int64_t)k * Fout * FIN + 4 * r;
-#pragma unroll 2
-    for (int cb = 0; cb < Fout; cb += 16) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(As + r * lda + cb + 4 * q);
+    for (int j = 0; j < 4; ++j) {
+      const int nxt = min((cb >> 2) + j + 1, nsteps - 1);            // next step: row 16 (nxt / 4) + 4 q + nxt % 4 of W^T
+      const int64_t o = (int64_t)(16 * (nxt >> 2) + (nxt & 3)) * FIN;
+      const f32x4 n0 = *reinterpret_cast<const f32x4*>(B0 + o), n1 = *reinterpret_cast<const f32x4*>(B1 + o);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(Bk + (int64_t)(cb + 4 * q + j) * FIN);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = mfma4(av[j], bv[e], acc[e]);
+      for (int e = 0; e < 4; ++e) {
+        acc[0][e] = mfma4(av[j], b0[e], acc[0][e]);
+        acc[1][e] = mfma4(av[j], b1[e], acc[1][e]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      b0 = n0; b1 = n1;
     }
-    float* out = k == 0 ? dX : g1;
-    const int ldo = k == 0 ? ldx : FIN;
+  }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(out + (row0 + 4 * q + i) * ldo + 4 * r) = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(dX + (row0 + 4 * q + i) * ldx + 4 * r) = (f32x4){acc[0][0][i], acc[0][1][i], acc[0][2][i], acc[0][3][i]};
+    *reinterpret_cast<f32x4*>(g1 + (row0 + 4 * q + i) * FIN + 4 * r) = (f32x4){acc[1][0][i], acc[1][1][i], acc[1][2][i], acc[1][3][i]};
   }
 }
 
 // Row-chunk partials of the parameter gradients (param_grads.hip's layout: [chunk][dweight | dbias | dM_L]):
 //   dweight[f*K + k][c] = sum_rows X_k[row][f] Gp[row][c], dbias[c] = sum_rows Gp[row][c], dM_L[f][g] = sum_rows X[row][f] dZ[row][g]
-// -- A^T B with the row index as the MFMA k dimension.  A workgroup owns a chunk of rows and the WHOLE output; the chunk is
-// walked in pieces of 32 rows whose X_0 / X_1 / Gp / dZ rows are staged in LDS with coalesced 16-byte loads (the next
-// piece's loads in flight in registers behind the current piece's 160 MFMAs per wave: with operands fetched straight into
-// the MFMA registers, one wave per SIMD and 20 MFMAs per round trip, the first version of this kernel took 46 us).
-// A tile (k, e) <-> f = 4r + e, B tile (h, e') <-> c = 64 h + 4r + e': both operands are 16-byte LDS reads of "row 4u + q".
-// Workgroup (chunk, k) takes the A tiles of X_k, wave w of it the tile e = w against every B tile (k = 0: also the dM_L tiles of
-// e = w and the bias): two workgroups per chunk and CU overlap one's staging with the other's products.
+// -- A^T B with the row index as the MFMA k dimension.  Chunks of 256 rows (AGCN_CLOUD_PG_ROWS), and the OUTPUT split over
+// workgroups: workgroup (chunk, k, z) takes the A tiles of X_k against the 64-column slice z of Gp (k = 0: also that slice of the
+// bias) -- or, the extra slice z = Fout / 64 in paper mode, X against dZ (dM_L); wave w of it the A tile e = w (f = 4r + e).
+// A chunk is walked in pieces of 64 rows staged in LDS with coalesced 16-byte loads, the next piece's loads in flight in
+// registers behind the current piece's MFMAs; both operands are 16-byte LDS reads of "row 4u + q" (B tile e' <-> c = 64 z + 4r + e').
+// History (32768 rows, 64 -> 128; partial + reduce): operands straight into the MFMA registers, 256 chunks: 46 + 25 us;
+// LDS-staged 32-row pieces, one workgroup per (chunk, k): 25 + 19; this layout: 25 + 8 -- 11 us of the reduce had been ONE
+// wave's serial loop over the 2048 slabs' dalpha partials (pg_wave_sum now), not the partials; 512-row chunks: 33 + 7.
 template <int FOUT>
 __global__ __launch_bounds__(256) void cloud_param_partial_kernel(ParamGradArgs a) {
-  constexpr int NH = FOUT / 64, PR = 32;   // rows per piece
-  __shared__ __attribute__((aligned(16))) float Xs[PR * FIN], dZs[PR * FIN], Gps[PR * FOUT];
+  constexpr int PR = 64;   // rows per piece
+  __shared__ __attribute__((aligned(16))) float Xs[PR * FIN], Gps[PR * 64];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = blockIdx.x;
+  constexpr int NH = FOUT / 64;
+  const int chunk = blockIdx.x, kx = blockIdx.y, h = blockIdx.z;
   const int r_begin = chunk * a.chunk_rows, r_end = min(a.rows, r_begin + a.chunk_rows);
-  const int kx = blockIdx.y;
-  const bool paper = a.paper != 0 && kx == 0;    // (dM_L rides with the X_0 workgroup)
-  f32x4 accW[NH][4], accM[4];
+  const bool with_m = h == NH;          // the extra z slice: X^T dZ instead of X_k^T Gp (only against X_0)
+  if (with_m && kx != 0) return;
+  const bool with_b = kx == 0 && !with_m;
+  f32x4 accW[4];
 #pragma unroll
-  for (int h = 0; h < NH; ++h)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) accW[h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) accM[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 bsum[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) bsum[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  struct Piece { f32x4 xa[2], dz[2], gp[2 * NH]; };
+  for (int e = 0; e < 4; ++e) accW[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+  struct Piece { f32x4 xa[4], gp[4]; };
   const float* Asrc = kx == 0 ? a.X : a.sv_X;
   const int lda = kx == 0 ? a.ldx : FIN;
-  auto load_piece = [&](int p0) {        // rows p0 .. p0 + 31 (clamped to the batch: chunks are multiples of 32 rows)
+  auto load_piece = [&](int p0) {        // rows p0 .. p0 + 63 (clamped to the batch; rows are multiples of 64)
     Piece g;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 4; ++m) {
       const int id = tid + 256 * m;
       const int64_t row = min(p0 + (id >> 4), a.rows - 1);
       g.xa[m] = *reinterpret_cast<const f32x4*>(Asrc + row * lda + 4 * (id & 15));
-      g.dz[m] = paper ? *reinterpret_cast<const f32x4*>(a.dZ + row * FIN + 4 * (id & 15)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int m = 0; m < 2 * NH; ++m) {
-      const int id = tid + 256 * m;
-      const int64_t row = min(p0 + id / (FOUT / 4), a.rows - 1);
-      g.gp[m] = *reinterpret_cast<const f32x4*>(a.Gp + row * FOUT + 4 * (id % (FOUT / 4)));
+      g.gp[m] = with_m ? *reinterpret_cast<const f32x4*>(a.dZ + row * FIN + 4 * (id & 15))
+                       : *reinterpret_cast<const f32x4*>(a.Gp + row * FOUT + 64 * h + 4 * (id & 15));
     }
     return g;
   };
   auto store_piece = [&](const Piece& g) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 4; ++m) {
       const int id = tid + 256 * m;
       *reinterpret_cast<f32x4*>(Xs + 4 * id) = g.xa[m];
-      if (paper) *reinterpret_cast<f32x4*>(dZs + 4 * id) = g.dz[m];
+      *reinterpret_cast<f32x4*>(Gps + 4 * id) = g.gp[m];
     }
-#pragma unroll
-    for (int m = 0; m < 2 * NH; ++m) *reinterpret_cast<f32x4*>(Gps + 4 * (tid + 256 * m)) = g.gp[m];
   };
   Piece pre = load_piece(r_begin);
 #pragma unroll 1
@@ -822,71 +827,56 @@ __global__ __launch_bounds__(256) void cloud_param_partial_kernel(ParamGradArgs 
     __syncthreads();
     if (p0 + PR < r_end) pre = load_piece(p0 + PR);
     const int nk = min(PR, r_end - p0) >> 2;       // k-steps of 4 rows in this piece
+#pragma unroll 4
     for (int u = 0; u < nk; ++u) {
       const int row = 4 * u + q;
       const f32x4 xa = *reinterpret_cast<const f32x4*>(Xs + row * FIN + 4 * r);
       const float xw = wave == 0 ? xa.x : wave == 1 ? xa.y : wave == 2 ? xa.z : xa.w;
-      f32x4 gp[NH];
+      const f32x4 gp = *reinterpret_cast<const f32x4*>(Gps + row * 64 + 4 * r);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) gp[h] = *reinterpret_cast<const f32x4*>(Gps + row * FOUT + 64 * h + 4 * r);
-#pragma unroll
-      for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) accW[h][e] = mfma4(xw, gp[h][e], accW[h][e]);
-      if (wave == 0 && kx == 0) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) bsum[h] += gp[h];
-      }
-      if (paper) {
-        const f32x4 dz = *reinterpret_cast<const f32x4*>(dZs + row * FIN + 4 * r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) accM[e] = mfma4(xw, dz[e], accM[e]);
-      }
+      for (int e = 0; e < 4; ++e) accW[e] = mfma4(xw, gp[e], accW[e]);
+      if (with_b && wave == 0) bsum += gp;
     }
   }
   float* out = a.part + (int64_t)chunk * a.part_stride;
-  // accumulator element i of tile (A tile e, B tile (h, e')): f = 4 (4q + i) + e, c = 64 h + 4r + e'
+  // accumulator element i of tile (A tile w, B tile e'): f = 4 (4q + i) + w, c = 64 h + 4r + e'
+  if (!with_m) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int f = 16 * q + 4 * i + wave;
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-      *reinterpret_cast<f32x4*>(out + (int64_t)(f * 2 + kx) * FOUT + 64 * h + 4 * r) =
-          (f32x4){accW[h][0][i], accW[h][1][i], accW[h][2][i], accW[h][3][i]};
-  }
-  if (wave == 0 && kx == 0) {
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      f32x4 t = bsum[h];
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {
-        t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
-      }
-      if (q == 0) *reinterpret_cast<f32x4*>(out + (int64_t)2 * FIN * FOUT + 64 * h + 4 * r) = t;
+    for (int i = 0; i < 4; ++i) {
+      const int f = 16 * q + 4 * i + wave;
+      *reinterpret_cast<f32x4*>(out + (int64_t)(f * 2 + kx) * FOUT + 64 * h + 4 * r) = (f32x4){accW[0][i], accW[1][i], accW[2][i], accW[3][i]};
     }
   }
-  if (paper) {
+  if (with_b && wave == 0) {
+    f32x4 t = bsum;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+    }
+    if (q == 0) *reinterpret_cast<f32x4*>(out + (int64_t)2 * FIN * FOUT + 64 * h + 4 * r) = t;
+  }
+  if (with_m) {
     float* outM = out + (int64_t)2 * FIN * FOUT + FOUT;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = 16 * q + 4 * i + wave;
-      *reinterpret_cast<f32x4*>(outM + (int64_t)f * FIN + 4 * r) = (f32x4){accM[0][i], accM[1][i], accM[2][i], accM[3][i]};
+      *reinterpret_cast<f32x4*>(outM + (int64_t)f * FIN + 4 * r) = (f32x4){accW[0][i], accW[1][i], accW[2][i], accW[3][i]};
     }
   }
 }
 
-// Fixed-order sum of the chunk partials: element e of [dweight | dbias | dM_L] = sum over four quarters of the chunk range
-// (one quarter per wave, 32 loads in flight, added in chunk order), the quarters added in order; and the scalars
-// (dalpha, dbeta: the per-slab partials in index order).  64 elements per workgroup.
-__global__ __launch_bounds__(256) void cloud_param_reduce_kernel(ParamGradArgs a) {
-  __shared__ float red[4][64];
+// Fixed-order sum of the chunk partials: element e of [dweight | dbias | dM_L] = sum over EIGHT ranges of the chunks (one range
+// per wave, all of its loads in flight at once -- up to 32 -- and added in chunk order), the ranges added in order; and the
+// scalars (dalpha, dbeta: the per-slab partials in index order).  64 elements per 512-thread workgroup.
+__global__ __launch_bounds__(512) void cloud_param_reduce_kernel(ParamGradArgs a) {
+  __shared__ float red[8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nW = (int64_t)a.K * a.Fin * a.Fout, nB = a.Fout, nM = a.paper ? (int64_t)a.Fin * a.Fin : 0;
   const int64_t total = nW + nB + nM;
   const int64_t e = (int64_t)blockIdx.x * 64 + lane;
-  const int per = (a.n_chunks + 3) >> 2, c_begin = wave * per, c_end = min(a.n_chunks, c_begin + per);
+  const int per = (a.n_chunks + 7) >> 3, c_begin = wave * per, c_end = min(a.n_chunks, c_begin + per);
   float s = 0.f;
-  if (e < total) {
+  if (e < total && c_begin < c_end) {
     const float* p = a.part + e;
     for (int c = c_begin; c < c_end; c += 32) {
       float v[32];
@@ -899,17 +889,17 @@ __global__ __launch_bounds__(256) void cloud_param_reduce_kernel(ParamGradArgs a
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && e < total) {
-    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    float t = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) t += red[w][lane];
     if (e < nW) a.dweight[e] = t;
     else if (e < nW + nB) a.dbias[e - nW] = t;
     else a.dM_L[e - nW - nB] = t;
   }
-  if (blockIdx.x == 0 && wave >= 2) {   // scalars: one wave each, fixed order
+  if (blockIdx.x == 0 && (wave == 2 || wave == 3)) {   // scalars: one wave each, fixed order
     float* dst = wave == 2 ? a.dalpha : a.dbeta;
     if (dst != nullptr && a.pg != nullptr) {
-      float t = 0.f;
-      for (int b = lane; b < a.B; b += 64) t += a.pg[2 * b + (wave - 2)];
-      t = wave_sum(t);
+      const float t = pg_wave_sum(a.pg, a.B, wave - 2, lane);
       if (lane == 0) dst[0] = t;
     }
   }
@@ -976,25 +966,36 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* st
 // The row-chunk partials of the parameter gradients (the caller runs param_grads.hip's reduce kernel behind it).
 bool cloud_param_grads_ok(const ParamGradArgs& a) { return cloud_env() && a.Fin == FIN && a.K == 2 && (a.Fout == 64 || a.Fout == 128) &&
                                                            (a.rows & 63) == 0 && (a.ldx & 3) == 0 && (a.chunk_rows & 3) == 0; }
-int launch_cloud_param_partials(const ParamGradArgs& a, void* stream) {
-  int rc = a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks, 2), 256, 0, PK_PARAM_PARTIAL,
+int launch_cloud_param_partials(const ParamGradArgs& a0, void* stream) {
+  // few, long chunks (<= the caller's chunk count: its partial buffer is sized for that many)
+  ParamGradArgs a = a0;
+  static const int chunk_target = [] { const char* e = std::getenv("AGCN_CLOUD_PG_ROWS"); return e ? std::max(64, std::atoi(e)) : 256; }();
+  a.n_chunks = std::max(1, std::min(a0.n_chunks, (a0.rows + chunk_target - 1) / chunk_target));
+  a.chunk_rows = ((a0.rows + a.n_chunks - 1) / a.n_chunks + 63) / 64 * 64;
+  const unsigned zm = a.paper ? 1u : 0u;   // the X^T dZ slice
+  int rc = a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks, 2, 2 + zm), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a)
-                       : launch_cloud(cloud_param_partial_kernel<64>, dim3((unsigned)a.n_chunks, 2), 256, 0, PK_PARAM_PARTIAL,
+                       : launch_cloud(cloud_param_partial_kernel<64>, dim3((unsigned)a.n_chunks, 2, 1 + zm), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a);
   if (rc != AGCN_OK) return rc;
   const int64_t total = (int64_t)a.K * a.Fin * a.Fout + a.Fout + (a.paper ? (int64_t)a.Fin * a.Fin : 0);
-  return launch_cloud(cloud_param_reduce_kernel, dim3((unsigned)((total + 63) / 64)), 256, 0, PK_PARAM_REDUCE, "cloud_param_reduce",
+  return launch_cloud(cloud_param_reduce_kernel, dim3((unsigned)((total + 63) / 64)), 512, 0, PK_PARAM_REDUCE, "cloud_param_reduce",
                       stream, a);
 }
 
-// Gp, g_0 -> dX, g_1 (the packed filter adjoint), then the strip kernels.  `WT`: K * Fout * 64 floats of workspace.
+// Gp, g_0 -> dX, g_1 (the packed filter adjoint), then the strip kernels.  `WT`: K * Fout * 64 floats of workspace for W^T, or
+// nullptr when the forward of this call pair was the cloud forward (which left W^T in the reserve: a.sv_WT).
 int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const unsigned strips = (unsigned)(a.n_slabs / 4);
   if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "cloud kernels: a gradient of L_sum is not supported");
   {
-    int rc0 = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep",
-                           stream, a.weight, WT, a.Fout, 2);
+    int rc0 = AGCN_OK;
+    if (WT != nullptr)
+      rc0 = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep",
+                         stream, a.weight, WT, a.Fout, 2);
+    else
+      WT = a.sv_WT;
     if (rc0 != AGCN_OK) return rc0;
     rc0 = launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD,
                        "cloud_filter_bwd", stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0,

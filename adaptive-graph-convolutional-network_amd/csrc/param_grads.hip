@@ -109,9 +109,7 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(ParamGradArgs a)
     if (wave < 2) {
       float* dst = wave == 0 ? a.dalpha : a.dbeta;
       if (dst != nullptr && a.pg != nullptr) {
-        float s = 0.f;
-        for (int b = lane; b < a.B; b += 64) s += a.pg[2 * b + wave];
-        s = wave_sum(s);
+        const float s = pg_wave_sum(a.pg, a.B, wave, lane);
         if (lane == 0) dst[0] = s;
       }
     }
@@ -289,9 +287,7 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   if (blockIdx.x == 0 && wave < 2) {
     float* dst = wave == 0 ? a.dalpha : a.dbeta;
     if (dst != nullptr && a.pg != nullptr) {
-      float v = 0.f;
-      for (int b = lane; b < a.B; b += 64) v += a.pg[2 * b + wave];
-      v = wave_sum(v);
+      const float v = pg_wave_sum(a.pg, a.B, wave, lane);
       if (lane == 0) dst[0] = v;
     }
   }
