@@ -79,9 +79,16 @@ __host__ inline unsigned xcd_grid(int n_strips) { return (unsigned)(8 * ((n_stri
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // sum over the 16 lanes that share q (= the 16 columns of a tile row), result in each of them
+// (DPP: lane ^ 1, lane ^ 2 inside the quad, then the half row mirrored, then the row mirrored -- no LDS round trips)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_mov<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
   return v;
 }
 __device__ __forceinline__ float wave_sum_all(float v) {
@@ -149,136 +156,182 @@ __device__ __forceinline__ const float* dense_l0(const SgcArgs& a, const WaveCtx
 
 // ------------------------------------------------------------------------------------------------
 // forward 1: S = exp(-||Z_i - Z_j||) (graphconv.py:163-180) -> res_W, r -> reserve (paper mode), partial degrees.
-// Workgroup = one 64-row block of a graph; a wave = NB 64 x 64 blocks at a time (one column of each per lane, the
-// columns' Z rows in 64 NB registers) against the block's rows, which come through the scalar cache into SGPRs
-// (uniform address: s_load_dwordx16), half a row at a time into one of two buffers: the half after the one being consumed
-// is requested right behind the wait for the current one -- scalar loads return out of order, so the only usable wait is
-// lgkmcnt(0) -- and has the 64 NB vector instructions of a half row to arrive.  Measured (32 clouds of 1024 points):
-//   the compiler's own schedule (8 instructions between request and wait)              175 us
-//   explicit double buffering, NB = 1 (64 instructions of cover, 5 waves per SIMD)      100 us
-//   two accumulation chains; 16 waves of a row block in one workgroup (shared rows)      100 us (neither binds)
-//   NB = 2 (128 instructions of cover, half the scalar requests per pair)               110 us
-// against 58 us of pure issue time (2 instructions per pair and feature); LDS-staged register blocks (slab_sim): 198 us.
-// 16-byte stores: a lane holds ONE column, so four rows of S (and r) are turned through a wave-private LDS patch [4][64]
-// and leave as one dwordx4 per lane (row lane / 16, columns 4 (lane % 16) ..); dword-per-lane stores are bound by store
-// issue.  Computing only the blocks on or above the diagonal and writing each also mirrored (a lane's four rows of its
-// column = 16 bytes of the mirrored row) was measured and rejected: 264 us -- 64 scattered 16-byte pieces per store
-// instruction are partial-line writes all the way to memory, and the kernels behind it slowed down as well.
-template <int NB>
-__global__ __launch_bounds__(64 * (NB == 1 ? 16 : 8)) void cloud_sim_kernel(SgcArgs a, float* dpart) {
-  extern __shared__ __attribute__((aligned(16))) float trbuf[];   // [waves][NB][2][4 * 64]
-  const int nw = (int)(blockDim.x >> 6);
+// S and r are symmetric: each unordered pair is computed ONCE.  A task = RT rows (i) of row block I against the 64 columns (j)
+// of a column block J >= I, run by ONE wave: a lane keeps its column's Z row in 64 registers, the rows come through the scalar
+// cache into SGPRs (uniform address: s_load_dwordx16), half a row at a time into one of two buffers -- the half after the one
+// being consumed is requested right behind the wait for the current one (scalar loads return out of order, so the only usable
+// wait is lgkmcnt(0)) and has the 64 vector instructions of a half row to arrive -- two vector instructions per pair and
+// feature, four accumulation chains.  The tasks of a graph are numbered in the order (I, piece h of RT rows, J): the four waves
+// of a workgroup take four consecutive ids, i.e. mostly the same rows (one scalar-cache fill serves them).
+// Stores are 16 bytes per lane in both orientations: four rows of the block are turned through a wave-private LDS patch [4][64]
+// (row lane / 16, columns 4 (lane % 16) ..); the MIRRORED block (off-diagonal tasks) leaves through patches [64 columns j][16
+// rows i] (the lane's value of row i at [lane][i], 16-byte groups swizzled by (lane / 2) % 4: 4-way conflicts on the scalar
+// writes, none on the 16-byte reads) as 64-byte row segments, 16 rows x 64 bytes per store instruction.
+// Degrees: a task gives the column sums of its RT rows to partial slot (I, h) and -- the row sums = the column sums of the
+// mirrored block -- to partial slot (J, 0); cloud_degree_kernel adds a node's slots in fixed order.
+// Measured (32 clouds of 1024 points, paper mode; tools/ubench/sim_rate.hip has the loop in isolation: 2.3 cycles per
+// instruction with four chains at 4 waves per SIMD; the kernel runs at ~1.97 GHz, SQ_BUSY_CYCLES / duration):
+//   full square, the compiler's schedule of the scalar loads (8 instructions of cover)              175 us
+//   full square, explicit double buffering, 16 waves of a row block per workgroup                  100-104 us
+//   each pair once, a lane's four rows as one 16-byte piece of the mirrored row (64 scattered pieces per instruction)  264 us
+//   each pair once, mirrored block through the [64][16] patches, 64-row tasks, workgroup = (strip, 4 column blocks)   88-90 us
+//   32-row tasks from task lists (below)                                                            75 us: 47 us of vector issue
+//     at the kernel's clock and the ubench's rate, 55-57 measured without stores / patches / sqrt + exp, +10 stores, +2, +3
+template <bool PAPER, int RT>
+__global__ __launch_bounds__(256, 4) void cloud_sim_kernel(SgcArgs a, float* dpart, int t_quota, int nquads, int qstride) {
+  constexpr int WSZ = PAPER ? 2560 : 1280;      // floats of LDS per wave: [4][64] S (, r) + [64][16] S^T (, r^T)
+  constexpr int NS = CS / RT;                   // partial-degree slots per row block
+  extern __shared__ __attribute__((aligned(16))) float trbuf[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int strip = xcd_strip(a.n_slabs >> 2);
-  if (strip < 0) return;
-  const int slab0 = 4 * strip;
-  const int b = a.slab_graph[slab0], r0 = a.slab_row[slab0];
-  const int n = a.n[b], row0 = a.row_off[b];
-  const int64_t toff = a.tile_off[b];
-  const bool paper = a.mode == AGCN_MODE_PAPER;
-  const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
-  float* dp = dpart + (toff >> 6) + (int64_t)(r0 >> 6) * n;   // partial degrees of this row block: [n / 64][n] per graph
-  const int ncb = n >> 6;
-  float* tr = trbuf + wave * (NB * 512);
-  for (int jb = NB * wave; jb < ncb; jb += NB * nw) {
-    float zj[NB][FIN];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      const int j = 64 * min(jb + c, ncb - 1) + lane;          // (a column block beyond the graph: recomputed, not stored)
-      const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)j * FIN);
-#pragma unroll
-      for (int f4 = 0; f4 < FIN / 4; ++f4) {
-        const f32x4 t = zp[f4];
-        zj[c][4 * f4 + 0] = t.x; zj[c][4 * f4 + 1] = t.y; zj[c][4 * f4 + 2] = t.z; zj[c][4 * f4 + 3] = t.w;
-      }
-    }
-    float cs[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) cs[c] = 0.f;
-    const float* zrow = Zg + (int64_t)r0 * FIN;
-    f32x16 A0, A1, B0, B1;
-    SLOAD16(A0, zrow, "0x0");
-    SLOAD16(A1, zrow, "0x40");
+  float* nS = trbuf + wave * WSZ;                // [4][64]
+  float* nR = nS + 256;
+  float* tS = nS + (PAPER ? 512 : 256);          // [64][16]
+  float* tR = tS + 1024;
+  const int fz = 4 * ((lane >> 1) & 3);
+  // PERSISTENT waves (4 workgroups per CU), static task lists: the ids (graph, block pair t, piece h), a quota of t_quota block
+  // pairs per graph (smaller graphs leave ids empty), are cut into eight contiguous ranges, one per XCD (workgroups go round
+  // robin over the XCDs: a cloud's Z rows and tiles stay in one L2), and the waves of an XCD take a range's ids in turn.
+  // (Task queues with an atomic cursor per XCD: 470-580 us -- thousands of same-address atomics, one round trip each.)
+  const int64_t total = (int64_t)a.B * t_quota * NS;
+  const int per_q = (int)((total + 7) >> 3);
+  const int xcd = (int)(blockIdx.x & 7);
+  const int wx = 4 * (int)(gridDim.x >> 3);      // waves per XCD
 #pragma unroll 1
-    for (int i4 = 0; i4 < CS; i4 += 4) {
+  for (int lid0 = 4 * (int)(blockIdx.x >> 3) + wave; lid0 < 4 * nquads; lid0 += wx) {
+  // (quads of ids -- the four waves of a workgroup: same rows -- in a strided order: workgroups that run side by side work on
+  //  different row blocks.  In id order they all write the same 256-byte column segment of rows 4 KB apart -- the mirrored
+  //  blocks (J, I) of one I -- i.e. into the same memory channels: 492 us.)
+  const int lid = 4 * (int)(((int64_t)(lid0 >> 2) * qstride) % nquads) + (lid0 & 3);
+  const int64_t id = (int64_t)xcd * per_q + lid;
+  if (lid >= per_q || id >= total) continue;
+  // (wave-uniform by construction; readfirstlane tells the compiler, which then keeps the pointers below in SGPRs -- the
+  //  s_load operands must be: with the row pointer in VGPRs the kernel assembled, gave the right results and took 492 us)
+  const int b = __builtin_amdgcn_readfirstlane((int)(id / (t_quota * NS)));
+  const int rem = __builtin_amdgcn_readfirstlane((int)(id - (int64_t)b * (t_quota * NS)));
+  const int n = __builtin_amdgcn_readfirstlane(a.n[b]), row0 = __builtin_amdgcn_readfirstlane(a.row_off[b]);
+  const int ncb = n >> 6;
+  if (rem >= ((ncb * (ncb + 1)) >> 1) * NS) continue;
+  // ids of a graph in the order (I, h, J >= I): neighbouring waves share their rows (the scalar cache serves them once)
+  int I = 0, J, h;
+  {
+    int left = rem, len = ncb;                   // (<= 25 steps of scalar arithmetic)
+    while (left >= len * NS) { left -= len * NS; --len; ++I; }
+    h = left / len;
+    J = I + (left - h * len);
+  }
+  const int rb0 = 64 * I;
+  const bool diag = J == I;
+  const int r0 = rb0 + RT * h;                   // first row of the task
+  const int64_t toff_v = a.tile_off[b];
+  const int64_t toff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(toff_v >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)toff_v));
+  const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
+  float zj[FIN];
+  {
+    const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)(64 * J + lane) * FIN);
+#pragma unroll
+    for (int f4 = 0; f4 < FIN / 4; ++f4) {
+      const f32x4 t = zp[f4];
+      zj[4 * f4 + 0] = t.x; zj[4 * f4 + 1] = t.y; zj[4 * f4 + 2] = t.z; zj[4 * f4 + 3] = t.w;
+    }
+  }
+  const int dlane = diag ? lane - RT * h : -1;   // S_ii = 0 (graphconv.py:171-173): on the diagonal block only
+  float cs = 0.f;
+  float* dpI = dpart + (toff >> 6) * NS + (int64_t)(I * NS + h) * n;    // partial degrees [n / RT][n] per graph
+  float* dpJ = dpart + (toff >> 6) * NS + (int64_t)(J * NS) * n;
+  const float* zrow = Zg + (int64_t)r0 * FIN;
+  f32x16 A0, A1, B0, B1;
+  SLOAD16(A0, zrow, "0x0");
+  SLOAD16(A1, zrow, "0x40");
+#pragma unroll 1
+  for (int g16 = 0; g16 < RT; g16 += 16) {
+#pragma unroll 1
+    for (int i4 = 0; i4 < 16; i4 += 4) {
 #pragma unroll 1
       for (int u = 0; u < 4; ++u) {
-        const int ii = i4 + u;
-        float acc[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) acc[c] = 0.f;
-        SWAIT2(A0, A1, cs[0]);
+        const int ii = g16 + i4 + u;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        SWAIT2(A0, A1, cs);
         SLOAD16_BEFORE(B0, zrow, "0x80", A0);
         SLOAD16_BEFORE(B1, zrow, "0xc0", A1);
-#pragma unroll
-        for (int f = 0; f < 16; ++f)
-#pragma unroll
-          for (int c = 0; c < NB; ++c) { const float d = A0[f] - zj[c][f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
-#pragma unroll
-        for (int f = 0; f < 16; ++f)
-#pragma unroll
-          for (int c = 0; c < NB; ++c) { const float d = A1[f] - zj[c][16 + f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
-        SWAIT2(B0, B1, acc[NB - 1]);
-        zrow += (ii + 1 < CS) ? FIN : 0;      // (the last request re-reads the last row: never used)
+#define AGCN_SIM16(SRC, BASE)                                                                                       \
+  _Pragma("unroll") for (int f = 0; f < 16; f += 4) {                                                             \
+    const float d0 = SRC[f] - zj[BASE + f], d1 = SRC[f + 1] - zj[BASE + f + 1];                                     \
+    const float d2 = SRC[f + 2] - zj[BASE + f + 2], d3 = SRC[f + 3] - zj[BASE + f + 3];                             \
+    c0 = __builtin_fmaf(d0, d0, c0); c1 = __builtin_fmaf(d1, d1, c1);                                               \
+    c2 = __builtin_fmaf(d2, d2, c2); c3 = __builtin_fmaf(d3, d3, c3);                                               \
+  }
+        AGCN_SIM16(A0, 0)
+        AGCN_SIM16(A1, 16)
+        SWAIT2(B0, B1, c3);
+        zrow += (ii + 1 < RT) ? FIN : 0;      // (the last request re-reads the last row: never used)
         SLOAD16_BEFORE(A0, zrow, "0x0", B0);
         SLOAD16_BEFORE(A1, zrow, "0x40", B1);
-#pragma unroll
-        for (int f = 0; f < 16; ++f)
-#pragma unroll
-          for (int c = 0; c < NB; ++c) { const float d = B0[f] - zj[c][32 + f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
-#pragma unroll
-        for (int f = 0; f < 16; ++f)
-#pragma unroll
-          for (int c = 0; c < NB; ++c) { const float d = B1[f] - zj[c][48 + f]; acc[c] = __builtin_fmaf(d, d, acc[c]); }
-        // ((z_i - z_j)^2 == (z_j - z_i)^2 and the same f order for both orientations of a pair: S bit-symmetric)
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-          const float rr = __builtin_amdgcn_sqrtf(acc[c]);
-          // S_ii = 0 (graphconv.py:171-173); exp(-1 * norm) otherwise (:176-177)
-          const float S = (r0 + ii == 64 * (jb + c) + lane) ? 0.f : __builtin_amdgcn_exp2f(rr * NLOG2E);
-          tr[c * 512 + u * 64 + lane] = S;
-          if (paper) tr[c * 512 + 256 + u * 64 + lane] = rr;
-          cs[c] += S;
-        }
+        AGCN_SIM16(B0, 32)
+        AGCN_SIM16(B1, 48)
+#undef AGCN_SIM16
+        // (each pair is computed once: S and r are symmetric to the bit)
+        const float rr = __builtin_amdgcn_sqrtf((c0 + c1) + (c2 + c3));
+        const float S = (ii == dlane) ? 0.f : __builtin_amdgcn_exp2f(rr * NLOG2E);   // exp(-1 * norm) (:176-177)
+        const int tcol = 16 * lane + ((i4 + u) ^ fz);
+        nS[u * 64 + lane] = S;
+        tS[tcol] = S;
+        if (PAPER) { nR[u * 64 + lane] = rr; tR[tcol] = rr; }
+        cs += S;
       }
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        if (jb + c < ncb) {
-          const int64_t o = toff + (int64_t)(r0 + i4 + (lane >> 4)) * n + 64 * (jb + c) + 4 * (lane & 15);
-          *reinterpret_cast<f32x4*>(a.res_W + o) = *reinterpret_cast<const f32x4*>(tr + c * 512 + 4 * lane);
-          if (paper)
-            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(tr + c * 512 + 256 + 4 * lane),
-                                        reinterpret_cast<f32x4*>(a.sv_r + o));
+      {
+        const int64_t o = toff + (int64_t)(r0 + g16 + i4 + (lane >> 4)) * n + 64 * J + 4 * (lane & 15);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(nS + 4 * lane);
+        *reinterpret_cast<f32x4*>(a.res_W + o) = sv;
+        if (PAPER) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(nR + 4 * lane), reinterpret_cast<f32x4*>(a.sv_r + o));
+        if (!diag) {   // row sums of this block = column sums of the mirrored one
+          const float rs = row16_sum((sv.x + sv.y) + (sv.z + sv.w));
+          if ((lane & 15) == 0) dpJ[r0 + g16 + i4 + (lane >> 4)] = rs;
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
-    SWAIT2(A0, A1, cs[0]);                   // (nothing of these column blocks' requests is left in flight)
+    if (!diag) {
 #pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (jb + c < ncb) dp[64 * (jb + c) + lane] = cs[c];
+      for (int m = 0; m < 4; ++m) {
+        const int j = (lane >> 2) + 16 * m;
+        const int src = 16 * j + 4 * ((lane & 3) ^ ((j >> 1) & 3));
+        const int64_t o = toff + (int64_t)(64 * J + j) * n + r0 + g16 + 4 * (lane & 3);
+        *reinterpret_cast<f32x4*>(a.res_W + o) = *reinterpret_cast<const f32x4*>(tS + src);
+        if (PAPER) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(tR + src), reinterpret_cast<f32x4*>(a.sv_r + o));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  SWAIT2(A0, A1, cs);                          // (nothing of the row requests is left in flight)
+  dpI[64 * J + lane] = cs;
   }
 }
 
-// forward 2: d_j = sum of the n / 64 partial column sums in row-block order + np.spacing(0) (graphconv.py:195-196),
-// s = d^-1/2 (:197).  One 64-thread workgroup per 64-row block.
-__global__ __launch_bounds__(64) void cloud_degree_kernel(SgcArgs a, const float* dpart) {
+// forward 2: d_j = sum of the node's partial column sums in slot order + np.spacing(0) (graphconv.py:195-196), s = d^-1/2 (:197).
+// Slot (rb, h) of column j: h-th RT-row piece of row block rb for rb <= j / 64 (computed blocks), for rb > j / 64 the mirrored
+// block's sum in slot (rb, 0) alone.  One 64-thread workgroup per 64-row block.
+__global__ __launch_bounds__(64) void cloud_degree_kernel(SgcArgs a, const float* dpart, int ns) {
   const int slab0 = 4 * (int)blockIdx.x;
   const int b = a.slab_graph[slab0], r0 = a.slab_row[slab0];
   const int n = a.n[b], row0 = a.row_off[b];
   const int64_t toff = a.tile_off[b];
   const int j = r0 + (int)threadIdx.x;
-  const float* dp = dpart + (toff >> 6) + j;
+  const float* dp = dpart + (toff >> 6) * ns + j;
   float d = 0.f;
-  const int nrb = n >> 6;
-  for (int rb = 0; rb < nrb; rb += 8) {   // eight loads in flight, added in row-block order
+  const int nslot = (n >> 6) * ns, own = ((r0 >> 6) + 1) * ns;   // slots below `own`: all ns pieces; above: piece 0 only
+  for (int s0 = 0; s0 < nslot; s0 += 8) {   // eight loads in flight, added in slot order
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = dp[(int64_t)min(rb + u, nrb - 1) * n];
+    for (int u = 0; u < 8; ++u) {
+      const int sl = s0 + u;
+      const bool live = sl < nslot && (sl < own || sl % ns == 0);
+      v[u] = live ? dp[(int64_t)sl * n] : 0.f;
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) d += (rb + u < nrb) ? v[u] : 0.f;
+    for (int u = 0; u < 8; ++u) d += v[u];
   }
   a.sv_s[row0 + j] = 1.0f / sqrtf(d + FLT_TRUE_MIN);
   if (r0 == 0 && threadIdx.x == 0) {   // clip_by_average_norm(R, 1) never clips for SGC_LL: scale exactly 1
@@ -931,7 +984,9 @@ bool cloud_path(const SgcArgs& a, bool quad) {
          (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 15) == 0 && al16(a.X) && al16(a.weight) && al16(a.bias) &&
          al16(a.M_L) && (a.n_slabs & 3) == 0;
 }
-size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / 64 + 64); }
+constexpr int SIM_RT = 32;   // rows per task of cloud_sim_kernel: 64 / SIM_RT partial-degree slots per row block (16: 72 + 9.5 us
+                             // similarity + degree kernel, 32: 75 + 7.7, 64: 84 + 6.5)
+size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / SIM_RT + 64); }
 
 int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
@@ -940,23 +995,34 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* st
     int rc0 = launch_cloud(cloud_project_kernel, dim3(strips), 256, 0, PK_PROJECT, "cloud_project", stream, a.X, a.ldx, a.M_L, a.sv_Z);
     if (rc0 != AGCN_OK) return rc0;
   }
-  // one wave per NB column blocks of the largest graph, up to 16 / NB per workgroup (larger graphs: the waves loop)
-  // (NB = 2 measured 110 us against 104 us: the kernel is bound by vector issue itself -- SQ counters: waves active 67 % of
-  //  their cycles at 3 waves per SIMD, 7.2e7 vector instructions = the 2 per pair and feature -- not by the scalar requests)
-  static const int nb_env = [] { const char* e = std::getenv("AGCN_CLOUD_SIM_NB"); return e ? std::atoi(e) : 1; }();
-  const int ncb = std::max(1, max_n / 64);
+  const int ncb = std::max(1, (int)max_n / CS);   // column blocks of the largest graph
+  static const int n_cu = [] {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+    (void)hipGetLastError();
+    return std::max(8, cu);
+  }();
+  const int ns = CS / SIM_RT;
   int rc;
-  if (nb_env == 2 && ncb >= 2) {
-    const int nw = std::max(1, std::min(8, (ncb + 1) / 2));
-    rc = launch_cloud(cloud_sim_kernel<2>, dim3(xcd_grid((int)strips)), 64 * nw, sizeof(float) * 1024 * nw, PK_CLOUD_SIM, "cloud_sim",
-                      stream, a, dpart);
-  } else {
-    const int nw = std::min(16, ncb);
-    rc = launch_cloud(cloud_sim_kernel<1>, dim3(xcd_grid((int)strips)), 64 * nw, sizeof(float) * 512 * nw, PK_CLOUD_SIM, "cloud_sim",
-                      stream, a, dpart);
+  {
+    const int t_quota = ncb * (ncb + 1) / 2;
+    const int64_t tasks = (int64_t)a.B * t_quota * ns;
+    const int per_q = (int)((tasks + 7) / 8), nquads = (per_q + 3) / 4;
+    int qstride = 1;                               // a stride coprime with the number of quads, about a third of it
+    for (int c = std::max(1, nquads / 3) | 1; c < nquads; c += 2) {
+      int x = c, y = nquads;
+      while (y) { const int tq = x % y; x = y; y = tq; }
+      if (x == 1) { qstride = c; break; }
+    }
+    // one task per wave up to 12 workgroups per CU (the hardware's workgroup scheduler balances better than a static split
+    // over resident waves: 75 against 79 us), beyond that the waves walk their lists
+    const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>((int64_t)12 * n_cu, (tasks + 3) / 4 + 7) / 8 * 8);
+    const size_t lds = sizeof(float) * 4 * (paper ? 2560 : 1280);
+    rc = paper ? launch_cloud(cloud_sim_kernel<true, SIM_RT>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride)
+               : launch_cloud(cloud_sim_kernel<false, SIM_RT>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride);
   }
   if (rc != AGCN_OK) return rc;
-  rc = launch_cloud(cloud_degree_kernel, dim3(strips), 64, 0, PK_CLOUD_DEG, "cloud_degree", stream, a, (const float*)dpart);
+  rc = launch_cloud(cloud_degree_kernel, dim3(strips), 64, 0, PK_CLOUD_DEG, "cloud_degree", stream, a, (const float*)dpart, ns);
   if (rc != AGCN_OK) return rc;
   const size_t lds = sizeof(float) * (CC * LD + 4 * 16 * LD);
   return paper ? launch_cloud(cloud_lap_kernel<true>, dim3(xcd_grid((int)strips)), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a)

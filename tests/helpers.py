@@ -226,4 +226,6 @@ def compare_with_oracle(out, caches, tot, variant, mode, K, has_prev, tot32=None
     if has_prev:
         _scalar_close(out["dbeta"], tot["dbeta"], None if tot32 is None else tot32["dbeta"], scale, "dbeta")
         for b in range(B):
-            assert_close(out["dLp"][b], tot["dLp"][b], GRAD_RTOL, "dL_prev[%d]" % b)
+            # (a 1 x 1 tile's clip adjoint is analytically 0: the fp32 oracle's own residue calibrates the bound there)
+            assert_close(out["dLp"][b], tot["dLp"][b], GRAD_RTOL, "dL_prev[%d]" % b,
+                         ref32=None if tot32 is None else tot32["dLp"][b])

@@ -43,6 +43,7 @@ def run(n_cases, seed, fin_choices=(1, 3, 5, 16, 33, 64, 75, 128), verbose=True,
                 if rs0.rand() < 0.5:
                     dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
             caches, tot = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLs)
+            tot32 = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLs, dtype=np.float32)[1]
             for name, (fm, sm, gbm, lim) in PATHS.items():
                 lib.agcn_set_fused_mode(fm)
                 lib.agcn_set_slab_mode(sm)
@@ -50,7 +51,7 @@ def run(n_cases, seed, fin_choices=(1, 3, 5, 16, 33, 64, 75, 128), verbose=True,
                 lib.agcn_set_lds_limit(lim)
                 try:
                     out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, variant, Lp, dLs)
-                    compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None)
+                    compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
                 except Exception as e:      # noqa: BLE001
                     fails += 1
                     print("FAIL case %d path %s: ns=%s Fin=%d Fout=%d K=%d variant=%d mode=%d prev=%s dLs=%s -> %s"
