@@ -617,6 +617,253 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_kernel(SgcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward 1, paper mode, on the BF16 matrix pipe at fp32 accuracy ("bf16 x 6"): every fp32 operand is split EXACTLY into
+// three bf16 pieces x = h + m + l (8 + 8 + 8 significant bits: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); the
+// differences are exact in fp32), and x y is taken as l h' + h l' + m m' + m h' + h m' + h h' (small terms first; the dropped
+// m l', l m', l l' are below 2^-24 |x y|): every bf16 x bf16 product is exact in the fp32 accumulator, so the error is that of
+// the fp32 additions alone -- on random data 0.2 x the error of the fmaf chain the f32 MFMA stands for (numpy emulation against
+// float64; the parity tests hold the same bounds as before).  Six v_mfma_f32_16x16x32_bf16 (16 cycles each) cover 32 k: 96
+// cycles instead of the 256 of eight v_mfma_f32_16x16x4_f32; the matrix time of a chunk goes 6144 -> 2304 cycles per wave.
+//   P[I, chunk]   = [g_1 | X_0][I] . [X_0 | g_1][chunk]^T   A: the wave's rows, split once; B: rows of the chunk's images, 16-byte reads
+//   dX[I]        += L[I, chunk] . g_1[chunk]                 A: the L strip (fp32 patch -> split per chunk); B: the SAME g_1 images read
+//                                                            transposed (ds_read_b64_tr_b16: k = the image row; tools/ubench/tr_read_check.hip)
+// The chunk's rows are staged as six bf16 images [64][72] (h / m / l of X_0 and g_1; image row 16 (rho % 4) + rho / 4 as
+// everywhere in this file): 54 KB + the four L patches = 72 KB of LDS, two workgroups per CU.  B pieces are requested one
+// 6-MFMA block ahead.  History: f32 MFMA kernel (cloud_bwd1_kernel<true>, kept for AGCN_CLOUD_BWD1_BF16X6=0): 143-154 us;
+// P alone on bf16 x 6 with 8-wave workgroups (110 KB: ONE workgroup per CU, nothing to run behind its barriers): 211 us.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+namespace {
+constexpr int LDH = 72;                          // bf16 elements per image row (144 bytes)
+constexpr int PLANE_H = 64 * LDH;                // bf16 elements per plane
+// two floats -> their three bf16 pieces, packed (low half = x0)
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const bf16x2 hv = (bf16x2){(__bf16)x0, (__bf16)x1};
+  h = __builtin_bit_cast(uint32_t, hv);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  const bf16x2 mv = (bf16x2){(__bf16)r0, (__bf16)r1};
+  m = __builtin_bit_cast(uint32_t, mv);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  const bf16x2 lv = (bf16x2){(__bf16)s0, (__bf16)s1};
+  l = __builtin_bit_cast(uint32_t, lv);
+}
+struct Pieces { u32x4 h, m, l; };                // eight consecutive k of one row / column
+__device__ __forceinline__ Pieces split3x8(const f32x4& lo, const f32x4& hi) {
+  uint32_t h[4], m[4], l[4];
+  split3(lo.x, lo.y, h[0], m[0], l[0]);
+  split3(lo.z, lo.w, h[1], m[1], l[1]);
+  split3(hi.x, hi.y, h[2], m[2], l[2]);
+  split3(hi.z, hi.w, h[3], m[3], l[3]);
+  Pieces p;
+  p.h = (u32x4){h[0], h[1], h[2], h[3]}; p.m = (u32x4){m[0], m[1], m[2], m[3]}; p.l = (u32x4){l[0], l[1], l[2], l[3]};
+  return p;
+}
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_x6(const Pieces& A, const Pieces& B, f32x4 acc) {
+  acc = mfma_bf(A.l, B.h, acc);
+  acc = mfma_bf(A.h, B.l, acc);
+  acc = mfma_bf(A.m, B.m, acc);
+  acc = mfma_bf(A.m, B.h, acc);
+  acc = mfma_bf(A.h, B.m, acc);
+  acc = mfma_bf(A.h, B.h, acc);
+  return acc;
+}
+// B pieces [k = 8q .. 8q + 7 of the block][column r]: rows of an image (the column index is the image ROW: 16-byte reads) ...
+__device__ __forceinline__ Pieces rows_B(const uint16_t* img, int off) {
+  Pieces b;
+  b.h = *reinterpret_cast<const u32x4*>(img + off);
+  b.m = *reinterpret_cast<const u32x4*>(img + PLANE_H + off);
+  b.l = *reinterpret_cast<const u32x4*>(img + 2 * PLANE_H + off);
+  return b;
+}
+// ... or columns of it (k = the image row): two transposed reads of a 4 x 16 block each; `off` = this lane's address inside the
+// first block (row 8q + r / 4, columns 4 (r % 4) ..), the second block 4 rows below
+__device__ __forceinline__ u32x4 tr8(const uint16_t* p) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * LDH));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  return (u32x4){l2.x, l2.y, h2.x, h2.y};
+}
+__device__ __forceinline__ Pieces cols_B(const uint16_t* img, int off) {
+  Pieces b;
+  b.h = tr8(img + off);
+  b.m = tr8(img + PLANE_H + off);
+  b.l = tr8(img + 2 * PLANE_H + off);
+  return b;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const int slab = 4 * strip + wave;
+  const WaveCtx c = wave_ctx(a, slab);
+  const int n = c.n;
+  uint16_t* PX = reinterpret_cast<uint16_t*>(smem);   // [3][64][LDH]  bf16 pieces of the chunk's X_0 rows
+  uint16_t* PG = PX + 3 * PLANE_H;                     // [3][64][LDH]  ... of its g_1 rows
+  float* Ls = smem + (6 * PLANE_H) / 2 + wave * (16 * LD);   // [16][LD] this wave's strip of L (fp32)
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * FIN;   // adjoint of X_1 (K = 2: plane 0)
+  int l0ld;
+  const float* L0d = dense_l0(a, c, &l0ld);
+  const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* L0t = L0d + (int64_t)(c.i0 + 4 * q) * l0ld + 4 * r;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  float si[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) si[i] = a.sv_s[c.row0 + c.i0 + 4 * q + i];
+  // A pieces of the wave's own rows: lane (r, q) holds [row r][32 kb + 8q .. + 7]
+  Pieces Ag[2], Ax[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const float* gp = g1 + (int64_t)(c.i0 + r) * FIN + 32 * kb + 8 * q;
+    const float* xp = Xg + (int64_t)(c.i0 + r) * a.ldx + 32 * kb + 8 * q;
+    Ag[kb] = split3x8(*reinterpret_cast<const f32x4*>(gp), *reinterpret_cast<const f32x4*>(gp + 4));
+    Ax[kb] = split3x8(*reinterpret_cast<const f32x4*>(xp), *reinterpret_cast<const f32x4*>(xp + 4));
+  }
+  struct Tiles { f32x4 rv[4], l0[4], sj; };
+  auto load_tiles = [&](int c0) {
+    Tiles g;
+    g.sj = *reinterpret_cast<const f32x4*>(sjp + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.rv[i] = *reinterpret_cast<const f32x4*>(Rt + (int64_t)i * n + c0);
+      g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
+    }
+    return g;
+  };
+  // staging: thread = (chunk row rho = tid / 4, features 16 (tid % 4) .. + 15) of both matrices
+  const int rho = tid >> 2, sg = tid & 3, irow = 16 * (rho & 3) + (rho >> 2);
+  struct Stage { f32x4 g[4], x[4]; };
+  auto stage_load16 = [&](int c0) {
+    Stage s;
+    const float* gp = g1 + (int64_t)(c0 + rho) * FIN + 16 * sg;
+    const float* xp = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      s.g[m] = *reinterpret_cast<const f32x4*>(gp + 4 * m);
+      s.x[m] = *reinterpret_cast<const f32x4*>(xp + 4 * m);
+    }
+    return s;
+  };
+  auto stage_store16 = [&](const Stage& s) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const Pieces pg = split3x8(s.g[2 * hf], s.g[2 * hf + 1]), px = split3x8(s.x[2 * hf], s.x[2 * hf + 1]);
+      const int o = irow * LDH + 16 * sg + 8 * hf;
+      *reinterpret_cast<u32x4*>(PG + o) = pg.h; *reinterpret_cast<u32x4*>(PG + PLANE_H + o) = pg.m; *reinterpret_cast<u32x4*>(PG + 2 * PLANE_H + o) = pg.l;
+      *reinterpret_cast<u32x4*>(PX + o) = px.h; *reinterpret_cast<u32x4*>(PX + PLANE_H + o) = px.m; *reinterpret_cast<u32x4*>(PX + 2 * PLANE_H + o) = px.l;
+    }
+  };
+
+  f32x4 acc[4];          // dX[I]: tile e <-> features 16 e + r
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ds[4] = {0.f, 0.f, 0.f, 0.f};
+  float dalpha_part = 0.f;
+  Stage pre = stage_load16(0);
+  Tiles cur = load_tiles(0);
+  const int offB = r * LDH + 8 * q;                                // rows_B: image row 16 t + r, k 32 kb + 8q ..
+  const int offT = (8 * q + (r >> 2)) * LDH + 4 * (r & 3);         // cols_B: row 32 kb + 8q + r / 4, columns 16 e + 4 (r % 4) ..
+#pragma unroll 1
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    __syncthreads();
+    stage_store16(pre);
+    __syncthreads();
+    if (c0 + CC < n) pre = stage_load16(c0 + CC);
+    f32x4 Sv[4];          // [i][t]: S_ij
+    f32x4 sj = cur.sj;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool diag = row == c0 + 4 * r + t;
+        Sv[i][t] = diag ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);          // cloud_sim's instruction
+        const float R = (diag ? 1.f : 0.f) - (si[i] * Sv[i][t]) * sj[t];                  // cloud_lap's instruction
+        Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(R, alpha) + cur.l0[i][t];
+      }
+    }
+    if (c0 + CC < n) cur = load_tiles(c0 + CC);
+    __builtin_amdgcn_wave_barrier();
+    // P[I, tile] = g_1[I] . X_0[tile]^T + X_0[I] . g_1[tile]^T (two accumulation chains), then the element-wise epilogue.
+    // Blocks (t, kb, which product) in a row, the next block's B pieces requested before this block's MFMAs.
+    f32x4 Qv[4];         // [i][t]
+    Pieces Bn = rows_B(PX, offB);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        Pieces Bc = Bn;
+        Bn = rows_B(PG, offB + 16 * t * LDH + 32 * kb);
+        __builtin_amdgcn_sched_barrier(0);
+        pa = mfma_x6(Ag[kb], Bc, pa);
+        Bc = Bn;
+        if (kb == 0) Bn = rows_B(PX, offB + 16 * t * LDH + 32);
+        else if (t < 3) Bn = rows_B(PX, offB + 16 * (t + 1) * LDH);
+        __builtin_amdgcn_sched_barrier(0);
+        pb = mfma_x6(Ax[kb], Bc, pb);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = c.i0 + 4 * q + i;
+        const bool diag = row == c0 + 4 * r + t;
+        const float R = (diag ? 1.f : 0.f) - (si[i] * Sv[i][t]) * sj[t];
+        const float P = pa[i] + pb[i];
+        dalpha_part = __builtin_fmaf(P, fminf(R, 0.f), dalpha_part);
+        const float Q = -(P * lrelu_grad(R, alpha));            // dA_ij + dA_ji, dA = -dR
+        Qv[i][t] = Q;
+        ds[i] = __builtin_fmaf(Q, Sv[i][t] * sj[t], ds[i]);      // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
+      }
+    }
+    // dX[I] += L[I, chunk] g_1[chunk]: A = the L patch (k = the patch column = the image row of the chunk's g_1), split here
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const float* lp = Ls + r * LD + 32 * kb + 8 * q;
+      const Pieces Al = split3x8(*reinterpret_cast<const f32x4*>(lp), *reinterpret_cast<const f32x4*>(lp + 4));
+      Pieces Tn = cols_B(PG, offT + 32 * kb * LDH);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const Pieces Tc = Tn;
+        if (e < 3) Tn = cols_B(PG, offT + 32 * kb * LDH + 16 * (e + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        acc[e] = mfma_x6(Al, Tc, acc[e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = Qv[i];
+  }
+  // dX rows of the strip (g_0 already there from the packed filter adjoint): lane (r, q) holds rows 4q + i, features 16 e + r
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dXg[(int64_t)(4 * q + i) * a.ldx + 16 * e + r] += acc[e][i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t = row16_sum(ds[i]);
+    if (r == 0) a.ws_dd[c.row0 + c.i0 + 4 * q + i] = degree_grad(si[i], t);   // dd_k = -1/2 s_k^3 ds_k
+  }
+  const float da = wave_sum_all(dalpha_part);
+  if (lane == 0) {
+    a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = 0.5f * da;
+    a.ws_pg[2 * (a.pg_slab_base + slab) + 1] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward 2 (paper mode): c_ij = -S_ij (Q_ij s_i s_j + dd_i + dd_j) / r_ij (0 where r_ij = 0 or S_ij = 0),
 // dZ[I] = rowsum(c) Z[I] - c Z, dX[I] += dZ[I] M_L^T.
 __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
@@ -1071,8 +1318,11 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   if (!paper)
     return launch_cloud(cloud_bwd1_kernel<false>, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
                         "cloud_bwd1", stream, a);
-  int rc = launch_cloud(cloud_bwd1_kernel<true>, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
-                        "cloud_bwd1", stream, a);
+  static const int bf_env = [] { const char* e = std::getenv("AGCN_CLOUD_BWD1_BF16X6"); return e ? std::atoi(e) : 1; }();
+  int rc = bf_env ? launch_cloud(cloud_bwd1_paper_kernel, dim3(xcd_grid((int)strips)), 256,
+                                 sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H, PK_CLOUD_BWD1, "cloud_bwd1", stream, a)
+                  : launch_cloud(cloud_bwd1_kernel<true>, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD),
+                                 PK_CLOUD_BWD1, "cloud_bwd1", stream, a);
   if (rc != AGCN_OK) return rc;
   return launch_cloud(cloud_bwd2_kernel, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2",
                       stream, a);
