@@ -429,6 +429,9 @@ using namespace agcn;
 
 // Which kernels a forward / backward call on this batch would launch (host logic only: nothing is launched, no device
 // pointer is dereferenced).  For tests and diagnostics.
+static bool cloud_shape(const AgcnLayerDesc* d);
+static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi);
+
 extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out) {
   const char* who = "agcn_sgc_ll_dispatch_info";
   int rc = check_desc(desc, who);
@@ -444,8 +447,8 @@ extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGr
   int path = fs.mode == 1 ? ((fs.spec_fwd ? 1 : 0) | (fs.spec_bwd ? 2 : 0) | 4)      // fused (+ specialised bits)
                           : (fs.mode == 2 ? 8 : (use_slabs(desc, batch, host.info) ? 16 : 32));
   // 64: the slab batch has the shape the point-cloud kernels take (pointer alignment is checked at the call)
-  if (path == 16 && desc->Fin == 64 && batch->L0_dense != nullptr && slab_quad_ok(host) && (desc->ldx & 3) == 0 &&
-      (desc->Fout & 3) == 0 && (desc->ldy & 3) == 0)
+  if ((path == 16 || (path == 32 && desc->variant == AGCN_SGC_LL_RESLAP)) && cloud_shape(desc) && cloud_candidate(desc, batch, host.info) &&
+      batch->L0_dense != nullptr && slab_quad_ok(host) && (desc->ldx & 3) == 0 && (desc->Fout & 15) == 0 && (desc->ldy & 3) == 0)
     path |= 64;
   const int32_t v[AGCN_DISPATCH_INFO_INTS] = {path, fs.spec_small_first, cg, cs, dg, cgb, csb, dgb};
   for (int i = 0; i < AGCN_DISPATCH_INFO_INTS; ++i) out[i] = v[i];
@@ -476,7 +479,16 @@ extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const voi
 }
 
 // layer shapes the point-cloud kernels (cloud_kernels.hip) are compiled for: their forward needs partial-degree scratch
-static bool cloud_shape(const AgcnLayerDesc* d) { return d->variant == AGCN_SGC_LL && d->K == 2 && d->Fin == 64; }
+static bool cloud_shape(const AgcnLayerDesc* d) {
+  return (d->variant == AGCN_SGC_LL || d->variant == AGCN_SGC_LL_RESLAP) && d->K == 2 && d->Fin == 64;
+}
+// Batches the point-cloud kernels (cloud_kernels.hip) may take: what the slab kernels take (SGC_LL), and SGC_LL_Reslap with a
+// dense symmetric L_orig on packed rows (cloud_path() checks the rest: multiples of 64 nodes, alignment, Fin = 64)
+static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
+  if (d->variant == AGCN_SGC_LL) return use_slabs(d, g, pi);
+  return agcn_get_slab_mode() != 0 && d->variant == AGCN_SGC_LL_RESLAP && d->K == 2 && pi.rows == pi.N1 &&
+         g->L0_dense != nullptr && g->L0_rowptr == nullptr && g->L0_symmetric == 1;
+}
 
 static size_t global_scratch_floats(const AgcnLayerDesc* d, const PlanView& host, bool bwd, Carver* c,
                                     float** tile, float** buf) {
@@ -676,9 +688,9 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     return AGCN_OK;
   }
   // point clouds (cloud_kernels.hip): projection, similarity, degree, Laplacian + Chebyshev + filter in four launches
-  if (use_slabs(desc, batch, host.info) && dpart && cloud_path(a, a.slab_quad != 0) &&
+  if (cloud_candidate(desc, batch, host.info) && dpart && cloud_path(a, a.slab_quad != 0) &&
       (reinterpret_cast<uintptr_t>(out->Y) & 15) == 0)
-    return launch_cloud_forward(a, dpart, host.info.max_n, hip_stream);
+    return launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
   // 1. Z = X . M_L over the packed rows (graphconv.py:164)
   RowsGemmArgs g;
   fill_rows(g, desc, host, dev);

@@ -346,14 +346,133 @@ __global__ __launch_bounds__(64) void cloud_degree_kernel(SgcArgs a, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// SGC_LL_Reslap at point-cloud sizes (graphconv_reslap.py:184-198).  Its two clip_by_norm stages need graph-wide sums of
+// squares before a single element can leave, so the Laplacian takes three strip kernels instead of one:
+//   cloud_rnorm_kernel   ||R||_F^2 per strip (paper mode; R = I in reference mode: n)
+//   cloud_rlap1_kernel   R2 = lrelu(clip(R)) -> res_L;  L_pre = R2 + L_orig + beta L_prev -> reserve;  ||L_pre||_F^2 per strip
+//   cloud_lap_kernel<.., RES>   La = lrelu(clip(L_pre)) -> L_sum, X_1 = La X_0, Y
+// The per-strip partials of a graph are added by every workgroup that needs the sum, lane k taking strip k, in one fixed
+// butterfly order (graphs have at most 25 strips).
+__device__ __forceinline__ float graph_sum(const float* part, int count, int lane) {
+  return wave_sum_all(lane < count ? part[lane] : 0.f);
+}
+__device__ __forceinline__ float block4_sum(float v, float* red, int wave, int lane) {
+  v = wave_sum_all(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void cloud_rnorm_kernel(SgcArgs a, float* rpart) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const WaveCtx c = wave_ctx(a, 4 * strip + wave);
+  const int n = c.n;
+  const float* Wt = a.res_W + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  float si[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) si[i] = a.sv_s[c.row0 + c.i0 + 4 * q + i];
+  float part = 0.f;
+#pragma unroll 2
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    const f32x4 sj = *reinterpret_cast<const f32x4*>(sjp + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 S = *reinterpret_cast<const f32x4*>(Wt + (int64_t)i * n + c0);
+      const int row = c.i0 + 4 * q + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float R = ((row == c0 + 4 * r + t) ? 1.f : 0.f) - (si[i] * S[t]) * sj[t];   // cloud_lap's instruction
+        part = __builtin_fmaf(R, R, part);
+      }
+    }
+  }
+  const float tot = block4_sum(part, red, wave, lane);
+  if (tid == 0) rpart[strip] = tot;
+}
+
+template <bool PAPER>
+__global__ __launch_bounds__(256) void cloud_rlap1_kernel(SgcArgs a, const float* rpart, float* lpart) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const WaveCtx c = wave_ctx(a, 4 * strip + wave);
+  const int n = c.n;
+  const int strip0 = strip - (a.slab_row[4 * strip] >> 6);
+  const float ssR = PAPER ? graph_sum(rpart + strip0, n >> 6, lane) : (float)n;
+  const float scR = clip_scale(ssR, 1.0f);
+  const float alpha = a.alpha[0];
+  const bool has_prev = a.L_prev != nullptr;
+  const float beta = has_prev ? a.beta[0] : 0.f;
+  int l0ld;
+  const float* L0d = dense_l0(a, c, &l0ld);
+  const int64_t o0 = c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* Wt = a.res_W + o0;
+  const float* Pt = has_prev ? a.L_prev + o0 : nullptr;
+  float* RLt = a.res_L + o0;
+  float* Lpt = a.sv_Lpre + o0;
+  const float* L0t = L0d + (int64_t)(c.i0 + 4 * q) * l0ld + 4 * r;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  float si[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) si[i] = PAPER ? a.sv_s[c.row0 + c.i0 + 4 * q + i] : 0.f;
+  struct Tiles { f32x4 s[4], l0[4], lp[4], sj; };
+  auto load_tiles = [&](int c0) {
+    Tiles g;
+    g.sj = PAPER ? *reinterpret_cast<const f32x4*>(sjp + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.s[i] = PAPER ? *reinterpret_cast<const f32x4*>(Wt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
+      g.lp[i] = has_prev ? *reinterpret_cast<const f32x4*>(Pt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return g;
+  };
+  float part = 0.f;
+  Tiles cur = load_tiles(0);
+#pragma unroll 1
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    const Tiles nxt = (c0 + CC < n) ? load_tiles(c0 + CC) : cur;      // the next chunk's tiles in flight
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+      f32x4 R2, Lp;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float R = (row == c0 + 4 * r + t) ? 1.f : 0.f;
+        if (PAPER) R = R - (si[i] * cur.s[i][t]) * cur.sj[t];
+        R2[t] = lrelu(R * scR, alpha);                                  // reslap:185-186
+        float v = R2[t] + cur.l0[i][t];                                // :193
+        if (has_prev) v = v + cur.lp[i][t] * beta;                     // :190
+        Lp[t] = v;
+        part = __builtin_fmaf(v, v, part);
+      }
+      __builtin_nontemporal_store(R2, reinterpret_cast<f32x4*>(RLt + (int64_t)i * n + c0));
+      *reinterpret_cast<f32x4*>(Lpt + (int64_t)i * n + c0) = Lp;
+    }
+    cur = nxt;
+  }
+  const float tot = block4_sum(part, red, wave, lane);
+  if (tid == 0) lpart[strip] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tile convention of the three strip kernels below: a wave owns 16 rows; of a 64-column chunk lane (r, q) holds, for
 // its rows 4q + i (i = 0..3), the four columns c0 + 4r + t (t = 0..3) as ONE f32x4 -- component t is the lane's element
 // of accumulator tile t, whose image index (column of the L / c strips, row of the staged chunk images) is 16 t + r.
 
 // forward 3: R = I - s S s (paper) | I (reference), res_L = lrelu(R), L = res_L + L_orig, X_1[I] = L[I, :] X_0
 // (graphconv.py:198-231) and the filter product Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b) (:238-251, 117-123).
-template <bool PAPER>
-__global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
+// RES: second Laplacian stage of SGC_LL_Reslap (graphconv_reslap.py:194-195): the tiles are L_pre (reserve, written by
+// cloud_rlap1_kernel), La = lrelu(clip_by_norm(L_pre, 1)) -> L_sum (the 4th output) and the L of the Chebyshev product.
+template <bool PAPER, bool RES = false>
+__global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* rpart, const float* lpart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -374,16 +493,36 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
   const float* sjp = a.sv_s + c.row0 + 4 * r;
   float si[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) si[i] = PAPER ? a.sv_s[c.row0 + c.i0 + 4 * q + i] : 0.f;
+  for (int i = 0; i < 4; ++i) si[i] = (PAPER && !RES) ? a.sv_s[c.row0 + c.i0 + 4 * q + i] : 0.f;
 
-  struct Tiles { f32x4 s[4], l0[4], sj; };
+  // Reslap: the two clip scales from the strips' partial sums of squares (every workgroup of a graph adds the same values in
+  // the same order: the same bits)
+  float ssR = 1.f, scR = 1.f, ssL = 1.f, scL = 1.f;
+  if constexpr (RES) {
+    const int strip0 = strip - (a.slab_row[4 * strip] >> 6), ncb = n >> 6;
+    ssR = PAPER ? graph_sum(rpart + strip0, ncb, lane) : (float)n;
+    ssL = graph_sum(lpart + strip0, ncb, lane);
+    scR = clip_scale(ssR, 1.0f);
+    scL = clip_scale(ssL, 1.0f);
+    if (c.i0 == 0 && tid == 0) {   // norms / scales for the backward projections
+      float* sc = a.sv_scal + 4 * c.b;
+      sc[0] = ssR; sc[1] = scR; sc[2] = ssL; sc[3] = scL;
+    }
+  }
+  const float* Lpt = RES ? a.sv_Lpre + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r : nullptr;
+  struct Tiles { f32x4 s[4], l0[4], sj; };   // (RES: s = the L_pre tiles, nothing else)
   auto load_tiles = [&](int c0) {
     Tiles g;
-    g.sj = PAPER ? *reinterpret_cast<const f32x4*>(sjp + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    g.sj = (PAPER && !RES) ? *reinterpret_cast<const f32x4*>(sjp + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      g.s[i] = PAPER ? *reinterpret_cast<const f32x4*>(Wt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
+      if constexpr (RES) {
+        g.s[i] = *reinterpret_cast<const f32x4*>(Lpt + (int64_t)i * n + c0);
+        g.l0[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
+        g.s[i] = PAPER ? *reinterpret_cast<const f32x4*>(Wt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
+      }
     }
     return g;
   };
@@ -403,6 +542,14 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
       f32x4 Lv, Ltv;
+      if constexpr (RES) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          Ltv[t] = lrelu(cur.s[i][t] * scL, alpha);                    // La = lrelu(clip_by_norm(L_pre, 1))  (reslap:194-195)
+          Ls[(4 * q + i) * LD + 16 * t + r] = Ltv[t];
+        }
+        __builtin_nontemporal_store(Ltv, reinterpret_cast<f32x4*>(LSt + (int64_t)i * n + c0));
+      } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float R = (row == c0 + 4 * r + t) ? 1.f : 0.f;                // reference: I - D*W*D elementwise == I
@@ -413,6 +560,7 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a) {
       }
       __builtin_nontemporal_store(Lv, reinterpret_cast<f32x4*>(RLt + (int64_t)i * n + c0));
       if (LSt) *reinterpret_cast<f32x4*>(LSt + (int64_t)i * n + c0) = Ltv;
+      }
     }
     // the next chunk's tiles: requested once this chunk's are consumed (into the same registers), in flight behind the product
     if (c0 + CC < n) cur = load_tiles(c0 + CC);
@@ -1227,15 +1375,19 @@ int launch_cloud(K kernel, dim3 grid, int threads, size_t lds, int prof_id, cons
 // same arguments).  `quad` = every graph a multiple of 64 nodes.
 bool cloud_path(const SgcArgs& a, bool quad) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  return cloud_env() && quad && a.Fin == FIN && a.K == 2 && a.variant == AGCN_SGC_LL && a.L0_dense != nullptr &&
-         (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 15) == 0 && al16(a.X) && al16(a.weight) && al16(a.bias) &&
-         al16(a.M_L) && (a.n_slabs & 3) == 0;
+  // SGC_LL_Reslap: the previous layer's Laplacian must be symmetric like L_orig (it is, whenever it is a Laplacian this
+  // path or the reference produced from symmetric inputs): La is then symmetric and La^T g_1 is taken as La g_1
+  const bool res_ok = a.variant != AGCN_SGC_LL_RESLAP || (a.sv_Lpre != nullptr && al16(a.sv_Lpre) && al16(a.L_prev));
+  return cloud_env() && quad && a.Fin == FIN && a.K == 2 && (a.variant == AGCN_SGC_LL || a.variant == AGCN_SGC_LL_RESLAP) && res_ok &&
+         a.L0_dense != nullptr && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 15) == 0 && al16(a.X) && al16(a.weight) &&
+         al16(a.bias) && al16(a.M_L) && (a.n_slabs & 3) == 0;
 }
 constexpr int SIM_RT = 32;   // rows per task of cloud_sim_kernel: 64 / SIM_RT partial-degree slots per row block (16: 72 + 9.5 us
                              // similarity + degree kernel, 32: 75 + 7.7, 64: 84 + 6.5)
-size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / SIM_RT + 64); }
+// forward workspace: the partial degrees [n / SIM_RT][n] per graph, then (Reslap) two partial sums of squares per 64-row strip
+size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / SIM_RT + 64) + 2 * (size_t)(tile_elems / 4096 + 16); }
 
-int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* stream) {
+int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t tile_elems, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const unsigned strips = (unsigned)(a.n_slabs / 4);
   {
@@ -1272,8 +1424,22 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, void* st
   rc = launch_cloud(cloud_degree_kernel, dim3(strips), 64, 0, PK_CLOUD_DEG, "cloud_degree", stream, a, (const float*)dpart, ns);
   if (rc != AGCN_OK) return rc;
   const size_t lds = sizeof(float) * (CC * LD + 4 * 16 * LD);
-  return paper ? launch_cloud(cloud_lap_kernel<true>, dim3(xcd_grid((int)strips)), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a)
-               : launch_cloud(cloud_lap_kernel<false>, dim3(xcd_grid((int)strips)), 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a);
+  const dim3 sgrid(xcd_grid((int)strips));
+  float* rpart = dpart + (size_t)(tile_elems / SIM_RT + 64);
+  float* lpart = rpart + (size_t)(tile_elems / 4096 + 16);
+  if (a.variant == AGCN_SGC_LL_RESLAP) {
+    if (paper) {
+      rc = launch_cloud(cloud_rnorm_kernel, sgrid, 256, 0, PK_CLOUD_LAP, "cloud_rnorm", stream, a, rpart);
+      if (rc != AGCN_OK) return rc;
+    }
+    rc = paper ? launch_cloud(cloud_rlap1_kernel<true>, sgrid, 256, 0, PK_CLOUD_LAP, "cloud_rlap1", stream, a, (const float*)rpart, lpart)
+               : launch_cloud(cloud_rlap1_kernel<false>, sgrid, 256, 0, PK_CLOUD_LAP, "cloud_rlap1", stream, a, (const float*)rpart, lpart);
+    if (rc != AGCN_OK) return rc;
+    return paper ? launch_cloud(cloud_lap_kernel<true, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)rpart, (const float*)lpart)
+                 : launch_cloud(cloud_lap_kernel<false, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)rpart, (const float*)lpart);
+  }
+  return paper ? launch_cloud(cloud_lap_kernel<true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)nullptr, (const float*)nullptr)
+               : launch_cloud(cloud_lap_kernel<false>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)nullptr, (const float*)nullptr);
 }
 
 // The row-chunk partials of the parameter gradients (the caller runs param_grads.hip's reduce kernel behind it).
