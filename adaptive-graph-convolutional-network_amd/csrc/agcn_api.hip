@@ -513,7 +513,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT, *spart; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -528,6 +528,14 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
     w->dA = c.take((size_t)pi.tile_elems);
     w->dAt = c.take((size_t)pi.tile_elems);
     w->dd = c.take((size_t)pi.rows);
+  }
+  w->spart = nullptr;
+  if (d->variant == AGCN_SGC_LL_RESLAP && cloud_shape(d)) {   // point-cloud kernels, Reslap: Q tile + dd (paper), strip partials
+    if (paper) {
+      w->dA = c.take((size_t)pi.tile_elems);
+      w->dd = c.take((size_t)pi.rows);
+    }
+    w->spart = c.take((size_t)8 * ((size_t)pi.n_slabs / 4 + 8));
   }
   w->n_chunks = n_chunks_for(pi.rows);
   w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
@@ -787,7 +795,17 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   const bool slabs = use_slabs(desc, batch, host.info);
   const FusedSplit fs = fused_split(desc, batch, host);
   const bool fused = fs.mode != 0;
-  bool cloud_bwd = false;
+  bool cloud_bwd = false, cloud_res = false;
+  // SGC_LL_Reslap on the point-cloud kernels: only behind the cloud forward (the per-graph forward leaves no r tiles); the
+  // same answer in both stages of a split call
+  if (reslap && !fused && w.WT && w.spart && cloud_candidate(desc, batch, host.info)) {
+    SgcArgs t = a;
+    t.n_slabs = host.info.n_slabs;
+    cloud_res = cloud_path(t, slab_quad_ok(host) != 0) && (reinterpret_cast<uintptr_t>(fwd->Y) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(dL_sum) & 15) == 0 &&
+                (!has_prev || (reinterpret_cast<uintptr_t>(grads->dL_prev) & 15) == 0);
+  }
   // arrival counters of the one-pass parameter-gradient kernel: zeroed by the first kernel of this call
   int32_t n_counters = 0;
   int32_t* counters = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, desc->K,
@@ -904,7 +922,11 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     cloud_bwd = slabs && w.WT && cloud_path(a, a.slab_quad != 0) && dL_sum == nullptr &&
                 (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
     RowsGemmArgs g;
-    if (cloud_bwd) {
+    if (cloud_res) {
+      a.pg_slab_base = 0;
+      rc = launch_cloud_backward_reslap(a, nullptr, w.spart, hip_stream);
+      if (rc != AGCN_OK) return rc;
+    } else if (cloud_bwd) {
       // the same predicate as the forward's: the cloud forward left W^T in the reserve (else it is built here, in workspace)
       const bool fwd_cloud = (reinterpret_cast<uintptr_t>(fwd->Y) & 15) == 0;
       rc = launch_cloud_backward(a, fwd_cloud ? nullptr : w.WT, hip_stream);
@@ -952,15 +974,15 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
-  pa.B = fused ? B + fs.n_big_slabs + coop_slabs : (slabs ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
+  pa.B = fused ? B + fs.n_big_slabs + coop_slabs : ((slabs || cloud_res) ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
-  pa.counters_zeroed = ((stages & 1) && !cloud_bwd) ? 1 : 0;
+  pa.counters_zeroed = ((stages & 1) && !cloud_bwd && !cloud_res) ? 1 : 0;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
   // point-cloud sizes: row-chunk partials with 16-byte operand loads + the fixed-order reduce (cloud_kernels.hip)
   static const int cloud_pg = [] { const char* e = std::getenv("AGCN_CLOUD_PG"); return e ? std::atoi(e) : 1; }();
-  if (cloud_pg && !fused && slabs && w.WT && cloud_param_grads_ok(pa) && (size_t)pa.n_chunks * pa.part_stride <= w.part_floats &&
+  if (cloud_pg && !fused && (slabs || cloud_res) && w.WT && cloud_param_grads_ok(pa) && (size_t)pa.n_chunks * pa.part_stride <= w.part_floats &&
       (reinterpret_cast<uintptr_t>(batch->X) & 15) == 0) {
     return launch_cloud_param_partials(pa, hip_stream);   // (partials + the fixed-order reduce)
   }

@@ -1012,6 +1012,285 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// SGC_LL_Reslap backward at point-cloud sizes.  With D = g_1 X_0^T + dL_sum (the gradient arriving on La; NOT symmetric) the
+// chain of graphconv_reslap.py:184-198 reads, element by element but for two graph-wide inner products,
+//   dLc   = D lrelu'(Lc)                       Lc = L_pre scL
+//   dLpre = aL dLc - bL L_pre                  clip adjoint: aL = scL, bL = <dLc, L_pre> / ||L_pre||^3 if the clip is active
+//   dL_prev = beta dLpre, dbeta = <dLpre, L_prev>, dalpha = <D, min(Lc, 0)> + <dLpre, min(R1, 0)>      R1 = R scR
+//   dR1   = dLpre lrelu'(R1),  dR = aR dR1 - bR R        aR = scR, bR = <dR1, R> / ||R||^3 if active
+// Everything behind dLc is LINEAR in the two inner products, so ONE pass over the pairs (pass A) collects eight sums per
+// graph from which bL, bR, dalpha and dbeta follow, and the passes behind it are purely element-wise:
+//   A  sums (per-strip partials; one product: g_1[I] X_0[J]^T)
+//   B  (paper) Q = -(dR + dR^T) -> workspace, ds -> dd: as backward 1 of SGC_LL with D_ij + D_ji = P_ij + dL_sum_ij + dL_sum_ji
+//      (R, L_pre, L_prev symmetric; the transposed dL_sum tile is read as 16-byte pieces along i)
+//   C  dL_prev -> out, dX[I] += La[I, :] g_1 (La symmetric: cloud_path), the graph's dalpha / dbeta -> ws_pg
+//   then cloud_bwd2_kernel as it is (Q, r, dd -> dZ).
+// All products on the bf16 pipe at fp32 accuracy (cloud_bwd1_paper_kernel's helpers).
+// Per-strip partial sums: [strip][8] = <dLc,Lpre>, <dLc,Lprev>, <Lpre,Lprev>, <dLc,min(R1,0)>, <Lpre,min(R1,0)>, <dLc,mR R>,
+// <Lpre,mR R>, <D,min(Lc,0)>.
+struct ResScal { float aL, bL, aR, bR, dalpha, dbeta; };
+__device__ __forceinline__ ResScal res_scalars(const SgcArgs& a, const float* spart, int strip0, int ncb, int b, int lane) {
+  float sm[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sm[k] = wave_sum_all(lane < ncb ? spart[(int64_t)(strip0 + lane) * 8 + k] : 0.f);
+  const float* sc = a.sv_scal + 4 * b;
+  const float ssR = sc[0], scR = sc[1], ssL = sc[2], scL = sc[3];
+  const float invL = 1.0f / sqrtf(ssL), invR = 1.0f / sqrtf(ssR);
+  ResScal z;
+  z.aL = scL;
+  z.bL = invL <= 1.0f ? sm[0] * invL * invL * invL : 0.f;          // (the oracle's clip_backward)
+  z.dbeta = z.aL * sm[1] - z.bL * sm[2];
+  z.dalpha = sm[7] + (z.aL * sm[3] - z.bL * sm[4]);
+  const float ipR = z.aL * sm[5] - z.bL * sm[6];
+  z.aR = scR;
+  z.bR = invR <= 1.0f ? ipR * invR * invR * invR : 0.f;
+  return z;
+}
+
+template <int PASS, bool PAPER>   // PASS 0 = A, 1 = B, 2 = C
+__global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* spart) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[4 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const int slab = 4 * strip + wave;
+  const WaveCtx c = wave_ctx(a, slab);
+  const int n = c.n;
+  const bool has_prev = a.L_prev != nullptr, has_dls = a.dL_sum != nullptr;
+  constexpr bool NEED_X = true;                       // X_0 images: the B operand of g_1[I] X_0[J]^T
+  constexpr bool NEED_G = PASS != 0;                  // g_1 images: X_0[I] g_1[J]^T (B), La g_1 (C)
+  // pass C without a previous Laplacian has no dL_prev to write: only the La g_1 product is left
+  const bool want_D = PASS != 2 || has_prev;
+  uint16_t* PX = reinterpret_cast<uint16_t*>(smem);   // [3][64][LDH]
+  uint16_t* PG = PX + 3 * PLANE_H;
+  float* Ls = smem + (6 * PLANE_H) / 2 + wave * (16 * LD);
+  const float alpha = a.alpha[0];
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * FIN;
+  const float* scal = a.sv_scal + 4 * c.b;
+  const float scR = scal[1], scL = scal[3];
+  const int64_t o0 = c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* Rt = a.sv_r + o0;
+  const float* Lpt = a.sv_Lpre + o0;
+  const float* Pvt = has_prev ? a.L_prev + o0 : nullptr;
+  const float* Dst = has_dls ? a.dL_sum + o0 : nullptr;
+  const float* DsT = has_dls ? a.dL_sum + c.toff + (int64_t)(4 * r) * n + c.i0 + 4 * q : nullptr;   // + (c0 + t) n: [t] over i
+  float* Qt = a.ws_dA + o0;
+  float* DPt = has_prev ? a.dL_prev + o0 : nullptr;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  float si[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) si[i] = PAPER ? a.sv_s[c.row0 + c.i0 + 4 * q + i] : 0.f;
+  ResScal z;
+  z.aL = z.bL = z.aR = z.bR = z.dalpha = z.dbeta = 0.f;
+  if constexpr (PASS != 0) z = res_scalars(a, spart, strip - (a.slab_row[4 * strip] >> 6), n >> 6, c.b, lane);
+  const float beta = has_prev ? a.beta[0] : 0.f;
+  // A pieces of the wave's own rows
+  Pieces Ag[2], Ax[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const float* gp = g1 + (int64_t)(c.i0 + r) * FIN + 32 * kb + 8 * q;
+    Ag[kb] = split3x8(*reinterpret_cast<const f32x4*>(gp), *reinterpret_cast<const f32x4*>(gp + 4));
+    if constexpr (PASS == 1) {
+      const float* xp = Xg + (int64_t)(c.i0 + r) * a.ldx + 32 * kb + 8 * q;
+      Ax[kb] = split3x8(*reinterpret_cast<const f32x4*>(xp), *reinterpret_cast<const f32x4*>(xp + 4));
+    }
+  }
+  const int rho = tid >> 2, sg = tid & 3, irow = 16 * (rho & 3) + (rho >> 2);
+  struct Stage { f32x4 g[4], x[4]; };
+  auto stage_load16 = [&](int c0) {
+    Stage st;
+    const float* gp = g1 + (int64_t)(c0 + rho) * FIN + 16 * sg;
+    const float* xp = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (NEED_G) st.g[m] = *reinterpret_cast<const f32x4*>(gp + 4 * m);
+      if (NEED_X) st.x[m] = *reinterpret_cast<const f32x4*>(xp + 4 * m);
+    }
+    return st;
+  };
+  auto stage_store16 = [&](const Stage& st) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int o = irow * LDH + 16 * sg + 8 * hf;
+      if (NEED_G) {
+        const Pieces pg = split3x8(st.g[2 * hf], st.g[2 * hf + 1]);
+        *reinterpret_cast<u32x4*>(PG + o) = pg.h; *reinterpret_cast<u32x4*>(PG + PLANE_H + o) = pg.m; *reinterpret_cast<u32x4*>(PG + 2 * PLANE_H + o) = pg.l;
+      }
+      if (NEED_X) {
+        const Pieces px = split3x8(st.x[2 * hf], st.x[2 * hf + 1]);
+        *reinterpret_cast<u32x4*>(PX + o) = px.h; *reinterpret_cast<u32x4*>(PX + PLANE_H + o) = px.m; *reinterpret_cast<u32x4*>(PX + 2 * PLANE_H + o) = px.l;
+      }
+    }
+  };
+  // the tiles an element needs BEFORE the products (prefetched a chunk ahead into the same registers) ...
+  struct Early { f32x4 rv[4], lp[4], sj; };
+  auto load_early = [&](int c0) {
+    Early g;
+    g.sj = PAPER ? *reinterpret_cast<const f32x4*>(sjp + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.rv[i] = (PAPER && PASS != 2) ? *reinterpret_cast<const f32x4*>(Rt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.lp[i] = *reinterpret_cast<const f32x4*>(Lpt + (int64_t)i * n + c0);
+    }
+    return g;
+  };
+  // ... and the ones only the epilogue needs (requested at the top of the chunk, in flight behind the products)
+  struct Late { f32x4 pv[4], ds[4], dt[4]; };
+  auto load_late = [&](int c0) {
+    Late g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.pv[i] = (PASS == 0 && has_prev) ? *reinterpret_cast<const f32x4*>(Pvt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.ds[i] = has_dls ? *reinterpret_cast<const f32x4*>(Dst + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.dt[i] = (PASS == 1 && has_dls) ? *reinterpret_cast<const f32x4*>(DsT + (int64_t)(c0 + i) * n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return g;
+  };
+  f32x4 acc[4];          // pass C: dX[I], tile e <-> features 16 e + r
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  Stage pre = stage_load16(0);
+  Early cur = load_early(0);
+  const int offB = r * LDH + 8 * q;
+  const int offT = (8 * q + (r >> 2)) * LDH + 4 * (r & 3);
+#pragma unroll 1
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    __syncthreads();
+    stage_store16(pre);
+    __syncthreads();
+    if (c0 + CC < n) pre = stage_load16(c0 + CC);
+    const Late late = load_late(c0);
+    // element-wise, before the products: S, R from r; Lc, La from L_pre
+    f32x4 Sv[4], Lp[4];
+    const f32x4 sj = cur.sj;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+      Lp[i] = cur.lp[i];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool diag = row == c0 + 4 * r + t;
+        Sv[i][t] = (!PAPER || PASS == 2 || diag) ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);
+        if constexpr (PASS == 2) Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(Lp[i][t] * scL, alpha);      // La
+      }
+    }
+    if (c0 + CC < n) cur = load_early(c0 + CC);
+    if constexpr (PASS == 2) __builtin_amdgcn_wave_barrier();
+    // products
+    f32x4 pa[4], pb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { pa[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    if (want_D) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const Pieces Bx = rows_B(PX, offB + 16 * t * LDH + 32 * kb);
+          pa[t] = mfma_x6(Ag[kb], Bx, pa[t]);
+          if constexpr (PASS == 1) {
+            const Pieces Bg = rows_B(PG, offB + 16 * t * LDH + 32 * kb);
+            pb[t] = mfma_x6(Ax[kb], Bg, pb[t]);
+          }
+        }
+      }
+    }
+    if constexpr (PASS == 2) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const float* lp = Ls + r * LD + 32 * kb + 8 * q;
+        const Pieces Al = split3x8(*reinterpret_cast<const f32x4*>(lp), *reinterpret_cast<const f32x4*>(lp + 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = mfma_x6(Al, cols_B(PG, offT + 32 * kb * LDH + 16 * e), acc[e]);
+      }
+    }
+    // element-wise, behind the products
+    f32x4 outv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool diag = row == c0 + 4 * r + t;
+        const float lpre = Lp[i][t];
+        const float Lc = lpre * scL;
+        const float mL = lrelu_grad(Lc, alpha);
+        float R = diag ? 1.f : 0.f;
+        if (PAPER && PASS != 2) R = R - (si[i] * Sv[i][t]) * sj[t];
+        const float R1 = R * scR;
+        const float mR = lrelu_grad(R1, alpha);
+        if constexpr (PASS == 0) {
+          const float D = pa[t][i] + late.ds[i][t];
+          const float dLc = D * mL;
+          const float lprev = late.pv[i][t];
+          const float nR = fminf(R1, 0.f), wR = mR * R;
+          sm[0] = __builtin_fmaf(dLc, lpre, sm[0]);
+          sm[1] = __builtin_fmaf(dLc, lprev, sm[1]);
+          sm[2] = __builtin_fmaf(lpre, lprev, sm[2]);
+          sm[3] = __builtin_fmaf(dLc, nR, sm[3]);
+          sm[4] = __builtin_fmaf(lpre, nR, sm[4]);
+          sm[5] = __builtin_fmaf(dLc, wR, sm[5]);
+          sm[6] = __builtin_fmaf(lpre, wR, sm[6]);
+          sm[7] = __builtin_fmaf(D, fminf(Lc, 0.f), sm[7]);
+        } else if constexpr (PASS == 1) {
+          const float Dsym = (pa[t][i] + pb[t][i]) + (late.ds[i][t] + late.dt[t][i]);
+          const float dLp2 = (z.aL * mL) * Dsym - 2.f * (z.bL * lpre);
+          const float Q = -(z.aR * (dLp2 * mR) - 2.f * (z.bR * R));      // dA_ij + dA_ji, dA = -dR
+          outv[i][t] = Q;
+          dsum[i] = __builtin_fmaf(Q, Sv[i][t] * sj[t], dsum[i]);         // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
+        } else {
+          const float D = pa[t][i] + late.ds[i][t];
+          outv[i][t] = beta * ((z.aL * mL) * D - z.bL * lpre);            // dL_prev = beta dLpre
+        }
+      }
+    }
+    if constexpr (PASS == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = outv[i];
+    }
+    if constexpr (PASS == 2) {
+      if (has_prev) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(outv[i], reinterpret_cast<f32x4*>(DPt + (int64_t)i * n + c0));
+      }
+    }
+  }
+  if constexpr (PASS == 0) {
+    // the strip's eight partial sums: lanes, then the four waves, in a fixed order
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float v = wave_sum_all(sm[k]);
+      if (lane == 0) red[wave * 8 + k] = v;
+    }
+    __syncthreads();
+    if (tid < 8) spart[(int64_t)strip * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
+  }
+  if constexpr (PASS == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = row16_sum(dsum[i]);
+      if (r == 0) a.ws_dd[c.row0 + c.i0 + 4 * q + i] = degree_grad(si[i], t);   // dd_k = -1/2 s_k^3 ds_k
+    }
+  }
+  if constexpr (PASS == 2) {
+    float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dXg[(int64_t)(4 * q + i) * a.ldx + 16 * e + r] += acc[e][i];
+    if (lane == 0) {   // the graph's dalpha / dbeta once, at its first slab
+      const bool first = c.i0 == 0;
+      a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = first ? z.dalpha : 0.f;
+      a.ws_pg[2 * (a.pg_slab_base + slab) + 1] = (first && has_prev) ? z.dbeta : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward 2 (paper mode): c_ij = -S_ij (Q_ij s_i s_j + dd_i + dd_j) / r_ij (0 where r_ij = 0 or S_ij = 0),
 // dZ[I] = rowsum(c) Z[I] - c Z, dX[I] += dZ[I] M_L^T.
 __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
@@ -1492,6 +1771,36 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   if (rc != AGCN_OK) return rc;
   return launch_cloud(cloud_bwd2_kernel, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2",
                       stream, a);
+}
+
+// SGC_LL_Reslap: the packed filter adjoint, then passes A, (B, backward 2 in paper mode,) C.  spart: 8 floats per 64-row strip.
+int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void* stream) {
+  const bool paper = a.mode == AGCN_MODE_PAPER;
+  const unsigned strips = (unsigned)(a.n_slabs / 4);
+  int rc = AGCN_OK;
+  if (WT != nullptr)
+    rc = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep", stream,
+                      a.weight, WT, a.Fout, 2);
+  else
+    WT = a.sv_WT;
+  if (rc != AGCN_OK) return rc;
+  rc = launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD, "cloud_filter_bwd",
+                    stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0, (const float*)WT, a.ws_Gp, a.dX,
+                    a.ldx, a.ws_g);
+  if (rc != AGCN_OK) return rc;
+  const dim3 grid(xcd_grid((int)strips));
+  const size_t lds = sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H;
+  rc = paper ? launch_cloud(cloud_rbwd_kernel<0, true>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdA", stream, a, spart)
+             : launch_cloud(cloud_rbwd_kernel<0, false>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdA", stream, a, spart);
+  if (rc != AGCN_OK) return rc;
+  if (paper) {
+    rc = launch_cloud(cloud_rbwd_kernel<1, true>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdB", stream, a, spart);
+    if (rc != AGCN_OK) return rc;
+  }
+  rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdC", stream, a, spart)
+             : launch_cloud(cloud_rbwd_kernel<2, false>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdC", stream, a, spart);
+  if (rc != AGCN_OK || !paper) return rc;
+  return launch_cloud(cloud_bwd2_kernel, grid, 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, a);
 }
 
 }  // namespace agcn

@@ -165,6 +165,7 @@ int launch_slab_backward(const SgcArgs& a, void* stream);
 bool cloud_path(const SgcArgs& a, bool quad);
 size_t cloud_dpart_floats(int64_t tile_elems);   // forward workspace: partial degrees
 int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t tile_elems, void* stream);
+int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void* stream);   // spart: 8 floats per 64-row strip
 int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream);   // (incl. the packed filter adjoint)
 bool cloud_param_grads_ok(const ParamGradArgs& a);
 int launch_cloud_param_partials(const ParamGradArgs& a, void* stream);   // row-chunk partials + their fixed-order sum
