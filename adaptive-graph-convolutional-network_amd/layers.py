@@ -199,8 +199,21 @@ class SGC_LL(Layer):
         if gb.plan.B != self.batch_size:
             raise ValueError("batch holds %d graphs, layer was built for batch_size=%d" % (gb.plan.B, self.batch_size))
         v = self.vars
-        Y, res_L, res_W, L_sum = SgcLLFunction.apply(_in32(X), v["weight"], v["bias"], v["M_L"], v["alpha"],
-                                                     v.get("beta"), L_prev, gb, cfg)
+        X32, W, M = _in32(X), v["weight"], v["M_L"]
+        pad = self._point_cloud_pad(gb, X32, cfg)
+        if pad:
+            # Narrow layers on point clouds (the first layers of the reference's point-cloud network, xyz -> n_filters_1:
+            # Point_AGCN.py:37-46) run on the point-cloud kernels of the 64-feature width with zero columns appended to X,
+            # zero rows / columns to M_L and zero rows to W (row f * K + k: the rows of the features behind Fin come last).
+            # Zero features change nothing: Z, the distances, X_1's columns and every gradient keep their values, and
+            # autograd's adjoint of the padding hands back exactly the un-padded blocks.
+            F = torch.nn.functional
+            X32 = F.pad(X32, (0, pad))
+            W = F.pad(W, (0, 0, 0, pad * self.K))
+            M = F.pad(M, (0, pad, 0, pad))
+            cfg = _Cfg(self.n_atom_feature + pad, self.nb_filter, self.K, self.laplacian_mode, self._variant,
+                       cfg.activation, lsum=cfg.lsum)
+        Y, res_L, res_W, L_sum = SgcLLFunction.apply(X32, W, v["bias"], M, v["alpha"], v.get("beta"), L_prev, gb, cfg)
         if self.dropout and self.training:
             # graphconv.py:121-122 / dropout.py:34-41: Dropout(p) on the activated nodes in the training phase, i.e.
             # tf.nn.dropout(x, keep_prob = 1 - p): kept entries scaled by 1 / (1 - p).  (No reference network enables it;
@@ -208,6 +221,26 @@ class SGC_LL(Layer):
             Y = torch.nn.functional.dropout(Y, p=float(self.dropout), training=True)
         nodes = RowViews(_out_as(Y, X.dtype), gb.plan, gb)
         return gb, nodes, TileViews(res_L, gb.plan), TileViews(res_W, gb.plan), TileViews(L_sum, gb.plan)
+
+    def _point_cloud_pad(self, gb, X, cfg):
+        """Feature columns to append so that the layer takes the point-cloud kernels (csrc/cloud_kernels.hip, 64 input
+        features), or 0.  Asked of the library's own dispatch logic: only batches that would otherwise fall to the general
+        slab kernels or the one-workgroup-per-graph fallback, and that have the shape the point-cloud kernels take (K = 2,
+        dense symmetric L_orig on packed rows, every graph a multiple of 64 nodes)."""
+        Fin = self.n_atom_feature
+        if self.K != 2 or Fin >= 64 or gb.l0_dense is None or not gb.l0_symmetric or gb.l0_rowptr is not None:
+            return 0
+        if self._variant == "SGC_LL" and Fin <= 4:
+            return 0                      # the streaming small-feature kernels are faster there
+        n = np.asarray(gb.plan.n_host if hasattr(gb.plan, "n_host") else gb.plan.n)
+        if n.size == 0 or np.any(n % 64 != 0):
+            return 0
+        from . import _ffi
+        from .functional import _desc, _gbatch
+        out = (_ffi.C.c_int32 * 8)()
+        desc = _desc(cfg, X.shape[1], cfg.Fout)
+        _ffi.check(_ffi.lib().agcn_sgc_ll_dispatch_info(_ffi.C.byref(desc), _ffi.C.byref(_gbatch(gb, X, None)), out, 8))
+        return 64 - Fin if out[0] in (16, 32) else 0
 
     def call(self, x):
         _, nodes, res_L, res_W, _ = self._apply(x, None)

@@ -1057,7 +1057,7 @@ def _sym_prev(rs, n, scale=0.05):
     return ((A + A.T) * np.float32(0.5)).astype(np.float32)
 
 
-@pytest.mark.parametrize("case", ["first_layer_of_a_block", "inner_layer"])
+@pytest.mark.parametrize("case", ["first_layer_of_a_block", "inner_layer", "xyz_first_layer", "narrow_sgc_ll"])
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
 def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     """SGC_LL_Reslap at point-cloud sizes -- the layer every convolution of the reference's point-cloud network is
@@ -1065,18 +1065,22 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     clouds that are multiples of 64 points (one of them n = 1024 in the first case), 64 -> 128, with and without the
     previous layer's Laplacian and the gradient arriving on L_sum.  Every output (Y, res_W, res_L, L_sum) and every
     gradient (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) against the float64 oracle."""
-    Fin, Fout, K = 64, 128, 2
+    # xyz_first_layer: the network's FIRST layer (3 -> 64, Point_AGCN.py:37-46); narrow_sgc_ll: SGC_LL at a width between the
+    # small-feature kernels and 64 -- both run on the point-cloud kernels with zero feature columns appended (layers.py)
+    Fin, Fout, K = {"xyz_first_layer": (3, 64, 2), "narrow_sgc_ll": (24, 64, 2)}.get(case, (64, 128, 2))
+    variant = orc.SGC_LL if case == "narrow_sgc_ll" else orc.SGC_LL_RESLAP
     inner = case == "inner_layer"
-    sizes = [256, 128, 320] if inner else [1024, 64]
-    rs = np.random.RandomState(9100 + len(sizes))
+    sizes = [256, 128, 320] if inner else ([1024, 64] if Fin == 64 else [512, 192])
+    rs = np.random.RandomState(9100 + len(sizes) + Fin)
     Xs, Ls, Gs = [], [], []
     for n in sizes:
         X, L, G = _cloud_case(rs, n, Fin, Fout, thresh=0.6)
         Xs.append(X); Ls.append(L); Gs.append(G)
     Xs[1][5] = Xs[1][4]
-    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL_RESLAP)
+    p = orc.init_params(rs, Fin, Fout, K, variant)
     p["alpha"] = np.array([0.8], dtype=np.float32)
-    p["beta"] = np.array([1.3], dtype=np.float32)
+    if variant == orc.SGC_LL_RESLAP:
+        p["beta"] = np.array([1.3], dtype=np.float32)
     p["bias"] = (0.1 * rs.randn(Fout)).astype(np.float32)
     Lp = [_sym_prev(rs, n) for n in sizes] if inner else None
     dLs = [(0.01 * rs.randn(n, n)).astype(np.float32) for n in sizes] if inner else None
@@ -1087,21 +1091,30 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
         l0_host[int(tile_off[b]):int(tile_off[b]) + L.size] = L.reshape(-1)
     gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0_host).to(DEV),
                         l0_ld=0, l0_symmetric=True)
-    layer = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, len(sizes), K, mode, p, DEV)
+    layer = make_layer(amd, variant, Fout, Fin, len(sizes), K, mode, p, DEV)
     Xt = gb.X.clone().requires_grad_(True)
     x = {"node_features": Xt, "graph_batch": gb, "res_lap": []}
     Lpt = None
     if Lp is not None:
         Lpt = torch.from_numpy(pack_tiles_np(Lp, plan)).to(DEV).requires_grad_(True)
         x["res_lap"] = amd.TileViews(Lpt, plan)
-    nodes, res_L, res_W, L_sum = layer(x)
+    if variant == orc.SGC_LL_RESLAP:
+        nodes, res_L, res_W, L_sum = layer(x)
+    else:
+        nodes, res_L, res_W = layer(x)
+        L_sum = None
     loss = (nodes.data * torch.from_numpy(np.concatenate(Gs)).to(DEV)).sum()
     if dLs is not None:
         loss = loss + (L_sum.data * torch.from_numpy(pack_tiles_np(dLs, plan)).to(DEV)).sum()
     loss.backward()
-    info = amd._ffi.dispatch_info(layer, gb)
-    assert (info[0] & 64) != 0, "point-cloud kernels expected (forward path bits %d)" % info[0]
-    caches, tot = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL_RESLAP, Gs, Lp, dLs)
+    if Fin == 64:
+        info = amd._ffi.dispatch_info(layer, gb)
+        assert (info[0] & 64) != 0, "point-cloud kernels expected (forward path bits %d)" % info[0]
+    else:
+        from agcn_amd.functional import _Cfg
+        cfg = _Cfg(Fin, Fout, K, layer.laplacian_mode, layer._variant, "relu", lsum=variant == orc.SGC_LL_RESLAP)
+        assert layer._point_cloud_pad(gb, gb.X, cfg) == 64 - Fin, "the layer must widen this batch to the point-cloud kernels"
+    caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs)
     k = float(np.sqrt(max(sizes) / 64.0))
     Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
     for b, n in enumerate(sizes):
@@ -1111,13 +1124,14 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
         assert_close(w, c["S"], FEATURE_RTOL, f"res_W[{b}]", atol_ulps=0)
         assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
         assert_close(to_np(res_L[b]), c["R2"], FEATURE_RTOL, f"res_L[{b}]", atol_ulps=FEATURE_ULPS * k)
-        assert_close(to_np(L_sum[b]), c["La"], FEATURE_RTOL, f"L_sum[{b}]", atol_ulps=FEATURE_ULPS * k)
+        if L_sum is not None:
+            assert_close(to_np(L_sum[b]), c["La"], FEATURE_RTOL, f"L_sum[{b}]", atol_ulps=FEATURE_ULPS * k)
         assert_close(dX[r0:r0 + n], tot["dX"][b], GRAD_RTOL, f"dX[{b}]", atol_ulps=GRAD_ULPS * k)
         r0 += n
     assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight", atol_ulps=GRAD_ULPS * k)
     assert_close(to_np(layer.vars["bias"].grad), tot["dbias"], GRAD_RTOL, "dbias", atol_ulps=GRAD_ULPS * k)
     scale = float(np.abs(tot["dweight"]).max())
-    tot32 = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL_RESLAP, Gs, Lp, dLs, dtype=np.float32)[1]
+    tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32)[1]
     from helpers import _scalar_close
     _scalar_close(to_np(layer.vars["alpha"].grad), tot["dalpha"], tot32["dalpha"], scale, "dalpha")
     if mode == orc.PAPER:
