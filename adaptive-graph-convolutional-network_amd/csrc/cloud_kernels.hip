@@ -1181,24 +1181,7 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
     }
     if (c0 + CC < n) cur = load_early(c0 + CC);
     if constexpr (PASS == 2) __builtin_amdgcn_wave_barrier();
-    // products
-    f32x4 pa[4], pb[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { pa[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    if (want_D) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const Pieces Bx = rows_B(PX, offB + 16 * t * LDH + 32 * kb);
-          pa[t] = mfma_x6(Ag[kb], Bx, pa[t]);
-          if constexpr (PASS == 1) {
-            const Pieces Bg = rows_B(PG, offB + 16 * t * LDH + 32 * kb);
-            pb[t] = mfma_x6(Ax[kb], Bg, pb[t]);
-          }
-        }
-      }
-    }
+    // L product of pass C first (its A operand, the patch, is the only consumer of La)
     if constexpr (PASS == 2) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -1208,13 +1191,21 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
         for (int e = 0; e < 4; ++e) acc[e] = mfma_x6(Al, cols_B(PG, offT + 32 * kb * LDH + 16 * e), acc[e]);
       }
     }
-    // element-wise, behind the products
+    // tile by tile: the product(s), then the element-wise part behind them
     f32x4 outv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = c.i0 + 4 * q + i;
+    for (int t = 0; t < 4; ++t) {
+      f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (want_D) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+        for (int kb = 0; kb < 2; ++kb) {
+          pa = mfma_x6(Ag[kb], rows_B(PX, offB + 16 * t * LDH + 32 * kb), pa);
+          if constexpr (PASS == 1) pb = mfma_x6(Ax[kb], rows_B(PG, offB + 16 * t * LDH + 32 * kb), pb);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = c.i0 + 4 * q + i;
         const bool diag = row == c0 + 4 * r + t;
         const float lpre = Lp[i][t];
         const float Lc = lpre * scL;
@@ -1224,7 +1215,7 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
         const float R1 = R * scR;
         const float mR = lrelu_grad(R1, alpha);
         if constexpr (PASS == 0) {
-          const float D = pa[t][i] + late.ds[i][t];
+          const float D = pa[i] + late.ds[i][t];
           const float dLc = D * mL;
           const float lprev = late.pv[i][t];
           const float nR = fminf(R1, 0.f), wR = mR * R;
@@ -1237,13 +1228,13 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
           sm[6] = __builtin_fmaf(lpre, wR, sm[6]);
           sm[7] = __builtin_fmaf(D, fminf(Lc, 0.f), sm[7]);
         } else if constexpr (PASS == 1) {
-          const float Dsym = (pa[t][i] + pb[t][i]) + (late.ds[i][t] + late.dt[t][i]);
+          const float Dsym = (pa[i] + pb[i]) + (late.ds[i][t] + late.dt[t][i]);
           const float dLp2 = (z.aL * mL) * Dsym - 2.f * (z.bL * lpre);
           const float Q = -(z.aR * (dLp2 * mR) - 2.f * (z.bR * R));      // dA_ij + dA_ji, dA = -dR
           outv[i][t] = Q;
           dsum[i] = __builtin_fmaf(Q, Sv[i][t] * sj[t], dsum[i]);         // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
         } else {
-          const float D = pa[t][i] + late.ds[i][t];
+          const float D = pa[i] + late.ds[i][t];
           outv[i][t] = beta * ((z.aL * mL) * D - z.bL * lpre);            // dL_prev = beta dLpre
         }
       }
@@ -1708,11 +1699,11 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
   float* lpart = rpart + (size_t)(tile_elems / 4096 + 16);
   if (a.variant == AGCN_SGC_LL_RESLAP) {
     if (paper) {
-      rc = launch_cloud(cloud_rnorm_kernel, sgrid, 256, 0, PK_CLOUD_LAP, "cloud_rnorm", stream, a, rpart);
+      rc = launch_cloud(cloud_rnorm_kernel, sgrid, 256, 0, PK_CLOUD_RNORM, "cloud_rnorm", stream, a, rpart);
       if (rc != AGCN_OK) return rc;
     }
-    rc = paper ? launch_cloud(cloud_rlap1_kernel<true>, sgrid, 256, 0, PK_CLOUD_LAP, "cloud_rlap1", stream, a, (const float*)rpart, lpart)
-               : launch_cloud(cloud_rlap1_kernel<false>, sgrid, 256, 0, PK_CLOUD_LAP, "cloud_rlap1", stream, a, (const float*)rpart, lpart);
+    rc = paper ? launch_cloud(cloud_rlap1_kernel<true>, sgrid, 256, 0, PK_CLOUD_RLAP1, "cloud_rlap1", stream, a, (const float*)rpart, lpart)
+               : launch_cloud(cloud_rlap1_kernel<false>, sgrid, 256, 0, PK_CLOUD_RLAP1, "cloud_rlap1", stream, a, (const float*)rpart, lpart);
     if (rc != AGCN_OK) return rc;
     return paper ? launch_cloud(cloud_lap_kernel<true, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)rpart, (const float*)lpart)
                  : launch_cloud(cloud_lap_kernel<false, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)rpart, (const float*)lpart);
@@ -1790,15 +1781,15 @@ int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void
   if (rc != AGCN_OK) return rc;
   const dim3 grid(xcd_grid((int)strips));
   const size_t lds = sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H;
-  rc = paper ? launch_cloud(cloud_rbwd_kernel<0, true>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdA", stream, a, spart)
-             : launch_cloud(cloud_rbwd_kernel<0, false>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdA", stream, a, spart);
+  rc = paper ? launch_cloud(cloud_rbwd_kernel<0, true>, grid, 256, lds, PK_CLOUD_RBWD_A, "cloud_rbwdA", stream, a, spart)
+             : launch_cloud(cloud_rbwd_kernel<0, false>, grid, 256, lds, PK_CLOUD_RBWD_A, "cloud_rbwdA", stream, a, spart);
   if (rc != AGCN_OK) return rc;
   if (paper) {
-    rc = launch_cloud(cloud_rbwd_kernel<1, true>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdB", stream, a, spart);
+    rc = launch_cloud(cloud_rbwd_kernel<1, true>, grid, 256, lds, PK_CLOUD_RBWD_B, "cloud_rbwdB", stream, a, spart);
     if (rc != AGCN_OK) return rc;
   }
-  rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdC", stream, a, spart)
-             : launch_cloud(cloud_rbwd_kernel<2, false>, grid, 256, lds, PK_CLOUD_BWD1, "cloud_rbwdC", stream, a, spart);
+  rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, a, spart)
+             : launch_cloud(cloud_rbwd_kernel<2, false>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, a, spart);
   if (rc != AGCN_OK || !paper) return rc;
   return launch_cloud(cloud_bwd2_kernel, grid, 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, a);
 }

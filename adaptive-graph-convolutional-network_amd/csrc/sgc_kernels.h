@@ -123,7 +123,7 @@ struct ParamGradArgs {
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
        PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD,
        PK_PARAM_ONEPASS, PK_SPEC_FWD, PK_SPEC_BWD, PK_CLOUD_SIM, PK_CLOUD_DEG, PK_CLOUD_LAP, PK_CLOUD_BWD1,
-       PK_CLOUD_BWD2, PK_COUNT };
+       PK_CLOUD_BWD2, PK_CLOUD_RNORM, PK_CLOUD_RLAP1, PK_CLOUD_RBWD_A, PK_CLOUD_RBWD_B, PK_CLOUD_RBWD_C, PK_COUNT };
 // Raises a kernel's dynamic-LDS cap (hipFuncAttributeMaxDynamicSharedMemorySize) once per kernel and size: the
 // driver call is skipped when the cap already covers `bytes` (it costs several microseconds per launch otherwise).
 // Tracked per (device, kernel).  Returns hipSuccess (0) or the HIP error code.

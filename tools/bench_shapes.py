@@ -6,6 +6,7 @@
   ref-feed                : 75->64 at B=256 in the reference's padded feed layout (max_atom 132, dense Laplacians)
   tox21-2048              : 75->64 at B=2048 (config[3] on one GPU)
   modelnet-3-64 / 64-128  : B graphs of n=1024 points, dense original Laplacian (config[2])
+  modelnet-reslap         : the same clouds through SGC_LL_Reslap 64 -> 128 with L_prev (the reference's point-cloud layer)
   epoch                   : ingest (graph store -> packed batch -> upload) + layer over an HIV-shaped dataset
   stack                   : 4 x SGC_LL -> DenseMol 64->256 -> GraphGatherMol(tanh), autograd, eager launches
 
@@ -175,6 +176,28 @@ def main():
             continue
         gb, n = modelnet_batch(amd, args.modelnet_batch, 1024, Fin, dev)
         run_layer(name, gb, n, 0, Fin, Fout, True)
+
+    if want("modelnet-reslap"):
+        # the layer the reference's point-cloud network is made of (Point_AGCN.py:37-71: SGC_LL_Reslap throughout), hidden width,
+        # with the previous layer's (symmetric) Laplacian coming in and a gradient arriving on L_sum
+        gb, n = modelnet_batch(amd, args.modelnet_batch, 1024, 64, dev)
+        layer = amd.SGC_LL_Reslap(128, 64, len(n), K=K, laplacian_mode=args.mode, device=dev)
+        layer.load_vars(synth.glorot_params(np.random.RandomState(123), 64, 128, K, reslap=True))
+        g = torch.Generator(device="cpu").manual_seed(5)
+        Lp = (0.05 * torch.randn(len(n), 1024, 1024, generator=g))
+        Lp = (0.5 * (Lp + Lp.transpose(1, 2))).reshape(-1).to(dev)
+        dY = torch.from_numpy(np.random.RandomState(7).randn(gb.plan.rows, 128).astype(np.float32)).to(dev)
+        st = amd.SgcLLStep(layer, gb, L_prev=Lp, dY=dY)
+        if args.eager:
+            t = timed(st.step, args.steps, args.warmup, dev)
+        else:
+            st.capture()
+            t = timed(st.replay, args.steps, args.warmup, dev)
+        out = {"workload": "modelnet-reslap 64->128 with L_prev", "mode": args.mode, "graphs": int(len(n)),
+               "N2": int(np.sum(np.asarray(n, np.int64) ** 2)), "us_per_step": round(t * 1e6, 2), "graphs_per_s": round(len(n) / t, 1)}
+        if args.prof:
+            out["kernel_us"] = kernel_profile(amd, st.step, 20, dev)
+        print(json.dumps(out), flush=True)
 
     if want("epoch"):
         # ingest + layer over a dataset: HIV-shaped sizes (mu = ln 23, clip [4, 222]); every batch is gathered
