@@ -32,7 +32,7 @@ class GraphBatch(C.Structure):
     _fields_ = [("plan_host", C.c_void_p), ("plan_dev", C.c_void_p), ("X", C.c_void_p),
                 ("L0_dense", C.c_void_p), ("L0_ld", C.c_int32), ("L0_symmetric", C.c_int32),
                 ("L0_rowptr", C.c_void_p), ("L0_col", C.c_void_p), ("L0_val", C.c_void_p),
-                ("L_prev", C.c_void_p)]
+                ("L_prev", C.c_void_p), ("L_prev_symmetric", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Params(C.Structure):

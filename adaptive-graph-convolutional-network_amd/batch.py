@@ -132,8 +132,11 @@ class TileViews(Sequence):
     """Lazy list of per-graph [n_b, n_b] views into a packed tile tensor (what the reference
     returns as a Python list of B tensors: graphconv.py:252)."""
 
-    def __init__(self, data, plan):
+    def __init__(self, data, plan, symmetric=False):
         self.data, self.plan = data, plan
+        # True: every tile equals its transpose (set by the layers for their own Laplacian outputs when their inputs were
+        # symmetric; a caller handing in res_lap tiles of its own may vouch for them) -- AgcnGraphBatch.L_prev_symmetric
+        self.symmetric = bool(symmetric)
 
     def __len__(self):
         return self.plan.B

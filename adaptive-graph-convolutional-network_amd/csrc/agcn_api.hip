@@ -487,7 +487,8 @@ static bool cloud_shape(const AgcnLayerDesc* d) {
 static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
   if (d->variant == AGCN_SGC_LL) return use_slabs(d, g, pi);
   return agcn_get_slab_mode() != 0 && d->variant == AGCN_SGC_LL_RESLAP && d->K == 2 && pi.rows == pi.N1 &&
-         g->L0_dense != nullptr && g->L0_rowptr == nullptr && g->L0_symmetric == 1;
+         g->L0_dense != nullptr && g->L0_rowptr == nullptr && g->L0_symmetric == 1 &&
+         (g->L_prev == nullptr || g->L_prev_symmetric == 1);
 }
 
 static size_t global_scratch_floats(const AgcnLayerDesc* d, const PlanView& host, bool bwd, Carver* c,

@@ -14,7 +14,7 @@ from .functional import _Cfg, _desc, _gbatch, _ptr
 
 
 class SgcLLStep(object):
-    def __init__(self, layer, batch, X=None, L_prev=None, dY=None, dL_sum=None):
+    def __init__(self, layer, batch, X=None, L_prev=None, dY=None, dL_sum=None, L_prev_symmetric=False):
         lib = _ffi.lib()
         self.lib, self.layer, self.batch = lib, layer, batch
         plan = batch.plan
@@ -86,7 +86,7 @@ class SgcLLStep(object):
             o += s
         self.reserve = take(self.rbytes, dtype=torch.uint8)
         self.ws = take(max(self.wf, self.wb), dtype=torch.uint8)
-        self.gb = _gbatch(batch, self.X, self.L_prev)
+        self.gb = _gbatch(batch, self.X, self.L_prev, L_prev_symmetric)
         self.pr = _ffi.Params(v["weight"].data_ptr(), v["bias"].data_ptr(), v["M_L"].data_ptr(),
                               v["alpha"].data_ptr(), _ptr(v.get("beta")))
         self.out = _ffi.Outputs(self.Y.data_ptr(), self.res_L.data_ptr(), self.res_W.data_ptr(), _ptr(self.L_sum))

@@ -121,9 +121,11 @@ class UnpackRowsFunction(torch.autograd.Function):
 
 
 class _Cfg(object):
-    __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation", "lsum")
+    __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation", "lsum", "prev_sym")
 
-    def __init__(self, Fin, Fout, K, mode, variant, activation, lsum=True):
+    def __init__(self, Fin, Fout, K, mode, variant, activation, lsum=True, prev_sym=False):
+        # prev_sym: the caller vouches that L_prev is symmetric (AgcnGraphBatch.L_prev_symmetric)
+        self.prev_sym = bool(prev_sym)
         self.Fin, self.Fout, self.K = int(Fin), int(Fout), int(K)
         self.mode, self.variant, self.activation = mode, variant, activation
         # lsum=False: an SGC_LL call whose combined Laplacian nobody reads (the reference's SGC_LL returns three
@@ -136,11 +138,12 @@ def _desc(cfg, ldx, ldy):
                           _ffi.ACT[cfg.activation], int(ldx), int(ldy))
 
 
-def _gbatch(batch, X, L_prev):
+def _gbatch(batch, X, L_prev, prev_symmetric=False):
     p = batch.plan
     return _ffi.GraphBatch(p.host_ptr, p.dev_ptr, X.data_ptr(), _ptr(batch.l0_dense), batch.l0_ld,
                            1 if batch.l0_symmetric else 0,
-                           _ptr(batch.l0_rowptr), _ptr(batch.l0_col), _ptr(batch.l0_val), _ptr(L_prev))
+                           _ptr(batch.l0_rowptr), _ptr(batch.l0_col), _ptr(batch.l0_val), _ptr(L_prev),
+                           1 if (prev_symmetric and L_prev is not None) else 0, 0)
 
 
 def _sizes(plan, cfg, ldx, ldy):
@@ -217,7 +220,7 @@ class SgcLLFunction(torch.autograd.Function):
         # reserve is first used -- include/agcn.h)
         reserve = torch.zeros(rbytes, dtype=torch.uint8, device=dev)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-        gb = _gbatch(batch, X, L_prev if reslap else None)
+        gb = _gbatch(batch, X, L_prev if reslap else None, cfg.prev_sym)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
         out = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(out),
@@ -255,7 +258,7 @@ class SgcLLFunction(torch.autograd.Function):
         dbeta = torch.empty_like(beta) if ctx.has_prev else None
         dLp = torch.empty_like(L_prev) if ctx.has_prev else None
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-        gb = _gbatch(batch, X, L_prev)
+        gb = _gbatch(batch, X, L_prev, ctx.cfg.prev_sym)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
         fw = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         gr = _ffi.Grads(dX.data_ptr(), dweight.data_ptr(), dbias.data_ptr(), _ptr(dM), dalpha.data_ptr(),

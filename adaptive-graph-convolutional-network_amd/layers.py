@@ -191,11 +191,12 @@ class SGC_LL(Layer):
             self.vars[k] = t.to(dev).requires_grad_(bool(self.trainable))
         self._built = True
 
-    def _apply(self, x, L_prev):
+    def _apply(self, x, L_prev, prev_sym=False):
         gb, X = _resolve_batch(x)
         self.build(X.device)
         cfg = _Cfg(self.n_atom_feature, self.nb_filter, self.K, self.laplacian_mode, self._variant,
-                   "relu" if self.activation == "relu" else "linear", lsum=self._variant == "SGC_LL_Reslap")
+                   "relu" if self.activation == "relu" else "linear", lsum=self._variant == "SGC_LL_Reslap",
+                   prev_sym=prev_sym and L_prev is not None)
         if gb.plan.B != self.batch_size:
             raise ValueError("batch holds %d graphs, layer was built for batch_size=%d" % (gb.plan.B, self.batch_size))
         v = self.vars
@@ -212,7 +213,7 @@ class SGC_LL(Layer):
             W = F.pad(W, (0, 0, 0, pad * self.K))
             M = F.pad(M, (0, pad, 0, pad))
             cfg = _Cfg(self.n_atom_feature + pad, self.nb_filter, self.K, self.laplacian_mode, self._variant,
-                       cfg.activation, lsum=cfg.lsum)
+                       cfg.activation, lsum=cfg.lsum, prev_sym=cfg.prev_sym)
         Y, res_L, res_W, L_sum = SgcLLFunction.apply(X32, W, v["bias"], M, v["alpha"], v.get("beta"), L_prev, gb, cfg)
         if self.dropout and self.training:
             # graphconv.py:121-122 / dropout.py:34-41: Dropout(p) on the activated nodes in the training phase, i.e.
@@ -220,7 +221,10 @@ class SGC_LL(Layer):
             # an element-wise torch op behind the layer, differentiable, not part of the fused kernels.)
             Y = torch.nn.functional.dropout(Y, p=float(self.dropout), training=True)
         nodes = RowViews(_out_as(Y, X.dtype), gb.plan, gb)
-        return gb, nodes, TileViews(res_L, gb.plan), TileViews(res_W, gb.plan), TileViews(L_sum, gb.plan)
+        # res_W and res_L are symmetric by construction; the summed Laplacian when L_orig and L_prev are
+        sum_sym = bool(gb.l0_symmetric) and (L_prev is None or cfg.prev_sym)
+        return (gb, nodes, TileViews(res_L, gb.plan, True), TileViews(res_W, gb.plan, True),
+                TileViews(L_sum, gb.plan, sum_sym))
 
     def _point_cloud_pad(self, gb, X, cfg):
         """Feature columns to append so that the layer takes the point-cloud kernels (csrc/cloud_kernels.hip, 64 input
@@ -239,6 +243,9 @@ class SGC_LL(Layer):
         from .functional import _desc, _gbatch
         out = (_ffi.C.c_int32 * 8)()
         desc = _desc(cfg, X.shape[1], cfg.Fout)
+        # (host logic only; whether a previous Laplacian comes in changes nothing unless it is not known to be symmetric)
+        if self._variant == "SGC_LL_Reslap" and getattr(self, "_prev_unsym", False):
+            return 0
         _ffi.check(_ffi.lib().agcn_sgc_ll_dispatch_info(_ffi.C.byref(desc), _ffi.C.byref(_gbatch(gb, X, None)), out, 8))
         return 64 - Fin if out[0] in (16, 32) else 0
 
@@ -256,9 +263,13 @@ class SGC_LL_Reslap(SGC_LL):
         gb, X = _resolve_batch(x)
         self.early_laps = x["res_lap"]
         L_prev = _pack_tiles(self.early_laps, gb.plan, X.device)
+        # symmetric previous Laplacians (this package's own outputs carry the flag; a caller may vouch with
+        # x["res_lap_symmetric"] = True): the point-cloud kernels need to know, everything else ignores it
+        prev_sym = bool(x.get("res_lap_symmetric", getattr(self.early_laps, "symmetric", False)))
+        self._prev_unsym = L_prev is not None and not prev_sym
         x2 = dict(x)
         x2["graph_batch"], x2["node_features"] = gb, X
-        _, nodes, res_L, res_W, L_sum = self._apply(x2, L_prev)
+        _, nodes, res_L, res_W, L_sum = self._apply(x2, L_prev, prev_sym)
         return nodes, res_L, res_W, L_sum
 
 

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AGCN_VERSION 101 /* 0.1.1: reserve header carries the cooperative kernels' status word */
+#define AGCN_VERSION 102 /* 0.1.2: AgcnGraphBatch.L_prev_symmetric */
 
 enum {
   AGCN_OK = 0,
@@ -161,6 +161,12 @@ typedef struct AgcnGraphBatch {
   const int32_t* L0_col;
   const float* L0_val;
   const float* L_prev;       /* Reslap only: res_lap tiles (graphconv_reslap.py:68,188-190) or NULL */
+  int32_t L_prev_symmetric;  /* 1 = caller guarantees L_prev == L_prev^T for every graph (true for the L_sum of a previous
+                              * layer whose own inputs were symmetric); with L0_symmetric it makes the summed Laplacian
+                              * symmetric, which the point-cloud kernels (graphs of hundreds of nodes and more) rely on --
+                              * without it such batches take the general per-graph path.  dL_sum / dL_prev are never
+                              * assumed symmetric */
+  int32_t reserved0;
 } AgcnGraphBatch;
 
 typedef struct AgcnParams { /* graphconv.py:75-83, graphconv_reslap.py:30-43 */

@@ -1057,7 +1057,7 @@ def _sym_prev(rs, n, scale=0.05):
     return ((A + A.T) * np.float32(0.5)).astype(np.float32)
 
 
-@pytest.mark.parametrize("case", ["first_layer_of_a_block", "inner_layer", "xyz_first_layer", "narrow_sgc_ll"])
+@pytest.mark.parametrize("case", ["first_layer_of_a_block", "inner_layer", "xyz_first_layer", "narrow_sgc_ll", "unvouched_prev"])
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
 def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     """SGC_LL_Reslap at point-cloud sizes -- the layer every convolution of the reference's point-cloud network is
@@ -1069,7 +1069,9 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     # small-feature kernels and 64 -- both run on the point-cloud kernels with zero feature columns appended (layers.py)
     Fin, Fout, K = {"xyz_first_layer": (3, 64, 2), "narrow_sgc_ll": (24, 64, 2)}.get(case, (64, 128, 2))
     variant = orc.SGC_LL if case == "narrow_sgc_ll" else orc.SGC_LL_RESLAP
-    inner = case == "inner_layer"
+    # unvouched_prev: an ASYMMETRIC previous Laplacian nobody vouches for -- the layer must leave the point-cloud kernels
+    # (which take La^T g_1 as La g_1) for the general per-graph path and still be right
+    inner = case in ("inner_layer", "unvouched_prev")
     sizes = [256, 128, 320] if inner else ([1024, 64] if Fin == 64 else [512, 192])
     rs = np.random.RandomState(9100 + len(sizes) + Fin)
     Xs, Ls, Gs = [], [], []
@@ -1083,6 +1085,8 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
         p["beta"] = np.array([1.3], dtype=np.float32)
     p["bias"] = (0.1 * rs.randn(Fout)).astype(np.float32)
     Lp = [_sym_prev(rs, n) for n in sizes] if inner else None
+    if case == "unvouched_prev":
+        Lp = [(0.05 * rs.randn(n, n)).astype(np.float32) for n in sizes]
     dLs = [(0.01 * rs.randn(n, n)).astype(np.float32) for n in sizes] if inner else None
     plan = amd.Plan(sizes, 0, DEV)
     tile_off = plan.tile_off
@@ -1097,7 +1101,7 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     Lpt = None
     if Lp is not None:
         Lpt = torch.from_numpy(pack_tiles_np(Lp, plan)).to(DEV).requires_grad_(True)
-        x["res_lap"] = amd.TileViews(Lpt, plan)
+        x["res_lap"] = amd.TileViews(Lpt, plan, symmetric=case != "unvouched_prev")    # (the caller vouches: _sym_prev)
     if variant == orc.SGC_LL_RESLAP:
         nodes, res_L, res_W, L_sum = layer(x)
     else:
@@ -1107,7 +1111,9 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     if dLs is not None:
         loss = loss + (L_sum.data * torch.from_numpy(pack_tiles_np(dLs, plan)).to(DEV)).sum()
     loss.backward()
-    if Fin == 64:
+    if case == "unvouched_prev":
+        pass
+    elif Fin == 64:
         info = amd._ffi.dispatch_info(layer, gb)
         assert (info[0] & 64) != 0, "point-cloud kernels expected (forward path bits %d)" % info[0]
     else:

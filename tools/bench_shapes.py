@@ -187,7 +187,7 @@ def main():
         Lp = (0.05 * torch.randn(len(n), 1024, 1024, generator=g))
         Lp = (0.5 * (Lp + Lp.transpose(1, 2))).reshape(-1).to(dev)
         dY = torch.from_numpy(np.random.RandomState(7).randn(gb.plan.rows, 128).astype(np.float32)).to(dev)
-        st = amd.SgcLLStep(layer, gb, L_prev=Lp, dY=dY)
+        st = amd.SgcLLStep(layer, gb, L_prev=Lp, dY=dY, L_prev_symmetric=True)
         if args.eager:
             t = timed(st.step, args.steps, args.warmup, dev)
         else:
