@@ -173,10 +173,13 @@ class ResidualGraphMolResLap(ResidualGraphMol):
     def _reset(self):
         super(ResidualGraphMolResLap, self)._reset()
         self.stack_laplacians = []
+        self._last_lap = None
 
     def _run_conv(self, layer, topo, idx):
         x = self._input(topo)
-        x["res_lap"] = self.stack_laplacians[-self.batch_size:]
+        # == self.stack_laplacians[-self.batch_size:] (every saved entry is one layer's batch_size Laplacians), but as the
+        # packed TileViews the layer returned: no per-graph copies, and the symmetry flag travels with it
+        x["res_lap"] = self._last_lap if self._last_lap is not None else []
         self.output, res_L, res_W, L = layer(x)
         self.res_L_set.extend(res_L)
         self.res_W_set.extend(res_W)
@@ -184,6 +187,7 @@ class ResidualGraphMolResLap(ResidualGraphMol):
             self.block_outputs.append(self.output)
         if layer.save_lap:                  # a list whose length is the batch size (tf_graphs.py:193-194)
             self.stack_laplacians.extend(L)
+            self._last_lap = L
 
     def get_laplacian(self):
         return self.stack_laplacians
@@ -237,16 +241,18 @@ class DenseConnectedGraphResLap(DenseConnectedGraph):
     def _reset(self):
         super(DenseConnectedGraphResLap, self)._reset()
         self.stack_laplacians = []
+        self._last_lap = None
 
     def _run_conv(self, layer, topo, idx):
         x = self._input(topo)
-        x["res_lap"] = self.stack_laplacians[-self.batch_size:]
+        x["res_lap"] = self._last_lap if self._last_lap is not None else []   # (see ResidualGraphMolResLap._run_conv)
         self.output, res_L, res_W, L = layer(x)
         self.res_L_set.extend(res_L)
         self.res_W_set.extend(res_W)
         self._save_output(layer)
         if layer.save_lap:
             self.stack_laplacians.extend(L)
+            self._last_lap = L
 
     def get_laplacian(self):
         return self.stack_laplacians

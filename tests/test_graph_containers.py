@@ -176,6 +176,68 @@ def test_reslap_container_reference_feed_golden(amd):
         assert_close(to_np(model.get_laplacian()[b]), g["l1_L_sum"][b, :n, :n], FEATURE_RTOL, "saved L[%d]" % b)
 
 
+def test_point_cloud_reslap_chain_through_the_container(amd):
+    """The start of the reference's point-cloud network (Point_AGCN.py:37-60: SGC_LL_Reslap(n_filters_1, xyz, save_lap) ->
+    SGC_LL_Reslap(n_filters_2, n_filters_1)) on two clouds with a dense symmetric L_orig, through ResidualGraphMolResLap:
+    the container hands the first layer's L_sum on as the packed, symmetric-flagged TileViews, so BOTH layers (the first
+    through zero-padded feature columns) run on the point-cloud kernels -- checked with the library's profiler -- and the
+    chain's output and the gradient reaching the first layer's parameters equal the float64 oracle's."""
+    from helpers import GRAD_RTOL, GRAD_ULPS, oracle_run
+    sizes, K = [256, 128], 2
+    rs = np.random.RandomState(4242)
+    Xs, Ls = [], []
+    for n in sizes:
+        pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        A = (d < 0.5 * d.mean()).astype(np.float64)
+        np.fill_diagonal(A, 0)
+        _, _, _, L = orc.graph_laplacian([list(np.nonzero(A[i])[0]) for i in range(n)])
+        Xs.append(pts); Ls.append(L.astype(np.float32))
+    p1 = orc.init_params(rs, 3, 64, K, orc.SGC_LL_RESLAP)
+    p2 = orc.init_params(rs, 64, 32, K, orc.SGC_LL_RESLAP)
+    for p in (p1, p2):
+        p["alpha"] = np.array([0.9], np.float32)
+        p["beta"] = np.array([1.1], np.float32)
+    plan = amd.Plan(sizes, 0, DEV)
+    l0 = np.zeros(int(plan.tile_off[-1]), np.float32)
+    for b, L in enumerate(Ls):
+        l0[int(plan.tile_off[b]):int(plan.tile_off[b]) + L.size] = L.reshape(-1)
+    gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0).to(DEV), l0_ld=0,
+                        l0_symmetric=True)
+    model = amd.ResidualGraphMolResLap(3, len(sizes), max(sizes))
+    l1 = make_layer(amd, orc.SGC_LL_RESLAP, 64, 3, len(sizes), K, orc.PAPER, p1, DEV)
+    l2 = make_layer(amd, orc.SGC_LL_RESLAP, 32, 64, len(sizes), K, orc.PAPER, p2, DEV)
+    l1.save_lap = True
+    model.add(l1)
+    model.add(l2)
+    lib = amd._ffi.lib()
+    lib.agcn_profile_enable(1)
+    try:
+        amd._ffi.profile_collect()
+        out = model(gb)
+        G = [rs.randn(n, 32).astype(np.float32) for n in sizes]
+        (out.data * torch.from_numpy(np.concatenate(G)).to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        prof = amd._ffi.profile_collect()
+    finally:
+        lib.agcn_profile_enable(0)
+    assert prof["cloud_rlap1_kernel"][1] == 2 and prof["cloud_rbwd_kernel<C>"][1] == 2, prof
+    assert prof["sgc_forward_kernel"][1] == 0 and prof["sgc_backward_kernel"][1] == 0
+    # oracle: layer 1, then layer 2 with layer 1's summed Laplacian; the gradient of layer 2's L_prev arrives on layer 1's L_sum
+    c1, _ = oracle_run(Xs, Ls, p1, K, orc.PAPER, orc.SGC_LL_RESLAP, [np.zeros((n, 64), np.float32) for n in sizes])
+    La1 = [c["La"].astype(np.float32) for c in c1]
+    Y1 = [c["Y"].astype(np.float32) for c in c1]
+    c2, t2 = oracle_run(Y1, Ls, p2, K, orc.PAPER, orc.SGC_LL_RESLAP, G, La1)
+    _, t1 = oracle_run(Xs, Ls, p1, K, orc.PAPER, orc.SGC_LL_RESLAP, [g.astype(np.float32) for g in t2["dX"]], None,
+                       [g.astype(np.float32) for g in t2["dLp"]])
+    r0 = 0
+    for b, n in enumerate(sizes):
+        assert_close(to_np(out.data)[r0:r0 + n], c2[b]["Y"], 4 * FEATURE_RTOL, "chain Y[%d]" % b, atol_ulps=4 * FEATURE_ULPS)
+        r0 += n
+    assert_close(to_np(l1.vars["weight"].grad), t1["dweight"], 4 * GRAD_RTOL, "layer 1 dweight", atol_ulps=4 * GRAD_ULPS)
+    assert_close(to_np(l1.vars["M_L"].grad), t1["dM_L"], 4 * GRAD_RTOL, "layer 1 dM_L", atol_ulps=4 * GRAD_ULPS)
+
+
 def test_segmentation_graph_backbone_and_two_heads(amd):
     """SegmentationGraph (seg_graph.py:9-125) with Seg_AGCN's layer list shape (Seg_AGCN.py:75-121: SGC_LL, SGC_LL,
     GraphPoolMol backbone; DenseMol -> GraphGatherMol -> FCL classifier head; SGC_LL, SGC_LL -> Merge segmentation head):
