@@ -13,14 +13,14 @@ bash tools/traffic.sh > $O/traffic_paper.txt 2>&1
 AGCN_BENCH_MODE=reference bash tools/traffic.sh > $O/traffic_reference.txt 2>&1
 cp gpurun_out/traffic/traffic_*.json $O/
 bash tools/mfma.sh > $O/mfma.txt 2>&1; cp gpurun_out/mfma/mfma.json $O/${T}_mfma_counters.json
-bash tools/prof_shapes.sh ${T}_modelnet --only modelnet-3-64,modelnet-64-128 --modelnet-batch 32 > $O/prof_modelnet.txt 2>&1
+bash tools/prof_shapes.sh ${T}_modelnet --only modelnet-3-64,modelnet-64-128,modelnet-reslap --modelnet-batch 32 > $O/prof_modelnet.txt 2>&1
 cp gpurun_out/prof_shapes/${T}_modelnet/${T}_modelnet_counters.json gpurun_out/prof_shapes/${T}_modelnet/${T}_modelnet_kernel_stats.csv $O/
-bash tools/sq_shapes.sh ${T}_modelnet --only modelnet-64-128 --modelnet-batch 32 > $O/sq_modelnet.txt 2>&1
+bash tools/sq_shapes.sh ${T}_modelnet --only modelnet-64-128,modelnet-reslap --modelnet-batch 32 > $O/sq_modelnet.txt 2>&1
 cp gpurun_out/sq_shapes/${T}_modelnet/${T}_modelnet_sq.json $O/
 for N in 2 4 8; do for s in 0 1; do timeout 100 python bench.py --shard-of $N --shard $s --no-cpu-baseline --no-secondary --skip-other-mode >> $O/${T}_shard_emulation.jsonl 2>/dev/null; done; done
 for b in 512 1024 2048 4096; do timeout 200 python bench.py --batch $b --no-cpu-baseline --no-secondary --skip-other-mode >> $O/${T}_batch_sweep.jsonl 2>/dev/null; done
 AGCN_BENCH_SELFTEST=1 timeout 300 python bench.py --gpus 2 --steps 100 --no-cpu-baseline --skip-other-mode > $O/${T}_bench_2ranks_one_gpu_gloo.json 2>/dev/null
 timeout 900 python tools/bench_shapes.py --prof --epoch-graphs 41127 --modelnet-batch 32 > $O/${T}_shapes_paper.jsonl 2>/dev/null
-timeout 300 python tools/bench_shapes.py --mode reference --only tox21-l1,tox21-l3,reslap,stack,modelnet-3-64,modelnet-64-128 --modelnet-batch 32 > $O/${T}_shapes_reference.jsonl 2>/dev/null
+timeout 300 python tools/bench_shapes.py --mode reference --only tox21-l1,tox21-l3,reslap,stack,modelnet-3-64,modelnet-64-128,modelnet-reslap --modelnet-batch 32 > $O/${T}_shapes_reference.jsonl 2>/dev/null
 AGCN_CLOUD=0 timeout 200 python tools/bench_shapes.py --only modelnet-64-128 --modelnet-batch 32 --prof > $O/${T}_modelnet_general_slab_kernels.jsonl 2>/dev/null
 ls -la $O
