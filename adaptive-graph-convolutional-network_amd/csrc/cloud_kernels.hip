@@ -624,10 +624,10 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward 1: dX[I] += L[I, :] g_1 (L symmetric);  paper: P = dL + dL^T = [g_1 | X_0][I] . [X_0 | g_1][J]^T,
-// Q = -lrelu'(R) P -> workspace, ds_i = sum_j Q_ij S_ij s_j -> dd_i, dalpha = 1/2 sum P_ij min(R_ij, 0).
-template <bool PAPER>
-__global__ __launch_bounds__(256, 2) void cloud_bwd1_kernel(SgcArgs a) {
+// backward 1, reference mode (R = I: no gradient reaches the similarity): dX[I] += L[I, :] g_1 with L = I + L_orig (symmetric).
+// (Paper mode: cloud_bwd1_paper_kernel below.  Its predecessor on the f32 MFMA instruction -- P = [g_1 | X_0][I] . [X_0 | g_1][J]^T
+// as two chains of 16 v_mfma_f32_16x16x4_f32 per tile, 6144 matrix cycles per chunk and wave -- ran at 143-154 us.)
+__global__ __launch_bounds__(256, 2) void cloud_bwd1_ref_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -637,109 +637,39 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_kernel(SgcArgs a) {
   const WaveCtx c = wave_ctx(a, slab);
   const int n = c.n;
   float* Gs = smem;                                  // [64][LD]  g_1 rows of the chunk
-  float* Xs = smem + CC * LD;                        // [64][LD]  X_0 rows of the chunk (paper)
-  float* Ls = smem + (PAPER ? 2 : 1) * CC * LD + wave * (16 * LD);   // [16][LD] this wave's strip of L
-  const float alpha = a.alpha[0];
-  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  float* Ls = smem + CC * LD + wave * (16 * LD);     // [16][LD] this wave's strip of L
   const float* g1 = a.ws_g + (int64_t)c.row0 * FIN;   // adjoint of X_1 (K = 2: plane 0)
   int l0ld;
   const float* L0d = dense_l0(a, c, &l0ld);
-  const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
-  float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
   const float* L0t = L0d + (int64_t)(c.i0 + 4 * q) * l0ld + 4 * r;
-  const float* sjp = a.sv_s + c.row0 + 4 * r;
-  float si[4];
-  f32x4 gIf[4], xIf[4];   // A fragments of the wave's own rows: lane (r, q) holds [row r][16 kb + 4q .. + 3]
-#pragma unroll
-  for (int i = 0; i < 4; ++i) si[i] = PAPER ? a.sv_s[c.row0 + c.i0 + 4 * q + i] : 0.f;
-  if (PAPER) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      gIf[kb] = *reinterpret_cast<const f32x4*>(g1 + (int64_t)(c.i0 + r) * FIN + 16 * kb + 4 * q);
-      xIf[kb] = *reinterpret_cast<const f32x4*>(Xg + (int64_t)(c.i0 + r) * a.ldx + 16 * kb + 4 * q);
-    }
-  }
-  struct Tiles { f32x4 rv[4], l0[4], sj; };
+  struct Tiles { f32x4 l0[4]; };
   auto load_tiles = [&](int c0) {
     Tiles g;
-    g.sj = PAPER ? *reinterpret_cast<const f32x4*>(sjp + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      g.rv[i] = PAPER ? *reinterpret_cast<const f32x4*>(Rt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
-    }
+    for (int i = 0; i < 4; ++i) g.l0[i] = *reinterpret_cast<const f32x4*>(L0t + (int64_t)i * l0ld + c0);
     return g;
   };
-
   f32x4 acc[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float ds[4] = {0.f, 0.f, 0.f, 0.f};
-  float dalpha_part = 0.f;
-  StageRegs preG = stage_load(g1, FIN, 0), preX;
-  if (PAPER) preX = stage_load(Xg, a.ldx, 0);
+  StageRegs preG = stage_load(g1, FIN, 0);
   Tiles cur = load_tiles(0);
 #pragma unroll 1
   for (int c0 = 0; c0 < n; c0 += CC) {
     __syncthreads();
     stage_store(Gs, preG);
-    if (PAPER) stage_store(Xs, preX);
     __syncthreads();
-    if (c0 + CC < n) {
-      preG = stage_load(g1, FIN, c0 + CC);
-      if (PAPER) preX = stage_load(Xg, a.ldx, c0 + CC);
-    }
-    f32x4 S[4], R[4];     // [i][t]: S_ij s_j and R_ij
+    if (c0 + CC < n) preG = stage_load(g1, FIN, c0 + CC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bool diag = row == c0 + 4 * r + t;
-        const float Sv = (!PAPER || diag) ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);   // cloud_sim's instruction
-        R[i][t] = diag ? 1.f : 0.f;
-        if (PAPER) R[i][t] = R[i][t] - (si[i] * Sv) * cur.sj[t];                                   // cloud_lap's instruction
-        S[i][t] = Sv * cur.sj[t];
-        Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(R[i][t], alpha) + cur.l0[i][t];
-      }
+      for (int t = 0; t < 4; ++t)
+        Ls[(4 * q + i) * LD + 16 * t + r] = ((row == c0 + 4 * r + t) ? 1.f : 0.f) + cur.l0[i][t];   // lrelu(I) = I
     }
-    // the next chunk's tiles: requested once this chunk's are consumed (into the same registers), in flight behind the products
     if (c0 + CC < n) cur = load_tiles(c0 + CC);
     __builtin_amdgcn_wave_barrier();
-    if (PAPER) {
-      // P[I, tile] = g_1[I] . X_0[tile]^T + X_0[I] . g_1[tile]^T (two independent accumulation chains per tile), then the
-      // tile's element-wise epilogue.  (Software-pipelined orders -- the next tile's MFMAs issued before this tile's
-      // epilogue, fragments read a tile ahead, sched_group_barrier interleaving -- were measured: no gain at 2 waves per
-      // SIMD, and 280-300 VGPRs without the launch bound; profiles/EXPERIMENTS.md.)
-      f32x4 Qv[4];         // [i][t]
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          const f32x4 bx = *reinterpret_cast<const f32x4*>(Xs + (16 * t + r) * LD + 16 * kb + 4 * q);
-          const f32x4 bg = *reinterpret_cast<const f32x4*>(Gs + (16 * t + r) * LD + 16 * kb + 4 * q);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            pa = mfma4(gIf[kb][j], bx[j], pa);
-            pb = mfma4(xIf[kb][j], bg[j], pb);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float P = pa[i] + pb[i];
-          dalpha_part = __builtin_fmaf(P, fminf(R[i][t], 0.f), dalpha_part);
-          const float Q = -(P * lrelu_grad(R[i][t], alpha));     // dA_ij + dA_ji, dA = -dR
-          Qv[i][t] = Q;
-          ds[i] = __builtin_fmaf(Q, S[i][t], ds[i]);              // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
-        }
-      }
-      strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = Qv[i];
-    } else {
-      strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
-    }
+    strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
   }
   // dX rows of the strip (g_0 already there from the packed filter adjoint)
   float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
@@ -750,16 +680,8 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_kernel(SgcArgs a) {
     v.x += acc[0][i]; v.y += acc[1][i]; v.z += acc[2][i]; v.w += acc[3][i];
     *p = v;
   }
-  if (PAPER) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float t = row16_sum(ds[i]);
-      if (r == 0) a.ws_dd[c.row0 + c.i0 + 4 * q + i] = degree_grad(si[i], t);   // dd_k = -1/2 s_k^3 ds_k
-    }
-  }
-  const float da = wave_sum_all(dalpha_part);
   if (lane == 0) {
-    a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = 0.5f * da;
+    a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = 0.f;
     a.ws_pg[2 * (a.pg_slab_base + slab) + 1] = 0.f;
   }
 }
@@ -777,8 +699,8 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_kernel(SgcArgs a) {
 //                                                            transposed (ds_read_b64_tr_b16: k = the image row; tools/ubench/tr_read_check.hip)
 // The chunk's rows are staged as six bf16 images [64][72] (h / m / l of X_0 and g_1; image row 16 (rho % 4) + rho / 4 as
 // everywhere in this file): 54 KB + the four L patches = 72 KB of LDS, two workgroups per CU.  B pieces are requested one
-// 6-MFMA block ahead.  History: f32 MFMA kernel (cloud_bwd1_kernel<true>, kept for AGCN_CLOUD_BWD1_BF16X6=0): 143-154 us;
-// P alone on bf16 x 6 with 8-wave workgroups (110 KB: ONE workgroup per CU, nothing to run behind its barriers): 211 us.
+// 6-MFMA block ahead.  History: on the f32 MFMA instruction 143-154 us; P alone on bf16 x 6 with 8-wave workgroups (110 KB:
+// ONE workgroup per CU, nothing to run behind its barriers) 211 us; this kernel 121 us.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1752,13 +1674,10 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
     if (rc0 != AGCN_OK) return rc0;
   }
   if (!paper)
-    return launch_cloud(cloud_bwd1_kernel<false>, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
+    return launch_cloud(cloud_bwd1_ref_kernel, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
                         "cloud_bwd1", stream, a);
-  static const int bf_env = [] { const char* e = std::getenv("AGCN_CLOUD_BWD1_BF16X6"); return e ? std::atoi(e) : 1; }();
-  int rc = bf_env ? launch_cloud(cloud_bwd1_paper_kernel, dim3(xcd_grid((int)strips)), 256,
-                                 sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H, PK_CLOUD_BWD1, "cloud_bwd1", stream, a)
-                  : launch_cloud(cloud_bwd1_kernel<true>, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD),
-                                 PK_CLOUD_BWD1, "cloud_bwd1", stream, a);
+  int rc = launch_cloud(cloud_bwd1_paper_kernel, dim3(xcd_grid((int)strips)), 256,
+                        sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H, PK_CLOUD_BWD1, "cloud_bwd1", stream, a);
   if (rc != AGCN_OK) return rc;
   return launch_cloud(cloud_bwd2_kernel, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2",
                       stream, a);
