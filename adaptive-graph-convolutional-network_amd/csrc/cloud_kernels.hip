@@ -1569,7 +1569,8 @@ bool cloud_path(const SgcArgs& a, bool quad) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // SGC_LL_Reslap: the previous layer's Laplacian must be symmetric like L_orig (it is, whenever it is a Laplacian this
   // path or the reference produced from symmetric inputs): La is then symmetric and La^T g_1 is taken as La g_1
-  const bool res_ok = a.variant != AGCN_SGC_LL_RESLAP || (a.sv_Lpre != nullptr && al16(a.sv_Lpre) && al16(a.L_prev));
+  const bool res_ok = a.variant != AGCN_SGC_LL_RESLAP ||
+                      (a.sv_Lpre != nullptr && a.L_sum != nullptr && al16(a.sv_Lpre) && al16(a.L_prev) && al16(a.L_sum));
   return cloud_env() && quad && a.Fin == FIN && a.K == 2 && (a.variant == AGCN_SGC_LL || a.variant == AGCN_SGC_LL_RESLAP) && res_ok &&
          a.L0_dense != nullptr && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 15) == 0 && al16(a.X) && al16(a.weight) &&
          al16(a.bias) && al16(a.M_L) && (a.n_slabs & 3) == 0;
