@@ -943,7 +943,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     if (rc != AGCN_OK) return rc;
     // 2. graph-local adjoints
     if (slabs) {
-      rc = launch_slab_backward(a, hip_stream);
+      rc = launch_slab_backward(a, hip_stream, host.info.max_n);
       if (rc != AGCN_OK) return rc;
     } else {
     if (w.n_glb > 0) {

@@ -160,7 +160,7 @@ int launch_fused_backward(const SgcArgs& a, int32_t first, int32_t count, size_t
 // slab-parallel SGC_LL (K = 2, packed rows, symmetric CSR L_orig)
 bool slab_path_fits(int32_t Fin);
 int launch_slab_forward(const SgcArgs& a, void* stream);
-int launch_slab_backward(const SgcArgs& a, void* stream);
+int launch_slab_backward(const SgcArgs& a, void* stream, int32_t max_n = 0);   // max_n: largest graph (0 = unknown)
 // point-cloud kernels (cloud_kernels.hip): slab batches with Fin = 64, dense L_orig, every graph a multiple of 64 nodes
 bool cloud_path(const SgcArgs& a, bool quad);
 size_t cloud_dpart_floats(int64_t tile_elems);   // forward workspace: partial degrees

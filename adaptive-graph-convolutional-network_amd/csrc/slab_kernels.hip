@@ -1277,6 +1277,239 @@ __global__ __launch_bounds__(256) AGCN_SMALL_WAVES_ATTR void slab_bwd2_small_ker
 }
 
 // ------------------------------------------------------------------------------------------------
+// The two backward kernels above evaluate every ORDERED pair (i, j) -- twice, once each.  Everything they accumulate is
+// symmetric in the pair (S, R, dA_ij + dA_ji, c_ij) or comes in mirror-image terms (L_ij g_j into row i, L_ij g_i into row j:
+// L is symmetric), so for batches of clouds that are multiples of 64 points each UNORDERED pair is evaluated once:
+// a task = the 64 x 64 block (I, J >= I) of a graph, one wave, lane = column j, rows i one after the other with the row's
+// data read from an LDS copy at a uniform address; a block is cut into two tasks of 32 rows (piece h) so that the waves finish
+// evenly.  Column-side sums stay in the lane's registers for the whole task; row-side sums (over the lanes) go through an LDS
+// patch [4 rows][4 values][64 lanes], added up by the wave every four rows.  Both leave as partials P[2 blk + h][node][4] --
+// node i of block I gets its entries of blk >= I from the row side of the task (I, blk) that holds its row (slot h = 0), and
+// both entries of blk < I from the column side of the tasks (blk, I, h), each written exactly once -- and a small kernel adds a
+// node's entries in slot order and finishes (dX, dd, dalpha | dZ, dX += dZ M_L^T).
+// History (32 clouds x 1024 points, 3 -> 64; ordered-pair kernels: 62 + 48 us): 64-row tasks, 8-row batches, 146 / 90 VGPRs,
+// 12 KB of LDS per wave: 51 + 50 us + 2 x 6 (reduce) -- 2.1 waves per SIMD on average, 44 % of the wave cycles waiting.
+//   PASS 1: values {L g_j[0..2], (dA_ij + dA_ji) S_ij s_j}      PASS 2: values {c_ij z_j[0..2], c_ij}
+template <int SF, int PASS>
+__global__ __launch_bounds__(256) void small_sym_kernel(SgcArgs a, float* P, float* pgt, int t_quota, int nquads, int qstride) {
+  extern __shared__ __attribute__((aligned(16))) float sym_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* rowbuf = sym_lds + wave * 1536;      // [32 rows][16]: z[0..3], g[4..7], x[8..11], s, dd
+  float* patch = rowbuf + 512;                // [4 rows][4 values][64 lanes]
+  constexpr int Fin = SF;
+  const float alpha = a.alpha[0];
+  const int64_t total = (int64_t)a.B * t_quota * 2;
+  const int per_q = (int)((total + 7) >> 3);
+  const int xcd = (int)(blockIdx.x & 7);
+  const int wx = 4 * (int)(gridDim.x >> 3);
+#pragma unroll 1
+  for (int lid0 = 4 * (int)(blockIdx.x >> 3) + wave; lid0 < 4 * nquads; lid0 += wx) {
+    const int lid = 4 * (int)(((int64_t)(lid0 >> 2) * qstride) % nquads) + (lid0 & 3);
+    const int64_t id = (int64_t)xcd * per_q + lid;
+    if (lid >= per_q || id >= total) continue;
+    const int b = __builtin_amdgcn_readfirstlane((int)(id / (2 * t_quota)));
+    const int rem = __builtin_amdgcn_readfirstlane((int)(id - (int64_t)b * (2 * t_quota)));
+    const int t = rem >> 1, h = rem & 1;
+    const int n = __builtin_amdgcn_readfirstlane(a.n[b]), row0 = __builtin_amdgcn_readfirstlane(a.row_off[b]);
+    const int ncb = n >> 6;
+    if (t >= ((ncb * (ncb + 1)) >> 1)) continue;
+    int I = 0, J;
+    {
+      int left = t, len = ncb;
+      while (left >= len) { left -= len; --len; ++I; }
+      J = I + left;
+    }
+    const bool diag = I == J;
+    const int64_t toff_v = a.tile_off[b];
+    const int64_t toff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(toff_v >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)toff_v));
+    const float* Xg = a.X + (int64_t)row0 * a.ldx;
+    const float* Zg = a.sv_Z + (int64_t)row0 * Fin;
+    const float* g1 = a.ws_g + (int64_t)row0 * Fin;
+    // this lane's column (block J) ...
+    float zj[SF], gj[SF], xj[SF];
+    const int jc = 64 * J + lane;
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+      zj[f] = Zg[(int64_t)jc * Fin + f];
+      gj[f] = g1[(int64_t)jc * Fin + f];
+      xj[f] = Xg[(int64_t)jc * a.ldx + f];
+    }
+    const float sj = a.sv_s[row0 + jc];
+    const float ddj = PASS == 2 ? a.ws_dd[row0 + jc] : 0.f;
+    // ... and the task's 32 rows of block I, one per lane of the lower half, into the LDS copy
+    const int i0 = 64 * I + 32 * h;
+    if (lane < 32) {
+      const int ir = i0 + lane;
+      float* rb = rowbuf + lane * 16;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        rb[f] = f < SF ? Zg[(int64_t)ir * Fin + min(f, SF - 1)] : 0.f;
+        rb[4 + f] = f < SF ? g1[(int64_t)ir * Fin + min(f, SF - 1)] : 0.f;
+        rb[8 + f] = f < SF ? Xg[(int64_t)ir * a.ldx + min(f, SF - 1)] : 0.f;
+      }
+      rb[12] = a.sv_s[row0 + ir];
+      rb[13] = PASS == 2 ? a.ws_dd[row0 + ir] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* L0d = a.L0_ld > 0 ? a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld : a.L0_dense + toff;
+    const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
+    const float* L0p = L0d + (int64_t)i0 * l0ld + jc;
+    float col[4] = {0.f, 0.f, 0.f, 0.f};
+    float dalpha_part = 0.f;
+    float* Pg = P + (toff >> 3);                  // [2 n / 64][n][4] per graph
+    float l0v[4];
+    if (PASS == 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) l0v[u] = L0p[(int64_t)u * l0ld];
+    }
+#pragma unroll 1
+    for (int g8 = 0; g8 < 32; g8 += 4) {
+      float l0c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) l0c[u] = PASS == 1 ? l0v[u] : 0.f;
+      if (PASS == 1 && g8 + 4 < 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) l0v[u] = L0p[(int64_t)(g8 + 4 + u) * l0ld];   // the next four rows' L_orig in flight
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ii = g8 + u;
+        const float* rb = rowbuf + ii * 16;       // (uniform address: one LDS broadcast per read)
+        const f32x4 zr = *reinterpret_cast<const f32x4*>(rb);
+        const f32x4 gr = *reinterpret_cast<const f32x4*>(rb + 4);
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(rb + 8);
+        const f32x4 sr = *reinterpret_cast<const f32x4*>(rb + 12);
+        float zi[SF], gi[SF], xi[SF];
+#pragma unroll
+        for (int f = 0; f < SF; ++f) { zi[f] = zr[f]; gi[f] = gr[f]; xi[f] = xr[f]; }
+        const float si = sr.x, ddi = sr.y;
+        const bool same = diag && 32 * h + ii == lane;
+        const float rij = small_dist<SF>(zi, zj);
+        const SmallPair p = small_pair<SF>(zi, gi, xi, zj, gj, xj, si, sj, alpha, same);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (PASS == 1) {
+          const float L = lrelu(p.R, alpha) + l0c[u];
+          const float w = (p.dA + p.dAt) * p.S;
+#pragma unroll
+          for (int f = 0; f < SF; ++f) v[f] = L * gj[f];
+          v[3] = w * sj;
+          // dalpha = sum over ORDERED pairs of dL_ij min(R_ij, 0): the mirrored pair's term rides along off the diagonal block
+          const float dLt = small_dot<SF>(xi, gj);
+          dalpha_part = __builtin_fmaf(diag ? p.dL : p.dL + dLt, fminf(p.R, 0.f), dalpha_part);
+          if (!diag) {
+#pragma unroll
+            for (int f = 0; f < SF; ++f) col[f] = __builtin_fmaf(L, gi[f], col[f]);
+            col[3] = __builtin_fmaf(w, si, col[3]);
+          }
+        } else {
+          const float dr_ij = -p.S * __builtin_fmaf(p.dA * si, sj, ddj);
+          const float dr_ji = -p.S * __builtin_fmaf(p.dAt * sj, si, ddi);
+          // r == 0 (coincident points): the term is defined as 0; S == 0 (underflow): dr = 0, never inf * 0
+          const bool ok = !same && rij > 0.f && p.S != 0.f;
+          const float cij = ok ? (dr_ij + dr_ji) * __builtin_amdgcn_rcpf(rij) : 0.f;
+#pragma unroll
+          for (int f = 0; f < SF; ++f) v[f] = cij * zj[f];
+          v[3] = cij;
+          if (!diag) {
+#pragma unroll
+            for (int f = 0; f < SF; ++f) col[f] = __builtin_fmaf(cij, zi[f], col[f]);
+            col[3] += cij;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) patch[(u * 4 + k) * 64 + lane] = v[k];
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        // 16 sums of 64: lane l adds quarter l & 3 of sum q = l >> 2 (= row q / 4, value q % 4), then its three neighbours'
+        const float* pp = patch + (lane >> 2) * 64 + 16 * (lane & 3);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(pp), x1 = *reinterpret_cast<const f32x4*>(pp + 4);
+        const f32x4 x2 = *reinterpret_cast<const f32x4*>(pp + 8), x3 = *reinterpret_cast<const f32x4*>(pp + 12);
+        float tsum = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
+                     (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
+        tsum += __shfl_xor(tsum, 1, 64);
+        tsum += __shfl_xor(tsum, 2, 64);
+        if ((lane & 3) == 0) Pg[((int64_t)(2 * J) * n + i0 + g8) * 4 + (lane >> 2)] = tsum;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!diag) *reinterpret_cast<f32x4*>(Pg + ((int64_t)(2 * I + h) * n + jc) * 4) = (f32x4){col[0], col[1], col[2], col[3]};
+    if (PASS == 1) {
+      const float da = wave_allsum(dalpha_part);
+      if (lane == 0) pgt[((int64_t)b * t_quota + t) * 2 + h] = da;
+    }
+  }
+}
+
+// one 256-thread workgroup per 64-row block: thread = (node, quarter of the slots); the four quarters are added in order
+template <int SF, int PASS>
+__global__ __launch_bounds__(256) void small_sym_reduce_kernel(SgcArgs a, const float* P, const float* pgt, int t_quota) {
+  __shared__ f32x4 part[4][64];
+  const int slab0 = 4 * (int)blockIdx.x;
+  const int b = a.slab_graph[slab0], r0 = a.slab_row[slab0];
+  const int n = a.n[b], row0 = a.row_off[b];
+  const int64_t toff = a.tile_off[b];
+  const int ncb = n >> 6, I = r0 >> 6;
+  const int node = (int)threadIdx.x & 63, qtr = (int)threadIdx.x >> 6;
+  const int i = r0 + node;
+  constexpr int Fin = SF;
+  const float* Pg = P + (toff >> 3) + (int64_t)i * 4;
+  f32x4 tot = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // slots 2 blk + h: both pieces of the blocks in front of the node's own (column side), slot 2 blk alone from there on
+  const int per = (2 * ncb + 3) >> 2, s_begin = qtr * per, s_end = min(2 * ncb, s_begin + per);
+  for (int k0 = s_begin; k0 < s_end; k0 += 8) {     // eight loads in flight, added in slot order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int sl = k0 + u;
+      const bool live = sl < s_end && ((sl >> 1) < I || (sl & 1) == 0);
+      v[u] = live ? *reinterpret_cast<const f32x4*>(Pg + (int64_t)sl * n * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tot += v[u];
+  }
+  part[qtr][node] = tot;
+  __syncthreads();
+  if (qtr != 0) return;
+  tot = (part[0][node] + part[1][node]) + (part[2][node] + part[3][node]);
+  if (PASS == 1) {
+    float* dXg = a.dX + (int64_t)(row0 + i) * a.ldx;
+#pragma unroll
+    for (int f = 0; f < SF; ++f) dXg[f] += tot[f];                  // (g_0 is there already)
+    a.ws_dd[row0 + i] = degree_grad(a.sv_s[row0 + i], tot[3]);
+    if (threadIdx.x < 4) {     // dalpha of the block row: its tasks (I, J >= I), in J order, at the block's first slab
+      float da = 0.f;
+      if (threadIdx.x == 0) {
+        const int off = I * ncb - ((I * (I - 1)) >> 1);
+        for (int J = I; J < ncb; ++J) {
+          const float* q = pgt + ((int64_t)b * t_quota + off + (J - I)) * 2;
+          da += q[0] + q[1];
+        }
+      }
+      a.ws_pg[2 * (a.pg_slab_base + slab0 + (int)threadIdx.x) + 0] = da;
+      a.ws_pg[2 * (a.pg_slab_base + slab0 + (int)threadIdx.x) + 1] = 0.f;
+    }
+  } else {
+    const float* Zg = a.sv_Z + (int64_t)(row0 + i) * Fin;
+    float dz[SF];
+#pragma unroll
+    for (int f = 0; f < SF; ++f) dz[f] = tot[3] * Zg[f] - tot[f];   // dZ_i = rowsum(c)_i Z_i - (c Z)_i
+    float* dZg = a.ws_dZ + (int64_t)(row0 + i) * Fin;
+    float* dXg = a.dX + (int64_t)(row0 + i) * a.ldx;
+#pragma unroll
+    for (int g = 0; g < SF; ++g) {
+      float dx = 0.f;
+#pragma unroll
+      for (int f = 0; f < SF; ++f) dx += dz[f] * a.M_L[g * Fin + f];   // (dZ M_L^T)[g] = sum_f dZ[f] M_L[g][f]
+      dZg[g] = dz[g];
+      dXg[g] += dx;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 namespace {
 size_t lds_sim(int Fin) { return sizeof(float) * ((size_t)Fin * SH + (size_t)Fin * CH1P); }
 size_t lds_lap(int Fin) {
@@ -1348,10 +1581,56 @@ int launch_slab_forward(const SgcArgs& a, void* stream) {
 }
 
 
-int launch_slab_backward(const SgcArgs& a, void* stream) {
+template <int SF>
+static int launch_small_sym(const SgcArgs& a, int32_t max_n, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ncb = std::max(1, (int)max_n / 64), t_quota = ncb * (ncb + 1) / 2;
+  const int64_t tasks = (int64_t)a.B * t_quota * 2;
+  const int per_q = (int)((tasks + 7) / 8), nquads = (per_q + 3) / 4;
+  int qstride = 1;
+  for (int c = std::max(1, nquads / 3) | 1; c < nquads; c += 2) {
+    int x = c, y = nquads;
+    while (y) { const int tq = x % y; x = y; y = tq; }
+    if (x == 1) { qstride = c; break; }
+  }
+  const unsigned wgs = (unsigned)(std::max<int64_t>(8, std::min<int64_t>(16 * 256, (tasks + 3) / 4 + 7)) / 8 * 8);
+  const unsigned strips = (unsigned)(a.n_slabs / 4);
+  const size_t lds = sizeof(float) * 4 * 1536;
+  float* P = a.ws_dA;      // (the streaming path keeps nothing n x n: the Q tile's space holds the partials, n^2 / 8 per graph)
+  float* pgt = a.ws_dAt;   // one dalpha partial per task
+  auto launch = [&](auto kern, dim3 grid, int threads, size_t l, int id, const char* what, auto... args) -> int {
+    prof_begin(id, stream);
+    hipLaunchKernelGGL(kern, grid, dim3(threads), l, s, args...);
+    prof_end(stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s launch: %s", what, hipGetErrorString(e));
+    return AGCN_OK;
+  };
+  int rc = launch(small_sym_kernel<SF, 1>, dim3(wgs), 256, lds, PK_SLAB_BWD1, "small_sym<1>", a, P, pgt, t_quota, nquads, qstride);
+  if (rc != AGCN_OK) return rc;
+  rc = launch(small_sym_reduce_kernel<SF, 1>, dim3(strips), 256, (size_t)0, PK_SLAB_BWD1, "small_sym_reduce<1>", a, (const float*)P,
+              (const float*)pgt, t_quota);
+  if (rc != AGCN_OK) return rc;
+  rc = launch(small_sym_kernel<SF, 2>, dim3(wgs), 256, lds, PK_SLAB_BWD2, "small_sym<2>", a, P, pgt, t_quota, nquads, qstride);
+  if (rc != AGCN_OK) return rc;
+  return launch(small_sym_reduce_kernel<SF, 2>, dim3(strips), 256, (size_t)0, PK_SLAB_BWD2, "small_sym_reduce<2>", a, (const float*)P,
+                (const float*)pgt, t_quota);
+}
+
+int launch_slab_backward(const SgcArgs& a, void* stream, int32_t max_n) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
   if (slab_small_features(a)) {   // point-cloud first layer: streaming variants (no LDS images, no chunk barriers)
     if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "slab path: a gradient of L_sum is not supported (SGC_LL only)");
+    // clouds of multiples of 64 points, paper mode: each unordered pair once (small_sym_kernel)
+    static const int sym_env = [] { const char* e = std::getenv("AGCN_SMALL_SYM"); return e ? std::atoi(e) : 1; }();
+    if (sym_env && paper && a.slab_quad != 0 && max_n >= 64 && a.pg_slab_base == 0 && a.ws_dA && a.ws_dAt && (a.n_slabs & 3) == 0) {
+      switch (a.Fin) {
+        case 1: return launch_small_sym<1>(a, max_n, stream);
+        case 2: return launch_small_sym<2>(a, max_n, stream);
+        case 3: return launch_small_sym<3>(a, max_n, stream);
+        default: return launch_small_sym<4>(a, max_n, stream);
+      }
+    }
     int rc;
     switch (a.Fin) {
       case 1: rc = launch_slab(slab_bwd1_small_kernel<1>, a, 0, PK_SLAB_BWD1, "slab_bwd1_small", stream); break;
