@@ -1373,54 +1373,91 @@ __global__ __launch_bounds__(256) void small_sym_kernel(SgcArgs a, float* P, flo
 #pragma unroll
         for (int u = 0; u < 4; ++u) l0v[u] = L0p[(int64_t)(g8 + 4 + u) * l0ld];   // the next four rows' L_orig in flight
       }
+      // the four rows' data first (uniform addresses: one LDS broadcast per read) -- all reads of the batch in front of its patch
+      // writes, so that the four rows' chains (distance -> sqrt -> exp -> ...) can be interleaved instead of run one after
+      // the other behind an LDS round trip each
+      f32x4 zr4[4], gr4[4], xr4[4], sr4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int ii = g8 + u;
-        const float* rb = rowbuf + ii * 16;       // (uniform address: one LDS broadcast per read)
-        const f32x4 zr = *reinterpret_cast<const f32x4*>(rb);
-        const f32x4 gr = *reinterpret_cast<const f32x4*>(rb + 4);
-        const f32x4 xr = *reinterpret_cast<const f32x4*>(rb + 8);
-        const f32x4 sr = *reinterpret_cast<const f32x4*>(rb + 12);
-        float zi[SF], gi[SF], xi[SF];
+        const float* rb = rowbuf + (g8 + u) * 16;
+        zr4[u] = *reinterpret_cast<const f32x4*>(rb);
+        gr4[u] = *reinterpret_cast<const f32x4*>(rb + 4);
+        xr4[u] = *reinterpret_cast<const f32x4*>(rb + 8);
+        sr4[u] = *reinterpret_cast<const f32x4*>(rb + 12);
+      }
+      // stage by stage over the four rows (four independent chains side by side; same expressions, same order per pair as
+      // small_pair / the ordered-pair kernels)
+      float vv[4][4];
+      float r_[4], S_[4], R_[4], dL_[4], dLt_[4], nlg_[4];
+      bool same_[4];
 #pragma unroll
-        for (int f = 0; f < SF; ++f) { zi[f] = zr[f]; gi[f] = gr[f]; xi[f] = xr[f]; }
-        const float si = sr.x, ddi = sr.y;
-        const bool same = diag && 32 * h + ii == lane;
-        const float rij = small_dist<SF>(zi, zj);
-        const SmallPair p = small_pair<SF>(zi, gi, xi, zj, gj, xj, si, sj, alpha, same);
+      for (int u = 0; u < 4; ++u) {
+        same_[u] = diag && 32 * h + g8 + u == lane;
+        float acc = 0.f;
+#pragma unroll
+        for (int f = 0; f < SF; ++f) { const float d = zr4[u][f] - zj[f]; acc = __builtin_fmaf(d, d, acc); }
+        r_[u] = acc;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r_[u] = __builtin_amdgcn_sqrtf(r_[u]);
+      // (exp and, below, rcp are taken unconditionally and selected afterwards: a branch around them would cut the batch into
+      //  basic blocks and the four chains would run one after the other again)
+      float e_[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e_[u] = __builtin_amdgcn_exp2f(r_[u] * -1.44269504088896341f);   // small_sim's instruction
+#pragma unroll
+      for (int u = 0; u < 4; ++u) S_[u] = same_[u] ? 0.f : e_[u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        R_[u] = (same_[u] ? 1.f : 0.f) - (sr4[u].x * S_[u]) * sj;          // slab_lap_small's expression
+        float a0 = gr4[u][0] * xj[0], a1 = xr4[u][0] * gj[0];
+#pragma unroll
+        for (int f = 1; f < SF; ++f) { a0 = __builtin_fmaf(gr4[u][f], xj[f], a0); a1 = __builtin_fmaf(xr4[u][f], gj[f], a1); }
+        dL_[u] = a0;                                                      // dL[i][j] = g_1[i] . X_0[j]
+        dLt_[u] = a1;                                                     // dL[j][i] = g_1[j] . X_0[i]
+        nlg_[u] = -lrelu_grad(R_[u], alpha);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float si = sr4[u].x, ddi = sr4[u].y;
+        const float dA = dL_[u] * nlg_[u], dAt = dLt_[u] * nlg_[u];
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (PASS == 1) {
-          const float L = lrelu(p.R, alpha) + l0c[u];
-          const float w = (p.dA + p.dAt) * p.S;
+          const float L = lrelu(R_[u], alpha) + l0c[u];
+          const float w = (dA + dAt) * S_[u];
 #pragma unroll
           for (int f = 0; f < SF; ++f) v[f] = L * gj[f];
           v[3] = w * sj;
           // dalpha = sum over ORDERED pairs of dL_ij min(R_ij, 0): the mirrored pair's term rides along off the diagonal block
-          const float dLt = small_dot<SF>(xi, gj);
-          dalpha_part = __builtin_fmaf(diag ? p.dL : p.dL + dLt, fminf(p.R, 0.f), dalpha_part);
+          dalpha_part = __builtin_fmaf(diag ? dL_[u] : dL_[u] + dLt_[u], fminf(R_[u], 0.f), dalpha_part);
           if (!diag) {
 #pragma unroll
-            for (int f = 0; f < SF; ++f) col[f] = __builtin_fmaf(L, gi[f], col[f]);
+            for (int f = 0; f < SF; ++f) col[f] = __builtin_fmaf(L, gr4[u][f], col[f]);
             col[3] = __builtin_fmaf(w, si, col[3]);
           }
         } else {
-          const float dr_ij = -p.S * __builtin_fmaf(p.dA * si, sj, ddj);
-          const float dr_ji = -p.S * __builtin_fmaf(p.dAt * sj, si, ddi);
+          const float dr_ij = -S_[u] * __builtin_fmaf(dA * si, sj, ddj);
+          const float dr_ji = -S_[u] * __builtin_fmaf(dAt * sj, si, ddi);
           // r == 0 (coincident points): the term is defined as 0; S == 0 (underflow): dr = 0, never inf * 0
-          const bool ok = !same && rij > 0.f && p.S != 0.f;
-          const float cij = ok ? (dr_ij + dr_ji) * __builtin_amdgcn_rcpf(rij) : 0.f;
+          const bool ok = !same_[u] && r_[u] > 0.f && S_[u] != 0.f;
+          const float craw = (dr_ij + dr_ji) * __builtin_amdgcn_rcpf(r_[u]);
+          const float cij = ok ? craw : 0.f;
 #pragma unroll
           for (int f = 0; f < SF; ++f) v[f] = cij * zj[f];
           v[3] = cij;
           if (!diag) {
 #pragma unroll
-            for (int f = 0; f < SF; ++f) col[f] = __builtin_fmaf(cij, zi[f], col[f]);
+            for (int f = 0; f < SF; ++f) col[f] = __builtin_fmaf(cij, zr4[u][f], col[f]);
             col[3] += cij;
           }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) patch[(u * 4 + k) * 64 + lane] = v[k];
+        for (int k = 0; k < 4; ++k) vv[u][k] = v[k];
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) patch[(u * 4 + k) * 64 + lane] = vv[u][k];
       __builtin_amdgcn_wave_barrier();
       {
         // 16 sums of 64: lane l adds quarter l & 3 of sum q = l >> 2 (= row q / 4, value q % 4), then its three neighbours'
