@@ -1149,6 +1149,93 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
             assert_close(g[b], tot["dLp"][b], GRAD_RTOL, f"dL_prev[{b}]", atol_ulps=GRAD_ULPS * k, ref32=tot32["dLp"][b])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_point_cloud_kernels_random_batches(amd, seed):
+    """The point-cloud kernels' task lists (similarity: (graph, block pair, piece) ids cut into eight ranges; first-layer
+    backward: the same with two pieces per block) on batches the fixed-size tests do not hit: 1 to 7 clouds of 64 to 448
+    points in any order, hidden width (both variants, Reslap with a symmetric previous Laplacian and a gradient on L_sum) and
+    the xyz first layer of SGC_LL.  Every output and gradient against the float64 oracle."""
+    rs = np.random.RandomState(7000 + seed)
+    sizes = [int(64 * rs.randint(1, 8)) for _ in range(int(rs.randint(1, 8)))]
+    variant = orc.SGC_LL_RESLAP if seed % 2 == 0 else orc.SGC_LL
+    Fin, Fout = (3, 64) if seed % 3 == 0 and variant == orc.SGC_LL else (64, 128 if seed % 2 else 64)
+    K, mode = 2, orc.PAPER
+    Xs, Ls, Gs = [], [], []
+    for n in sizes:
+        if Fin == 3:
+            X = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+            _, L, G = _cloud_case(rs, n, 64, Fout, thresh=0.6)
+        else:
+            X, L, G = _cloud_case(rs, n, Fin, Fout, thresh=0.6)
+        Xs.append(X); Ls.append(L); Gs.append(G)
+    p = orc.init_params(rs, Fin, Fout, K, variant)
+    p["alpha"] = np.array([0.75], dtype=np.float32)
+    reslap = variant == orc.SGC_LL_RESLAP
+    if reslap:
+        p["beta"] = np.array([0.9], dtype=np.float32)
+    Lp = [_sym_prev(rs, n) for n in sizes] if reslap else None
+    dLs = [(0.01 * rs.randn(n, n)).astype(np.float32) for n in sizes] if reslap else None
+    plan = amd.Plan(sizes, 0, DEV)
+    l0 = np.zeros(int(plan.tile_off[-1]), np.float32)
+    for b, L in enumerate(Ls):
+        l0[int(plan.tile_off[b]):int(plan.tile_off[b]) + L.size] = L.reshape(-1)
+    gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0).to(DEV), l0_ld=0,
+                        l0_symmetric=True)
+    lib = amd._ffi.lib()
+    lib.agcn_set_fused_mode(0)          # (small clouds would fit the per-graph fused kernels: this test is about the strip kernels)
+    lib.agcn_profile_enable(1)
+    amd._ffi.profile_collect()
+    try:
+        layer = make_layer(amd, variant, Fout, Fin, len(sizes), K, mode, p, DEV)
+        Xt = gb.X.clone().requires_grad_(True)
+        x = {"node_features": Xt, "graph_batch": gb}
+        Lpt = None
+        if reslap:
+            Lpt = torch.from_numpy(pack_tiles_np(Lp, plan)).to(DEV).requires_grad_(True)
+            x["res_lap"] = amd.TileViews(Lpt, plan, symmetric=True)
+            nodes, res_L, res_W, L_sum = layer(x)
+            loss = (nodes.data * torch.from_numpy(np.concatenate(Gs)).to(DEV)).sum() + \
+                   (L_sum.data * torch.from_numpy(pack_tiles_np(dLs, plan)).to(DEV)).sum()
+        else:
+            nodes, res_L, res_W = layer(x)
+            loss = (nodes.data * torch.from_numpy(np.concatenate(Gs)).to(DEV)).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        prof = amd._ffi.profile_collect()
+    finally:
+        lib.agcn_profile_enable(0)
+        lib.agcn_set_fused_mode(1)
+    if Fin == 3:
+        assert prof["slab_sim_kernel"][1] == 1 and prof["slab_bwd1_kernel"][1] == 2, prof     # (pair kernel + its reduce)
+    elif reslap:
+        assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_rlap1_kernel"][1] == 1 and prof["cloud_rbwd_kernel<B>"][1] == 1, prof
+    else:
+        assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_bwd1_kernel"][1] == 1, prof
+    caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs)
+    tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32)[1]
+    k = float(np.sqrt(max(sizes) / 64.0))
+    Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
+    for b, n in enumerate(sizes):
+        c = caches[b]
+        assert_close(Y[r0:r0 + n], c["Y"], FEATURE_RTOL, f"Y[{b}]", atol_ulps=FEATURE_ULPS * k)
+        w = to_np(res_W[b])
+        assert_close(w, c["S"], FEATURE_RTOL, f"res_W[{b}]", atol_ulps=0)
+        assert np.array_equal(w, w.T) and np.all(np.diag(w) == 0)
+        assert_close(to_np(res_L[b]), c["R2"], FEATURE_RTOL, f"res_L[{b}]", atol_ulps=FEATURE_ULPS * k)
+        assert_close(dX[r0:r0 + n], tot["dX"][b], GRAD_RTOL, f"dX[{b}]", atol_ulps=GRAD_ULPS * k)
+        r0 += n
+    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight", atol_ulps=GRAD_ULPS * k)
+    assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L", atol_ulps=GRAD_ULPS * k, ref32=tot32["dM_L"])
+    from helpers import _scalar_close
+    scale = float(np.abs(tot["dweight"]).max())
+    _scalar_close(to_np(layer.vars["alpha"].grad), tot["dalpha"], tot32["dalpha"], scale, "dalpha")
+    if reslap:
+        _scalar_close(to_np(layer.vars["beta"].grad), tot["dbeta"], tot32["dbeta"], scale, "dbeta")
+        g = unpack_tiles_np(to_np(Lpt.grad), plan)
+        for b in range(len(sizes)):
+            assert_close(g[b], tot["dLp"][b], GRAD_RTOL, f"dL_prev[{b}]", atol_ulps=GRAD_ULPS * k, ref32=tot32["dLp"][b])
+
+
 @pytest.mark.parametrize("sizes", [[512, 256, 320, 64], [300, 257, 519, 131]], ids=["multiples_of_64", "ragged"])
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
 def test_point_cloud_batch_hidden_features(amd, mode, sizes):
