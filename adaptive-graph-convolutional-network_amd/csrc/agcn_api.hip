@@ -408,6 +408,7 @@ void fill_common(SgcArgs& a, const AgcnLayerDesc* d, const AgcnGraphBatch* g, co
   a.L_prev = d->variant == AGCN_SGC_LL_RESLAP ? g->L_prev : nullptr;
   a.weight = p->weight; a.bias = p->bias; a.M_L = p->M_L; a.alpha = p->alpha; a.beta = p->beta;
   a.Y = o->Y; a.res_L = o->res_L; a.res_W = o->res_W; a.L_sum = o->L_sum;
+  a.foff = 0; a.fstride = d->Fin; a.half_acc = 0; a.half_last = 1;
 }
 
 int check_batch(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnParams* p, const char* who) {
@@ -447,7 +448,7 @@ extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGr
   int path = fs.mode == 1 ? ((fs.spec_fwd ? 1 : 0) | (fs.spec_bwd ? 2 : 0) | 4)      // fused (+ specialised bits)
                           : (fs.mode == 2 ? 8 : (use_slabs(desc, batch, host.info) ? 16 : 32));
   // 64: the slab batch has the shape the point-cloud kernels take (pointer alignment is checked at the call)
-  if ((path == 16 || (path == 32 && desc->variant == AGCN_SGC_LL_RESLAP)) && cloud_shape(desc) && cloud_candidate(desc, batch, host.info) &&
+  if ((path == 16 || path == 32) && cloud_shape(desc) && cloud_candidate(desc, batch, host.info) &&
       batch->L0_dense != nullptr && slab_quad_ok(host) && (desc->ldx & 3) == 0 && (desc->Fout & 15) == 0 && (desc->ldy & 3) == 0)
     path |= 64;
   const int32_t v[AGCN_DISPATCH_INFO_INTS] = {path, fs.spec_small_first, cg, cs, dg, cgb, csb, dgb};
@@ -480,12 +481,16 @@ extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const voi
 
 // layer shapes the point-cloud kernels (cloud_kernels.hip) are compiled for: their forward needs partial-degree scratch
 static bool cloud_shape(const AgcnLayerDesc* d) {
-  return (d->variant == AGCN_SGC_LL || d->variant == AGCN_SGC_LL_RESLAP) && d->K == 2 && d->Fin == 64;
+  return (d->variant == AGCN_SGC_LL || d->variant == AGCN_SGC_LL_RESLAP) && d->K == 2 && (d->Fin == 64 || d->Fin == 128);
 }
 // Batches the point-cloud kernels (cloud_kernels.hip) may take: what the slab kernels take (SGC_LL), and SGC_LL_Reslap with a
 // dense symmetric L_orig on packed rows (cloud_path() checks the rest: multiples of 64 nodes, alignment, Fin = 64)
 static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
-  if (d->variant == AGCN_SGC_LL) return use_slabs(d, g, pi);
+  if (d->variant == AGCN_SGC_LL && use_slabs(d, g, pi)) return true;
+  // (the general slab kernels' LDS plan may not fit a 128-feature layer: the point-cloud kernels do not depend on it)
+  if (d->variant == AGCN_SGC_LL)
+    return agcn_get_slab_mode() != 0 && d->K == 2 && pi.rows == pi.N1 && g->L0_dense != nullptr && g->L0_rowptr == nullptr &&
+           g->L0_symmetric == 1;
   return agcn_get_slab_mode() != 0 && d->variant == AGCN_SGC_LL_RESLAP && d->K == 2 && pi.rows == pi.N1 &&
          g->L0_dense != nullptr && g->L0_rowptr == nullptr && g->L0_symmetric == 1 &&
          (g->L_prev == nullptr || g->L_prev_symmetric == 1);
@@ -698,8 +703,23 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   }
   // point clouds (cloud_kernels.hip): projection, similarity, degree, Laplacian + Chebyshev + filter in four launches
   if (cloud_candidate(desc, batch, host.info) && dpart && cloud_path(a, a.slab_quad != 0) &&
-      (reinterpret_cast<uintptr_t>(out->Y) & 15) == 0)
-    return launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
+      (reinterpret_cast<uintptr_t>(out->Y) & 15) == 0) {
+    if (desc->Fin != 128) return launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
+    // 128 input features: Z = X M_L and the filter product as packed-row launches around the strip kernels
+    RowsGemmArgs g;
+    fill_rows(g, desc, host, dev);
+    g.Kd = desc->Fin; g.N = desc->Fin;
+    g.A0 = batch->X; g.lda0 = desc->ldx; g.Bm = params->M_L; g.Out0 = a.sv_Z; g.ldo0 = desc->Fin;
+    rc = launch_rows_gemm(g, RG_PROJECT, hip_stream);
+    if (rc != AGCN_OK) return rc;
+    rc = launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
+    if (rc != AGCN_OK) return rc;
+    fill_rows(g, desc, host, dev);
+    g.Kd = desc->Fin * desc->K; g.N = desc->Fout;
+    g.A0 = batch->X; g.lda0 = desc->ldx; g.A1 = a.sv_X; g.a1_plane = (int64_t)host.info.rows * desc->Fin;
+    g.Bm = params->weight; g.bias = params->bias; g.Out0 = out->Y; g.ldo0 = desc->ldy;
+    return launch_rows_gemm(g, RG_FILTER, hip_stream);
+  }
   // 1. Z = X . M_L over the packed rows (graphconv.py:164)
   RowsGemmArgs g;
   fill_rows(g, desc, host, dev);
@@ -799,6 +819,13 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   bool cloud_bwd = false, cloud_res = false;
   // SGC_LL_Reslap on the point-cloud kernels: only behind the cloud forward (the per-graph forward leaves no r tiles); the
   // same answer in both stages of a split call
+  // SGC_LL: either backward works behind either forward (both forwards leave Z, X_1, s and the r tiles)
+  if (!reslap && !fused && w.WT && (w.dA || !paper) && cloud_shape(desc) && cloud_candidate(desc, batch, host.info)) {
+    SgcArgs t = a;
+    t.n_slabs = host.info.n_slabs;
+    cloud_bwd = cloud_path(t, slab_quad_ok(host) != 0) && dL_sum == nullptr && (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
+  }
   if (reslap && !fused && w.WT && w.spart && cloud_candidate(desc, batch, host.info)) {
     SgcArgs t = a;
     t.n_slabs = host.info.n_slabs;
@@ -920,18 +947,34 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd; a.ws_Gp = w.Gp;
     // point clouds: either backward works behind either forward (both forwards leave Z, X_1, s and the r tiles)
-    cloud_bwd = slabs && w.WT && cloud_path(a, a.slab_quad != 0) && dL_sum == nullptr &&
-                (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
     RowsGemmArgs g;
-    if (cloud_res) {
-      a.pg_slab_base = 0;
-      rc = launch_cloud_backward_reslap(a, nullptr, w.spart, hip_stream);
+    if (cloud_res || cloud_bwd) {
+      const bool wide = desc->Fin == 128;
+      if (wide) {    // [g_0 | g_1] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_1 -> workspace
+        fill_rows(g, desc, host, dev);
+        g.Kd = desc->Fout; g.N = desc->Fin * desc->K;
+        g.A0 = dY; g.lda0 = desc->ldy; g.Yact = fwd->Y; g.ldy = desc->ldy; g.Bm = params->weight;
+        g.Out0 = grads->dX; g.ldo0 = desc->ldx; g.Out1 = w.g; g.o1_plane = (int64_t)host.info.rows * desc->Fin;
+        g.Gp = w.Gp; g.zero_ptr = counters; g.zero_count = n_counters;
+        rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
+        if (rc != AGCN_OK) return rc;
+      }
+      if (cloud_res) {
+        a.pg_slab_base = 0;
+        rc = launch_cloud_backward_reslap(a, nullptr, w.spart, hip_stream);
+      } else {
+        // the same predicate as the forward's: the cloud forward left W^T in the reserve (else it is built here, in workspace)
+        const bool fwd_cloud = (reinterpret_cast<uintptr_t>(fwd->Y) & 15) == 0;
+        rc = launch_cloud_backward(a, fwd_cloud ? nullptr : w.WT, hip_stream);
+      }
       if (rc != AGCN_OK) return rc;
-    } else if (cloud_bwd) {
-      // the same predicate as the forward's: the cloud forward left W^T in the reserve (else it is built here, in workspace)
-      const bool fwd_cloud = (reinterpret_cast<uintptr_t>(fwd->Y) & 15) == 0;
-      rc = launch_cloud_backward(a, fwd_cloud ? nullptr : w.WT, hip_stream);
-      if (rc != AGCN_OK) return rc;
+      if (wide && paper) {   // dX += dZ . M_L^T
+        fill_rows(g, desc, host, dev);
+        g.Kd = desc->Fin; g.N = desc->Fin;
+        g.A0 = w.dZ; g.lda0 = desc->Fin; g.Bm = params->M_L; g.Out0 = grads->dX; g.ldo0 = desc->ldx;
+        rc = launch_rows_gemm(g, RG_PROJECT_BWD, hip_stream);
+        if (rc != AGCN_OK) return rc;
+      }
     } else {
     // 1. [g_0|g_1|..] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_k -> workspace
     fill_rows(g, desc, host, dev);
@@ -975,10 +1018,10 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
-  pa.B = fused ? B + fs.n_big_slabs + coop_slabs : ((slabs || cloud_res) ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
+  pa.B = fused ? B + fs.n_big_slabs + coop_slabs : ((slabs || cloud_res || cloud_bwd) ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
-  pa.counters_zeroed = ((stages & 1) && !cloud_bwd && !cloud_res) ? 1 : 0;
+  pa.counters_zeroed = ((stages & 1) && ((!cloud_bwd && !cloud_res) || desc->Fin == 128)) ? 1 : 0;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
   // point-cloud sizes: row-chunk partials with 16-byte operand loads + the fixed-order reduce (cloud_kernels.hip)

@@ -177,8 +177,10 @@ __device__ __forceinline__ const float* dense_l0(const SgcArgs& a, const WaveCtx
 //   each pair once, mirrored block through the [64][16] patches, 64-row tasks, workgroup = (strip, 4 column blocks)   88-90 us
 //   32-row tasks from task lists (below)                                                            75 us: 47 us of vector issue
 //     at the kernel's clock and the ubench's rate, 55-57 measured without stores / patches / sqrt + exp, +10 stores, +2, +3
-template <bool PAPER, int RT>
-__global__ __launch_bounds__(256, 4) void cloud_sim_kernel(SgcArgs a, float* dpart, int t_quota, int nquads, int qstride) {
+// NF: features (64, or 128: the lane keeps 128 registers of its column's row and every row takes two rounds of the
+// double-buffered 64-float loads -- 2 waves per SIMD)
+template <bool PAPER, int RT, int NF = 64>
+__global__ __launch_bounds__(256, NF == 64 ? 4 : 2) void cloud_sim_kernel(SgcArgs a, float* dpart, int t_quota, int nquads, int qstride) {
   constexpr int WSZ = PAPER ? 2560 : 1280;      // floats of LDS per wave: [4][64] S (, r) + [64][16] S^T (, r^T)
   constexpr int NS = CS / RT;                   // partial-degree slots per row block
   extern __shared__ __attribute__((aligned(16))) float trbuf[];
@@ -226,12 +228,12 @@ __global__ __launch_bounds__(256, 4) void cloud_sim_kernel(SgcArgs a, float* dpa
   const int64_t toff_v = a.tile_off[b];
   const int64_t toff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(toff_v >> 32)) << 32) |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)toff_v));
-  const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
-  float zj[FIN];
+  const float* Zg = a.sv_Z + (int64_t)row0 * NF;
+  float zj[NF];
   {
-    const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)(64 * J + lane) * FIN);
+    const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)(64 * J + lane) * NF);
 #pragma unroll
-    for (int f4 = 0; f4 < FIN / 4; ++f4) {
+    for (int f4 = 0; f4 < NF / 4; ++f4) {
       const f32x4 t = zp[f4];
       zj[4 * f4 + 0] = t.x; zj[4 * f4 + 1] = t.y; zj[4 * f4 + 2] = t.z; zj[4 * f4 + 3] = t.w;
     }
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, 4) void cloud_sim_kernel(SgcArgs a, float* dpa
   float cs = 0.f;
   float* dpI = dpart + (toff >> 6) * NS + (int64_t)(I * NS + h) * n;    // partial degrees [n / RT][n] per graph
   float* dpJ = dpart + (toff >> 6) * NS + (int64_t)(J * NS) * n;
-  const float* zrow = Zg + (int64_t)r0 * FIN;
+  const float* zrow = Zg + (int64_t)r0 * NF;
   f32x16 A0, A1, B0, B1;
   SLOAD16(A0, zrow, "0x0");
   SLOAD16(A1, zrow, "0x40");
@@ -252,9 +254,6 @@ __global__ __launch_bounds__(256, 4) void cloud_sim_kernel(SgcArgs a, float* dpa
       for (int u = 0; u < 4; ++u) {
         const int ii = g16 + i4 + u;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        SWAIT2(A0, A1, cs);
-        SLOAD16_BEFORE(B0, zrow, "0x80", A0);
-        SLOAD16_BEFORE(B1, zrow, "0xc0", A1);
 #define AGCN_SIM16(SRC, BASE)                                                                                       \
   _Pragma("unroll") for (int f = 0; f < 16; f += 4) {                                                             \
     const float d0 = SRC[f] - zj[BASE + f], d1 = SRC[f + 1] - zj[BASE + f + 1];                                     \
@@ -262,14 +261,20 @@ __global__ __launch_bounds__(256, 4) void cloud_sim_kernel(SgcArgs a, float* dpa
     c0 = __builtin_fmaf(d0, d0, c0); c1 = __builtin_fmaf(d1, d1, c1);                                               \
     c2 = __builtin_fmaf(d2, d2, c2); c3 = __builtin_fmaf(d3, d3, c3);                                               \
   }
-        AGCN_SIM16(A0, 0)
-        AGCN_SIM16(A1, 16)
-        SWAIT2(B0, B1, c3);
-        zrow += (ii + 1 < RT) ? FIN : 0;      // (the last request re-reads the last row: never used)
-        SLOAD16_BEFORE(A0, zrow, "0x0", B0);
-        SLOAD16_BEFORE(A1, zrow, "0x40", B1);
-        AGCN_SIM16(B0, 32)
-        AGCN_SIM16(B1, 48)
+#pragma unroll
+        for (int hh = 0; hh < NF / 64; ++hh) {   // 64 floats of the row per round (rows are contiguous: + 64 floats each time)
+          SWAIT2(A0, A1, cs);
+          SLOAD16_BEFORE(B0, zrow, "0x80", A0);
+          SLOAD16_BEFORE(B1, zrow, "0xc0", A1);
+          AGCN_SIM16(A0, 64 * hh)
+          AGCN_SIM16(A1, 64 * hh + 16)
+          SWAIT2(B0, B1, c3);
+          zrow += (ii + 1 < RT || hh + 1 < NF / 64) ? 64 : 0;   // (the last request re-reads the last 64 floats: never used)
+          SLOAD16_BEFORE(A0, zrow, "0x0", B0);
+          SLOAD16_BEFORE(A1, zrow, "0x40", B1);
+          AGCN_SIM16(B0, 64 * hh + 32)
+          AGCN_SIM16(B1, 64 * hh + 48)
+        }
 #undef AGCN_SIM16
         // (each pair is computed once: S and r are symmetric to the bit)
         const float rr = __builtin_amdgcn_sqrtf((c0 + c1) + (c2 + c3));
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(64) void cloud_degree_kernel(SgcArgs a, const float
     sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
   }
   // W^T for the backward's filter adjoint (WT[k][c][f] = W[f * K + k][c]) -> reserve, a slice per workgroup
+  if (a.Fin == FIN)
   for (int e = (int)blockIdx.x * 64 + (int)threadIdx.x; e < 2 * a.Fout * FIN; e += (int)gridDim.x * 64) {
     const int f = e % FIN, kc = e / FIN, c = kc % a.Fout, k = kc / a.Fout;
     a.sv_WT[e] = a.weight[(int64_t)(f * 2 + k) * a.Fout + c];
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* 
   float* Bs = smem;                             // [64][LD]  the chunk's rows of X_0
   float* Ls = smem + CC * LD + wave * (16 * LD);   // [16][LD]  this wave's strip of L
   const float alpha = a.alpha[0];
-  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx + a.foff;
   int l0ld;
   const float* L0d = dense_l0(a, c, &l0ld);
   const float* Wt = a.res_W + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
@@ -570,13 +576,14 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* 
   // X_1[I] = L[I, :] X_0 -> reserve; and, with X_0[I], the A images of the filter product
   __syncthreads();                    // the chunk image is dead: its space holds the X_0[I] images now
   float* X0s = smem + wave * (16 * LD);   // (inside Bs: 4 x 16 rows)
-  float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * FIN;
+  float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * a.fstride + a.foff;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const f32x4 v = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
-    *reinterpret_cast<f32x4*>(Xo + (int64_t)(4 * q + i) * FIN + 4 * r) = v;
+    *reinterpret_cast<f32x4*>(Xo + (int64_t)(4 * q + i) * a.fstride + 4 * r) = v;
     *reinterpret_cast<f32x4*>(Ls + (4 * q + i) * LD + 4 * r) = v;
   }
+  if (a.fstride != FIN) return;       // 128-feature layer, one half of X_1 done: the filter product is a packed-row launch
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int row = q + 4 * m;
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_ref_kernel(SgcArgs a) {
   const int n = c.n;
   float* Gs = smem;                                  // [64][LD]  g_1 rows of the chunk
   float* Ls = smem + CC * LD + wave * (16 * LD);     // [16][LD] this wave's strip of L
-  const float* g1 = a.ws_g + (int64_t)c.row0 * FIN;   // adjoint of X_1 (K = 2: plane 0)
+  const float* g1 = a.ws_g + (int64_t)c.row0 * a.fstride + a.foff;   // adjoint of X_1 (K = 2: plane 0)
   int l0ld;
   const float* L0d = dense_l0(a, c, &l0ld);
   const float* L0t = L0d + (int64_t)(c.i0 + 4 * q) * l0ld + 4 * r;
@@ -652,14 +659,14 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_ref_kernel(SgcArgs a) {
   f32x4 acc[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  StageRegs preG = stage_load(g1, FIN, 0);
+  StageRegs preG = stage_load(g1, a.fstride, 0);
   Tiles cur = load_tiles(0);
 #pragma unroll 1
   for (int c0 = 0; c0 < n; c0 += CC) {
     __syncthreads();
     stage_store(Gs, preG);
     __syncthreads();
-    if (c0 + CC < n) preG = stage_load(g1, FIN, c0 + CC);
+    if (c0 + CC < n) preG = stage_load(g1, a.fstride, c0 + CC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_ref_kernel(SgcArgs a) {
     strip_mma(acc, Ls, Gs, r, q);     // dX[I] += L[I, chunk] g_1[chunk]
   }
   // dX rows of the strip (g_0 already there from the packed filter adjoint)
-  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x4* p = reinterpret_cast<f32x4*>(dXg + (int64_t)(4 * q + i) * a.ldx + 4 * r);
@@ -769,6 +776,9 @@ __device__ __forceinline__ Pieces cols_B(const uint16_t* img, int off) {
 }
 }  // namespace
 
+// FS: row stride of the packed feature arrays (= Fin: 64, or 128 with the kernel run once per 64-column half); ACC: second half
+// (Q, ds and dalpha are linear in the per-half products: this run adds to the first one's)
+template <int FS, bool ACC>
 __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -782,8 +792,8 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
   uint16_t* PG = PX + 3 * PLANE_H;                     // [3][64][LDH]  ... of its g_1 rows
   float* Ls = smem + (6 * PLANE_H) / 2 + wave * (16 * LD);   // [16][LD] this wave's strip of L (fp32)
   const float alpha = a.alpha[0];
-  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
-  const float* g1 = a.ws_g + (int64_t)c.row0 * FIN;   // adjoint of X_1 (K = 2: plane 0)
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx + a.foff;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * FS + a.foff;   // adjoint of X_1 (K = 2: plane 0)
   int l0ld;
   const float* L0d = dense_l0(a, c, &l0ld);
   const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
   Pieces Ag[2], Ax[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    const float* gp = g1 + (int64_t)(c.i0 + r) * FIN + 32 * kb + 8 * q;
+    const float* gp = g1 + (int64_t)(c.i0 + r) * FS + 32 * kb + 8 * q;
     const float* xp = Xg + (int64_t)(c.i0 + r) * a.ldx + 32 * kb + 8 * q;
     Ag[kb] = split3x8(*reinterpret_cast<const f32x4*>(gp), *reinterpret_cast<const f32x4*>(gp + 4));
     Ax[kb] = split3x8(*reinterpret_cast<const f32x4*>(xp), *reinterpret_cast<const f32x4*>(xp + 4));
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
   struct Stage { f32x4 g[4], x[4]; };
   auto stage_load16 = [&](int c0) {
     Stage s;
-    const float* gp = g1 + (int64_t)(c0 + rho) * FIN + 16 * sg;
+    const float* gp = g1 + (int64_t)(c0 + rho) * FS + 16 * sg;
     const float* xp = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -912,24 +922,33 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
         acc[e] = mfma_x6(Al, Tc, acc[e]);
       }
     }
+    if (ACC) {    // second feature half of a 128-feature layer: Q is linear in P
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Qv[i] += *reinterpret_cast<const f32x4*>(Qt + (int64_t)i * n + c0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = Qv[i];
   }
   // dX rows of the strip (g_0 already there from the packed filter adjoint): lane (r, q) holds rows 4q + i, features 16 e + r
-  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) dXg[(int64_t)(4 * q + i) * a.ldx + 16 * e + r] += acc[e][i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float t = row16_sum(ds[i]);
-    if (r == 0) a.ws_dd[c.row0 + c.i0 + 4 * q + i] = degree_grad(si[i], t);   // dd_k = -1/2 s_k^3 ds_k
+    float t = row16_sum(ds[i]);
+    if (r == 0) {
+      float* dd = a.ws_dd + c.row0 + c.i0 + 4 * q + i;
+      if (ACC) t += *dd;                                      // (the first half left the raw ds)
+      *dd = a.half_last ? degree_grad(si[i], t) : t;                 // dd_k = -1/2 s_k^3 ds_k
+    }
   }
   const float da = wave_sum_all(dalpha_part);
   if (lane == 0) {
-    a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = 0.5f * da;
-    a.ws_pg[2 * (a.pg_slab_base + slab) + 1] = 0.f;
+    float* pg = a.ws_pg + 2 * (a.pg_slab_base + slab);
+    pg[0] = (ACC ? pg[0] : 0.f) + 0.5f * da;
+    pg[1] = 0.f;
   }
 }
 
@@ -969,7 +988,7 @@ __device__ __forceinline__ ResScal res_scalars(const SgcArgs& a, const float* sp
   return z;
 }
 
-template <int PASS, bool PAPER>   // PASS 0 = A, 1 = B, 2 = C
+template <int PASS, bool PAPER, int FS = 64, bool ACC = false>   // PASS 0 = A, 1 = B, 2 = C; FS / ACC: see cloud_bwd1_paper_kernel
 __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* spart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[4 * 8];
@@ -980,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   const int slab = 4 * strip + wave;
   const WaveCtx c = wave_ctx(a, slab);
   const int n = c.n;
-  const bool has_prev = a.L_prev != nullptr, has_dls = a.dL_sum != nullptr;
+  const bool has_prev = a.L_prev != nullptr, has_dls = a.dL_sum != nullptr && !ACC;
   constexpr bool NEED_X = true;                       // X_0 images: the B operand of g_1[I] X_0[J]^T
   constexpr bool NEED_G = PASS != 0;                  // g_1 images: X_0[I] g_1[J]^T (B), La g_1 (C)
   // pass C without a previous Laplacian has no dL_prev to write: only the La g_1 product is left
@@ -989,8 +1008,8 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   uint16_t* PG = PX + 3 * PLANE_H;
   float* Ls = smem + (6 * PLANE_H) / 2 + wave * (16 * LD);
   const float alpha = a.alpha[0];
-  const float* Xg = a.X + (int64_t)c.row0 * a.ldx;
-  const float* g1 = a.ws_g + (int64_t)c.row0 * FIN;
+  const float* Xg = a.X + (int64_t)c.row0 * a.ldx + a.foff;
+  const float* g1 = a.ws_g + (int64_t)c.row0 * FS + a.foff;
   const float* scal = a.sv_scal + 4 * c.b;
   const float scR = scal[1], scL = scal[3];
   const int64_t o0 = c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
@@ -1013,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   Pieces Ag[2], Ax[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    const float* gp = g1 + (int64_t)(c.i0 + r) * FIN + 32 * kb + 8 * q;
+    const float* gp = g1 + (int64_t)(c.i0 + r) * FS + 32 * kb + 8 * q;
     Ag[kb] = split3x8(*reinterpret_cast<const f32x4*>(gp), *reinterpret_cast<const f32x4*>(gp + 4));
     if constexpr (PASS == 1) {
       const float* xp = Xg + (int64_t)(c.i0 + r) * a.ldx + 32 * kb + 8 * q;
@@ -1024,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   struct Stage { f32x4 g[4], x[4]; };
   auto stage_load16 = [&](int c0) {
     Stage st;
-    const float* gp = g1 + (int64_t)(c0 + rho) * FIN + 16 * sg;
+    const float* gp = g1 + (int64_t)(c0 + rho) * FS + 16 * sg;
     const float* xp = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -1136,6 +1155,8 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
         if (PAPER && PASS != 2) R = R - (si[i] * Sv[i][t]) * sj[t];
         const float R1 = R * scR;
         const float mR = lrelu_grad(R1, alpha);
+        // (second feature half of a 128-feature layer, ACC: only the terms linear in this half's products; dL_sum and
+        //  everything that does not depend on D went in with the first half)
         if constexpr (PASS == 0) {
           const float D = pa[i] + late.ds[i][t];
           const float dLc = D * mL;
@@ -1143,30 +1164,40 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
           const float nR = fminf(R1, 0.f), wR = mR * R;
           sm[0] = __builtin_fmaf(dLc, lpre, sm[0]);
           sm[1] = __builtin_fmaf(dLc, lprev, sm[1]);
-          sm[2] = __builtin_fmaf(lpre, lprev, sm[2]);
           sm[3] = __builtin_fmaf(dLc, nR, sm[3]);
-          sm[4] = __builtin_fmaf(lpre, nR, sm[4]);
           sm[5] = __builtin_fmaf(dLc, wR, sm[5]);
-          sm[6] = __builtin_fmaf(lpre, wR, sm[6]);
           sm[7] = __builtin_fmaf(D, fminf(Lc, 0.f), sm[7]);
+          if (!ACC) {
+            sm[2] = __builtin_fmaf(lpre, lprev, sm[2]);
+            sm[4] = __builtin_fmaf(lpre, nR, sm[4]);
+            sm[6] = __builtin_fmaf(lpre, wR, sm[6]);
+          }
         } else if constexpr (PASS == 1) {
           const float Dsym = (pa[i] + pb[i]) + (late.ds[i][t] + late.dt[t][i]);
-          const float dLp2 = (z.aL * mL) * Dsym - 2.f * (z.bL * lpre);
-          const float Q = -(z.aR * (dLp2 * mR) - 2.f * (z.bR * R));      // dA_ij + dA_ji, dA = -dR
+          const float dLp2 = ACC ? (z.aL * mL) * Dsym : (z.aL * mL) * Dsym - 2.f * (z.bL * lpre);
+          const float Q = ACC ? -(z.aR * (dLp2 * mR)) : -(z.aR * (dLp2 * mR) - 2.f * (z.bR * R));   // dA_ij + dA_ji, dA = -dR
           outv[i][t] = Q;
           dsum[i] = __builtin_fmaf(Q, Sv[i][t] * sj[t], dsum[i]);         // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
         } else {
           const float D = pa[i] + late.ds[i][t];
-          outv[i][t] = beta * ((z.aL * mL) * D - z.bL * lpre);            // dL_prev = beta dLpre
+          outv[i][t] = ACC ? beta * ((z.aL * mL) * D) : beta * ((z.aL * mL) * D - z.bL * lpre);   // dL_prev = beta dLpre
         }
       }
     }
     if constexpr (PASS == 1) {
+      if (ACC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outv[i] += *reinterpret_cast<const f32x4*>(Qt + (int64_t)i * n + c0);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = outv[i];
     }
     if constexpr (PASS == 2) {
       if (has_prev) {
+        if (ACC) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) outv[i] += *reinterpret_cast<const f32x4*>(DPt + (int64_t)i * n + c0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(outv[i], reinterpret_cast<f32x4*>(DPt + (int64_t)i * n + c0));
       }
@@ -1180,17 +1211,24 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
       if (lane == 0) red[wave * 8 + k] = v;
     }
     __syncthreads();
-    if (tid < 8) spart[(int64_t)strip * 8 + tid] = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
+    if (tid < 8) {
+      float* sp = spart + (int64_t)strip * 8 + tid;
+      *sp = (ACC ? *sp : 0.f) + ((red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]));
+    }
   }
   if constexpr (PASS == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float t = row16_sum(dsum[i]);
-      if (r == 0) a.ws_dd[c.row0 + c.i0 + 4 * q + i] = degree_grad(si[i], t);   // dd_k = -1/2 s_k^3 ds_k
+      float t = row16_sum(dsum[i]);
+      if (r == 0) {
+        float* dd = a.ws_dd + c.row0 + c.i0 + 4 * q + i;
+        if (ACC) t += *dd;                                    // (the first half left the raw ds)
+        *dd = a.half_last ? degree_grad(si[i], t) : t;               // dd_k = -1/2 s_k^3 ds_k
+      }
     }
   }
   if constexpr (PASS == 2) {
-    float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+    float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1216,7 +1254,7 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
   const int n = c.n;
   float* Zs = smem;                                  // [64][LD]  Z rows of the chunk
   float* Cs = smem + CC * LD + wave * (16 * LD);     // [16][LD]  this wave's strip of c
-  const float* Zg = a.sv_Z + (int64_t)c.row0 * FIN;
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * a.fstride + a.foff;
   const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
   const float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
   const float* sjp = a.sv_s + c.row0 + 4 * r;
@@ -1243,14 +1281,14 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  StageRegs pre = stage_load(Zg, FIN, 0);
+  StageRegs pre = stage_load(Zg, a.fstride, 0);
   Tiles cur = load_tiles(0);
 #pragma unroll 1
   for (int c0 = 0; c0 < n; c0 += CC) {
     __syncthreads();
     stage_store(Zs, pre);
     __syncthreads();
-    if (c0 + CC < n) pre = stage_load(Zg, FIN, c0 + CC);
+    if (c0 + CC < n) pre = stage_load(Zg, a.fstride, c0 + CC);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
@@ -1272,19 +1310,20 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
     strip_mma(acc, Cs, Zs, r, q);
   }
   // dZ_i = rowsum(c)_i Z_i - (c Z)_i -> workspace (for dM_L) and the A image of the product below
-  float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * FIN;
+  float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * a.fstride + a.foff;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float csum = row16_sum(cs[i]);
-    const f32x4 z = *reinterpret_cast<const f32x4*>(Zg + (int64_t)(c.i0 + 4 * q + i) * FIN + 4 * r);
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Zg + (int64_t)(c.i0 + 4 * q + i) * a.fstride + 4 * r);
     const f32x4 v = (f32x4){csum * z.x - acc[0][i], csum * z.y - acc[1][i], csum * z.z - acc[2][i], csum * z.w - acc[3][i]};
-    *reinterpret_cast<f32x4*>(dZg + (int64_t)(4 * q + i) * FIN + 4 * r) = v;
+    *reinterpret_cast<f32x4*>(dZg + (int64_t)(4 * q + i) * a.fstride + 4 * r) = v;
     *reinterpret_cast<f32x4*>(Cs + (4 * q + i) * LD + 4 * r) = v;
   }
   __builtin_amdgcn_wave_barrier();
+  if (a.fstride != FIN) return;       // 128-feature layer: dX += dZ M_L^T is a packed-row launch behind the two halves
   // dX[I] += dZ[I] M_L^T   (adjoint of graphconv.py:164): B[k][f] = M_L[f][k], the lane's M_L rows read along k; tile t
   // stands for the output columns 4r + t, so a lane's four results of a row are one 16-byte read-modify-write
-  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx;
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
   f32x4 d[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -1571,7 +1610,7 @@ bool cloud_path(const SgcArgs& a, bool quad) {
   // path or the reference produced from symmetric inputs): La is then symmetric and La^T g_1 is taken as La g_1
   const bool res_ok = a.variant != AGCN_SGC_LL_RESLAP ||
                       (a.sv_Lpre != nullptr && a.L_sum != nullptr && al16(a.sv_Lpre) && al16(a.L_prev) && al16(a.L_sum));
-  return cloud_env() && quad && a.Fin == FIN && a.K == 2 && (a.variant == AGCN_SGC_LL || a.variant == AGCN_SGC_LL_RESLAP) && res_ok &&
+  return cloud_env() && quad && (a.Fin == FIN || a.Fin == 2 * FIN) && a.K == 2 && (a.variant == AGCN_SGC_LL || a.variant == AGCN_SGC_LL_RESLAP) && res_ok &&
          a.L0_dense != nullptr && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && (a.Fout & 15) == 0 && al16(a.X) && al16(a.weight) &&
          al16(a.bias) && al16(a.M_L) && (a.n_slabs & 3) == 0;
 }
@@ -1583,7 +1622,10 @@ size_t cloud_dpart_floats(int64_t tile_elems) { return (size_t)(tile_elems / SIM
 int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t tile_elems, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const unsigned strips = (unsigned)(a.n_slabs / 4);
-  {
+  // 128-feature layers (the third / fourth convolution of the point-cloud network): Z = X M_L and the filter product are the
+  // caller's packed-row launches; the similarity takes all 128 features, the Laplacian kernel runs once per 64-column half of X_0
+  const bool wide = a.Fin == 2 * FIN;
+  if (!wide) {
     int rc0 = launch_cloud(cloud_project_kernel, dim3(strips), 256, 0, PK_PROJECT, "cloud_project", stream, a.X, a.ldx, a.M_L, a.sv_Z);
     if (rc0 != AGCN_OK) return rc0;
   }
@@ -1610,6 +1652,10 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
     // over resident waves: 75 against 79 us), beyond that the waves walk their lists
     const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>((int64_t)12 * n_cu, (tasks + 3) / 4 + 7) / 8 * 8);
     const size_t lds = sizeof(float) * 4 * (paper ? 2560 : 1280);
+    if (wide)
+      rc = paper ? launch_cloud(cloud_sim_kernel<true, SIM_RT, 128>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride)
+                 : launch_cloud(cloud_sim_kernel<false, SIM_RT, 128>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride);
+    else
     rc = paper ? launch_cloud(cloud_sim_kernel<true, SIM_RT>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride)
                : launch_cloud(cloud_sim_kernel<false, SIM_RT>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride);
   }
@@ -1628,11 +1674,20 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
     rc = paper ? launch_cloud(cloud_rlap1_kernel<true>, sgrid, 256, 0, PK_CLOUD_RLAP1, "cloud_rlap1", stream, a, (const float*)rpart, lpart)
                : launch_cloud(cloud_rlap1_kernel<false>, sgrid, 256, 0, PK_CLOUD_RLAP1, "cloud_rlap1", stream, a, (const float*)rpart, lpart);
     if (rc != AGCN_OK) return rc;
-    return paper ? launch_cloud(cloud_lap_kernel<true, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)rpart, (const float*)lpart)
-                 : launch_cloud(cloud_lap_kernel<false, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)rpart, (const float*)lpart);
   }
-  return paper ? launch_cloud(cloud_lap_kernel<true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)nullptr, (const float*)nullptr)
-               : launch_cloud(cloud_lap_kernel<false>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, a, (const float*)nullptr, (const float*)nullptr);
+  const bool res = a.variant == AGCN_SGC_LL_RESLAP;
+  for (int half = 0; half < (wide ? 2 : 1); ++half) {
+    SgcArgs ah = a;
+    ah.foff = 64 * half;
+    if (res)
+      rc = paper ? launch_cloud(cloud_lap_kernel<true, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)rpart, (const float*)lpart)
+                 : launch_cloud(cloud_lap_kernel<false, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)rpart, (const float*)lpart);
+    else
+      rc = paper ? launch_cloud(cloud_lap_kernel<true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)nullptr, (const float*)nullptr)
+                 : launch_cloud(cloud_lap_kernel<false>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)nullptr, (const float*)nullptr);
+    if (rc != AGCN_OK) return rc;
+  }
+  return AGCN_OK;
 }
 
 // The row-chunk partials of the parameter gradients (the caller runs param_grads.hip's reduce kernel behind it).
@@ -1659,9 +1714,10 @@ int launch_cloud_param_partials(const ParamGradArgs& a0, void* stream) {
 // nullptr when the forward of this call pair was the cloud forward (which left W^T in the reserve: a.sv_WT).
 int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
+  const bool wide = a.Fin == 2 * FIN;      // (128 features: the packed filter adjoint was the caller's launch; two halves)
   const unsigned strips = (unsigned)(a.n_slabs / 4);
   if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "cloud kernels: a gradient of L_sum is not supported");
-  {
+  if (!wide) {
     int rc0 = AGCN_OK;
     if (WT != nullptr)
       rc0 = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep",
@@ -1674,44 +1730,76 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
                        (const float*)WT, a.ws_Gp, a.dX, a.ldx, a.ws_g);
     if (rc0 != AGCN_OK) return rc0;
   }
-  if (!paper)
-    return launch_cloud(cloud_bwd1_ref_kernel, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD1,
-                        "cloud_bwd1", stream, a);
-  int rc = launch_cloud(cloud_bwd1_paper_kernel, dim3(xcd_grid((int)strips)), 256,
-                        sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H, PK_CLOUD_BWD1, "cloud_bwd1", stream, a);
-  if (rc != AGCN_OK) return rc;
-  return launch_cloud(cloud_bwd2_kernel, dim3(xcd_grid((int)strips)), 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2",
-                      stream, a);
+  const dim3 grid(xcd_grid((int)strips));
+  const size_t lds_f32 = sizeof(float) * (CC * LD + 4 * 16 * LD);
+  const size_t lds_bf = sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H;
+  int rc = AGCN_OK;
+  for (int half = 0; half < (wide ? 2 : 1) && rc == AGCN_OK; ++half) {
+    SgcArgs ah = a;
+    ah.foff = 64 * half; ah.half_acc = half; ah.half_last = (half == (wide ? 1 : 0)) ? 1 : 0;
+    if (!paper)
+      rc = launch_cloud(cloud_bwd1_ref_kernel, grid, 256, lds_f32, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
+    else if (!wide)
+      rc = launch_cloud(cloud_bwd1_paper_kernel<64, false>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
+    else
+      rc = half == 0 ? launch_cloud(cloud_bwd1_paper_kernel<128, false>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah)
+                     : launch_cloud(cloud_bwd1_paper_kernel<128, true>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
+  }
+  if (rc != AGCN_OK || !paper) return rc;
+  for (int half = 0; half < (wide ? 2 : 1) && rc == AGCN_OK; ++half) {
+    SgcArgs ah = a;
+    ah.foff = 64 * half;
+    rc = launch_cloud(cloud_bwd2_kernel, grid, 256, lds_f32, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+  }
+  return rc;
 }
 
 // SGC_LL_Reslap: the packed filter adjoint, then passes A, (B, backward 2 in paper mode,) C.  spart: 8 floats per 64-row strip.
 int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void* stream) {
   const bool paper = a.mode == AGCN_MODE_PAPER;
+  const bool wide = a.Fin == 2 * FIN;      // (128 features: the packed filter adjoint was the caller's launch; two halves per pass)
   const unsigned strips = (unsigned)(a.n_slabs / 4);
   int rc = AGCN_OK;
-  if (WT != nullptr)
-    rc = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep", stream,
-                      a.weight, WT, a.Fout, 2);
-  else
-    WT = a.sv_WT;
-  if (rc != AGCN_OK) return rc;
-  rc = launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD, "cloud_filter_bwd",
-                    stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0, (const float*)WT, a.ws_Gp, a.dX,
-                    a.ldx, a.ws_g);
-  if (rc != AGCN_OK) return rc;
-  const dim3 grid(xcd_grid((int)strips));
-  const size_t lds = sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H;
-  rc = paper ? launch_cloud(cloud_rbwd_kernel<0, true>, grid, 256, lds, PK_CLOUD_RBWD_A, "cloud_rbwdA", stream, a, spart)
-             : launch_cloud(cloud_rbwd_kernel<0, false>, grid, 256, lds, PK_CLOUD_RBWD_A, "cloud_rbwdA", stream, a, spart);
-  if (rc != AGCN_OK) return rc;
-  if (paper) {
-    rc = launch_cloud(cloud_rbwd_kernel<1, true>, grid, 256, lds, PK_CLOUD_RBWD_B, "cloud_rbwdB", stream, a, spart);
+  if (!wide) {
+    if (WT != nullptr)
+      rc = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep", stream,
+                        a.weight, WT, a.Fout, 2);
+    else
+      WT = a.sv_WT;
+    if (rc != AGCN_OK) return rc;
+    rc = launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD, "cloud_filter_bwd",
+                      stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0, (const float*)WT, a.ws_Gp, a.dX,
+                      a.ldx, a.ws_g);
     if (rc != AGCN_OK) return rc;
   }
-  rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, a, spart)
-             : launch_cloud(cloud_rbwd_kernel<2, false>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, a, spart);
+  const dim3 grid(xcd_grid((int)strips));
+  const size_t lds = sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H;
+  const int nh = wide ? 2 : 1;
+  auto args = [&](int half) {
+    SgcArgs ah = a;
+    ah.foff = 64 * half; ah.half_acc = half; ah.half_last = (half == nh - 1) ? 1 : 0;
+    return ah;
+  };
+#define AGCN_RBWD(PASS, PAPER, ID, NAME)                                                                                            \
+  for (int half = 0; half < nh && rc == AGCN_OK; ++half) {                                                                         \
+    const SgcArgs ah = args(half);                                                                                                  \
+    rc = !wide ? launch_cloud(cloud_rbwd_kernel<PASS, PAPER, 64, false>, grid, 256, lds, ID, NAME, stream, ah, spart)              \
+       : half == 0 ? launch_cloud(cloud_rbwd_kernel<PASS, PAPER, 128, false>, grid, 256, lds, ID, NAME, stream, ah, spart)         \
+                   : launch_cloud(cloud_rbwd_kernel<PASS, PAPER, 128, true>, grid, 256, lds, ID, NAME, stream, ah, spart);          \
+  }
+  if (paper) { AGCN_RBWD(0, true, PK_CLOUD_RBWD_A, "cloud_rbwdA") } else { AGCN_RBWD(0, false, PK_CLOUD_RBWD_A, "cloud_rbwdA") }
+  if (rc != AGCN_OK) return rc;
+  if (paper) { AGCN_RBWD(1, true, PK_CLOUD_RBWD_B, "cloud_rbwdB") }
+  if (rc != AGCN_OK) return rc;
+  if (paper) { AGCN_RBWD(2, true, PK_CLOUD_RBWD_C, "cloud_rbwdC") } else { AGCN_RBWD(2, false, PK_CLOUD_RBWD_C, "cloud_rbwdC") }
+#undef AGCN_RBWD
   if (rc != AGCN_OK || !paper) return rc;
-  return launch_cloud(cloud_bwd2_kernel, grid, 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, a);
+  for (int half = 0; half < nh && rc == AGCN_OK; ++half) {
+    SgcArgs ah = a;
+    ah.foff = 64 * half;
+    rc = launch_cloud(cloud_bwd2_kernel, grid, 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+  }
+  return rc;
 }
 
 }  // namespace agcn

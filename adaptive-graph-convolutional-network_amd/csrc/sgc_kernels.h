@@ -72,6 +72,12 @@ struct SgcArgs {
   // fused backward kernel (saves a memset node in front of it)
   int32_t* zero_ptr;
   int32_t zero_count;
+  // point-cloud kernels (cloud_kernels.hip) on layers of 128 input features: the strip kernels work on 64 feature columns at a
+  // time -- `foff` = first column of the half (0 / 64), `fstride` = row stride of the packed feature arrays (Z, g_1, X_1, dZ: Fin)
+  // -- and run once per half.  Everything that couples the halves is linear in the per-half products, so the second run ADDS
+  // (`half_acc`: n x n outputs read-modify-write, per-graph sums and ds added to the first run's); `half_last` = this run
+  // finishes the quantities that need both halves (dd).  64-feature layers: foff 0, fstride 64, half_acc 0, half_last 1.
+  int32_t foff, fstride, half_acc, half_last;
 };
 
 enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3, RG_DENSE = 4 };

@@ -1057,7 +1057,8 @@ def _sym_prev(rs, n, scale=0.05):
     return ((A + A.T) * np.float32(0.5)).astype(np.float32)
 
 
-@pytest.mark.parametrize("case", ["first_layer_of_a_block", "inner_layer", "xyz_first_layer", "narrow_sgc_ll", "unvouched_prev"])
+@pytest.mark.parametrize("case", ["first_layer_of_a_block", "inner_layer", "xyz_first_layer", "narrow_sgc_ll", "unvouched_prev",
+                                  "wide_inner_layer", "wide_sgc_ll"])
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
 def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     """SGC_LL_Reslap at point-cloud sizes -- the layer every convolution of the reference's point-cloud network is
@@ -1073,6 +1074,8 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     # (which take La^T g_1 as La g_1) for the general per-graph path and still be right
     inner = case in ("inner_layer", "unvouched_prev")
     sizes = [256, 128, 320] if inner else ([1024, 64] if Fin == 64 else [512, 192])
+    if variant == orc.SGC_LL_RESLAP and not inner and Fin == 64:
+        sizes = [1024, 64]
     rs = np.random.RandomState(9100 + len(sizes) + Fin)
     Xs, Ls, Gs = [], [], []
     for n in sizes:
@@ -1113,7 +1116,7 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     loss.backward()
     if case == "unvouched_prev":
         pass
-    elif Fin == 64:
+    elif Fin >= 64:
         info = amd._ffi.dispatch_info(layer, gb)
         assert (info[0] & 64) != 0, "point-cloud kernels expected (forward path bits %d)" % info[0]
     else:

@@ -177,6 +177,31 @@ def main():
         gb, n = modelnet_batch(amd, args.modelnet_batch, 1024, Fin, dev)
         run_layer(name, gb, n, 0, Fin, Fout, True)
 
+    if want("modelnet-128-128"):
+        # the network's third convolution (l_n_filters = [64, 128, 128, 64]): 128 input features, SGC_LL
+        gb, n = modelnet_batch(amd, args.modelnet_batch, 1024, 128, dev)
+        run_layer("modelnet-128-128", gb, n, 0, 128, 128, True)
+
+    if want("modelnet-reslap-128"):
+        gb, n = modelnet_batch(amd, args.modelnet_batch, 1024, 128, dev)
+        layer = amd.SGC_LL_Reslap(128, 128, len(n), K=K, laplacian_mode=args.mode, device=dev)
+        layer.load_vars(synth.glorot_params(np.random.RandomState(123), 128, 128, K, reslap=True))
+        g = torch.Generator(device="cpu").manual_seed(5)
+        Lp = (0.05 * torch.randn(len(n), 1024, 1024, generator=g))
+        Lp = (0.5 * (Lp + Lp.transpose(1, 2))).reshape(-1).to(dev)
+        dY = torch.from_numpy(np.random.RandomState(7).randn(gb.plan.rows, 128).astype(np.float32)).to(dev)
+        st = amd.SgcLLStep(layer, gb, L_prev=Lp, dY=dY, L_prev_symmetric=True)
+        if args.eager:
+            t = timed(st.step, args.steps, args.warmup, dev)
+        else:
+            st.capture()
+            t = timed(st.replay, args.steps, args.warmup, dev)
+        out = {"workload": "modelnet-reslap 128->128 with L_prev", "mode": args.mode, "graphs": int(len(n)),
+               "N2": int(np.sum(np.asarray(n, np.int64) ** 2)), "us_per_step": round(t * 1e6, 2), "graphs_per_s": round(len(n) / t, 1)}
+        if args.prof:
+            out["kernel_us"] = kernel_profile(amd, st.step, 20, dev)
+        print(json.dumps(out), flush=True)
+
     if want("modelnet-reslap"):
         # the layer the reference's point-cloud network is made of (Point_AGCN.py:37-71: SGC_LL_Reslap throughout), hidden width,
         # with the previous layer's (symmetric) Laplacian coming in and a gradient arriving on L_sum
