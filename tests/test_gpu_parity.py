@@ -1162,6 +1162,8 @@ def test_point_cloud_kernels_random_batches(amd, seed):
     sizes = [int(64 * rs.randint(1, 8)) for _ in range(int(rs.randint(1, 8)))]
     variant = orc.SGC_LL_RESLAP if seed % 2 == 0 else orc.SGC_LL
     Fin, Fout = (3, 64) if seed % 3 == 0 and variant == orc.SGC_LL else (64, 128 if seed % 2 else 64)
+    if seed in (4, 5):
+        Fin, Fout = 128, 64          # the 128-feature layers (two feature halves per strip kernel)
     K, mode = 2, orc.PAPER
     Xs, Ls, Gs = [], [], []
     for n in sizes:
