@@ -1213,9 +1213,11 @@ def test_point_cloud_kernels_random_batches(amd, seed):
     if Fin == 3:
         assert prof["slab_sim_kernel"][1] == 1 and prof["slab_bwd1_kernel"][1] == 2, prof     # (pair kernel + its reduce)
     elif reslap:
-        assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_rlap1_kernel"][1] == 1 and prof["cloud_rbwd_kernel<B>"][1] == 1, prof
+        nh = 2 if Fin == 128 else 1      # (128 features: every strip kernel behind the similarity once per 64-column half)
+        assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_rlap1_kernel"][1] == 1 and prof["cloud_rbwd_kernel<B>"][1] == nh, prof
     else:
-        assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_bwd1_kernel"][1] == 1, prof
+        nh = 2 if Fin == 128 else 1
+        assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_bwd1_kernel"][1] == nh, prof
     caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs)
     tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32)[1]
     k = float(np.sqrt(max(sizes) / 64.0))
