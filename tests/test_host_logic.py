@@ -289,16 +289,22 @@ def test_member_budget_knob_and_cloud_dispatch(amd):
     assert _dispatch(amd, clouds, 64, 128, 1)["path"] == 16          # CSR L_orig: the general slab kernels
     import ctypes as C
 
-    def path(n_arr, Fin, Fout):
+    def path(n_arr, Fin, Fout, variant=0, l_prev=None, prev_sym=0):
         n_arr = np.ascontiguousarray(n_arr, np.int32)
         nb = lib.agcn_plan_bytes_for(n_arr.ctypes.data, n_arr.size, 0)
         pl = np.zeros(nb, np.uint8)
         assert lib.agcn_plan_build(n_arr.ctypes.data, n_arr.size, 0, pl.ctypes.data, nb) == 0
-        desc = amd._ffi.LayerDesc(Fin, Fout, 2, 1, 0, 1, Fin, Fout)
-        gb = amd._ffi.GraphBatch(pl.ctypes.data, 1, 1, 1, 0, 1, None, None, None, None)      # dense L_orig, symmetric
+        desc = amd._ffi.LayerDesc(Fin, Fout, 2, 1, variant, 1, Fin, Fout)
+        gb = amd._ffi.GraphBatch(pl.ctypes.data, 1, 1, 1, 0, 1, None, None, None, l_prev, prev_sym, 0)   # dense L_orig, symmetric
         out = (C.c_int32 * 8)()
         assert lib.agcn_sgc_ll_dispatch_info(C.byref(desc), C.byref(gb), out, 8) == 0
         return out[0]
+    # SGC_LL_Reslap (the layer of the reference's point-cloud network) and the 128-feature layers take the point-cloud kernels
+    # too; a previous Laplacian must be vouched symmetric (AgcnGraphBatch.L_prev_symmetric), else the general per-graph path
+    assert path(clouds, 64, 128, variant=1) & 64 and path(clouds, 128, 128, variant=1) & 64 and path(clouds, 128, 64) & 64
+    assert path(clouds, 64, 128, variant=1, l_prev=1, prev_sym=1) & 64
+    assert path(clouds, 64, 128, variant=1, l_prev=1, prev_sym=0) == 32
+    assert path([300, 257], 128, 128, variant=1) == 32            # not multiples of 64
     assert path(clouds, 64, 128) == 16 | 64
     assert path([512, 256, 320, 64], 64, 128) == 16 | 64
     assert path([300, 257, 519, 131], 64, 128) == 16          # not multiples of 64: general slab kernels
