@@ -491,7 +491,8 @@ static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, con
   if (d->variant == AGCN_SGC_LL)
     return agcn_get_slab_mode() != 0 && d->K == 2 && pi.rows == pi.N1 && g->L0_dense != nullptr && g->L0_rowptr == nullptr &&
            g->L0_symmetric == 1;
-  return agcn_get_slab_mode() != 0 && d->variant == AGCN_SGC_LL_RESLAP && d->K == 2 && pi.rows == pi.N1 &&
+  // (the Reslap kernels add a graph's per-strip partial sums with one lane per 64-row strip: graphs of up to 4096 nodes)
+  return agcn_get_slab_mode() != 0 && d->variant == AGCN_SGC_LL_RESLAP && d->K == 2 && pi.rows == pi.N1 && pi.max_n <= 4096 &&
          g->L0_dense != nullptr && g->L0_rowptr == nullptr && g->L0_symmetric == 1 &&
          (g->L_prev == nullptr || g->L_prev_symmetric == 1);
 }

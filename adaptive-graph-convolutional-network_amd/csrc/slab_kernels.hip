@@ -1660,7 +1660,8 @@ int launch_slab_backward(const SgcArgs& a, void* stream, int32_t max_n) {
     if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "slab path: a gradient of L_sum is not supported (SGC_LL only)");
     // clouds of multiples of 64 points, paper mode: each unordered pair once (small_sym_kernel)
     static const int sym_env = [] { const char* e = std::getenv("AGCN_SMALL_SYM"); return e ? std::atoi(e) : 1; }();
-    if (sym_env && paper && a.slab_quad != 0 && max_n >= 64 && a.pg_slab_base == 0 && a.ws_dA && a.ws_dAt && (a.n_slabs & 3) == 0) {
+    // (one dalpha partial per task lives in the second tile-sized scratch: B * ncb_max^2 floats, within it for B <= 4096)
+    if (sym_env && paper && a.slab_quad != 0 && max_n >= 64 && a.B <= 4096 && a.pg_slab_base == 0 && a.ws_dA && a.ws_dAt && (a.n_slabs & 3) == 0) {
       switch (a.Fin) {
         case 1: return launch_small_sym<1>(a, max_n, stream);
         case 2: return launch_small_sym<2>(a, max_n, stream);
