@@ -1,8 +1,9 @@
-// Point-cloud ("cloud") kernels: SGC_LL, K = 2, hidden-layer width Fin = 64, DENSE symmetric L_orig, every graph a
-// multiple of 64 nodes (ModelNet-shaped batches, n = 1024: BASELINE config 3, the "MFMA A.X path").  Same math as
-// slab_kernels.hip (graphconv.py:163-236 and its TF autodiff) -- the n x n work of a graph cut into row strips walked
-// in 64-column chunks -- rebuilt around what the general slab kernels measured as their limits at this size
-// (profiles/r03a_modelnet_baseline_*: bwd1 358 us at 23 % matrix-pipe utilisation and 700 MB of traffic):
+// Point-cloud ("cloud") kernels: SGC_LL and SGC_LL_Reslap, K = 2, 64 or 128 input features, DENSE symmetric L_orig, every
+// graph a multiple of 64 nodes (ModelNet-shaped batches, n = 1024: BASELINE config 3, the "MFMA A.X path"; the layers of
+// models/networks/Point_AGCN.py).  Same math as slab_kernels.hip (graphconv.py:163-236, graphconv_reslap.py:136-230 and their
+// TF autodiff) -- the n x n work of a graph cut into row strips walked in 64-column chunks -- rebuilt around what the general
+// slab kernels measured as their limits at this size (profiles/r03a_modelnet_baseline_*: bwd1 358 us at 23 % matrix-pipe
+// utilisation and 700 MB of traffic):
 //
 //  * 64-row strips, one wave per 16 rows.  The chunk's 64 rows of X_0 / g_1 / Z (the B operands of every product) are
 //    staged in LDS ONCE per workgroup and chunk with fully coalesced 16-byte loads and serve four waves (the 16-row
@@ -18,11 +19,16 @@
 //  * the backward keeps ONE n x n tile between its two kernels instead of two: only Q_ij = dA_ij + dA_ji is ever used
 //    (ds_i = sum_j Q_ij S_ij s_j, c_ij = -S_ij (Q_ij s_i s_j + dd_i + dd_j) / r_ij, dalpha = 1/2 sum P_ij min(R_ij, 0)
 //    with P = dL + dL^T: R and S are symmetric), and P is ONE product of depth 2 Fin: [g_1 | X_0][I] . [X_0 | g_1][J]^T.
-//  * the similarity kernel keeps a column's Z row in 64 registers and reads the row operand through the SCALAR cache
-//    (uniform address, constant address space -> s_load): two vector instructions per pair and feature, no LDS at all
-//    (the LDS-staged 4 x 2 register blocks of slab_sim are bound by LDS bandwidth: 198 us against 58 us of issue time).
-//    Column sums over a wave's 64 rows are complete per (row block, column) and go out as partial degrees; a tiny
-//    kernel adds the n / 64 partials of a node in fixed order (S is bit-symmetric: column sums == row sums).
+//  * the similarity is computed ONCE per unordered pair (tasks of 32 rows x 64 columns of the blocks on / above the diagonal,
+//    one wave each): a lane keeps its column's Z row in registers and reads the row operand through the SCALAR cache
+//    (uniform address -> s_load): two vector instructions per pair and feature; both orientations of a block leave as
+//    16-byte stores through wave-private LDS patches; partial degrees per (row block piece, column), added by a tiny kernel.
+//  * the backward products of paper mode run on the BF16 matrix pipe at fp32 accuracy: operands split exactly into three bf16
+//    pieces, six v_mfma_f32_16x16x32_bf16 per 32 k (cloud_bwd1_paper_kernel, cloud_rbwd_kernel).
+//  * SGC_LL_Reslap: its two clip_by_norm stages become extra strip passes (graph-wide sums as per-strip partials), and
+//    because the clip adjoints are linear in their inner products ONE backward pass collects every graph-wide sum.
+//  * 128 input features: the strip kernels run once per 64-column half (SgcArgs::foff / fstride / half_acc); what couples the
+//    halves is linear in the per-half products, so the second run adds to the first one's outputs.
 // Reductions are per-lane sequential + fixed shuffle trees: bit-reproducible.  No floating-point atomics.
 #include "agcn_device.h"
 #include "sgc_kernels.h"
