@@ -35,7 +35,6 @@
 
 #include <float.h>
 
-#include <atomic>
 #include <cstdlib>
 
 namespace agcn {
@@ -1637,18 +1636,11 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
     if (rc0 != AGCN_OK) return rc0;
   }
   const int ncb = std::max(1, (int)max_n / CS);   // column blocks of the largest graph
-  // CU count of the CURRENT device (cached per device: a process may drive several parts)
-  const int n_cu = [] {
-    static std::atomic<int> cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
-    int cu = cache[dev].load(std::memory_order_relaxed);
-    if (cu == 0) {
-      if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cu = 256; }
-      cu = std::max(8, cu);
-      cache[dev].store(cu, std::memory_order_relaxed);
-    }
-    return cu;
+  static const int n_cu = [] {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+    (void)hipGetLastError();
+    return std::max(8, cu);
   }();
   const int ns = CS / SIM_RT;
   int rc;
