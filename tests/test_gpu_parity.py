@@ -1164,7 +1164,7 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
         assert not any(k_.startswith(("sgc_forward", "sgc_backward", "fused_", "spec_", "slab_")) for k_ in prof), prof
         if vname == "reslap":
             assert prof["cloud_rlap1_kernel"][1] == 1, prof
-    caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs)
+    caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, Y_tie=to_np(nodes.data))
     k = float(np.sqrt(max(sizes) / 64.0))
     Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
     for b, n in enumerate(sizes):
@@ -1181,7 +1181,7 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
     assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight", atol_ulps=GRAD_ULPS * k)
     assert_close(to_np(layer.vars["bias"].grad), tot["dbias"], GRAD_RTOL, "dbias", atol_ulps=GRAD_ULPS * k)
     scale = float(np.abs(tot["dweight"]).max())
-    tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32)[1]
+    tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32, Y_tie=to_np(nodes.data))[1]
     from helpers import _scalar_close
     _scalar_close(to_np(layer.vars["alpha"].grad), tot["dalpha"], tot32["dalpha"], scale, "dalpha")
     if mode == orc.PAPER:
@@ -1265,8 +1265,8 @@ def test_point_cloud_kernels_random_batches(amd, seed, mode):
     else:
         nh = 2 if Fin == 128 else 1
         assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_bwd1_kernel"][1] == nh, prof
-    caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs)
-    tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32)[1]
+    caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, Y_tie=to_np(nodes.data))
+    tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32, Y_tie=to_np(nodes.data))[1]
     k = float(np.sqrt(max(sizes) / 64.0))
     Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
     for b, n in enumerate(sizes):
