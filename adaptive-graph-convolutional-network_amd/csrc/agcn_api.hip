@@ -15,6 +15,26 @@
 #include "spec_kernels.h"
 
 namespace agcn {
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> g_cus_of[MAX_DEVICES];
+std::atomic<uint32_t*> g_status_of[MAX_DEVICES];
+}  // namespace
+DeviceInfo current_device_info() {
+  DeviceInfo d{256, nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES) {
+    int v = g_cus_of[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+      (void)hipGetLastError();
+      g_cus_of[dev].store(v, std::memory_order_relaxed);
+    }
+    d.n_cus = v;
+    d.status_word = g_status_of[dev].load(std::memory_order_relaxed);
+  }
+  return d;
+}
 
 namespace {
 
@@ -157,20 +177,8 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   // runs 12 us itself, so only graphs whose own chain is much longer than that 24 us pay: five tiles and up
   // (the n = 95 graph of an 8-GPU shard: backward 46.2 -> 26.3 us; B = 256 with n <= 59: nothing to gain, measured).
   static const int min_force = [] { const char* e = std::getenv("AGCN_COOP_MIN_N"); return e ? std::atoi(e) : 0; }();
-  // CU count of the CURRENT device (the thresholds below rest on "members fit the chip"): cached per device id
-  int n_cus = 256;
-  {
-    static std::atomic<int> cus_of[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-      int v = cus_of[dev].load(std::memory_order_relaxed);
-      if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus_of[dev].store(v, std::memory_order_relaxed);
-      }
-      n_cus = v;
-    }
-  }
+  // CU count of the CURRENT device (the thresholds below rest on "members fit the chip")
+  const int n_cus = current_device_info().n_cus;
   const int member_budget = std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members());
   // (with two and more rounds of workgroups per CU the tail graph matters less than the extra workgroups cost:
   //  512 graphs: 6.0 M graphs/s without, 5.7 M with members for its one 70-node graph)
@@ -473,6 +481,32 @@ extern "C" int agcn_sgc_ll_reserve_status(const void* reserve, size_t reserve_by
   return AGCN_OK;
 }
 
+extern "C" int agcn_set_device_status_word(int32_t device, void* word) {
+  if (device < 0 || device >= MAX_DEVICES) return fail(AGCN_EINVAL, "agcn_set_device_status_word: device %d out of range", device);
+  if (word != nullptr && (reinterpret_cast<uintptr_t>(word) & 3) != 0) return fail(AGCN_EINVAL, "agcn_set_device_status_word: unaligned word");
+  g_status_of[device].store(static_cast<uint32_t*>(word), std::memory_order_relaxed);
+  return AGCN_OK;
+}
+
+extern "C" int agcn_device_status(int32_t device, void* hip_stream, int32_t* timeouts) {
+  const char* who = "agcn_device_status";
+  if (device < 0 || device >= MAX_DEVICES || !timeouts) return fail(AGCN_EINVAL, "%s: bad argument", who);
+  *timeouts = 0;
+  const uint32_t* word = g_status_of[device].load(std::memory_order_relaxed);
+  if (word == nullptr) return AGCN_OK;       // nothing registered: nothing to report
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  uint32_t v = 0;
+  hipError_t e = hipMemcpyAsync(&v, word, sizeof(v), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: %s", who, hipGetErrorString(e));
+  *timeouts = (int32_t)v;
+  if (v != 0)
+    return fail(AGCN_EDEVICE, "%s: %u wait(s) between the workgroups that share a large graph ran out on device %d since the "
+                "status word was last zeroed (members not co-resident, see agcn_set_coop_members); the results of those steps "
+                "are NaN", who, v, device);
+  return AGCN_OK;
+}
+
 extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
   AgcnPlanInfo pi;
   if (check_desc(desc, "agcn_sgc_ll_reserve_bytes") != AGCN_OK || agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;
@@ -593,6 +627,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
+  a.dev_status = current_device_info().status_word;
+  a.coop_ticks = agcn_get_coop_timeout_ticks();
   a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
   a.tp_first = host.info.B - 1;
 
@@ -801,6 +837,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
+  a.dev_status = current_device_info().status_word;
+  a.coop_ticks = agcn_get_coop_timeout_ticks();
   a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
   a.tp_first = host.info.B - 1;
   a.dY = dY; a.dL_sum = dL_sum; a.dX = grads->dX; a.dL_prev = has_prev ? grads->dL_prev : nullptr;
@@ -830,10 +868,17 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   if (reslap && !fused && w.WT && w.spart && cloud_candidate(desc, batch, host.info)) {
     SgcArgs t = a;
     t.n_slabs = host.info.n_slabs;
-    cloud_res = cloud_path(t, slab_quad_ok(host) != 0) && (reinterpret_cast<uintptr_t>(fwd->Y) & 15) == 0 &&
-                (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 &&
+    // the forward's own predicate (forward_impl: cloud_candidate, cloud_shape -> workspace, cloud_path, Y aligned) ...
+    const bool fwd_cloud = cloud_shape(desc) && cloud_path(t, slab_quad_ok(host) != 0) && (reinterpret_cast<uintptr_t>(fwd->Y) & 15) == 0;
+    // ... and what the backward passes need on top of it.  A point-cloud forward leaves L_pre, the scales and the r tiles the
+    // way ITS backward reads them; nothing tests the per-graph backward behind it, so a call that cannot take the
+    // point-cloud backward is refused instead of silently pairing the two.
+    cloud_res = fwd_cloud && (reinterpret_cast<uintptr_t>(grads->dX) & 15) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(dL_sum) & 15) == 0 &&
                 (!has_prev || (reinterpret_cast<uintptr_t>(grads->dL_prev) & 15) == 0);
+    if (fwd_cloud && !cloud_res)
+      return fail(AGCN_EINVAL, "%s: this batch took the point-cloud forward kernels; their backward needs 16-byte aligned dX, dY, "
+                  "dL_sum and dL_prev", who);
   }
   // arrival counters of the one-pass parameter-gradient kernel: zeroed by the first kernel of this call
   int32_t n_counters = 0;

@@ -74,6 +74,12 @@ inline int plan_view(const void* plan_host, const void* base, PlanView* v) {
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+// Per-device facts of the CURRENT HIP device (agcn_api.hip; cached per device id, lock-free): its CU count -- the grids and
+// the cooperative-member budget are sized for the device a call runs on, not the one the process saw first -- and the
+// caller-registered persistent status word (agcn_set_device_status_word), or nullptr.
+struct DeviceInfo { int n_cus; uint32_t* status_word; };
+DeviceInfo current_device_info();
+
 }  // namespace agcn
 
 #endif  // AGCN_INTERNAL_H_

@@ -1636,12 +1636,7 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
     if (rc0 != AGCN_OK) return rc0;
   }
   const int ncb = std::max(1, (int)max_n / CS);   // column blocks of the largest graph
-  static const int n_cu = [] {
-    int dev = 0, cu = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
-    (void)hipGetLastError();
-    return std::max(8, cu);
-  }();
+  const int n_cu = std::max(8, current_device_info().n_cus);   // (of the device this call runs on)
   const int ns = CS / SIM_RT;
   int rc;
   {

@@ -43,6 +43,9 @@ struct SgcArgs {
   // exchange words of the cooperative backward (spec_backward_coop.h): [B][97] 64-bit words, zeroed per graph by the
   // specialised forward kernel
   uint64_t* sv_xch;
+  uint32_t* dev_status; // the device's persistent status word (agcn_set_device_status_word) or nullptr: a wait that runs out
+                        // counts itself there as well (it outlives the reserve)
+  uint32_t coop_ticks;  // bound of such a wait in ticks of the 100 MHz constant clock (agcn_set_coop_timeout_ticks)
   int32_t coop_slabs;   // 16-wave launch: its first coop_slabs workgroups are members (slabs of the plan's slab table),
   int32_t plain_count;  // the next plain_count one graph each, the rest TWO small graphs each (spec_forward.hip)
   int32_t dual_stride;  // floats of LDS between the two halves of such a workgroup

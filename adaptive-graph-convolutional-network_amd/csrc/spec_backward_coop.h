@@ -49,17 +49,18 @@ constexpr int COOP_HEADER_WORDS = 2 * COOP_DIR_WORDS;
 // library never clears it; agcn_sgc_ll_reserve_status reads it) and poisons the value it was waiting for with NaN: a
 // timed-out step is wrong loudly, in the gradients AND in the return code of the next status check, never silently.
 constexpr int COOP_STATUS_WORD = COOP_HEADER_WORDS;     // 64-bit word index inside the reserve header
-constexpr unsigned long long COOP_TIMEOUT_TICKS = 1000000ull;   // 10 ms at 100 MHz
-__device__ __forceinline__ uint64_t coop_wait_word(uint64_t* status, const uint64_t* word, uint32_t want, bool* ok) {
+constexpr unsigned COOP_TIMEOUT_TICKS = 1000000u;   // 10 ms at 100 MHz: the default of agcn_set_coop_timeout_ticks (SgcArgs::coop_ticks)
+__device__ __forceinline__ uint64_t coop_wait_word(uint64_t* status, uint32_t* dev_status, uint32_t ticks, const uint64_t* word, uint32_t want, bool* ok) {
   const unsigned long long t0 = wall_clock64();
   uint64_t w;
   for (;;) {
     w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((uint32_t)(w >> 32) == want) { *ok = true; return w; }
-    if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS) break;
+    if (wall_clock64() - t0 >= (unsigned long long)ticks) break;
     __builtin_amdgcn_s_sleep(2);
   }
   __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (dev_status != nullptr) __hip_atomic_fetch_add(dev_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   *ok = false;
   return w;
 }
@@ -393,7 +394,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   // the other members' dd: poll their words until the flag is this backward's
   if (tid < n && (tid < i0 || tid >= i0 + 16)) {
     bool got;
-    const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, xch + tid, wants[tid >> 4], &got);
+    const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, a.dev_status, a.coop_ticks, xch + tid, wants[tid >> 4], &got);
     ddv[tid] = got ? __uint_as_float((uint32_t)w) : __builtin_nanf("");   // (a wait that ran out is loud: NaN + status word)
   }
   lds_barrier();
@@ -706,7 +707,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   if (tid < n4 && (!paper || tid >= n)) s_vec[tid] = 0.f;
   if (paper && tid < n && (tid < i0 || tid >= i0 + 16)) {
     bool got;
-    const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, xch + tid, wants[tid >> 4], &got);
+    const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, a.dev_status, a.coop_ticks, xch + tid, wants[tid >> 4], &got);
     s_vec[tid] = got ? __uint_as_float((uint32_t)w) : __builtin_nanf("");
   }
   {   // the strip's rows of res_W and r, and s: out behind the exchange

@@ -349,8 +349,12 @@ class SgcLLEpochLanes(object):
         # All member workgroups of the launches in flight must be resident together (csrc/spec_backward_coop.h): the
         # library's budget of 120 per launch is sized for two concurrent launches; with more lanes it is divided
         # (process-wide knob, include/agcn.h agcn_set_coop_members).
+        # The knob is process-wide: the previous value comes back with close() / the end of a `with` block / the object's
+        # death, so that step objects built later get the full budget again.
+        self._prev_members = None
         if lanes > 2:
-            _ffi.lib().agcn_set_coop_members(min(_ffi.lib().agcn_get_coop_members(), 240 // lanes))
+            self._prev_members = _ffi.lib().agcn_get_coop_members()
+            _ffi.lib().agcn_set_coop_members(min(self._prev_members, 240 // lanes))
         self.streams = _overlapping_streams(self.device, lanes)
         self._j = 0
         torch.cuda.synchronize(self.device)      # buffers, parameters and the store were filled on other streams
@@ -360,6 +364,27 @@ class SgcLLEpochLanes(object):
         self._j += 1
         s = self.streams[k]
         return self.steps[k].step(self.rstore.stage(graph_ids, lane=k, stream=s), dY, stream=s)
+
+    def close(self):
+        """Waits for the lanes and gives the cooperative-member budget back (only lanes > 2 lowered it)."""
+        if self._prev_members is not None:
+            for s in self.streams:
+                s.synchronize()
+            _ffi.lib().agcn_set_coop_members(self._prev_members)
+            self._prev_members = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def synchronize(self, check=True):
         """Waits for every lane and (check=True) raises AgcnError if a cooperative wait ran out on any of them."""

@@ -1,10 +1,8 @@
 """torch.autograd bridge to the C ABI: one forward / one backward call per layer for the
 whole batch.  PyTorch is used for device memory, streams and autograd bookkeeping only --
 all arithmetic happens in the HIP library (there is no eager fallback)."""
-import collections
 import ctypes as C
 import functools
-import weakref
 
 import torch
 
@@ -167,21 +165,39 @@ def _sizes(plan, cfg, ldx, ldy):
     return hit
 
 
-# Reserves of recent autograd calls (weak: a reserve dies with its autograd graph): check_device_status() reads their
-# status words.  Bounded: a training loop that never checks does not grow it.
-_recent_reserves = collections.deque(maxlen=256)
+# One persistent status word per device, registered with the library (include/agcn.h: agcn_set_device_status_word): a wait
+# between the workgroups that share a large graph that runs out counts itself there.  The reserves of the autograd path die
+# with their autograd graph -- right after backward() --, so the count has to live somewhere that outlives them (the weak
+# references this module kept until round 3 were all dead by the time a training loop looked at them).
+_status_words = {}
+
+
+def _status_word(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _status_words.get(idx)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        _ffi.check(_ffi.lib().agcn_set_device_status_word(idx, w.data_ptr()))
+        _status_words[idx] = w
+    return w
 
 
 def check_device_status():
-    """Synchronises the devices of the recent SGC_LL autograd calls and raises AgcnError if a wait between the workgroups
-    that share a large graph ran out in any of them (include/agcn.h: agcn_sgc_ll_reserve_status) -- their gradients are NaN
-    then.  Call it where the training loop synchronises anyway (reading the loss).  Returns the number of reserves checked."""
+    """Synchronises the devices that ran SGC_LL autograd calls and raises AgcnError if a wait between the workgroups that share
+    a large graph ran out in any call since the last check -- forward OR backward: the count is kept in a persistent word per
+    device, not in the reserves (which autograd frees once backward has run).  The gradients of such a step are NaN.  Call it
+    where the training loop synchronises anyway (reading the loss).  Returns the number of devices checked; the word is
+    cleared when an error is raised, so that one bad step is reported once."""
     n = 0
-    while _recent_reserves:
-        r = _recent_reserves.popleft()()
-        if r is not None:
-            _ffi.reserve_status(r)
-            n += 1
+    for idx, w in list(_status_words.items()):
+        with torch.cuda.device(idx):
+            t = C.c_int32(0)
+            rc = _ffi.lib().agcn_device_status(idx, torch.cuda.current_stream(idx).cuda_stream, C.byref(t))
+            if rc != 0:
+                msg = _ffi.lib().agcn_last_error().decode()
+                w.zero_()
+                raise _ffi.AgcnError("agcn error %d: %s" % (rc, msg))
+        n += 1
     return n
 
 
@@ -210,6 +226,7 @@ class SgcLLFunction(torch.autograd.Function):
                 raise ValueError("L_prev given without beta")
             beta = _f32c(beta, "beta")
         dev = X.device
+        _status_word(dev)
         ldx, ldy = X.shape[1], cfg.Fout
         Y = torch.empty((plan.rows, ldy), dtype=torch.float32, device=dev)
         res_L = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
@@ -225,7 +242,6 @@ class SgcLLFunction(torch.autograd.Function):
         out = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(out),
                                            reserve.data_ptr(), rbytes, ws.data_ptr(), wbytes, _stream(dev)))
-        _recent_reserves.append(weakref.ref(reserve))
         ctx.batch, ctx.cfg, ctx.has_prev, ctx.has_beta = batch, cfg, (reslap and L_prev is not None), beta is not None
         ctx.save_for_backward(X, weight, bias, M_L, alpha, beta, L_prev if reslap else None,
                               Y, res_L, res_W, L_sum, reserve)

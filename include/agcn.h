@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AGCN_VERSION 102 /* 0.1.2: AgcnGraphBatch.L_prev_symmetric */
+#define AGCN_VERSION 103 /* 0.1.3: agcn_set_device_status_word / agcn_device_status */
 
 enum {
   AGCN_OK = 0,
@@ -211,6 +211,13 @@ size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_hos
  * when it is 0, AGCN_EDEVICE otherwise (every result computed with this reserve since the header was last zeroed is
  * suspect; zero the header to re-arm). */
 int agcn_sgc_ll_reserve_status(const void* reserve, size_t reserve_bytes, void* hip_stream, int32_t* timeouts);
+/* The same count, kept where it outlives the reserve.  A caller whose reserves are short-lived (an autograd graph frees
+ * them as soon as backward has run) registers ONE 4-byte device word per device -- caller-owned, zeroed by the caller, alive
+ * until it is unregistered with NULL --; every wait that runs out in a later call ON THAT DEVICE counts itself there too.
+ * agcn_device_status copies the word to the host on `hip_stream` and waits for it, like agcn_sgc_ll_reserve_status:
+ * AGCN_OK when 0 (or when nothing is registered), AGCN_EDEVICE otherwise.  The library never clears the word. */
+int agcn_set_device_status_word(int32_t device, void* word);
+int agcn_device_status(int32_t device, void* hip_stream, int32_t* timeouts);
 size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 
@@ -457,6 +464,11 @@ void agcn_set_spec_small(int32_t on);
  * to [0, 120].  Process-wide, like the other knobs. */
 int32_t agcn_get_coop_members(void);
 void agcn_set_coop_members(int32_t members);
+/* Bound of a member's wait for a sibling's word, in ticks of the device's 100 MHz constant clock (default 1 000 000 = 10 ms:
+ * three orders of magnitude beyond a step).  0 makes every wait that is not satisfied by its first poll run out -- the
+ * deterministic way to exercise the reporting path (status words, NaN poisoning) in a test.  Process-wide. */
+uint32_t agcn_get_coop_timeout_ticks(void);
+void agcn_set_coop_timeout_ticks(uint32_t ticks);
 
 /* Environment switches of the point-cloud kernels, read once per process (A/B measurements; results within the same
  * tolerances either way): AGCN_SLAB_SMALL=0 -- slab batches with Fin <= 4 and a dense L_orig take the general slab

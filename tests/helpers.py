@@ -42,6 +42,9 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / den) if b.size else 0.0
 
 
+K32_CAP = 8.0     # the widest a bound is ever calibrated to: 8 x the stated one (the fp32 oracle at 4 x)
+
+
 def assert_close(a, b, rtol, what, atol_ulps=None, ref32=None):
     """Element-wise: |a - b| <= rtol |b| + atol_ulps eps scale (+ the flush-to-zero range), scale = the largest
     |b| in the element's row (last axis) or column (axis -2); whole-vector max for 1-D.  atol_ulps defaults to
@@ -70,7 +73,11 @@ def assert_close(a, b, rtol, what, atol_ulps=None, ref32=None):
         k32 = float((np.abs(np.asarray(ref32, dtype=np.float64) - b64) / bound).max())
         kgpu = float((err / bound).max())
         print("%-12s fp32 oracle %.2f x the bound, HIP %.2f x the bound (rtol %.0e + %g ulp)" % (what, k32, kgpu, rtol, atol_ulps))
-        bound = bound * max(1.0, 2.0 * k32)
+        # calibration, capped: twice the fp32 oracle's own error, never more than K32_CAP x the stated bound -- a case on
+        # which the fp32 oracle itself is further off is ill-conditioned test data and must be fixed there, not absorbed
+        assert k32 <= K32_CAP / 2.0, ("%s: the fp32 oracle is %.1f x the bound away from the float64 one: ill-conditioned case"
+                                      % (what, k32))
+        bound = bound * min(max(1.0, 2.0 * k32), K32_CAP)
     bad = err > bound
     if bad.any():
         k = np.unravel_index(np.argmax(err / bound), err.shape)
@@ -223,7 +230,9 @@ def _scalar_close(got, want, want32, scale, what):
     e32 = abs(float(np.asarray(want32).reshape(-1)[0]) - want) if want32 is not None else None
     print("%-12s fp32 oracle %s, HIP %.2f x the bar (%.1e of the gradient scale)"
           % (what, "n/a" if e32 is None else "%.2f x the bar" % (e32 / bar), abs(got - want) / bar, GRAD_RTOL))
-    allowed = max(bar, 2.0 * e32) if e32 is not None else 2.0 * bar
+    if e32 is not None:
+        assert e32 <= K32_CAP / 2.0 * bar, "%s: the fp32 oracle is %.1f x the bar away from the float64 one: ill-conditioned case" % (what, e32 / bar)
+    allowed = min(max(bar, 2.0 * e32), K32_CAP * bar) if e32 is not None else 2.0 * bar
     assert abs(got - want) <= allowed, "%s %r vs %r (allowed %.3e)" % (what, got, want, allowed)
 
 

@@ -103,7 +103,8 @@ def test_golden_reference_feed(amd, name, lds_limit, pack):
                 if k in ("alpha", "beta"):
                     got = 0.0 if v.grad is None else float(v.grad[0])
                     want = float(g[prefix + "d_" + k][0]) if has else 0.0
-                    assert abs(got - want) <= 10 * GRAD_RTOL * max(abs(want), scale), (prefix, k, got, want)
+                    # (the golden is the reference's own fp32 result: two fp32 sums, each within one bar of the exact value)
+                    assert abs(got - want) <= 2 * GRAD_RTOL * max(abs(want), scale), (prefix, k, got, want)
                 elif k == "M_L":
                     assert not has and v.grad is None     # the reference gives M_L no gradient
                 else:
@@ -304,7 +305,8 @@ def test_bf16_feature_storage(amd):
     for b in range(B):
         assert_close(to_np(res_W[b]), caches[b]["S"], FEATURE_RTOL, "res_W fp32")
     assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight fp32")
-    assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], 5 * GRAD_RTOL, "dM_L fp32")
+    tot32 = oracle_run(Xb, L0, p, K, orc.PAPER, orc.SGC_LL, Gb, dtype=np.float32)[1]
+    assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L fp32", ref32=tot32["dM_L"])
     # conversion itself: round to nearest even, exact widening
     x = torch.randn(1000, 7, device=DEV)
     from agcn_amd.functional import CastRowsFunction
@@ -332,7 +334,8 @@ def test_fused_path_large_graph_and_wide_layer(amd):
             for b in range(len(ns)):
                 assert np.array_equal(out["res_W"][b], out["res_W"][b].T)
                 assert_close(out["res_W"][b], slab["res_W"][b], FEATURE_RTOL, "res_W fused vs slab")
-            assert_close(np.concatenate(out["dX"]), np.concatenate(slab["dX"]), 5 * GRAD_RTOL, "dX fused vs slab")
+            # (two fp32 results, each held to GRAD_RTOL against the oracle above: their difference to twice that)
+            assert_close(np.concatenate(out["dX"]), np.concatenate(slab["dX"]), 2 * GRAD_RTOL, "dX fused vs slab")
 
 
 def test_graphed_network_step(amd):
@@ -462,9 +465,10 @@ def test_sgc_ll_upstream_gradient_of_the_combined_laplacian(amd, path):
             (L_sum * torch.from_numpy(pack_tiles_np(dLsum, gb.plan)).to(DEV)).sum()
         loss.backward()
         assert_close(to_np(Xt.grad), np.concatenate(tot["dX"]), GRAD_RTOL, "dX with dL_sum")
-        assert_close(to_np(v["M_L"].grad), tot["dM_L"], 5 * GRAD_RTOL, "dM_L with dL_sum")
-        da = float(np.asarray(tot["dalpha"]).reshape(-1)[0])
-        assert abs(float(v["alpha"].grad[0]) - da) <= 10 * GRAD_RTOL * max(abs(da), float(np.abs(tot["dweight"]).max()))
+        tot32 = oracle_run(X, L0, p, K, orc.PAPER, orc.SGC_LL, G, None, dLsum, dtype=np.float32)[1]
+        assert_close(to_np(v["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L with dL_sum", ref32=tot32["dM_L"])
+        from helpers import _scalar_close
+        _scalar_close(to_np(v["alpha"].grad), tot["dalpha"], tot32["dalpha"], float(np.abs(tot["dweight"]).max()), "dalpha with dL_sum")
     finally:
         lib.agcn_set_fused_mode(1)
         lib.agcn_set_slab_mode(1)
@@ -786,7 +790,7 @@ def test_dense_block_end_golden(amd):
         assert_close(to_np(layer.vars["weight_outblock"][i].grad), g["dWout%d" % i], GRAD_RTOL, "DenseBlockEnd dWout")
     for k, ref in (("beta_inblock", "dbeta1"), ("beta_outblock", "dbeta2")):
         got, want = float(layer.vars[k].grad[0]), float(g[ref][0])
-        assert abs(got - want) <= 5 * GRAD_RTOL * abs(want), (k, got, want)
+        assert abs(got - want) <= 2 * GRAD_RTOL * abs(want), (k, got, want)      # (golden = the reference's fp32 sum)
 
 
 def test_dense_block_end_packed_chain(amd):
@@ -914,27 +918,29 @@ def test_simple_agcn_stack_packed(amd):
     out = gather({"node_features": h, "graph_batch": gb})
     Gout = rs.randn(B, 32)
     (out * torch.from_numpy(Gout.astype(np.float32)).to(DEV)).sum().backward()
-    # oracle, float64
-    f64 = lambda d: {k: v.astype(np.float64) for k, v in d.items()}
-    hs, caches = [x.astype(np.float64) for x in X], []
-    for p in params:
-        c = orc.layer_forward(hs, [l.astype(np.float64) for l in L0], f64(p), K, orc.PAPER, orc.SGC_LL)
-        caches.append(c)
-        hs = [ci["Y"] for ci in c]
-    hd = [orc.dense_mol_forward(x, Wd.astype(np.float64), bd.astype(np.float64)) for x in hs]
-    o, pre = orc.graph_gather_forward(hd, "tanh")
-    # six stages deep (4 x SGC_LL, DenseMol, GraphGatherMol): every stage is held to the per-layer bar elsewhere; here
-    # the rounding of each stage feeds the next, so the end-to-end bound is the per-layer one times the depth
-    # (5 x on the forward value, 10 x on gradients that also cross the six backward stages)
-    assert_close(to_np(out), o, 5 * FEATURE_RTOL, "stack output", atol_ulps=5 * FEATURE_ULPS)
-    g = orc.graph_gather_backward(o, pre, Gout, ns, "tanh")
-    g = [orc.dense_mol_backward(x, Wd.astype(np.float64), gi)[0] for x, gi in zip(hs, g)]
-    for c, p in zip(caches[::-1], params[::-1]):
-        tot = orc.layer_backward(c, g, f64(p), K, orc.PAPER, orc.SGC_LL)
-        g = tot["dX"]
-    assert_close(to_np(Xt.grad), np.concatenate(g, 0), 10 * GRAD_RTOL, "stack dX", atol_ulps=10 * GRAD_ULPS)
-    assert_close(to_np(layers[0].vars["M_L"].grad), tot["dM_L"], 10 * GRAD_RTOL, "stack dM_L (layer 1)",
-                 atol_ulps=10 * GRAD_ULPS)
+    # the chained oracle, in float64 (ground truth) and in float32 (what the reference's own arithmetic achieves on this
+    # six-stage chain: the calibration of the bounds, helpers.assert_close ref32 -- no depth multipliers)
+    def chain(dt):
+        cast = lambda d: {k: v.astype(dt) for k, v in d.items()}  # noqa: E731
+        hs, caches = [x.astype(dt) for x in X], []
+        for p in params:
+            c = orc.layer_forward(hs, [l.astype(dt) for l in L0], cast(p), K, orc.PAPER, orc.SGC_LL)
+            caches.append(c)
+            hs = [ci["Y"] for ci in c]
+        hd = [orc.dense_mol_forward(x, Wd.astype(dt), bd.astype(dt)) for x in hs]
+        o, pre = orc.graph_gather_forward(hd, "tanh")
+        g = orc.graph_gather_backward(o, pre, Gout.astype(dt), ns, "tanh")
+        g = [orc.dense_mol_backward(x, Wd.astype(dt), gi)[0] for x, gi in zip(hs, g)]
+        for c, p in zip(caches[::-1], params[::-1]):
+            tot = orc.layer_backward(c, g, cast(p), K, orc.PAPER, orc.SGC_LL)
+            g = tot["dX"]
+        return o, np.concatenate(g, 0), tot["dM_L"]
+
+    o, dX, dM = chain(np.float64)
+    o32, dX32, dM32 = chain(np.float32)
+    assert_close(to_np(out), o, FEATURE_RTOL, "stack output", ref32=o32)
+    assert_close(to_np(Xt.grad), dX, GRAD_RTOL, "stack dX", ref32=dX32)
+    assert_close(to_np(layers[0].vars["M_L"].grad), dM, GRAD_RTOL, "stack dM_L (layer 1)", ref32=dM32)
 
 
 @pytest.mark.parametrize("symmetric", [True, False], ids=["slab", "globaltile"])
@@ -1006,7 +1012,7 @@ def _run_dense_clouds(amd, sizes, Xs, Ls, Gs, p, Fin, Fout, K, mode):
     return layer, gb, Xt, nodes, res_L, res_W
 
 
-def _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, kg):
+def _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, kg, tot32=None):
     Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
     for b, n in enumerate(sizes):
         c = caches[b]
@@ -1023,10 +1029,11 @@ def _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode
     assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight", atol_ulps=GRAD_ULPS * kg)
     assert_close(to_np(layer.vars["bias"].grad), tot["dbias"], GRAD_RTOL, "dbias", atol_ulps=GRAD_ULPS * kg)
     if mode == orc.PAPER:
-        assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L", atol_ulps=GRAD_ULPS * kg)
-        da = float(np.asarray(tot["dalpha"]).reshape(-1)[0])
-        scale = max(abs(da), float(np.abs(tot["dweight"]).max()))
-        assert abs(float(to_np(layer.vars["alpha"].grad).reshape(-1)[0]) - da) <= GRAD_RTOL * 10 * scale, "dalpha"
+        assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L", atol_ulps=GRAD_ULPS * kg,
+                     ref32=None if tot32 is None else tot32["dM_L"])
+        from helpers import _scalar_close
+        _scalar_close(to_np(layer.vars["alpha"].grad), tot["dalpha"], None if tot32 is None else tot32["dalpha"],
+                      float(np.abs(tot["dweight"]).max()), "dalpha")
     else:
         assert layer.vars["M_L"].grad is None
 
@@ -1047,9 +1054,10 @@ def test_modelnet_hidden_layer_at_size(amd, mode):
     p["bias"] = (0.1 * rs.randn(Fout)).astype(np.float32)
     layer, gb, Xt, nodes, res_L, res_W = _run_dense_clouds(amd, [n], [X], [L], [G], p, Fin, Fout, K, mode)
     assert (amd._ffi.dispatch_info(layer, gb)[0] & 16) != 0, "n = 1024 must take the slab-parallel kernels"
-    caches, tot = oracle_run([X], [L], p, K, mode, orc.SGC_LL, [G])
+    caches, tot = oracle_run([X], [L], p, K, mode, orc.SGC_LL, [G], Y_tie=to_np(nodes.data))
+    tot32 = oracle_run([X], [L], p, K, mode, orc.SGC_LL, [G], dtype=np.float32, Y_tie=to_np(nodes.data))[1]
     k = float(np.sqrt(n / 64.0))                              # n-term sums: see test_modelnet_shaped_dense_adjacency
-    _check_dense_clouds([n], caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k)
+    _check_dense_clouds([n], caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k, tot32)
 
 
 def _sym_prev(rs, n, scale=0.05):
@@ -1193,6 +1201,40 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
             assert_close(g[b], tot["dLp"][b], GRAD_RTOL, f"dL_prev[{b}]", atol_ulps=GRAD_ULPS * k, ref32=tot32["dLp"][b])
 
 
+def test_point_cloud_reslap_backward_refuses_misaligned_buffers(amd):
+    """The point-cloud forward of SGC_LL_Reslap leaves its reserve the way the point-cloud BACKWARD reads it; that backward
+    needs 16-byte aligned dX / dY / dL_sum / dL_prev on top of what the forward needs.  A C-ABI caller with an offset view
+    (here: dY four bytes into a buffer) must get AGCN_EINVAL, not a silent pairing of the point-cloud forward with the
+    per-graph backward."""
+    sizes, Fin, Fout, K = [128, 64], 64, 64, 2
+    rs = np.random.RandomState(77)
+    Xs, Ls = [], []
+    for n in sizes:
+        X, L, _ = _cloud_case(rs, n, Fin, Fout, thresh=0.6)
+        Xs.append(X); Ls.append(L)
+    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL_RESLAP)
+    plan = amd.Plan(sizes, 0, DEV)
+    l0 = np.zeros(int(plan.tile_off[-1]), np.float32)
+    for b, L in enumerate(Ls):
+        l0[int(plan.tile_off[b]):int(plan.tile_off[b]) + L.size] = L.reshape(-1)
+    gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0).to(DEV), l0_ld=0,
+                        l0_symmetric=True)
+    lib = amd._ffi.lib()
+    lib.agcn_set_fused_mode(0)
+    try:
+        layer = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, len(sizes), K, orc.PAPER, p, DEV)
+        assert (amd._ffi.dispatch_info(layer, gb)[0] & 64) != 0
+        Xt = gb.X.clone().requires_grad_(True)
+        nodes, _, _, _ = layer({"node_features": Xt, "graph_batch": gb, "res_lap": []})
+        buf = torch.randn(nodes.data.numel() + 4, device=DEV)
+        dY = buf[1:1 + nodes.data.numel()].view(nodes.data.shape)            # contiguous, 4 bytes off a 16-byte boundary
+        assert dY.data_ptr() % 16 == 4
+        with pytest.raises(amd.AgcnError, match="16-byte aligned"):
+            nodes.data.backward(dY)
+    finally:
+        lib.agcn_set_fused_mode(1)
+
+
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_point_cloud_kernels_random_batches(amd, seed, mode):
@@ -1309,9 +1351,10 @@ def test_point_cloud_batch_hidden_features(amd, mode, sizes):
     p = orc.init_params(rs, Fin, Fout, K)
     p["alpha"] = np.array([1.2], dtype=np.float32)
     layer, gb, Xt, nodes, res_L, res_W = _run_dense_clouds(amd, sizes, Xs, Ls, Gs, p, Fin, Fout, K, mode)
-    caches, tot = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL, Gs)
+    caches, tot = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL, Gs, Y_tie=to_np(nodes.data))
+    tot32 = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL, Gs, dtype=np.float32, Y_tie=to_np(nodes.data))[1]
     k = float(np.sqrt(max(sizes) / 64.0))
-    _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k)
+    _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k, tot32)
 
 
 @pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
@@ -1433,8 +1476,9 @@ def test_far_away_nodes_do_not_poison_the_gradients(amd, path):
         for k in ("dweight", "dbias", "dM_L", "dalpha"):
             assert np.all(np.isfinite(out[k])), k
         assert all(np.all(np.isfinite(d)) for d in out["dX"])
-        assert_close(out["dM_L"], tot["dM_L"], 5 * GRAD_RTOL, "dM_L with far-away nodes")
-        assert_close(out["dweight"], tot["dweight"], 5 * GRAD_RTOL, "dweight with far-away nodes")
+        # (the oracle of this test runs in float32 -- the overflow it is about does not exist in float64 --: two fp32 results)
+        assert_close(out["dM_L"], tot["dM_L"], 2 * GRAD_RTOL, "dM_L with far-away nodes")
+        assert_close(out["dweight"], tot["dweight"], 2 * GRAD_RTOL, "dweight with far-away nodes")
     finally:
         lib.agcn_set_fused_mode(1)
         lib.agcn_set_slab_mode(1)
@@ -1680,6 +1724,47 @@ def test_cooperative_waits_are_never_silent(amd):
         ep.check()
     word.zero_()
     assert ep.check() == 0
+
+
+def test_autograd_status_outlives_the_reserve(amd):
+    """The autograd path's reserves die with the autograd graph -- right after backward() --, so a wait that ran out must be
+    visible AFTER that: agcn_amd.check_device_status() reads a persistent per-device word (agcn_set_device_status_word).
+    Waits are made to run out deterministically (agcn_set_coop_timeout_ticks(0): any wait not satisfied by its first poll),
+    the step's tensors are dropped, and the check must still raise -- once; the next clean step checks clean."""
+    import gc
+    ns = [96, 81, 80, 64, 59, 49, 48, 33, 32, 17, 5, 40, 95, 70]
+    Fin, Fout, K = 75, 64, 2
+    rs, X, L0, csr, p, G = synth_case(5, ns, Fin, Fout, K, orc.SGC_LL, atoms=True)
+    lib = amd._ffi.lib()
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, orc.PAPER, p, DEV)
+    assert amd._ffi.dispatch_info(layer, gb)[6] > 0, "the batch must use member workgroups"
+    Gt = torch.from_numpy(np.concatenate(G, 0)).to(DEV)
+
+    def step():
+        Xt = gb.X.clone().requires_grad_(True)
+        nodes, _, _ = layer({"node_features": Xt, "graph_batch": gb})
+        (nodes.data * Gt).sum().backward()
+        g = Xt.grad.clone()
+        del Xt, nodes
+        return g
+
+    amd.check_device_status()                     # (clean slate; registers nothing new)
+    g_ok = step()
+    assert amd.check_device_status() >= 1 and bool(torch.isfinite(g_ok).all())
+    lib.agcn_set_coop_timeout_ticks(0)
+    try:
+        g_bad = step()
+        torch.cuda.synchronize()
+    finally:
+        lib.agcn_set_coop_timeout_ticks(1000000)
+    gc.collect()                                  # every reserve of that step is gone by now
+    assert not bool(torch.isfinite(g_bad).all()), "a wait that ran out poisons its step with NaN"
+    with pytest.raises(amd.AgcnError, match="ran out"):
+        amd.check_device_status()
+    assert amd.check_device_status() >= 1         # reported once: the word was cleared with the raise
+    g_again = step()
+    assert amd.check_device_status() >= 1 and torch.equal(g_again, g_ok)
 
 
 @pytest.mark.parametrize("Fin,Fout", [(75, 64), (64, 128), (128, 128), (128, 64), (64, 64)])
