@@ -8,7 +8,7 @@ from ._ffi import AgcnError  # noqa: F401
 from .batch import GraphBatch, Plan, RowViews, TileViews  # noqa: F401
 from .graph_structure import Graph, MolGraph, laplacian_csr  # noqa: F401
 from .layers import (SGC_LL, SGC_LL_Reslap, GraphGatherMol, DenseMol, BlockEnd, DenseBlockEnd, GraphPoolMol,  # noqa: F401
-                     MultitaskHead, Layer)
+                     MultitaskHead, Layer, set_debug_checks)
 from .graphs import (SequentialGraphMol, ResidualGraphMol, ResidualGraphMolResLap, DenseConnectedGraph,  # noqa: F401
                      DenseConnectedGraphResLap, SegmentationGraph)
 from .store import GraphStore, ResidentStore  # noqa: F401

@@ -137,6 +137,7 @@ class TileViews(Sequence):
         # True: every tile equals its transpose (set by the layers for their own Laplacian outputs when their inputs were
         # symmetric; a caller handing in res_lap tiles of its own may vouch for them) -- AgcnGraphBatch.L_prev_symmetric
         self.symmetric = bool(symmetric)
+        self._verified = False      # True: the flag was derived by this package, not vouched for (layers.py: _verify_vouches)
 
     def __len__(self):
         return self.plan.B
@@ -202,6 +203,9 @@ class GraphBatch(object):
         # True only when every original Laplacian equals its transpose (checked on the host at
         # pack time); the slab-parallel kernels rely on it
         self.l0_symmetric = bool(l0_symmetric)
+        # the flag was COMPUTED by this package (from_arrays / from_padded) rather than vouched for by the caller of this
+        # constructor: the layers verify a vouch on the device once (layers.py: _verify_vouches)
+        self._l0_verified = False
         # > 0: the batch came from the reference's padded feed with this max_atom; per-graph views of layer outputs
         # are then padded to it on demand (RowViews)
         self.pad_stride = 0
@@ -240,9 +244,11 @@ class GraphBatch(object):
         sym = bool(csr_symmetry_flags(plan.row_off, rowptr, col, val).all())
         if col.size == 0:       # all-zero Laplacians: keep the device pointers non-null (never dereferenced)
             col, val = np.zeros(1, np.int32), np.zeros(1, np.float32)
-        return cls(plan, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev),
-                   torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
-                   l0_symmetric=sym)
+        gb = cls(plan, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev),
+                 torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
+                 l0_symmetric=sym)
+        gb._l0_verified = True
+        return gb
 
     @classmethod
     def from_padded(cls, node_features, laplacians, data_slice, device=None, pack=None):
@@ -272,10 +278,13 @@ class GraphBatch(object):
             pack = PACK_REFERENCE_FEED and device.type == "cuda"
         if not pack:
             plan = Plan(n, max_atom, device)
-            return cls(plan, X, l0_dense=L, l0_ld=max_atom if L is not None else 0, l0_symmetric=sym)
+            gb = cls(plan, X, l0_dense=L, l0_ld=max_atom if L is not None else 0, l0_symmetric=sym)
+            gb._l0_verified = True
+            return gb
         from .functional import PackRowsFunction
         gb = cls(Plan(n, 0, device), None, l0_dense=L, l0_ld=max_atom if L is not None else 0, l0_symmetric=sym)
         gb.pad_stride = int(max_atom)
+        gb._l0_verified = True
         gb.X = PackRowsFunction.apply(X, gb, max_atom)
         return gb
 

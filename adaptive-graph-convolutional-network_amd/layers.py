@@ -18,6 +18,8 @@ res_L == I and no gradient to M_L; "paper" = I - D^-1/2 W D^-1/2, differentiable
 """
 from collections import defaultdict
 
+import os
+
 import numpy as np
 import torch
 
@@ -42,6 +44,18 @@ def get_uid(prefix=""):
     """models/operators/model_operatos.py:156-168."""
     _UID_PREFIXES[prefix] += 1
     return _UID_PREFIXES[prefix]
+
+
+# AGCN_DEBUG_CHECKS=1 / set_debug_checks(True): symmetry vouches are verified on every call, not only the first one per layer
+_DEBUG_CHECKS = [os.environ.get("AGCN_DEBUG_CHECKS", "0") not in ("", "0")]
+
+
+def set_debug_checks(on):
+    """Verify caller-vouched symmetry flags on EVERY layer call (a launch + a 4-byte read each), not only on a layer object's
+    first call.  Returns the previous setting."""
+    prev = _DEBUG_CHECKS[0]
+    _DEBUG_CHECKS[0] = bool(on)
+    return prev
 
 
 class Layer(object):
@@ -161,6 +175,7 @@ class SGC_LL(Layer):
         self._device = device
         self._generator = generator
         self._built = False
+        self._vouch_checked = False     # _verify_vouches has run on this layer object
 
     def build(self, device=None):
         """Creates the parameters once (the reference re-creates them on every call,
@@ -214,6 +229,7 @@ class SGC_LL(Layer):
             M = F.pad(M, (0, pad, 0, pad))
             cfg = _Cfg(self.n_atom_feature + pad, self.nb_filter, self.K, self.laplacian_mode, self._variant,
                        cfg.activation, lsum=cfg.lsum, prev_sym=cfg.prev_sym)
+        self._verify_vouches(gb, L_prev, cfg.prev_sym)
         Y, res_L, res_W, L_sum = SgcLLFunction.apply(X32, W, v["bias"], M, v["alpha"], v.get("beta"), L_prev, gb, cfg)
         if self.dropout and self.training:
             # graphconv.py:121-122 / dropout.py:34-41: Dropout(p) on the activated nodes in the training phase, i.e.
@@ -223,8 +239,43 @@ class SGC_LL(Layer):
         nodes = RowViews(_out_as(Y, X.dtype), gb.plan, gb)
         # res_W and res_L are symmetric by construction; the summed Laplacian when L_orig and L_prev are
         sum_sym = bool(gb.l0_symmetric) and (L_prev is None or cfg.prev_sym)
-        return (gb, nodes, TileViews(res_L, gb.plan, True), TileViews(res_W, gb.plan, True),
-                TileViews(L_sum, gb.plan, sum_sym))
+        outs = (TileViews(res_L, gb.plan, True), TileViews(res_W, gb.plan, True), TileViews(L_sum, gb.plan, sum_sym))
+        for t in outs:
+            t._verified = True           # (derived from inputs that were computed symmetric or have been verified)
+        return (gb, nodes) + outs
+
+    def _verify_vouches(self, gb, L_prev, prev_sym):
+        """A symmetry flag somebody VOUCHED for -- `GraphBatch(..., l0_dense=..., l0_symmetric=True)`, `TileViews(...,
+        symmetric=True)` / `x["res_lap_symmetric"]` -- is checked on the device the first time this layer object sees one
+        (agcn_tiles_asymmetry: one launch + one 4-byte read), and on every call under AGCN_DEBUG_CHECKS=1 /
+        `agcn_amd.set_debug_checks(True)`: the point-cloud kernels take La^T g_1 as La g_1 on the strength of those flags,
+        so a false vouch would be a silently wrong dX.  Flags this package computed itself are not re-checked."""
+        todo = []
+        laps = getattr(self, "early_laps", None)
+        if prev_sym and L_prev is not None and not getattr(laps, "_verified", False):
+            todo.append(("the previous Laplacian (res_lap, vouched symmetric)", L_prev, 0, laps))
+        if gb.l0_symmetric and gb.l0_dense is not None and not gb._l0_verified:
+            todo.append(("the dense original Laplacian (l0_symmetric=True)", gb.l0_dense, gb.l0_ld, gb))
+        if not todo or (self._vouch_checked and not _DEBUG_CHECKS[0]):
+            return
+        from . import _ffi
+        from .functional import _stream
+        dev = gb.plan.dev.device
+        counts = torch.zeros(len(todo), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            for k, (_, t, ld, _) in enumerate(todo):
+                _ffi.check(_ffi.lib().agcn_tiles_asymmetry(gb.plan.host_ptr, gb.plan.dev_ptr, t.data_ptr(), int(ld),
+                                                          counts[k:].data_ptr(), _stream(dev)))
+        bad = counts.tolist()
+        for (what, _, _, obj), c in zip(todo, bad):
+            if c:
+                raise _ffi.AgcnError("%s is NOT symmetric: %d element pair(s) differ from their transposes; the flag must be "
+                                     "dropped (the layer then takes the general kernels)" % (what, c))
+            if obj is gb:
+                gb._l0_verified = True
+            elif obj is not None and hasattr(obj, "_verified"):
+                obj._verified = True
+        self._vouch_checked = True
 
     def _point_cloud_pad(self, gb, X, cfg):
         """Feature columns to append so that the layer takes the point-cloud kernels (csrc/cloud_kernels.hip, 64 input

@@ -261,6 +261,15 @@ int agcn_graph_gather_backward(const void* plan_host, const void* plan_dev, cons
                                const float* dOut, int32_t F, int32_t ldx, int32_t activation,
                                float* dX /* [rows, ldx], pad rows zeroed */, void* hip_stream);
 
+/* Check of a symmetry vouch (AgcnGraphBatch.L0_symmetric for a dense L_orig, L_prev_symmetric): ADDS to *count_dev (a
+ * caller-owned, caller-zeroed device int32) the number of element pairs i < j of the per-graph tiles whose two sides differ
+ * bit for bit.  `tiles`: packed tiles (ld = 0: graph b at tile_off[b], leading dimension n_b) or the reference's padded feed
+ * (ld = max_atom: graph b at b * ld * ld).  Asynchronous on `hip_stream`; reading the count is the caller's synchronisation.
+ * The point-cloud kernels take La^T g_1 as La g_1 on the strength of those flags: a false vouch is a silently wrong dX, so the
+ * Python layers run this once per layer object (and on every call under AGCN_DEBUG_CHECKS=1) and raise on a non-zero count. */
+int agcn_tiles_asymmetry(const void* plan_host, const void* plan_dev, const float* tiles, int32_t ld,
+                         int32_t* count_dev, void* hip_stream);
+
 /* ---- "next" rows: the layers around the SGC stack --------------------------------
  * rows_dense: Y = act(A . W [+ bias] [+ Add]) over the row space of a batch.
  *   DenseMol  (models/layers/dense_layer.py:33-50): activation LINEAR (the layer stores one but never

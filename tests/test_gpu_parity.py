@@ -1201,6 +1201,57 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
             assert_close(g[b], tot["dLp"][b], GRAD_RTOL, f"dL_prev[{b}]", atol_ulps=GRAD_ULPS * k, ref32=tot32["dLp"][b])
 
 
+def test_false_symmetry_vouch_is_detected(amd):
+    """The point-cloud kernels take La^T g_1 as La g_1 because the caller says L_orig and the previous Laplacian are symmetric
+    (AgcnGraphBatch.L0_symmetric / L_prev_symmetric).  A FALSE vouch -- tiles that are not symmetric handed in with
+    symmetric=True -- must raise AgcnError on the layer's first call (agcn_tiles_asymmetry), not produce a silently wrong dX;
+    true vouches pass, and the raw C-ABI count is exact."""
+    sizes, Fin, Fout, K = [128, 64], 64, 64, 2
+    rs = np.random.RandomState(78)
+    Xs, Ls = [], []
+    for n in sizes:
+        X, L, _ = _cloud_case(rs, n, Fin, Fout, thresh=0.6)
+        Xs.append(X); Ls.append(L)
+    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL_RESLAP)
+    plan = amd.Plan(sizes, 0, DEV)
+
+    def batch(Ls_, vouch=True):
+        l0 = np.zeros(int(plan.tile_off[-1]), np.float32)
+        for b, L in enumerate(Ls_):
+            l0[int(plan.tile_off[b]):int(plan.tile_off[b]) + L.size] = L.reshape(-1)
+        return amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0).to(DEV), l0_ld=0,
+                              l0_symmetric=vouch)
+
+    def run(gb, Lp, vouch):
+        layer = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, len(sizes), K, orc.PAPER, p, DEV)
+        Lpt = torch.from_numpy(pack_tiles_np(Lp, plan)).to(DEV)
+        return layer({"node_features": gb.X, "graph_batch": gb, "res_lap": amd.TileViews(Lpt, plan, symmetric=vouch)})
+
+    good = [_sym_prev(rs, n) for n in sizes]
+    bad = [g.copy() for g in good]
+    bad[1][3, 17] += 1e-3                                   # ONE element of one tile off its mirror image
+    run(batch(Ls), good, True)                              # true vouches: fine
+    with pytest.raises(amd.AgcnError, match="previous Laplacian.*NOT symmetric: 1 element pair"):
+        run(batch(Ls), bad, True)
+    run(batch(Ls), bad, False)                              # not vouched for: the general kernels, no error
+    Lbad = [l.copy() for l in Ls]
+    Lbad[0][5, 9] += 1e-3; Lbad[0][100, 2] += 1e-3
+    with pytest.raises(amd.AgcnError, match="original Laplacian.*NOT symmetric: 2 element pair"):
+        run(batch(Lbad), good, True)
+    # a layer object checks once; under set_debug_checks(True) every call does
+    layer = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, len(sizes), K, orc.PAPER, p, DEV)
+    gb = batch(Ls)
+    tv = lambda Lp: amd.TileViews(torch.from_numpy(pack_tiles_np(Lp, plan)).to(DEV), plan, symmetric=True)  # noqa: E731
+    layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tv(good)})
+    layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tv(bad)})      # second call of the same layer: not re-checked
+    prev = amd.set_debug_checks(True)
+    try:
+        with pytest.raises(amd.AgcnError, match="NOT symmetric"):
+            layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tv(bad)})
+    finally:
+        amd.set_debug_checks(prev)
+
+
 def test_point_cloud_reslap_backward_refuses_misaligned_buffers(amd):
     """The point-cloud forward of SGC_LL_Reslap leaves its reserve the way the point-cloud BACKWARD reads it; that backward
     needs 16-byte aligned dX / dY / dL_sum / dL_prev on top of what the forward needs.  A C-ABI caller with an offset view
