@@ -135,6 +135,19 @@ def oracle_run(X, L0, p, K, mode, variant, G, Lp=None, dLsum=None, dtype=np.floa
     return caches, tot
 
 
+def oracle_pair(X, L0, p, K, mode, variant, G, Lp=None, dLsum=None, Y_got=None):
+    """The float64 oracle (ground truth; activation ties settled on the side the kernel's Y is on, if given) and the float32
+    oracle (the calibration of the parameter-gradient bounds: what the reference's own arithmetic achieves) of one case.
+    The float32 run takes ITS ties from the float64 run: a mask element that flips between the two oracles would otherwise
+    show up as an fp32-oracle error of thousands of bounds on that graph and silently widen the calibrated bound
+    (test_full_size_every_graph_every_gradient[reslap-reference-b256], graph 11, before the calibration was capped).
+    Returns (caches, tot, tot32)."""
+    caches, tot = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLsum, Y_tie=Y_got)
+    ypre64 = np.concatenate([c["Ypre"] for c in caches])
+    _, tot32 = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLsum, dtype=np.float32, Y_tie=ypre64)
+    return caches, tot, tot32
+
+
 def pack_tiles_np(tiles, plan):
     out = np.zeros(int(plan.tile_elems), dtype=np.float32)
     for b, t in enumerate(tiles):

@@ -9,7 +9,7 @@ import torch
 
 import agcn_oracle as orc
 from conftest import GOLDEN
-from helpers import (FEATURE_RTOL, FEATURE_ULPS, GRAD_RTOL, GRAD_ULPS, assert_close, compare_with_oracle, golden_params, load_golden,
+from helpers import (oracle_pair, FEATURE_RTOL, FEATURE_ULPS, GRAD_RTOL, GRAD_ULPS, assert_close, compare_with_oracle, golden_params, load_golden,
                      make_layer, oracle_run, pack_tiles_np, run_packed, synth_case, to_np, unpack_tiles_np)
 
 pytestmark = pytest.mark.gpu
@@ -159,9 +159,8 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
         if variant == orc.SGC_LL_RESLAP:
             Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
             dLsum = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
-        caches, tot = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLsum)
-        _, tot32 = oracle_run(X, L0, p, K, mode, variant, G, Lp, dLsum, dtype=np.float32)   # what fp32 itself achieves
         out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, variant, Lp, dLsum)
+        caches, tot, tot32 = oracle_pair(X, L0, p, K, mode, variant, G, Lp, dLsum, Y_got=np.concatenate(out["Y"]))
         compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
     finally:
         amd._ffi.lib().agcn_set_fused_global_b(-1)
@@ -305,7 +304,7 @@ def test_bf16_feature_storage(amd):
     for b in range(B):
         assert_close(to_np(res_W[b]), caches[b]["S"], FEATURE_RTOL, "res_W fp32")
     assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight fp32")
-    tot32 = oracle_run(Xb, L0, p, K, orc.PAPER, orc.SGC_LL, Gb, dtype=np.float32)[1]
+    tot32 = oracle_run(Xb, L0, p, K, orc.PAPER, orc.SGC_LL, Gb, dtype=np.float32, Y_tie=np.concatenate([c["Ypre"] for c in caches]))[1]
     assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L fp32", ref32=tot32["dM_L"])
     # conversion itself: round to nearest even, exact widening
     x = torch.randn(1000, 7, device=DEV)
@@ -465,7 +464,8 @@ def test_sgc_ll_upstream_gradient_of_the_combined_laplacian(amd, path):
             (L_sum * torch.from_numpy(pack_tiles_np(dLsum, gb.plan)).to(DEV)).sum()
         loss.backward()
         assert_close(to_np(Xt.grad), np.concatenate(tot["dX"]), GRAD_RTOL, "dX with dL_sum")
-        tot32 = oracle_run(X, L0, p, K, orc.PAPER, orc.SGC_LL, G, None, dLsum, dtype=np.float32)[1]
+        tot32 = oracle_run(X, L0, p, K, orc.PAPER, orc.SGC_LL, G, None, dLsum, dtype=np.float32,
+                           Y_tie=np.concatenate([c["Ypre"] for c in caches]))[1]
         assert_close(to_np(v["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L with dL_sum", ref32=tot32["dM_L"])
         from helpers import _scalar_close
         _scalar_close(to_np(v["alpha"].grad), tot["dalpha"], tot32["dalpha"], float(np.abs(tot["dweight"]).max()), "dalpha with dL_sum")
@@ -622,9 +622,8 @@ def test_full_size_every_graph_every_gradient(amd, variant, mode, B):
         p["beta"] = np.array([1.2], np.float32)
         Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
         dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
-    caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, variant, G, Lp, dLs)
-    _, tot32 = oracle_run(sb["X"], sb["L0"], p, K, mode, variant, G, Lp, dLs, dtype=np.float32)
     out = run_packed(amd, DEV, ns, sb["X"], sb["csr"], p, G, Fin, Fout, K, mode, variant, Lp, dLs)
+    caches, tot, tot32 = oracle_pair(sb["X"], sb["L0"], p, K, mode, variant, G, Lp, dLs, Y_got=np.concatenate(out["Y"]))
     compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
 
 
@@ -1710,9 +1709,8 @@ def test_reslap_takes_the_specialised_kernels(amd, mode, Fin, Fout):
                        dL_sum=torch.from_numpy(pack_tiles_np(dLs, gb.plan)).to(DEV))
     names = st.kernel_names()
     assert "spec_forward_kernel" in names[0] and "spec_backward_kernel" in names[1], names
-    caches, tot = oracle_run(X, sb["L0"], p, K, mode, orc.SGC_LL_RESLAP, G, Lp, dLs)
-    _, tot32 = oracle_run(X, sb["L0"], p, K, mode, orc.SGC_LL_RESLAP, G, Lp, dLs, dtype=np.float32)
     out = run_packed(amd, DEV, ns, X, sb["csr"], p, G, Fin, Fout, K, mode, orc.SGC_LL_RESLAP, Lp, dLs)
+    caches, tot, tot32 = oracle_pair(X, sb["L0"], p, K, mode, orc.SGC_LL_RESLAP, G, Lp, dLs, Y_got=np.concatenate(out["Y"]))
     compare_with_oracle(out, caches, tot, orc.SGC_LL_RESLAP, mode, K, has_prev=True, tot32=tot32)
 
 
