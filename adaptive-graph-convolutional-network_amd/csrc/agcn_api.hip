@@ -554,7 +554,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT, *spart; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT, *MT, *spart; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -586,6 +586,7 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
   w->part = c.take(w->part_floats);
   w->n_glb = (int)global_scratch_floats(d, host, true, &c, &w->tile, &w->buf);
   w->WT = cloud_shape(d) ? c.take((size_t)d->K * d->Fout * d->Fin) : nullptr;   // cloud kernels: W^T for the filter adjoint
+  w->MT = (cloud_shape(d) && d->Fin == 128 && paper) ? c.take((size_t)d->Fin * d->Fin) : nullptr;   // rows_wide.hip: M_L^T
   return c.off;
 }
 
@@ -743,14 +744,22 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
       (reinterpret_cast<uintptr_t>(out->Y) & 15) == 0) {
     if (desc->Fin != 128) return launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
     // 128 input features: Z = X M_L and the filter product as packed-row launches around the strip kernels
+    const bool rw = rows_wide_ok(host.info.rows, desc->Fin, desc->Fout, desc->K, desc->ldx, desc->ldy);
     RowsGemmArgs g;
-    fill_rows(g, desc, host, dev);
-    g.Kd = desc->Fin; g.N = desc->Fin;
-    g.A0 = batch->X; g.lda0 = desc->ldx; g.Bm = params->M_L; g.Out0 = a.sv_Z; g.ldo0 = desc->Fin;
-    rc = launch_rows_gemm(g, RG_PROJECT, hip_stream);
+    if (rw) {
+      rc = launch_rows_wide_project(batch->X, desc->ldx, params->M_L, a.sv_Z, host.info.rows, hip_stream);
+    } else {
+      fill_rows(g, desc, host, dev);
+      g.Kd = desc->Fin; g.N = desc->Fin;
+      g.A0 = batch->X; g.lda0 = desc->ldx; g.Bm = params->M_L; g.Out0 = a.sv_Z; g.ldo0 = desc->Fin;
+      rc = launch_rows_gemm(g, RG_PROJECT, hip_stream);
+    }
     if (rc != AGCN_OK) return rc;
     rc = launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
     if (rc != AGCN_OK) return rc;
+    if (rw)
+      return launch_rows_wide_filter(batch->X, desc->ldx, a.sv_X, params->weight, params->bias, desc->activation == AGCN_ACT_RELU ? 1 : 0,
+                                     out->Y, desc->ldy, desc->Fout, host.info.rows, hip_stream);
     fill_rows(g, desc, host, dev);
     g.Kd = desc->Fin * desc->K; g.N = desc->Fout;
     g.A0 = batch->X; g.lda0 = desc->ldx; g.A1 = a.sv_X; g.a1_plane = (int64_t)host.info.rows * desc->Fin;
@@ -856,6 +865,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   const FusedSplit fs = fused_split(desc, batch, host);
   const bool fused = fs.mode != 0;
   bool cloud_bwd = false, cloud_res = false;
+  bool filter_bwd_zeroed = true;    // the general packed filter adjoint zeroes the one-pass kernel's arrival counters
   // SGC_LL_Reslap on the point-cloud kernels: only behind the cloud forward (the per-graph forward leaves no r tiles); the
   // same answer in both stages of a split call
   // SGC_LL: either backward works behind either forward (both forwards leave Z, X_1, s and the r tiles)
@@ -996,7 +1006,14 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     RowsGemmArgs g;
     if (cloud_res || cloud_bwd) {
       const bool wide = desc->Fin == 128;
-      if (wide) {    // [g_0 | g_1] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_1 -> workspace
+      const bool rw = wide && w.WT != nullptr && (w.MT != nullptr || !paper) &&
+                      rows_wide_ok(host.info.rows, desc->Fin, desc->Fout, desc->K, desc->ldx, desc->ldy);
+      if (rw) {      // (rows_wide.hip; the parameter gradients then take the row-chunk partials: no arrival counters to zero)
+        rc = launch_rows_wide_filter_bwd(dY, fwd->Y, desc->ldy, desc->activation == AGCN_ACT_RELU ? 1 : 0, params->weight, params->M_L,
+                                         w.WT, w.MT, w.Gp, grads->dX, desc->ldx, w.g, desc->Fout, host.info.rows, hip_stream);
+        if (rc != AGCN_OK) return rc;
+        filter_bwd_zeroed = false;
+      } else if (wide) {    // [g_0 | g_1] = (dY . act'(Y)) . W^T over the packed rows; g_0 -> dX, g_1 -> workspace
         fill_rows(g, desc, host, dev);
         g.Kd = desc->Fout; g.N = desc->Fin * desc->K;
         g.A0 = dY; g.lda0 = desc->ldy; g.Yact = fwd->Y; g.ldy = desc->ldy; g.Bm = params->weight;
@@ -1014,7 +1031,10 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         rc = launch_cloud_backward(a, fwd_cloud ? nullptr : w.WT, hip_stream);
       }
       if (rc != AGCN_OK) return rc;
-      if (wide && paper) {   // dX += dZ . M_L^T
+      if (rw && paper) {
+        rc = launch_rows_wide_project_bwd(w.dZ, w.MT, grads->dX, desc->ldx, host.info.rows, hip_stream);
+        if (rc != AGCN_OK) return rc;
+      } else if (wide && paper) {   // dX += dZ . M_L^T
         fill_rows(g, desc, host, dev);
         g.Kd = desc->Fin; g.N = desc->Fin;
         g.A0 = w.dZ; g.lda0 = desc->Fin; g.Bm = params->M_L; g.Out0 = grads->dX; g.ldo0 = desc->ldx;
@@ -1067,12 +1087,12 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.B = fused ? B + fs.n_big_slabs + coop_slabs : ((slabs || cloud_res || cloud_bwd) ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
-  pa.counters_zeroed = ((stages & 1) && ((!cloud_bwd && !cloud_res) || desc->Fin == 128)) ? 1 : 0;
+  pa.counters_zeroed = ((stages & 1) && ((!cloud_bwd && !cloud_res) || (desc->Fin == 128 && filter_bwd_zeroed))) ? 1 : 0;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
   // point-cloud sizes: row-chunk partials with 16-byte operand loads + the fixed-order reduce (cloud_kernels.hip)
   static const int cloud_pg = [] { const char* e = std::getenv("AGCN_CLOUD_PG"); return e ? std::atoi(e) : 1; }();
-  if (cloud_pg && !fused && (slabs || cloud_res) && w.WT && cloud_param_grads_ok(pa) && (size_t)pa.n_chunks * pa.part_stride <= w.part_floats &&
+  if (cloud_pg && !fused && (slabs || cloud_res || cloud_bwd) && w.WT && cloud_param_grads_ok(pa) && (size_t)pa.n_chunks * pa.part_stride <= w.part_floats &&
       (reinterpret_cast<uintptr_t>(batch->X) & 15) == 0) {
     return launch_cloud_param_partials(pa, hip_stream);   // (partials + the fixed-order reduce)
   }

@@ -1692,8 +1692,11 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
 }
 
 // The row-chunk partials of the parameter gradients (the caller runs param_grads.hip's reduce kernel behind it).
-bool cloud_param_grads_ok(const ParamGradArgs& a) { return cloud_env() && a.Fin == FIN && a.K == 2 && (a.Fout == 64 || a.Fout == 128) &&
-                                                           (a.rows & 63) == 0 && (a.ldx & 3) == 0 && (a.chunk_rows & 3) == 0; }
+bool cloud_param_grads_ok(const ParamGradArgs& a) {
+  const bool wide = a.Fin == 2 * FIN && rows_wide_ok(a.rows, a.Fin, a.Fout, a.K, a.ldx, a.Fout);    // (rows_wide.hip)
+  return cloud_env() && (a.Fin == FIN || wide) && a.K == 2 && (a.Fout == 64 || a.Fout == 128) && (a.rows & 63) == 0 && (a.ldx & 3) == 0 &&
+         (a.chunk_rows & 3) == 0;
+}
 int launch_cloud_param_partials(const ParamGradArgs& a0, void* stream) {
   // few, long chunks (<= the caller's chunk count: its partial buffer is sized for that many)
   ParamGradArgs a = a0;
@@ -1701,7 +1704,7 @@ int launch_cloud_param_partials(const ParamGradArgs& a0, void* stream) {
   a.n_chunks = std::max(1, std::min(a0.n_chunks, (a0.rows + chunk_target - 1) / chunk_target));
   a.chunk_rows = ((a0.rows + a.n_chunks - 1) / a.n_chunks + 63) / 64 * 64;
   const unsigned zm = a.paper ? 1u : 0u;   // the X^T dZ slice
-  int rc = a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks, 2, 2 + zm), 256, 0, PK_PARAM_PARTIAL,
+  int rc = a.Fin == 2 * FIN ? launch_rows_wide_param_partials(a, stream) : a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks, 2, 2 + zm), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a)
                        : launch_cloud(cloud_param_partial_kernel<64>, dim3((unsigned)a.n_chunks, 2, 1 + zm), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a);

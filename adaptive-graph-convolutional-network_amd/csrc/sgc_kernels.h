@@ -178,6 +178,15 @@ int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void
 int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream);   // (incl. the packed filter adjoint)
 bool cloud_param_grads_ok(const ParamGradArgs& a);
 int launch_cloud_param_partials(const ParamGradArgs& a, void* stream);   // row-chunk partials + their fixed-order sum
+// packed-row products of the 128-input-feature point-cloud layers (rows_wide.hip)
+bool rows_wide_ok(int rows, int Fin, int Fout, int K, int ldx, int ldy);
+int launch_rows_wide_project(const float* X, int ldx, const float* M, float* Z, int rows, void* stream);
+int launch_rows_wide_filter(const float* X0, int ldx, const float* X1, const float* W, const float* bias, int relu, float* Y, int ldy,
+                            int Fout, int rows, void* stream);
+int launch_rows_wide_filter_bwd(const float* dY, const float* Y, int ldy, int relu, const float* W, const float* M, float* WT, float* MT,
+                                float* Gp, float* dX, int ldx, float* g1, int Fout, int rows, void* stream);
+int launch_rows_wide_project_bwd(const float* dZ, const float* MT, float* dX, int ldx, int rows, void* stream);
+int launch_rows_wide_param_partials(const ParamGradArgs& a, void* stream);
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper);
 // the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number
