@@ -182,8 +182,19 @@ def similarity(x, M):
     """graphconv.py:164-180 vectorised: Z = x.M; W_ij = exp(-||Z_i - Z_j||_2),
     W_ii = 0.  Returns (S, Z, r)."""
     Z = x @ M
-    diff = Z[:, None, :] - Z[None, :, :]
-    r = np.sqrt((diff * diff).sum(axis=-1, dtype=Z.dtype))
+    n = Z.shape[0]
+    if n <= 256:
+        diff = Z[:, None, :] - Z[None, :, :]
+        r = np.sqrt((diff * diff).sum(axis=-1, dtype=Z.dtype))
+    else:
+        # the same arithmetic in blocks of rows (every pair's sum over the features is its own reduction along the last
+        # axis: identical bits), so that the [rows, n, F] temporaries stay in cache at point-cloud sizes (n = 1024, F = 128 in
+        # float64: 1 GB each otherwise)
+        r = np.empty((n, n), dtype=Z.dtype)
+        step = max(1, (1 << 21) // max(1, n * Z.shape[1]))
+        for i0 in range(0, n, step):
+            diff = Z[i0:i0 + step, None, :] - Z[None, :, :]
+            r[i0:i0 + step] = np.sqrt((diff * diff).sum(axis=-1, dtype=Z.dtype))
     S = np.exp(-r)
     np.fill_diagonal(S, 0)
     return S.astype(x.dtype), Z, r

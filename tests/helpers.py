@@ -279,3 +279,103 @@ def compare_with_oracle(out, caches, tot, variant, mode, K, has_prev, tot32=None
             # (a 1 x 1 tile's clip adjoint is analytically 0: the fp32 oracle's own residue calibrates the bound there)
             assert_close(out["dLp"][b], tot["dLp"][b], GRAD_RTOL, "dL_prev[%d]" % b,
                          ref32=None if tot32 is None else tot32["dLp"][b])
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# The reference's point-cloud network (models/networks/Point_AGCN.py:34-90) as a chained oracle: DenseConnectedGraphResLap with
+#   SGC_LL_Reslap(f1, xyz, save_lap, save_output), SGC_LL_Reslap(f2, f1, save_output), DenseBlockEnd(0, [f1, f2], f2),
+#   SGC_LL_Reslap(f3, f2, save_lap, save_output), SGC_LL_Reslap(f4, f3, save_output), DenseBlockEnd(1, [f3, f4], f4),
+#   DenseMol(final, f4), GraphGatherMol(tanh)
+# The previous Laplacian of a convolution is the most recently SAVED one (tf_graphs.py:346,360-361): layers 2 and 3 both get
+# layer 1's, layer 4 gets layer 3's -- so layer 1's L_sum collects two cross-layer gradients.
+def point_cloud_network_params(rs, widths=(64, 128, 128, 64), final=256, raw=3, K=2, dense_scale=0.004):
+    f1, f2, f3, f4 = widths
+    P = {"conv": [], "K": K}
+    for fin, fout in ((raw, f1), (f1, f2), (f2, f3), (f3, f4)):
+        p = orc.init_params(rs, fin, fout, K, orc.SGC_LL_RESLAP)
+        p["alpha"] = np.array([0.9], np.float32)
+        p["beta"] = np.array([0.8], np.float32)
+        p["bias"] = (0.05 * rs.randn(fout)).astype(np.float32)
+        P["conv"].append(p)
+    P["be"] = [{"Win": [orc.glorot_uniform(rs, (f1, f2)), orc.glorot_uniform(rs, (f2, f2))], "Wout": [],
+                "b1": np.array([0.7], np.float32), "b2": np.array([1.0], np.float32)},
+               {"Win": [orc.glorot_uniform(rs, (f3, f4)), orc.glorot_uniform(rs, (f4, f4))], "Wout": [orc.glorot_uniform(rs, (f2, f4))],
+                "b1": np.array([0.6], np.float32), "b2": np.array([0.5], np.float32)}]
+    # (a row-sum over ~1000 points goes into the tanh of the readout: small dense weights keep it off saturation)
+    P["Wd"] = (dense_scale * orc.glorot_uniform(rs, (f4, final))).astype(np.float32)
+    P["bd"] = (0.001 * rs.randn(final)).astype(np.float32)
+    return P
+
+
+def point_cloud_network_oracle(Xs, Ls, P, Gout, mode, dtype=np.float64, Y_ties=None):
+    """Forward + backward of the network on per-cloud arrays.  Y_ties: per convolution, the kernel's (or the float64 oracle's)
+    packed Y, to settle activation ties (align_relu_ties).  Returns a dict: out [B, final], conv Y's, and the gradients."""
+    K = P["K"]
+    c_ = lambda d: {k: np.asarray(v).astype(dtype) for k, v in d.items()}  # noqa: E731
+    pc = [c_(p) for p in P["conv"]]
+    X = [x.astype(dtype) for x in Xs]
+    L0 = [l.astype(dtype) for l in Ls]
+    V = orc.SGC_LL_RESLAP
+    ns = [x.shape[0] for x in Xs]
+
+    def conv(i, h, Lp):
+        c = orc.layer_forward(h, L0, pc[i], K, mode, V, Lp_list=Lp)
+        if Y_ties is not None:
+            align_relu_ties(c, pc[i], Y_ties[i])
+        return c
+
+    def be_fwd(i, x, ins, outs):
+        b = P["be"][i]
+        res = [orc.dense_block_end_forward(x[g], [a[g] for a in ins], [w.astype(dtype) for w in b["Win"]], [o[g] for o in outs],
+                                           [w.astype(dtype) for w in b["Wout"]], b["b1"].astype(dtype), b["b2"].astype(dtype))
+               for g in range(len(ns))]
+        return [r[0] for r in res], [r[1] for r in res]
+
+    c1 = conv(0, X, None)
+    Y1, La1 = [c["Y"] for c in c1], [c["La"] for c in c1]
+    c2 = conv(1, Y1, La1)
+    Y2 = [c["Y"] for c in c2]
+    B0, pre0 = be_fwd(0, Y2, [Y1, Y2], [])
+    c3 = conv(2, B0, La1)
+    Y3, La3 = [c["Y"] for c in c3], [c["La"] for c in c3]
+    c4 = conv(3, Y3, La3)
+    Y4 = [c["Y"] for c in c4]
+    B1, pre1 = be_fwd(1, Y4, [Y3, Y4], [B0])
+    Wd, bd = P["Wd"].astype(dtype), P["bd"].astype(dtype)
+    D = [orc.dense_mol_forward(x, Wd, bd) for x in B1]
+    out, pre = orc.graph_gather_forward(D, "tanh")
+    res = {"out": out, "Y": [np.concatenate(y) for y in (Y1, Y2, Y3, Y4)], "La1": La1, "La3": La3}
+    if Gout is None:
+        return res
+    gD = orc.graph_gather_backward(out, pre, Gout.astype(dtype), ns, "tanh")
+    dm = [orc.dense_mol_backward(x, Wd, g) for x, g in zip(B1, gD)]
+    res["dWd"], res["dbd"] = sum(d[1] for d in dm), sum(d[2] for d in dm)
+    gB1 = [d[0] for d in dm]
+
+    def be_bwd(i, ins, outs, pres, G):
+        b = P["be"][i]
+        r = [orc.dense_block_end_backward([a[g] for a in ins], [w.astype(dtype) for w in b["Win"]], [o[g] for o in outs],
+                                          [w.astype(dtype) for w in b["Wout"]], b["b1"].astype(dtype), b["b2"].astype(dtype), pres[g], G[g])
+             for g in range(len(ns))]
+        dx = [x[0] for x in r]
+        da = [[x[1][l] for x in r] for l in range(len(ins))]
+        do = [[x[3][l] for x in r] for l in range(len(outs))]
+        dWi = [sum(x[2][l] for x in r) for l in range(len(ins))]
+        dWo = [sum(x[4][l] for x in r) for l in range(len(outs))]
+        return dx, da, do, dWi, dWo, sum(x[5] for x in r), sum(x[6] for x in r)
+
+    add = lambda a, b: [u + v for u, v in zip(a, b)]  # noqa: E731
+    dx, da, do, res["be1_dWin"], res["be1_dWout"], res["be1_db1"], res["be1_db2"] = be_bwd(1, [Y3, Y4], [B0], pre1, gB1)
+    gY4 = add(dx, da[1])
+    t4 = orc.layer_backward(c4, gY4, pc[3], K, mode, V)
+    gY3 = add(t4["dX"], da[0])
+    t3 = orc.layer_backward(c3, gY3, pc[2], K, mode, V, t4["dLp"])            # layer 4's dL_prev arrives on layer 3's L_sum
+    gB0 = add(t3["dX"], do[0])
+    dx, da, _, res["be0_dWin"], _, res["be0_db1"], _ = be_bwd(0, [Y1, Y2], [], pre0, gB0)
+    gY2 = add(dx, da[1])
+    t2 = orc.layer_backward(c2, gY2, pc[1], K, mode, V)
+    gY1 = add(t2["dX"], da[0])
+    t1 = orc.layer_backward(c1, gY1, pc[0], K, mode, V, add(t2["dLp"], t3["dLp"]))   # layers 2 AND 3 read layer 1's L_sum
+    res["conv_grads"] = [t1, t2, t3, t4]
+    res["dX"] = np.concatenate(t1["dX"])
+    return res

@@ -238,6 +238,109 @@ def test_point_cloud_reslap_chain_through_the_container(amd):
     assert_close(to_np(l1.vars["M_L"].grad), t1["dM_L"], 4 * GRAD_RTOL, "layer 1 dM_L", atol_ulps=4 * GRAD_ULPS)
 
 
+def build_point_cloud_network(amd, P, B, max_atom, mode):
+    """The reference's point-cloud network, entry for entry (models/networks/Point_AGCN.py:34-90), through the container it uses."""
+    f = [int(p["weight"].shape[1]) for p in P["conv"]]
+    raw, K = int(P["conv"][0]["M_L"].shape[0]), P["K"]
+    m = amd.DenseConnectedGraphResLap(2, raw, B, max_atom)
+    convs = []
+    for i, (fin, fout) in enumerate(((raw, f[0]), (f[0], f[1]), (f[1], f[2]), (f[2], f[3]))):
+        lay = make_layer(amd, orc.SGC_LL_RESLAP, fout, fin, B, K, mode, P["conv"][i], DEV)
+        lay.save_output = True
+        lay.save_lap = i in (0, 2)
+        convs.append(lay)
+    be = []
+    for i, (res, outw) in enumerate((([f[0], f[1]], f[1]), ([f[2], f[3]], f[3]))):
+        lay = amd.DenseBlockEnd(i, res, outw, "relu", max_atom=max_atom, batch_size=B, device=DEV)
+        b = P["be"][i]
+        lay.load_vars(b["Win"], b["Wout"], b["b1"], b["b2"])
+        be.append(lay)
+    dense = amd.DenseMol(int(P["Wd"].shape[1]), f[3], activation="relu", device=DEV)
+    dense.load_vars(P["Wd"], P["bd"])
+    for lay in (convs[0], convs[1], be[0], convs[2], convs[3], be[1], dense, amd.GraphGatherMol(B, activation="tanh")):
+        m.add(lay)
+    return m, convs, be, dense
+
+
+@pytest.mark.parametrize("mode", [orc.PAPER, orc.REFERENCE], ids=["paper", "reference"])
+def test_point_cloud_network_whole(amd, mode):
+    """The WHOLE point-cloud network of the reference (Point_AGCN.py:34-90: DenseConnectedGraphResLap with the eight-entry layer
+    list -- SGC_LL_Reslap 3 -> 64 (save_lap) -> 128 | DenseBlockEnd | 128 -> 128 (save_lap) -> 64 | DenseBlockEnd | DenseMol 256 |
+    GraphGatherMol; widths utils/hyper_parameters.py:8-24) on clouds of 1024 points (meshloader.py:34-39), forward + backward,
+    against the chained float64 oracle (tests/helpers.py, itself pinned to torch autograd in test_oracle_autograd.py): the
+    readout, the input gradient and every parameter gradient of every layer, bounds calibrated on the chain run in float32.
+    Every convolution must run on the point-cloud kernels (library profiler: no per-graph kernel launches)."""
+    from helpers import (GRAD_RTOL, _scalar_close, point_cloud_network_oracle, point_cloud_network_params)
+    sizes = [1024, 1024, 256]
+    rs = np.random.RandomState(1024)
+    Xs, Ls = [], []
+    for n in sizes:
+        pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        A = (d < 0.6 * d.mean()).astype(np.float64)                       # meshloader.py:264-285 threshold rule
+        np.fill_diagonal(A, 0)
+        _, _, _, L = orc.graph_laplacian([list(np.nonzero(A[i])[0]) for i in range(n)])
+        Xs.append(pts); Ls.append(L.astype(np.float32))
+    P = point_cloud_network_params(rs)
+    B = len(sizes)
+    plan = amd.Plan(sizes, 0, DEV)
+    l0 = np.zeros(int(plan.tile_off[-1]), np.float32)
+    for b, L in enumerate(Ls):
+        l0[int(plan.tile_off[b]):int(plan.tile_off[b]) + L.size] = L.reshape(-1)
+    gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0).to(DEV), l0_ld=0,
+                        l0_symmetric=True)
+    model, convs, be, dense = build_point_cloud_network(amd, P, B, max(sizes), mode)
+    Gout = rs.randn(B, int(P["Wd"].shape[1])).astype(np.float32)
+    Xt = gb.X.clone().requires_grad_(True)
+    gb.X = Xt
+    conv_Y = []                                   # the kernels' Y of every convolution: settles activation ties (helpers)
+    for lay in convs:
+        def recording(x, _call=lay.call):
+            res = _call(x)
+            conv_Y.append(res[0].data.detach())
+            return res
+        lay.call = recording
+    lib = amd._ffi.lib()
+    lib.agcn_profile_enable(1)
+    try:
+        amd._ffi.profile_collect()
+        out = model(gb)
+        (out * torch.from_numpy(Gout).to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        prof = {k: v[1] for k, v in amd._ffi.profile_collect().items() if v[1]}
+    finally:
+        lib.agcn_profile_enable(0)
+    assert tuple(out.shape) == (B, int(P["Wd"].shape[1]))
+    assert len(model.get_laplacian()) == 2 * B and len(model.get_resL_set()) == 4 * B
+    # four convolutions, all on the point-cloud kernels (the 128-feature ones: two halves per strip kernel)
+    assert prof["cloud_sim_kernel"] == 4 and prof["cloud_rlap1_kernel"] == 4 and prof["cloud_lap_kernel"] == 6, prof
+    assert not any(k.startswith(("sgc_forward", "sgc_backward", "fused_", "spec_", "slab_")) for k in prof), prof
+    assert len(conv_Y) == 4
+    r = point_cloud_network_oracle(Xs, Ls, P, Gout, mode, np.float64, Y_ties=[to_np(y) for y in conv_Y])
+    r32 = point_cloud_network_oracle(Xs, Ls, P, Gout, mode, np.float32, Y_ties=r["Y"])
+    assert_close(to_np(out), r["out"], FEATURE_RTOL, "network readout", ref32=r32["out"])
+    assert_close(to_np(Xt.grad), r["dX"], GRAD_RTOL, "network dX", ref32=r32["dX"])
+    for i, lay in enumerate(convs):
+        t, t32 = r["conv_grads"][i], r32["conv_grads"][i]
+        scale = float(np.abs(t["dweight"]).max())
+        assert_close(to_np(lay.vars["weight"].grad), t["dweight"], GRAD_RTOL, "conv %d dweight" % (i + 1), ref32=t32["dweight"])
+        assert_close(to_np(lay.vars["bias"].grad), t["dbias"], GRAD_RTOL, "conv %d dbias" % (i + 1), ref32=t32["dbias"])
+        _scalar_close(to_np(lay.vars["alpha"].grad), t["dalpha"], t32["dalpha"], scale, "conv %d dalpha" % (i + 1))
+        if i > 0:
+            _scalar_close(to_np(lay.vars["beta"].grad), t["dbeta"], t32["dbeta"], scale, "conv %d dbeta" % (i + 1))
+        if mode == orc.PAPER:
+            assert_close(to_np(lay.vars["M_L"].grad), t["dM_L"], GRAD_RTOL, "conv %d dM_L" % (i + 1), ref32=t32["dM_L"])
+        else:
+            assert lay.vars["M_L"].grad is None
+    assert_close(to_np(dense.W.grad), r["dWd"], GRAD_RTOL, "DenseMol dW", ref32=r32["dWd"])
+    for i, lay in enumerate(be):
+        for l, w in enumerate(lay.vars["weight_inblock"]):
+            assert_close(to_np(w.grad), r["be%d_dWin" % i][l], GRAD_RTOL, "block end %d dWin[%d]" % (i, l), ref32=r32["be%d_dWin" % i][l])
+        sc = float(max(np.abs(w).max() for w in r["be%d_dWin" % i]))
+        _scalar_close(to_np(lay.vars["beta_inblock"].grad), r["be%d_db1" % i], r32["be%d_db1" % i], sc, "block end %d dbeta_in" % i)
+    assert_close(to_np(be[1].vars["weight_outblock"][0].grad), r["be1_dWout"][0], GRAD_RTOL, "block end 1 dWout", ref32=r32["be1_dWout"][0])
+
+
 def test_segmentation_graph_backbone_and_two_heads(amd):
     """SegmentationGraph (seg_graph.py:9-125) with Seg_AGCN's layer list shape (Seg_AGCN.py:75-121: SGC_LL, SGC_LL,
     GraphPoolMol backbone; DenseMol -> GraphGatherMol -> FCL classifier head; SGC_LL, SGC_LL -> Merge segmentation head):

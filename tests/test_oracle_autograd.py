@@ -181,3 +181,63 @@ def test_known_answers():
     a = np.float32(-1.75)
     S, _, _ = orc.similarity(np.array([[0.0], [a]], dtype=np.float32), np.array([[1.0]], dtype=np.float32))
     np.testing.assert_allclose(S[0, 1], np.exp(-abs(a)), rtol=1e-6)
+
+
+def test_point_cloud_network_oracle_vs_autograd_f64():
+    """The chained oracle of the reference's point-cloud network (tests/helpers.py: point_cloud_network_oracle; Point_AGCN.py:34-90:
+    four SGC_LL_Reslap in two densely connected blocks, the second and third both reading the FIRST one's saved Laplacian,
+    DenseMol, GraphGatherMol) against the same network written with the independent torch statement of a layer: every
+    gradient, including the two cross-layer Laplacian edges that meet on layer 1's L_sum."""
+    import helpers
+    rs = np.random.RandomState(0)
+    sizes = [40, 17]
+    Xs = [rs.uniform(-1, 1, (n, 3)).astype(np.float32) for n in sizes]
+    Ls = []
+    for x in Xs:
+        n = x.shape[0]
+        d = np.sqrt(((x[:, None] - x[None]) ** 2).sum(-1))
+        A = (d < 0.6 * d.mean()).astype(float)
+        np.fill_diagonal(A, 0)
+        Ls.append(orc.graph_laplacian([list(np.nonzero(A[i])[0]) for i in range(n)])[3].astype(np.float32))
+    P = helpers.point_cloud_network_params(rs, widths=(16, 24, 24, 16), final=12, dense_scale=0.1)
+    G = rs.randn(len(sizes), 12)
+    r = helpers.point_cloud_network_oracle(Xs, Ls, P, G, orc.PAPER)
+    tp = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=True)  # noqa: E731
+    pc = [{k: tp(v) for k, v in p.items()} for p in P["conv"]]
+    be = [{"Win": [tp(w) for w in b["Win"]], "Wout": [tp(w) for w in b["Wout"]], "b1": tp(b["b1"]), "b2": tp(b["b2"])} for b in P["be"]]
+    Wd, bd = tp(P["Wd"]), tp(P["bd"])
+    Xt = [tp(x) for x in Xs]
+    outs, V, M = [], orc.SGC_LL_RESLAP, orc.PAPER
+    for g in range(len(sizes)):
+        L0 = torch.tensor(Ls[g].astype(np.float64))
+        Y1, _, _, La1 = torch_forward(Xt[g], L0, None, pc[0], 2, M, V)
+        Y2, _, _, _ = torch_forward(Y1, L0, La1, pc[1], 2, M, V)
+        B0 = torch.relu(Y2 + (Y1 @ be[0]["Win"][0]) * be[0]["b1"][0] + (Y2 @ be[0]["Win"][1]) * be[0]["b1"][0])
+        Y3, _, _, La3 = torch_forward(B0, L0, La1, pc[2], 2, M, V)
+        Y4, _, _, _ = torch_forward(Y3, L0, La3, pc[3], 2, M, V)
+        B1 = torch.relu(Y4 + (Y3 @ be[1]["Win"][0]) * be[1]["b1"][0] + (Y4 @ be[1]["Win"][1]) * be[1]["b1"][0] +
+                        (B0 @ be[1]["Wout"][0]) * be[1]["b2"][0])
+        outs.append(torch.tanh((B1 @ Wd + bd).sum(0)))
+    out = torch.stack(outs)
+    (out * torch.tensor(G)).sum().backward()
+
+    def close(a, b, what):
+        a, b = np.asarray(a, dtype=np.float64).reshape(-1), b.detach().numpy().reshape(-1)
+        assert np.abs(a - b).max() <= 1e-11 * (np.abs(b).max() + 1e-300), what
+
+    close(r["out"], out, "out")
+    close(r["dX"], torch.cat([x.grad for x in Xt]), "dX")
+    for i in range(4):
+        for k in ("weight", "bias", "M_L", "alpha", "beta"):
+            g, o = pc[i][k].grad, r["conv_grads"][i]["d" + k]
+            assert (g is None) == (o is None), (i, k)
+            if g is not None:
+                close(o, g, "layer %d d%s" % (i + 1, k))
+    close(r["dWd"], Wd.grad, "dWd")
+    close(r["dbd"], bd.grad, "dbd")
+    for i in range(2):
+        for l, w in enumerate(be[i]["Win"]):
+            close(r["be%d_dWin" % i][l], w.grad, "block end %d dWin" % i)
+        close(r["be%d_db1" % i], be[i]["b1"].grad, "block end %d dbeta1" % i)
+    close(r["be1_dWout"][0], be[1]["Wout"][0].grad, "block end 1 dWout")
+    close(r["be1_db2"], be[1]["b2"].grad, "block end 1 dbeta2")
