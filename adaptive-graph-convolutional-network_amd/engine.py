@@ -471,7 +471,10 @@ class GraphedStep(object):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # captured on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were created
+        # on, and one that outlives an iteration (a container or layer attribute that still references the last step's
+        # graph) would otherwise meet the capture on a different stream -- a synchronisation inside the capture
+        with torch.cuda.graph(self.graph, stream=side):
             self.outputs = fn()
 
     def replay(self):

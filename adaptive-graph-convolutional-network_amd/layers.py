@@ -320,7 +320,13 @@ class SGC_LL_Reslap(SGC_LL):
         self._prev_unsym = L_prev is not None and not prev_sym
         x2 = dict(x)
         x2["graph_batch"], x2["node_features"] = gb, X
-        _, nodes, res_L, res_W, L_sum = self._apply(x2, L_prev, prev_sym)
+        try:
+            _, nodes, res_L, res_W, L_sum = self._apply(x2, L_prev, prev_sym)
+        finally:
+            # (the attribute mirrors graphconv_reslap.py:68 for the duration of the call only: kept, it would hold the PREVIOUS
+            #  layer's autograd graph -- and with it that layer's AccumulateGrad nodes -- alive until this layer's next call,
+            #  across iterations and streams: a whole-network step then could not be captured into a HIP graph)
+            self.early_laps = None
         return nodes, res_L, res_W, L_sum
 
 

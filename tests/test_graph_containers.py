@@ -341,6 +341,57 @@ def test_point_cloud_network_whole(amd, mode):
     assert_close(to_np(be[1].vars["weight_outblock"][0].grad), r["be1_dWout"][0], GRAD_RTOL, "block end 1 dWout", ref32=r32["be1_dWout"][0])
 
 
+def test_reslap_container_step_captures_into_one_hip_graph(amd):
+    """A whole ResLap network step (container + autograd forward + backward) as ONE HIP graph (agcn_amd.GraphedStep): replays
+    reproduce the eager step bit for bit.  Regression: SGC_LL_Reslap kept `early_laps` (the previous layer's L_sum, i.e. its
+    whole autograd graph) as an attribute between calls, so the first layer's AccumulateGrad nodes survived from the warm-up
+    into the capture on another stream -- a synchronisation inside the capture (bench.py's point-cloud network line crashed)."""
+    from helpers import point_cloud_network_params
+    sizes = [128, 64]
+    rs = np.random.RandomState(5)
+    Xs, Ls = [], []
+    for n in sizes:
+        pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        d = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+        A = (d < 0.6 * d.mean()).astype(np.float64)
+        np.fill_diagonal(A, 0)
+        _, _, _, L = orc.graph_laplacian([list(np.nonzero(A[i])[0]) for i in range(n)])
+        Xs.append(pts); Ls.append(L.astype(np.float32))
+    P = point_cloud_network_params(rs, widths=(64, 128, 128, 64), final=32, dense_scale=0.05)
+    B = len(sizes)
+    plan = amd.Plan(sizes, 0, DEV)
+    l0 = np.zeros(int(plan.tile_off[-1]), np.float32)
+    for b, L in enumerate(Ls):
+        l0[int(plan.tile_off[b]):int(plan.tile_off[b]) + L.size] = L.reshape(-1)
+    gb = amd.GraphBatch(plan, torch.from_numpy(np.concatenate(Xs)).to(DEV), l0_dense=torch.from_numpy(l0).to(DEV), l0_ld=0,
+                        l0_symmetric=True)
+    model, convs, be, dense = build_point_cloud_network(amd, P, B, max(sizes), orc.PAPER)
+    G = torch.from_numpy(rs.randn(B, 32).astype(np.float32)).to(DEV)
+    params = [v for lay in convs for v in lay.vars.values()] + dense.parameters()
+    for lay in be:
+        params += [lay.vars["beta_inblock"], lay.vars["beta_outblock"]] + lay.vars["weight_inblock"] + lay.vars["weight_outblock"]
+
+    def step():
+        for q in params:
+            q.grad = None
+        out = model(gb)
+        out.backward(G)
+        return out.detach()
+
+    want_out = step().clone()
+    want = [None if q.grad is None else q.grad.clone() for q in params]
+    assert all(lay.early_laps is None for lay in convs)
+    gs = amd.GraphedStep(step, DEV)
+    for _ in range(2):
+        got_out = gs.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got_out, want_out)
+        for q, w in zip(params, want):
+            assert (q.grad is None) == (w is None)
+            if w is not None:
+                assert torch.equal(q.grad, w)
+
+
 def test_segmentation_graph_backbone_and_two_heads(amd):
     """SegmentationGraph (seg_graph.py:9-125) with Seg_AGCN's layer list shape (Seg_AGCN.py:75-121: SGC_LL, SGC_LL,
     GraphPoolMol backbone; DenseMol -> GraphGatherMol -> FCL classifier head; SGC_LL, SGC_LL -> Merge segmentation head):
