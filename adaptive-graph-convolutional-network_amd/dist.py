@@ -81,3 +81,51 @@ def flatten_grads(tensors):
         views.append(flat[o:o + t.numel()].view_as(t))
         o += t.numel()
     return flat, views
+
+
+class GradBucket(object):
+    """ONE flat fp32 bucket behind the `.grad` fields of a list of parameters -- every SGC layer's [weight | bias | M_L | alpha
+    (| beta)], the dense tail, the task heads (140 821 floats = 563 KB for SimpleAGCN + DenseMol + 12 heads) -- so
+    that a whole-network step needs ONE collective.  Each parameter's `.grad` is a view into the bucket; autograd accumulates
+    into the views in place, `zero()` (one memset) starts a step, `all_reduce()` (one RCCL all-reduce, SUM: the reference's
+    loss divides by the GLOBAL batch size, multitask_classifier.py:207-208) ends it.  Works inside `engine.GraphedStep`:
+
+        bucket = dist.GradBucket(params)
+        def step():
+            bucket.zero()
+            loss(model(batch)).backward()
+            bucket.all_reduce()            # captured into the HIP graph behind the last backward kernel (RCCL), or leave it
+        gs = GraphedStep(step, dev)        # out of `step` and call bucket.all_reduce() after gs.replay() (same stream)
+
+    Parameters that get no gradient (M_L in reference mode) keep a zero section."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p is not None and p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("GradBucket holds fp32 parameters of one device")
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.attach()
+
+    def attach(self):
+        """(Re)points every parameter's .grad at its section of the bucket (after something set it to None)."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def zero(self):
+        self.attach()
+        self.flat.zero_()
+
+    def all_reduce(self, group=None):
+        return allreduce_bucket(self.flat, group)
+
+    def nbytes(self):
+        return self.flat.numel() * 4

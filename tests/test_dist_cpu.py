@@ -152,3 +152,61 @@ def test_bucket_equality_world8_full_global_batch(amd):
 def test_single_process_is_noop(amd):
     t = torch.arange(4, dtype=torch.float32)
     assert torch.equal(amd.dist.allreduce_bucket(t.clone()), t)
+
+
+def _bucket_worker(rank, world, port, out_q):
+    """A multi-layer model (two linear stages + a scalar) trained data-parallel with ONE flat bucket behind every .grad
+    (agcn_amd.dist.GradBucket): autograd accumulates into the bucket's views, one SUM all-reduce per step."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import agcn_amd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    agcn_amd.dist.init_from_env("gloo")
+    params, X, G = _bucket_case()
+    n = np.full(X.shape[0], 10, np.int32)
+    mine = agcn_amd.dist.shard_graphs(agcn_amd.dist.graph_cost(n, 4, 3, 2), world)[rank]
+    bucket = agcn_amd.dist.GradBucket(params)
+    for _ in range(2):                                  # second step: the bucket is re-zeroed, not accumulated
+        bucket.zero()
+        _bucket_loss(params, X[mine], G[mine]).backward()
+        bucket.all_reduce()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    if rank == 0:
+        out_q.put(bucket.flat.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _bucket_case():
+    g = torch.Generator().manual_seed(3)
+    W1 = torch.randn(4, 5, generator=g, dtype=torch.float64).float().requires_grad_(True)
+    W2 = torch.randn(5, 3, generator=g).requires_grad_(True)
+    a = torch.ones(1, requires_grad=True)
+    frozen = torch.randn(2, requires_grad=True)         # never reached by the loss: its section stays zero
+    X = torch.randn(16, 4, generator=g)
+    G = torch.randn(16, 3, generator=g)
+    return [W1, W2, a, frozen], X, G
+
+
+def _bucket_loss(params, X, G):
+    W1, W2, a, _ = params
+    return ((torch.relu(X @ W1) @ W2 * a) * G).sum()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_grad_bucket_multilayer_allreduce(amd, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    params, X, G = _bucket_case()
+    _bucket_loss(params, X, G).backward()
+    want = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert np.all(got[-2:] == 0) and got.size == 4 * 5 + 5 * 3 + 1 + 2

@@ -26,14 +26,14 @@ def _free_port():
     return port
 
 
-def _run_ranks(backend, shared, world, out):
+def _run_ranks(backend, shared, world, out, what=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), backend,
-                                       "1" if shared else "0", out], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")] + ([what] if what else []) +
+                                      [backend, "1" if shared else "0", out], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
 
@@ -58,6 +58,32 @@ def test_dp_step_matches_single_rank(flavour, tmp_path):
     # every section of the bucket carries signal (dweight | dbias | dM_L | dalpha)
     for k, g in ref.grads.items():
         assert float(g.abs().max()) > 0, k
+
+
+@pytest.mark.parametrize("flavour", ["gloo_shared", "rccl"])
+def test_dp_multilayer_step_one_bucket(flavour, tmp_path):
+    """The multi-layer step under data parallelism (ONE flat bucket over every layer's gradients): two ranks run
+    the HIP-graphed 4-layer stack + DenseMol + GraphGatherMol on their LPT shards (agcn_amd.dist.GradBucket inside
+    agcn_amd.GraphedStep), one all-reduce of the flat bucket behind each replay; the result equals the single-process
+    gradients of the whole batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = 2
+    if flavour == "rccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL data-parallel test needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    out = str(tmp_path / "stack0.npz")
+    _run_ranks("nccl" if flavour == "rccl" else "gloo", flavour == "gloo_shared", world, out, what="stack")
+    got = np.load(out)
+    assert int(got["ranks"]) == world
+    import dist_worker
+    Fin, Fout, K, data, p, G = dist_worker.global_batch()
+    bucket, _ = dist_worker.run_stack_shard(np.arange(len(data["n"])), torch.device("cuda", 0), graphed=False)
+    torch.cuda.synchronize()
+    want = bucket.flat.cpu().numpy()
+    assert int(got["nbytes"]) == want.size * 4 and want.size == sum(p.numel() for p in bucket.params)
+    # (two shards summed in a different order than one batch: fp32 sums of ~2000-row products)
+    np.testing.assert_allclose(got["bucket"], want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+    assert float(np.abs(want).max()) > 0
 
 
 def test_allreduce_captured_into_the_step_graph(tmp_path):
@@ -88,3 +114,23 @@ def test_bench_launches_its_own_ranks():
     assert res.returncode == 0
     line = json.loads(res.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["value"] > 0
+
+
+@pytest.mark.parametrize("gpus,dtype", [(1, "f32"), (2, "bf16")])
+def test_bench_hiv_epoch_workload(gpus, dtype):
+    """BASELINE config 4's command -- `python bench.py --gpus N --workload hiv-epoch [--dtype bf16]`: the LPT-sharded epoch out
+    of the HBM-resident store, one gradient-bucket all-reduce per global batch -- on this box (N = 2: two ranks sharing cuda:0
+    over gloo when there is one GPU) with a small data set: the line must report the ranks the process group counted, one
+    global batch per step and a positive rate."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if gpus > 1 and torch.cuda.device_count() < gpus:
+        env["AGCN_BENCH_SELFTEST"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "hiv-epoch", "--dtype", dtype,
+                          "--epoch-graphs", "2048", "--steps", "6", "--warmup", "2"], env=env, stdout=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == gpus and line["dtype"] == dtype and line["value"] > 0 and line["steps"] == 6
+    assert line["config"]["global_batch"] == 256 * gpus and line["config"]["global_batches_per_epoch"] == 2048 // (256 * gpus)
+    assert "hiv" in line["config"]["workload"].lower() and line["config"]["bucket_bytes"] == 4 * (150 * 64 + 64 + 75 * 75 + 1)

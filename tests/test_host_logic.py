@@ -309,3 +309,28 @@ def test_member_budget_knob_and_cloud_dispatch(amd):
     assert path([512, 256, 320, 64], 64, 128) == 16 | 64
     assert path([300, 257, 519, 131], 64, 128) == 16          # not multiples of 64: general slab kernels
     assert path(clouds, 3, 64) == 16                             # the first layer has kernels of its own (Fin <= 4)
+
+
+def test_hiv_epoch_plan_is_a_balanced_partition():
+    """bench.py --workload hiv-epoch: global batches in data-set order (the reference's batching rule on the global batch
+    size), each split over the ranks by LPT: a partition of the data set, equal counts per rank and batch (up to one), per-rank
+    work within a few per cent of each other."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import agcn_amd
+    rs = np.random.RandomState(3)
+    n = np.clip(np.rint(rs.lognormal(np.log(23.0), 0.5, size=5000)), 4, 222).astype(np.int32)
+    for world in (1, 2, 8):
+        per_rank = bench.hiv_epoch_plan(n, world, 256, 75, 64, 2)
+        assert len(per_rank) == world and len({len(p) for p in per_rank}) == 1
+        allidx = np.sort(np.concatenate([np.concatenate(p) for p in per_rank]))
+        assert np.array_equal(allidx, np.arange(len(n)))
+        cost = agcn_amd.dist.graph_cost(n, 75, 64, 2)
+        for j in range(len(per_rank[0])):
+            sizes = [len(per_rank[r][j]) for r in range(world)]
+            assert max(sizes) <= 256 and max(sizes) == -(-sum(sizes) // world)      # (never more than the even share, rounded up)
+            loads = np.array([cost[per_rank[r][j]].sum() for r in range(world)], dtype=np.float64)
+            assert loads.max() / loads.mean() < 1.05
