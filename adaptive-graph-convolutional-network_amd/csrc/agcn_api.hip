@@ -12,6 +12,7 @@
 
 #include "sgc_kernels.h"
 #include "spec_backward_coop.h"
+#include "spec_tail.h"
 #include "spec_kernels.h"
 
 namespace agcn {
@@ -362,7 +363,9 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   ReserveLayout r;
   // exchange header of the cooperative kernels (spec_backward_coop.h): fixed size, at offset 0 whatever the batch, zero
   // when the reserve is first used (include/agcn.h) and self-maintaining afterwards
-  r.xch = c.off; c.take((size_t)2 * spec::COOP_HEADER_WORDS);
+  // + the words of the trailing parameter-gradient workgroups (spec_tail.h): generation, exit counter, producer flags
+  r.xch = c.off; c.take((size_t)spec::TAIL_OFF_FLOATS + spec::TAIL_WORDS);
+  static_assert(sizeof(float) * (spec::TAIL_OFF_FLOATS + spec::TAIL_WORDS) <= AGCN_RESERVE_HEADER_BYTES, "reserve header");
   r.Z = c.off; c.take((size_t)pi.rows * d->Fin);
   r.s = c.off; c.take((size_t)pi.rows);
   r.scal = c.off; c.take((size_t)4 * pi.B);
@@ -441,6 +444,17 @@ using namespace agcn;
 static bool cloud_shape(const AgcnLayerDesc* d);
 static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi);
 
+// Parameter gradients as trailing workgroups of the specialised backward launch (spec_tail.h): SGC_LL, paper mode, the
+// whole batch in ONE 16-wave launch (no general fused kernel in front, no 8-wave launch beside it), units within the header.
+// AGCN_SPEC_TAIL=0 keeps the separate parameter-gradient kernel (A/B measurements).
+static bool spec_tail_ok(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, int coop_graphs, int coop_slabs) {
+  static const int on = [] { const char* e = std::getenv("AGCN_SPEC_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!on || fs.mode != 1 || !fs.spec_bwd || d->variant != AGCN_SGC_LL || d->mode != AGCN_MODE_PAPER || d->K != 2) return false;
+  const int B = host.info.B;
+  if (fs.spec_bwd_first != 0 || std::max(fs.spec_bwd_first, fs.spec_small_first) < B) return false;
+  return coop_slabs + (B - coop_graphs) <= spec::TAIL_MAX_UNITS;
+}
+
 extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out) {
   const char* who = "agcn_sgc_ll_dispatch_info";
   int rc = check_desc(desc, who);
@@ -459,6 +473,7 @@ extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGr
   if ((path == 16 || path == 32) && cloud_shape(desc) && cloud_candidate(desc, batch, host.info) &&
       batch->L0_dense != nullptr && slab_quad_ok(host) && (desc->ldx & 3) == 0 && (desc->Fout & 15) == 0 && (desc->ldy & 3) == 0)
     path |= 64;
+  if (spec_tail_ok(desc, host, fs, cgb, csb)) path |= 128;     // the backward launch carries the parameter gradients
   const int32_t v[AGCN_DISPATCH_INFO_INTS] = {path, fs.spec_small_first, cg, cs, dg, cgb, csb, dgb};
   for (int i = 0; i < AGCN_DISPATCH_INFO_INTS; ++i) out[i] = v[i];
   return AGCN_OK;
@@ -866,6 +881,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   const bool fused = fs.mode != 0;
   bool cloud_bwd = false, cloud_res = false;
   bool filter_bwd_zeroed = true;    // the general packed filter adjoint zeroes the one-pass kernel's arrival counters
+  bool tail_done = false;           // the specialised backward launch carried the parameter gradients (spec_tail.h)
   // SGC_LL_Reslap on the point-cloud kernels: only behind the cloud forward (the per-graph forward leaves no r tiles); the
   // same answer in both stages of a split call
   // SGC_LL: either backward works behind either forward (both forwards leave Z, X_1, s and the r tiles)
@@ -957,6 +973,16 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       // leading slabs of the slab table, which is in the same largest-first order), spec_backward_coop.h
       const int first_plain = coop_graphs;
       a.coop_slabs = coop_slabs;
+      // parameter gradients as trailing workgroups of this launch (spec_tail.h): a whole backward call only
+      tail_done = stages == 3 && !conc && !two && spec_tail_ok(desc, host, fs, coop_graphs, coop_slabs) && grads->dweight &&
+                  grads->dbias && grads->dM_L && grads->dalpha;
+      if (tail_done) {
+        a.tail = reinterpret_cast<uint32_t*>(rb + rl.xch) + spec::TAIL_OFF_FLOATS;
+        a.tail_tiles = spec::tail_tiles(desc->Fin, desc->Fout, desc->K, true);
+        a.tail_first = first_plain;
+        a.tail_graphs = B - first_plain;
+        a.g_dweight = grads->dweight; a.g_dbias = grads->dbias; a.g_dM = grads->dM_L; a.g_dalpha = grads->dalpha;
+      }
       SideStream* side = nullptr;
       std::unique_lock<std::mutex> side_lock2;
       if (conc) {   // large graphs beside the small ones, as in the forward
@@ -1076,7 +1102,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     }
     }
   }
-  if (!(stages & 2)) return AGCN_OK;
+  if (!(stages & 2) || tail_done) return AGCN_OK;
 
   ParamGradArgs pa;
   std::memset(&pa, 0, sizeof(pa));

@@ -46,6 +46,12 @@ struct SgcArgs {
   uint32_t* dev_status; // the device's persistent status word (agcn_set_device_status_word) or nullptr: a wait that runs out
                         // counts itself there as well (it outlives the reserve)
   uint32_t coop_ticks;  // bound of such a wait in ticks of the 100 MHz constant clock (agcn_set_coop_timeout_ticks)
+  // parameter gradients as trailing workgroups of the specialised backward launch (spec_tail.h); tail == nullptr: off
+  uint32_t* tail;        // generation word, exit counter and the producer units' flags (reserve header)
+  int32_t tail_tiles;    // trailing workgroups (one per 16 x 16 tile of dweight / dM_L)
+  int32_t tail_first;    // schedule position of the first graph that is a unit of its own (the graphs before it are spread
+  int32_t tail_graphs;   // over member slabs), and how many such graphs
+  float *g_dweight, *g_dbias, *g_dM, *g_dalpha;
   int32_t coop_slabs;   // 16-wave launch: its first coop_slabs workgroups are members (slabs of the plan's slab table),
   int32_t plain_count;  // the next plain_count one graph each, the rest TWO small graphs each (spec_forward.hip)
   int32_t dual_stride;  // floats of LDS between the two halves of such a workgroup

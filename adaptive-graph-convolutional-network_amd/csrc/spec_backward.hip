@@ -14,6 +14,7 @@
 //   B3  every global store: dX, and the hand-off to the parameter-gradient kernel (Gp, dZ, dalpha)
 // No global store precedes the last global load (one in-order vmcnt for loads and stores on gfx950).
 #include "spec_backward_coop.h"
+#include "spec_tail.h"
 #include "spec_kernels.h"
 
 #include <float.h>
@@ -60,6 +61,10 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   const float* Yg = a.Y + (int64_t)row0 * a.ldy;
   const float* dYg = a.dY + (int64_t)row0 * a.ldy;
   const float alpha = a.alpha[0];
+  // parameter gradients as trailing workgroups of this launch (spec_tail.h): dZ and the dalpha partial leave with agent-scope
+  // stores, Gp is not handed off at all (the dweight tiles rebuild it from dY and Y), a flag says when this graph is done
+  const bool tail = !RESLAP && a.tail != nullptr;
+  const uint32_t tgen = tail ? tail_load(a.tail + TAIL_GEN) : 0u;
 
   AGCN_STAMP(4, 0);
   // ---- B0 ------------------------------------------------------------------------------------------------
@@ -612,12 +617,16 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
             const int i = i0 + i4;
             if (i < n) {
               AGCN_ST(8, &dXg[(int64_t)i * a.ldx + f], dxacc[sl][i4] + xacc[sl][i4]);
-              if (paper) a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[sl][i4];
+              if (paper) {
+                if (tail) tail_store_f(a.ws_dZ + (int64_t)(row0 + i) * FIN + f, zacc[sl][i4]);
+                else a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[sl][i4];
+              }
             }
           }
         }
       }
     }
+    if (!tail) {
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
       const int i = wave + NW * u;
@@ -627,12 +636,23 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         if (i < n && c < FOUT) a.ws_Gp[(int64_t)(row0 + i) * FOUT + c] = gpv[u][cp];
       }
     }
+    }
   }
   const float da = body_sum<NW>(dalpha_part, red, tid);
   const float db = RESLAP ? body_sum<NW>(dbeta_part, red, tid) : 0.f;
   if (tid == 0) {
-    a.ws_pg[2 * g.b + 0] = da;
-    a.ws_pg[2 * g.b + 1] = db;
+    if (tail) {
+      tail_store_f(a.ws_pg + 2 * g.b + 0, da);
+    } else {
+      a.ws_pg[2 * g.b + 0] = da;
+      a.ws_pg[2 * g.b + 1] = db;
+    }
+  }
+  if (tail) {
+    tail_publish(a, a.coop_slabs + (gpos - a.tail_first), tgen, tid == 0, [] { __syncthreads(); });
+    if (threadIdx.x == 0) tail_exit(a, tgen);
+    AGCN_STAMP(4, 9);
+    return;
   }
   if (blockIdx.x == 0) {   // arrival counters of the parameter-gradient kernel that follows this one
     for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
@@ -650,7 +670,12 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     spec_backward_body<FIN, FOUT, NW, false, true>(a, first + (int)blockIdx.x, smem);
   } else if constexpr (FULL) {
     // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
+    //       [parameter-gradient tiles: tail_tiles (spec_tail.h)]
     int blk = (int)blockIdx.x;
+    if (a.tail_tiles > 0 && blk >= (int)gridDim.x - a.tail_tiles) {
+      tail_param_grads<FIN, FOUT>(a, blk - ((int)gridDim.x - a.tail_tiles), smem);
+      return;
+    }
     if (blk < a.coop_slabs) {   // (spec_backward_coop.h)
       coop_backward_member<FIN, FOUT>(a, blk, smem);
       return;
@@ -662,6 +687,12 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     }
     spec_backward_body<FIN, FOUT, NW_LARGE, false, false>(a, first + blk, smem);
   } else {
+    if constexpr (NW == NW_LARGE) {
+      if (a.tail_tiles > 0 && (int)blockIdx.x >= (int)gridDim.x - a.tail_tiles) {
+        tail_param_grads<FIN, FOUT>(a, (int)blockIdx.x - ((int)gridDim.x - a.tail_tiles), smem);
+        return;
+      }
+    }
     spec_backward_body<FIN, FOUT, NW, false, false>(a, first + (int)blockIdx.x, smem);
   }
 }
@@ -710,8 +741,10 @@ static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count
   const unsigned members = NW == spec::NW_LARGE ? (unsigned)(a.coop_slabs + a.dual_pairs) : 0u;
   SgcArgs aa = a;
   aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
-  if (full) hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>), dim3(members + count), dim3(64 * NW), lds_bytes, s, aa, first);
-  else hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, false>), dim3(members + count), dim3(64 * NW), lds_bytes, s, aa, first);
+  const unsigned tiles = (NW == spec::NW_LARGE && aa.tail != nullptr) ? (unsigned)aa.tail_tiles : 0u;
+  if (tiles == 0) { aa.tail = nullptr; aa.tail_tiles = 0; }
+  if (full) hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>), dim3(members + count + tiles), dim3(64 * NW), lds_bytes, s, aa, first);
+  else hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, false>), dim3(members + count + tiles), dim3(64 * NW), lds_bytes, s, aa, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_backward launch: %s", hipGetErrorString(e));

@@ -49,6 +49,11 @@ constexpr int COOP_HEADER_WORDS = 2 * COOP_DIR_WORDS;
 // library never clears it; agcn_sgc_ll_reserve_status reads it) and poisons the value it was waiting for with NaN: a
 // timed-out step is wrong loudly, in the gradients AND in the return code of the next status check, never silently.
 constexpr int COOP_STATUS_WORD = COOP_HEADER_WORDS;     // 64-bit word index inside the reserve header
+}  // namespace spec
+}  // namespace agcn
+#include "spec_tail_proto.h"
+namespace agcn {
+namespace spec {
 constexpr unsigned COOP_TIMEOUT_TICKS = 1000000u;   // 10 ms at 100 MHz: the default of agcn_set_coop_timeout_ticks (SgcArgs::coop_ticks)
 __device__ __forceinline__ uint64_t coop_wait_word(uint64_t* status, uint32_t* dev_status, uint32_t ticks, const uint64_t* word, uint32_t want, bool* ok) {
   const unsigned long long t0 = wall_clock64();
@@ -112,6 +117,8 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
   const int me = i0 >> 4;                      // member index == this strip's row tile
   const bool relu = a.activation == AGCN_ACT_RELU;
+  const bool tail = a.tail != nullptr;         // (spec_tail.h)
+  const uint32_t tgen = tail ? tail_load(a.tail + TAIL_GEN) : 0u;
   float* red = smem;
   float* s_vec = smem + d.o_s;
   float* ddv = smem + d.o_dd;
@@ -497,12 +504,13 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
         const int i = i0 + 4 * q + i4;
         if (i < n) {
           dXg[(int64_t)i * a.ldx + f] = dxacc[i4] + acc[i4];
-          a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[i4];
+          if (tail) tail_store_f(a.ws_dZ + (int64_t)(row0 + i) * FIN + f, zacc[i4]);
+          else a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[i4];
         }
       }
     }
   }
-  if (i0 + wave < n) {
+  if (!tail && i0 + wave < n) {
 #pragma unroll
     for (int cp = 0; cp < CPO; ++cp) {
       const int c = lane + 64 * cp;
@@ -511,16 +519,26 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   }
   const float da = block_sum(dalpha_part, red);
   if (tid == 0) {
-    a.ws_pg[2 * (a.B + sl) + 0] = da;
-    a.ws_pg[2 * (a.B + sl) + 1] = 0.f;
-    if (i0 == 0) {
-      a.ws_pg[2 * b + 0] = 0.f;
-      a.ws_pg[2 * b + 1] = 0.f;
+    if (tail) {
+      tail_store_f(a.ws_pg + 2 * (a.B + sl), da);
+      if (i0 == 0) tail_store_f(a.ws_pg + 2 * b, 0.f);
+    } else {
+      a.ws_pg[2 * (a.B + sl) + 0] = da;
+      a.ws_pg[2 * (a.B + sl) + 1] = 0.f;
+      if (i0 == 0) {
+        a.ws_pg[2 * b + 0] = 0.f;
+        a.ws_pg[2 * b + 1] = 0.f;
+      }
     }
     // this member holds every sibling's words by now: its next launch gets a new epoch
     __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   AGCN_STAMP(5, 9);
+  if (tail) {      // (spec_tail.h: this slab's dZ rows are out -> its flag; every workgroup counts itself out)
+    tail_publish(a, sl, tgen, tid == 0, [] { __syncthreads(); });
+    if (tid == 0) tail_exit(a, tgen);
+    return;
+  }
   if (sl == 0) {   // arrival counters of the parameter-gradient kernel that follows
     for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
   }

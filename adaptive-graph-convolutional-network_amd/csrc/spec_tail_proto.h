@@ -1,0 +1,50 @@
+// Constants and the producer / exit side of the trailing parameter-gradient workgroups (spec_tail.h has the description and the
+// consumer).  Included by spec_backward_coop.h behind its own header constants.
+#ifndef AGCN_SPEC_TAIL_PROTO_H_
+#define AGCN_SPEC_TAIL_PROTO_H_
+
+namespace agcn {
+namespace spec {
+
+constexpr int TAIL_OFF_FLOATS = 2 * COOP_HEADER_WORDS + 64;   // behind the exchange words and the status word
+constexpr int TAIL_GEN = 0, TAIL_DONE = 1, TAIL_FLAGS = 8;    // uint32 word indices inside the tail region
+constexpr int TAIL_MAX_UNITS = 4088;                          // flags: 8 + 4088 words = 16 KB; the header is 64 KB
+constexpr int TAIL_WORDS = TAIL_FLAGS + TAIL_MAX_UNITS;
+constexpr int TAIL_T = 16;                                    // output tile: 16 x 16
+
+AGCN_HD inline int tail_tiles(int Fin, int Fout, int K, bool paper) {
+  const int tfW = (Fin * K + TAIL_T - 1) / TAIL_T, tcW = (Fout + TAIL_T - 1) / TAIL_T, tfM = (Fin + TAIL_T - 1) / TAIL_T;
+  return tfW * tcW + (paper ? tfM * tfM : 0);
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t tail_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tail_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tail_store_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float tail_load_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// A producer unit is done: every thread of the unit has issued its agent-scope stores (dZ rows, the dalpha partial).  Each
+// storing wave drains them, the unit's threads meet, one thread publishes.  `bar`: a barrier every thread of the WORKGROUP
+// reaches (the bodies' barriers are workgroup-wide also in the paired flavour).
+template <class Barrier>
+__device__ __forceinline__ void tail_publish(const SgcArgs& a, int slot, uint32_t gen, bool leader, Barrier bar) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bar();
+  if (leader) tail_store(a.tail + TAIL_FLAGS + slot, gen + 1u);
+}
+
+// Every workgroup of the launch, at its very end (one thread): the last one re-arms the protocol for the next launch.
+__device__ __forceinline__ void tail_exit(const SgcArgs& a, uint32_t gen) {
+  const uint32_t old = __hip_atomic_fetch_add(a.tail + TAIL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old == gridDim.x - 1) {
+    tail_store(a.tail + TAIL_DONE, 0u);
+    tail_store(a.tail + TAIL_GEN, gen + 1u);
+  }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace spec
+}  // namespace agcn
+
+#endif  // AGCN_SPEC_TAIL_PROTO_H_

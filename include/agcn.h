@@ -223,7 +223,9 @@ size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const voi
 
 /* Which kernels a forward / backward call on this batch would launch: host logic only (nothing is launched, device
  * pointers of `batch` are only tested for NULL).  out[0] = path: 4 fused one-launch-per-direction kernels (| 1 / | 2:
- * the specialised forward / backward), 8 mixed, 16 slab kernels, 32 per-graph kernels; out[1] = schedule position of
+ * the specialised forward / backward; | 128: a whole-backward call computes the parameter gradients in trailing workgroups
+ * of the backward launch instead of a kernel of their own), 8 mixed, 16 slab kernels, 32 per-graph kernels, | 64 point-cloud
+ * kernels; out[1] = schedule position of
  * the first graph of the 8-wave launch (== B: none); out[2..4] = forward: graphs spread over member workgroups,
  * members, graphs packed two to a workgroup; out[5..7] = the same for the backward. */
 #define AGCN_DISPATCH_INFO_INTS 8
