@@ -220,8 +220,10 @@ def test_dispatch_table(amd):
     members = int(np.ceil(n256[n256 >= 33] / 16.0).sum())
     # the headline batch: specialised kernels, every graph >= 33 nodes spread over members, exactly enough pairs of
     # small graphs for the launch to fit 256 CUs, the same plan for the forward and the backward
+    # (| 128: paper mode, the whole batch in one 16-wave launch -> the backward launch carries the parameter gradients,
+    #  csrc/spec_tail.h)
     d = _dispatch(amd, n256, 75, 64, 1)
-    assert d["path"] == 7 and d["small_first"] == 256
+    assert d["path"] == 7 | 128 and d["small_first"] == 256
     assert (d["f_graphs"], d["f_members"]) == (big, members) == (d["b_graphs"], d["b_members"])
     assert d["f_paired"] == d["b_paired"] == 2 * (256 + members - big - 256) and d["f_paired"] <= tiny
     # reference mode: members in the forward only
@@ -229,17 +231,17 @@ def test_dispatch_table(amd):
     assert d["path"] == 7 and d["f_members"] == members and d["b_members"] == 0 and d["b_paired"] == 0
     # half a chip of graphs: members, nobody paired
     d = _dispatch(amd, tox(128), 75, 64, 1)
-    assert d["path"] == 7 and d["f_members"] > 0 and d["f_paired"] == 0
+    assert d["path"] == 7 | 128 and d["f_members"] > 0 and d["f_paired"] == 0
     # two rounds of workgroups per CU: no members, small graphs in pairs
     d = _dispatch(amd, tox(600), 75, 64, 1)
-    assert d["path"] == 7 and d["small_first"] == 600 and d["f_members"] == 0 and d["f_paired"] > 0
+    assert d["path"] == 7 | 128 and d["small_first"] == 600 and d["f_members"] == 0 and d["f_paired"] > 0
     # 1024 graphs and up: 8-wave launch beside the 16-wave one, nothing else
     d = _dispatch(amd, tox(2048), 75, 64, 1)
     assert d["path"] == 7 and 0 < d["small_first"] < 2048 and d["f_members"] == d["f_paired"] == 0
     # a full batch without enough small graphs: only graphs of five tiles and up are spread
     n = np.concatenate([np.full(250, 40), [96, 80, 64, 40, 40, 40]]).astype(np.int32)
     d = _dispatch(amd, n, 75, 64, 1)
-    assert d["path"] == 7 and d["f_graphs"] == 2 and d["f_members"] == 6 + 5 and d["f_paired"] == 0
+    assert d["path"] == 7 | 128 and d["f_graphs"] == 2 and d["f_members"] == 6 + 5 and d["f_paired"] == 0
     # a molecule beyond the specialised kernels' 96 nodes: the whole batch on the slab kernels (general fused kernels
     # when it is small enough for them); other layer widths / Reslap: general fused kernels
     n = n256.copy()
@@ -248,7 +250,7 @@ def test_dispatch_table(amd):
     # ... unless it is within the members' reach (<= 128 nodes, paper mode): specialised kernels, that graph on 8 members
     n[3] = 120
     d = _dispatch(amd, n, 75, 64, 1)
-    assert d["path"] == 7 and d["f_graphs"] >= 1 and d["f_members"] >= 8 and d["b_members"] == d["f_members"]
+    assert d["path"] == 7 | 128 and d["f_graphs"] >= 1 and d["f_members"] >= 8 and d["b_members"] == d["f_members"]
     assert _dispatch(amd, n, 75, 64, 0)["path"] == 16          # (reference mode: no members in the backward)
     assert _dispatch(amd, n, 128, 128, 1)["path"] == 16        # (the members' LDS plan does not fit at this width)
     assert _dispatch(amd, n256, 80, 64, 1)["path"] == 4
@@ -275,10 +277,10 @@ def test_member_budget_knob_and_cloud_dispatch(amd):
         assert 40 < full <= 120
         lib.agcn_set_coop_members(40)
         d = _dispatch(amd, n256, 75, 64, 1)
-        assert d["path"] == 7 and 0 < d["f_members"] <= 40 and d["b_members"] <= 40
+        assert d["path"] == 7 | 128 and 0 < d["f_members"] <= 40 and d["b_members"] <= 40
         lib.agcn_set_coop_members(0)
         d = _dispatch(amd, n256, 75, 64, 1)
-        assert d["path"] == 7 and d["f_members"] == 0 and d["b_members"] == 0
+        assert d["path"] == 7 | 128 and d["f_members"] == 0 and d["b_members"] == 0
         lib.agcn_set_coop_members(100000)
         assert lib.agcn_get_coop_members() == 120
         lib.agcn_set_coop_members(-5)
