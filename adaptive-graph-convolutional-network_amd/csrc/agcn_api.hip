@@ -446,10 +446,9 @@ static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, con
 
 // Parameter gradients as trailing workgroups of the specialised backward launch (spec_tail.h): SGC_LL, paper mode, the
 // whole batch in ONE 16-wave launch (no general fused kernel in front, no 8-wave launch beside it), units within the header.
-// AGCN_SPEC_TAIL=0 keeps the separate parameter-gradient kernel (A/B measurements).
+// agcn_set_spec_tail(0) / AGCN_SPEC_TAIL=0 keeps the separate parameter-gradient kernel (A/B measurements).
 static bool spec_tail_ok(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, int coop_graphs, int coop_slabs) {
-  static const int on = [] { const char* e = std::getenv("AGCN_SPEC_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (!on || fs.mode != 1 || !fs.spec_bwd || d->variant != AGCN_SGC_LL || d->mode != AGCN_MODE_PAPER || d->K != 2) return false;
+  if (!agcn_get_spec_tail() || fs.mode != 1 || !fs.spec_bwd || d->variant != AGCN_SGC_LL || d->mode != AGCN_MODE_PAPER || d->K != 2) return false;
   const int B = host.info.B;
   if (fs.spec_bwd_first != 0 || std::max(fs.spec_bwd_first, fs.spec_small_first) < B) return false;
   return coop_slabs + (B - coop_graphs) <= spec::TAIL_MAX_UNITS;

@@ -73,6 +73,12 @@ extern "C" void agcn_set_coop_members(int32_t m) { g_coop_members.store(m < 0 ? 
 std::atomic<uint32_t> g_coop_ticks{1000000u};   // 10 ms of the 100 MHz constant clock
 extern "C" uint32_t agcn_get_coop_timeout_ticks(void) { return g_coop_ticks.load(); }
 extern "C" void agcn_set_coop_timeout_ticks(uint32_t ticks) { g_coop_ticks.store(ticks); }
+std::atomic<int32_t> g_spec_tail{[] {
+  const char* e = std::getenv("AGCN_SPEC_TAIL");   // 0: the parameter gradients stay a kernel of their own
+  return (e && e[0] == '0') ? 0 : 1;
+}()};
+extern "C" int32_t agcn_get_spec_tail(void) { return g_spec_tail.load(); }
+extern "C" void agcn_set_spec_tail(int32_t on) { g_spec_tail.store(on ? 1 : 0); }
 extern "C" void agcn_set_spec_small(int32_t on) { g_spec_small.store(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 extern "C" void agcn_set_spec_mode(int32_t mode) { g_spec_mode.store(mode < 0 ? 0 : (mode > 7 ? 7 : mode)); }
 extern "C" int32_t agcn_get_slab_mode(void) { return g_slab_mode.load(); }

@@ -151,7 +151,7 @@ def _sizes(plan, cfg, ldx, ldy):
     # the library's process-wide dispatch knobs change which kernels (and so which workspaces) a call takes
     knobs = (lib.agcn_get_lds_limit(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(),
              lib.agcn_get_fused_global_b(), lib.agcn_get_param_grad_onepass(), lib.agcn_get_spec_mode(),
-             lib.agcn_get_spec_small())
+             lib.agcn_get_spec_small(), lib.agcn_get_spec_tail())
     key = (cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, int(ldx), int(ldy)) + knobs
     cache = plan.__dict__.setdefault("_size_cache", {})
     hit = cache.get(key)

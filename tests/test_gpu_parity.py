@@ -1775,6 +1775,83 @@ def test_cooperative_waits_are_never_silent(amd):
     assert ep.check() == 0
 
 
+@pytest.mark.parametrize("B", [32, 256, 600])
+def test_param_grads_ride_in_the_backward_launch(amd, B):
+    """A whole-backward call on a batch the specialised kernels take in one 16-wave launch (SGC_LL, paper mode) computes
+    dweight / dbias / dM_L / dalpha in TRAILING WORKGROUPS of the backward launch (csrc/spec_tail.h; dispatch bit 128): no
+    parameter-gradient kernel is launched, the gradients equal the separate kernel's (agcn_set_spec_tail(0)) to the gradient
+    tolerance (another summation order) and the float64 oracle's, and they are bit-identical call after call and replay after
+    replay (the producer flags are re-armed by a generation word inside the launch).  B = 32: one workgroup per graph; 256:
+    members + paired small graphs; 600: paired graphs, two rounds of workgroups per CU."""
+    from agcn_amd import synth
+    Fin, Fout, K = 75, 64, 2
+    data = synth.tox21_batch(1000 + B, B, Fin)
+    p = orc.init_params(np.random.RandomState(9), Fin, Fout, K)
+    p["alpha"] = np.array([0.8], np.float32)
+    p["bias"] = (0.1 * np.random.RandomState(10).randn(Fout)).astype(np.float32)
+    gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], DEV)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, orc.PAPER, p, DEV)
+    dY = torch.from_numpy(np.random.RandomState(11).randn(gb.plan.rows, Fout).astype(np.float32)).to(DEV)
+    lib = amd._ffi.lib()
+    assert lib.agcn_get_spec_tail() == 1 and (amd._ffi.dispatch_info(layer, gb)[0] & 128) != 0
+    st = amd.SgcLLStep(layer, gb, dY=dY)
+    lib.agcn_profile_enable(1)
+    try:
+        amd._ffi.profile_collect()
+        st.step()
+        torch.cuda.synchronize()
+        prof = {k: v[1] for k, v in amd._ffi.profile_collect().items() if v[1]}
+    finally:
+        lib.agcn_profile_enable(0)
+    assert prof == {"spec_forward_kernel": 1, "spec_backward_kernel": 1}, prof
+    first = st.bucket.clone()
+    dX = st.dX.clone()
+    assert st.check() == 0 and bool(torch.isfinite(first).all())
+    for _ in range(4):                                   # call after call ...
+        st.step()
+        torch.cuda.synchronize()
+        assert torch.equal(st.bucket, first) and torch.equal(st.dX, dX)
+    st.capture(steps=3)                                  # ... and replay after replay (three steps per launch)
+    for _ in range(3):
+        st.bucket.zero_()
+        st.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(st.bucket, first) and torch.equal(st.dX, dX)
+    assert st.check() == 0
+    # against the separate kernel
+    lib.agcn_set_spec_tail(0)
+    try:
+        assert (amd._ffi.dispatch_info(layer, gb)[0] & 128) == 0
+        st0 = amd.SgcLLStep(layer, gb, dY=dY)
+        st0.step()
+        torch.cuda.synchronize()
+        assert "param_grad" in st0.kernel_names()[2]
+        for k in ("weight", "bias", "M_L", "alpha"):
+            a, b = to_np(st.grads[k]), to_np(st0.grads[k])
+            scale = float(np.abs(to_np(st0.grads["weight"])).max())
+            if a.size == 1:
+                assert abs(float(a.reshape(-1)[0]) - float(b.reshape(-1)[0])) <= 2 * GRAD_RTOL * max(abs(float(b.reshape(-1)[0])), scale), k
+            else:
+                assert_close(a, b, 2 * GRAD_RTOL, "d%s: backward-launch tiles vs the separate kernel" % k)
+        assert torch.equal(st0.dX, dX)
+    finally:
+        lib.agcn_set_spec_tail(1)
+    # and against the float64 oracle
+    G = [to_np(dY)[int(gb.plan.row_off[b]):int(gb.plan.row_off[b]) + int(data["n"][b])] for b in range(B)]
+    L0 = [orc_dense(c, int(nb)) for c, nb in zip(data["csr"], data["n"])]
+    caches, tot, tot32 = oracle_pair(data["X"], L0, p, K, orc.PAPER, orc.SGC_LL, G, Y_got=to_np(st.Y))
+    assert_close(to_np(st.grads["weight"]), tot["dweight"], GRAD_RTOL, "dweight", ref32=tot32["dweight"])
+    assert_close(to_np(st.grads["bias"]), tot["dbias"], GRAD_RTOL, "dbias", ref32=tot32["dbias"])
+    assert_close(to_np(st.grads["M_L"]), tot["dM_L"], GRAD_RTOL, "dM_L", ref32=tot32["dM_L"])
+    from helpers import _scalar_close
+    _scalar_close(to_np(st.grads["alpha"]), tot["dalpha"], tot32["dalpha"], float(np.abs(tot["dweight"]).max()), "dalpha")
+
+
+def orc_dense(csr, n):
+    import scipy.sparse as sp
+    return sp.csr_matrix((np.asarray(csr[2], dtype=np.float64), csr[1], csr[0]), shape=(n, n)).toarray().astype(np.float32)
+
+
 def test_autograd_status_outlives_the_reserve(amd):
     """The autograd path's reserves die with the autograd graph -- right after backward() --, so a wait that ran out must be
     visible AFTER that: agcn_amd.check_device_status() reads a persistent per-device word (agcn_set_device_status_word).
