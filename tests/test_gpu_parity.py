@@ -1642,7 +1642,10 @@ def test_epoch_lanes_give_the_single_lane_results(amd):
             k = (j - 1) % 2
             lanes.streams[k].synchronize()
             prev = lanes.steps[k]
-            got.append((prev.Y.clone(), prev.dX.clone(), prev.bucket.clone()))
+            # (copied ON the lane's stream: a copy on the default stream is not ordered against the lane's next step, which
+            #  reuses these buffers -- with every CU busy it was seen to run after that step's forward had overwritten Y)
+            with torch.cuda.stream(lanes.streams[k]):
+                got.append((prev.Y.clone(), prev.dX.clone(), prev.bucket.clone()))
     lanes.synchronize()
     got.append((st.Y.clone(), st.dX.clone(), st.bucket.clone()))
     assert len(got) == len(want)
@@ -1752,9 +1755,13 @@ def test_cooperative_waits_are_never_silent(amd):
             k = (j - 1) % 2
             lanes.streams[k].synchronize()
             prev = lanes.steps[k]
-            got.append((prev.Y.clone(), prev.dX.clone(), prev.bucket.clone()))
+            # (copied ON the lane's stream: a copy on the default stream is not ordered against the lane's next step, which
+            #  reuses these buffers -- with every CU busy it was seen to run after that step's forward had overwritten Y)
+            with torch.cuda.stream(lanes.streams[k]):
+                got.append((prev.Y.clone(), prev.dX.clone(), prev.bucket.clone()))
     lanes.synchronize(check=False)
     got.append((st.Y.clone(), st.dX.clone(), st.bucket.clone()))
+    torch.cuda.synchronize()
     hog_stream.synchronize()
     raised = False
     for stp in lanes.steps:
