@@ -74,8 +74,11 @@ std::atomic<uint32_t> g_coop_ticks{1000000u};   // 10 ms of the 100 MHz constant
 extern "C" uint32_t agcn_get_coop_timeout_ticks(void) { return g_coop_ticks.load(); }
 extern "C" void agcn_set_coop_timeout_ticks(uint32_t ticks) { g_coop_ticks.store(ticks); }
 std::atomic<int32_t> g_spec_tail{[] {
-  const char* e = std::getenv("AGCN_SPEC_TAIL");   // 0: the parameter gradients stay a kernel of their own
-  return (e && e[0] == '0') ? 0 : 1;
+  // 1: parameter gradients in trailing workgroups of the backward launch (spec_tail.h).  OFF by default: correct and
+  // bit-reproducible, but measured SLOWER (first version, one workgroup per tile walking every row: backward 18.4 + 10.2 -> 80.6 us
+  // -- ~78 dependent k-steps per wave at a memory round trip per eight: profiles/EXPERIMENTS.md)
+  const char* e = std::getenv("AGCN_SPEC_TAIL");
+  return (e && e[0] == '1') ? 1 : 0;
 }()};
 extern "C" int32_t agcn_get_spec_tail(void) { return g_spec_tail.load(); }
 extern "C" void agcn_set_spec_tail(int32_t on) { g_spec_tail.store(on ? 1 : 0); }

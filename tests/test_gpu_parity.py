@@ -1800,7 +1800,9 @@ def test_param_grads_ride_in_the_backward_launch(amd, B):
     layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, orc.PAPER, p, DEV)
     dY = torch.from_numpy(np.random.RandomState(11).randn(gb.plan.rows, Fout).astype(np.float32)).to(DEV)
     lib = amd._ffi.lib()
-    assert lib.agcn_get_spec_tail() == 1 and (amd._ffi.dispatch_info(layer, gb)[0] & 128) != 0
+    prev_tail = lib.agcn_get_spec_tail()
+    lib.agcn_set_spec_tail(1)
+    assert (amd._ffi.dispatch_info(layer, gb)[0] & 128) != 0
     st = amd.SgcLLStep(layer, gb, dY=dY)
     lib.agcn_profile_enable(1)
     try:
@@ -1842,7 +1844,7 @@ def test_param_grads_ride_in_the_backward_launch(amd, B):
                 assert_close(a, b, 2 * GRAD_RTOL, "d%s: backward-launch tiles vs the separate kernel" % k)
         assert torch.equal(st0.dX, dX)
     finally:
-        lib.agcn_set_spec_tail(1)
+        lib.agcn_set_spec_tail(prev_tail)
     # and against the float64 oracle
     G = [to_np(dY)[int(gb.plan.row_off[b]):int(gb.plan.row_off[b]) + int(data["n"][b])] for b in range(B)]
     L0 = [orc_dense(c, int(nb)) for c, nb in zip(data["csr"], data["n"])]

@@ -222,6 +222,8 @@ def test_dispatch_table(amd):
     # small graphs for the launch to fit 256 CUs, the same plan for the forward and the backward
     # (| 128: paper mode, the whole batch in one 16-wave launch -> the backward launch carries the parameter gradients,
     #  csrc/spec_tail.h)
+    prev_tail = amd._ffi.lib().agcn_get_spec_tail()
+    amd._ffi.lib().agcn_set_spec_tail(1)
     d = _dispatch(amd, n256, 75, 64, 1)
     assert d["path"] == 7 | 128 and d["small_first"] == 256
     assert (d["f_graphs"], d["f_members"]) == (big, members) == (d["b_graphs"], d["b_members"])
@@ -252,6 +254,9 @@ def test_dispatch_table(amd):
     d = _dispatch(amd, n, 75, 64, 1)
     assert d["path"] == 7 | 128 and d["f_graphs"] >= 1 and d["f_members"] >= 8 and d["b_members"] == d["f_members"]
     assert _dispatch(amd, n, 75, 64, 0)["path"] == 16          # (reference mode: no members in the backward)
+    amd._ffi.lib().agcn_set_spec_tail(0)
+    assert _dispatch(amd, n256, 75, 64, 1)["path"] == 7
+    amd._ffi.lib().agcn_set_spec_tail(prev_tail)
     assert _dispatch(amd, n, 128, 128, 1)["path"] == 16        # (the members' LDS plan does not fit at this width)
     assert _dispatch(amd, n256, 80, 64, 1)["path"] == 4
     # SGC_LL_Reslap at the specialised widths: the specialised kernels' Reslap flavour, one workgroup per graph (no members,
@@ -277,10 +282,10 @@ def test_member_budget_knob_and_cloud_dispatch(amd):
         assert 40 < full <= 120
         lib.agcn_set_coop_members(40)
         d = _dispatch(amd, n256, 75, 64, 1)
-        assert d["path"] == 7 | 128 and 0 < d["f_members"] <= 40 and d["b_members"] <= 40
+        assert d["path"] & ~128 == 7 and 0 < d["f_members"] <= 40 and d["b_members"] <= 40
         lib.agcn_set_coop_members(0)
         d = _dispatch(amd, n256, 75, 64, 1)
-        assert d["path"] == 7 | 128 and d["f_members"] == 0 and d["b_members"] == 0
+        assert d["path"] & ~128 == 7 and d["f_members"] == 0 and d["b_members"] == 0
         lib.agcn_set_coop_members(100000)
         assert lib.agcn_get_coop_members() == 120
         lib.agcn_set_coop_members(-5)
