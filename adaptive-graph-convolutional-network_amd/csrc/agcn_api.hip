@@ -451,7 +451,15 @@ static bool spec_tail_ok(const AgcnLayerDesc* d, const PlanView& host, const Fus
   if (!agcn_get_spec_tail() || fs.mode != 1 || !fs.spec_bwd || d->variant != AGCN_SGC_LL || d->mode != AGCN_MODE_PAPER || d->K != 2) return false;
   const int B = host.info.B;
   if (fs.spec_bwd_first != 0 || std::max(fs.spec_bwd_first, fs.spec_small_first) < B) return false;
-  return coop_slabs + (B - coop_graphs) <= spec::TAIL_MAX_UNITS;
+  return coop_slabs + (B - coop_graphs) <= spec::TAIL_MAX_UNITS &&
+         spec::tail_tiles(d->Fin, d->Fout, d->K, true) <= spec::TAIL_MAX_TILES;
+}
+// 4-row k-steps of the tail's walk: the graphs that are units of their own + the member slabs
+static int spec_tail_ksteps(const PlanView& host, int coop_graphs, int coop_slabs) {
+  int T = 0;
+  for (int sp = coop_graphs; sp < host.info.B; ++sp) T += (host.n[host.order[sp]] + 3) / 4;
+  for (int sl = 0; sl < coop_slabs; ++sl) T += (std::min(16, host.n[host.slab_graph[sl]] - host.slab_row[sl]) + 3) / 4;
+  return T;
 }
 
 extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out) {
@@ -976,8 +984,14 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       tail_done = stages == 3 && !conc && !two && spec_tail_ok(desc, host, fs, coop_graphs, coop_slabs) && grads->dweight &&
                   grads->dbias && grads->dM_L && grads->dalpha;
       if (tail_done) {
+        const int tiles = spec::tail_tiles(desc->Fin, desc->Fout, desc->K, true);
+        const int S = spec::tail_splits(spec_tail_ksteps(host, coop_graphs, coop_slabs));
+        tail_done = (size_t)(S - 1) * tiles * spec::TAIL_PSTRIDE <= w.part_floats;      // (the partial tiles live in `part`)
+        a.tail_splits = S; a.tail_tiles_per_split = tiles; a.tail_tiles = S * tiles;
+        a.tail_part = w.part;
+      }
+      if (tail_done) {
         a.tail = reinterpret_cast<uint32_t*>(rb + rl.xch) + spec::TAIL_OFF_FLOATS;
-        a.tail_tiles = spec::tail_tiles(desc->Fin, desc->Fout, desc->K, true);
         a.tail_first = first_plain;
         a.tail_graphs = B - first_plain;
         a.g_dweight = grads->dweight; a.g_dbias = grads->dbias; a.g_dM = grads->dM_L; a.g_dalpha = grads->dalpha;

@@ -48,7 +48,9 @@ struct SgcArgs {
   uint32_t coop_ticks;  // bound of such a wait in ticks of the 100 MHz constant clock (agcn_set_coop_timeout_ticks)
   // parameter gradients as trailing workgroups of the specialised backward launch (spec_tail.h); tail == nullptr: off
   uint32_t* tail;        // generation word, exit counter and the producer units' flags (reserve header)
-  int32_t tail_tiles;    // trailing workgroups (one per 16 x 16 tile of dweight / dM_L)
+  int32_t tail_tiles;    // trailing workgroups: tail_splits x tail_tiles_per_split
+  int32_t tail_splits, tail_tiles_per_split;
+  float* tail_part;      // [tail_splits - 1][tiles][TAIL_PSTRIDE] partial tiles of the non-reducing splits (workspace)
   int32_t tail_first;    // schedule position of the first graph that is a unit of its own (the graphs before it are spread
   int32_t tail_graphs;   // over member slabs), and how many such graphs
   float *g_dweight, *g_dbias, *g_dM, *g_dalpha;

@@ -12,13 +12,16 @@
 //   * dweight / dbias tiles need nothing the backward computes (X_0, X_1, dY, Y are final before it starts): they walk all
 //     rows straight away, in the shadow of the large graphs.
 //   * dM_L tiles need dZ, which the producers write.  Every producer UNIT (a plain graph, one graph of a pair, one member slab)
-//     stores its dZ rows with agent-scope stores and then publishes flag[unit] = generation + 1.  A tile walks the units in ONE
-//     FIXED ORDER chosen to follow the expected completion order -- smallest graph first (the schedule backwards), the member
-//     slabs last -- polling the flags 64 at a time and consuming the ready prefix, so that when the last producer finishes only
-//     its own rows are left: flag round trip + one load round trip + the 16-wave sum.
-// No row split, so no cross-workgroup hand-off: a tile's 16 waves share the 4-row k-steps of the walk round-robin (k-step g of
-// the walk -> wave g mod 16: fixed by the plan, whatever the timing), add their accumulators in wave order in LDS and write the
-// result.  Bit-reproducible run to run and replay to replay.
+//     stores its dZ rows with agent-scope stores and then publishes flag[unit] = generation + 1.
+// The units are walked in ONE FIXED ORDER that follows the expected completion order -- smallest graph first (the schedule
+// backwards), the member slabs last -- and the walk's 4-row k-steps are cut into S contiguous SPLITS; a tail workgroup is
+// (split, 16 x 32 tile), 16 waves, k-step g of the split -> wave g mod 16: about ten k-steps per wave, ONE round of loads in
+// flight.  (The first version had no splits: one workgroup per tile walked all ~1250 k-steps, 78 dependent k-steps per wave at
+// a memory round trip per eight -- the backward went from 18.4 + 10.2 to 80.6 us.)  A split waits for the flags of ITS units
+// only, so the early splits are done while the large graphs still run; split S - 1 of a tile -- the largest graphs, which
+// finish last anyway -- is the tile's REDUCER: it first fetches the other splits' partial tiles (handed over with agent-scope
+// stores + a flag per (split, tile)), then waits for its own producers, and adds partials in split order and its own sum last:
+// the order is fixed by the plan, whatever the timing.  Bit-reproducible run to run and replay to replay.
 // Generation protocol (the flags must not be left over from the previous launch / HIP-graph replay on the same reserve):
 // word TAIL_GEN is read by every workgroup when it starts; every workgroup counts itself in TAIL_DONE when it ends, and the
 // last one resets the counter and bumps TAIL_GEN -- i.e. after every workgroup of this launch has read it.  All of it lives in
@@ -32,21 +35,27 @@ namespace agcn {
 namespace spec {
 
 #if defined(__HIPCC__)
-// One tail workgroup = one 16 x 16 output tile; 16 waves.
+// One tail workgroup = (row split s, 16 x 32 output tile); 16 waves.  Grid order: split-major (the early splits -- the smallest
+// graphs -- first).  Split S - 1 of a tile is its REDUCER: it adds the other splits' partial tiles in split order and its own
+// accumulators last, and writes the result.
 template <int FIN, int FOUT>
-__device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int tile, float* smem) {
-  constexpr int K = 2, NWV = 16;
-  constexpr int tfW = (FIN * K + TAIL_T - 1) / TAIL_T, tcW = (FOUT + TAIL_T - 1) / TAIL_T, tfM = (FIN + TAIL_T - 1) / TAIL_T;
+__device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int wg, float* smem) {
+  constexpr int K = 2, NWV = 16, TE = TAIL_TE;
+  constexpr int tfW = (FIN * K + 15) / 16, tcW = (FOUT + 31) / 32, tfM = (FIN + 15) / 16, tcM = (FIN + 31) / 32;
+  constexpr int NTW = tfW * tcW;
+  static_assert(tfM * tcM + NTW <= TAIL_MAX_TILES, "tail tiles");
   const int tid = (int)threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = uni(tid >> 6);
   const uint32_t gen = tail_load(a.tail + TAIL_GEN);
-  const bool isW = tile < tfW * tcW;
-  const int rem = isW ? tile : tile - tfW * tcW;
+  const int tiles = a.tail_tiles_per_split, S = a.tail_splits;
+  const int split = wg / tiles, tile = wg - split * tiles;
+  const bool isW = tile < NTW;
+  const int rem = isW ? tile : tile - NTW;
   const int tf = isW ? tfW : tfM;
   const int itc = rem / tf, itf = rem - itc * tf;
-  const int f0 = itf * TAIL_T, c0 = itc * TAIL_T;
+  const int f0 = itf * 16, c0 = itc * 32;
   const int Fa = isW ? FIN * K : FIN, Fb = isW ? FOUT : FIN;
-  // A operand: column j = f0 + r of [X_0 | X_1] interleaved (j = f * K + k) or of X;  B operand: column c0 + r of Gp or dZ
+  // A operand: column j = f0 + r of [X_0 | X_1] interleaved (j = f * K + k) or of X;  B operand: columns c0 + r, c0 + 16 + r
   const int j = min(f0 + r, Fa - 1);
   const bool jv = (f0 + r) < Fa;
   const float* Ap;
@@ -55,158 +64,209 @@ __device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int til
     const int f = j >> 1;
     if ((j & 1) == 0) { Ap = a.X + f; lda = a.ldx; } else { Ap = a.sv_X + f; lda = FIN; }
   } else { Ap = a.X + j; lda = a.ldx; }
-  const int c = min(c0 + r, Fb - 1);
-  const bool cv = (c0 + r) < Fb;
+  const int cA = min(c0 + r, Fb - 1), cB = min(c0 + 16 + r, Fb - 1);
+  const bool cAv = (c0 + r) < Fb, cBv = (c0 + 16 + r) < Fb;
   const bool relu = a.activation == AGCN_ACT_RELU;
   const bool with_bias = isW && itf == 0;
-  const bool last_tile = tile == (int)tail_tiles(FIN, FOUT, K, a.mode == AGCN_MODE_PAPER) - 1;
-
-  // the walk: positions 0 .. G-1 = the graphs of schedule positions first + G - 1 down to first (smallest first), then the
-  // member slabs 0 .. coop_slabs - 1
-  const int G = a.tail_graphs, P = G + a.coop_slabs;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  int64_t kbase = 0;                 // k-steps of the walk in front of the current window
-  bool timed_out = false;
+  const bool reducer = split == S - 1;
   const unsigned long long t_start = wall_clock64();
-#pragma unroll 1
-  for (int pos = 0; pos < P; pos += 64) {
-    // lane i: unit pos + i
-    const int u = pos + lane;
-    int urow = 0, un = 0, slot = 0;
+  bool timed_out = false;
+  float* wsum = smem;                          // [16][512]
+  float* bs = smem + NWV * TE;                 // [16][32]
+  int* any_timeout = reinterpret_cast<int*>(smem + NWV * TE + NWV * 32);
+
+  // ---- the reducer fetches the other splits' partial tiles first: their producers are the smaller graphs -----------------
+  float part[TAIL_MAX_SPLITS - 1];     // thread tid: element tid of the partial tile (tid < 512) or bias partial tid - 512
+#pragma unroll
+  for (int x = 0; x < TAIL_MAX_SPLITS - 1; ++x) part[x] = 0.f;
+  if (reducer && S > 1) {
+    const uint32_t* f2 = a.tail + TAIL_FLAGS2 + tile;      // flag of (split x, tile): f2[x * tiles]
+    for (;;) {
+      const uint32_t fl = (lane < S - 1) ? tail_load(f2 + lane * tiles) : gen + 1u;
+      if (__ballot(fl == gen + 1u) == ~0ull) break;
+      if (wall_clock64() - t_start >= (unsigned long long)a.coop_ticks) { timed_out = true; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (!timed_out && tid < TE + 32) {
+#pragma unroll
+      for (int x = 0; x < TAIL_MAX_SPLITS - 1; ++x)
+        if (x < S - 1) {
+          const float* pp = a.tail_part + ((int64_t)x * tiles + tile) * TAIL_PSTRIDE;
+          if (tid < TE || with_bias) part[x] = tail_load_f(pp + tid);
+        }
+    }
+  }
+
+  // ---- the walk: units 0 .. G-1 = the graphs of schedule positions first + G - 1 down to first (smallest first), then the
+  // member slabs; lane l holds the units l, l + 64, ... (TAIL_NWIN windows) and the inclusive prefix of their k-steps ----------
+  const int G = a.tail_graphs, P = G + a.coop_slabs;
+  int urow[TAIL_NWIN], un[TAIL_NWIN], pe[TAIL_NWIN];
+  int carry = 0;
+#pragma unroll
+  for (int w = 0; w < TAIL_NWIN; ++w) {
+    const int u = 64 * w + lane;
+    urow[w] = 0; un[w] = 0;
     if (u < G) {
       const int sp = a.tail_first + (G - 1 - u);
       const AgcnGraphDesc* gd = a.graph_desc + sp;
-      un = gd->n; urow = gd->row0;
-      slot = a.coop_slabs + (sp - a.tail_first);
+      un[w] = gd->n; urow[w] = gd->row0;
     } else if (u < P) {
       const int sl = u - G;
       const int b = a.slab_graph[sl], i0 = a.slab_row[sl];
-      urow = a.row_off[b] + i0;
-      un = min(16, a.n[b] - i0);
-      slot = sl;
+      urow[w] = a.row_off[b] + i0;
+      un[w] = min(16, a.n[b] - i0);
     }
-    const int ks = (un + 3) >> 2;
-    // inclusive prefix of the k-steps over the window's lanes
-    int pe = ks;
+  }
+#pragma unroll
+  for (int w = 0; w < TAIL_NWIN; ++w) {
+    int v = (un[w] + 3) >> 2;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(pe, o, 64);
-      if (lane >= o) pe += v;
+      const int t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
     }
-    const int pb = pe - ks;
-    const int Tw = __shfl(pe, 63, 64);
-    // this wave's k-steps of the window: t with (kbase + t) % 16 == wave
-    int t = (int)(((int64_t)wave - kbase) & 15);
-    int nready = isW ? 64 : 0;
+    pe[w] = v + carry;
+    carry = __shfl(pe[w], 63, 64);
+  }
+  const int T = carry;                                   // k-steps of the whole walk (== a.tail_ksteps)
+  const int K0 = (int)(((int64_t)T * split) / S), K1 = (int)(((int64_t)T * (split + 1)) / S);
+  // unit of walk k-step g: the number of units whose inclusive prefix is <= g
+  auto unit_of = [&](int g) {
+    int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < TAIL_NWIN; ++w) cnt += __builtin_popcountll(__ballot(pe[w] <= g));
+    return cnt;
+  };
+  // ---- wait for this split's producers (dM_L tiles only) -------------------------------------------------------------------
+  if (!isW && K1 > K0 && !timed_out) {
+    const int u0 = unit_of(K0), u1 = unit_of(K1 - 1);     // units u0 .. u1
     for (;;) {
-      if (!isW) {
-        const uint32_t fl = (u < P) ? tail_load(a.tail + TAIL_FLAGS + slot) : gen + 1u;
-        const unsigned long long ok = __ballot(fl == gen + 1u);
-        const int lead = (ok == ~0ull) ? 64 : __builtin_ctzll(~ok);
-        if (lead == nready) {
-          if (wall_clock64() - t_start >= (unsigned long long)a.coop_ticks + 1000000ull) { timed_out = true; break; }
-          __builtin_amdgcn_s_sleep(4);
-          continue;
-        }
-        nready = lead;
-      }
-      const int Tr = nready == 64 ? Tw : __shfl(pb, nready, 64);   // k-steps of the ready prefix
-      // eight k-steps per round: all loads requested, then the products
-#pragma unroll 1
-      while (t < Tr) {
-        float av[8], bv[8], yv[8];
-        bool rv[8];
+      bool ok = true;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          const int tt = t + 16 * x;
-          const bool in = tt < Tr;
-          const int tc = in ? tt : t;
-          const int ui = __builtin_popcountll(__ballot(pe <= tc));       // unit of k-step tc (window-local)
-          const int row = __shfl(urow, ui, 64) + 4 * (tc - __shfl(pb, ui, 64)) + q;
-          const bool valid = in && (4 * (tc - __shfl(pb, ui, 64)) + q) < __shfl(un, ui, 64);
-          const int rowc = min(row, a.rows - 1);
-          rv[x] = valid;
-          av[x] = Ap[(int64_t)rowc * lda];
-          if (isW) {
-            bv[x] = a.dY[(int64_t)rowc * a.ldy + c];
-            yv[x] = a.Y[(int64_t)rowc * a.ldy + c];
-          } else {
-            bv[x] = tail_load_f(a.ws_dZ + (int64_t)rowc * FIN + c);
-            yv[x] = 1.f;
-          }
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          const float xa = (rv[x] && jv) ? av[x] : 0.f;
-          float xb = (rv[x] && cv) ? bv[x] : 0.f;
-          if (isW && relu && !(yv[x] > 0.f)) xb = 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xb, acc, 0, 0, 0);
-          bsum += xb;
-        }
-        t += 16 * min(8, (Tr - t + 15) >> 4);      // (only the k-steps that were inside the ready prefix)
+      for (int w = 0; w < TAIL_NWIN; ++w) {
+        const int u = 64 * w + lane;
+        // flag slot of unit u: graphs behind the member slabs, in schedule order (the walk runs the schedule backwards)
+        const int slot = u < G ? a.coop_slabs + (G - 1 - u) : u - G;
+        if (u >= u0 && u <= u1) ok = ok && (tail_load(a.tail + TAIL_FLAGS + slot) == gen + 1u);
       }
-      if (nready == 64) break;
+      if (__ballot(ok) == ~0ull) break;
+      if (wall_clock64() - t_start >= (unsigned long long)a.coop_ticks) { timed_out = true; break; }
+      __builtin_amdgcn_s_sleep(4);
     }
-    if (timed_out) break;
-    kbase += Tw;
   }
-  // ---- the tile: sum of the 16 waves' accumulators in wave order ---------------------------------------------------------
-  float* wsum = smem;                         // [16][256]
-  float* bs = smem + NWV * 256;               // [16][16]
+  // ---- this wave's k-steps of the split: K0 + wave, + 16, ...; TAIL_KR per round, all loads of a round in flight --------------
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  float bsum0 = 0.f, bsum1 = 0.f;
+  if (!timed_out) {
+#pragma unroll 1
+    for (int g0 = K0 + wave; g0 < K1; g0 += 16 * TAIL_KR) {
+      float av[TAIL_KR], b0[TAIL_KR], b1[TAIL_KR], y0[TAIL_KR], y1[TAIL_KR];
+      bool rv[TAIL_KR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) wsum[wave * 256 + (4 * q + i) * 16 + r] = acc[i];
-  if (with_bias) {
-    float b = bsum;                           // column c0 + r: the four row groups q of the lane's k-steps
-    b += __shfl_xor(b, 16, 64);
-    b += __shfl_xor(b, 32, 64);
-    if (q == 0) bs[wave * 16 + r] = b;
+      for (int x = 0; x < TAIL_KR; ++x) {
+        const int g = g0 + 16 * x;
+        const bool in = g < K1;
+        const int gc = in ? g : g0;
+        const int ui = unit_of(gc);
+        int ur = 0, nn = 0, pend = 0;
+#pragma unroll
+        for (int w = 0; w < TAIL_NWIN; ++w)
+          if ((ui >> 6) == w) { ur = __shfl(urow[w], ui & 63, 64); nn = __shfl(un[w], ui & 63, 64); pend = __shfl(pe[w], ui & 63, 64); }
+        const int jstep = gc - (pend - ((nn + 3) >> 2));          // k-step inside the unit
+        const int row = ur + 4 * jstep + q;
+        rv[x] = in && (4 * jstep + q) < nn;
+        const int rowc = min(row, a.rows - 1);
+        av[x] = Ap[(int64_t)rowc * lda];
+        if (isW) {
+          b0[x] = a.dY[(int64_t)rowc * a.ldy + cA]; b1[x] = a.dY[(int64_t)rowc * a.ldy + cB];
+          y0[x] = a.Y[(int64_t)rowc * a.ldy + cA]; y1[x] = a.Y[(int64_t)rowc * a.ldy + cB];
+        } else {
+          b0[x] = tail_load_f(a.ws_dZ + (int64_t)rowc * FIN + cA); b1[x] = tail_load_f(a.ws_dZ + (int64_t)rowc * FIN + cB);
+          y0[x] = y1[x] = 1.f;
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < TAIL_KR; ++x) {
+        const float xa = (rv[x] && jv) ? av[x] : 0.f;
+        float xb0 = (rv[x] && cAv) ? b0[x] : 0.f, xb1 = (rv[x] && cBv) ? b1[x] : 0.f;
+        if (isW && relu) { if (!(y0[x] > 0.f)) xb0 = 0.f; if (!(y1[x] > 0.f)) xb1 = 0.f; }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xb0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xb1, acc1, 0, 0, 0);
+        bsum0 += xb0; bsum1 += xb1;
+      }
+    }
   }
-  int* any_timeout = reinterpret_cast<int*>(smem + NWV * 256 + 256);
+  // ---- the split's tile: the 16 waves' accumulators in wave order ------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    wsum[wave * TE + (4 * q + i) * 32 + r] = acc0[i];
+    wsum[wave * TE + (4 * q + i) * 32 + 16 + r] = acc1[i];
+  }
+  if (with_bias) {
+    float u0 = bsum0, u1 = bsum1;
+    u0 += __shfl_xor(u0, 16, 64); u0 += __shfl_xor(u0, 32, 64);
+    u1 += __shfl_xor(u1, 16, 64); u1 += __shfl_xor(u1, 32, 64);
+    if (q == 0) { bs[wave * 32 + r] = u0; bs[wave * 32 + 16 + r] = u1; }
+  }
   if (tid == 0) *any_timeout = 0;
   __syncthreads();
   if (timed_out && lane == 0) *any_timeout = 1;
   __syncthreads();
   const bool bad = *any_timeout != 0;
-  if (tid < 256) {
-    float v = 0.f;
+  float v = 0.f;
+  if (tid < TE) {
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) v += wsum[w * 256 + tid];
-    if (bad) v = __builtin_nanf("");
-    const int ff = f0 + (tid >> 4), cc = c0 + (tid & 15);
-    if (ff < Fa && cc < Fb) {
-      if (isW) a.g_dweight[(int64_t)ff * FOUT + cc] = v;
-      else a.g_dM[(int64_t)ff * FIN + cc] = v;
+    for (int w = 0; w < NWV; ++w) v += wsum[w * TE + tid];
+  } else if (tid < TE + 32 && with_bias) {
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) v += bs[w * 32 + (tid - TE)];
+  }
+  if (!reducer) {
+    // hand-off: the partial tile (+ bias partials) with agent-scope stores, then the flag of (split, tile)
+    float* pp = a.tail_part + ((int64_t)split * tiles + tile) * TAIL_PSTRIDE;
+    if (tid < TE || (tid < TE + 32 && with_bias)) tail_store_f(pp + tid, bad ? __builtin_nanf("") : v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) tail_store(a.tail + TAIL_FLAGS2 + split * tiles + tile, gen + 1u);
+  } else {
+    float t = 0.f;
+#pragma unroll
+    for (int x = 0; x < TAIL_MAX_SPLITS - 1; ++x)
+      if (x < S - 1) t += part[x];
+    t += v;
+    if (bad) t = __builtin_nanf("");
+    if (tid < TE) {
+      const int ff = f0 + (tid >> 5), cc = c0 + (tid & 31);
+      if (ff < Fa && cc < Fb) {
+        if (isW) a.g_dweight[(int64_t)ff * FOUT + cc] = t;
+        else a.g_dM[(int64_t)ff * FIN + cc] = t;
+      }
+    } else if (tid < TE + 32 && with_bias) {
+      const int cc = c0 + (tid - TE);
+      if (cc < FOUT) a.g_dbias[cc] = t;
     }
-  } else if (tid < 272 && with_bias) {
-    const int cc = tid - 256;
-    float v = 0.f;
+    // dalpha: the per-unit partials, by the reducer of the LAST tile (a dM_L tile: every split of it has waited for its
+    // producers, and this workgroup has seen every split's flag), one wave, index order
+    if (tile == tiles - 1 && wave == 0 && a.g_dalpha != nullptr) {
+      const int npg = a.B + a.coop_slabs;
+      float tsum = 0.f;
+      for (int b0i = 0; b0i < npg; b0i += 64 * 8) {
+        float pv[8];
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) v += bs[w * 16 + cc];
-    if (bad) v = __builtin_nanf("");
-    if (c0 + cc < FOUT) a.g_dbias[c0 + cc] = v;
+        for (int x = 0; x < 8; ++x) {
+          const int b = b0i + 64 * x + lane;
+          pv[x] = b < npg ? tail_load_f(a.ws_pg + 2 * b) : 0.f;
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) tsum += pv[x];
+      }
+      tsum = wave_sum(tsum);
+      if (lane == 0) a.g_dalpha[0] = bad ? __builtin_nanf("") : tsum;
+    }
   }
   if (bad && tid == 0) {
     __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(a.sv_xch + COOP_STATUS_WORD), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.dev_status != nullptr) __hip_atomic_fetch_add(a.dev_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // dalpha: the per-unit partials (agent-scope stores of the producers, in front of their flags), by the LAST tile -- a dM_L
-  // tile in paper mode, which has seen every flag by now --, one wave, index order
-  if (last_tile && wave == 0 && a.g_dalpha != nullptr) {
-    const int npg = a.B + a.coop_slabs;
-    float tsum = 0.f;
-    for (int b0 = 0; b0 < npg; b0 += 64 * 8) {
-      float v[8];
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        const int b = b0 + 64 * x + lane;
-        v[x] = b < npg ? tail_load_f(a.ws_pg + 2 * b) : 0.f;
-      }
-#pragma unroll
-      for (int x = 0; x < 8; ++x) tsum += v[x];
-    }
-    tsum = wave_sum(tsum);
-    if (lane == 0) a.g_dalpha[0] = bad ? __builtin_nanf("") : tsum;
   }
   if (tid == 0) tail_exit(a, gen);
 }

@@ -8,13 +8,24 @@ namespace spec {
 
 constexpr int TAIL_OFF_FLOATS = 2 * COOP_HEADER_WORDS + 64;   // behind the exchange words and the status word
 constexpr int TAIL_GEN = 0, TAIL_DONE = 1, TAIL_FLAGS = 8;    // uint32 word indices inside the tail region
-constexpr int TAIL_MAX_UNITS = 4088;                          // flags: 8 + 4088 words = 16 KB; the header is 64 KB
-constexpr int TAIL_WORDS = TAIL_FLAGS + TAIL_MAX_UNITS;
-constexpr int TAIL_T = 16;                                    // output tile: 16 x 16
+constexpr int TAIL_NWIN = 6;                                  // the walk is held in registers: 6 windows of 64 units
+constexpr int TAIL_MAX_UNITS = 64 * TAIL_NWIN;
+constexpr int TAIL_MAX_SPLITS = 12;
+constexpr int TAIL_MAX_TILES = 128;                           // (128 -> 128: 16 * 4 + 8 * 4 = 96)
+constexpr int TAIL_FLAGS2 = TAIL_FLAGS + TAIL_MAX_UNITS;      // flags of the partial tiles, [split][tile]
+constexpr int TAIL_WORDS = TAIL_FLAGS2 + TAIL_MAX_SPLITS * TAIL_MAX_TILES;
+constexpr int TAIL_TE = 512;                                  // output tile: 16 x 32
+constexpr int TAIL_PSTRIDE = TAIL_TE + 32;                    // floats per partial tile (+ the bias partials of its columns)
+constexpr int TAIL_KR = 8;                                    // k-steps per wave and round of loads
 
+// output tiles of dweight (16 rows of the interleaved [f * K + k] index x 32 columns) and dM_L
 AGCN_HD inline int tail_tiles(int Fin, int Fout, int K, bool paper) {
-  const int tfW = (Fin * K + TAIL_T - 1) / TAIL_T, tcW = (Fout + TAIL_T - 1) / TAIL_T, tfM = (Fin + TAIL_T - 1) / TAIL_T;
-  return tfW * tcW + (paper ? tfM * tfM : 0);
+  return ((Fin * K + 15) / 16) * ((Fout + 31) / 32) + (paper ? ((Fin + 15) / 16) * ((Fin + 31) / 32) : 0);
+}
+// row splits for a walk of T k-steps: about TAIL_KR k-steps per wave (16 waves per workgroup)
+AGCN_HD inline int tail_splits(int T) {
+  int s = (T + 16 * TAIL_KR - 1) / (16 * TAIL_KR);
+  return s < 1 ? 1 : (s > TAIL_MAX_SPLITS ? TAIL_MAX_SPLITS : s);
 }
 
 #if defined(__HIPCC__)

@@ -1782,14 +1782,14 @@ def test_cooperative_waits_are_never_silent(amd):
     assert ep.check() == 0
 
 
-@pytest.mark.parametrize("B", [32, 256, 600])
+@pytest.mark.parametrize("B", [32, 256, 380])
 def test_param_grads_ride_in_the_backward_launch(amd, B):
     """A whole-backward call on a batch the specialised kernels take in one 16-wave launch (SGC_LL, paper mode) computes
     dweight / dbias / dM_L / dalpha in TRAILING WORKGROUPS of the backward launch (csrc/spec_tail.h; dispatch bit 128): no
     parameter-gradient kernel is launched, the gradients equal the separate kernel's (agcn_set_spec_tail(0)) to the gradient
     tolerance (another summation order) and the float64 oracle's, and they are bit-identical call after call and replay after
     replay (the producer flags are re-armed by a generation word inside the launch).  B = 32: one workgroup per graph; 256:
-    members + paired small graphs; 600: paired graphs, two rounds of workgroups per CU."""
+    members + paired small graphs; 380: members and pairs, more workgroups than CUs."""
     from agcn_amd import synth
     Fin, Fout, K = 75, 64, 2
     data = synth.tox21_batch(1000 + B, B, Fin)
