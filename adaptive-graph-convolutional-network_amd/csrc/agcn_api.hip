@@ -986,9 +986,12 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       if (tail_done) {
         const int tiles = spec::tail_tiles(desc->Fin, desc->Fout, desc->K, true);
         const int S = spec::tail_splits(spec_tail_ksteps(host, coop_graphs, coop_slabs));
-        tail_done = (size_t)(S - 1) * tiles * spec::TAIL_PSTRIDE <= w.part_floats;      // (the partial tiles live in `part`)
+        tail_done = (size_t)(S - 1) * tiles * spec::TAIL_PSTRIDE <= w.part_floats &&     // (the partial tiles live in `part`)
+                    coop_slabs + (B - coop_graphs) + S * tiles <= spec::TAIL_MAX_WGS;
         a.tail_splits = S; a.tail_tiles_per_split = tiles; a.tail_tiles = S * tiles;
         a.tail_part = w.part;
+        static const int dbg = [] { const char* e = std::getenv("AGCN_TAIL_DEBUG"); return e ? std::atoi(e) : 0; }();
+        a.tail_debug = dbg;
       }
       if (tail_done) {
         a.tail = reinterpret_cast<uint32_t*>(rb + rl.xch) + spec::TAIL_OFF_FLOATS;

@@ -51,6 +51,7 @@ struct SgcArgs {
   int32_t tail_tiles;    // trailing workgroups: tail_splits x tail_tiles_per_split
   int32_t tail_splits, tail_tiles_per_split;
   float* tail_part;      // [tail_splits - 1][tiles][TAIL_PSTRIDE] partial tiles of the non-reducing splits (workspace)
+  int32_t tail_debug;    // AGCN_TAIL_DEBUG (timing experiments only): 1 tail workgroups exit at once, 2 no flag waits, 4 no products
   int32_t tail_first;    // schedule position of the first graph that is a unit of its own (the graphs before it are spread
   int32_t tail_graphs;   // over member slabs), and how many such graphs
   float *g_dweight, *g_dbias, *g_dM, *g_dalpha;

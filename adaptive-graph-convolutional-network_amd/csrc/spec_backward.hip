@@ -65,6 +65,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   // stores, Gp is not handed off at all (the dweight tiles rebuild it from dY and Y), a flag says when this graph is done
   const bool tail = !RESLAP && a.tail != nullptr;
   const uint32_t tgen = tail ? tail_load(a.tail + TAIL_GEN) : 0u;
+  if (tail && threadIdx.x == 0) tail_started(a, tgen);
 
   AGCN_STAMP(4, 0);
   // ---- B0 ------------------------------------------------------------------------------------------------
@@ -650,7 +651,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   }
   if (tail) {
     tail_publish(a, a.coop_slabs + (gpos - a.tail_first), tgen, tid == 0, [] { __syncthreads(); });
-    if (threadIdx.x == 0) tail_exit(a, tgen);
     AGCN_STAMP(4, 9);
     return;
   }

@@ -119,6 +119,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const bool relu = a.activation == AGCN_ACT_RELU;
   const bool tail = a.tail != nullptr;         // (spec_tail.h)
   const uint32_t tgen = tail ? tail_load(a.tail + TAIL_GEN) : 0u;
+  if (tail && tid == 0) tail_started(a, tgen);
   float* red = smem;
   float* s_vec = smem + d.o_s;
   float* ddv = smem + d.o_dd;
@@ -536,7 +537,6 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 9);
   if (tail) {      // (spec_tail.h: this slab's dZ rows are out -> its flag; every workgroup counts itself out)
     tail_publish(a, sl, tgen, tid == 0, [] { __syncthreads(); });
-    if (tid == 0) tail_exit(a, tgen);
     return;
   }
   if (sl == 0) {   // arrival counters of the parameter-gradient kernel that follows

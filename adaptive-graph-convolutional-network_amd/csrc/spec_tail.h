@@ -23,9 +23,10 @@
 // stores + a flag per (split, tile)), then waits for its own producers, and adds partials in split order and its own sum last:
 // the order is fixed by the plan, whatever the timing.  Bit-reproducible run to run and replay to replay.
 // Generation protocol (the flags must not be left over from the previous launch / HIP-graph replay on the same reserve):
-// word TAIL_GEN is read by every workgroup when it starts; every workgroup counts itself in TAIL_DONE when it ends, and the
-// last one resets the counter and bumps TAIL_GEN -- i.e. after every workgroup of this launch has read it.  All of it lives in
-// the reserve header (zero when a reserve is first used: include/agcn.h).
+// word TAIL_GEN is read by every workgroup when it starts, and each says so with a plain agent-scope store into a word of its own
+// (TAIL_STARTED + blockIdx); one designated tail workgroup bumps TAIL_GEN once it has seen all of those -- i.e. after every
+// workgroup of this launch has read it.  (No read-modify-write atomics: an exit counter on one address serialised ~600
+// device-scope atomics, +40 us.)  All of it lives in the reserve header (zero when a reserve is first used: include/agcn.h).
 #ifndef AGCN_SPEC_TAIL_H_
 #define AGCN_SPEC_TAIL_H_
 
@@ -47,6 +48,11 @@ __device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int wg,
   const int tid = (int)threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = uni(tid >> 6);
   const uint32_t gen = tail_load(a.tail + TAIL_GEN);
+  if (tid == 0) tail_started(a, gen);
+  if (a.tail_debug & 1) {
+    if (wg == (a.tail_splits - 1) * a.tail_tiles_per_split && wave == 0) tail_bump(a, gen, lane);
+    return;
+  }
   const int tiles = a.tail_tiles_per_split, S = a.tail_splits;
   const int split = wg / tiles, tile = wg - split * tiles;
   const bool isW = tile < NTW;
@@ -79,7 +85,7 @@ __device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int wg,
   float part[TAIL_MAX_SPLITS - 1];     // thread tid: element tid of the partial tile (tid < 512) or bias partial tid - 512
 #pragma unroll
   for (int x = 0; x < TAIL_MAX_SPLITS - 1; ++x) part[x] = 0.f;
-  if (reducer && S > 1) {
+  if (reducer && S > 1 && !(a.tail_debug & 2)) {
     const uint32_t* f2 = a.tail + TAIL_FLAGS2 + tile;      // flag of (split x, tile): f2[x * tiles]
     for (;;) {
       const uint32_t fl = (lane < S - 1) ? tail_load(f2 + lane * tiles) : gen + 1u;
@@ -138,7 +144,7 @@ __device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int wg,
     return cnt;
   };
   // ---- wait for this split's producers (dM_L tiles only) -------------------------------------------------------------------
-  if (!isW && K1 > K0 && !timed_out) {
+  if (!isW && K1 > K0 && !timed_out && !(a.tail_debug & 2)) {
     const int u0 = unit_of(K0), u1 = unit_of(K1 - 1);     // units u0 .. u1
     for (;;) {
       bool ok = true;
@@ -157,7 +163,7 @@ __device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int wg,
   // ---- this wave's k-steps of the split: K0 + wave, + 16, ...; TAIL_KR per round, all loads of a round in flight --------------
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
   float bsum0 = 0.f, bsum1 = 0.f;
-  if (!timed_out) {
+  if (!timed_out && !(a.tail_debug & 4)) {
 #pragma unroll 1
     for (int g0 = K0 + wave; g0 < K1; g0 += 16 * TAIL_KR) {
       float av[TAIL_KR], b0[TAIL_KR], b1[TAIL_KR], y0[TAIL_KR], y1[TAIL_KR];
@@ -268,7 +274,8 @@ __device__ __forceinline__ void tail_param_grads(const SgcArgs& a, const int wg,
     __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(a.sv_xch + COOP_STATUS_WORD), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.dev_status != nullptr) __hip_atomic_fetch_add(a.dev_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tid == 0) tail_exit(a, gen);
+  // the generation word moves on once every workgroup of the launch has read it: by the reducer of tile 0 (a dweight tile)
+  if (reducer && tile == 0 && wave == 0) tail_bump(a, gen, lane);
 }
 #endif  // __HIPCC__
 

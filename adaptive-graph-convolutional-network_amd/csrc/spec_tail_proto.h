@@ -13,7 +13,9 @@ constexpr int TAIL_MAX_UNITS = 64 * TAIL_NWIN;
 constexpr int TAIL_MAX_SPLITS = 12;
 constexpr int TAIL_MAX_TILES = 128;                           // (128 -> 128: 16 * 4 + 8 * 4 = 96)
 constexpr int TAIL_FLAGS2 = TAIL_FLAGS + TAIL_MAX_UNITS;      // flags of the partial tiles, [split][tile]
-constexpr int TAIL_WORDS = TAIL_FLAGS2 + TAIL_MAX_SPLITS * TAIL_MAX_TILES;
+constexpr int TAIL_STARTED = TAIL_FLAGS2 + TAIL_MAX_SPLITS * TAIL_MAX_TILES;   // one word per workgroup of the launch
+constexpr int TAIL_MAX_WGS = 4096;
+constexpr int TAIL_WORDS = TAIL_STARTED + TAIL_MAX_WGS;
 constexpr int TAIL_TE = 512;                                  // output tile: 16 x 32
 constexpr int TAIL_PSTRIDE = TAIL_TE + 32;                    // floats per partial tile (+ the bias partials of its columns)
 constexpr int TAIL_KR = 8;                                    // k-steps per wave and round of loads
@@ -44,15 +46,25 @@ __device__ __forceinline__ void tail_publish(const SgcArgs& a, int slot, uint32_
   if (leader) tail_store(a.tail + TAIL_FLAGS + slot, gen + 1u);
 }
 
-// Every workgroup of the launch, at its very end (one thread): the last one re-arms the protocol for the next launch.
-__device__ __forceinline__ void tail_exit(const SgcArgs& a, uint32_t gen) {
-  const uint32_t old = __hip_atomic_fetch_add(a.tail + TAIL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (old == gridDim.x - 1) {
-    tail_store(a.tail + TAIL_DONE, 0u);
-    tail_store(a.tail + TAIL_GEN, gen + 1u);
-  }
+// Every workgroup of the launch, as soon as it has read the generation word (one thread): "I have read it".  Plain agent-scope
+// stores -- an exit COUNTER on one address (first version) serialised ~600 device-scope atomics: +40 us on the launch.
+__device__ __forceinline__ void tail_started(const SgcArgs& a, uint32_t gen) {
+  tail_store(a.tail + TAIL_STARTED + blockIdx.x, gen + 1u);
 }
-
+// ONE designated workgroup (a dweight reducer: done early, off the critical path), at its end (one wave): when every workgroup
+// of the launch has read the generation word it may change -- the next launch's flags are told apart by it.
+__device__ __forceinline__ void tail_bump(const SgcArgs& a, uint32_t gen, int lane) {
+  const int n = (int)gridDim.x;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+    for (int i = lane; i < n; i += 64) ok = ok && (tail_load(a.tail + TAIL_STARTED + i) == gen + 1u);
+    if (__ballot(ok) == ~0ull) break;
+    if (wall_clock64() - t0 >= 100000000ull) break;     // (1 s: a launch that never got all its workgroups started)
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (lane == 0) tail_store(a.tail + TAIL_GEN, gen + 1u);
+}
 #endif  // __HIPCC__
 
 }  // namespace spec
