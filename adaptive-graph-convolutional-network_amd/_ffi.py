@@ -25,7 +25,8 @@ class PlanInfo(C.Structure):
 
 class LayerDesc(C.Structure):
     _fields_ = [("Fin", C.c_int32), ("Fout", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32),
-                ("variant", C.c_int32), ("activation", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32)]
+                ("variant", C.c_int32), ("activation", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32),
+                ("feat_dtype", C.c_int32)]
 
 
 class GraphBatch(C.Structure):

@@ -62,6 +62,8 @@ int check_desc(const AgcnLayerDesc* d, const char* who) {
   if (d->activation != AGCN_ACT_LINEAR && d->activation != AGCN_ACT_RELU)
     return fail(AGCN_EINVAL, "%s: unsupported activation %d (linear or relu)", who, d->activation);
   if (d->ldx < d->Fin || d->ldy < d->Fout) return fail(AGCN_EINVAL, "%s: ldx/ldy smaller than Fin/Fout", who);
+  if (d->feat_dtype != AGCN_DTYPE_F32 && d->feat_dtype != AGCN_DTYPE_BF16)
+    return fail(AGCN_EINVAL, "%s: unknown feature dtype %d", who, d->feat_dtype);
   return AGCN_OK;
 }
 
@@ -357,7 +359,7 @@ SideStream& side_stream() {
   return ss;
 }
 
-struct ReserveLayout { size_t Z, s, scal, X, Lpre, r, MT, WT, xch, total; };
+struct ReserveLayout { size_t Z, s, scal, X, X0, Lpre, r, MT, WT, xch, total; };
 ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   Carver c(nullptr);
   ReserveLayout r;
@@ -370,6 +372,8 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   r.s = c.off; c.take((size_t)pi.rows);
   r.scal = c.off; c.take((size_t)4 * pi.B);
   r.X = c.off; c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
+  // bf16 feature storage: the widened fp32 copy of X the forward leaves for the backward and the parameter gradients
+  r.X0 = c.off; if (d->feat_dtype == AGCN_DTYPE_BF16) c.take((size_t)pi.rows * d->Fin);
   r.Lpre = c.off; if (d->variant == AGCN_SGC_LL_RESLAP) c.take((size_t)pi.tile_elems);
   // r_ij tiles (fused and slab paths, paper mode): reserved whenever one of them COULD be taken
   r.r = c.off;
@@ -420,6 +424,7 @@ void fill_common(SgcArgs& a, const AgcnLayerDesc* d, const AgcnGraphBatch* g, co
   a.weight = p->weight; a.bias = p->bias; a.M_L = p->M_L; a.alpha = p->alpha; a.beta = p->beta;
   a.Y = o->Y; a.res_L = o->res_L; a.res_W = o->res_W; a.L_sum = o->L_sum;
   a.foff = 0; a.fstride = d->Fin; a.half_acc = 0; a.half_last = 1;
+  a.feat_bf16 = d->feat_dtype == AGCN_DTYPE_BF16 ? 1 : 0; a.lddx = d->ldx;
 }
 
 int check_batch(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnParams* p, const char* who) {
@@ -443,6 +448,13 @@ using namespace agcn;
 // pointer is dereferenced).  For tests and diagnostics.
 static bool cloud_shape(const AgcnLayerDesc* d);
 static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi);
+
+// bf16 feature storage is served when every graph of the batch takes the specialised kernels in both directions (the general
+// fused / slab / per-graph kernels read and write fp32 rows only)
+static bool bf16_served(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs) {
+  (void)host;
+  return fs.mode == 1 && fs.spec_fwd && fs.spec_bwd && d->variant == AGCN_SGC_LL && d->K == 2 && fs.spec_bwd_first == 0;
+}
 
 // Parameter gradients as trailing workgroups of the specialised backward launch (spec_tail.h): SGC_LL, paper mode, the
 // whole batch in ONE 16-wave launch (no general fused kernel in front, no 8-wave launch beside it), units within the header.
@@ -481,6 +493,7 @@ extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGr
       batch->L0_dense != nullptr && slab_quad_ok(host) && (desc->ldx & 3) == 0 && (desc->Fout & 15) == 0 && (desc->ldy & 3) == 0)
     path |= 64;
   if (spec_tail_ok(desc, host, fs, cgb, csb)) path |= 128;     // the backward launch carries the parameter gradients
+  if (bf16_served(desc, host, fs)) path |= 256;                // feat_dtype = AGCN_DTYPE_BF16 is served on this batch
   const int32_t v[AGCN_DISPATCH_INFO_INTS] = {path, fs.spec_small_first, cg, cs, dg, cgb, csb, dgb};
   for (int i = 0; i < AGCN_DISPATCH_INFO_INTS; ++i) out[i] = v[i];
   return AGCN_OK;
@@ -646,6 +659,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_s = reinterpret_cast<float*>(rb + rl.s);
   a.sv_scal = reinterpret_cast<float*>(rb + rl.scal);
   a.sv_X = reinterpret_cast<float*>(rb + rl.X);
+  a.sv_X0 = reinterpret_cast<float*>(rb + rl.X0);
   a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
@@ -654,6 +668,12 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.coop_ticks = agcn_get_coop_timeout_ticks();
   a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
   a.tp_first = host.info.B - 1;
+  if (a.feat_bf16) {   // (host logic: which kernels this batch takes)
+    const FusedSplit fsb = fused_split(desc, batch, host);
+    if (!bf16_served(desc, host, fsb))
+      return fail(AGCN_EINVAL, "%s: bf16 features are read / written by the specialised kernels only and this batch does not take "
+                  "them (agcn_sgc_ll_dispatch_info bit 256); convert with agcn_cast_rows", who);
+  }
 
   Carver c(workspace);
   const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
@@ -873,6 +893,14 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.coop_slabs = 0; a.plain_count = 0; a.dual_pairs = 0; a.dual_stride = 0;
   a.tp_first = host.info.B - 1;
   a.dY = dY; a.dL_sum = dL_sum; a.dX = grads->dX; a.dL_prev = has_prev ? grads->dL_prev : nullptr;
+  if (a.feat_bf16) {
+    const FusedSplit fsb = fused_split(desc, batch, host);
+    if (!bf16_served(desc, host, fsb))
+      return fail(AGCN_EINVAL, "%s: bf16 features are read / written by the specialised kernels only (agcn_sgc_ll_dispatch_info)", who);
+    // X as the forward widened it (the reserve's fp32 copy): the backward and the parameter gradients read fp32 rows
+    a.sv_X0 = reinterpret_cast<float*>(rb + rl.X0);
+    a.X = a.sv_X0; a.ldx = desc->Fin;
+  }
   a.ws_g = w.g; a.ws_dZ = w.dZ; a.ws_pg = w.pg; a.ws_tile = w.tile; a.ws_buf = w.buf;
 
   // Reslap with K == 1 and no incoming dL_sum: L never reaches Y, so dL_prev == 0
@@ -1123,11 +1151,11 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   ParamGradArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.rows = host.info.rows; pa.Fin = desc->Fin; pa.Fout = desc->Fout; pa.K = desc->K;
-  pa.ldx = desc->ldx; pa.paper = paper ? 1 : 0;
+  pa.ldx = a.ldx; pa.paper = paper ? 1 : 0;
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = fused ? B + fs.n_big_slabs + coop_slabs : ((slabs || cloud_res || cloud_bwd) ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
-  pa.X = batch->X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
+  pa.X = a.X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
   pa.counters_zeroed = ((stages & 1) && ((!cloud_bwd && !cloud_res) || (desc->Fin == 128 && filter_bwd_zeroed))) ? 1 : 0;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;

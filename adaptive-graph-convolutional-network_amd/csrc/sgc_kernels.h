@@ -19,6 +19,9 @@ struct SgcArgs {
   // layer
   int32_t Fin, Fout, K, mode, variant, activation, ldx, ldy;
   // inputs
+  int32_t feat_bf16;   // 1: X (forward), Y, dY, dX are bf16 matrices (specialised kernels only); the forward then leaves a
+  float* sv_X0;        // widened fp32 copy of X in the reserve ([rows][Fin]) and the backward / parameter gradients read that
+  int32_t lddx;        // row stride of dX in elements (the backward's X may be the reserve copy with stride Fin)
   const float* X;
   const float* L0_dense;
   int32_t L0_ld;

@@ -95,21 +95,28 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   }
   // dY, Y rows: wave w takes rows w, w + NW, ..
   float gy[RPW][CPO], yy[RPW][CPO];
+  by_dtype(a.feat_bf16 != 0, [&](auto BF) {
 #pragma unroll
-  for (int u = 0; u < RPW; ++u) {
-    const int i = min(wave + NW * u, n - 1);
+    for (int u = 0; u < RPW; ++u) {
+      const int i = min(wave + NW * u, n - 1);
 #pragma unroll
-    for (int cp = 0; cp < CPO; ++cp) {
-      const int c = min(lane + 64 * cp, FOUT - 1);
-      gy[u][cp] = 0.f;
-      yy[u][cp] = 0.f;
-      // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
-      if (u < rpw) {
-        gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
-        yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
+      for (int cp = 0; cp < CPO; ++cp) {
+        const int c = min(lane + 64 * cp, FOUT - 1);
+        gy[u][cp] = 0.f;
+        yy[u][cp] = 0.f;
+        // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
+        if (u < rpw) {
+          if constexpr (decltype(BF)::value) {
+            gy[u][cp] = bf16_load(a.dY, (int64_t)(row0 + i) * a.ldy + c);
+            yy[u][cp] = bf16_load(a.Y, (int64_t)(row0 + i) * a.ldy + c);
+          } else {
+            gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
+            yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
+          }
+        }
       }
     }
-  }
+  });
   if (t1a < t1b) load_wc(wb0, t1a, 0, 0);
   // r tile rows (the forward stored r_ij for i < j)
   float rr[RPW][2];
@@ -572,7 +579,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   AGCN_STAMP(4, 8);
   // ---- dX += dZ M_L^T, then B3: every global store -------------------------------------------------------------
   {
-    float* dXg = a.dX + (int64_t)row0 * a.ldx;
+    float* dXg = a.dX + (int64_t)row0 * a.lddx;
     auto mma_mc = [&](f32x4 acc, const float (&bf)[CHM], int t, int ch) {
       const float* Ap = DZimg + ((t / NCB) * 16 + r) * LDX + q;
 #pragma unroll
@@ -617,7 +624,8 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
           for (int i4 = 0; i4 < 4; ++i4) {
             const int i = i0 + i4;
             if (i < n) {
-              AGCN_ST(8, &dXg[(int64_t)i * a.ldx + f], dxacc[sl][i4] + xacc[sl][i4]);
+              if (a.feat_bf16) bf16_store(a.dX, (int64_t)(row0 + i) * a.lddx + f, dxacc[sl][i4] + xacc[sl][i4]);
+              else AGCN_ST(8, &dXg[(int64_t)i * a.lddx + f], dxacc[sl][i4] + xacc[sl][i4]);
               if (paper) {
                 if (tail) tail_store_f(a.ws_dZ + (int64_t)(row0 + i) * FIN + f, zacc[sl][i4]);
                 else a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[sl][i4];

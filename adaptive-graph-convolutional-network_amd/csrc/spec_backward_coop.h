@@ -156,20 +156,28 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     csr_p1 = a.L0_rowptr[row0 + tid + 1];
   }
   float gy[RPW][CPO], yy[RPW][CPO];
+  by_dtype(a.feat_bf16 != 0, [&](auto BF) {
 #pragma unroll
-  for (int u = 0; u < RPW; ++u) {
-    const int i = min(wave + NW * u, n - 1);
+    for (int u = 0; u < RPW; ++u) {
+      const int i = min(wave + NW * u, n - 1);
 #pragma unroll
-    for (int cp = 0; cp < CPO; ++cp) {
-      const int c = min(lane + 64 * cp, FOUT - 1);
-      gy[u][cp] = 0.f;
-      yy[u][cp] = 0.f;
-      if (u < rpw) {
-        gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
-        yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
+      for (int cp = 0; cp < CPO; ++cp) {
+        const int c = min(lane + 64 * cp, FOUT - 1);
+        gy[u][cp] = 0.f;
+        yy[u][cp] = 0.f;
+        // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
+        if (u < rpw) {
+          if constexpr (decltype(BF)::value) {
+            gy[u][cp] = bf16_load(a.dY, (int64_t)(row0 + i) * a.ldy + c);
+            yy[u][cp] = bf16_load(a.Y, (int64_t)(row0 + i) * a.ldy + c);
+          } else {
+            gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
+            yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
+          }
+        }
       }
     }
-  }
+  });
   // r rows of the strip: wave il owns row i0 + il (the forward stored both triangles for these graphs)
   float rr[2];
   {
@@ -499,12 +507,13 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     }
     const int f = cb * 16 + r;
     if (f < FIN) {
-      float* dXg = a.dX + (int64_t)row0 * a.ldx;
+      float* dXg = a.dX + (int64_t)row0 * a.lddx;
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
         const int i = i0 + 4 * q + i4;
         if (i < n) {
-          dXg[(int64_t)i * a.ldx + f] = dxacc[i4] + acc[i4];
+          if (a.feat_bf16) bf16_store(a.dX, (int64_t)(row0 + i) * a.lddx + f, dxacc[i4] + acc[i4]);
+          else dXg[(int64_t)i * a.lddx + f] = dxacc[i4] + acc[i4];
           if (tail) tail_store_f(a.ws_dZ + (int64_t)(row0 + i) * FIN + f, zacc[i4]);
           else a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[i4];
         }
@@ -608,12 +617,18 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   }
   for (int ib = wave; ib < n4; ib += 4 * NW) {
     float xr[4][CP];
+    by_dtype(a.feat_bf16 != 0, [&](auto BF) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* rp = Xg + (int64_t)min(ib + NW * u, n - 1) * a.ldx;
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ro = (int64_t)min(ib + NW * u, n - 1) * a.ldx;
 #pragma unroll
-      for (int cp = 0; cp < CP; ++cp) xr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
-    }
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = min(lane + 64 * cp, FIN - 1);
+          if constexpr (decltype(BF)::value) xr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
+          else xr[u][cp] = Xg[ro + c];
+        }
+      }
+    });
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = ib + NW * u;
@@ -833,7 +848,8 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       if (i < n) {
         float v = acc[i4] + bias;
         if (relu) v = fmaxf(v, 0.f);
-        Yg[(int64_t)i * a.ldy + c] = v;
+        if (a.feat_bf16) bf16_store(a.Y, (int64_t)(row0 + i) * a.ldy + c, v);
+        else Yg[(int64_t)i * a.ldy + c] = v;
       }
     }
   }
@@ -843,6 +859,14 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     for (int cp = 0; cp < CP; ++cp) {
       const int c = lane + 64 * cp;
       if (c < FIN) Xo[c] = X1s[wave * LDX + c];
+    }
+    if (a.feat_bf16) {   // ... and, bf16 features, the widened X rows of the strip (spec_kernels.h)
+      float* X0o = a.sv_X0 + (int64_t)(row0 + i0 + wave) * FIN;
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        const int c = lane + 64 * cp;
+        if (c < FIN) X0o[c] = Ximg[(i0 + wave) * LDX + c];
+      }
     }
   }
   if (i0 == 0) {

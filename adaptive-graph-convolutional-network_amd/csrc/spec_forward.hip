@@ -86,12 +86,18 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
   // X rows: wave w takes rows w, w + 16, ..; lanes run along the features
   for (int i0 = wave; i0 < n4; i0 += 4 * NW) {
     float xr[4][CP];
+    by_dtype(a.feat_bf16 != 0, [&](auto BF) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* rp = Xg + (int64_t)min(i0 + NW * u, n - 1) * a.ldx;
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ro = (int64_t)min(i0 + NW * u, n - 1) * a.ldx;
 #pragma unroll
-      for (int cp = 0; cp < CP; ++cp) xr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
-    }
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = min(lane + 64 * cp, FIN - 1);
+          if constexpr (decltype(BF)::value) xr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
+          else xr[u][cp] = Xg[ro + c];
+        }
+      }
+    });
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + NW * u;
@@ -441,7 +447,8 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
           if (i0 + i4 < n) {
             float v = yacc[sl][i4] + ybias[sl];
             if (relu) v = fmaxf(v, 0.f);
-            AGCN_ST(4, &Yg[(int64_t)(i0 + i4) * a.ldy + c], v);
+            if (a.feat_bf16) bf16_store(a.Y, (int64_t)(row0 + i0 + i4) * a.ldy + c, v);      // (stores only: no load behind them)
+            else AGCN_ST(4, &Yg[(int64_t)(i0 + i4) * a.ldy + c], v);
           }
         }
       }
@@ -454,6 +461,15 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         const int c = lane + 64 * cp;
         if (c < FIN) AGCN_ST(2, &Xo[i * FIN + c], X1img[i * LDX + c]);
       }
+    if (a.feat_bf16) {     // the widened X rows for the backward and the parameter gradients
+      float* X0o = a.sv_X0 + (int64_t)row0 * FIN;
+      for (int i = wave; i < n; i += NW)
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < FIN) X0o[i * FIN + c] = Ximg[i * LDX + c];
+        }
+    }
   }
   // The blocks of the last (smallest) graphs of the batch -- positions tp_first .. B-1, at most 32 of them -- also leave
   // transposed copies of the parameters in the reserve for the backward kernel (its B operands W^T and M_L^T then load

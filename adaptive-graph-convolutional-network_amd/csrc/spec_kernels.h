@@ -11,6 +11,7 @@
 #ifndef AGCN_SPEC_KERNELS_H_
 #define AGCN_SPEC_KERNELS_H_
 
+#include <type_traits>
 #include "agcn_device.h"
 #include "sgc_kernels.h"
 
@@ -108,6 +109,24 @@ AGCN_HD inline BwdLds bwd_lds(int n, int F4, int Fout, int NW) {
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_exp_neg(float r) { return __builtin_amdgcn_exp2f(r * -1.44269504088896341f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// bf16 feature storage (AgcnLayerDesc.feat_dtype = AGCN_DTYPE_BF16: X, Y, dY, dX are bf16 matrices with the same row strides in
+// ELEMENTS): widened exactly on load, rounded to nearest even on store (NaN stays NaN); everything in between is fp32
+__device__ __forceinline__ float bf16_load(const float* base, int64_t idx) {
+  return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[idx] << 16);
+}
+__device__ __forceinline__ void bf16_store(float* base, int64_t idx, float v) {
+  uint32_t u = __float_as_uint(v);
+  u = ((u & 0x7fffffffu) > 0x7f800000u) ? (u | 0x00400000u) : u + 0x7fffu + ((u >> 16) & 1u);
+  reinterpret_cast<uint16_t*>(base)[idx] = (uint16_t)(u >> 16);
+}
+// the two flavours of a load / store loop: `body(std::true_type / false_type)`, chosen by ONE wave-uniform branch around the
+// whole loop (a dtype test per load would put every load into a branch region of its own, and a load in one is waited for
+// before the next is issued)
+template <class F>
+__device__ __forceinline__ void by_dtype(bool bf, F body) {
+  if (bf) body(std::true_type{}); else body(std::false_type{});
+}
 
 // LDS-only workgroup barrier: global stores issued before it need not have completed.
 __device__ __forceinline__ void lds_barrier() { __syncthreads(); }

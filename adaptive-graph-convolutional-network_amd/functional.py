@@ -119,9 +119,11 @@ class UnpackRowsFunction(torch.autograd.Function):
 
 
 class _Cfg(object):
-    __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation", "lsum", "prev_sym")
+    __slots__ = ("Fin", "Fout", "K", "mode", "variant", "activation", "lsum", "prev_sym", "bf16")
 
-    def __init__(self, Fin, Fout, K, mode, variant, activation, lsum=True, prev_sym=False):
+    def __init__(self, Fin, Fout, K, mode, variant, activation, lsum=True, prev_sym=False, bf16=False):
+        # bf16: X / Y / dY / dX are bf16 tensors read and written by the kernels themselves (AgcnLayerDesc.feat_dtype)
+        self.bf16 = bool(bf16)
         # prev_sym: the caller vouches that L_prev is symmetric (AgcnGraphBatch.L_prev_symmetric)
         self.prev_sym = bool(prev_sym)
         self.Fin, self.Fout, self.K = int(Fin), int(Fout), int(K)
@@ -133,7 +135,7 @@ class _Cfg(object):
 
 def _desc(cfg, ldx, ldy):
     return _ffi.LayerDesc(cfg.Fin, cfg.Fout, cfg.K, _ffi.MODE[cfg.mode], _ffi.VARIANT[cfg.variant],
-                          _ffi.ACT[cfg.activation], int(ldx), int(ldy))
+                          _ffi.ACT[cfg.activation], int(ldx), int(ldy), 1 if getattr(cfg, "bf16", False) else 0)
 
 
 def _gbatch(batch, X, L_prev, prev_symmetric=False):
@@ -152,7 +154,7 @@ def _sizes(plan, cfg, ldx, ldy):
     knobs = (lib.agcn_get_lds_limit(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(),
              lib.agcn_get_fused_global_b(), lib.agcn_get_param_grad_onepass(), lib.agcn_get_spec_mode(),
              lib.agcn_get_spec_small(), lib.agcn_get_spec_tail())
-    key = (cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, int(ldx), int(ldy)) + knobs
+    key = (cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, int(ldx), int(ldy), bool(cfg.bf16)) + knobs
     cache = plan.__dict__.setdefault("_size_cache", {})
     hit = cache.get(key)
     if hit is None:
@@ -209,7 +211,13 @@ class SgcLLFunction(torch.autograd.Function):
     def forward(ctx, X, weight, bias, M_L, alpha, beta, L_prev, batch, cfg):
         lib = _ffi.lib()
         _require_gpu(X, "node features")
-        X = _f32c(X, "node features")
+        fdt = torch.bfloat16 if cfg.bf16 else torch.float32
+        if cfg.bf16:
+            if X.dtype != torch.bfloat16:
+                raise TypeError("a bf16 layer call needs bf16 node features")
+            X = X if X.is_contiguous() else X.contiguous()
+        else:
+            X = _f32c(X, "node features")
         weight, bias, M_L, alpha = (_f32c(weight, "weight"), _f32c(bias, "bias"), _f32c(M_L, "M_L"),
                                     _f32c(alpha, "alpha"))
         plan = batch.plan
@@ -228,7 +236,7 @@ class SgcLLFunction(torch.autograd.Function):
         dev = X.device
         _status_word(dev)
         ldx, ldy = X.shape[1], cfg.Fout
-        Y = torch.empty((plan.rows, ldy), dtype=torch.float32, device=dev)
+        Y = torch.empty((plan.rows, ldy), dtype=fdt, device=dev)
         res_L = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         L_sum = torch.empty(plan.tile_elems if cfg.lsum else 0, dtype=torch.float32, device=dev)
@@ -259,7 +267,11 @@ class SgcLLFunction(torch.autograd.Function):
         paper = cfg.mode == "paper"
         if dY is None:
             dY = torch.zeros_like(Y)
-        dY = _f32c(dY, "dY")
+        if cfg.bf16:
+            dY = dY.to(torch.bfloat16)
+            dY = dY if dY.is_contiguous() else dY.contiguous()
+        else:
+            dY = _f32c(dY, "dY")
         if dL_sum is not None:
             dL_sum = _f32c(dL_sum, "dL_sum")
         ldx, ldy = X.shape[1], cfg.Fout

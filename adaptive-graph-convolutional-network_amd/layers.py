@@ -215,6 +215,22 @@ class SGC_LL(Layer):
         if gb.plan.B != self.batch_size:
             raise ValueError("batch holds %d graphs, layer was built for batch_size=%d" % (gb.plan.B, self.batch_size))
         v = self.vars
+        if X.dtype == torch.bfloat16 and self._bf16_served(gb, X, cfg):
+            # bf16 features straight into (and out of) the specialised kernels: no conversion launches (include/agcn.h:
+            # AgcnLayerDesc.feat_dtype); everything between the loads and the stores is fp32
+            cfgb = _Cfg(cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, lsum=cfg.lsum, prev_sym=cfg.prev_sym,
+                        bf16=True)
+            self._verify_vouches(gb, L_prev, cfg.prev_sym)
+            Y, res_L, res_W, L_sum = SgcLLFunction.apply(X, v["weight"], v["bias"], v["M_L"], v["alpha"], v.get("beta"), L_prev, gb,
+                                                         cfgb)
+            if self.dropout and self.training:
+                Y = torch.nn.functional.dropout(Y, p=float(self.dropout), training=True)
+            nodes = RowViews(Y, gb.plan, gb)
+            sum_sym = bool(gb.l0_symmetric) and (L_prev is None or cfg.prev_sym)
+            outs = (TileViews(res_L, gb.plan, True), TileViews(res_W, gb.plan, True), TileViews(L_sum, gb.plan, sum_sym))
+            for t in outs:
+                t._verified = True
+            return (gb, nodes) + outs
         X32, W, M = _in32(X), v["weight"], v["M_L"]
         pad = self._point_cloud_pad(gb, X32, cfg)
         if pad:
@@ -276,6 +292,25 @@ class SGC_LL(Layer):
             elif obj is not None and hasattr(obj, "_verified"):
                 obj._verified = True
         self._vouch_checked = True
+
+    def _bf16_served(self, gb, X, cfg):
+        """True when the library's kernels for this batch read / write bf16 features themselves (dispatch bit 256: every graph
+        on the specialised kernels).  Host logic only, cached on the plan."""
+        if self._variant != "SGC_LL" or not X.is_cuda or X.shape[1] != cfg.Fin:
+            return False
+        from . import _ffi
+        from .functional import _desc, _gbatch
+        lib = _ffi.lib()
+        key = ("bf16_served", cfg.Fin, cfg.Fout, cfg.K, cfg.mode, lib.agcn_get_lds_limit(), lib.agcn_get_fused_mode(),
+               lib.agcn_get_spec_mode(), lib.agcn_get_slab_mode())
+        cache = gb.plan.__dict__.setdefault("_size_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            out = (_ffi.C.c_int32 * 8)()
+            desc = _desc(cfg, X.shape[1], cfg.Fout)
+            _ffi.check(lib.agcn_sgc_ll_dispatch_info(_ffi.C.byref(desc), _ffi.C.byref(_gbatch(gb, X, None)), out, 8))
+            hit = cache[key] = bool(out[0] & 256)
+        return hit
 
     def _point_cloud_pad(self, gb, X, cfg):
         """Feature columns to append so that the layer takes the point-cloud kernels (csrc/cloud_kernels.hip, 64 input

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AGCN_VERSION 103 /* 0.1.3: agcn_set_device_status_word / agcn_device_status */
+#define AGCN_VERSION 104 /* 0.1.4: AgcnLayerDesc.feat_dtype (bf16 features read / written by the specialised kernels) */
 
 enum {
   AGCN_OK = 0,
@@ -139,6 +139,10 @@ typedef struct AgcnLayerDesc {
   int32_t activation; /* AGCN_ACT_LINEAR or AGCN_ACT_RELU (graphconv.py:53,117-123) */
   int32_t ldx;        /* row stride of X and dX in floats (>= Fin) */
   int32_t ldy;        /* row stride of Y and dY in floats (>= Fout) */
+  int32_t feat_dtype; /* AGCN_DTYPE_F32 (0), or AGCN_DTYPE_BF16: X, Y, dY, dX are bf16 matrices (row strides in ELEMENTS) --
+                       * "bf16 features + fp32 Laplacian": widened exactly on load, rounded to nearest even on store, every
+                       * tile, product and parameter gradient in fp32.  Served by the specialised kernels only (dispatch bits
+                       * 1 | 2 of agcn_sgc_ll_dispatch_info); other batches: AGCN_EINVAL (convert with agcn_cast_rows) */
 } AgcnLayerDesc;
 
 /* Device pointers unless stated otherwise. */

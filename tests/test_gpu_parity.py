@@ -313,6 +313,70 @@ def test_bf16_feature_storage(amd):
     assert torch.equal(CastRowsFunction.apply(x.to(torch.bfloat16), torch.float32), x.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("shape", ["tox21_b256", "hiv_within_reach", "hiv_beyond_reach", "reference_mode"])
+def test_bf16_features_every_graph(amd, shape):
+    """BASELINE config 4 ("bf16 features + fp32 Laplacian") at batch size, every graph: bf16 node features / upstream gradients
+    in, bf16 activations / input gradients out, fp32 tiles, Laplacian and parameter gradients.  Where every graph of the batch
+    takes the specialised kernels (dispatch bit 256) they read and write the bf16 rows THEMSELVES (AgcnLayerDesc.feat_dtype: no
+    conversion launches; the forward leaves a widened copy of X for the backward); other batches (a molecule beyond the
+    members' reach: slab kernels) go through the conversion kernels.  Declared tolerance: the float64 oracle on the
+    bf16-rounded inputs -- Y and dX to one bf16 rounding (2^-8 relative), res_W / res_L and every parameter gradient to the
+    usual fp32 bars (their inputs are the same rounded values; nothing else is rounded)."""
+    Fin, Fout, K = 75, 64, 2
+    mode = orc.REFERENCE if shape == "reference_mode" else orc.PAPER
+    if shape in ("tox21_b256", "reference_mode"):
+        sb = orc.synth_batch(123, 256)
+    else:
+        want_beyond = shape == "hiv_beyond_reach"
+        for seed in range(40, 400):
+            nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
+            if int((nsa > 96).sum()) >= 1 and ((nsa.max() > 128) == want_beyond):
+                break
+        sb = orc.synth_batch(seed, 256, mu=np.log(23.0), hi=222)
+    ns = [int(v) for v in sb["ns"]]
+    rs = np.random.RandomState(17)
+    p = orc.init_params(rs, Fin, Fout, K)
+    p["alpha"] = np.array([0.8], np.float32)
+    bf = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()  # noqa: E731
+    Xb = [bf(x) for x in sb["X"]]
+    Gb = [bf(rs.randn(n, Fout).astype(np.float32)) for n in ns]
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(Xb, 0), sb["csr"], DEV)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, mode, p, DEV)
+    served = (amd._ffi.dispatch_info(layer, gb)[0] & 256) != 0
+    assert served == (shape != "hiv_beyond_reach" and not (shape == "hiv_within_reach" and mode == orc.REFERENCE))
+    Xt = gb.X.to(torch.bfloat16).requires_grad_(True)
+    lib = amd._ffi.lib()
+    lib.agcn_profile_enable(1)
+    try:
+        amd._ffi.profile_collect()
+        nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+        assert nodes.data.dtype == torch.bfloat16 and res_W.data.dtype == torch.float32
+        nodes.data.backward(torch.from_numpy(np.concatenate(Gb, 0)).to(DEV).to(torch.bfloat16))
+        torch.cuda.synchronize()
+        prof = {k: v[1] for k, v in amd._ffi.profile_collect().items() if v[1]}
+    finally:
+        lib.agcn_profile_enable(0)
+    assert Xt.grad.dtype == torch.bfloat16
+    if served:
+        assert prof["spec_forward_kernel"] >= 1 and prof["spec_backward_kernel"] >= 1 and "fused_forward_kernel" not in prof, prof
+    Yg = to_np(nodes.data.float())
+    caches, tot, tot32 = oracle_pair(Xb, sb["L0"], p, K, mode, orc.SGC_LL, Gb, Y_got=Yg)
+    dXg, r0 = to_np(Xt.grad.float()), 0
+    for b, n in enumerate(ns):
+        assert_close(Yg[r0:r0 + n], caches[b]["Y"], BF16_RTOL, "Y[%d] (bf16 out)" % b)
+        assert_close(dXg[r0:r0 + n], tot["dX"][b], BF16_RTOL, "dX[%d] (bf16 out)" % b)
+        w = to_np(res_W[b])
+        assert_close(w, caches[b]["S"], FEATURE_RTOL, "res_W[%d] (fp32)" % b)
+        assert np.array_equal(w, w.T)
+        r0 += n
+    assert_close(to_np(layer.vars["weight"].grad), tot["dweight"], GRAD_RTOL, "dweight (fp32)", ref32=tot32["dweight"])
+    assert_close(to_np(layer.vars["bias"].grad), tot["dbias"], GRAD_RTOL, "dbias (fp32)", ref32=tot32["dbias"])
+    if mode == orc.PAPER:
+        assert_close(to_np(layer.vars["M_L"].grad), tot["dM_L"], GRAD_RTOL, "dM_L (fp32)", ref32=tot32["dM_L"])
+        from helpers import _scalar_close
+        _scalar_close(to_np(layer.vars["alpha"].grad), tot["dalpha"], tot32["dalpha"], float(np.abs(tot["dweight"]).max()), "dalpha")
+
+
 def test_fused_path_large_graph_and_wide_layer(amd):
     """The fused kernels with the parameters read from global memory (no LDS images of M_L / W): a 95-node graph
     at 75 -> 64 (the straggler of a 2048-graph Tox21-shaped batch) and a 128 -> 128 layer, both of which do not fit

@@ -205,8 +205,10 @@ def _dispatch(amd, n, Fin, Fout, mode, variant=0, K=2, symmetric=1, csr=True):
                              one if csr else None, None)
     out = (C.c_int32 * 8)()
     assert lib.agcn_sgc_ll_dispatch_info(C.byref(desc), C.byref(gb), out, 8) == 0, lib.agcn_last_error()
-    return dict(zip(("path", "small_first", "f_graphs", "f_members", "f_paired", "b_graphs", "b_members", "b_paired"),
-                    list(out)))
+    d = dict(zip(("path", "small_first", "f_graphs", "f_members", "f_paired", "b_graphs", "b_members", "b_paired"), list(out)))
+    d["bf16"] = bool(d["path"] & 256)      # (bit 256: AgcnLayerDesc.feat_dtype = bf16 is served on this batch)
+    d["path"] &= ~256
+    return d
 
 
 def test_dispatch_table(amd):
@@ -225,7 +227,7 @@ def test_dispatch_table(amd):
     prev_tail = amd._ffi.lib().agcn_get_spec_tail()
     amd._ffi.lib().agcn_set_spec_tail(1)
     d = _dispatch(amd, n256, 75, 64, 1)
-    assert d["path"] == 7 | 128 and d["small_first"] == 256
+    assert d["path"] == 7 | 128 and d["small_first"] == 256 and d["bf16"]
     assert (d["f_graphs"], d["f_members"]) == (big, members) == (d["b_graphs"], d["b_members"])
     assert d["f_paired"] == d["b_paired"] == 2 * (256 + members - big - 256) and d["f_paired"] <= tiny
     # reference mode: members in the forward only
@@ -248,7 +250,8 @@ def test_dispatch_table(amd):
     # when it is small enough for them); other layer widths / Reslap: general fused kernels
     n = n256.copy()
     n[3] = 150
-    assert _dispatch(amd, n, 75, 64, 1)["path"] == 16
+    assert _dispatch(amd, n, 75, 64, 1)["path"] == 16 and not _dispatch(amd, n, 75, 64, 1)["bf16"]
+    assert _dispatch(amd, tox(2048), 75, 64, 1)["bf16"] and not _dispatch(amd, n256, 75, 64, 1, variant=1)["bf16"]
     # ... unless it is within the members' reach (<= 128 nodes, paper mode): specialised kernels, that graph on 8 members
     n[3] = 120
     d = _dispatch(amd, n, 75, 64, 1)
