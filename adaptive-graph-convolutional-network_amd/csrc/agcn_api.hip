@@ -372,7 +372,8 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   r.s = c.off; c.take((size_t)pi.rows);
   r.scal = c.off; c.take((size_t)4 * pi.B);
   r.X = c.off; c.take((size_t)(d->K - 1) * pi.rows * d->Fin);
-  r.X0 = c.off;
+  // bf16 feature storage: the widened fp32 copy of X the forward leaves for the backward and the parameter gradients
+  r.X0 = c.off; if (d->feat_dtype == AGCN_DTYPE_BF16) c.take((size_t)pi.rows * d->Fin);
   r.Lpre = c.off; if (d->variant == AGCN_SGC_LL_RESLAP) c.take((size_t)pi.tile_elems);
   // r_ij tiles (fused and slab paths, paper mode): reserved whenever one of them COULD be taken
   r.r = c.off;
@@ -896,6 +897,9 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     const FusedSplit fsb = fused_split(desc, batch, host);
     if (!bf16_served(desc, host, fsb))
       return fail(AGCN_EINVAL, "%s: bf16 features are read / written by the specialised kernels only (agcn_sgc_ll_dispatch_info)", who);
+    // X as the forward widened it (the reserve's fp32 copy): the backward and the parameter gradients read fp32 rows
+    a.sv_X0 = reinterpret_cast<float*>(rb + rl.X0);
+    a.X = a.sv_X0; a.ldx = desc->Fin;
   }
   a.ws_g = w.g; a.ws_dZ = w.dZ; a.ws_pg = w.pg; a.ws_tile = w.tile; a.ws_buf = w.buf;
 
@@ -1005,7 +1009,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       const int first_plain = coop_graphs;
       a.coop_slabs = coop_slabs;
       // parameter gradients as trailing workgroups of this launch (spec_tail.h): a whole backward call only
-      tail_done = stages == 3 && !conc && !two && !a.feat_bf16 && spec_tail_ok(desc, host, fs, coop_graphs, coop_slabs) && grads->dweight &&
+      tail_done = stages == 3 && !conc && !two && spec_tail_ok(desc, host, fs, coop_graphs, coop_slabs) && grads->dweight &&
                   grads->dbias && grads->dM_L && grads->dalpha;
       if (tail_done) {
         const int tiles = spec::tail_tiles(desc->Fin, desc->Fout, desc->K, true);
@@ -1151,7 +1155,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = fused ? B + fs.n_big_slabs + coop_slabs : ((slabs || cloud_res || cloud_bwd) ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
-  pa.X = a.X; pa.x_bf16 = a.feat_bf16; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
+  pa.X = a.X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
   pa.counters_zeroed = ((stages & 1) && ((!cloud_bwd && !cloud_res) || (desc->Fin == 128 && filter_bwd_zeroed))) ? 1 : 0;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;

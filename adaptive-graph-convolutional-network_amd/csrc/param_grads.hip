@@ -134,10 +134,7 @@ __global__ __launch_bounds__(256) void param_grad_reduce_kernel(ParamGradArgs a)
 // workgroup order) and is kept for diagnostics (AGCN_PG_TF=32).
 // KS = MFMA k-steps (of 4 rows) whose operand loads a wave issues in one go.  8; 16 (both round trips of a 64-row slice
 // in flight together) was measured SLOWER -- B = 2048: 51 vs 38 us -- the registers cost the second resident workgroup.
-// XBF: X is a bf16 matrix (AgcnLayerDesc.feat_dtype; X_1, Gp and dZ stay fp32).  The lanes of a dweight tile alternate between
-// X and X_1 columns, so every lane does the SAME 4-byte load at "its element's address rounded down to a dword" and picks its
-// half (bf16 lanes) or the whole word (fp32 lanes): no per-lane branch around a load, nothing read beyond the element's dword.
-template <int TF, int KS, bool XBF = false>
+template <int TF, int KS>
 __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs a) {
   constexpr int NA = TF / 16, TE = TF * 32;   // A fragments per wave, floats per tile
   __shared__ float wsum[16][512 + 16];
@@ -182,20 +179,16 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   const float* Ap[NA];
   int64_t lda = 0;
   bool jv[NA];
-  bool xb[NA];                              // XBF: this lane's A column is a column of the bf16 X
 #pragma unroll
   for (int x = 0; x < NA; ++x) {
     const int j = min(f0 + 16 * x + r, Fa - 1);
     jv[x] = (f0 + 16 * x + r) < Fa;
-    xb[x] = false;
     if (p == 0) {
       const int f = j / K, kx = j - f * K;
-      if (kx == 0) { Ap[x] = a.X + f; lda = a.ldx; xb[x] = XBF; }
+      if (kx == 0) { Ap[x] = a.X + f; lda = a.ldx; }
       else { Ap[x] = a.sv_X + (int64_t)(kx - 1) * a.rows * Fin + f; lda = Fin; }
-    } else if (p == 2) { Ap[x] = a.X + j; lda = a.ldx; xb[x] = XBF; }
+    } else if (p == 2) { Ap[x] = a.X + j; lda = a.ldx; }
     else { Ap[x] = a.X; lda = 0; }
-    if (XBF && xb[x])                       // (element f of a bf16 row: byte offset 2 f, not 4 f)
-      Ap[x] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.X) + 2 * (Ap[x] - a.X));
   }
   // (K == 2 alternates X / sv_X columns with different strides: keep one stride per fragment)
   int64_t ldax[NA];
@@ -218,17 +211,7 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
     for (int u = 0; u < KS; ++u) {
       const int row = min(rr + 4 * u + q, last_row);
 #pragma unroll
-      for (int x = 0; x < NA; ++x) {
-        if constexpr (XBF) {
-          // byte address of the element: bf16 lanes step 2 bytes per element, fp32 lanes 4
-          const uintptr_t ad = reinterpret_cast<uintptr_t>(Ap[x]) + (uintptr_t)((int64_t)row * ldax[x]) * (xb[x] ? 2u : 4u);
-          const uint32_t raw = *reinterpret_cast<const uint32_t*>(ad & ~(uintptr_t)3);
-          const uint32_t bits = xb[x] ? ((ad & 2) ? (raw & 0xffff0000u) : (raw << 16)) : raw;
-          av[x][u] = (p == 1) ? 1.0f : __uint_as_float(bits);
-        } else {
-          av[x][u] = (p == 1) ? 1.0f : Ap[x][(int64_t)row * ldax[x]];
-        }
-      }
+      for (int x = 0; x < NA; ++x) av[x][u] = (p == 1) ? 1.0f : Ap[x][(int64_t)row * ldax[x]];
       b0[u] = Bp[(int64_t)row * ldb + cA];
       b1[u] = Bp[(int64_t)row * ldb + cB];
     }
@@ -375,7 +358,6 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
       hipError_t e = hipMemsetAsync(aa.counters, 0, sizeof(int32_t) * (size_t)nt, s);
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad counters memset: %s", hipGetErrorString(e));
     }
-    if (aa.x_bf16 && TF != 16) return fail(AGCN_EINVAL, "param_grads: bf16 features need the 16-row tile flavour");
     prof_begin(PK_PARAM_ONEPASS, stream);
     // XCD-aware order: off for small batches (the rows fit every L2; the plain order has the shorter tail:
     // B = 256: 13.6 vs 15.4 us), split-major from ~8k rows on (512 / 1024 / 2048 / 4096 graphs: 19.5 / 26.3 / 38.3 /
@@ -384,15 +366,13 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
     const int xcd = xcd_force >= 0 ? xcd_force : (a.rows >= 8192 ? 2 : 0);
     aa.xcd = xcd;
     const dim3 grid((unsigned)(nt * (xcd ? ((S + 7) & ~7) : S)));
-    if (aa.x_bf16) hipLaunchKernelGGL((param_grad_onepass_kernel<16, 8, true>), grid, dim3(1024), 0, s, aa);
-    else if (TF == 32) hipLaunchKernelGGL((param_grad_onepass_kernel<32, 8>), grid, dim3(1024), 0, s, aa);
+    if (TF == 32) hipLaunchKernelGGL((param_grad_onepass_kernel<32, 8>), grid, dim3(1024), 0, s, aa);
     else hipLaunchKernelGGL((param_grad_onepass_kernel<16, 8>), grid, dim3(1024), 0, s, aa);
     prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_onepass launch: %s", hipGetErrorString(e));
     return AGCN_OK;
   }
-  if (a.x_bf16) return fail(AGCN_EINVAL, "param_grads: bf16 features are read by the one-pass kernel only (agcn_set_param_grad_onepass)");
   const int tfW = (a.Fin * a.K + 15) / 16, tcW = (a.Fout + 31) / 32;
   const int tfM = (a.Fin + 15) / 16, tcM = (a.Fin + 31) / 32;
   int items = tfW * tcW;

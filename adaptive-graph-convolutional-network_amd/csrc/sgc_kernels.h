@@ -19,9 +19,9 @@ struct SgcArgs {
   // layer
   int32_t Fin, Fout, K, mode, variant, activation, ldx, ldy;
   // inputs
-  int32_t feat_bf16;   // 1: X, Y, dY, dX are bf16 matrices, read and written by the specialised kernels themselves
-  float* sv_X0;        // (unused)
-  int32_t lddx;        // row stride of dX in elements
+  int32_t feat_bf16;   // 1: X (forward), Y, dY, dX are bf16 matrices (specialised kernels only); the forward then leaves a
+  float* sv_X0;        // widened fp32 copy of X in the reserve ([rows][Fin]) and the backward / parameter gradients read that
+  int32_t lddx;        // row stride of dX in elements (the backward's X may be the reserve copy with stride Fin)
   const float* X;
   const float* L0_dense;
   int32_t L0_ld;
@@ -124,7 +124,6 @@ struct RowsGemmArgs {
 
 struct ParamGradArgs {
   int32_t rows, Fin, Fout, K, ldx, paper;
-  int32_t x_bf16;        // 1: X is a bf16 matrix [rows][ldx elements] (one-pass kernel only)
   int32_t n_chunks, chunk_rows, B;   // B = number of [dalpha, dbeta] partial pairs in pg
   int32_t wgs_per_chunk; // set by the launcher
   int64_t part_stride;  // floats per chunk in `part`

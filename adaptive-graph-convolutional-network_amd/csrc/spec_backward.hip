@@ -280,21 +280,15 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   // (paper) the X_0 rows B2 needs are requested now; their round trip overlaps the matrix work
   float xzr[RPW][CP];
   if (paper || RESLAP) {
-    by_dtype(a.feat_bf16 != 0, [&](auto BF) {
 #pragma unroll
-      for (int u = 0; u < RPW; ++u) {
-        const int64_t ro = (int64_t)min(wave + NW * u, n - 1) * a.ldx;
+    for (int u = 0; u < RPW; ++u) {
+      const float* rp = Xg + (int64_t)min(wave + NW * u, n - 1) * a.ldx;
 #pragma unroll
-        for (int cp = 0; cp < CP; ++cp) {
-          const int c = min(lane + 64 * cp, FIN - 1);
-          xzr[u][cp] = 0.f;
-          if (u < rpw) {
-            if constexpr (decltype(BF)::value) xzr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
-            else xzr[u][cp] = Xg[ro + c];
-          }
-        }
+      for (int cp = 0; cp < CP; ++cp) {
+        xzr[u][cp] = 0.f;
+        if (u < rpw) xzr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
       }
-    });
+    }
   }
 #pragma unroll
   for (int sl = 0; sl < MAXTB; ++sl) {

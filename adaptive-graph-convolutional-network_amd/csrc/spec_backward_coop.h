@@ -292,21 +292,15 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 
   // ---- M3: dX[I] = g_0[I] + L^T[I, :] g_1 (waves < NCB keep their tile);  X_0 rows requested meanwhile ------------
   float xzr[RPW][CP];
-  by_dtype(a.feat_bf16 != 0, [&](auto BF) {
 #pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-      const int64_t ro = (int64_t)min(wave + NW * u, n - 1) * a.ldx;
+  for (int u = 0; u < RPW; ++u) {
+    const float* rp = Xg + (int64_t)min(wave + NW * u, n - 1) * a.ldx;
 #pragma unroll
-      for (int cp = 0; cp < CP; ++cp) {
-        const int c = min(lane + 64 * cp, FIN - 1);
-        xzr[u][cp] = 0.f;
-        if (u < rpw) {
-          if constexpr (decltype(BF)::value) xzr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
-          else xzr[u][cp] = Xg[ro + c];
-        }
-      }
+    for (int cp = 0; cp < CP; ++cp) {
+      xzr[u][cp] = 0.f;
+      if (u < rpw) xzr[u][cp] = rp[min(lane + 64 * cp, FIN - 1)];
     }
-  });
+  }
   f32x4 dxacc = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (wave < NCB) {
     const int cb = wave;
@@ -865,6 +859,14 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     for (int cp = 0; cp < CP; ++cp) {
       const int c = lane + 64 * cp;
       if (c < FIN) Xo[c] = X1s[wave * LDX + c];
+    }
+    if (a.feat_bf16) {   // ... and, bf16 features, the widened X rows of the strip (spec_kernels.h)
+      float* X0o = a.sv_X0 + (int64_t)(row0 + i0 + wave) * FIN;
+#pragma unroll
+      for (int cp = 0; cp < CP; ++cp) {
+        const int c = lane + 64 * cp;
+        if (c < FIN) X0o[c] = Ximg[(i0 + wave) * LDX + c];
+      }
     }
   }
   if (i0 == 0) {

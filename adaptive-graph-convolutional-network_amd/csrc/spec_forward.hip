@@ -461,6 +461,15 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         const int c = lane + 64 * cp;
         if (c < FIN) AGCN_ST(2, &Xo[i * FIN + c], X1img[i * LDX + c]);
       }
+    if (a.feat_bf16) {     // the widened X rows for the backward and the parameter gradients
+      float* X0o = a.sv_X0 + (int64_t)row0 * FIN;
+      for (int i = wave; i < n; i += NW)
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const int c = lane + 64 * cp;
+          if (c < FIN) X0o[i * FIN + c] = Ximg[i * LDX + c];
+        }
+    }
   }
   // The blocks of the last (smallest) graphs of the batch -- positions tp_first .. B-1, at most 32 of them -- also leave
   // transposed copies of the parameters in the reserve for the backward kernel (its B operands W^T and M_L^T then load
