@@ -66,6 +66,19 @@ class ResidentStoreC(C.Structure):
                 ("val_dev", C.c_void_p), ("x_bf16", C.c_int32), ("reserved", C.c_int32)]
 
 
+class EpochBuffers(C.Structure):
+    _fields_ = [("stage_host", C.c_void_p), ("stage_dev", C.c_void_p), ("stage_cap", C.c_size_t),
+                ("X", C.c_void_p), ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p),
+                ("rows_cap", C.c_int64), ("nnz_cap", C.c_int64), ("tiles_cap", C.c_int64),
+                ("Y", C.c_void_p), ("res_L", C.c_void_p), ("res_W", C.c_void_p), ("dY", C.c_void_p),
+                ("dX", C.c_void_p), ("dweight", C.c_void_p), ("dbias", C.c_void_p), ("dM_L", C.c_void_p), ("dalpha", C.c_void_p),
+                ("reserve", C.c_void_p), ("reserve_bytes", C.c_size_t), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class EpochNeeds(C.Structure):
+    _fields_ = [("reserve_bytes", C.c_size_t), ("workspace_bytes", C.c_size_t)]
+
+
 class StagedBatch(C.Structure):
     _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("max_n", C.c_int32), ("symmetric", C.c_int32),
                 ("stage_bytes", C.c_int64), ("plan", PlanInfo)]
@@ -80,7 +93,7 @@ SYMBOLS = [
     "agcn_plan_bytes", "agcn_plan_bytes_for", "agcn_plan_build", "agcn_plan_info",
     "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
-    "agcn_sgc_ll_dispatch_info", "agcn_sgc_ll_reserve_status", "agcn_set_device_status_word", "agcn_device_status", "agcn_get_coop_timeout_ticks", "agcn_set_coop_timeout_ticks", "agcn_tiles_asymmetry", "agcn_get_spec_tail", "agcn_set_spec_tail",
+    "agcn_sgc_ll_dispatch_info", "agcn_sgc_ll_reserve_status", "agcn_set_device_status_word", "agcn_device_status", "agcn_get_coop_timeout_ticks", "agcn_set_coop_timeout_ticks", "agcn_tiles_asymmetry", "agcn_epoch_step", "agcn_get_spec_tail", "agcn_set_spec_tail",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
     "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
@@ -179,6 +192,8 @@ def _declare(lib):
     lib.agcn_set_device_status_word.argtypes = [I32, P]
     lib.agcn_device_status.restype = C.c_int
     lib.agcn_device_status.argtypes = [I32, P, C.POINTER(C.c_int32)]
+    lib.agcn_epoch_step.restype = C.c_int
+    lib.agcn_epoch_step.argtypes = [P, P, I32, P, P, P, I32, P, P, P, P]
     lib.agcn_tiles_asymmetry.restype = C.c_int
     lib.agcn_tiles_asymmetry.argtypes = [P, P, P, I32, P, P]
     lib.agcn_get_spec_tail.restype = I32

@@ -1,0 +1,55 @@
+// One batch of an epoch in ONE C-ABI call (include/agcn.h: agcn_epoch_step): stage the batch `ids` out of the HBM-resident
+// store (agcn_store_stage_batch: plan + gather table into a pinned blob, one copy, one gather launch), then the layer's
+// forward and backward on the staged batch -- everything the Python epoch loop did per batch around three C calls (plan
+// objects, size queries, ctypes structs: 44 us of host time per batch, which bounded two batches in flight).
+// Host logic only: every launch goes through the entry points a caller would use one by one.
+#include "agcn_internal.h"
+
+#include <hip/hip_runtime.h>
+
+using namespace agcn;
+
+extern "C" int agcn_epoch_step(const AgcnResidentStore* store, const int64_t* ids, int32_t B, const AgcnLayerDesc* desc,
+                               const AgcnParams* params, const AgcnEpochBuffers* buf, int32_t restage, AgcnStagedBatch* info,
+                               AgcnEpochNeeds* needs, void* slot_event, void* hip_stream) {
+  const char* who = "agcn_epoch_step";
+  if (!store || !ids || !desc || !params || !buf || !info || !needs || B < 1) return fail(AGCN_EINVAL, "%s: bad argument", who);
+  if (desc->variant != AGCN_SGC_LL) return fail(AGCN_EINVAL, "%s: drives SGC_LL layers", who);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  hipEvent_t ev = static_cast<hipEvent_t>(slot_event);
+  if (restage) {
+    // the copy that last read this pinned blob must have executed before the blob is rewritten
+    if (ev != nullptr && hipEventSynchronize(ev) != hipSuccess) return fail(AGCN_EDEVICE, "%s: hipEventSynchronize failed", who);
+    int rc = agcn_store_stage_batch(store, ids, B, buf->stage_host, buf->stage_dev, buf->stage_cap, buf->X, desc->Fin,
+                                    buf->rows_cap, buf->rowptr, buf->col, buf->val, buf->nnz_cap, info, hip_stream);
+    if (rc != AGCN_OK) return rc;
+    if (ev != nullptr && hipEventRecord(ev, s) != hipSuccess) return fail(AGCN_EDEVICE, "%s: hipEventRecord failed", who);
+  }
+  if (info->plan.rows > buf->rows_cap || info->plan.tile_elems > buf->tiles_cap)
+    return fail(AGCN_ENOSPACE, "%s: batch (rows %d, tile floats %lld) exceeds the output capacity (%lld, %lld)", who,
+                info->plan.rows, (long long)info->plan.tile_elems, (long long)buf->rows_cap, (long long)buf->tiles_cap);
+  AgcnLayerDesc d = *desc;
+  d.ldx = desc->Fin; d.ldy = desc->Fout;
+  needs->reserve_bytes = agcn_sgc_ll_reserve_bytes(&d, buf->stage_host);
+  const size_t wf = agcn_sgc_ll_forward_workspace_bytes(&d, buf->stage_host), wb = agcn_sgc_ll_backward_workspace_bytes(&d, buf->stage_host);
+  needs->workspace_bytes = wf > wb ? wf : wb;
+  if (needs->reserve_bytes == 0) return fail(AGCN_EINVAL, "%s: staged plan rejected", who);
+  if (needs->reserve_bytes > buf->reserve_bytes || needs->workspace_bytes > buf->workspace_bytes)
+    return AGCN_ENOSPACE;        // (the caller grows the buffers -- zero-filled reserve -- and calls again with restage = 0)
+  AgcnGraphBatch gb;
+  std::memset(&gb, 0, sizeof(gb));
+  gb.plan_host = buf->stage_host; gb.plan_dev = buf->stage_dev;
+  gb.X = buf->X;
+  gb.L0_symmetric = info->symmetric;
+  gb.L0_rowptr = buf->rowptr; gb.L0_col = buf->col; gb.L0_val = buf->val;
+  AgcnOutputs out;
+  std::memset(&out, 0, sizeof(out));
+  out.Y = buf->Y; out.res_L = buf->res_L; out.res_W = buf->res_W;
+  int rc = agcn_sgc_ll_forward(&d, &gb, params, &out, buf->reserve, needs->reserve_bytes, buf->workspace, buf->workspace_bytes, hip_stream);
+  if (rc != AGCN_OK) return rc;
+  AgcnGrads gr;
+  std::memset(&gr, 0, sizeof(gr));
+  gr.dX = buf->dX; gr.dweight = buf->dweight; gr.dbias = buf->dbias; gr.dM_L = buf->dM_L; gr.dalpha = buf->dalpha;
+  return agcn_sgc_ll_backward(&d, &gb, params, &out, buf->dY, nullptr, &gr, buf->reserve, needs->reserve_bytes, buf->workspace,
+                              buf->workspace_bytes, hip_stream);
+}

@@ -7,6 +7,8 @@ All parameter gradients of the layer live in ONE flat fp32 bucket
 RCCL all-reduce per step (see dist.py)."""
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import _ffi
@@ -212,6 +214,8 @@ class SgcLLEpochStep(object):
         self._reserve = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
         self._ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
         self.plan = None
+        self._rows = self._tile_elems = 0
+        self._ebufs, self._einfo, self._eneeds = {}, _ffi.StagedBatch(), _ffi.EpochNeeds()     # (step_ids)
 
     def _fit(self, plan):
         if plan.rows > self.rows_cap or plan.tile_elems > self.tiles_cap or plan.B > self.batch_cap:
@@ -230,6 +234,7 @@ class SgcLLEpochStep(object):
             if wb > self._ws.numel():
                 self._ws = torch.zeros(int(wb * 1.5), dtype=torch.uint8, device=self.device)
             torch.cuda.synchronize(self.device)
+            self._ebufs.clear()
         return rb
 
     def step(self, batch, dY=None, stream=None):
@@ -252,7 +257,74 @@ class SgcLLEpochStep(object):
                                                  C.byref(self.gr), self._reserve.data_ptr(), rb, self._ws.data_ptr(),
                                                  self._ws.numel(), stream))
         self.plan, self.batch = plan, batch       # (keeps the batch's device tensors alive until the next step)
+        self._rows, self._tile_elems = plan.rows, plan.tile_elems
         self._stream = stream
+        return self
+
+    def step_ids(self, rstore, graph_ids, lane=0, dY=None, stream=None):
+        """Stage the batch `graph_ids` out of the resident store `rstore` (lane `lane`'s buffers) and run forward + backward on
+        it in ONE C-ABI call (include/agcn.h: agcn_epoch_step) -- no plan object, no size queries, no per-batch structs on
+        the Python side.  Same kernels, same bits as `step(rstore.stage(graph_ids, lane))`."""
+        ids = np.ascontiguousarray(graph_ids, dtype=np.int64)
+        B = int(ids.size)
+        if B > min(self.batch_cap, rstore.batch_cap):
+            raise ValueError("batch of %d graphs exceeds the capacity" % B)
+        sl = rstore._slots[rstore._k]
+        rstore._k = (rstore._k + 1) % len(rstore._slots)
+        tstream = torch.cuda.current_stream(self.device) if stream is None else stream
+        st = tstream.cuda_stream
+        ev = sl.get("ev")
+        if ev is None:                       # one HIP event per pinned blob: waited for and recorded inside the call
+            if sl["done"] is not None:
+                sl["done"].synchronize()
+            e = torch.cuda.Event()
+            e.record(tstream)
+            sl["done"], ev = e, int(e.cuda_event)
+            sl["ev"] = ev
+        key = (id(rstore), lane, sl["ptr"], None if dY is None else dY.data_ptr())
+        buf = self._ebufs.get(key)
+        if buf is None:
+            if rstore.F != self.cfg.Fin or rstore.rows_cap > self.rows_cap or rstore.tiles_cap > self.tiles_cap:
+                raise ValueError("the resident store's capacities exceed this step's")
+            ln = rstore.lanes[lane]
+            g = self.grads
+            buf = self._ebufs[key] = _ffi.EpochBuffers(
+                sl["ptr"], ln["stage"].data_ptr(), rstore.stage_cap, ln["X"].data_ptr(), ln["rowptr"].data_ptr(),
+                ln["col"].data_ptr(), ln["val"].data_ptr(), rstore.rows_cap, rstore.nnz_cap, self.tiles_cap,
+                self._Y.data_ptr(), self._res_L.data_ptr(), self._res_W.data_ptr(), (self._dY if dY is None else dY).data_ptr(),
+                self._dX.data_ptr(), g["weight"].data_ptr(), g["bias"].data_ptr(), _ptr(g.get("M_L")), g["alpha"].data_ptr(),
+                self._reserve.data_ptr(), self._reserve.numel(), self._ws.data_ptr(), self._ws.numel())
+        info, needs = self._einfo, self._eneeds
+        rc = self.lib.agcn_epoch_step(C.byref(rstore._c), ids.ctypes.data, B, C.byref(self.desc), C.byref(self.pr), C.byref(buf), 1,
+                                      C.byref(info), C.byref(needs), ev, st)
+        if rc == -2 and needs.reserve_bytes:                # AGCN_ENOSPACE: grow (as _fit does) and run the staged batch
+            torch.cuda.synchronize(self.device)
+            if needs.reserve_bytes > self._reserve.numel():
+                self._reserve = torch.zeros(int(needs.reserve_bytes * 1.5), dtype=torch.uint8, device=self.device)
+            if needs.workspace_bytes > self._ws.numel():
+                self._ws = torch.zeros(int(needs.workspace_bytes * 1.5), dtype=torch.uint8, device=self.device)
+            torch.cuda.synchronize(self.device)
+            self._ebufs.clear()
+            return self._retry_ids(rstore, ids, lane, dY, sl, ev, st)
+        _ffi.check(rc)
+        self._rows, self._tile_elems = int(info.plan.rows), int(info.plan.tile_elems)
+        self.plan = self.batch = None
+        self._stream = st
+        return self
+
+    def _retry_ids(self, rstore, ids, lane, dY, sl, ev, st):
+        ln, g = rstore.lanes[lane], self.grads
+        buf = _ffi.EpochBuffers(
+            sl["ptr"], ln["stage"].data_ptr(), rstore.stage_cap, ln["X"].data_ptr(), ln["rowptr"].data_ptr(),
+            ln["col"].data_ptr(), ln["val"].data_ptr(), rstore.rows_cap, rstore.nnz_cap, self.tiles_cap,
+            self._Y.data_ptr(), self._res_L.data_ptr(), self._res_W.data_ptr(), (self._dY if dY is None else dY).data_ptr(),
+            self._dX.data_ptr(), g["weight"].data_ptr(), g["bias"].data_ptr(), _ptr(g.get("M_L")), g["alpha"].data_ptr(),
+            self._reserve.data_ptr(), self._reserve.numel(), self._ws.data_ptr(), self._ws.numel())
+        _ffi.check(self.lib.agcn_epoch_step(C.byref(rstore._c), ids.ctypes.data, int(ids.size), C.byref(self.desc), C.byref(self.pr),
+                                            C.byref(buf), 0, C.byref(self._einfo), C.byref(self._eneeds), ev, st))
+        self._rows, self._tile_elems = int(self._einfo.plan.rows), int(self._einfo.plan.tile_elems)
+        self.plan = self.batch = None
+        self._stream = st
         return self
 
     def check(self):
@@ -267,19 +339,19 @@ class SgcLLEpochStep(object):
     # views of the current batch's results
     @property
     def Y(self):
-        return self._Y[:self.plan.rows]
+        return self._Y[:self._rows]
 
     @property
     def dX(self):
-        return self._dX[:self.plan.rows]
+        return self._dX[:self._rows]
 
     @property
     def res_L(self):
-        return self._res_L[:self.plan.tile_elems]
+        return self._res_L[:self._tile_elems]
 
     @property
     def res_W(self):
-        return self._res_W[:self.plan.tile_elems]
+        return self._res_W[:self._tile_elems]
 
 
 def _overlapping_streams(device, k, candidates=12, spin=400000):
@@ -363,7 +435,7 @@ class SgcLLEpochLanes(object):
         k = self._j % len(self.steps)
         self._j += 1
         s = self.streams[k]
-        return self.steps[k].step(self.rstore.stage(graph_ids, lane=k, stream=s), dY, stream=s)
+        return self.steps[k].step_ids(self.rstore, graph_ids, lane=k, dY=dY, stream=s)      # (one C-ABI call per batch)
 
     def close(self):
         """Waits for the lanes and gives the cooperative-member budget back (only lanes > 2 lowered it)."""

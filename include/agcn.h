@@ -422,6 +422,34 @@ int agcn_store_stage_batch(const AgcnResidentStore* store, const int64_t* ids, i
                            int32_t* rowptr_out, int32_t* col_out, float* val_out, int64_t nnz_cap,
                            AgcnStagedBatch* info, void* hip_stream);
 
+/* ---- one batch of an epoch in ONE call ------------------------------------------------------------------------------
+ * agcn_store_stage_batch + agcn_sgc_ll_forward + agcn_sgc_ll_backward (SGC_LL; rows packed: ldx = Fin, ldy = Fout) on capacity
+ * buffers the caller allocated once: what a host loop does per batch around the three entry points -- plan objects, size
+ * queries, argument structs -- happens here, in C (the Python loop spent 44 us of host time per batch there; with two batches
+ * in flight the epoch was host-bound).  All pointers caller-owned; device buffers unless noted.
+ *   restage = 1: stage the batch `ids` first (slot_event: a hipEvent_t, or NULL -- it is WAITED for before the pinned blob
+ *                `stage_host` is rewritten and RECORDED behind the copy that reads it, so that a blob is reused safely);
+ *   restage = 0: the batch staged by the previous call with the same buffers (`info` as that call left it) -- the retry
+ *                after AGCN_ENOSPACE.
+ * Returns AGCN_ENOSPACE with `needs` filled in when `reserve` / `workspace` are too small for this batch (nothing of the
+ * layer has been launched; a new reserve must be zero-filled in its first AGCN_RESERVE_HEADER_BYTES). */
+typedef struct AgcnEpochBuffers {
+  void* stage_host;          /* PINNED host blob (agcn_store_stage_bytes) */
+  void* stage_dev;           /* its device twin */
+  size_t stage_cap;
+  float* X; int32_t* rowptr; int32_t* col; float* val;   /* the staged batch: [rows_cap][Fin], [rows_cap + 1], [nnz_cap] x 2 */
+  int64_t rows_cap, nnz_cap, tiles_cap;
+  float *Y, *res_L, *res_W;  /* [rows_cap][Fout], [tiles_cap] x 2 */
+  const float* dY;           /* [rows_cap][Fout] upstream gradient */
+  float *dX, *dweight, *dbias, *dM_L, *dalpha;
+  void* reserve; size_t reserve_bytes;
+  void* workspace; size_t workspace_bytes;
+} AgcnEpochBuffers;
+typedef struct AgcnEpochNeeds { size_t reserve_bytes, workspace_bytes; } AgcnEpochNeeds;
+int agcn_epoch_step(const AgcnResidentStore* store, const int64_t* ids, int32_t B, const AgcnLayerDesc* desc,
+                    const AgcnParams* params, const AgcnEpochBuffers* buf, int32_t restage, AgcnStagedBatch* info,
+                    AgcnEpochNeeds* needs, void* slot_event, void* hip_stream);
+
 /* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel of
  * the path).  Off by default.  agcn_profile_collect waits for the events recorded since the last
  * collect and returns, per kernel id < agcn_profile_kernels(), the total milliseconds and the
