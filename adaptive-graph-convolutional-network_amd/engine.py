@@ -269,8 +269,12 @@ class SgcLLEpochStep(object):
         B = int(ids.size)
         if B > min(self.batch_cap, rstore.batch_cap):
             raise ValueError("batch of %d graphs exceeds the capacity" % B)
-        sl = rstore._slots[rstore._k]
-        rstore._k = (rstore._k + 1) % len(rstore._slots)
+        # (the pinned blobs of lane k: slots k, k + lanes, ... -- every lane rotates through its own, so that lanes driven from
+        #  different host threads share nothing)
+        nl = len(rstore.lanes)
+        kk = rstore._lane_k[lane]
+        rstore._lane_k[lane] = kk + 1
+        sl = rstore._slots[lane + nl * (kk % (len(rstore._slots) // nl))]
         tstream = torch.cuda.current_stream(self.device) if stream is None else stream
         st = tstream.cuda_stream
         ev = sl.get("ev")
@@ -436,6 +440,37 @@ class SgcLLEpochLanes(object):
         self._j += 1
         s = self.streams[k]
         return self.steps[k].step_ids(self.rstore, graph_ids, lane=k, dY=dY, stream=s)      # (one C-ABI call per batch)
+
+    def run(self, selections, dY=None, on_batch=None):
+        """A whole list of batches, lane k taking batches k, k + lanes, ... from a HOST THREAD of its own.  A batch is one
+        C-ABI call (`agcn_epoch_step`: ~50 us of host time, almost all of it kernel-launch API calls) during which ctypes has
+        released the GIL, so the lanes' host work overlaps too and the GPU -- not the host -- bounds the epoch.
+        `on_batch(j, step)` runs in the lane's thread right after batch j has been enqueued (enqueue further work on
+        `self.streams[j % lanes]` there: the step's buffers are reused by that lane's next batch).  Returns when everything is
+        enqueued; `synchronize()` waits for the GPU."""
+        import threading
+        sels = list(selections)
+        nl = len(self.steps)
+        errs = []
+
+        def lane(k):
+            try:
+                with torch.cuda.device(self.device):
+                    for j in range(k, len(sels), nl):
+                        st = self.steps[k].step_ids(self.rstore, sels[j], lane=k, dY=dY, stream=self.streams[k])
+                        if on_batch is not None:
+                            on_batch(j, st)
+            except BaseException as e:          # noqa: B902  (re-raised in the caller's thread)
+                errs.append(e)
+
+        threads = [threading.Thread(target=lane, args=(k,)) for k in range(nl)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        self._j += len(sels)
+        if errs:
+            raise errs[0]
 
     def close(self):
         """Waits for the lanes and gives the cooperative-member budget back (only lanes > 2 lowered it)."""

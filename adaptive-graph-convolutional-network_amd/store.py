@@ -256,6 +256,7 @@ class ResidentStore(object):
             t = torch.zeros(self.stage_cap, dtype=torch.uint8, pin_memory=True)
             self._slots.append({"t": t, "np": t.numpy(), "ptr": t.data_ptr(), "done": None})
         self._k = 0
+        self._lane_k = [0] * len(self.lanes)      # (engine.SgcLLEpochStep.step_ids: every lane rotates through its own blobs)
         h = store._c
         self._c = _ffi.ResidentStoreC(h, self.X.data_ptr(), self.rowptr.data_ptr(), self.col.data_ptr(),
                                       self.val.data_ptr(), 1 if dtype == torch.bfloat16 else 0, 0)

@@ -1781,6 +1781,39 @@ def test_reslap_takes_the_specialised_kernels(amd, mode, Fin, Fout):
     compare_with_oracle(out, caches, tot, orc.SGC_LL_RESLAP, mode, K, has_prev=True, tot32=tot32)
 
 
+def test_epoch_lanes_run_from_one_thread_per_lane(amd):
+    """`SgcLLEpochLanes.run`: every lane driven from a host thread of its own (one `agcn_epoch_step` call per batch, the GIL
+    released inside it) gives, batch for batch, the bits of the single-lane loop -- gradient buckets accumulated per lane in
+    the `on_batch` hook (on the lane's stream) and summed at the end equal the single-lane sum over the same batches."""
+    from agcn_amd import synth
+    data = synth.tox21_batch(56, 1500, mu=np.log(23.0), hi=222)
+    store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+    p = orc.init_params(np.random.RandomState(4), 75, 64, 2)
+    layer = make_layer(amd, orc.SGC_LL, 64, 75, 256, 2, orc.PAPER, p, DEV)
+    sels = store._selections(256, False, np.random.RandomState(2))
+    r1 = store.to_device(DEV, 256)
+    ep = amd.SgcLLEpochStep(layer, r1.rows_cap, r1.tiles_cap, 256, device=DEV)
+    want = []
+    for sel in sels:
+        ep.step(r1.stage(sel))
+        torch.cuda.synchronize()
+        want.append((ep.Y.clone(), ep.bucket.clone()))
+    r2 = store.to_device(DEV, 256, lanes=2)
+    lanes = amd.SgcLLEpochLanes(layer, r2, lanes=2)
+    got = [None] * len(sels)
+
+    def on_batch(j, st):
+        with torch.cuda.stream(lanes.streams[j % 2]):          # (copies ordered before the lane's next batch)
+            got[j] = (st.Y.clone(), st.bucket.clone())
+
+    for _ in range(2):                                        # twice: the pinned blobs and events are reused
+        lanes.run(sels, on_batch=on_batch)
+        lanes.synchronize()
+        torch.cuda.synchronize()
+        for j in range(len(sels)):
+            assert torch.equal(got[j][0], want[j][0]) and torch.equal(got[j][1], want[j][1]), j
+
+
 def test_cooperative_waits_are_never_silent(amd):
     """The workgroups that share a large graph wait for each other inside a launch (csrc/spec_backward_coop.h); the wait
     is bounded and, when it runs out, reported: NaN in the step's results AND a sticky status word that
