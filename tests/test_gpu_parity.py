@@ -737,6 +737,54 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach)
             assert ("spec_backward_kernel" in names[1]) == (fused_mode == 3), names
 
 
+@pytest.mark.parametrize("reach", ["beyond_members", "within_members"])
+@pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
+def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode, reach):
+    """The SGC_LL_Reslap twin of the test above (every convolution of ResAGCN.py:79-92 / DenseAGCN.py:112-146 is one): an
+    HIV-shaped 256-graph batch, 64 -> 64, with a few molecules beyond the one-workgroup kernels' 96 nodes, a previous Laplacian
+    and a gradient arriving on L_sum.  SGC_LL_Reslap has no member / slab flavour yet: such a batch leaves the specialised
+    kernels WHOLE for the general per-graph path (mixed dispatch, fused_mode 3: the oversized molecules alone).  Whatever
+    runs, EVERY graph's Y / res_W / res_L / L_sum and EVERY gradient (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) must
+    match the float64 oracle; the kernels that ran are asserted so that a change of dispatch shows up here."""
+    Fin, Fout, K = 64, 64, 2
+    for seed in range(40, 400):
+        nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
+        big = int((nsa > 96).sum())
+        if 1 <= big <= 4 and ((nsa.max() > 128) == (reach == "beyond_members")):
+            break
+    else:
+        pytest.fail("no seed gives such a batch")
+    sb = orc.synth_batch(seed, 256, Fin=Fin, mu=np.log(23.0), hi=222, features="normal")
+    ns = [int(v) for v in sb["ns"]]
+    rs = np.random.RandomState(seed)
+    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL_RESLAP)
+    p["alpha"] = np.array([0.8], np.float32)
+    p["beta"] = np.array([1.2], np.float32)
+    G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
+    Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
+    dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
+    lib = amd._ffi.lib()
+    seen = {}
+    for fused_mode in (1, 3):
+        lib.agcn_set_fused_mode(fused_mode)
+        try:
+            out = run_packed(amd, DEV, ns, sb["X"], sb["csr"], p, G, Fin, Fout, K, mode, orc.SGC_LL_RESLAP, Lp, dLs)
+            caches, tot, tot32 = oracle_pair(sb["X"], sb["L0"], p, K, mode, orc.SGC_LL_RESLAP, G, Lp, dLs, Y_got=np.concatenate(out["Y"]))
+            compare_with_oracle(out, caches, tot, orc.SGC_LL_RESLAP, mode, K, has_prev=True, tot32=tot32)
+            gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(sb["X"], 0), sb["csr"], DEV)
+            layer = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, 256, K, mode, p, DEV)
+            from helpers import pack_tiles_np
+            st = amd.SgcLLStep(layer, gb, L_prev=torch.from_numpy(pack_tiles_np(Lp, gb.plan)).to(DEV),
+                               dL_sum=torch.from_numpy(pack_tiles_np(dLs, gb.plan)).to(DEV))
+            seen[fused_mode] = st.kernel_names()
+        finally:
+            lib.agcn_set_fused_mode(1)
+    # default dispatch: nothing specialised (no Reslap flavour reaches beyond 96 nodes), the per-graph kernels do all of it
+    assert "spec_forward_kernel" not in seen[1][0] and "sgc_forward_kernel" in seen[1][0], seen
+    assert "spec_backward_kernel" not in seen[1][1] and "sgc_backward_kernel" in seen[1][1], seen
+    print("Reslap, oversized molecules:", seen)
+
+
 def test_errors_are_loud(amd):
     gb = amd.GraphBatch.from_arrays(np.array([4], np.int32), np.zeros((4, 5), np.float32),
                                     [orc.graph_laplacian([[1], [0, 2], [1, 3], [2]])[:3]], DEV)
