@@ -22,7 +22,7 @@ if fs:
     shutil.copy(fs[0], out + "/${tag}_kernel_stats.csv")
     for r in csv.DictReader(open(fs[0])):
         if "agcn" in r["Name"]:
-            k = r["Name"].split("(")[0].replace("void ", "")
+            k = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             res[k]["avg_us"] = round(float(r["AverageNs"]) / 1000, 2)
             res[k]["calls"] = int(r["Calls"])
 def pmc(d):
@@ -30,7 +30,7 @@ def pmc(d):
     for f in glob.glob(out + "/%s/*/*counter_collection.csv" % d):
         for r in csv.DictReader(open(f)):
             if "agcn" in r["Kernel_Name"]:
-                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 for k, v in pmc("FETCH_SIZE").items():
     x = v.get("FETCH_SIZE", [])

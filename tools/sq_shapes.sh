@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$out/p/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "agcn" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in acc.items():
     m = {c: sum(x) / len(x) for c, x in v.items()}
