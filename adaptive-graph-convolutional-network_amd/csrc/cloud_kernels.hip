@@ -483,7 +483,10 @@ __global__ __launch_bounds__(256) void cloud_rlap1_kernel(SgcArgs a, const float
 // (graphconv.py:198-231) and the filter product Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b) (:238-251, 117-123).
 // RES: second Laplacian stage of SGC_LL_Reslap (graphconv_reslap.py:194-195): the tiles are L_pre (reserve, written by
 // cloud_rlap1_kernel), La = lrelu(clip_by_norm(L_pre, 1)) -> L_sum (the 4th output) and the L of the Chebyshev product.
-template <bool PAPER, bool RES = false>
+// NH: 64-column halves of the feature matrices handled by ONE run (1: 64-feature layers -- and the filter product behind the
+// strip loop --; 2: 128-feature layers, foff = 0: the n x n tiles are read and written ONCE for both halves -- run once per half
+// (rounds 3 and 4a) every tile was read twice: 83 + 73 us and 277 + 143 MB of reads for X_1 = L X_0, profiles/r04_modelnet128_*).
+template <bool PAPER, bool RES = false, int NH = 1>
 __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* rpart, const float* lpart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -492,8 +495,8 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* 
   if (strip < 0) return;
   const WaveCtx c = wave_ctx(a, 4 * strip + wave);
   const int n = c.n;
-  float* Bs = smem;                             // [64][LD]  the chunk's rows of X_0
-  float* Ls = smem + CC * LD + wave * (16 * LD);   // [16][LD]  this wave's strip of L
+  float* Bs = smem;                             // [NH][64][LD]  the chunk's rows of X_0 (one image per feature half)
+  float* Ls = smem + NH * CC * LD + wave * (16 * LD);   // [16][LD]  this wave's strip of L
   const float alpha = a.alpha[0];
   const float* Xg = a.X + (int64_t)c.row0 * a.ldx + a.foff;
   int l0ld;
@@ -539,17 +542,25 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* 
     return g;
   };
 
-  f32x4 acc[4];
+  f32x4 acc[NH][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  StageRegs pre = stage_load(Xg, a.ldx, 0);
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  StageRegs pre[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) pre[h] = stage_load(Xg + 64 * h, a.ldx, 0);
   Tiles cur = load_tiles(0);
 #pragma unroll 1
   for (int c0 = 0; c0 < n; c0 += CC) {
     __syncthreads();                  // every wave is done with the previous chunk's rows
-    stage_store(Bs, pre);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) stage_store(Bs + h * CC * LD, pre[h]);
     __syncthreads();
-    if (c0 + CC < n) pre = stage_load(Xg, a.ldx, c0 + CC);   // the next chunk's rows in flight behind this chunk's arithmetic
+    if (c0 + CC < n) {                // the next chunk's rows in flight behind this chunk's arithmetic
+#pragma unroll
+      for (int h = 0; h < NH; ++h) pre[h] = stage_load(Xg + 64 * h, a.ldx, c0 + CC);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
@@ -577,19 +588,22 @@ __global__ __launch_bounds__(256) void cloud_lap_kernel(SgcArgs a, const float* 
     // the next chunk's tiles: requested once this chunk's are consumed (into the same registers), in flight behind the product
     if (c0 + CC < n) cur = load_tiles(c0 + CC);
     __builtin_amdgcn_wave_barrier();
-    strip_mma(acc, Ls, Bs, r, q);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) strip_mma(acc[h], Ls, Bs + h * CC * LD, r, q);
   }
   // X_1[I] = L[I, :] X_0 -> reserve; and, with X_0[I], the A images of the filter product
   __syncthreads();                    // the chunk image is dead: its space holds the X_0[I] images now
   float* X0s = smem + wave * (16 * LD);   // (inside Bs: 4 x 16 rows)
   float* Xo = a.sv_X + (int64_t)(c.row0 + c.i0) * a.fstride + a.foff;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x4 v = (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
-    *reinterpret_cast<f32x4*>(Xo + (int64_t)(4 * q + i) * a.fstride + 4 * r) = v;
-    *reinterpret_cast<f32x4*>(Ls + (4 * q + i) * LD + 4 * r) = v;
-  }
-  if (a.fstride != FIN) return;       // 128-feature layer, one half of X_1 done: the filter product is a packed-row launch
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = (f32x4){acc[h][0][i], acc[h][1][i], acc[h][2][i], acc[h][3][i]};
+      *reinterpret_cast<f32x4*>(Xo + (int64_t)(4 * q + i) * a.fstride + 64 * h + 4 * r) = v;
+      if (NH == 1) *reinterpret_cast<f32x4*>(Ls + (4 * q + i) * LD + 4 * r) = v;
+    }
+  if (NH != 1 || a.fstride != FIN) return;   // 128-feature layer: the filter product is a packed-row launch
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int row = q + 4 * m;
@@ -1250,6 +1264,8 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
 // ------------------------------------------------------------------------------------------------
 // backward 2 (paper mode): c_ij = -S_ij (Q_ij s_i s_j + dd_i + dd_j) / r_ij (0 where r_ij = 0 or S_ij = 0),
 // dZ[I] = rowsum(c) Z[I] - c Z, dX[I] += dZ[I] M_L^T.
+// NH: feature halves per run, as cloud_lap_kernel (2: the Q and r tiles are read once for both halves of dZ = rowsum(c) Z - c Z).
+template <int NH = 1>
 __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -1258,8 +1274,8 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
   if (strip < 0) return;
   const WaveCtx c = wave_ctx(a, 4 * strip + wave);
   const int n = c.n;
-  float* Zs = smem;                                  // [64][LD]  Z rows of the chunk
-  float* Cs = smem + CC * LD + wave * (16 * LD);     // [16][LD]  this wave's strip of c
+  float* Zs = smem;                                  // [NH][64][LD]  Z rows of the chunk
+  float* Cs = smem + NH * CC * LD + wave * (16 * LD);   // [16][LD]  this wave's strip of c
   const float* Zg = a.sv_Z + (int64_t)c.row0 * a.fstride + a.foff;
   const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
   const float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
@@ -1283,18 +1299,26 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
     }
     return g;
   };
-  f32x4 acc[4];
+  f32x4 acc[NH][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  StageRegs pre = stage_load(Zg, a.fstride, 0);
+  StageRegs pre[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) pre[h] = stage_load(Zg + 64 * h, a.fstride, 0);
   Tiles cur = load_tiles(0);
 #pragma unroll 1
   for (int c0 = 0; c0 < n; c0 += CC) {
     __syncthreads();
-    stage_store(Zs, pre);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) stage_store(Zs + h * CC * LD, pre[h]);
     __syncthreads();
-    if (c0 + CC < n) pre = stage_load(Zg, a.fstride, c0 + CC);
+    if (c0 + CC < n) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) pre[h] = stage_load(Zg + 64 * h, a.fstride, c0 + CC);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = c.i0 + 4 * q + i;
@@ -1313,20 +1337,24 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
     }
     if (c0 + CC < n) cur = load_tiles(c0 + CC);   // (into the registers just consumed; in flight behind the product)
     __builtin_amdgcn_wave_barrier();
-    strip_mma(acc, Cs, Zs, r, q);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) strip_mma(acc[h], Cs, Zs + h * CC * LD, r, q);
   }
   // dZ_i = rowsum(c)_i Z_i - (c Z)_i -> workspace (for dM_L) and the A image of the product below
   float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * a.fstride + a.foff;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float csum = row16_sum(cs[i]);
-    const f32x4 z = *reinterpret_cast<const f32x4*>(Zg + (int64_t)(c.i0 + 4 * q + i) * a.fstride + 4 * r);
-    const f32x4 v = (f32x4){csum * z.x - acc[0][i], csum * z.y - acc[1][i], csum * z.z - acc[2][i], csum * z.w - acc[3][i]};
-    *reinterpret_cast<f32x4*>(dZg + (int64_t)(4 * q + i) * a.fstride + 4 * r) = v;
-    *reinterpret_cast<f32x4*>(Cs + (4 * q + i) * LD + 4 * r) = v;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const f32x4 z = *reinterpret_cast<const f32x4*>(Zg + (int64_t)(c.i0 + 4 * q + i) * a.fstride + 64 * h + 4 * r);
+      const f32x4 v = (f32x4){csum * z.x - acc[h][0][i], csum * z.y - acc[h][1][i], csum * z.z - acc[h][2][i], csum * z.w - acc[h][3][i]};
+      *reinterpret_cast<f32x4*>(dZg + (int64_t)(4 * q + i) * a.fstride + 64 * h + 4 * r) = v;
+      if (NH == 1) *reinterpret_cast<f32x4*>(Cs + (4 * q + i) * LD + 4 * r) = v;
+    }
   }
   __builtin_amdgcn_wave_barrier();
-  if (a.fstride != FIN) return;       // 128-feature layer: dX += dZ M_L^T is a packed-row launch behind the two halves
+  if (NH != 1 || a.fstride != FIN) return;   // 128-feature layer: dX += dZ M_L^T is a packed-row launch behind it
   // dX[I] += dZ[I] M_L^T   (adjoint of graphconv.py:164): B[k][f] = M_L[f][k], the lane's M_L rows read along k; tile t
   // stands for the output columns 4r + t, so a lane's four results of a row are one 16-byte read-modify-write
   float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
@@ -1663,7 +1691,7 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
   if (rc != AGCN_OK) return rc;
   rc = launch_cloud(cloud_degree_kernel, dim3(strips), 64, 0, PK_CLOUD_DEG, "cloud_degree", stream, a, (const float*)dpart, ns);
   if (rc != AGCN_OK) return rc;
-  const size_t lds = sizeof(float) * (CC * LD + 4 * 16 * LD);
+  const size_t lds = sizeof(float) * ((wide ? 2 : 1) * CC * LD + 4 * 16 * LD);
   const dim3 sgrid(xcd_grid((int)strips));
   float* rpart = dpart + (size_t)(tile_elems / SIM_RT + 64);
   float* lpart = rpart + (size_t)(tile_elems / 4096 + 16);
@@ -1677,9 +1705,20 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
     if (rc != AGCN_OK) return rc;
   }
   const bool res = a.variant == AGCN_SGC_LL_RESLAP;
-  for (int half = 0; half < (wide ? 2 : 1); ++half) {
+  if (wide) {      // both feature halves in one run (NH = 2): the n x n tiles are read and written once
     SgcArgs ah = a;
-    ah.foff = 64 * half;
+    ah.foff = 0;
+    if (res)
+      rc = paper ? launch_cloud(cloud_lap_kernel<true, true, 2>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)rpart, (const float*)lpart)
+                 : launch_cloud(cloud_lap_kernel<false, true, 2>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)rpart, (const float*)lpart);
+    else
+      rc = paper ? launch_cloud(cloud_lap_kernel<true, false, 2>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)nullptr, (const float*)nullptr)
+                 : launch_cloud(cloud_lap_kernel<false, false, 2>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)nullptr, (const float*)nullptr);
+    return rc;
+  }
+  {
+    SgcArgs ah = a;
+    ah.foff = 0;
     if (res)
       rc = paper ? launch_cloud(cloud_lap_kernel<true, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)rpart, (const float*)lpart)
                  : launch_cloud(cloud_lap_kernel<false, true>, sgrid, 256, lds, PK_CLOUD_LAP, "cloud_lap", stream, ah, (const float*)rpart, (const float*)lpart);
@@ -1750,10 +1789,11 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
                      : launch_cloud(cloud_bwd1_paper_kernel<128, true>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
   }
   if (rc != AGCN_OK || !paper) return rc;
-  for (int half = 0; half < (wide ? 2 : 1) && rc == AGCN_OK; ++half) {
+  {   // (128 features: both halves in one run, the Q and r tiles read once)
     SgcArgs ah = a;
-    ah.foff = 64 * half;
-    rc = launch_cloud(cloud_bwd2_kernel, grid, 256, lds_f32, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+    ah.foff = 0;
+    rc = wide ? launch_cloud(cloud_bwd2_kernel<2>, grid, 256, lds_f32 + sizeof(float) * CC * LD, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah)
+              : launch_cloud(cloud_bwd2_kernel<1>, grid, 256, lds_f32, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
   }
   return rc;
 }
@@ -1798,10 +1838,11 @@ int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void
   if (paper) { AGCN_RBWD(2, true, PK_CLOUD_RBWD_C, "cloud_rbwdC") } else { AGCN_RBWD(2, false, PK_CLOUD_RBWD_C, "cloud_rbwdC") }
 #undef AGCN_RBWD
   if (rc != AGCN_OK || !paper) return rc;
-  for (int half = 0; half < nh && rc == AGCN_OK; ++half) {
+  {
     SgcArgs ah = a;
-    ah.foff = 64 * half;
-    rc = launch_cloud(cloud_bwd2_kernel, grid, 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+    ah.foff = 0;
+    rc = wide ? launch_cloud(cloud_bwd2_kernel<2>, grid, 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, ah)
+              : launch_cloud(cloud_bwd2_kernel<1>, grid, 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
   }
   return rc;
 }
