@@ -946,6 +946,18 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   int32_t* counters = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, desc->K,
                                           paper ? 1 : 0, &n_counters);
   a.zero_ptr = counters; a.zero_count = n_counters;
+  // ... or, where every graph of the call takes the specialised backward kernel (all of whose workgroups clear a slice), the
+  // granules of the tagged hand-off (param_grad_tagged_kernel); a whole backward call only
+  bool pg_tagged = false;
+  if (stages == 3 && fused && fs.mode == 1 && fs.spec_bwd && fs.spec_bwd_first == 0) {
+    int32_t n16 = 0;
+    float* tags = param_grad_tag_region(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, desc->K, paper ? 1 : 0, &n16);
+    if (tags != nullptr) {
+      pg_tagged = true;
+      a.ztag_ptr = tags; a.ztag_count16 = n16;
+      a.zero_ptr = nullptr; a.zero_count = 0;
+    }
+  }
   // cooperative backward (spec_backward_coop.h)
   int coop_graphs = 0, coop_slabs = 0, dual_graphs = 0;
   coop_plan(desc, host, fs, true, &coop_graphs, &coop_slabs, &dual_graphs);
@@ -1022,6 +1034,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         a.tail_debug = dbg;
       }
       if (tail_done) {
+        a.ztag_ptr = nullptr; a.ztag_count16 = 0; pg_tagged = false;
         a.tail = reinterpret_cast<uint32_t*>(rb + rl.xch) + spec::TAIL_OFF_FLOATS;
         a.tail_first = first_plain;
         a.tail_graphs = B - first_plain;
@@ -1157,7 +1170,9 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   pa.B = fused ? B + fs.n_big_slabs + coop_slabs : ((slabs || cloud_res || cloud_bwd) ? host.info.n_slabs : B); pa.part_stride = w.part_stride;
   pa.X = a.X; pa.sv_X = a.sv_X; pa.Gp = w.Gp; pa.dZ = w.dZ; pa.part = w.part; pa.pg = w.pg;
   pa.part_floats = w.part_floats;
-  pa.counters_zeroed = ((stages & 1) && ((!cloud_bwd && !cloud_res) || (desc->Fin == 128 && filter_bwd_zeroed))) ? 1 : 0;
+  pa.counters_zeroed = ((stages & 1) && !pg_tagged && ((!cloud_bwd && !cloud_res) || (desc->Fin == 128 && filter_bwd_zeroed))) ? 1 : 0;
+  pa.tags_zeroed = pg_tagged ? 1 : 0;
+  pa.dev_status = a.dev_status; pa.ticks = a.coop_ticks;
   pa.dweight = grads->dweight; pa.dbias = grads->dbias; pa.dM_L = paper ? grads->dM_L : nullptr;
   pa.dalpha = grads->dalpha; pa.dbeta = has_prev ? grads->dbeta : nullptr;
   // point-cloud sizes: row-chunk partials with 16-byte operand loads + the fixed-order reduce (cloud_kernels.hip)

@@ -44,13 +44,15 @@ std::atomic<int32_t> g_fused_gb{[] {
 }()};
 extern "C" int32_t agcn_get_fused_global_b(void) { return g_fused_gb.load(); }
 extern "C" void agcn_set_fused_global_b(int32_t mode) { g_fused_gb.store(mode < 0 ? -1 : (mode > 0 ? 1 : 0)); }
-// 1 (default): one-pass parameter-gradient kernel; 0: partial + reduce launches
+// 2 (default): one-pass parameter-gradient kernel, the row splits' partial tiles handed to the tile's last split as tagged
+// 8-byte granules where the preceding kernel of the call can clear them (param_grad_tagged_kernel; else as 1);
+// 1: one-pass kernel with arrival counters (the last workgroup to arrive adds the splits); 0: partial + reduce launches
 std::atomic<int32_t> g_pg_onepass{[] {
   const char* e = std::getenv("AGCN_PG_ONEPASS");
-  return (e && e[0] == '0') ? 0 : 1;
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
 }()};
 extern "C" int32_t agcn_get_param_grad_onepass(void) { return g_pg_onepass.load(); }
-extern "C" void agcn_set_param_grad_onepass(int32_t on) { g_pg_onepass.store(on ? 1 : 0); }
+extern "C" void agcn_set_param_grad_onepass(int32_t on) { g_pg_onepass.store(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 std::atomic<int32_t> g_spec_mode{[] {
   // bit 0: specialised forward, bit 1: specialised backward, bit 2: large graphs' backward spread over several workgroups
   const char* e = std::getenv("AGCN_SPEC");

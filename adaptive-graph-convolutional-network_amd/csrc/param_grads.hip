@@ -8,6 +8,7 @@
 // fixed-order reduction -- no atomics, so the result is reproducible bit for bit.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "agcn_device.h"
 #include "sgc_kernels.h"
@@ -293,6 +294,144 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Tagged hand-off variant of the one-pass kernel (batches below 8k rows, TF = 16): same tiles, same row splits, same products,
+// same sums in the same order (bit-identical results) -- but the splits' partial tiles travel as 8-byte (value, tag) GRANULES:
+// one agent-scope store per element, no drain of the stores, no arrival counter, no second round of loads.  The workgroup of
+// a tile's LAST split (the shortest one, and the last in dispatch order: every producer has been dispatched before it) is the
+// tile's reducer: it polls the S - 1 granules of each of its elements (all requested at once), adds them in split order, its own
+// partial last, and writes the gradient.  Against the arrival-counter hand-off that removes two of the four memory round trips
+// (MI355X_MICROARCH.md, hand-off price list: data-tagged granules ~1 us against ~1.8x that for payload + drained flag, + the
+// counter's fan-in, + the reducer's dependent loads).  The granules' tags are CLEARED by the preceding kernel of the same call
+// (the specialised backward: spec::zero_tags, a slice per workgroup), so no state outlives a call and a tag of 1 can only come
+// from this launch's producers.  Waits are bounded as the cooperative kernels' (10 ms; NaN + the device status word).
+// (two workgroups per CU -- at most 64 VGPRs -- so that every workgroup of a 256-graph batch is resident at once: with one per CU the
+//  reducers, dispatched last, started 5 us into the launch)
+template <int KS>
+__global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArgs a) {
+  __shared__ float wsum[16][512 + 16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int K = a.K, Fin = a.Fin, Fout = a.Fout;
+  const int S = a.n_chunks, nt = a.n_tiles;
+  const int s = (int)blockIdx.x / nt, t = (int)blockIdx.x - s * nt;      // split-major: the reducers (s = S - 1) come last
+  AGCN_STAMP(7, 0);
+  const int tfW = (Fin * K + 15) / 16, tcW = (Fout + 31) >> 5;
+  const int tfM = (Fin + 15) / 16;
+  int p, rem;
+  if (t < tfW * tcW) { p = 0; rem = t; }
+  else if (t < tfW * tcW + tcW) { p = 1; rem = t - tfW * tcW; }
+  else { p = 2; rem = t - tfW * tcW - tcW; }
+  const int Fa = p == 0 ? Fin * K : (p == 1 ? 1 : Fin), Fb = p == 2 ? Fin : Fout;
+  const int tf = p == 0 ? tfW : (p == 1 ? 1 : tfM);
+  const int itc = rem / tf, itf = rem - itc * tf;
+  const int f0 = itf * 16, c0 = itc * 32;
+  const int last_row = a.rows - 1;
+  const int r_begin = s * a.chunk_rows + wave * a.wgs_per_chunk;
+  const int r_end = min(min(a.rows, (s + 1) * a.chunk_rows), r_begin + a.wgs_per_chunk);
+
+  const int j = min(f0 + r, Fa - 1);
+  const bool jv = (f0 + r) < Fa;
+  const float* Ap;
+  int64_t lda;
+  if (p == 0) {
+    const int f = j / K, kx = j - f * K;
+    if (kx == 0) { Ap = a.X + f; lda = a.ldx; }
+    else { Ap = a.sv_X + (int64_t)(kx - 1) * a.rows * Fin + f; lda = Fin; }
+  } else if (p == 2) { Ap = a.X + j; lda = a.ldx; }
+  else { Ap = a.X; lda = 0; }
+  const float* Bp = (p == 2) ? a.dZ : a.Gp;
+  const int ldb = (p == 2) ? Fin : Fout;
+  const int cA = min(c0 + r, Fb - 1), cB = min(c0 + 16 + r, Fb - 1);
+  const bool cAv = (c0 + r) < Fb, cBv = (c0 + 16 + r) < Fb;
+
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  for (int rr = r_begin; rr < r_end; rr += 4 * KS) {
+    float av[KS], b0[KS], b1[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int row = min(rr + 4 * u + q, last_row);
+      av[u] = (p == 1) ? 1.0f : Ap[(int64_t)row * lda];
+      b0[u] = Bp[(int64_t)row * ldb + cA];
+      b1[u] = Bp[(int64_t)row * ldb + cB];
+    }
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const bool rv = (rr + 4 * u + q) < r_end;
+      const float xv = (rv && jv) ? av[u] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, (rv && cAv) ? b0[u] : 0.f, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, (rv && cBv) ? b1[u] : 0.f, acc1, 0, 0, 0);
+    }
+  }
+  AGCN_STAMP(7, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    wsum[wave][(4 * q + i) * 32 + r] = acc0[i];
+    wsum[wave][(4 * q + i) * 32 + 16 + r] = acc1[i];
+  }
+  __syncthreads();
+  if (tid < 512) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += wsum[w][tid];
+    if (s != S - 1) {
+      // producer: one granule per element, fire and forget
+      __hip_atomic_store(a.gran + ((int64_t)t * (S - 1) + s) * 512 + tid, ((uint64_t)1u << 32) | (uint64_t)__float_as_uint(v),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      AGCN_STAMP(7, 2);
+      // reducer: the other splits' granules of this element -- ALL requested back to back (clamped addresses, no branch between
+      // the loads: a load inside a branch region of its own is waited for on the spot, and nine dependent round trips of
+      // agent-scope loads were 50 us), re-requested together until every tag is set
+      const uint64_t* base = a.gran + (int64_t)t * (S - 1) * 512;     // (uniform: scalar base + one vector offset per load)
+      const uint32_t toff = (uint32_t)tid;
+      const unsigned long long t0 = wall_clock64();
+      bool ok = true;
+      float tot = 0.f;
+      // (chunks of nine splits: the registers of fifteen loads in flight would cost the second resident workgroup)
+      for (int u0 = 0; u0 < S - 1 && ok; u0 += 9) {
+        uint64_t w[9];
+        for (;;) {
+#pragma unroll
+          for (int u = 0; u < 9; ++u)
+            w[u] = __hip_atomic_load(base + min(u0 + u, S - 2) * 512 + toff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool all = true;
+#pragma unroll
+          for (int u = 0; u < 9; ++u) all = all && ((uint32_t)(w[u] >> 32) == 1u);
+          if (all) break;
+          if (wall_clock64() - t0 >= (unsigned long long)a.ticks) { ok = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u)
+          if (u0 + u < S - 1) tot += __uint_as_float((uint32_t)w[u]);
+      }
+      AGCN_STAMP(7, 3);
+      tot += v;
+      if (!ok) {     // (never silently: NaN in the gradient + the device's status word)
+        tot = __builtin_nanf("");
+        if (a.dev_status != nullptr) __hip_atomic_fetch_add(a.dev_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int ff = f0 + (tid >> 5), c = c0 + (tid & 31);
+      if (ff < Fa && c < Fb) {
+        if (p == 0) a.dweight[(int64_t)ff * Fout + c] = tot;
+        else if (p == 1) a.dbias[c] = tot;
+        else a.dM_L[(int64_t)ff * Fin + c] = tot;
+      }
+    }
+  }
+  AGCN_STAMP(7, 4);
+  // scalars: one wave each of workgroup 0, fixed order (the per-graph partials come from the previous kernel)
+  if (blockIdx.x == 0 && wave >= 8 && wave < 10) {
+    float* dst = wave == 8 ? a.dalpha : a.dbeta;
+    if (dst != nullptr && a.pg != nullptr) {
+      const float v = pg_wave_sum(a.pg, a.B, wave - 8, lane);
+      if (lane == 0) dst[0] = v;
+    }
+  }
+}
+
 namespace {
 // output rows per tile of the one-pass kernel: 32 when the row count makes the kernel bandwidth-bound
 int pg_tf(int rows) {
@@ -323,19 +462,45 @@ void pg_split(int rows, int nt, int* rows_per_wave, int* S) {
 int pg_mode() { return agcn_get_param_grad_onepass(); }
 }  // namespace
 
-// floats of `part` the one-pass kernel needs: S partial tiles per output tile + the arrival counters
+// the tagged hand-off serves the batches the plain workgroup order serves (below 8k rows), 16-row tiles, at most 16 row splits
+static bool pg_tagged_shape(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper, int* nt_out, int* S_out, int* rpw_out) {
+  static const int xcd_force = [] { const char* e = std::getenv("AGCN_PG_XCD"); return e ? std::atoi(e) : -1; }();
+  if (rows >= 8192 || xcd_force > 0 || pg_tf(rows) != 16) return false;
+  int rpw, S;
+  const int nt = pg_tiles(Fin, Fout, K, paper != 0, 16);
+  pg_split(rows, nt, &rpw, &S);
+  if (S > 16) return false;
+  *nt_out = nt; *S_out = S; *rpw_out = rpw;
+  return true;
+}
+
+// floats of `part` the one-pass kernel needs: S partial tiles per output tile + the arrival counters, or (tagged hand-off)
+// S - 1 tiles of 8-byte granules per output tile
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper) {
   int rpw, S;
   const int TF = pg_tf(rows);
   const size_t nt = (size_t)pg_tiles(Fin, Fout, K, paper != 0, TF);
   pg_split(rows, (int)nt, &rpw, &S);
-  return nt * S * (TF * 32) + ((nt + 63) / 64) * 64;
+  size_t need = nt * S * (TF * 32) + ((nt + 63) / 64) * 64;
+  int nt2, S2, rpw2;
+  if (pg_tagged_shape(rows, Fin, Fout, K, paper, &nt2, &S2, &rpw2)) need = std::max(need, (size_t)nt2 * (S2 - 1) * 1024 + 4);
+  return need;
+}
+
+float* param_grad_tag_region(float* part, size_t part_floats, int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper,
+                             int32_t* count16) {
+  *count16 = 0;
+  int nt, S, rpw;
+  if (pg_mode() != 2 || !part || !pg_tagged_shape(rows, Fin, Fout, K, paper, &nt, &S, &rpw)) return nullptr;
+  if (part_floats < (size_t)nt * (S - 1) * 1024 + 4 || (reinterpret_cast<uintptr_t>(part) & 15) != 0) return nullptr;
+  *count16 = nt * (S - 1) * 256;          // 512 granules of 8 bytes per (tile, split)
+  return part;
 }
 
 int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t paper, int32_t* count) {
   *count = 0;
-  if (pg_mode() != 1 || !part || part_floats < param_grad_onepass_floats(rows, Fin, Fout, K, paper)) return nullptr;
+  if (pg_mode() < 1 || !part || part_floats < param_grad_onepass_floats(rows, Fin, Fout, K, paper)) return nullptr;
   int rpw, S;
   const int TF = pg_tf(rows);
   const int nt = pg_tiles(Fin, Fout, K, paper != 0, TF);
@@ -346,7 +511,22 @@ int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int3
 
 int launch_param_grads(const ParamGradArgs& a, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (pg_mode() == 1 && a.part_floats >= param_grad_onepass_floats(a.rows, a.Fin, a.Fout, a.K, a.paper)) {
+  if (a.tags_zeroed) {     // the caller had the preceding kernel clear the granules: param_grad_tag_region said yes
+    int nt, S, rpw;
+    if (!pg_tagged_shape(a.rows, a.Fin, a.Fout, a.K, a.paper, &nt, &S, &rpw) || a.part_floats < (size_t)nt * (S - 1) * 1024 + 4)
+      return fail(AGCN_EINVAL, "param_grads: tagged hand-off requested for a shape it does not serve");
+    ParamGradArgs aa = a;
+    aa.n_chunks = S; aa.wgs_per_chunk = rpw; aa.chunk_rows = 16 * rpw;
+    aa.n_tiles = nt;
+    aa.gran = reinterpret_cast<uint64_t*>(a.part);
+    prof_begin(PK_PARAM_TAGGED, stream);
+    hipLaunchKernelGGL((param_grad_tagged_kernel<8>), dim3((unsigned)(nt * S)), dim3(1024), 0, s, aa);
+    prof_end(stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_tagged launch: %s", hipGetErrorString(e));
+    return AGCN_OK;
+  }
+  if (pg_mode() >= 1 && a.part_floats >= param_grad_onepass_floats(a.rows, a.Fin, a.Fout, a.K, a.paper)) {
     ParamGradArgs aa = a;
     int rpw, S;
     const int TF = pg_tf(a.rows);

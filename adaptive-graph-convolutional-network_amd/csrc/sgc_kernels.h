@@ -87,6 +87,10 @@ struct SgcArgs {
   // fused backward kernel (saves a memset node in front of it)
   int32_t* zero_ptr;
   int32_t zero_count;
+  // ... or the granules of its tagged hand-off (param_grad_tagged_kernel): `ztag_count16` 16-byte units at ztag_ptr, cleared by
+  // ALL workgroups of the specialised backward launch, a slice each (spec::zero_tags)
+  float* ztag_ptr;
+  int32_t ztag_count16;
   // point-cloud kernels (cloud_kernels.hip) on layers of 128 input features: the strip kernels work on 64 feature columns at a
   // time -- `foff` = first column of the half (0 / 64), `fstride` = row stride of the packed feature arrays (Z, g_1, X_1, dZ: Fin)
   // -- and run once per half.  Everything that couples the halves is linear in the per-half products, so the second run ADDS
@@ -136,6 +140,13 @@ struct ParamGradArgs {
   int32_t* counters;    // one-pass kernel: per-tile arrival counters (set by the launcher)
   int32_t counters_zeroed;  // 1 = a preceding kernel of the same call already zeroed them
   int32_t xcd;              // one-pass kernel: XCD-aware workgroup order (set by the launcher)
+  // tagged hand-off (param_grad_tagged_kernel): the granules [n_tiles][S - 1][512] of (value, tag) words inside `part`, cleared
+  // by the preceding kernel of the same call (tags_zeroed = 1: set by the caller, who also passed SgcArgs::ztag_ptr to it)
+  int32_t tags_zeroed;
+  uint64_t* gran;           // (set by the launcher)
+  int32_t n_tiles;          // (set by the launcher)
+  uint32_t* dev_status;     // the device's persistent status word or nullptr: a wait that runs out counts itself there
+  uint32_t ticks;           // bound of such a wait (100 MHz constant clock)
   const float* pg;      // [B][2]
   float *dweight, *dbias, *dM_L, *dalpha, *dbeta;
 };
@@ -144,7 +155,7 @@ struct ParamGradArgs {
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
        PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD,
        PK_PARAM_ONEPASS, PK_SPEC_FWD, PK_SPEC_BWD, PK_CLOUD_SIM, PK_CLOUD_DEG, PK_CLOUD_LAP, PK_CLOUD_BWD1,
-       PK_CLOUD_BWD2, PK_CLOUD_RNORM, PK_CLOUD_RLAP1, PK_CLOUD_RBWD_A, PK_CLOUD_RBWD_B, PK_CLOUD_RBWD_C, PK_COUNT };
+       PK_CLOUD_BWD2, PK_CLOUD_RNORM, PK_CLOUD_RLAP1, PK_CLOUD_RBWD_A, PK_CLOUD_RBWD_B, PK_CLOUD_RBWD_C, PK_PARAM_TAGGED, PK_COUNT };
 // Raises a kernel's dynamic-LDS cap (hipFuncAttributeMaxDynamicSharedMemorySize) once per kernel and size: the
 // driver call is skipped when the cap already covers `bytes` (it costs several microseconds per launch otherwise).
 // Tracked per (device, kernel).  Returns hipSuccess (0) or the HIP error code.
@@ -204,6 +215,9 @@ size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_
 // the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number
 int32_t* param_grad_counters(float* part, size_t part_floats, int32_t rows, int32_t Fin, int32_t Fout, int32_t K,
                              int32_t paper, int32_t* count);
+// the granules of the tagged hand-off inside `part` (nullptr when that kernel will not be used) and their size in 16-byte units
+float* param_grad_tag_region(float* part, size_t part_floats, int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper,
+                             int32_t* count16);
 
 }  // namespace agcn
 #endif

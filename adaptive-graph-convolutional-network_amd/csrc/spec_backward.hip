@@ -662,6 +662,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     AGCN_STAMP(4, 9);
     return;
   }
+  zero_tags(a);
   if (blockIdx.x == 0) {   // arrival counters of the parameter-gradient kernel that follows this one
     for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
   }

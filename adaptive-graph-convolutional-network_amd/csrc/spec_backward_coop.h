@@ -548,6 +548,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     tail_publish(a, sl, tgen, tid == 0, [] { __syncthreads(); });
     return;
   }
+  zero_tags(a);
   if (sl == 0) {   // arrival counters of the parameter-gradient kernel that follows
     for (int e = tid; e < a.zero_count; e += NT) a.zero_ptr[e] = 0;
   }

@@ -186,6 +186,21 @@ __device__ __forceinline__ float body_sum(float v, float* red, int tid) {
   return red[31];
 }
 
+// the granules of the parameter-gradient kernel that follows this launch (param_grad_tagged_kernel): every workgroup clears a
+// slice, behind everything else it does.  AGENT-SCOPE stores like every other access to these words: a plain store leaves the
+// (cleared) line in this XCD's L2, where the reducer's polls of the next kernel kept finding it for ~100 us (measured: the
+// step 47 -> 143 us) -- lines that only ever see agent-scope accesses are not kept anywhere.
+__device__ __forceinline__ void zero_tags(const SgcArgs& a) {
+  if (a.ztag_count16 > 0) {
+    f32x4* p = reinterpret_cast<f32x4*>(a.ztag_ptr);
+    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int step = (int)(gridDim.x * blockDim.x);
+    // (16-byte agent-scope stores: two granules each; as 8-byte atomic stores the slice cost the backward kernel 0.6 us)
+    for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < a.ztag_count16; e += step)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p + e), "v"(z) : "memory");
+  }
+}
+
 // contiguous, balanced share of T tiles for wave w of NW
 template <int NW>
 __device__ __forceinline__ void tile_range(int T, int w, int& t0, int& t1) {

@@ -140,8 +140,10 @@ class SgcLLStep(object):
     def kernel_names(self):
         """Names of the kernels one forward / per-graph backward / parameter-gradient call launches on this
         batch (three strings), found by running each once under the library's launch profiler."""
-        out = []
-        for fn in (self.forward, lambda: self.backward(1), lambda: self.backward(2)):
+        names = []
+        # (the parameter-gradient kernel of a WHOLE backward call: a call of that stage alone may take another kernel -- the
+        #  tagged hand-off needs the per-graph kernel of the same call in front of it)
+        for fn in (self.forward, lambda: self.backward(1), lambda: self.backward(3)):
             torch.cuda.synchronize(self.device)
             self.lib.agcn_profile_enable(1)
             try:
@@ -149,8 +151,8 @@ class SgcLLStep(object):
                 prof = _ffi.profile_collect()
             finally:
                 self.lib.agcn_profile_enable(0)
-            out.append("+".join(k for k, (ms, c) in prof.items() if c > 0))
-        return out
+            names.append([k for k, (ms, c) in prof.items() if c > 0])
+        return ["+".join(names[0]), "+".join(names[1]), "+".join(k for k in names[2] if k not in names[1])]
 
     def replay(self):
         self._graph.replay()

@@ -482,8 +482,11 @@ void agcn_set_fused_mode(int32_t mode);
  * graph's own working set fits LDS).  Same results to the last few ulps (different summation grouping). */
 int32_t agcn_get_fused_global_b(void);
 void agcn_set_fused_global_b(int32_t mode);
-/* 1 (default): parameter gradients in one launch (row splits reduced by the last-arriving workgroup in fixed
- * order); 0: partial + reduce launches.  Both bit-reproducible. */
+/* 2 (default): parameter gradients in one launch, the row splits' partial tiles handed to the workgroup of the tile's last
+ * split as tagged 8-byte granules (where the per-graph kernel of the same call can clear them: whole backward calls on the
+ * shape-specialised kernels, batches below 8192 rows; elsewhere as 1); 1: one launch, arrival counters (the last workgroup
+ * to arrive adds the splits); 0: partial + reduce launches.  All three add in fixed order: bit-reproducible, and 1 and 2
+ * bit-identical to each other. */
 int32_t agcn_get_param_grad_onepass(void);
 void agcn_set_param_grad_onepass(int32_t on);
 /* Shape-specialised fused kernels (csrc/spec_*.hip: SGC_LL, K = 2, layer widths 75->64, 64->128, 128->128, 128->64,

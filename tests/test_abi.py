@@ -136,7 +136,7 @@ def test_new_entry_points_validate_before_launching(amd):
     assert rc != 0 and b"go together" in lib.agcn_last_error()
     # knobs round-trip
     for setter, getter, values in ((lib.agcn_set_fused_global_b, lib.agcn_get_fused_global_b, (0, 1, -1)),
-                                   (lib.agcn_set_param_grad_onepass, lib.agcn_get_param_grad_onepass, (0, 1)),
+                                   (lib.agcn_set_param_grad_onepass, lib.agcn_get_param_grad_onepass, (0, 1, 2)),
                                    (lib.agcn_set_fused_mode, lib.agcn_get_fused_mode, (0, 2, 3, 1)),
                                    (lib.agcn_set_spec_mode, lib.agcn_get_spec_mode, (0, 1, 2, 3, 7)),
                                    (lib.agcn_set_spec_small, lib.agcn_get_spec_small, (0, 1, 2))):

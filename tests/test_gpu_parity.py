@@ -152,7 +152,7 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
     amd._ffi.lib().agcn_set_fused_mode({"fused": 1, "mixed": 2, "mixed_slab": 3}.get(path, 0))
     amd._ffi.lib().agcn_set_fused_global_b(gb)
     # the legacy two-launch parameter gradients ride along on the LDS-image flavour
-    amd._ffi.lib().agcn_set_param_grad_onepass(0 if gb == 0 else 1)
+    amd._ffi.lib().agcn_set_param_grad_onepass(0 if gb == 0 else 2)
     try:
         rs, X, L0, csr, p, G = synth_case(1000 + case, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
         Lp = dLsum = None
@@ -164,7 +164,7 @@ def test_packed_vs_oracle(amd, case, variant, mode, path):
         compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
     finally:
         amd._ffi.lib().agcn_set_fused_global_b(-1)
-        amd._ffi.lib().agcn_set_param_grad_onepass(1)
+        amd._ffi.lib().agcn_set_param_grad_onepass(2)
         amd._ffi.lib().agcn_set_lds_limit(160 * 1024)
         amd._ffi.lib().agcn_set_slab_mode(1)
         amd._ffi.lib().agcn_set_fused_mode(1)
@@ -1999,6 +1999,78 @@ def test_param_grads_ride_in_the_backward_launch(amd, B):
     assert_close(to_np(st.grads["M_L"]), tot["dM_L"], GRAD_RTOL, "dM_L", ref32=tot32["dM_L"])
     from helpers import _scalar_close
     _scalar_close(to_np(st.grads["alpha"]), tot["dalpha"], tot32["dalpha"], float(np.abs(tot["dweight"]).max()), "dalpha")
+
+
+@pytest.mark.parametrize("shape", [(256, 75, 64, "sgc"), (37, 64, 128, "sgc"), (256, 128, 128, "sgc"), (256, 64, 64, "reslap"),
+                                   (20, 75, 64, "sgc"), (400, 75, 64, "sgc")],
+                         ids=["tox21_l1", "b37_64_128", "tox21_l3", "reslap_64_64", "one_split", "many_splits"])
+def test_param_grads_tagged_hand_off(amd, shape):
+    """The parameter-gradient kernel of a whole backward call on the specialised kernels (param_grad_tagged_kernel: the row
+    splits' partial tiles handed to the tile's last split as tagged 8-byte granules, cleared by the backward kernel of the same
+    call) gives BIT-IDENTICAL gradients to the arrival-counter kernel (agcn_set_param_grad_onepass(1): same tiles, same splits,
+    same order of additions), call after call with the workspace poisoned in between, and replay after replay; the kernels
+    that ran are asserted through the library's profiler.  one_split: a batch of fewer than 512 rows (no hand-off at all);
+    many_splits: 400 graphs (15 row splits, more workgroups than the chip holds at once: the reducers are dispatched last)."""
+    from agcn_amd import synth
+    B, Fin, Fout, kind = shape
+    K = 2
+    variant = orc.SGC_LL_RESLAP if kind == "reslap" else orc.SGC_LL
+    data = synth.tox21_batch(4000 + B + Fin, B, Fin)
+    p = orc.init_params(np.random.RandomState(19), Fin, Fout, K)
+    p["alpha"] = np.array([0.7], np.float32)
+    gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], DEV)
+    if int(gb.plan.rows) >= 8192:
+        pytest.skip("batches of 8k rows and more keep the XCD-ordered arrival-counter kernel")
+    layer = make_layer(amd, variant, Fout, Fin, B, K, orc.PAPER, p, DEV)
+    rs = np.random.RandomState(21)
+    # two upstream gradients, alternated: a granule left over from the previous call then differs from the fresh one
+    dYs = [torch.from_numpy(rs.randn(gb.plan.rows, Fout).astype(np.float32)).to(DEV) for _ in range(2)]
+    lib = amd._ffi.lib()
+    prev = lib.agcn_get_param_grad_onepass()
+    try:
+        lib.agcn_set_param_grad_onepass(1)
+        st1 = amd.SgcLLStep(layer, gb, dY=dYs[0])
+        want = []
+        for d in dYs:
+            st1.dY.copy_(d)
+            st1.step()
+            torch.cuda.synchronize()
+            want.append(st1.bucket.clone())
+        assert not torch.equal(want[0], want[1])
+        assert "param_grad_onepass_kernel" in st1.kernel_names()[2]
+        lib.agcn_set_param_grad_onepass(2)
+        st = amd.SgcLLStep(layer, gb, dY=dYs[0])
+        lib.agcn_profile_enable(1)
+        try:
+            amd._ffi.profile_collect()
+            st.step()
+            torch.cuda.synchronize()
+            prof = {k: v[1] for k, v in amd._ffi.profile_collect().items() if v[1]}
+        finally:
+            lib.agcn_profile_enable(0)
+        assert prof.get("param_grad_tagged_kernel") == 1 and "param_grad_onepass_kernel" not in prof, prof
+        assert bool(torch.isfinite(st.bucket).all()) and torch.equal(st.bucket, want[0])
+        for it in range(8):                                   # call after call; stale granules differ or are poisoned
+            st.dY.copy_(dYs[it & 1])
+            st.bucket.zero_()
+            if it >= 4:
+                st.ws.view(torch.float32)[: st.ws.numel() // 4].fill_(float("nan") if it & 2 else 1.0)
+            st.step()
+            torch.cuda.synchronize()
+            assert torch.equal(st.bucket, want[it & 1]), it
+        st.dY.copy_(dYs[1])
+        st.capture(steps=3)                                   # replay after replay (three steps per launch)
+        for it in range(6):
+            st.dY.copy_(dYs[it & 1])
+            st.bucket.zero_()
+            st.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(st.bucket, want[it & 1]), it
+        assert st.check() == 0
+        amd.functional.check_device_status()            # (raises if a reducer's wait ran out)
+    finally:
+        lib.agcn_set_param_grad_onepass(prev)
+
 
 
 def orc_dense(csr, n):

@@ -36,7 +36,7 @@ for (B, Fin, Fout, iters) in ((256, 75, 64, 3000), (256, 128, 128, 1500), (2048,
         st.step()
         torch.cuda.synchronize()
         refs.append(st.bucket.clone())
-    lib.agcn_set_param_grad_onepass(1)
+    lib.agcn_set_param_grad_onepass(int(os.environ.get("AGCN_STRESS_PG_MODE", "2")))   # 2: tagged granules, 1: arrival counters
     noise = torch.randn(64 << 20, device=dev)            # 256 MB of unrelated traffic between steps
     for mode in ("eager", "graph"):
         if mode == "graph":
