@@ -296,10 +296,10 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
 
 
 // ------------------------------------------------------------------------------------------------
-// Tagged hand-off variant of the one-pass kernel (batches below 8k rows, TF = 16): same tiles, same row splits, same products,
-// same sums in the same order (bit-identical results) -- but the splits' partial tiles travel as 8-byte (value, tag) GRANULES:
+// Tagged hand-off variant of the one-pass kernel (batches below 8k rows, TF = 16): the same tiles and products over EIGHT row
+// splits, one per XCD -- and the splits' partial tiles travel as 8-byte (value, tag) GRANULES:
 // one agent-scope store per element, no drain of the stores, no arrival counter, no second round of loads.  The workgroup of
-// a tile's LAST split (the shortest one, and the last in dispatch order: every producer has been dispatched before it) is the
+// a tile's LAST split (the shortest one; behind its tile's producers in dispatch order: they have all been dispatched) is the
 // tile's reducer: it polls the S - 1 granules of each of its elements (all requested at once), adds them in split order, its own
 // partial last, and writes the gradient.  Against the arrival-counter hand-off that removes two of the four memory round trips
 // (MI355X_MICROARCH.md, hand-off price list: data-tagged granules ~1 us against ~1.8x that for payload + drained flag, + the
@@ -315,7 +315,11 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
   const int r = lane & 15, q = lane >> 4;
   const int K = a.K, Fin = a.Fin, Fout = a.Fout;
   const int S = a.n_chunks, nt = a.n_tiles;
-  const int s = (int)blockIdx.x / nt, t = (int)blockIdx.x - s * nt;      // split-major: the reducers (s = S - 1) come last
+  // split = block % S: with the EIGHT splits of a batch of 128 rows and more, and workgroups dealt round-robin over the 8 XCDs,
+  // every workgroup of one row split runs on one XCD -- a row of X / X_1 / Gp / dZ is then fetched into ONE L2 instead of all
+  // eight (the plain order's 370 workgroups waited 3.5 - 6.6 us for their operands: 23 MB over the fabric for 3.6 MB of rows).
+  // A speed matter only.  The reducer (s = S - 1) follows its tile's producers in dispatch order.
+  const int t = (int)blockIdx.x / S, s = (int)blockIdx.x - t * S;
   AGCN_STAMP(7, 0);
   const int tfW = (Fin * K + 15) / 16, tcW = (Fout + 31) >> 5;
   const int tfM = (Fin + 15) / 16;
@@ -389,23 +393,22 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
       const unsigned long long t0 = wall_clock64();
       bool ok = true;
       float tot = 0.f;
-      // (chunks of nine splits: the registers of fifteen loads in flight would cost the second resident workgroup)
-      for (int u0 = 0; u0 < S - 1 && ok; u0 += 9) {
-        uint64_t w[9];
+      if (S > 1) {        // (S <= 8: at most seven granules per element)
+        uint64_t w[7];
         for (;;) {
 #pragma unroll
-          for (int u = 0; u < 9; ++u)
-            w[u] = __hip_atomic_load(base + min(u0 + u, S - 2) * 512 + toff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int u = 0; u < 7; ++u)
+            w[u] = __hip_atomic_load(base + min(u, S - 2) * 512 + toff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           bool all = true;
 #pragma unroll
-          for (int u = 0; u < 9; ++u) all = all && ((uint32_t)(w[u] >> 32) == 1u);
+          for (int u = 0; u < 7; ++u) all = all && ((uint32_t)(w[u] >> 32) == 1u);
           if (all) break;
           if (wall_clock64() - t0 >= (unsigned long long)a.ticks) { ok = false; break; }
           __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int u = 0; u < 9; ++u)
-          if (u0 + u < S - 1) tot += __uint_as_float((uint32_t)w[u]);
+        for (int u = 0; u < 7; ++u)
+          if (u < S - 1) tot += __uint_as_float((uint32_t)w[u]);
       }
       AGCN_STAMP(7, 3);
       tot += v;
@@ -431,6 +434,7 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
     }
   }
 }
+
 
 namespace {
 // output rows per tile of the one-pass kernel: 32 when the row count makes the kernel bandwidth-bound
@@ -462,17 +466,20 @@ void pg_split(int rows, int nt, int* rows_per_wave, int* S) {
 int pg_mode() { return agcn_get_param_grad_onepass(); }
 }  // namespace
 
-// the tagged hand-off serves the batches the plain workgroup order serves (below 8k rows), 16-row tiles, at most 16 row splits
+// the tagged hand-off serves the batches below 8k rows: 16-row tiles, EIGHT row splits (one per XCD) of 16 waves x rpw rows each.
+// (32 x 32 tiles of 32 consecutive features of one Chebyshev term -- half the cache lines per output, one workgroup per CU --
+//  measured equal at 75 -> 64 and slower at 128 -> 64, 67.1 against 62.9 us per step: profiles/EXPERIMENTS.md)
 static bool pg_tagged_shape(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper, int* nt_out, int* S_out, int* rpw_out) {
   static const int xcd_force = [] { const char* e = std::getenv("AGCN_PG_XCD"); return e ? std::atoi(e) : -1; }();
-  if (rows >= 8192 || xcd_force > 0 || pg_tf(rows) != 16) return false;
-  int rpw, S;
-  const int nt = pg_tiles(Fin, Fout, K, paper != 0, 16);
-  pg_split(rows, nt, &rpw, &S);
-  if (S > 16) return false;
-  *nt_out = nt; *S_out = S; *rpw_out = rpw;
+  if (rows < 1 || rows >= 8192 || xcd_force > 0 || pg_tf(rows) != 16) return false;
+  const int rpw = (rows + 127) / 128;                       // rows per wave: any number (the k-steps of 4 rows are masked)
+  *nt_out = pg_tiles(Fin, Fout, K, paper != 0, 16);
+  *S_out = (rows + 16 * rpw - 1) / (16 * rpw);              // <= 8
+  *rpw_out = rpw;
   return true;
 }
+// floats of the granules: 512 8-byte words per (tile, producing split)
+static size_t pg_tagged_floats(int nt, int S) { return (size_t)nt * (S - 1) * 1024 + 4; }
 
 // floats of `part` the one-pass kernel needs: S partial tiles per output tile + the arrival counters, or (tagged hand-off)
 // S - 1 tiles of 8-byte granules per output tile
@@ -483,7 +490,7 @@ size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_
   pg_split(rows, (int)nt, &rpw, &S);
   size_t need = nt * S * (TF * 32) + ((nt + 63) / 64) * 64;
   int nt2, S2, rpw2;
-  if (pg_tagged_shape(rows, Fin, Fout, K, paper, &nt2, &S2, &rpw2)) need = std::max(need, (size_t)nt2 * (S2 - 1) * 1024 + 4);
+  if (pg_tagged_shape(rows, Fin, Fout, K, paper, &nt2, &S2, &rpw2)) need = std::max(need, pg_tagged_floats(nt2, S2));
   return need;
 }
 
@@ -492,7 +499,7 @@ float* param_grad_tag_region(float* part, size_t part_floats, int32_t rows, int3
   *count16 = 0;
   int nt, S, rpw;
   if (pg_mode() != 2 || !part || !pg_tagged_shape(rows, Fin, Fout, K, paper, &nt, &S, &rpw)) return nullptr;
-  if (part_floats < (size_t)nt * (S - 1) * 1024 + 4 || (reinterpret_cast<uintptr_t>(part) & 15) != 0) return nullptr;
+  if (part_floats < pg_tagged_floats(nt, S) || (reinterpret_cast<uintptr_t>(part) & 15) != 0) return nullptr;
   *count16 = nt * (S - 1) * 256;          // 512 granules of 8 bytes per (tile, split)
   return part;
 }
@@ -513,14 +520,14 @@ int launch_param_grads(const ParamGradArgs& a, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a.tags_zeroed) {     // the caller had the preceding kernel clear the granules: param_grad_tag_region said yes
     int nt, S, rpw;
-    if (!pg_tagged_shape(a.rows, a.Fin, a.Fout, a.K, a.paper, &nt, &S, &rpw) || a.part_floats < (size_t)nt * (S - 1) * 1024 + 4)
+    if (!pg_tagged_shape(a.rows, a.Fin, a.Fout, a.K, a.paper, &nt, &S, &rpw) || a.part_floats < pg_tagged_floats(nt, S))
       return fail(AGCN_EINVAL, "param_grads: tagged hand-off requested for a shape it does not serve");
     ParamGradArgs aa = a;
     aa.n_chunks = S; aa.wgs_per_chunk = rpw; aa.chunk_rows = 16 * rpw;
     aa.n_tiles = nt;
     aa.gran = reinterpret_cast<uint64_t*>(a.part);
     prof_begin(PK_PARAM_TAGGED, stream);
-    hipLaunchKernelGGL((param_grad_tagged_kernel<8>), dim3((unsigned)(nt * S)), dim3(1024), 0, s, aa);
+    hipLaunchKernelGGL((param_grad_tagged_kernel<10>), dim3((unsigned)(nt * S)), dim3(1024), 0, s, aa);
     prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "param_grad_tagged launch: %s", hipGetErrorString(e));
