@@ -170,7 +170,12 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   *graphs = *slabs = *dual_graphs = 0;
   const int B = host.info.B;
   // (reference mode: the backward has no n x n work to spread; the forward still has the similarity tile)
-  if (d->variant != AGCN_SGC_LL) return;   // (the Reslap flavour of the specialised kernels: one workgroup per graph)
+  // SGC_LL_Reslap: members in both directions too (they exchange the graph-wide clip norms / inner products as well), no
+  // paired small graphs
+  const bool reslap = d->variant == AGCN_SGC_LL_RESLAP;
+  if (d->variant != AGCN_SGC_LL && !reslap) return;
+  static const int res_coop = [] { const char* e = std::getenv("AGCN_RESLAP_COOP"); return e ? std::atoi(e) : 1; }();   // bit 0 forward, bit 1 backward
+  if (reslap && !((res_coop >> (backward ? 1 : 0)) & 1)) return;
   if ((d->mode != AGCN_MODE_PAPER && backward) || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
       fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
     return;
@@ -185,7 +190,8 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   const int member_budget = std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members());
   // (with two and more rounds of workgroups per CU the tail graph matters less than the extra workgroups cost:
   //  512 graphs: 6.0 M graphs/s without, 5.7 M with members for its one 70-node graph)
-  static const int dual_on = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
+  static const int dual_env = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
+  const int dual_on = reslap ? 0 : dual_env;
   // (never beyond DUAL_MAX_N: both halves of a paired workgroup must run the same barrier sequence, spec_forward.hip)
   static const int dual_max = [] {
     const char* e = std::getenv("AGCN_DUAL_MAX_N");
@@ -366,8 +372,10 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   // exchange header of the cooperative kernels (spec_backward_coop.h): fixed size, at offset 0 whatever the batch, zero
   // when the reserve is first used (include/agcn.h) and self-maintaining afterwards
   // + the words of the trailing parameter-gradient workgroups (spec_tail.h): generation, exit counter, producer flags
-  r.xch = c.off; c.take((size_t)spec::TAIL_OFF_FLOATS + spec::TAIL_WORDS);
+  // + the scalar exchange words of the SGC_LL_Reslap members (behind the tail words)
+  r.xch = c.off; c.take((size_t)2 * (spec::COOP_SCAL_WORD + spec::COOP_SCAL_WORDS));
   static_assert(sizeof(float) * (spec::TAIL_OFF_FLOATS + spec::TAIL_WORDS) <= AGCN_RESERVE_HEADER_BYTES, "reserve header");
+  static_assert(sizeof(uint64_t) * (spec::COOP_SCAL_WORD + spec::COOP_SCAL_WORDS) <= AGCN_RESERVE_HEADER_BYTES, "reserve header");
   r.Z = c.off; c.take((size_t)pi.rows * d->Fin);
   r.s = c.off; c.take((size_t)pi.rows);
   r.scal = c.off; c.take((size_t)4 * pi.B);

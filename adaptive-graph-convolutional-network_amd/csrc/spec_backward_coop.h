@@ -54,6 +54,10 @@ constexpr int COOP_STATUS_WORD = COOP_HEADER_WORDS;     // 64-bit word index ins
 #include "spec_tail_proto.h"
 namespace agcn {
 namespace spec {
+// SGC_LL_Reslap members also exchange graph-wide SUMS (the two clip norms of the forward, the two clip inner products of the
+// backward): one 64-bit (value, epoch) word per member, direction and kind, behind the tail words of the header
+constexpr int COOP_SCAL_WORD = (TAIL_OFF_FLOATS + TAIL_WORDS + 1) / 2;     // 64-bit word index inside the reserve header
+constexpr int COOP_SCAL_WORDS = 4 * COOP_MAX_MEMBERS;                      // [direction][kind][member]
 constexpr unsigned COOP_TIMEOUT_TICKS = 1000000u;   // 10 ms at 100 MHz: the default of agcn_set_coop_timeout_ticks (SgcArgs::coop_ticks)
 __device__ __forceinline__ uint64_t coop_wait_word(uint64_t* status, uint32_t* dev_status, uint32_t ticks, const uint64_t* word, uint32_t want, bool* ok) {
   const unsigned long long t0 = wall_clock64();
@@ -69,6 +73,30 @@ __device__ __forceinline__ uint64_t coop_wait_word(uint64_t* status, uint32_t* d
   *ok = false;
   return w;
 }
+
+#if defined(__HIPCC__)
+// Sum of one scalar over ALL members of a graph: this member's `part` is summed over the workgroup, published as a (value,
+// epoch) word in its slot (slots[me]), the siblings' words are polled, and every member adds the ntm values in member order --
+// the same bits in every member.  wants[m]: the epoch tag member m publishes under.  Contains barriers (uniform control flow).
+__device__ __forceinline__ float coop_graph_sum(const SgcArgs& a, float part, float* red, float* gs, uint64_t* slots, int me, int ntm,
+                                                const uint32_t* wants, int tid) {
+  const float mine = block_sum(part, red);
+  if (tid == 0) {      // published before anyone polls (a divergent branch could put a spinning sibling poll in front of it)
+    __hip_atomic_store(slots + me, ((uint64_t)wants[me] << 32) | (uint64_t)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gs[me] = mine;
+  }
+  if (tid < ntm && tid != me) {
+    bool got;
+    const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, a.dev_status, a.coop_ticks, slots + tid, wants[tid], &got);
+    gs[tid] = got ? __uint_as_float((uint32_t)w) : __builtin_nanf("");
+  }
+  __syncthreads();
+  float tot = 0.f;
+  for (int m = 0; m < ntm; ++m) tot += gs[m];
+  __syncthreads();
+  return tot;
+}
+#endif
 
 struct CoopLds {
   int n4, ldt;
@@ -579,8 +607,11 @@ AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4) {
 //   -> res_L[I, :], L[I, :] -> X_1[I] = L[I, :] X_0 -> Y[I].
 // The distance sums run over the features in index order for both (i, j) and (j, i), so S stays bit-symmetric across
 // members; degrees are wave sums (not the serial column sums of the one-workgroup kernel: last-ulp differences).
-template <int FIN, int FOUT>
+// RESLAP (SGC_LL_Reslap, graphconv_reslap.py:184-198): the two clip_by_norm stages need ||R||_F and ||L_pre||_F of the WHOLE graph:
+// two more exchanges (coop_graph_sum), the same sums in the same order in every member.
+template <int FIN, int FOUT, bool RESLAP = false>
 __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int sl, float* smem) {
+  __shared__ float coop_gs[8];
   constexpr int NW = 16;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
@@ -606,8 +637,9 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   uint64_t* xch = a.sv_xch + COOP_DIR_WORDS + (sl - me) * 16;                     // direction 1
   uint64_t* xep = a.sv_xch + COOP_DIR_WORDS + COOP_MAX_MEMBERS * 16 + (sl - me);
   uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [8], see coop_backward_member
-  if (paper && tid < ntm)
+  if ((paper || RESLAP) && tid < ntm)
     wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  uint64_t* xsc = a.sv_xch + COOP_SCAL_WORD + 2 * COOP_MAX_MEMBERS + (sl - me);      // direction 1, kind 0; kind 1 COOP_MAX_MEMBERS on
 
   AGCN_STAMP(0, 0);
   // ---- P0: X rows (all), CSR rows of the strip ----------------------------------------------------------------------
@@ -640,6 +672,15 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
           if (c < F4) Ximg[i * LDX + c] = (i < n && c < FIN) ? xr[u][cp] : 0.f;
         }
       }
+    }
+  }
+  // Reslap: the strip's rows of L_prev (wave il = row i0 + il), requested with the first round of loads
+  float lprv[2] = {0.f, 0.f};
+  if constexpr (RESLAP) {
+    if (a.L_prev != nullptr) {
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp)
+        if (64 * cp < n) lprv[cp] = a.L_prev[toff + (uint32_t)(min(i0 + wave, n - 1) * n + min(lane + 64 * cp, n - 1))];
     }
   }
   int csr_c[6] = {0, 0, 0, 0, 0, 0};
@@ -763,11 +804,86 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
 
   AGCN_STAMP(0, 3);
   // ---- P3: res_L[I, :], L[I, :] = lrelu(R) + L_orig ----------------------------------------------------------------
+  float ssR = 1.f, scR = 1.f, ssL = 0.f, scL = 1.f;
   {
     const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
     const float* L0d = !a.L0_dense ? nullptr
                                    : (a.L0_ld > 0 ? a.L0_dense + (int64_t)b * a.L0_ld * a.L0_ld : a.L0_dense + toff);
     const int i = i0 + wave;
+    if constexpr (RESLAP) {
+      // R rows of the strip (kept in registers), ||R||_F^2 of the whole graph -> scR   (graphconv_reslap.py:185)
+      float Rk[2] = {0.f, 0.f};
+      float part = 0.f;
+      if (i < n) {
+        const float si = s_vec[i];
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const int j = lane + 64 * cp;
+          if (j < n) {
+            float R = (i == j) ? 1.f : 0.f;
+            if (paper) R = R - (si * St[wave * ldt + j]) * s_vec[j];
+            Rk[cp] = R;
+            part += R * R;
+          }
+        }
+      }
+      ssR = paper ? coop_graph_sum(a, part, smem, coop_gs, xsc, me, ntm, wants, tid) : (float)n;   // (reference mode: R = I)
+      scR = clip_scale(ssR, 1.0f);
+      // R2 = lrelu(cn(R)) -> res_L; L_pre = R2 + L_orig + beta L_prev (:188-190) -> strip image (dense L_orig here, CSR below)
+      const bool has_prev = a.L_prev != nullptr;
+      const float beta = has_prev ? a.beta[0] : 0.f;
+      if (i < n) {
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const int j = lane + 64 * cp;
+          if (j < n) {
+            const float R2 = lrelu(Rk[cp] * scR, alpha);
+            a.res_L[toff + (uint32_t)(i * n + j)] = R2;
+            float v = R2;
+            if (L0d) v += L0d[(int64_t)i * l0ld + j];
+            if (has_prev) v = v + lprv[cp] * beta;
+            St[wave * ldt + j] = v;
+          }
+        }
+      }
+      lds_barrier();
+      if (a.L0_rowptr && tid < 16 && i0 + tid < n) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+          if (csr_p0 + u < csr_p1) St[tid * ldt + csr_c[u]] += csr_v[u];
+        for (int p = csr_p0 + 6; p < csr_p1; ++p) St[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+      }
+      lds_barrier();
+      // ||L_pre||_F^2 of the whole graph -> scL; second clip + leaky-ReLU (:194-198): L_pre out (reserve), La -> strip + 4th output
+      float part2 = 0.f;
+      float vk[2] = {0.f, 0.f};
+      if (i < n) {
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const int j = lane + 64 * cp;
+          if (j < n) {
+            vk[cp] = St[wave * ldt + j];
+            part2 += vk[cp] * vk[cp];
+          }
+        }
+      }
+      ssL = coop_graph_sum(a, part2, smem, coop_gs, xsc + COOP_MAX_MEMBERS, me, ntm, wants, tid);
+      scL = clip_scale(ssL, 1.0f);
+      if (i < n) {
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const int j = lane + 64 * cp;
+          if (j < n) {
+            const float La = lrelu(vk[cp] * scL, alpha);
+            const uint32_t o = toff + (uint32_t)(i * n + j);
+            a.sv_Lpre[o] = vk[cp];
+            a.L_sum[o] = La;
+            St[wave * ldt + j] = La;
+          }
+        }
+      }
+      lds_barrier();
+    } else {
     if (i < n) {
       const float si = s_vec[i];
 #pragma unroll
@@ -783,7 +899,9 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         }
       }
     }
+    }
   }
+  if constexpr (!RESLAP) {
   lds_barrier();
   if (a.L0_rowptr && tid < 16 && i0 + tid < n) {
 #pragma unroll
@@ -796,6 +914,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     const int i = i0 + wave;
     if (i < n)
       for (int j = lane; j < n; j += 64) a.L_sum[toff + (uint32_t)(i * n + j)] = St[wave * ldt + j];
+  }
   }
 
   AGCN_STAMP(0, 4);
@@ -879,10 +998,11 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     }
     if (tid == 0) {
       float* sc = a.sv_scal + 4 * b;
-      sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f;
+      if constexpr (RESLAP) { sc[0] = ssR; sc[1] = scR; sc[2] = ssL; sc[3] = scL; }
+      else { sc[0] = 1.f; sc[1] = 1.f; sc[2] = 0.f; sc[3] = 1.f; }
     }
   }
-  if (paper && tid == 0) __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((paper || RESLAP) && tid == 0) __hip_atomic_store(xep + me, (uint64_t)wants[me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   AGCN_STAMP(0, 6);
 }
 #endif
