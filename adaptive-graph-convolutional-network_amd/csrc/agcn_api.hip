@@ -170,11 +170,10 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   *graphs = *slabs = *dual_graphs = 0;
   const int B = host.info.B;
   // (reference mode: the backward has no n x n work to spread; the forward still has the similarity tile)
-  // SGC_LL_Reslap: members in both directions too (they exchange the graph-wide clip norms / inner products as well), no
-  // paired small graphs
+  // SGC_LL_Reslap: members in both directions too (they exchange the graph-wide clip norms / inner products as well)
   const bool reslap = d->variant == AGCN_SGC_LL_RESLAP;
   if (d->variant != AGCN_SGC_LL && !reslap) return;
-  static const int res_coop = [] { const char* e = std::getenv("AGCN_RESLAP_COOP"); return e ? std::atoi(e) : 1; }();   // bit 0 forward, bit 1 backward
+  static const int res_coop = [] { const char* e = std::getenv("AGCN_RESLAP_COOP"); return e ? std::atoi(e) : 3; }();   // bit 0 forward, bit 1 backward
   if (reslap && !((res_coop >> (backward ? 1 : 0)) & 1)) return;
   if ((d->mode != AGCN_MODE_PAPER && backward) || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
       fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
@@ -190,8 +189,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   const int member_budget = std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members());
   // (with two and more rounds of workgroups per CU the tail graph matters less than the extra workgroups cost:
   //  512 graphs: 6.0 M graphs/s without, 5.7 M with members for its one 70-node graph)
-  static const int dual_env = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
-  const int dual_on = reslap ? 0 : dual_env;
+  static const int dual_on = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
   // (never beyond DUAL_MAX_N: both halves of a paired workgroup must run the same barrier sequence, spec_forward.hip)
   static const int dual_max = [] {
     const char* e = std::getenv("AGCN_DUAL_MAX_N");
@@ -236,7 +234,8 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
 // reference-mode backward has no members), one 16-wave launch.
 void coop_reach(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host, size_t lim) {
   const AgcnPlanInfo& pi = host.info;
-  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 || d->mode != AGCN_MODE_PAPER || d->variant != AGCN_SGC_LL) return;
+  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 || d->mode != AGCN_MODE_PAPER ||
+      (d->variant != AGCN_SGC_LL && d->variant != AGCN_SGC_LL_RESLAP)) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || pi.B >= 1024 || pi.B < 2) return;
   int k = 0;

@@ -675,8 +675,20 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
 template <int FIN, int FOUT, int NW, bool FULL, bool RESLAP = false>
 __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMALL_OCC) : 4) void spec_backward_kernel(SgcArgs a, int first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if constexpr (RESLAP) {   // (no members, no paired graphs: one workgroup per graph)
-    spec_backward_body<FIN, FOUT, NW, false, true>(a, first + (int)blockIdx.x, smem);
+  if constexpr (RESLAP) {   // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
+    int blk = (int)blockIdx.x;
+    if constexpr (NW == NW_LARGE) {
+      if (blk < a.coop_slabs) {
+        coop_backward_member<FIN, FOUT, true>(a, blk, smem);
+        return;
+      }
+      blk -= a.coop_slabs;
+      if (blk >= a.plain_count) {
+        spec_backward_body<FIN, FOUT, NW_SMALL, true, true>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
+        return;
+      }
+    }
+    spec_backward_body<FIN, FOUT, NW, false, true>(a, first + blk, smem);
   } else if constexpr (FULL) {
     // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
     //       [parameter-gradient tiles: tail_tiles (spec_tail.h)]
@@ -726,14 +738,16 @@ size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout) {
 template <int FIN, int FOUT, int NW>
 static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (a.variant == AGCN_SGC_LL_RESLAP) {
-    if (a.coop_slabs > 0 || a.dual_pairs > 0) return fail(AGCN_EINVAL, "spec_backward: no cooperative layout for SGC_LL_Reslap");
+    if ((a.dual_pairs > 0 || a.coop_slabs > 0) && NW != spec::NW_LARGE) return fail(AGCN_EINVAL, "spec_backward: members / paired graphs need the 16-wave launch");
+    SgcArgs aa = a;
+    aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
     auto kern = &spec::spec_backward_kernel<FIN, FOUT, NW, false, true>;
     if (lds_bytes > 64 * 1024) {
       hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes));
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_bwd): %s", hipGetErrorString(e));
     }
     prof_begin(PK_SPEC_BWD, s);
-    hipLaunchKernelGGL(kern, dim3(count), dim3(64 * NW), lds_bytes, s, a, first);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(count + (NW == spec::NW_LARGE ? a.coop_slabs + a.dual_pairs : 0))), dim3(64 * NW), lds_bytes, s, aa, first);
     prof_end(s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_backward launch: %s", hipGetErrorString(e));

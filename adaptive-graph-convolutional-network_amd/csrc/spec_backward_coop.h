@@ -128,8 +128,14 @@ __device__ __forceinline__ uint64_t coop_pack(float v, uint32_t flag) {
 }
 
 // One member: slab `sl` of the plan's slab table.  1024 threads.
-template <int FIN, int FOUT>
+// RESLAP (SGC_LL_Reslap, paper mode): L is the forward's 4th output La (its COLUMN strip is loaded: La need not be symmetric);
+// between dLa = g_1 X_0^T + dL_sum and the pair passes sit the adjoints of the two clip + leaky-ReLU stages -- element-wise but
+// for two graph-wide inner products, which the members exchange as sums (coop_graph_sum).  Every element-wise quantity is
+// evaluated for (i, j) AND (j, i) by the thread that owns (row i of the strip, column j): the row strips of L_pre / L_prev /
+// dL_sum arrive as coalesced loads, the column strips as gathers, all in that thread's registers.
+template <int FIN, int FOUT, bool RESLAP = false>
 __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int sl, float* smem) {
+  __shared__ float coop_gs[8];
   constexpr int NW = 16, NT = 1024;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
@@ -145,7 +151,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
   const int me = i0 >> 4;                      // member index == this strip's row tile
   const bool relu = a.activation == AGCN_ACT_RELU;
-  const bool tail = a.tail != nullptr;         // (spec_tail.h)
+  const bool tail = !RESLAP && a.tail != nullptr;         // (spec_tail.h)
   const uint32_t tgen = tail ? tail_load(a.tail + TAIL_GEN) : 0u;
   if (tail && tid == 0) tail_started(a, tgen);
   float* red = smem;
@@ -168,6 +174,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const float alpha = a.alpha[0];
   uint64_t* xch = a.sv_xch + (sl - me) * 16;                        // this graph's slots (direction 0): row i at xch + i
   uint64_t* xep = a.sv_xch + COOP_MAX_MEMBERS * 16 + (sl - me);     // ... and its members' epoch words
+  uint64_t* xsc = a.sv_xch + COOP_SCAL_WORD + (sl - me);            // scalar sums, direction 0, kind 0; kind 1 COOP_MAX_MEMBERS on
   // Every member has an epoch word of its own (keyed by ITS slab index, like its 16 slots: a slot is only ever written
   // under one epoch counter, whatever graphs of whatever batches use it over time).  A member reads the epochs of all
   // members of its graph before it publishes anything and bumps its own when it is done -- by then it holds every
@@ -179,7 +186,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 0);
   // ---- M0: one round of loads ---------------------------------------------------------------------------------
   int csr_p0 = 0, csr_p1 = 0;
-  if (a.L0_rowptr && tid < n) {
+  if (!RESLAP && a.L0_rowptr && tid < n) {
     csr_p0 = a.L0_rowptr[row0 + tid];
     csr_p1 = a.L0_rowptr[row0 + tid + 1];
   }
@@ -215,6 +222,14 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       rr[cp] = 0.f;
       if (64 * cp < n) rr[cp] = a.sv_r[toff + (uint32_t)(i * n + min(lane + 64 * cp, n - 1))];
     }
+  }
+  // Reslap: the COLUMN strip of La (wave il = column i0 + il, lanes run over the rows k): LT[il][k] = La[k][i0 + il]
+  float lac[2] = {0.f, 0.f};
+  if constexpr (RESLAP) {
+    const int i = min(i0 + wave, n - 1);
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+      if (64 * cp < n) lac[cp] = a.L_sum[toff + (uint32_t)(min(lane + 64 * cp, n - 1) * n + i)];
   }
   const float s_own = a.sv_s[row0 + min(tid, n - 1)];
   int csr_c[6] = {0, 0, 0, 0, 0, 0};
@@ -254,6 +269,15 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 1);
 
   // ---- M1: L^T strip  LT[il][k] = lrelu(R_k,i) + L_orig[k][i],  R_ki = delta - (s_k S) s_i  (the forward's operand order)
+  if constexpr (RESLAP) {
+    const int i = i0 + wave;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int k = lane + 64 * cp;
+      if (k < n4) LT[wave * ldt + k] = (i < n && k < n) ? lac[cp] : 0.f;
+    }
+  }
+  if constexpr (!RESLAP)
   {
     const int l0ld = a.L0_ld > 0 ? a.L0_ld : n;
     const float* L0d = !a.L0_dense ? nullptr
@@ -277,7 +301,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     }
   }
   lds_barrier();
-  if (a.L0_rowptr && tid < n) {      // CSR row tid: its entries in the columns of the strip
+  if (!RESLAP && a.L0_rowptr && tid < n) {      // CSR row tid: its entries in the columns of the strip
 #pragma unroll
     for (int u = 0; u < 6; ++u)
       if (csr_p0 + u < csr_p1 && csr_c[u] >= i0 && csr_c[u] < i0 + 16) LT[(csr_c[u] - i0) * ldt + tid] += csr_v[u];
@@ -364,6 +388,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 4);
 
   // ---- M4: dL row strip (g_1[I] X_0^T) and column strip ((g_1 X_0[I]^T)^T = X_0[I] g_1^T);  Z rows requested --------
+  float lpr[2] = {0.f, 0.f}, lpc[2] = {0.f, 0.f}, lpv[2] = {0.f, 0.f}, dlsr[2] = {0.f, 0.f}, dlsc[2] = {0.f, 0.f};
   {
     const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
 #pragma unroll
@@ -373,6 +398,21 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       for (int cp = 0; cp < CP; ++cp) {
         xzr[u][cp] = 0.f;
         if (u < rpw) xzr[u][cp] = Zg[i * FIN + min(lane + 64 * cp, FIN - 1)];
+      }
+    }
+    if constexpr (RESLAP) {      // the strips of the clip adjoints (consumed in M5), requested with the Z rows
+      const bool has_prev = a.L_prev != nullptr && a.dL_prev != nullptr;
+      const int i = min(i0 + wave, n - 1);
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        if (64 * cp < n) {
+          const int j = min(lane + 64 * cp, n - 1);
+          const uint32_t oij = toff + (uint32_t)(i * n + j), oji = toff + (uint32_t)(j * n + i);
+          lpr[cp] = a.sv_Lpre[oij];
+          lpc[cp] = a.sv_Lpre[oji];
+          if (has_prev) lpv[cp] = a.L_prev[oij];
+          if (a.dL_sum) { dlsr[cp] = a.dL_sum[oij]; dlsc[cp] = a.dL_sum[oji]; }
+        }
       }
     }
     int ta, tb;
@@ -406,7 +446,88 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 
   AGCN_STAMP(5, 5);
   // ---- M5: pass 1 over the strip's rows (wave il = row i0 + il): dalpha, ds_i -> dd_i, published to the other members
-  float dalpha_part = 0.f;
+  float dalpha_part = 0.f, dbeta_part = 0.f;
+  float dlpk[2] = {0.f, 0.f};
+  if constexpr (RESLAP) {
+    // adjoints of  La = lrelu(cn(Lpre)),  Lpre = R2 + L_orig + beta L_prev,  R2 = lrelu(cn(R))   (graphconv_reslap.py:184-198),
+    // for (i, j) and (j, i); the strips DLr / DLc hold g_1 X_0^T and become dR_ij / dR_ji
+    const float* sc = a.sv_scal + 4 * b;
+    const float ssR = sc[0], scR = sc[1], ssL = sc[2], scL = sc[3];
+    const float invL = 1.0f / sqrtf(ssL), invR = 1.0f / sqrtf(ssR);
+    const bool clipL = invL <= 1.0f, clipR = invR <= 1.0f;   // TF MinimumGrad: ties take the norm branch
+    const bool has_prev = a.L_prev != nullptr && a.dL_prev != nullptr;
+    const float beta = has_prev ? a.beta[0] : 0.f;
+    const int i = i0 + wave;
+    const bool iv = i < n;
+    const float si = s_vec[min(i, n4 - 1)];
+    float dij[2] = {0.f, 0.f}, dji[2] = {0.f, 0.f};     // dLc, then dLpre, dR1, dR
+    float dot_part = 0.f;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int j = lane + 64 * cp;
+      if (iv && j < n) {
+        const float dLa_ij = DLr[wave * ldt + j] + dlsr[cp], dLa_ji = DLc[wave * ldt + j] + dlsc[cp];
+        const float Lc_ij = lpr[cp] * scL, Lc_ji = lpc[cp] * scL;
+        dalpha_part += dLa_ij * fminf(Lc_ij, 0.f);
+        dij[cp] = dLa_ij * lrelu_grad(Lc_ij, alpha);
+        dji[cp] = dLa_ji * lrelu_grad(Lc_ji, alpha);
+        dot_part += dij[cp] * lpr[cp];
+      }
+    }
+    const float dot = coop_graph_sum(a, dot_part, red, coop_gs, xsc, me, ntm, wants, tid);
+    const float k3 = clipL ? dot * invL * invL * invL : 0.f;
+    float Rij[2] = {0.f, 0.f}, Rji[2] = {0.f, 0.f};
+    float dotR_part = 0.f;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int j = lane + 64 * cp;
+      if (iv && j < n) {
+        if (clipL) {
+          dij[cp] = dij[cp] * invL - lpr[cp] * k3;
+          dji[cp] = dji[cp] * invL - lpc[cp] * k3;
+        }
+        if (has_prev) {
+          dbeta_part += dij[cp] * lpv[cp];
+          dlpk[cp] = dij[cp] * beta;      // dL_prev[i][j]: stored with everything else at the end (no store in front of a load)
+        }
+        const float sj = s_vec[j];
+        const float Sv = (i == j) ? 0.f : fast_exp_neg(RS[wave * ldt + j]);
+        const float dlt = (i == j) ? 1.f : 0.f;
+        Rij[cp] = dlt - (si * Sv) * sj;
+        Rji[cp] = dlt - (sj * Sv) * si;
+        const float R1ij = Rij[cp] * scR, R1ji = Rji[cp] * scR;
+        dalpha_part += dij[cp] * fminf(R1ij, 0.f);
+        dij[cp] = dij[cp] * lrelu_grad(R1ij, alpha);          // dR1
+        dji[cp] = dji[cp] * lrelu_grad(R1ji, alpha);
+        dotR_part += dij[cp] * Rij[cp];
+      }
+    }
+    const float dotR = coop_graph_sum(a, dotR_part, red, coop_gs, xsc + COOP_MAX_MEMBERS, me, ntm, wants, tid);
+    const float k3R = clipR ? dotR * invR * invR * invR : 0.f;
+    float dsum = 0.f;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int j = lane + 64 * cp;
+      if (j < n4) {
+        float dRij = 0.f, dRji = 0.f;
+        if (iv && j < n) {
+          dRij = clipR ? dij[cp] * invR - Rij[cp] * k3R : dij[cp];
+          dRji = clipR ? dji[cp] * invR - Rji[cp] * k3R : dji[cp];
+          const float sj = s_vec[j];
+          const float Sv = (i == j) ? 0.f : fast_exp_neg(RS[wave * ldt + j]);
+          dsum += (-dRij * Sv) * sj + (-dRji * Sv) * sj;         // P_ij s_j + P_ji s_j, P = dA . S, dA = -dR
+        }
+        DLr[wave * ldt + j] = dRij;
+        DLc[wave * ldt + j] = dRji;
+      }
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0 && iv) {
+      const float ddk = degree_grad(s_vec[i], dsum);   // dd_k = -1/2 s_k^3 ds_k
+      ddv[i] = ddk;
+      __hip_atomic_store(xch + i, coop_pack(ddk, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else
   {
     const int i = i0 + wave;
     float dsum = 0.f;
@@ -460,8 +581,9 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
             const float Sv = fast_exp_neg(rv);
             const float sj = s_vec[j];
             const float Rij = -((si * Sv) * sj), Rji = -((sj * Sv) * si);
-            const float dAij = -(DLr[wave * ldt + j] * lrelu_grad(Rij, alpha));
-            const float dAji = -(DLc[wave * ldt + j] * lrelu_grad(Rji, alpha));
+            // (Reslap: the strips hold dR already)
+            const float dAij = -(RESLAP ? DLr[wave * ldt + j] : DLr[wave * ldt + j] * lrelu_grad(Rij, alpha));
+            const float dAji = -(RESLAP ? DLc[wave * ldt + j] : DLc[wave * ldt + j] * lrelu_grad(Rji, alpha));
             if (Sv != 0.f && rv > 0.f) {
               const float dr_ij = -Sv * (dAij * si * sj + ddv[j]);
               const float dr_ji = -Sv * (dAji * sj * si + ddi);
@@ -555,14 +677,27 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       if (c < FOUT) a.ws_Gp[(int64_t)(row0 + i0 + wave) * FOUT + c] = gpown[cp];
     }
   }
+  if constexpr (RESLAP) {
+    if (a.L_prev != nullptr && a.dL_prev != nullptr) {
+      const int i = i0 + wave;
+      if (i < n) {
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp)
+          if (lane + 64 * cp < n) a.dL_prev[toff + (uint32_t)(i * n + lane + 64 * cp)] = dlpk[cp];
+      }
+      if (i0 == 0 && tid < (int)((uint32_t)(a.tile_off[b + 1] - a.tile_off[b]) - (uint32_t)(n * n)))
+        a.dL_prev[toff + (uint32_t)(n * n) + tid] = 0.f;   // alignment floats behind the tile
+    }
+  }
   const float da = block_sum(dalpha_part, red);
+  const float db = RESLAP ? block_sum(dbeta_part, red) : 0.f;
   if (tid == 0) {
     if (tail) {
       tail_store_f(a.ws_pg + 2 * (a.B + sl), da);
       if (i0 == 0) tail_store_f(a.ws_pg + 2 * b, 0.f);
     } else {
       a.ws_pg[2 * (a.B + sl) + 0] = da;
-      a.ws_pg[2 * (a.B + sl) + 1] = 0.f;
+      a.ws_pg[2 * (a.B + sl) + 1] = db;
       if (i0 == 0) {
         a.ws_pg[2 * b + 0] = 0.f;
         a.ws_pg[2 * b + 1] = 0.f;

@@ -742,10 +742,12 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach)
 def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode, reach):
     """The SGC_LL_Reslap twin of the test above (every convolution of ResAGCN.py:79-92 / DenseAGCN.py:112-146 is one): an
     HIV-shaped 256-graph batch, 64 -> 64, with a few molecules beyond the one-workgroup kernels' 96 nodes, a previous Laplacian
-    and a gradient arriving on L_sum.  SGC_LL_Reslap has no member / slab flavour yet: such a batch leaves the specialised
-    kernels WHOLE for the general per-graph path (mixed dispatch, fused_mode 3: the oversized molecules alone).  Whatever
-    runs, EVERY graph's Y / res_W / res_L / L_sum and EVERY gradient (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) must
-    match the float64 oracle; the kernels that ran are asserted so that a change of dispatch shows up here."""
+    and a gradient arriving on L_sum.  within_members (largest molecule <= 128 atoms, paper mode): the specialised kernels
+    take the batch, the oversized molecules spread over member workgroups (which exchange the graph-wide clip norms and inner
+    products).  Beyond that (or reference mode: its backward has no members) SGC_LL_Reslap has no slab flavour: the batch
+    leaves the specialised kernels WHOLE for the general per-graph path.  Whatever runs, EVERY graph's Y / res_W / res_L /
+    L_sum and EVERY gradient (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) must match the float64 oracle; the kernels
+    that ran are asserted so that a change of dispatch shows up here."""
     Fin, Fout, K = 64, 64, 2
     for seed in range(40, 400):
         nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
@@ -779,9 +781,12 @@ def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode,
             seen[fused_mode] = st.kernel_names()
         finally:
             lib.agcn_set_fused_mode(1)
-    # default dispatch: nothing specialised (no Reslap flavour reaches beyond 96 nodes), the per-graph kernels do all of it
-    assert "spec_forward_kernel" not in seen[1][0] and "sgc_forward_kernel" in seen[1][0], seen
-    assert "spec_backward_kernel" not in seen[1][1] and "sgc_backward_kernel" in seen[1][1], seen
+    if reach == "within_members" and mode == orc.PAPER:
+        assert seen[1][0] == "spec_forward_kernel" and seen[1][1] == "spec_backward_kernel", seen
+    else:
+        # nothing specialised (no Reslap flavour reaches beyond 128 nodes), the per-graph kernels do all of it
+        assert "spec_forward_kernel" not in seen[1][0] and "sgc_forward_kernel" in seen[1][0], seen
+        assert "spec_backward_kernel" not in seen[1][1] and "sgc_backward_kernel" in seen[1][1], seen
     print("Reslap, oversized molecules:", seen)
 
 
@@ -1803,7 +1808,8 @@ def test_epoch_pipeline_gives_the_plain_loop_results(amd):
 def test_reslap_takes_the_specialised_kernels(amd, mode, Fin, Fout):
     """SGC_LL_Reslap at the ResLap networks' widths (ResAGCN.py:79-92, Point_AGCN.py:37-71: 64 -> 64, 128 -> 64, ...): a
     256-graph Tox21-shaped batch with a previous Laplacian and an upstream gradient of L_sum must run on the specialised
-    kernels' Reslap flavour (kernel names asserted) and match the float64 oracle on every graph and every gradient
+    kernels' Reslap flavour (kernel names asserted) -- its largest graphs on member workgroups that exchange the graph-wide
+    clip norms / inner products (dispatch asserted) -- and match the float64 oracle on every graph and every gradient
     (dbeta, dL_prev included)."""
     K, B = 2, 256
     sb = orc.synth_batch(321, B)
@@ -1824,6 +1830,11 @@ def test_reslap_takes_the_specialised_kernels(amd, mode, Fin, Fout):
                        dL_sum=torch.from_numpy(pack_tiles_np(dLs, gb.plan)).to(DEV))
     names = st.kernel_names()
     assert "spec_forward_kernel" in names[0] and "spec_backward_kernel" in names[1], names
+    # the largest graphs spread over member workgroups (forward: both modes; backward: paper mode), small graphs paired to
+    # make room for them (include/agcn.h: agcn_sgc_ll_dispatch_info)
+    info = amd._ffi.dispatch_info(layer, gb)
+    assert info[2] > 0 and info[3] >= 3 * info[2], info
+    assert (info[5] > 0) == (mode == orc.PAPER), info
     out = run_packed(amd, DEV, ns, X, sb["csr"], p, G, Fin, Fout, K, mode, orc.SGC_LL_RESLAP, Lp, dLs)
     caches, tot, tot32 = oracle_pair(X, sb["L0"], p, K, mode, orc.SGC_LL_RESLAP, G, Lp, dLs, Y_got=np.concatenate(out["Y"]))
     compare_with_oracle(out, caches, tot, orc.SGC_LL_RESLAP, mode, K, has_prev=True, tot32=tot32)

@@ -25,10 +25,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     np.savez(sys.argv[4], **{k: np.stack(v) for k, v in out_all.items()})
 else:
     for mode in ("reference", "paper"):
-        for coop in ("0", "1"):
+        for coop in ("0", "3"):
             env = dict(os.environ, AGCN_RESLAP_COOP=coop)
             subprocess.check_call([sys.executable, __file__, "child", mode, "12", "/tmp/dbg_%s_%s.npz" % (mode, coop)], env=env)
-        a, b = np.load("/tmp/dbg_%s_0.npz" % mode), np.load("/tmp/dbg_%s_1.npz" % mode)
+        a, b = np.load("/tmp/dbg_%s_0.npz" % mode), np.load("/tmp/dbg_%s_3.npz" % mode)
         for k in a.files:
             x, y = a[k], b[k]
             d = np.abs(x - y)
