@@ -262,10 +262,16 @@ def test_dispatch_table(amd):
     amd._ffi.lib().agcn_set_spec_tail(prev_tail)
     assert _dispatch(amd, n, 128, 128, 1)["path"] == 16        # (the members' LDS plan does not fit at this width)
     assert _dispatch(amd, n256, 80, 64, 1)["path"] == 4
-    # SGC_LL_Reslap at the specialised widths: the specialised kernels' Reslap flavour, one workgroup per graph (no members,
-    # no pairs); other widths: the general fused kernels
-    d = _dispatch(amd, n256, 64, 64, 1, variant=1)
-    assert d["path"] == 7 and d["f_members"] == d["b_members"] == d["f_paired"] == d["b_paired"] == 0
+    # SGC_LL_Reslap at the specialised widths: the specialised kernels' Reslap flavour with the same layout as SGC_LL (the largest
+    # graphs on members, small graphs paired to make room; reference mode: members in the forward only; a 120-node molecule
+    # within the members' reach); other widths: the general fused kernels
+    d, d0 = _dispatch(amd, n256, 64, 64, 1, variant=1), _dispatch(amd, n256, 64, 64, 1)
+    assert d["path"] == 7 and d["f_members"] == d["b_members"] == d0["f_members"] > 40 and d["f_paired"] == d["b_paired"] == d0["f_paired"] > 0
+    d = _dispatch(amd, n256, 64, 64, 0, variant=1)
+    assert d["path"] == 7 and d["f_members"] > 40 and d["b_members"] == 0
+    d = _dispatch(amd, n, 64, 64, 1, variant=1)
+    assert d["path"] == 7 and d["f_members"] >= 8 and d["b_members"] == d["f_members"]
+    assert _dispatch(amd, n, 64, 64, 0, variant=1)["path"] == 32   # (reference mode, 120 nodes: the general per-graph kernels)
     assert _dispatch(amd, n256, 80, 64, 1, variant=1)["path"] == 4
     assert _dispatch(amd, n256, 75, 64, 1, K=3)["path"] == 32
     del rs
