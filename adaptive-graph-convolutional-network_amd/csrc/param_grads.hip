@@ -393,22 +393,24 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
       const unsigned long long t0 = wall_clock64();
       bool ok = true;
       float tot = 0.f;
-      if (S > 1) {        // (S <= 8: at most seven granules per element)
-        uint64_t w[7];
+      // (S <= 8: seven granules per element, one round; S = 16: two rounds of eight -- the registers of fifteen loads in flight
+      //  would cost the second resident workgroup)
+      for (int u0 = 0; u0 < S - 1 && ok; u0 += 8) {
+        uint64_t w[8];
         for (;;) {
 #pragma unroll
-          for (int u = 0; u < 7; ++u)
-            w[u] = __hip_atomic_load(base + min(u, S - 2) * 512 + toff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int u = 0; u < 8; ++u)
+            w[u] = __hip_atomic_load(base + min(u0 + u, S - 2) * 512 + toff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           bool all = true;
 #pragma unroll
-          for (int u = 0; u < 7; ++u) all = all && ((uint32_t)(w[u] >> 32) == 1u);
+          for (int u = 0; u < 8; ++u) all = all && ((uint32_t)(w[u] >> 32) == 1u);
           if (all) break;
           if (wall_clock64() - t0 >= (unsigned long long)a.ticks) { ok = false; break; }
           __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int u = 0; u < 7; ++u)
-          if (u < S - 1) tot += __uint_as_float((uint32_t)w[u]);
+        for (int u = 0; u < 8; ++u)
+          if (u0 + u < S - 1) tot += __uint_as_float((uint32_t)w[u]);
       }
       AGCN_STAMP(7, 3);
       tot += v;
@@ -466,15 +468,21 @@ void pg_split(int rows, int nt, int* rows_per_wave, int* S) {
 int pg_mode() { return agcn_get_param_grad_onepass(); }
 }  // namespace
 
-// the tagged hand-off serves the batches below 8k rows: 16-row tiles, EIGHT row splits (one per XCD) of 16 waves x rpw rows each.
+// the tagged hand-off serves the batches below 8k rows: 16-row tiles, eight or sixteen row splits (split % 8 = its XCD) of 16 waves
+// x rpw rows each.
 // (32 x 32 tiles of 32 consecutive features of one Chebyshev term -- half the cache lines per output, one workgroup per CU --
 //  measured equal at 75 -> 64 and slower at 128 -> 64, 67.1 against 62.9 us per step: profiles/EXPERIMENTS.md)
 static bool pg_tagged_shape(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper, int* nt_out, int* S_out, int* rpw_out) {
   static const int xcd_force = [] { const char* e = std::getenv("AGCN_PG_XCD"); return e ? std::atoi(e) : -1; }();
   if (rows < 1 || rows >= 8192 || xcd_force > 0 || pg_tf(rows) != 16) return false;
-  const int rpw = (rows + 127) / 128;                       // rows per wave: any number (the k-steps of 4 rows are masked)
+  // rows per wave: any number (the k-steps of 4 rows are masked), at most 40 = ONE round of operand loads (10 k-steps in
+  // flight per lane); from 5121 rows on two splits per XCD (HIV-shaped batches, ~6.4 k rows: 50 rows per wave in two rounds
+  // measured 1 % SLOWER than the arrival-counter kernel, profiles/EXPERIMENTS.md)
+  static const int s_force = [] { const char* e = std::getenv("AGCN_PG_TAG_SPLITS"); return e ? std::atoi(e) : 0; }();
+  const int s_target = (s_force == 8 || s_force == 16) ? s_force : (rows <= 5120 ? 8 : 16);
+  const int rpw = (rows + 16 * s_target - 1) / (16 * s_target);
   *nt_out = pg_tiles(Fin, Fout, K, paper != 0, 16);
-  *S_out = (rows + 16 * rpw - 1) / (16 * rpw);              // <= 8
+  *S_out = (rows + 16 * rpw - 1) / (16 * rpw);              // <= s_target
   *rpw_out = rpw;
   return true;
 }

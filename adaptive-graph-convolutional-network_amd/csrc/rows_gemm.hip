@@ -240,6 +240,14 @@ __global__ __launch_bounds__(NTHR) void rows_gemm_kernel(RowsGemmArgs a) {
       }
     }
   }
+  if (MODE == RG_FILTER_BWD && a.ztag_count16 > 0) {
+    // granules of the parameter-gradient kernel behind this launch: 16-byte agent-scope stores (spec_kernels.h: zero_tags)
+    f32x4* zp = reinterpret_cast<f32x4*>(a.ztag_ptr);
+    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int step = (int)(gridDim.x * gridDim.y * blockDim.x);
+    for (int e = (int)((blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x); e < a.ztag_count16; e += step)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(zp + e), "v"(z) : "memory");
+  }
   AGCN_STAMP(MODE == RG_PROJECT ? 0 : MODE == RG_FILTER ? 2 : MODE == RG_FILTER_BWD ? 3 : MODE == RG_DENSE ? 6 : 5, 5);
 }
 

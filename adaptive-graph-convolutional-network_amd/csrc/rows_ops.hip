@@ -216,7 +216,12 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   g.Kd = desc->Fout; g.N = desc->Fin;
   g.A0 = dY; g.lda0 = desc->ldy; g.Yact = Y; g.ldy = desc->ldy; g.Bm = W;
   g.Out0 = dX; g.ldo0 = desc->ldx; g.Gp = Gp; g.scale = scale;
-  g.zero_ptr = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &g.zero_count);
+  // the hand-off of the parameter-gradient kernel behind it: tagged granules cleared by this launch's workgroups (general
+  // kernel only: the narrow kernels of few-column products keep the arrival counters), else arrival counters
+  int32_t n16 = 0;
+  float* tags = (desc->Fin > 8) ? param_grad_tag_region(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &n16) : nullptr;
+  if (tags != nullptr) { g.ztag_ptr = tags; g.ztag_count16 = n16; }
+  else g.zero_ptr = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &g.zero_count);
   rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
   if (rc != AGCN_OK) return rc;
 
@@ -226,7 +231,9 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   pa.n_chunks = w.n_chunks;
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = 0; pa.part_stride = w.part_stride;
-  pa.X = X; pa.Gp = Gp; pa.part = w.part; pa.part_floats = w.part_floats; pa.counters_zeroed = 1;
+  pa.X = X; pa.Gp = Gp; pa.part = w.part; pa.part_floats = w.part_floats;
+  pa.counters_zeroed = tags ? 0 : 1; pa.tags_zeroed = tags ? 1 : 0;
+  pa.dev_status = current_device_info().status_word; pa.ticks = agcn_get_coop_timeout_ticks();
   pa.dweight = dW; pa.dbias = dbias ? dbias : w.dbias;
   rc = launch_param_grads(pa, hip_stream);
   if (rc != AGCN_OK || !scale) return rc;

@@ -122,6 +122,8 @@ struct RowsGemmArgs {
   const int32_t* row_graph; // [rows]
   int32_t* zero_ptr;        // RG_FILTER_BWD: counters to zero for the parameter-gradient kernel that follows
   int32_t zero_count;
+  float* ztag_ptr;          // ... or the granules of its tagged hand-off (param_grad_tagged_kernel): ztag_count16 16-byte units,
+  int32_t ztag_count16;     // a slice per workgroup, behind everything else it does (big_n == 0 only)
   int32_t kc;               // K chunk staged in LDS (set by the launcher)
   int32_t nt;               // column tiles per workgroup (set by the launcher)
 };
