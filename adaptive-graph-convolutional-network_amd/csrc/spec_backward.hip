@@ -628,7 +628,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
               else AGCN_ST(8, &dXg[(int64_t)i * a.lddx + f], dxacc[sl][i4] + xacc[sl][i4]);
               if (paper) {
                 if (tail) tail_store_f(a.ws_dZ + (int64_t)(row0 + i) * FIN + f, zacc[sl][i4]);
-                else a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[sl][i4];
+                else AGCN_ST(8, &a.ws_dZ[(int64_t)(row0 + i) * FIN + f], zacc[sl][i4]);
               }
             }
           }
@@ -642,7 +642,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
 #pragma unroll
       for (int cp = 0; cp < CPO; ++cp) {
         const int c = lane + 64 * cp;
-        if (i < n && c < FOUT) a.ws_Gp[(int64_t)(row0 + i) * FOUT + c] = gpv[u][cp];
+        if (i < n && c < FOUT) AGCN_ST(8, &a.ws_Gp[(int64_t)(row0 + i) * FOUT + c], gpv[u][cp]);
       }
     }
     }

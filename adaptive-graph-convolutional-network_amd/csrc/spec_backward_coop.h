@@ -663,9 +663,9 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
         const int i = i0 + 4 * q + i4;
         if (i < n) {
           if (a.feat_bf16) bf16_store(a.dX, (int64_t)(row0 + i) * a.lddx + f, dxacc[i4] + acc[i4]);
-          else dXg[(int64_t)i * a.lddx + f] = dxacc[i4] + acc[i4];
+          else AGCN_ST(8, &dXg[(int64_t)i * a.lddx + f], dxacc[i4] + acc[i4]);
           if (tail) tail_store_f(a.ws_dZ + (int64_t)(row0 + i) * FIN + f, zacc[i4]);
-          else a.ws_dZ[(int64_t)(row0 + i) * FIN + f] = zacc[i4];
+          else AGCN_ST(8, &a.ws_dZ[(int64_t)(row0 + i) * FIN + f], zacc[i4]);
         }
       }
     }
@@ -674,7 +674,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 #pragma unroll
     for (int cp = 0; cp < CPO; ++cp) {
       const int c = lane + 64 * cp;
-      if (c < FOUT) a.ws_Gp[(int64_t)(row0 + i0 + wave) * FOUT + c] = gpown[cp];
+      if (c < FOUT) AGCN_ST(8, &a.ws_Gp[(int64_t)(row0 + i0 + wave) * FOUT + c], gpown[cp]);
     }
   }
   if constexpr (RESLAP) {
@@ -853,7 +853,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         if (rt == me) {
 #pragma unroll
           for (int i4 = 0; i4 < 4; ++i4)
-            if (ib + i4 < n) Zg[(ib + i4) * FIN + c] = acc[i4];
+            if (ib + i4 < n) AGCN_ST(2, &Zg[(ib + i4) * FIN + c], acc[i4]);
         }
       }
     }
@@ -928,8 +928,8 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         const int j = lane + 64 * cp;
         if (j < n) {
           const uint32_t o = toff + (uint32_t)(i * n + j);
-          a.res_W[o] = skeep[cp];
-          if (paper) a.sv_r[o] = rkeep[cp];
+          AGCN_ST(1, &a.res_W[o], skeep[cp]);
+          if (paper) AGCN_ST(2, &a.sv_r[o], rkeep[cp]);
         }
       }
       if (lane == 0) a.sv_s[row0 + i] = paper ? sd_keep : 0.f;
@@ -973,7 +973,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
           const int j = lane + 64 * cp;
           if (j < n) {
             const float R2 = lrelu(Rk[cp] * scR, alpha);
-            a.res_L[toff + (uint32_t)(i * n + j)] = R2;
+            AGCN_ST(1, &a.res_L[toff + (uint32_t)(i * n + j)], R2);
             float v = R2;
             if (L0d) v += L0d[(int64_t)i * l0ld + j];
             if (has_prev) v = v + lprv[cp] * beta;
@@ -1011,8 +1011,8 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
           if (j < n) {
             const float La = lrelu(vk[cp] * scL, alpha);
             const uint32_t o = toff + (uint32_t)(i * n + j);
-            a.sv_Lpre[o] = vk[cp];
-            a.L_sum[o] = La;
+            AGCN_ST(2, &a.sv_Lpre[o], vk[cp]);
+            AGCN_ST(1, &a.L_sum[o], La);
             St[wave * ldt + j] = La;
           }
         }
@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
           float R = (i == j) ? 1.f : 0.f;
           if (paper) R = R - (si * S) * s_vec[j];
           const float R2 = lrelu(R, alpha);
-          a.res_L[toff + (uint32_t)(i * n + j)] = R2;
+          AGCN_ST(1, &a.res_L[toff + (uint32_t)(i * n + j)], R2);
           St[wave * ldt + j] = R2 + (L0d ? L0d[(int64_t)i * l0ld + j] : 0.f);
         }
       }
@@ -1104,7 +1104,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         float v = acc[i4] + bias;
         if (relu) v = fmaxf(v, 0.f);
         if (a.feat_bf16) bf16_store(a.Y, (int64_t)(row0 + i) * a.ldy + c, v);
-        else Yg[(int64_t)i * a.ldy + c] = v;
+        else AGCN_ST(4, &Yg[(int64_t)i * a.ldy + c], v);
       }
     }
   }
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
 #pragma unroll
     for (int cp = 0; cp < CP; ++cp) {
       const int c = lane + 64 * cp;
-      if (c < FIN) Xo[c] = X1s[wave * LDX + c];
+      if (c < FIN) AGCN_ST(2, &Xo[c], X1s[wave * LDX + c]);
     }
     if (a.feat_bf16) {   // ... and, bf16 features, the widened X rows of the strip (spec_kernels.h)
       float* X0o = a.sv_X0 + (int64_t)(row0 + i0 + wave) * FIN;

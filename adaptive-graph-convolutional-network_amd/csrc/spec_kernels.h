@@ -20,9 +20,19 @@
 #ifndef AGCN_NT
 #define AGCN_NT 0
 #endif
+// -DAGCN_WT=<bits>: the same classes as agent-scope (write-through) stores -- they leave the XCD's L2 as they are issued instead of
+// at the end-of-kernel write-back, and the next kernel finds them in memory.  Default 8: the backward's dX and its hand-off to
+// the parameter-gradient kernel (Gp, dZ) -- measured on the headline, A/B/A/B on one box: backward 18.9 -> 18.3 us, the
+// parameter-gradient kernel behind it 9.55 -> 9.2 us, step 43.4-43.6 -> 42.4-42.6 us.  The other classes do not pay: Y (4) costs
+// the forward 0.35 us and gains the backward nothing (12: 43.1 us), res_W / res_L (1) and the reserve (2) are neutral to slightly
+// negative (3: 43.6, 9: 42.7, 10: 42.7-42.8, 7: 45.1, 15: 43.6-43.8 us).
+#ifndef AGCN_WT
+#define AGCN_WT 8
+#endif
 #define AGCN_ST(bit, ptr, val)                                          \
   do {                                                                  \
-    if ((AGCN_NT) & (bit)) __builtin_nontemporal_store((val), (ptr));   \
+    if ((AGCN_WT) & (bit)) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
+    else if ((AGCN_NT) & (bit)) __builtin_nontemporal_store((val), (ptr));   \
     else *(ptr) = (val);                                                \
   } while (0)
 
