@@ -87,6 +87,7 @@ class StagedBatch(C.Structure):
 MODE = {"reference": 0, "paper": 1}
 VARIANT = {"SGC_LL": 0, "SGC_LL_Reslap": 1}
 ACT = {None: 0, "linear": 0, "relu": 1, "tanh": 2}
+RESERVE_HEADER_BYTES = 65536      # include/agcn.h: AGCN_RESERVE_HEADER_BYTES (what must be zero when a reserve is first used)
 
 # every symbol include/agcn.h declares (tests/test_abi.py checks the two lists agree)
 SYMBOLS = [

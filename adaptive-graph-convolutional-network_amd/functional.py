@@ -241,9 +241,11 @@ class SgcLLFunction(torch.autograd.Function):
         res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         L_sum = torch.empty(plan.tile_elems if cfg.lsum else 0, dtype=torch.float32, device=dev)
         desc, rbytes, wbytes, _ = _sizes(plan, cfg, ldx, ldy)
-        # (zero-filled: the reserve starts with the exchange header of the cooperative kernels, which must be zero when a
-        # reserve is first used -- include/agcn.h)
-        reserve = torch.zeros(rbytes, dtype=torch.uint8, device=dev)
+        # (the reserve starts with the exchange header of the cooperative kernels, which must be zero when a reserve is first
+        # used -- include/agcn.h: AGCN_RESERVE_HEADER_BYTES; only that: at point-cloud sizes the reserve holds n x n tiles,
+        # and zero-filling all of it was 75 us per layer call)
+        reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
+        reserve[:min(rbytes, _ffi.RESERVE_HEADER_BYTES)].zero_()
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         gb = _gbatch(batch, X, L_prev if reslap else None, cfg.prev_sym)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))

@@ -31,6 +31,14 @@ def test_exports_every_declared_symbol(amd):
     assert lib.agcn_version() == 104
 
 
+def test_header_constants_match_the_c_header(amd):
+    """Constants the Python side restates from include/agcn.h."""
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "agcn.h")).read()
+    m = re.search(r"#define\s+AGCN_RESERVE_HEADER_BYTES\s+(\d+)", text)
+    assert m and int(m.group(1)) == amd._ffi.RESERVE_HEADER_BYTES
+
+
 def test_plan_packed(amd):
     n = np.array([5, 3, 9, 4, 9], dtype=np.int32)
     p = amd.Plan(n)

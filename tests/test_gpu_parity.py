@@ -625,6 +625,47 @@ def test_graph_gather_golden(amd, act):
     assert_close(np.stack([to_np(x.grad) for x in Xl]), g["dX"], FEATURE_RTOL, "gather dX")
 
 
+@pytest.mark.parametrize("layout", ["packed", "padded"])
+@pytest.mark.parametrize("act", ["tanh", "relu", "linear"])
+def test_graph_gather_large_graphs(amd, act, layout):
+    """GraphGatherMol on graphs of hundreds of nodes (the point-cloud network's readout: graphgather.py:40-77 on clouds of 1024
+    points) takes the kernels that split a graph's rows over the waves of a workgroup (csrc/gather.hip): ragged sizes, packed
+    rows and the reference's padded lists (pad rows must not count and get zero gradient), against a float64 sum."""
+    rs = np.random.RandomState(77)
+    ns, F = [1024, 300, 777, 16, 1], 200
+    Xs = [(rs.randn(n, F) * 0.05).astype(np.float32) for n in ns]
+    G = rs.randn(len(ns), F).astype(np.float32)
+    layer = amd.GraphGatherMol(len(ns), activation=act)
+    if layout == "packed":
+        plan = amd.Plan(np.asarray(ns, np.int32), 0, DEV)
+        Xt = torch.from_numpy(np.concatenate(Xs, 0)).to(DEV).requires_grad_(True)
+        gb = amd.GraphBatch(plan, Xt)
+        out = layer({"node_features": Xt, "graph_batch": gb})
+    else:
+        ma = max(ns)
+        pad = np.zeros((len(ns), ma, F), np.float32)
+        for b, x in enumerate(Xs):
+            pad[b, :ns[b]] = x
+            pad[b, ns[b]:] = 7.0          # garbage in the pad rows: must not be summed
+        Xl = [torch.from_numpy(pad[b]).to(DEV).requires_grad_(True) for b in range(len(ns))]
+        ds = np.stack([np.asarray(ns), np.zeros(len(ns), np.int64)], 1)
+        out = layer({"node_features": Xl, "data_slice": ds})
+    want = np.stack([x.astype(np.float64).sum(0) for x in Xs])
+    wact = np.tanh(want) if act == "tanh" else (np.maximum(want, 0) if act == "relu" else want)
+    assert_close(to_np(out), wact, FEATURE_RTOL, "gather out (large graphs)")
+    (out * torch.from_numpy(G).to(DEV)).sum().backward()
+    gact = G * ((1 - wact ** 2) if act == "tanh" else ((want > 0) if act == "relu" else 1.0))
+    if layout == "packed":
+        got = to_np(Xt.grad)
+        wantg = np.concatenate([np.repeat(gact[b:b + 1], ns[b], 0) for b in range(len(ns))], 0)
+        assert_close(got, wantg, FEATURE_RTOL, "gather dX (large graphs)")
+    else:
+        for b in range(len(ns)):
+            gb_ = to_np(Xl[b].grad)
+            assert_close(gb_[:ns[b]], np.repeat(gact[b:b + 1], ns[b], 0), FEATURE_RTOL, "gather dX[%d]" % b)
+            assert np.all(gb_[ns[b]:] == 0)
+
+
 def test_full_size_properties(amd):
     """BASELINE config[1] size (Tox21-shaped B=256, 75->64, K=2): size-independent properties."""
     B, Fin, Fout, K = 256, 75, 64, 2
