@@ -29,5 +29,8 @@ for dt in f32 bf16; do timeout 200 python bench.py --workload hiv-epoch --dtype 
 AGCN_BENCH_SELFTEST=1 timeout 300 python bench.py --gpus 2 --workload hiv-epoch --dtype bf16 --steps 80 --warmup 5 >> $O/${T}_hiv_epoch.jsonl 2>/dev/null
 timeout 900 python tools/bench_shapes.py --prof --epoch-graphs 41127 --modelnet-batch 32 > $O/${T}_shapes_paper.jsonl 2>/dev/null
 timeout 300 python tools/bench_shapes.py --mode reference --only tox21-l1,tox21-l3,reslap,stack,modelnet-3-64,modelnet-64-128,modelnet-reslap --modelnet-batch 32 > $O/${T}_shapes_reference.jsonl 2>/dev/null
+# the reference's whole point-cloud network, eager, under rocprofv3: which kernels its step is made of (torch glue included)
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/netstats -- python3 $GRAFT_REPO_ROOT/tools/prof_network.py 10 > $O/netstats.log 2>&1 )
+cp $O/netstats/*/*kernel_stats.csv $O/${T}_network_kernel_stats.csv
 AGCN_CLOUD=0 timeout 200 python tools/bench_shapes.py --only modelnet-64-128 --modelnet-batch 32 --prof > $O/${T}_modelnet_general_slab_kernels.jsonl 2>/dev/null
 ls -la $O

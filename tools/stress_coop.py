@@ -16,13 +16,24 @@ from agcn_amd.engine import _overlapping_streams  # noqa: E402
 dev = torch.device("cuda", 0)
 scale = float(os.environ.get("AGCN_STRESS_SCALE", "1"))
 bad = 0
-for (B, mu, hi) in ((256, np.log(16.0), 132), (256, np.log(23.0), 128), (100, np.log(30.0), 96)):
-    data = synth.tox21_batch(7, B, 75, mu=mu, hi=hi)
+# (the last case: SGC_LL_Reslap, whose members also exchange the graph-wide clip norms / inner products -- three exchanges in a
+#  row per direction, csrc/spec_backward_coop.h: coop_graph_sum)
+for (B, mu, hi, reslap) in ((256, np.log(16.0), 132, False), (256, np.log(23.0), 128, False), (100, np.log(30.0), 96, False),
+                            (256, np.log(23.0), 128, True)):
+    Fin = 64 if reslap else 75
+    data = synth.tox21_batch(7, B, Fin, mu=mu, hi=hi)
     gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
-    layer = amd.SGC_LL(64, 75, B, K=2, laplacian_mode="paper", device=dev)
-    layer.load_vars(synth.glorot_params(np.random.RandomState(1), 75, 64, 2))
+    if reslap:
+        layer = amd.SGC_LL_Reslap(64, Fin, B, K=2, laplacian_mode="paper", device=dev)
+        layer.load_vars(synth.glorot_params(np.random.RandomState(1), Fin, 64, 2, reslap=True))
+        extra = dict(L_prev=0.1 * torch.randn(gb.plan.tile_elems, device=dev), dL_sum=0.1 * torch.randn(gb.plan.tile_elems, device=dev))
+        assert amd._ffi.dispatch_info(layer, gb)[6] > 0, "the Reslap batch must have backward members"
+    else:
+        layer = amd.SGC_LL(64, Fin, B, K=2, laplacian_mode="paper", device=dev)
+        layer.load_vars(synth.glorot_params(np.random.RandomState(1), Fin, 64, 2))
+        extra = {}
     dY = torch.randn(gb.plan.rows, 64, device=dev)
-    steps = [amd.SgcLLStep(layer, gb, dY=dY) for _ in range(2)]
+    steps = [amd.SgcLLStep(layer, gb, dY=dY, **extra) for _ in range(2)]
     steps[0].step()
     torch.cuda.synchronize()
     ref = (steps[0].bucket.clone(), steps[0].dX.clone(), steps[0].Y.clone(), steps[0].res_L.clone())
@@ -50,7 +61,7 @@ for (B, mu, hi) in ((256, np.log(16.0), 132), (256, np.log(23.0), 128), (100, np
             diff += (steps[0].bucket != ref[0]).sum() + (steps[0].dX != ref[1]).sum()
     torch.cuda.synchronize()
     d = int(diff)
-    print("B=%d max_n=%d: %d mismatching values, %.1f s" % (B, int(data["n"].max()), d, time.perf_counter() - t0), flush=True)
+    print("B=%d max_n=%d%s: %d mismatching values, %.1f s" % (B, int(data["n"].max()), " Reslap" if reslap else "", d, time.perf_counter() - t0), flush=True)
     bad += d
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
