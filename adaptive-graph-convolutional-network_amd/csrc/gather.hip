@@ -14,7 +14,16 @@ __global__ __launch_bounds__(256) void graph_gather_fwd_kernel(const int32_t* n,
   const float* Xg = X + (int64_t)row_off[b] * ldx;
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     float s = 0.f;
-    for (int i = 0; i < nb; ++i) s += Xg[(int64_t)i * ldx + f];   // tf.reduce_sum(x, 0), graphgather.py:74
+    // tf.reduce_sum(x, 0), graphgather.py:74: rows added in index order, sixteen loads in flight at a time (one dependent load
+    // per row was 15 us for 256 molecules x 256 features: a memory round trip per row)
+    for (int i0 = 0; i0 < nb; i0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = Xg[(int64_t)min(i0 + u, nb - 1) * ldx + f];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (i0 + u < nb) s += v[u];
+    }
     if (act == AGCN_ACT_TANH) s = tanhf(s);
     else if (act == AGCN_ACT_RELU) s = fmaxf(s, 0.f);
     out[(int64_t)b * F + f] = s;

@@ -203,6 +203,52 @@ def check_device_status():
     return n
 
 
+# Reserve buffers of the autograd path are LEASED from a pool per (device, stream, size class) instead of allocated -- and their
+# 64 KB exchange header zero-filled, one fill kernel per layer call: 3.7 us, 5 % of a molecule network's step -- on every forward.
+# A reserve may serve any batch after any other (the header is self-maintaining: include/agcn.h), so a buffer that comes back
+# from the pool needs nothing.  A lease goes back when the autograd node that holds it dies (after backward(), or when the outputs
+# of a forward-only call are dropped).  Under stream capture: a pooled buffer (allocated eagerly, e.g. by the warm-up steps
+# GraphedStep runs on its capture stream) is used at its fixed address by every replay, so it is kept alive for good and never
+# handed out again; a buffer allocated INSIDE a capture belongs to the graph's own memory pool and never enters this one.
+_reserve_pool = {}
+_reserve_pool_bytes = [0]
+_RESERVE_POOL_CAP = 2 << 30
+_captured_keepalive = []
+
+
+class _ReserveLease(object):
+    __slots__ = ("tensor", "key", "pooled")
+
+    def __del__(self):
+        try:
+            if self.pooled and _reserve_pool_bytes[0] + self.tensor.numel() <= _RESERVE_POOL_CAP:
+                _reserve_pool.setdefault(self.key, []).append(self.tensor)
+                _reserve_pool_bytes[0] += self.tensor.numel()
+        except Exception:          # (interpreter shutdown)
+            pass
+
+
+def _lease_reserve(dev, rbytes):
+    size = (rbytes + 262143) // 262144 * 262144 if rbytes < (64 << 20) else rbytes      # size classes of 256 KB
+    capturing = torch.cuda.is_current_stream_capturing()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(dev).cuda_stream, size)
+    lease = _ReserveLease()
+    lease.key = key
+    lst = _reserve_pool.get(key)
+    if lst:
+        lease.tensor = lst.pop()
+        _reserve_pool_bytes[0] -= lease.tensor.numel()
+        lease.pooled = not capturing
+        if capturing:
+            _captured_keepalive.append(lease.tensor)
+    else:
+        lease.tensor = torch.empty(size, dtype=torch.uint8, device=dev)
+        lease.tensor[:min(size, _ffi.RESERVE_HEADER_BYTES)].zero_()      # (must be zero when a reserve is first used)
+        lease.pooled = not capturing
+    return lease
+
+
 class SgcLLFunction(torch.autograd.Function):
     """(Y, res_L, res_W, L_sum) = SGC_LL[_Reslap](X; weight, bias, M_L, alpha, beta, L_prev)."""
 
@@ -241,20 +287,21 @@ class SgcLLFunction(torch.autograd.Function):
         res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         L_sum = torch.empty(plan.tile_elems if cfg.lsum else 0, dtype=torch.float32, device=dev)
         desc, rbytes, wbytes, _ = _sizes(plan, cfg, ldx, ldy)
-        # (the reserve starts with the exchange header of the cooperative kernels, which must be zero when a reserve is first
-        # used -- include/agcn.h: AGCN_RESERVE_HEADER_BYTES; only that: at point-cloud sizes the reserve holds n x n tiles,
-        # and zero-filling all of it was 75 us per layer call)
-        reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
-        reserve[:min(rbytes, _ffi.RESERVE_HEADER_BYTES)].zero_()
+        # (the reserve starts with the exchange header of the cooperative kernels, which must be zero when a reserve is FIRST
+        # used -- include/agcn.h: AGCN_RESERVE_HEADER_BYTES; only that: at point-cloud sizes the reserve holds n x n tiles, and
+        # zero-filling all of it was 75 us per layer call -- and only then: see _lease_reserve)
+        lease = _lease_reserve(dev, rbytes)
+        reserve = lease.tensor
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         gb = _gbatch(batch, X, L_prev if reslap else None, cfg.prev_sym)
         pr = _ffi.Params(weight.data_ptr(), bias.data_ptr(), M_L.data_ptr(), alpha.data_ptr(), _ptr(beta))
         out = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(out),
-                                           reserve.data_ptr(), rbytes, ws.data_ptr(), wbytes, _stream(dev)))
+                                           reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, _stream(dev)))
         ctx.batch, ctx.cfg, ctx.has_prev, ctx.has_beta = batch, cfg, (reslap and L_prev is not None), beta is not None
+        ctx.reserve_lease = lease
         ctx.save_for_backward(X, weight, bias, M_L, alpha, beta, L_prev if reslap else None,
-                              Y, res_L, res_W, L_sum, reserve)
+                              Y, res_L, res_W, L_sum)
         ctx.mark_non_differentiable(res_L, res_W)
         ctx.set_materialize_grads(False)      # an unused L_sum must reach the library as "no upstream gradient"
         return Y, res_L, res_W, L_sum
@@ -263,7 +310,8 @@ class SgcLLFunction(torch.autograd.Function):
     @_on_tensor_device
     def backward(ctx, dY, _dres_L, _dres_W, dL_sum):
         lib = _ffi.lib()
-        X, weight, bias, M_L, alpha, beta, L_prev, Y, res_L, res_W, L_sum, reserve = ctx.saved_tensors
+        X, weight, bias, M_L, alpha, beta, L_prev, Y, res_L, res_W, L_sum = ctx.saved_tensors
+        reserve = ctx.reserve_lease.tensor
         batch, cfg, plan = ctx.batch, ctx.cfg, ctx.batch.plan
         dev = X.device
         paper = cfg.mode == "paper"

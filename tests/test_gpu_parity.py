@@ -2138,6 +2138,66 @@ def orc_dense(csr, n):
     return sp.csr_matrix((np.asarray(csr[2], dtype=np.float64), csr[1], csr[0]), shape=(n, n)).toarray().astype(np.float32)
 
 
+def test_autograd_reserves_are_leased_not_allocated(amd):
+    """The autograd path's reserve buffers come from a pool per (device, stream, size class) and go back when the autograd node
+    dies (functional._lease_reserve): a second step on the same batch reuses the first one's buffer (no allocation, no zero-fill
+    of the exchange header), two forwards before any backward get DIFFERENT buffers, a forward-only call gives its buffer back
+    when its outputs are dropped -- and the results do not depend on any of it (members exchange through the header)."""
+    import gc
+    from agcn_amd import functional as fn, synth
+    B, Fin, Fout, K = 64, 75, 64, 2
+    data = synth.tox21_batch(77, B, Fin, mu=np.log(30.0), hi=96)          # (large graphs: members in both directions)
+    gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], DEV)
+    layer = amd.SGC_LL(Fout, Fin, B, K=K, laplacian_mode="paper", device=DEV)
+    layer.load_vars(synth.glorot_params(np.random.RandomState(5), Fin, Fout, K))
+    assert amd._ffi.dispatch_info(layer, gb)[3] > 0
+    G = torch.randn(gb.plan.rows, Fout, device=DEV)
+
+    def pooled():
+        return sum(len(v) for v in fn._reserve_pool.values())
+
+    def step():
+        X = gb.X.clone().requires_grad_(True)
+        for v in layer.vars.values():
+            v.grad = None
+        nodes, _, _ = layer({"node_features": X, "graph_batch": gb})
+        (nodes.data * G).sum().backward()
+        return X.grad.clone(), layer.vars["weight"].grad.clone(), layer.vars["M_L"].grad.clone()
+
+    gc.collect()
+    fn._reserve_pool.clear()               # (buffers other tests of this process left behind)
+    fn._reserve_pool_bytes[0] = 0
+    first = step()
+    gc.collect()
+    n1 = pooled()
+    assert n1 == 1
+    for _ in range(3):
+        again = step()
+        gc.collect()
+        assert pooled() == n1                                    # the same buffer went out and came back
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+    # two forwards in flight: two different buffers
+    Xa, Xb = gb.X.clone().requires_grad_(True), gb.X.clone().requires_grad_(True)
+    ya = layer({"node_features": Xa, "graph_batch": gb})[0].data
+    yb = layer({"node_features": Xb, "graph_batch": gb})[0].data
+    assert pooled() == 0
+    (ya * G).sum().backward()
+    (yb * G).sum().backward()
+    assert torch.equal(Xa.grad, first[0]) and torch.equal(Xb.grad, first[0])
+    del ya, yb, Xa, Xb
+    gc.collect()
+    assert pooled() == n1 + 1
+    # forward only: the buffer comes back when the outputs go
+    with torch.no_grad():
+        y = layer({"node_features": gb.X, "graph_batch": gb})[0].data
+    del y
+    gc.collect()
+    assert pooled() == n1 + 1
+    torch.cuda.synchronize()
+    amd.functional.check_device_status()
+
+
 def test_autograd_status_outlives_the_reserve(amd):
     """The autograd path's reserves die with the autograd graph -- right after backward() --, so a wait that ran out must be
     visible AFTER that: agcn_amd.check_device_status() reads a persistent per-device word (agcn_set_device_status_word).
