@@ -386,7 +386,7 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   r.r = c.off;
   if (d->K == 2 && d->mode == AGCN_MODE_PAPER) c.take((size_t)pi.tile_elems);
   // transposed parameter copies (specialised kernels)
-  r.MT = c.off; c.take((size_t)d->Fin * d->Fin);
+  r.MT = c.off; c.take((size_t)((d->Fin + 15) & ~15) * d->Fin);      // k-blocked: [F4 / 4][Fin][4], zero beyond Fin
   r.WT = c.off; c.take((size_t)d->K * d->Fout * d->Fin);
   r.total = c.off;
   return r;

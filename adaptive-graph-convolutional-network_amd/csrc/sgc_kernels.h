@@ -40,8 +40,8 @@ struct SgcArgs {
   float* sv_Lpre;  // [tile_elems] Reslap: L before the second clip
   // transposed parameter copies written by the specialised forward kernel for the specialised backward one (row-major
   // with the MFMA k index as the row: a fragment load then touches 4 cache lines instead of 16)
-  float* sv_MT;    // [Fin][Fin]        M_L^T
-  float* sv_WT;    // [K][Fout][Fin]    WT[k][c][f] = W[f*K + k][c]
+  float* sv_MT;    // [F4/4][Fin][4]        MT[k/4][f][k%4] = M_L[f][k], zero for k >= Fin (k-blocked: spec_kernels.h kb_frag)
+  float* sv_WT;    // [K][Fout/4][Fin][4]   WT[kk][c/4][f][c%4] = W[f*K + kk][c]      (cloud kernels: [K][Fout][Fin])
   int32_t tp_first; // specialised forward: the graphs at schedule positions tp_first .. B-1 write sv_MT / sv_WT
   // exchange words of the cooperative backward (spec_backward_coop.h): [B][97] 64-bit words, zeroed per graph by the
   // specialised forward kernel

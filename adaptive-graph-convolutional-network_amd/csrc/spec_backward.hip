@@ -75,15 +75,16 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   // matrix: a wave keeps its dX tiles in registers.
   // Fragments are streamed in chunks of at most 16 / 20 k-steps through two register buffers (the next chunk is in
   // flight while the current one feeds the matrix cores), whatever the layer width.
-  constexpr int NKW = FOUT / 4;            // k-steps over the output features
-  constexpr int CHW = 16, NCHW = NKW / CHW;
+  constexpr int NKBW = FOUT / 16;          // 16-k blocks over the output features (spec_kernels.h: kb_frag / kb_mma)
+  constexpr int CHW = 4, NCHW = NKBW / CHW; // blocks per chunk (16 k-steps: four 16-byte loads per lane)
   int t1a, t1b;
   tile_range<NW>(ntm * NCB, wave, t1a, t1b);
-  float wb0[CHW], wb1[CHW];
-  auto load_wc = [&](float (&wf)[CHW], int t, int kk, int ch) {
-    const float* p = a.sv_WT + kk * (FOUT * FIN) + (q + 4 * CHW * ch) * FIN + min((t % NCB) * 16 + r, FIN - 1);
+  f32x4 wb0[CHW], wb1[CHW];
+  auto load_wc = [&](f32x4 (&wf)[CHW], int t, int kk, int ch) {
+    const float* base = a.sv_WT + kk * (FOUT * FIN);
+    const int f = min((t % NCB) * 16 + r, FIN - 1);
 #pragma unroll
-    for (int u = 0; u < CHW; ++u) wf[u] = p[4 * u * FIN];
+    for (int u = 0; u < CHW; ++u) wf[u] = kb_frag(base, CHW * ch + u, q, f, FIN);
   };
   // One memory round trip for the whole phase: every independent load is requested before the first LDS store (loads
   // return in order, so a store that waits for its data also waits for every older load), the row pointers first --
@@ -239,10 +240,10 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   // ---- G: g_0 = Gp . W_0^T -> registers, g_1 = Gp . W_1^T -> image ------------------------------------------------
   f32x4 dxacc[MAXTB];
   {
-    auto mma_wc = [&](f32x4 acc, const float (&wf)[CHW], int t, int ch) {
-      const float* Ap = GPimg + ((t / NCB) * 16 + r) * LDG + q + 4 * CHW * ch;
+    auto mma_wc = [&](f32x4 acc, const f32x4 (&wf)[CHW], int t, int ch) {
+      const float* Ap = GPimg + ((t / NCB) * 16 + r) * LDG;
 #pragma unroll
-      for (int u = 0; u < CHW; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], wf[u], acc, 0, 0, 0);
+      for (int u = 0; u < CHW; ++u) acc = kb_mma(acc, Ap, CHW * ch + u, q, wf[u]);
       return acc;
     };
 #pragma unroll
@@ -560,17 +561,15 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }   // paper
   }
   // M_L^T fragments of the last product from the transposed copy: B[k][f] = MT[k][f] row-major
-  constexpr int CHM = 20, NCHM = (NKS + CHM - 1) / CHM;
-  float mb0[CHM], mb1[CHM];
-  auto load_mc = [&](float (&bf)[CHM], int t, int ch) {
-    const float* p = a.sv_MT + q * FIN + min((t % NCB) * 16 + r, FIN - 1);
+  constexpr int NKBM = F4 / 16;            // 16-k blocks over the input features (the copy is zero beyond FIN)
+  constexpr int CHM = 5, NCHM = (NKBM + CHM - 1) / CHM;
+  f32x4 mb0[CHM], mb1[CHM];
+  auto load_mc = [&](f32x4 (&bf)[CHM], int t, int ch) {
+    const int f = min((t % NCB) * 16 + r, FIN - 1);
 #pragma unroll
     for (int uu = 0; uu < CHM; ++uu) {
       const int u = ch * CHM + uu;       // (compile-time after unrolling)
-      if (u < NKS) {
-        if (4 * u + 3 < FIN) bf[uu] = p[4 * u * FIN];
-        else bf[uu] = p[(min(4 * u + q, FIN - 1) - q) * FIN];
-      }
+      if (u < NKBM) bf[uu] = kb_frag(a.sv_MT, u, q, f, FIN);
     }
   };
   if (paper && t1a < t1b) load_mc(mb0, t1a, 0);
@@ -580,12 +579,12 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   // ---- dX += dZ M_L^T, then B3: every global store -------------------------------------------------------------
   {
     float* dXg = a.dX + (int64_t)row0 * a.lddx;
-    auto mma_mc = [&](f32x4 acc, const float (&bf)[CHM], int t, int ch) {
-      const float* Ap = DZimg + ((t / NCB) * 16 + r) * LDX + q;
+    auto mma_mc = [&](f32x4 acc, const f32x4 (&bf)[CHM], int t, int ch) {
+      const float* Ap = DZimg + ((t / NCB) * 16 + r) * LDX;
 #pragma unroll
       for (int uu = 0; uu < CHM; ++uu) {
         const int u = ch * CHM + uu;
-        if (u < NKS) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[uu], acc, 0, 0, 0);
+        if (u < NKBM) acc = kb_mma(acc, Ap, u, q, bf[uu]);
       }
       return acc;
     };

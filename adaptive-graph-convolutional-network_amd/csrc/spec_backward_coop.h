@@ -314,23 +314,24 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 2);
   // ---- M2: g_1 = Gp W_1^T for ALL rows -> image;  g_0 = Gp[I] W_0^T -> image -------------------------------------
   {
-    constexpr int CHW = 16, NCHW = NKW / CHW;
+    constexpr int CHW = 4, NCHW = NKW / (4 * CHW);   // 16-k blocks per chunk (spec_kernels.h: kb_frag / kb_mma)
     int ta, tb;
     tile_range<NW>((ntm + 1) * NCB, wave, ta, tb);
     for (int t = ta; t < tb; ++t) {
       const bool own = t >= ntm * NCB;            // a g_0 tile of the strip
       const int rt = own ? me : t / NCB, cb = own ? t - ntm * NCB : t - rt * NCB;
       const int kk = own ? 0 : 1;
-      const float* Ap = GPimg + (rt * 16 + r) * LDG + q;
+      const float* Ap = GPimg + (rt * 16 + r) * LDG;
+      const float* wbase = a.sv_WT + kk * (FOUT * FIN);
+      const int fcl = min(cb * 16 + r, FIN - 1);
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ch = 0; ch < NCHW; ++ch) {
-        const float* p = a.sv_WT + kk * (FOUT * FIN) + (q + 4 * CHW * ch) * FIN + min(cb * 16 + r, FIN - 1);
-        float wf[CHW];
+        f32x4 wf[CHW];
 #pragma unroll
-        for (int u = 0; u < CHW; ++u) wf[u] = p[4 * u * FIN];
+        for (int u = 0; u < CHW; ++u) wf[u] = kb_frag(wbase, CHW * ch + u, q, fcl, FIN);
 #pragma unroll
-        for (int u = 0; u < CHW; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * (CHW * ch + u)], wf[u], acc, 0, 0, 0);
+        for (int u = 0; u < CHW; ++u) acc = kb_mma(acc, Ap, CHW * ch + u, q, wf[u]);
       }
       const int f = cb * 16 + r;
       const bool fv = f < FIN;
@@ -637,23 +638,19 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   // ---- M8: dX[I] += dZ[I] M_L^T, then every global store ------------------------------------------------------------
   if (wave < NCB) {
     const int cb = wave;
-    const float* Ap = DZimg + r * LDX + q;
-    const float* p = a.sv_MT + q * FIN + min(cb * 16 + r, FIN - 1);
+    const float* Ap = DZimg + r * LDX;
+    const int fcl = min(cb * 16 + r, FIN - 1);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int CHM = 16;
+    constexpr int NKBM = F4 / 16, CHM = 4;       // 16-k blocks over the input features (the copy is zero beyond FIN)
 #pragma unroll
-    for (int u0 = 0; u0 < NKS; u0 += CHM) {
-      float bf[CHM];
+    for (int u0 = 0; u0 < NKBM; u0 += CHM) {
+      f32x4 bf[CHM];
 #pragma unroll
-      for (int uu = 0; uu < CHM; ++uu) {
-        const int u = u0 + uu;
-        if (u < NKS) bf[uu] = (4 * u + 3 < FIN) ? p[4 * u * FIN] : p[(min(4 * u + q, FIN - 1) - q) * FIN];
-      }
+      for (int uu = 0; uu < CHM; ++uu)
+        if (u0 + uu < NKBM) bf[uu] = kb_frag(a.sv_MT, u0 + uu, q, fcl, FIN);
 #pragma unroll
-      for (int uu = 0; uu < CHM; ++uu) {
-        const int u = u0 + uu;
-        if (u < NKS) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[uu], acc, 0, 0, 0);
-      }
+      for (int uu = 0; uu < CHM; ++uu)
+        if (u0 + uu < NKBM) acc = kb_mma(acc, Ap, u0 + uu, q, bf[uu]);
     }
     const int f = cb * 16 + r;
     if (f < FIN) {

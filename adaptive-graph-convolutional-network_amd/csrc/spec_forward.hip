@@ -472,20 +472,24 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
     }
   }
   // The blocks of the last (smallest) graphs of the batch -- positions tp_first .. B-1, at most 32 of them -- also leave
-  // transposed copies of the parameters in the reserve for the backward kernel (its B operands W^T and M_L^T then load
-  // row-major: 4 cache lines per fragment load instead of 16).  Stores only, behind every load of the block; in
+  // transposed, k-blocked copies of the parameters in the reserve for the backward kernel (its B operands W^T and M_L^T then
+  // load as 16 bytes per lane for four k-steps, 8 cache lines per load: 16 lines per four k-steps row-major, 64 from W itself).  Stores only, behind every load of the block; in
   // chunks of 512 elements dealt round-robin to the sharing blocks (whatever their thread count).  (One block doing
   // all of it was the tail of the launch at Fin = 128: 48 k strided loads, 42 instead of 25 us.)
   if (gpos >= a.tp_first) {
     const int nsh = a.B - a.tp_first, me = gpos - a.tp_first;
     if (tid < 512) {
-      for (int e = me * 512 + tid; e < FIN * FIN; e += nsh * 512) {
-        const int k = e / FIN, f = e - k * FIN;
-        a.sv_MT[e] = a.M_L[f * FIN + k];
+      // k-BLOCKED: [k / 4][f][k % 4] (k = the backward's MFMA k index: an input feature of M_L resp. an output feature of W),
+      // zero beyond the last k -- a lane's B values of FOUR k-steps are one 16-byte load (spec_kernels.h: kb_frag)
+      for (int e = me * 512 + tid; e < F4 * FIN; e += nsh * 512) {
+        const int kg = e / (4 * FIN), rem = e - kg * (4 * FIN);
+        const int f = rem >> 2, k = 4 * kg + (rem & 3);
+        a.sv_MT[e] = k < FIN ? a.M_L[f * FIN + k] : 0.f;
       }
       for (int e = me * 512 + tid; e < 2 * FOUT * FIN; e += nsh * 512) {
         const int kk = e / (FOUT * FIN), rem = e - kk * (FOUT * FIN);
-        const int c = rem / FIN, f = rem - c * FIN;
+        const int cg = rem / (4 * FIN), rem2 = rem - cg * (4 * FIN);
+        const int f = rem2 >> 2, c = 4 * cg + (rem2 & 3);
         a.sv_WT[e] = a.weight[(f * 2 + kk) * FOUT + c];
       }
     }

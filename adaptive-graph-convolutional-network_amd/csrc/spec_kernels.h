@@ -146,15 +146,25 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 struct GraphRec { int b, n, row0; uint32_t toff, npad; };
 // one 32-byte record per schedule position (plan.cpp); tile offsets fit 32 bits on this path (checked by the launcher)
+// The record comes through the SCALAR cache (one s_load_dwordx8 at a wave-uniform address; the plan is read-only while a step
+// runs).  Every other load of the workgroup depends on it: as a vector load (what the compiler emits for the plain C++ form: it
+// cannot prove the record is not stored to) it was a whole vector-memory round trip in front of the first round of loads -- the
+// first phase of the one-workgroup bodies took 3.2 us against 1.5 us in the members, which read their tables with scalar loads.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ GraphRec load_graph(const AgcnGraphDesc* gd) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(gd);
-  const f32x4 g0 = p[0], g1 = p[1];
+  // (the address is wave-uniform but not always provably so -- the paired workgroups pick their graph by threadIdx.x >> 9 --:
+  //  made scalar explicitly; a vector register here would assemble and run several times slower)
+  const uint64_t ga = reinterpret_cast<uint64_t>(gd);
+  const uint64_t gs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ga >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ga);
+  i32x8 rec;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(gs) : "memory");
   GraphRec g;
-  g.b = uni(__float_as_int(g0[0]));
-  g.n = uni(__float_as_int(g0[1]));
-  g.row0 = uni(__float_as_int(g0[2]));
-  g.toff = (uint32_t)uni(__float_as_int(g1[0]));
-  g.npad = (uint32_t)uni(__float_as_int(g1[2])) - g.toff - (uint32_t)(g.n * g.n);
+  g.b = rec[0];
+  g.n = rec[1];
+  g.row0 = rec[2];
+  g.toff = (uint32_t)rec[4];
+  g.npad = (uint32_t)rec[6] - g.toff - (uint32_t)(g.n * g.n);
   return g;
 }
 
@@ -209,6 +219,27 @@ __device__ __forceinline__ void zero_tags(const SgcArgs& a) {
     for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < a.ztag_count16; e += step)
       asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p + e), "v"(z) : "memory");
   }
+}
+
+// The backward's products against the transposed parameter copies (g = Gp W^T, dX += dZ M_L^T) walk k in blocks of 16 with the
+// k index PERMUTED inside a block: MFMA step j of block b pairs A[row r][16 b + 4 q + j] with B[k = 16 b + 4 q + j][column] -- so
+// that a lane's A values of four steps are 16 consecutive bytes of the LDS image (two 8-byte reads: the images' row strides are
+// 2 mod 4 floats) and its B values ONE 16-byte load of the k-blocked copy [k / 4][f][k % 4] the forward left in the reserve.
+// (Row-major copies, one dword per lane and k-step: sixteen loads of 4 x 64 bytes per lane and 16 k-steps -- the first round of
+// loads of the backward kernel was 1024 cache lines of parameter fragments per workgroup.)
+//   kb_frag: the B fragment of block `kblk` for output column `f` (clamped by the caller); base = copy of one Chebyshev term
+__device__ __forceinline__ f32x4 kb_frag(const float* base, int kblk, int q, int f, int fin) {
+  return *reinterpret_cast<const f32x4*>(base + ((int64_t)(4 * kblk + q) * fin + f) * 4);
+}
+//   kb_mma: acc += A[16 x 16 of block kblk] . B;  arow = image row of this lane (image + row * ld), 8-byte aligned at 16 kblk + 4 q
+__device__ __forceinline__ f32x4 kb_mma(f32x4 acc, const float* arow, int kblk, int q, const f32x4& b) {
+  const f32x2 a0 = *reinterpret_cast<const f32x2*>(arow + 16 * kblk + 4 * q);
+  const f32x2 a1 = *reinterpret_cast<const f32x2*>(arow + 16 * kblk + 4 * q + 2);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b[3], acc, 0, 0, 0);
+  return acc;
 }
 
 // contiguous, balanced share of T tiles for wave w of NW
