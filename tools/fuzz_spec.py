@@ -12,7 +12,7 @@ for extra in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if extra not in sys.path:
         sys.path.insert(0, extra)
 import agcn_oracle as orc  # noqa: E402
-from helpers import compare_with_oracle, oracle_run, run_packed, synth_case  # noqa: E402
+from helpers import compare_with_oracle, oracle_pair, oracle_run, run_packed, synth_case  # noqa: E402
 
 DEV = "cuda:0"
 SHAPES = ((75, 64), (64, 128), (128, 128), (128, 64), (64, 64))
@@ -32,18 +32,33 @@ def main():
             ns[int(rs0.randint(B))] = int(rs0.choice([128, 127, 113, 112, 97, 96, 95, 81, 80, 65, 64, 49, 48, 33]))
         Fin, Fout = SHAPES[int(rs0.randint(len(SHAPES)))]
         mode = orc.PAPER if rs0.rand() < 0.7 else orc.REFERENCE
-        rs, X, L0, csr, p, G = synth_case(20_000 + case, ns, Fin, Fout, 2, orc.SGC_LL, atoms=(Fin == 75))
+        # a third of the cases: SGC_LL_Reslap (members exchange the graph-wide clip norms / inner products too), with or
+        # without a previous Laplacian, with or without a gradient arriving on L_sum
+        variant = orc.SGC_LL_RESLAP if rs0.rand() < 0.34 else orc.SGC_LL
+        rs, X, L0, csr, p, G = synth_case(20_000 + case, ns, Fin, Fout, 2, variant, atoms=(Fin == 75))
         p["alpha"] = np.array([rs0.choice([1.0, 0.7, 0.2])], np.float32)
-        caches, tot = oracle_run(X, L0, p, 2, mode, orc.SGC_LL, G, None, None)
+        Lp = dLs = None
+        if variant == orc.SGC_LL_RESLAP:
+            p["beta"] = np.array([rs0.choice([1.0, 1.3, 0.4])], np.float32)
+            if rs0.rand() < 0.7:
+                Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
+            if rs0.rand() < 0.6:
+                dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
         try:
-            out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, 2, mode, orc.SGC_LL, None, None)
-            compare_with_oracle(out, caches, tot, orc.SGC_LL, mode, 2, has_prev=False)
-            print("ok   case %d: B=%d max_n=%d n>=33: %d n<=16: %d %d->%d mode=%d" % (
-                case, B, max(ns), sum(v >= 33 for v in ns), sum(v <= 16 for v in ns), Fin, Fout, mode), flush=True)
+            out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, 2, mode, variant, Lp, dLs)
+            if variant == orc.SGC_LL_RESLAP:
+                caches, tot, tot32 = oracle_pair(X, L0, p, 2, mode, variant, G, Lp, dLs, Y_got=np.concatenate(out["Y"]))
+                compare_with_oracle(out, caches, tot, variant, mode, 2, has_prev=Lp is not None, tot32=tot32)
+            else:
+                caches, tot = oracle_run(X, L0, p, 2, mode, variant, G, None, None)
+                compare_with_oracle(out, caches, tot, variant, mode, 2, has_prev=False)
+            print("ok   case %d: B=%d max_n=%d n>=33: %d n<=16: %d %d->%d mode=%d%s" % (
+                case, B, max(ns), sum(v >= 33 for v in ns), sum(v <= 16 for v in ns), Fin, Fout, mode,
+                "" if variant == orc.SGC_LL else " Reslap prev=%d dLs=%d" % (Lp is not None, dLs is not None)), flush=True)
         except Exception as e:      # noqa: BLE001
             fails += 1
-            print("FAIL case %d: B=%d max_n=%d %d->%d mode=%d -> %s" % (case, B, max(ns), Fin, Fout, mode, str(e)[:300]),
-                  flush=True)
+            print("FAIL case %d: B=%d max_n=%d %d->%d mode=%d variant=%d -> %s" % (case, B, max(ns), Fin, Fout, mode, variant,
+                                                                                  str(e)[:300]), flush=True)
     print("failures:", fails)
     return 1 if fails else 0
 
