@@ -296,8 +296,8 @@ __global__ __launch_bounds__(1024) void param_grad_onepass_kernel(ParamGradArgs 
 
 
 // ------------------------------------------------------------------------------------------------
-// Tagged hand-off variant of the one-pass kernel (batches below 8k rows, TF = 16): the same tiles and products over EIGHT row
-// splits, one per XCD -- and the splits' partial tiles travel as 8-byte (value, tag) GRANULES:
+// Tagged hand-off variant of the one-pass kernel (batches below 8k rows, TF = 16): the same tiles and products over eight row
+// splits (sixteen from 5121 rows on), split % 8 = its XCD -- and the splits' partial tiles travel as 8-byte (value, tag) GRANULES:
 // one agent-scope store per element, no drain of the stores, no arrival counter, no second round of loads.  The workgroup of
 // a tile's LAST split (the shortest one; behind its tile's producers in dispatch order: they have all been dispatched) is the
 // tile's reducer: it polls the S - 1 granules of each of its elements (all requested at once), adds them in split order, its own
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int K = a.K, Fin = a.Fin, Fout = a.Fout;
-  const int S = a.n_chunks, nt = a.n_tiles;
+  const int S = a.n_chunks;
   // split = block % S: with the EIGHT splits of a batch of 128 rows and more, and workgroups dealt round-robin over the 8 XCDs,
   // every workgroup of one row split runs on one XCD -- a row of X / X_1 / Gp / dZ is then fetched into ONE L2 instead of all
   // eight (the plain order's 370 workgroups waited 3.5 - 6.6 us for their operands: 23 MB over the fabric for 3.6 MB of rows).
