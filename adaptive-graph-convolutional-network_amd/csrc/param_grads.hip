@@ -321,16 +321,20 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
   // A speed matter only.  The reducer (s = S - 1) follows its tile's producers in dispatch order.
   const int t = (int)blockIdx.x / S, s = (int)blockIdx.x - t * S;
   AGCN_STAMP(7, 0);
-  const int tfW = (Fin * K + 15) / 16, tcW = (Fout + 31) >> 5;
+  // dweight tiles: 16 consecutive FEATURES of ONE Chebyshev term x 32 columns (rows f K + k of dweight, k fixed per tile) -- an A
+  // fragment load then takes 64 contiguous bytes of a row of ONE array instead of 32 bytes of X_0 and 32 of X_1 (half the cache
+  // lines); the sums of an output element are the same rows in the same order whatever the tiling
   const int tfM = (Fin + 15) / 16;
+  const int tfW = K * tfM, tcW = (Fout + 31) >> 5;
   int p, rem;
   if (t < tfW * tcW) { p = 0; rem = t; }
   else if (t < tfW * tcW + tcW) { p = 1; rem = t - tfW * tcW; }
   else { p = 2; rem = t - tfW * tcW - tcW; }
-  const int Fa = p == 0 ? Fin * K : (p == 1 ? 1 : Fin), Fb = p == 2 ? Fin : Fout;
+  const int Fa = p == 1 ? 1 : Fin, Fb = p == 2 ? Fin : Fout;          // rows (features) / columns of this tile's matrix
   const int tf = p == 0 ? tfW : (p == 1 ? 1 : tfM);
   const int itc = rem / tf, itf = rem - itc * tf;
-  const int f0 = itf * 16, c0 = itc * 32;
+  const int kx = p == 0 ? itf / tfM : 0;                                // Chebyshev term of a dweight tile
+  const int f0 = (p == 0 ? itf - kx * tfM : itf) * 16, c0 = itc * 32;
   const int last_row = a.rows - 1;
   const int r_begin = s * a.chunk_rows + wave * a.wgs_per_chunk;
   const int r_end = min(min(a.rows, (s + 1) * a.chunk_rows), r_begin + a.wgs_per_chunk);
@@ -340,9 +344,8 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
   const float* Ap;
   int64_t lda;
   if (p == 0) {
-    const int f = j / K, kx = j - f * K;
-    if (kx == 0) { Ap = a.X + f; lda = a.ldx; }
-    else { Ap = a.sv_X + (int64_t)(kx - 1) * a.rows * Fin + f; lda = Fin; }
+    if (kx == 0) { Ap = a.X + j; lda = a.ldx; }
+    else { Ap = a.sv_X + (int64_t)(kx - 1) * a.rows * Fin + j; lda = Fin; }
   } else if (p == 2) { Ap = a.X + j; lda = a.ldx; }
   else { Ap = a.X; lda = 0; }
   const float* Bp = (p == 2) ? a.dZ : a.Gp;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(1024, 8) void param_grad_tagged_kernel(ParamGradArg
       }
       const int ff = f0 + (tid >> 5), c = c0 + (tid & 31);
       if (ff < Fa && c < Fb) {
-        if (p == 0) a.dweight[(int64_t)ff * Fout + c] = tot;
+        if (p == 0) a.dweight[(int64_t)(ff * K + kx) * Fout + c] = tot;
         else if (p == 1) a.dbias[c] = tot;
         else a.dM_L[(int64_t)ff * Fin + c] = tot;
       }
@@ -481,7 +484,8 @@ static bool pg_tagged_shape(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, 
   static const int s_force = [] { const char* e = std::getenv("AGCN_PG_TAG_SPLITS"); return e ? std::atoi(e) : 0; }();
   const int s_target = (s_force == 8 || s_force == 16) ? s_force : (rows <= 5120 ? 8 : 16);
   const int rpw = (rows + 16 * s_target - 1) / (16 * s_target);
-  *nt_out = pg_tiles(Fin, Fout, K, paper != 0, 16);
+  const int tfM = (Fin + 15) / 16, tc = (Fout + 31) / 32;   // dweight tiles per Chebyshev term (see the kernel)
+  *nt_out = K * tfM * tc + tc + (paper ? tfM * ((Fin + 31) / 32) : 0);
   *S_out = (rows + 16 * rpw - 1) / (16 * rpw);              // <= s_target
   *rpw_out = rpw;
   return true;
