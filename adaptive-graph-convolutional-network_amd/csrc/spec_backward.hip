@@ -108,8 +108,8 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
         if (u < rpw) {
           if constexpr (decltype(BF)::value) {
-            gy[u][cp] = bf16_load(a.dY, (int64_t)(row0 + i) * a.ldy + c);
-            yy[u][cp] = bf16_load(a.Y, (int64_t)(row0 + i) * a.ldy + c);
+            gy[u][cp] = bf16_load_raw(a.dY, (int64_t)(row0 + i) * a.ldy + c);
+            yy[u][cp] = bf16_load_raw(a.Y, (int64_t)(row0 + i) * a.ldy + c);
           } else {
             gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
             yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
@@ -156,6 +156,15 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       csr_c[u] = a.L0_col[pp];
       csr_v[u] = a.L0_val[pp];
     }
+  }
+  if (a.feat_bf16) {     // (widened HERE, behind every load of the round: spec_kernels.h, bf16_load_raw)
+#pragma unroll
+    for (int u = 0; u < RPW; ++u)
+#pragma unroll
+      for (int cp = 0; cp < CPO; ++cp) {
+        gy[u][cp] = bf16_widen(gy[u][cp]);
+        yy[u][cp] = bf16_widen(yy[u][cp]);
+      }
   }
   // Gp = dY . act'(Y) -> image (A operand of phase G); kept in registers for the hand-off store at the end
   float gpv[RPW][CPO];

@@ -203,8 +203,8 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
         // (uniform bound + clamped addresses, never a per-lane branch: a load under one is waited for on the spot)
         if (u < rpw) {
           if constexpr (decltype(BF)::value) {
-            gy[u][cp] = bf16_load(a.dY, (int64_t)(row0 + i) * a.ldy + c);
-            yy[u][cp] = bf16_load(a.Y, (int64_t)(row0 + i) * a.ldy + c);
+            gy[u][cp] = bf16_load_raw(a.dY, (int64_t)(row0 + i) * a.ldy + c);
+            yy[u][cp] = bf16_load_raw(a.Y, (int64_t)(row0 + i) * a.ldy + c);
           } else {
             gy[u][cp] = dYg[(int64_t)i * a.ldy + c];
             yy[u][cp] = Yg[(int64_t)i * a.ldy + c];
@@ -241,6 +241,15 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       csr_c[u] = a.L0_col[pp];
       csr_v[u] = a.L0_val[pp];
     }
+  }
+  if (a.feat_bf16) {     // (widened HERE, behind every load of the round: spec_kernels.h, bf16_load_raw)
+#pragma unroll
+    for (int u = 0; u < RPW; ++u)
+#pragma unroll
+      for (int cp = 0; cp < CPO; ++cp) {
+        gy[u][cp] = bf16_widen(gy[u][cp]);
+        yy[u][cp] = bf16_widen(yy[u][cp]);
+      }
   }
   float gpown[CPO];   // Gp row i0 + wave (this wave loaded it: rows wave, wave + 16, ..), for the hand-off store
 #pragma unroll

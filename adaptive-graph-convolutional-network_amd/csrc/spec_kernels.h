@@ -125,6 +125,16 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float bf16_load(const float* base, int64_t idx) {
   return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[idx] << 16);
 }
+// The load and the widening SEPARATELY: a load loop that widens on the spot (`x << 16` right behind each 2-byte load) makes the
+// compiler wait for every load before it issues the next one wherever the loads sit in blocks of their own (the wave-uniform
+// `u < rpw` branches): a dependent memory round trip per row -- the bf16 forward / backward were 2.3 us slower than the fp32 ones
+// for that alone.  bf16_load_raw leaves the 16 bits in the low half (no arithmetic), bf16_widen runs behind the whole loop.
+// (Backward kernels only: the forward's X loads sit in ONE block and are hoisted as they are -- split the same way its bf16
+// flavour got 3.4 us SLOWER.)
+__device__ __forceinline__ float bf16_load_raw(const float* base, int64_t idx) {
+  return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[idx]);
+}
+__device__ __forceinline__ float bf16_widen(float raw) { return __uint_as_float(__float_as_uint(raw) << 16); }
 __device__ __forceinline__ void bf16_store(float* base, int64_t idx, float v) {
   uint32_t u = __float_as_uint(v);
   u = ((u & 0x7fffffffu) > 0x7f800000u) ? (u | 0x00400000u) : u + 0x7fffu + ((u >> 16) & 1u);
