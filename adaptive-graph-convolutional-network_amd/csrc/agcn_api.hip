@@ -145,9 +145,14 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   const AgcnPlanInfo& pi = host.info;
   // opt-in (agcn_set_fused_mode(3)): measured SLOWER than the whole batch on the slab path -- the side chain's six
   // launches each wait for CUs the specialised workgroups hold (HIV-shaped epoch: 1.58 M graphs/s mixed, 1.78 M all-slab)
-  if (agcn_get_fused_mode() < 3 || (agcn_get_spec_mode() & 3) != 3) return;
+  // SGC_LL_Reslap has no slab flavour: without this its whole batch would leave for the general per-graph pipeline (HIV-shaped,
+  // one 158-atom molecule: 445 us per step against 73) -- so its oversized molecules take the per-graph kernels on the side
+  // stream BY DEFAULT (big_pg; AGCN_RESLAP_MIXED=0 disables)
+  static const int res_mixed = [] { const char* e = std::getenv("AGCN_RESLAP_MIXED"); return e ? std::atoi(e) : 1; }();
+  const bool reslap = d->variant == AGCN_SGC_LL_RESLAP;
+  if (agcn_get_fused_mode() < ((reslap && res_mixed) ? 1 : 3) || (agcn_get_spec_mode() & 3) != 3) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
-  if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || !use_slabs(d, g, pi)) return;
+  if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || (!reslap && !use_slabs(d, g, pi))) return;
   int nb = 0, ns = 0;
   while (nb < pi.B) {
     const int n = host.n[host.order[nb]];
@@ -158,7 +163,7 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   }
   if (nb == 0 || nb == pi.B || nb > std::max(2, pi.B / 16)) return;
   FusedSplit m{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  m.mode = 2; m.n_big = nb; m.n_big_slabs = ns; m.thr = host.n[host.order[nb]]; m.big_pg = 0;
+  m.mode = 2; m.n_big = nb; m.n_big_slabs = reslap ? 0 : ns; m.thr = host.n[host.order[nb]]; m.big_pg = reslap ? 1 : 0;
   m.spec_fwd = m.spec_bwd = 1; m.spec_bwd_first = nb; m.spec_small_first = pi.B;
   *f = m;
 }
@@ -243,7 +248,7 @@ void coop_reach(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
     const int n = host.n[host.order[k]];
     if (std::max(spec_fwd_lds_bytes(n, d->Fin, d->Fout, spec::NW_LARGE),
                  spec_bwd_lds_bytes(n, d->Fin, d->Fout, spec::NW_LARGE)) <= lim) break;
-    if (n > spec::COOP_MAX_N || spec_coop_lds_bytes(n, d->Fin, d->Fout) > lim || spec_coop_fwd_lds_bytes(n, d->Fin) > lim)
+    if (n > spec::COOP_MAX_N_WIDE || spec_coop_lds_bytes(n, d->Fin, d->Fout) > lim || spec_coop_fwd_lds_bytes(n, d->Fin) > lim)
       return;
     ++k;
   }
@@ -715,6 +720,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
         int cg = 0, cs = 0, dg = 0;
         coop_plan(desc, host, fs, false, &cg, &cs, &dg);
         a.coop_slabs = cs;
+        a.coop_wide = (cs > 0 && host.n[host.order[0]] > spec::COOP_MAX_N) ? 1 : 0;
         a.tp_first = std::max(cg, B - 32);   // (cg < B: the last graph of the schedule is never spread over members)
         size_t lds = spec_fwd_lds_bytes(host.n[host.order[cg]], desc->Fin, desc->Fout, spec::NW_LARGE);
         if (cs > 0) lds = std::max(lds, spec_coop_fwd_lds_bytes(host.n[host.order[0]], desc->Fin));
@@ -759,7 +765,11 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     rc = launch_rows_gemm(g, RG_PROJECT, ss.s);
     if (rc != AGCN_OK) return rc;
     if (fs.big_pg) {
-      rc = launch_sgc_forward(a, 0, fs.n_big, true, sgc_lds_bytes(host.n[host.order[0]], desc->Fin), ss.s);
+      // (the leading ones whose n x n tile does not fit LDS: the flavour with the tile in workspace)
+      const int ng = std::min(n_glb, fs.n_big);
+      if (ng > 0) rc = launch_sgc_forward(a, 0, ng, false, 4 * (32 + (size_t)((host.info.max_n + 3) & ~3)), ss.s);
+      if (rc == AGCN_OK && ng < fs.n_big)
+        rc = launch_sgc_forward(a, ng, fs.n_big - ng, true, sgc_lds_bytes(host.n[host.order[ng]], desc->Fin), ss.s);
     } else {
       SgcArgs ab = a;
       ab.n_slabs = fs.n_big_slabs;
@@ -993,7 +1003,10 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       rc = launch_rows_gemm(g, RG_FILTER_BWD, ss->s);
       if (rc != AGCN_OK) return rc;
       if (fs.big_pg) {
-        rc = launch_sgc_backward(a, 0, fs.n_big, true, sgc_lds_bytes_bwd(host.n[host.order[0]], desc->Fin), ss->s);
+        const int ng = std::min(w.n_glb, fs.n_big);
+        if (ng > 0) rc = launch_sgc_backward(a, 0, ng, false, 4 * (32 + 2 * (size_t)((host.info.max_n + 3) & ~3)), ss->s);
+        if (rc == AGCN_OK && ng < fs.n_big)
+          rc = launch_sgc_backward(a, ng, fs.n_big - ng, true, sgc_lds_bytes_bwd(host.n[host.order[ng]], desc->Fin), ss->s);
       } else {
         SgcArgs ab = a;
         ab.n_slabs = fs.n_big_slabs;
@@ -1027,6 +1040,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       // leading slabs of the slab table, which is in the same largest-first order), spec_backward_coop.h
       const int first_plain = coop_graphs;
       a.coop_slabs = coop_slabs;
+      a.coop_wide = (coop_slabs > 0 && host.n[host.order[0]] > spec::COOP_MAX_N) ? 1 : 0;
       // parameter gradients as trailing workgroups of this launch (spec_tail.h): a whole backward call only
       tail_done = stages == 3 && !conc && !two && spec_tail_ok(desc, host, fs, coop_graphs, coop_slabs) && grads->dweight &&
                   grads->dbias && grads->dM_L && grads->dalpha;

@@ -482,7 +482,7 @@ static bool pg_tagged_shape(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, 
   // flight per lane); from 5121 rows on two splits per XCD (HIV-shaped batches, ~6.4 k rows: 50 rows per wave in two rounds
   // measured 1 % SLOWER than the arrival-counter kernel, profiles/EXPERIMENTS.md)
   static const int s_force = [] { const char* e = std::getenv("AGCN_PG_TAG_SPLITS"); return e ? std::atoi(e) : 0; }();
-  const int s_target = (s_force == 8 || s_force == 16) ? s_force : (rows <= 5120 ? 8 : 16);
+  const int s_target = (s_force >= 2 && s_force <= 16) ? s_force : (rows <= 5120 ? 8 : 16);
   const int rpw = (rows + 16 * s_target - 1) / (16 * s_target);
   const int tfM = (Fin + 15) / 16, tc = (Fout + 31) / 32;   // dweight tiles per Chebyshev term (see the kernel)
   *nt_out = K * tfM * tc + tc + (paper ? tfM * ((Fin + 31) / 32) : 0);

@@ -58,6 +58,7 @@ struct SgcArgs {
   int32_t tail_first;    // schedule position of the first graph that is a unit of its own (the graphs before it are spread
   int32_t tail_graphs;   // over member slabs), and how many such graphs
   float *g_dweight, *g_dbias, *g_dM, *g_dalpha;
+  int32_t coop_wide;    // 1: a cooperative graph has more than COOP_MAX_N nodes (the launch takes the kernel variant with the wide members)
   int32_t coop_slabs;   // 16-wave launch: its first coop_slabs workgroups are members (slabs of the plan's slab table),
   int32_t plain_count;  // the next plain_count one graph each, the rest TWO small graphs each (spec_forward.hip)
   int32_t dual_stride;  // floats of LDS between the two halves of such a workgroup

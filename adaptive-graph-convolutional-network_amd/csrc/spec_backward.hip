@@ -680,14 +680,17 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
 // FULL: the launch may carry members of cooperative graphs and workgroups of two small graphs (16-wave flavour only; a
 // variant of its own so that launches without them keep the plain kernel's register allocation).
 // 8-wave flavour: held to AGCN_SMALL_OCC waves per SIMD where that does not spill much (feature widths up to 80).
-template <int FIN, int FOUT, int NW, bool FULL, bool RESLAP = false>
+// FULL == 2: as 1, with the WIDE members (graphs of up to COOP_MAX_N_WIDE nodes: 12 rows of an image per wave, three 64-column
+// passes per strip row -- more registers, so a variant of its own, launched only when a batch has such a graph).
+template <int FIN, int FOUT, int NW, int FULL, bool RESLAP = false>
 __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMALL_OCC) : 4) void spec_backward_kernel(SgcArgs a, int first) {
+  constexpr int MAXN = FULL == 2 ? COOP_MAX_N_WIDE : COOP_MAX_N;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if constexpr (RESLAP) {   // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
     int blk = (int)blockIdx.x;
     if constexpr (NW == NW_LARGE) {
       if (blk < a.coop_slabs) {
-        coop_backward_member<FIN, FOUT, true>(a, blk, smem);
+        coop_backward_member<FIN, FOUT, true, MAXN>(a, blk, smem);
         return;
       }
       blk -= a.coop_slabs;
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
       return;
     }
     if (blk < a.coop_slabs) {   // (spec_backward_coop.h)
-      coop_backward_member<FIN, FOUT>(a, blk, smem);
+      coop_backward_member<FIN, FOUT, false, MAXN>(a, blk, smem);
       return;
     }
     blk -= a.coop_slabs;
@@ -749,7 +752,10 @@ static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count
     if ((a.dual_pairs > 0 || a.coop_slabs > 0) && NW != spec::NW_LARGE) return fail(AGCN_EINVAL, "spec_backward: members / paired graphs need the 16-wave launch");
     SgcArgs aa = a;
     aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
-    auto kern = &spec::spec_backward_kernel<FIN, FOUT, NW, false, true>;
+    auto kern = &spec::spec_backward_kernel<FIN, FOUT, NW, 0, true>;
+    if constexpr (NW == spec::NW_LARGE) {
+      if (a.coop_wide && a.coop_slabs > 0) kern = &spec::spec_backward_kernel<FIN, FOUT, NW, 2, true>;
+    }
     if (lds_bytes > 64 * 1024) {
       hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes));
       if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_bwd): %s", hipGetErrorString(e));
@@ -762,10 +768,12 @@ static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count
     return AGCN_OK;
   }
   const bool full = NW == spec::NW_LARGE && (a.coop_slabs > 0 || a.dual_pairs > 0);
+  auto kern = &spec::spec_backward_kernel<FIN, FOUT, NW, 0>;
+  if constexpr (NW == spec::NW_LARGE) {
+    if (full) kern = (a.coop_wide && a.coop_slabs > 0) ? &spec::spec_backward_kernel<FIN, FOUT, NW, 2> : &spec::spec_backward_kernel<FIN, FOUT, NW, 1>;
+  }
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = static_cast<hipError_t>(
-        ensure_dynamic_lds(full ? reinterpret_cast<const void*>(&spec::spec_backward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>)
-                                : reinterpret_cast<const void*>(&spec::spec_backward_kernel<FIN, FOUT, NW, false>), lds_bytes));
+    hipError_t e = static_cast<hipError_t>(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes));
     if (e != hipSuccess) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(spec_bwd): %s", hipGetErrorString(e));
   }
   prof_begin(PK_SPEC_BWD, s);
@@ -774,8 +782,7 @@ static int launch_spec_backward_t(const SgcArgs& a, int32_t first, int32_t count
   aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
   const unsigned tiles = (NW == spec::NW_LARGE && aa.tail != nullptr) ? (unsigned)aa.tail_tiles : 0u;
   if (tiles == 0) { aa.tail = nullptr; aa.tail_tiles = 0; }
-  if (full) hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, NW == spec::NW_LARGE>), dim3(members + count + tiles), dim3(64 * NW), lds_bytes, s, aa, first);
-  else hipLaunchKernelGGL((spec::spec_backward_kernel<FIN, FOUT, NW, false>), dim3(members + count + tiles), dim3(64 * NW), lds_bytes, s, aa, first);
+  hipLaunchKernelGGL(kern, dim3(members + count + tiles), dim3(64 * NW), lds_bytes, s, aa, first);
   prof_end(s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "spec_backward launch: %s", hipGetErrorString(e));

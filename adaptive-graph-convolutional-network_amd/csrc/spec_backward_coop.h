@@ -40,6 +40,9 @@ constexpr int DUAL_MAX_N = 16;         // graphs that may be packed two to a wor
 // beyond the 96 nodes of the one-workgroup kernels (whose backward keeps two n x n tiles) as far as its LDS plan fits
 // (spec_coop_lds_bytes): lanes cover 128 columns, a wave 8 rows of an image, the epoch table 8 members.
 constexpr int COOP_MAX_N = 128;
+// ... and the WIDE members (a kernel variant of their own, launched only for a batch with such a graph: spec_backward.hip):
+// three 64-column passes, 12 rows of an image per wave -- HIV-shaped batches: 5.6 % have a molecule beyond 128 atoms, none beyond 192
+constexpr int COOP_MAX_N_WIDE = 192;
 // exchange header at the start of the reserve, per direction (0 backward, 1 forward): one slot per member row, one
 // epoch word per member (a graph uses the rows / the epoch of its first slab)
 constexpr int COOP_DIR_WORDS = COOP_MAX_MEMBERS * 16 + COOP_MAX_MEMBERS;
@@ -133,14 +136,15 @@ __device__ __forceinline__ uint64_t coop_pack(float v, uint32_t flag) {
 // for two graph-wide inner products, which the members exchange as sums (coop_graph_sum).  Every element-wise quantity is
 // evaluated for (i, j) AND (j, i) by the thread that owns (row i of the strip, column j): the row strips of L_pre / L_prev /
 // dL_sum arrive as coalesced loads, the column strips as gathers, all in that thread's registers.
-template <int FIN, int FOUT, bool RESLAP = false>
+template <int FIN, int FOUT, bool RESLAP = false, int MAXN = COOP_MAX_N>
 __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int sl, float* smem) {
-  __shared__ float coop_gs[8];
+  __shared__ float coop_gs[MAXN / 16];
+  constexpr int NCP = MAXN / 64;               // 64-column passes of a strip row (lanes cover MAXN columns)
   constexpr int NW = 16, NT = 1024;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64, NKW = FOUT / 4;
-  constexpr int RPW = 8;                       // rows of an [n x F] matrix one wave may own (n4 <= 128 = COOP_MAX_N)
+  constexpr int RPW = MAXN / 16;               // rows of an [n x F] matrix one wave may own (n4 <= MAXN)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -179,7 +183,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   // under one epoch counter, whatever graphs of whatever batches use it over time).  A member reads the epochs of all
   // members of its graph before it publishes anything and bumps its own when it is done -- by then it holds every
   // sibling's words, so every sibling has read the epochs.
-  uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [8] in the (otherwise unused) tail of the `red` area
+  uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [<= 16] in the (otherwise unused) tail of the `red` area
   if (tid < ntm)
     wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 
@@ -214,21 +218,21 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     }
   });
   // r rows of the strip: wave il owns row i0 + il (the forward stored both triangles for these graphs)
-  float rr[2];
+  float rr[NCP];
   {
     const int i = min(i0 + wave, n - 1);
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       rr[cp] = 0.f;
       if (64 * cp < n) rr[cp] = a.sv_r[toff + (uint32_t)(i * n + min(lane + 64 * cp, n - 1))];
     }
   }
   // Reslap: the COLUMN strip of La (wave il = column i0 + il, lanes run over the rows k): LT[il][k] = La[k][i0 + il]
-  float lac[2] = {0.f, 0.f};
+  float lac[NCP] = {};
   if constexpr (RESLAP) {
     const int i = min(i0 + wave, n - 1);
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp)
+    for (int cp = 0; cp < NCP; ++cp)
       if (64 * cp < n) lac[cp] = a.L_sum[toff + (uint32_t)(min(lane + 64 * cp, n - 1) * n + i)];
   }
   const float s_own = a.sv_s[row0 + min(tid, n - 1)];
@@ -268,7 +272,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   {
     const int i = i0 + wave;
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       const int j = lane + 64 * cp;
       if (j < n4) RS[wave * ldt + j] = (i < n && j < n && j != i) ? rr[cp] : 0.f;
     }
@@ -281,7 +285,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   if constexpr (RESLAP) {
     const int i = i0 + wave;
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       const int k = lane + 64 * cp;
       if (k < n4) LT[wave * ldt + k] = (i < n && k < n) ? lac[cp] : 0.f;
     }
@@ -294,7 +298,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     const int i = i0 + wave;
     const float si = s_vec[min(i, n4 - 1)];
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       const int k = lane + 64 * cp;
       if (k < n4) {
         float out = 0.f;
@@ -398,7 +402,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 4);
 
   // ---- M4: dL row strip (g_1[I] X_0^T) and column strip ((g_1 X_0[I]^T)^T = X_0[I] g_1^T);  Z rows requested --------
-  float lpr[2] = {0.f, 0.f}, lpc[2] = {0.f, 0.f}, lpv[2] = {0.f, 0.f}, dlsr[2] = {0.f, 0.f}, dlsc[2] = {0.f, 0.f};
+  float lpr[NCP] = {}, lpc[NCP] = {}, lpv[NCP] = {}, dlsr[NCP] = {}, dlsc[NCP] = {};
   {
     const float* Zg = a.sv_Z + (int64_t)row0 * FIN;
 #pragma unroll
@@ -414,7 +418,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       const bool has_prev = a.L_prev != nullptr && a.dL_prev != nullptr;
       const int i = min(i0 + wave, n - 1);
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
+      for (int cp = 0; cp < NCP; ++cp) {
         if (64 * cp < n) {
           const int j = min(lane + 64 * cp, n - 1);
           const uint32_t oij = toff + (uint32_t)(i * n + j), oji = toff + (uint32_t)(j * n + i);
@@ -457,7 +461,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 5);
   // ---- M5: pass 1 over the strip's rows (wave il = row i0 + il): dalpha, ds_i -> dd_i, published to the other members
   float dalpha_part = 0.f, dbeta_part = 0.f;
-  float dlpk[2] = {0.f, 0.f};
+  float dlpk[NCP] = {};
   if constexpr (RESLAP) {
     // adjoints of  La = lrelu(cn(Lpre)),  Lpre = R2 + L_orig + beta L_prev,  R2 = lrelu(cn(R))   (graphconv_reslap.py:184-198),
     // for (i, j) and (j, i); the strips DLr / DLc hold g_1 X_0^T and become dR_ij / dR_ji
@@ -470,10 +474,10 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     const int i = i0 + wave;
     const bool iv = i < n;
     const float si = s_vec[min(i, n4 - 1)];
-    float dij[2] = {0.f, 0.f}, dji[2] = {0.f, 0.f};     // dLc, then dLpre, dR1, dR
+    float dij[NCP] = {}, dji[NCP] = {};     // dLc, then dLpre, dR1, dR
     float dot_part = 0.f;
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       const int j = lane + 64 * cp;
       if (iv && j < n) {
         const float dLa_ij = DLr[wave * ldt + j] + dlsr[cp], dLa_ji = DLc[wave * ldt + j] + dlsc[cp];
@@ -486,10 +490,10 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     }
     const float dot = coop_graph_sum(a, dot_part, red, coop_gs, xsc, me, ntm, wants, tid);
     const float k3 = clipL ? dot * invL * invL * invL : 0.f;
-    float Rij[2] = {0.f, 0.f}, Rji[2] = {0.f, 0.f};
+    float Rij[NCP] = {}, Rji[NCP] = {};
     float dotR_part = 0.f;
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       const int j = lane + 64 * cp;
       if (iv && j < n) {
         if (clipL) {
@@ -516,7 +520,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     const float k3R = clipR ? dotR * invR * invR * invR : 0.f;
     float dsum = 0.f;
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
+    for (int cp = 0; cp < NCP; ++cp) {
       const int j = lane + 64 * cp;
       if (j < n4) {
         float dRij = 0.f, dRji = 0.f;
@@ -544,7 +548,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     if (i < n) {   // (uniform)
       const float si = s_vec[i];
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
+      for (int cp = 0; cp < NCP; ++cp) {
         const int j = lane + 64 * cp;
         if (j < n) {
           const float sj = s_vec[j];
@@ -582,7 +586,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     if (i < n) {
       const float si = s_vec[i], ddi = ddv[i];
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
+      for (int cp = 0; cp < NCP; ++cp) {
         const int j = lane + 64 * cp;
         if (j < n4) {
           float cij = 0.f;
@@ -606,7 +610,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       }
     } else {
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp)
+      for (int cp = 0; cp < NCP; ++cp)
         if (lane + 64 * cp < n4) DLr[wave * ldt + lane + 64 * cp] = 0.f;
     }
     rsum = wave_sum(rsum);
@@ -688,7 +692,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       const int i = i0 + wave;
       if (i < n) {
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp)
+        for (int cp = 0; cp < NCP; ++cp)
           if (lane + 64 * cp < n) a.dL_prev[toff + (uint32_t)(i * n + lane + 64 * cp)] = dlpk[cp];
       }
       if (i0 == 0 && tid < (int)((uint32_t)(a.tile_off[b + 1] - a.tile_off[b]) - (uint32_t)(n * n)))
@@ -750,9 +754,10 @@ AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4) {
 // members; degrees are wave sums (not the serial column sums of the one-workgroup kernel: last-ulp differences).
 // RESLAP (SGC_LL_Reslap, graphconv_reslap.py:184-198): the two clip_by_norm stages need ||R||_F and ||L_pre||_F of the WHOLE graph:
 // two more exchanges (coop_graph_sum), the same sums in the same order in every member.
-template <int FIN, int FOUT, bool RESLAP = false>
+template <int FIN, int FOUT, bool RESLAP = false, int MAXN = COOP_MAX_N>
 __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int sl, float* smem) {
-  __shared__ float coop_gs[8];
+  __shared__ float coop_gs[MAXN / 16];
+  constexpr int NCP = MAXN / 64;               // 64-column passes of a strip row (lanes cover MAXN columns)
   constexpr int NW = 16;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
@@ -777,7 +782,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   const float alpha = a.alpha[0];
   uint64_t* xch = a.sv_xch + COOP_DIR_WORDS + (sl - me) * 16;                     // direction 1
   uint64_t* xep = a.sv_xch + COOP_DIR_WORDS + COOP_MAX_MEMBERS * 16 + (sl - me);
-  uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [8], see coop_backward_member
+  uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [<= 16], see coop_backward_member
   if ((paper || RESLAP) && tid < ntm)
     wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   uint64_t* xsc = a.sv_xch + COOP_SCAL_WORD + 2 * COOP_MAX_MEMBERS + (sl - me);      // direction 1, kind 0; kind 1 COOP_MAX_MEMBERS on
@@ -816,11 +821,11 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     }
   }
   // Reslap: the strip's rows of L_prev (wave il = row i0 + il), requested with the first round of loads
-  float lprv[2] = {0.f, 0.f};
+  float lprv[NCP] = {};
   if constexpr (RESLAP) {
     if (a.L_prev != nullptr) {
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp)
+      for (int cp = 0; cp < NCP; ++cp)
         if (64 * cp < n) lprv[cp] = a.L_prev[toff + (uint32_t)(min(i0 + wave, n - 1) * n + min(lane + 64 * cp, n - 1))];
     }
   }
@@ -868,15 +873,28 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
 
   AGCN_STAMP(0, 2);
   // ---- P2: S[I, :], r[I, :], degree of the strip's rows (wave il = row i0 + il) -> s published -----------------------
-  float rkeep[2] = {0.f, 0.f}, skeep[2] = {0.f, 0.f}, sd_keep = 0.f;
+  float rkeep[NCP] = {}, skeep[NCP] = {}, sd_keep = 0.f;
   {
     const int i = i0 + wave;
     float dsum = 0.f;
     if (i < n) {   // (uniform)
-      float acc[2] = {0.f, 0.f};
+      float acc[NCP] = {};
       const int j0 = min(lane, n - 1), j1 = min(lane + 64, n - 1);
       const float* zi = Zt + i;
-      if (n > 64) {   // (uniform)
+      if constexpr (NCP > 2) {   // (wide members: n > 128)
+        int jc[NCP];
+#pragma unroll
+        for (int cp = 0; cp < NCP; ++cp) jc[cp] = min(lane + 64 * cp, n - 1);
+#pragma unroll 4
+        for (int f = 0; f < FIN; ++f) {
+          const float zv = zi[f * ldz];
+#pragma unroll
+          for (int cp = 0; cp < NCP; ++cp) {
+            const float dv = zv - Zt[f * ldz + jc[cp]];
+            acc[cp] = fmaf(dv, dv, acc[cp]);
+          }
+        }
+      } else if (n > 64) {   // (uniform)
 #pragma unroll 4
         for (int f = 0; f < FIN; ++f) {
           const float zv = zi[f * ldz];
@@ -892,7 +910,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         }
       }
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
+      for (int cp = 0; cp < NCP; ++cp) {
         const int j = lane + 64 * cp;
         if (j < n4) {
           float sv = 0.f;
@@ -907,7 +925,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       }
     } else {
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp)
+      for (int cp = 0; cp < NCP; ++cp)
         if (lane + 64 * cp < n4) St[wave * ldt + lane + 64 * cp] = 0.f;
     }
     dsum = wave_sum(dsum);
@@ -930,7 +948,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     const int i = i0 + wave;
     if (i < n) {
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
+      for (int cp = 0; cp < NCP; ++cp) {
         const int j = lane + 64 * cp;
         if (j < n) {
           const uint32_t o = toff + (uint32_t)(i * n + j);
@@ -953,12 +971,12 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     const int i = i0 + wave;
     if constexpr (RESLAP) {
       // R rows of the strip (kept in registers), ||R||_F^2 of the whole graph -> scR   (graphconv_reslap.py:185)
-      float Rk[2] = {0.f, 0.f};
+      float Rk[NCP] = {};
       float part = 0.f;
       if (i < n) {
         const float si = s_vec[i];
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
+        for (int cp = 0; cp < NCP; ++cp) {
           const int j = lane + 64 * cp;
           if (j < n) {
             float R = (i == j) ? 1.f : 0.f;
@@ -975,7 +993,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       const float beta = has_prev ? a.beta[0] : 0.f;
       if (i < n) {
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
+        for (int cp = 0; cp < NCP; ++cp) {
           const int j = lane + 64 * cp;
           if (j < n) {
             const float R2 = lrelu(Rk[cp] * scR, alpha);
@@ -997,10 +1015,10 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       lds_barrier();
       // ||L_pre||_F^2 of the whole graph -> scL; second clip + leaky-ReLU (:194-198): L_pre out (reserve), La -> strip + 4th output
       float part2 = 0.f;
-      float vk[2] = {0.f, 0.f};
+      float vk[NCP] = {};
       if (i < n) {
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
+        for (int cp = 0; cp < NCP; ++cp) {
           const int j = lane + 64 * cp;
           if (j < n) {
             vk[cp] = St[wave * ldt + j];
@@ -1012,7 +1030,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       scL = clip_scale(ssL, 1.0f);
       if (i < n) {
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
+        for (int cp = 0; cp < NCP; ++cp) {
           const int j = lane + 64 * cp;
           if (j < n) {
             const float La = lrelu(vk[cp] * scL, alpha);
@@ -1028,7 +1046,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     if (i < n) {
       const float si = s_vec[i];
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
+      for (int cp = 0; cp < NCP; ++cp) {
         const int j = lane + 64 * cp;
         if (j < n) {
           const float S = St[wave * ldt + j];

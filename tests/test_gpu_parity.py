@@ -732,34 +732,54 @@ def test_full_size_every_graph_every_gradient(amd, variant, mode, B):
     compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
 
 
-@pytest.mark.parametrize("reach", ["beyond_members", "within_members"])
+def _hiv_batch_for_reach(reach, Fin, features):
+    """An HIV-shaped 256-graph batch with 1-4 molecules beyond the one-workgroup kernels' 96 nodes whose LARGEST molecule is
+    within the members' reach (<= 128 atoms), within the wide members' (129 .. 192) or beyond every member (the largest
+    molecule of a within-reach batch replaced by one of 200 atoms: the synthetic distribution has none that large)."""
+    want_wide = reach == "wide_members"
+    for seed in range(40, 400):      # (the node counts are the first thing synth_batch draws from its seed)
+        nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
+        big = int((nsa > 96).sum())
+        if 1 <= big <= 4 and ((128 < nsa.max() <= 192) if want_wide else (nsa.max() <= 128)):
+            break
+    else:
+        pytest.fail("no seed gives such a batch")
+    sb = orc.synth_batch(seed, 256, Fin=Fin, mu=np.log(23.0), hi=222, features=features)
+    assert np.array_equal(np.asarray(sb["ns"]), nsa)
+    if reach == "beyond_members":
+        rs = np.random.RandomState(1000 + seed)
+        k, nb = int(np.argmax(nsa)), 200
+        adj = orc.synth_adj_lists(rs, nb)
+        x = orc.synth_atom_features(rs, nb) if (features == "atoms" and Fin == 75) else np.maximum(rs.randn(nb, Fin), 0).astype(np.float32)
+        indptr, indices, data, L = orc.graph_laplacian(adj)
+        sb["ns"] = np.asarray(sb["ns"]).copy()
+        sb["ns"][k] = nb
+        sb["X"][k], sb["adj"][k], sb["L0"][k], sb["csr"][k] = x, adj, L.astype(np.float32), (indptr, indices, data)
+    return seed, sb
+
+
+@pytest.mark.parametrize("reach", ["beyond_members", "wide_members", "within_members"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach):
     """BASELINE configs[4]'s batch shape (HIV-like sizes, mu = ln 23, up to 222 atoms): a 256-graph batch with a few
     molecules beyond the one-workgroup kernels' 96-node LDS plan.
     within_members (largest molecule <= 128 atoms, paper mode): the specialised kernels take the batch, the oversized
-    molecules spread over member workgroups.  beyond_members (a molecule > 128 atoms; or reference mode): the whole
+    molecules spread over member workgroups.  wide_members (129 .. 192 atoms, paper mode): the same, with the kernel
+    variant whose members cover three 64-column passes.  beyond_members (a 200-atom molecule; or reference mode): the whole
     batch takes the slab kernels by default; with agcn_set_fused_mode(3) the oversized molecules take the slab kernels
     on the side stream beside the specialised kernels ("mixed" dispatch).  The launches must be exactly that, and
     EVERY graph and EVERY gradient must match the float64 oracle either way."""
     Fin, Fout, K = 75, 64, 2
-    for seed in range(40, 400):      # (the node counts are the first thing synth_batch draws from its seed)
-        nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
-        big = int((nsa > 96).sum())
-        if 1 <= big <= 4 and ((nsa.max() > 128) == (reach == "beyond_members")):
-            break
-    else:
-        pytest.fail("no seed gives such a batch")
-    sb = orc.synth_batch(seed, 256, mu=np.log(23.0), hi=222)
-    assert np.array_equal(np.asarray(sb["ns"]), nsa)
+    seed, sb = _hiv_batch_for_reach(reach, Fin, "atoms")
     ns = [int(v) for v in sb["ns"]]
+    assert (max(ns) > 192) == (reach == "beyond_members") and (max(ns) > 128) == (reach != "within_members")
     rs = np.random.RandomState(seed)
     p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL)
     p["alpha"] = np.array([0.8], np.float32)
     G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
     caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, orc.SGC_LL, G, None, None)
     lib = amd._ffi.lib()
-    members_take_it = reach == "within_members" and mode == orc.PAPER
+    members_take_it = reach != "beyond_members" and mode == orc.PAPER
     for fused_mode in (1, 3):      # 1 (default); 3: mixed dispatch allowed
         lib.agcn_set_fused_mode(fused_mode)
         try:
@@ -778,27 +798,22 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach)
             assert ("spec_backward_kernel" in names[1]) == (fused_mode == 3), names
 
 
-@pytest.mark.parametrize("reach", ["beyond_members", "within_members"])
+@pytest.mark.parametrize("reach", ["beyond_members", "wide_members", "within_members"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode, reach):
     """The SGC_LL_Reslap twin of the test above (every convolution of ResAGCN.py:79-92 / DenseAGCN.py:112-146 is one): an
     HIV-shaped 256-graph batch, 64 -> 64, with a few molecules beyond the one-workgroup kernels' 96 nodes, a previous Laplacian
-    and a gradient arriving on L_sum.  within_members (largest molecule <= 128 atoms, paper mode): the specialised kernels
-    take the batch, the oversized molecules spread over member workgroups (which exchange the graph-wide clip norms and inner
-    products).  Beyond that (or reference mode: its backward has no members) SGC_LL_Reslap has no slab flavour: the batch
-    leaves the specialised kernels WHOLE for the general per-graph path.  Whatever runs, EVERY graph's Y / res_W / res_L /
+    and a gradient arriving on L_sum.  within_members / wide_members (largest molecule <= 128 / <= 192 atoms, paper mode): the
+    specialised kernels take the batch, the oversized molecules spread over member workgroups (which exchange the graph-wide
+    clip norms and inner products).  Beyond that (or reference mode: its backward has no members) SGC_LL_Reslap has no slab flavour: the oversized
+    molecules take the general per-graph kernels on the side stream, the rest of the batch the specialised kernels beside
+    them ("mixed" dispatch, the default for SGC_LL_Reslap).  Whatever runs, EVERY graph's Y / res_W / res_L /
     L_sum and EVERY gradient (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) must match the float64 oracle; the kernels
     that ran are asserted so that a change of dispatch shows up here."""
     Fin, Fout, K = 64, 64, 2
-    for seed in range(40, 400):
-        nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
-        big = int((nsa > 96).sum())
-        if 1 <= big <= 4 and ((nsa.max() > 128) == (reach == "beyond_members")):
-            break
-    else:
-        pytest.fail("no seed gives such a batch")
-    sb = orc.synth_batch(seed, 256, Fin=Fin, mu=np.log(23.0), hi=222, features="normal")
+    seed, sb = _hiv_batch_for_reach(reach, Fin, "normal")
     ns = [int(v) for v in sb["ns"]]
+    assert (max(ns) > 192) == (reach == "beyond_members") and (max(ns) > 128) == (reach != "within_members")
     rs = np.random.RandomState(seed)
     p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL_RESLAP)
     p["alpha"] = np.array([0.8], np.float32)
@@ -822,12 +837,14 @@ def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode,
             seen[fused_mode] = st.kernel_names()
         finally:
             lib.agcn_set_fused_mode(1)
-    if reach == "within_members" and mode == orc.PAPER:
+    if reach != "beyond_members" and mode == orc.PAPER:
         assert seen[1][0] == "spec_forward_kernel" and seen[1][1] == "spec_backward_kernel", seen
     else:
-        # nothing specialised (no Reslap flavour reaches beyond 128 nodes), the per-graph kernels do all of it
-        assert "spec_forward_kernel" not in seen[1][0] and "sgc_forward_kernel" in seen[1][0], seen
-        assert "spec_backward_kernel" not in seen[1][1] and "sgc_backward_kernel" in seen[1][1], seen
+        # mixed dispatch: the oversized molecules (no Reslap flavour of the members reaches beyond 128 nodes, the reference-mode
+        # backward has no members) take the per-graph kernels on the side stream, everything else the specialised kernels
+        for fm in (1, 3):
+            assert "spec_forward_kernel" in seen[fm][0] and "sgc_forward_kernel" in seen[fm][0], seen
+            assert "spec_backward_kernel" in seen[fm][1] and "sgc_backward_kernel" in seen[fm][1], seen
     print("Reslap, oversized molecules:", seen)
 
 

@@ -249,10 +249,22 @@ def test_dispatch_table(amd):
     # a molecule beyond the specialised kernels' 96 nodes: the whole batch on the slab kernels (general fused kernels
     # when it is small enough for them); other layer widths / Reslap: general fused kernels
     n = n256.copy()
-    n[3] = 150
+    n[3] = 200
     assert _dispatch(amd, n, 75, 64, 1)["path"] == 16 and not _dispatch(amd, n, 75, 64, 1)["bf16"]
     assert _dispatch(amd, tox(2048), 75, 64, 1)["bf16"] and not _dispatch(amd, n256, 75, 64, 1, variant=1)["bf16"]
-    # ... unless it is within the members' reach (<= 128 nodes, paper mode): specialised kernels, that graph on 8 members
+    # ... unless it is within the members' reach (<= 128 nodes; <= 192 on the kernel variant with the wide members, as far as
+    # their LDS plan fits; paper mode): specialised kernels, that graph on 8 (10) members
+    n[3] = 150
+    d = _dispatch(amd, n, 75, 64, 1)
+    assert d["path"] & 7 == 7 and d["f_members"] >= 10 and d["b_members"] == d["f_members"]
+    assert _dispatch(amd, n, 75, 64, 0)["path"] == 16
+    d = _dispatch(amd, n, 64, 64, 1, variant=1)
+    assert d["path"] == 7 and d["f_members"] >= 10 and d["b_members"] == d["f_members"]
+    n[3] = 180      # (75 -> 64: the members' images of 180 rows x 80 features do not fit LDS; 64 -> 64 does)
+    assert _dispatch(amd, n, 75, 64, 1)["path"] == 16
+    assert _dispatch(amd, n, 64, 64, 1, variant=1)["path"] == 7
+    n[3] = 200      # SGC_LL_Reslap beyond every member: mixed dispatch (that molecule on the per-graph kernels, side stream)
+    assert _dispatch(amd, n, 64, 64, 1, variant=1)["path"] == 8
     n[3] = 120
     d = _dispatch(amd, n, 75, 64, 1)
     assert d["path"] == 7 | 128 and d["f_graphs"] >= 1 and d["f_members"] >= 8 and d["b_members"] == d["f_members"]
@@ -271,7 +283,7 @@ def test_dispatch_table(amd):
     assert d["path"] == 7 and d["f_members"] > 40 and d["b_members"] == 0
     d = _dispatch(amd, n, 64, 64, 1, variant=1)
     assert d["path"] == 7 and d["f_members"] >= 8 and d["b_members"] == d["f_members"]
-    assert _dispatch(amd, n, 64, 64, 0, variant=1)["path"] == 32   # (reference mode, 120 nodes: the general per-graph kernels)
+    assert _dispatch(amd, n, 64, 64, 0, variant=1)["path"] == 8    # (reference mode, 120 nodes: mixed -- that molecule on the per-graph kernels)
     assert _dispatch(amd, n256, 80, 64, 1, variant=1)["path"] == 4
     assert _dispatch(amd, n256, 75, 64, 1, K=3)["path"] == 32
     del rs
