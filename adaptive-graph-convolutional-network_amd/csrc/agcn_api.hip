@@ -153,6 +153,11 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   if (agcn_get_fused_mode() < ((reslap && res_mixed) ? 1 : 3) || (agcn_get_spec_mode() & 3) != 3) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || (!reslap && !use_slabs(d, g, pi))) return;
+  if (reslap && g->L0_dense != nullptr) {   // (point clouds -- every graph a multiple of 64 nodes, dense L_orig -- stay with the cloud kernels)
+    bool all64 = true;
+    for (int i = 0; i < pi.B && all64; ++i) all64 = (host.n[i] & 63) == 0;
+    if (all64) return;
+  }
   int nb = 0, ns = 0;
   while (nb < pi.B) {
     const int n = host.n[host.order[nb]];

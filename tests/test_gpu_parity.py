@@ -313,7 +313,7 @@ def test_bf16_feature_storage(amd):
     assert torch.equal(CastRowsFunction.apply(x.to(torch.bfloat16), torch.float32), x.to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("shape", ["tox21_b256", "hiv_within_reach", "hiv_beyond_reach", "reference_mode"])
+@pytest.mark.parametrize("shape", ["tox21_b256", "hiv_within_reach", "hiv_wide_reach", "hiv_beyond_reach", "reference_mode"])
 def test_bf16_features_every_graph(amd, shape):
     """BASELINE config 4 ("bf16 features + fp32 Laplacian") at batch size, every graph: bf16 node features / upstream gradients
     in, bf16 activations / input gradients out, fp32 tiles, Laplacian and parameter gradients.  Where every graph of the batch
@@ -326,13 +326,9 @@ def test_bf16_features_every_graph(amd, shape):
     mode = orc.REFERENCE if shape == "reference_mode" else orc.PAPER
     if shape in ("tox21_b256", "reference_mode"):
         sb = orc.synth_batch(123, 256)
-    else:
-        want_beyond = shape == "hiv_beyond_reach"
-        for seed in range(40, 400):
-            nsa = np.asarray(orc.synth_node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222))
-            if int((nsa > 96).sum()) >= 1 and ((nsa.max() > 128) == want_beyond):
-                break
-        sb = orc.synth_batch(seed, 256, mu=np.log(23.0), hi=222)
+    else:   # (largest molecule <= 128 atoms: members; 129 .. 192: the wide members; a 200-atom molecule: beyond both)
+        _, sb = _hiv_batch_for_reach({"hiv_within_reach": "within_members", "hiv_wide_reach": "wide_members",
+                                      "hiv_beyond_reach": "beyond_members"}[shape], Fin, "atoms")
     ns = [int(v) for v in sb["ns"]]
     rs = np.random.RandomState(17)
     p = orc.init_params(rs, Fin, Fout, K)

@@ -1,6 +1,6 @@
 """Randomised check of the specialised kernels' dispatch (plain workgroups, cooperative members, paired small graphs,
 8-/16-wave launches side by side) against the float64 oracle: random batch sizes around the thresholds, graph sizes up
-to 128 nodes, the five covered layer shapes, both Laplacian modes.
+to 210 nodes (the members reach 128, the wide members 192), the five covered layer shapes, both Laplacian modes.
 usage: python tools/fuzz_spec.py [n_cases] [seed]"""
 import os
 import sys
@@ -23,6 +23,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     import agcn_amd as amd
     rs0 = np.random.RandomState(seed)
+    only = int(os.environ.get("AGCN_FUZZ_ONLY", "-1"))
     fails = 0
     for case in range(n_cases):
         B = int(rs0.choice([1, 2, 3, 7, 16, 33, 64, 120, 200, 255, 256, 257, 300, 390, 520, 1030]))
@@ -30,6 +31,8 @@ def main():
         ns = [int(v) for v in np.clip(np.rint(rs0.lognormal(mu, 0.6, size=B)), 1, 96)]
         if rs0.rand() < 0.4:      # thresholds of the dispatch, incl. graphs only the members can take (97 .. 128)
             ns[int(rs0.randint(B))] = int(rs0.choice([128, 127, 113, 112, 97, 96, 95, 81, 80, 65, 64, 49, 48, 33]))
+        elif rs0.rand() < 0.35:   # ... and only the WIDE members (129 .. 192; beyond their LDS plan / beyond 192: slab or mixed dispatch)
+            ns[int(rs0.randint(B))] = int(rs0.choice([129, 143, 144, 145, 158, 160, 161, 176, 177, 191, 192, 193, 210]))
         Fin, Fout = SHAPES[int(rs0.randint(len(SHAPES)))]
         mode = orc.PAPER if rs0.rand() < 0.7 else orc.REFERENCE
         # a third of the cases: SGC_LL_Reslap (members exchange the graph-wide clip norms / inner products too), with or
@@ -44,19 +47,44 @@ def main():
                 Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
             if rs0.rand() < 0.6:
                 dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
+        if only >= 0 and case != only:      # (AGCN_FUZZ_ONLY: every random draw of the skipped cases has been made above)
+            continue
         try:
             out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, 2, mode, variant, Lp, dLs)
             if variant == orc.SGC_LL_RESLAP:
                 caches, tot, tot32 = oracle_pair(X, L0, p, 2, mode, variant, G, Lp, dLs, Y_got=np.concatenate(out["Y"]))
                 compare_with_oracle(out, caches, tot, variant, mode, 2, has_prev=Lp is not None, tot32=tot32)
             else:
-                caches, tot = oracle_run(X, L0, p, 2, mode, variant, G, None, None)
+                # (activation ties settled on the side the kernel's Y is on: with ~2 M activations per large case one pre-activation
+                #  within rounding of zero is expected now and then -- seed 11, case 53: +1.5e-7 in float64, 0 in fp32)
+                caches, tot = oracle_run(X, L0, p, 2, mode, variant, G, None, None, Y_tie=np.concatenate(out["Y"]))
                 compare_with_oracle(out, caches, tot, variant, mode, 2, has_prev=False)
             print("ok   case %d: B=%d max_n=%d n>=33: %d n<=16: %d %d->%d mode=%d%s" % (
                 case, B, max(ns), sum(v >= 33 for v in ns), sum(v <= 16 for v in ns), Fin, Fout, mode,
                 "" if variant == orc.SGC_LL else " Reslap prev=%d dLs=%d" % (Lp is not None, dLs is not None)), flush=True)
         except Exception as e:      # noqa: BLE001
             fails += 1
+            if only >= 0:      # which graphs: size, schedule position (largest first), worst dX error
+                order = np.argsort(-np.asarray(ns), kind="stable")
+                pos = np.empty(B, np.int64)
+                pos[order] = np.arange(B)
+                ref = tot["dX"]
+                for b in range(B):
+                    err = float(np.abs(out["dX"][b] - ref[b]).max()) / (float(np.abs(ref[b]).max()) + 1e-30)
+                    if err > 1e-3:
+                        print("  graph %d: n=%d, schedule position %d, dX rel err %.3g" % (b, ns[b], pos[b], err), flush=True)
+                        # the same graph ALONE (its dX does not depend on the rest of the batch)
+                        o1 = run_packed(amd, DEV, [ns[b]], [X[b]], [csr[b]], p, [G[b]], Fin, Fout, 2, mode, variant,
+                                        None if Lp is None else [Lp[b]], None if dLs is None else [dLs[b]])
+                        e1 = float(np.abs(o1["dX"][0] - ref[b]).max()) / (float(np.abs(ref[b]).max()) + 1e-30)
+                        eY = float(np.abs(out["Y"][b] - o1["Y"][0]).max())
+                        rows = np.abs(out["dX"][b] - ref[b]).max(axis=1) / (float(np.abs(ref[b]).max()) + 1e-30)
+                        ypre = caches[b]["Ypre"]
+                        flips = np.argwhere((out["Y"][b] > 0) != (ypre > 0))
+                        print("    ReLU sign differences against the float64 oracle (row, column, HIP Y, oracle pre-activation): %s" % (
+                            [(int(i), int(j), float(out["Y"][b][i, j]), float(ypre[i, j])) for i, j in flips[:8]]), flush=True)
+                        print("    alone: dX rel err %.3g; Y batch-vs-alone max diff %.3g; rows with error > 1e-3: %s" % (
+                            e1, eY, np.nonzero(rows > 1e-3)[0].tolist()), flush=True)
             print("FAIL case %d: B=%d max_n=%d %d->%d mode=%d variant=%d -> %s" % (case, B, max(ns), Fin, Fout, mode, variant,
                                                                                   str(e)[:300]), flush=True)
     print("failures:", fails)

@@ -18,11 +18,19 @@ scale = float(os.environ.get("AGCN_STRESS_SCALE", "1"))
 bad = 0
 # (the last case: SGC_LL_Reslap, whose members also exchange the graph-wide clip norms / inner products -- three exchanges in a
 #  row per direction, csrc/spec_backward_coop.h: coop_graph_sum)
-for (B, mu, hi, reslap) in ((256, np.log(16.0), 132, False), (256, np.log(23.0), 128, False), (100, np.log(30.0), 96, False),
-                            (256, np.log(23.0), 128, True)):
+# (wide: a seed whose batch has a molecule of 129 .. 192 atoms -- the kernel variant with the wide members)
+for (B, mu, hi, reslap, wide) in ((256, np.log(16.0), 132, False, False), (256, np.log(23.0), 128, False, False), (100, np.log(30.0), 96, False, False),
+                                  (256, np.log(23.0), 128, True, False), (256, np.log(23.0), 222, False, True), (256, np.log(23.0), 222, True, True)):
     Fin = 64 if reslap else 75
-    data = synth.tox21_batch(7, B, Fin, mu=mu, hi=hi)
+    seed = 7
+    if wide:
+        for seed in range(40, 400):
+            nsa = synth.node_counts(np.random.RandomState(seed), B, mu=mu, hi=hi)
+            if 128 < nsa.max() <= 160:
+                break
+    data = synth.tox21_batch(seed, B, Fin, mu=mu, hi=hi)
     gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
+    assert (int(data["n"].max()) > 128) == wide
     if reslap:
         layer = amd.SGC_LL_Reslap(64, Fin, B, K=2, laplacian_mode="paper", device=dev)
         layer.load_vars(synth.glorot_params(np.random.RandomState(1), Fin, 64, 2, reslap=True))
@@ -32,6 +40,8 @@ for (B, mu, hi, reslap) in ((256, np.log(16.0), 132, False), (256, np.log(23.0),
         layer = amd.SGC_LL(64, Fin, B, K=2, laplacian_mode="paper", device=dev)
         layer.load_vars(synth.glorot_params(np.random.RandomState(1), Fin, 64, 2))
         extra = {}
+    if wide:
+        assert amd._ffi.dispatch_info(layer, gb)[0] & 7 == 7 and amd._ffi.dispatch_info(layer, gb)[6] >= 9, "the wide batch must run on members"
     dY = torch.randn(gb.plan.rows, 64, device=dev)
     steps = [amd.SgcLLStep(layer, gb, dY=dY, **extra) for _ in range(2)]
     steps[0].step()
