@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""SGC_LL_Reslap 64 -> 64 (with L_prev and a gradient on L_sum) on HIV-shaped 256-graph batches: one whose largest molecule is
-within the cooperative members' reach (<= 128 atoms) and one beyond it, per agcn_set_fused_mode setting -- what the dispatch
-costs when a batch leaves the specialised kernels.  Prints one JSON line per case: us per step (HIP-graph replay) + kernels."""
+"""SGC_LL_Reslap 64 -> 64 (with L_prev) or SGC_LL 64 -> 64 on HIV-shaped 256-graph batches: one whose largest molecule is within the
+cooperative members' reach (<= 128 atoms), one within the WIDE members' (129 .. 192) and one beyond both (that batch's largest
+molecule replaced by one of 200 atoms), per agcn_set_fused_mode setting -- what the dispatch costs when a batch leaves the
+specialised kernels.  usage: probe_reslap_reach.py reslap|sgc.  One JSON line per case: us per step (HIP-graph replay) + kernels."""
 import json
 import os
 import sys
@@ -24,7 +25,7 @@ def pick(beyond):
     for seed in range(40, 400):
         nsa = synth.node_counts(np.random.RandomState(seed), 256, mu=np.log(23.0), hi=222)
         big = int((nsa > 96).sum())
-        if 1 <= big <= 4 and ((nsa.max() > 128) == beyond):
+        if 1 <= big <= 4 and ((128 < nsa.max() <= 192) if beyond else (nsa.max() <= 128)):
             return seed, int(nsa.max())
     raise SystemExit("no seed")
 
@@ -40,9 +41,17 @@ def timed(fn, steps=200, warmup=20):
     return (time.perf_counter() - t0) / steps
 
 
-for beyond in (False, True):
-    seed, nmax = pick(beyond)
+from agcn_amd.graph_structure import laplacian_csr   # noqa: E402
+for beyond in (False, True, None):
+    seed, nmax = pick(bool(beyond))
     data = synth.tox21_batch(seed, 256, 64, mu=np.log(23.0), hi=222)
+    if beyond is None:      # beyond every member: a 200-atom molecule in place of the largest one
+        rs = np.random.RandomState(5)
+        k, nmax = int(np.argmax(data["n"])), 200
+        data["n"] = data["n"].copy()
+        data["n"][k] = nmax
+        data["X"][k] = np.maximum(rs.randn(nmax, 64), 0).astype(np.float32)
+        data["csr"][k] = laplacian_csr(synth.molecule_adjacency(rs, nmax))
     gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], dev)
     for fm in (1, 3):
         lib.agcn_set_fused_mode(fm)
