@@ -185,9 +185,18 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   if (d->variant != AGCN_SGC_LL && !reslap) return;
   static const int res_coop = [] { const char* e = std::getenv("AGCN_RESLAP_COOP"); return e ? std::atoi(e) : 3; }();   // bit 0 forward, bit 1 backward
   if (reslap && !((res_coop >> (backward ? 1 : 0)) & 1)) return;
-  if ((d->mode != AGCN_MODE_PAPER && backward) || fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 ||
-      fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
+  if (fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 || fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
     return;
+  if (d->mode != AGCN_MODE_PAPER && backward) {
+    // reference mode: members only for the graphs no single workgroup can hold (coop_reach: the fs.coop_forced leading ones)
+    int s = 0;
+    for (int k = 0; k < fs.coop_forced && k < B - 1; ++k) s += (host.n[host.order[k]] + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
+    if (fs.coop_forced > 0 && fs.coop_forced < B && s <= std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members()) &&
+        B + s - fs.coop_forced <= current_device_info().n_cus + current_device_info().n_cus / 2) {
+      *graphs = fs.coop_forced; *slabs = s;
+    }
+    return;
+  }
   // Members are whole-CU workgroups like every other one.  While the launch still fits the chip (graphs + extra
   // members <= CUs) every graph of three tiles and up is spread out (B = 128: backward 27.2 -> 17.8 us).  Beyond
   // that an extra workgroup starts only when another one has finished -- 12 us even for the smallest graph -- and
@@ -240,11 +249,11 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
 }
 // Batches whose few largest graphs are beyond the one-workgroup kernels (n > 96) but within the members' reach
 // (n <= COOP_MAX_N and their LDS plan fits): the specialised kernels take the batch with those graphs spread over
-// members -- instead of the whole batch on the slab kernels (HIV-shaped epoch: 36 % of the batches).  Paper mode (the
-// reference-mode backward has no members), one 16-wave launch.
+// members -- instead of the whole batch on the slab kernels (HIV-shaped epoch: 36 % of the batches).  One 16-wave launch.
+// (Reference mode: the backward spreads exactly these graphs -- its plain workgroups have no n x n work worth spreading.)
 void coop_reach(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host, size_t lim) {
   const AgcnPlanInfo& pi = host.info;
-  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 || d->mode != AGCN_MODE_PAPER ||
+  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 ||
       (d->variant != AGCN_SGC_LL && d->variant != AGCN_SGC_LL_RESLAP)) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || pi.B >= 1024 || pi.B < 2) return;
@@ -264,6 +273,8 @@ void coop_reach(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   int cg = 0, cs = 0, dg = 0;
   coop_plan(d, host, m, true, &cg, &cs, &dg);
   if (cg < k) return;   // (the planner would not spread all of them: member budget, batch too large)
+  coop_plan(d, host, m, false, &cg, &cs, &dg);
+  if (cg < k) return;
   *f = m;
 }
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host);

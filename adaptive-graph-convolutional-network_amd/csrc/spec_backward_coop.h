@@ -155,6 +155,10 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
   const int me = i0 >> 4;                      // member index == this strip's row tile
   const bool relu = a.activation == AGCN_ACT_RELU;
+  // REFERENCE mode (R = I: no gradient reaches the similarity tile): the members exist for the graphs no single workgroup can hold
+  // (n > 96); the pair passes, the dd exchange and dZ are skipped -- SGC_LL: dX[I] = g_0[I] + L^T[I, :] g_1 and the Gp rows;
+  // SGC_LL_Reslap: also the clip adjoints towards dL_prev / dbeta / dalpha (one exchanged inner product)
+  const bool paper = a.mode == AGCN_MODE_PAPER;
   const bool tail = !RESLAP && a.tail != nullptr;         // (spec_tail.h)
   const uint32_t tgen = tail ? tail_load(a.tail + TAIL_GEN) : 0u;
   if (tail && tid == 0) tail_started(a, tgen);
@@ -224,7 +228,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 #pragma unroll
     for (int cp = 0; cp < NCP; ++cp) {
       rr[cp] = 0.f;
-      if (64 * cp < n) rr[cp] = a.sv_r[toff + (uint32_t)(i * n + min(lane + 64 * cp, n - 1))];
+      if (paper && 64 * cp < n) rr[cp] = a.sv_r[toff + (uint32_t)(i * n + min(lane + 64 * cp, n - 1))];
     }
   }
   // Reslap: the COLUMN strip of La (wave il = column i0 + il, lanes run over the rows k): LT[il][k] = La[k][i0 + il]
@@ -303,9 +307,9 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       if (k < n4) {
         float out = 0.f;
         if (i < n && k < n) {
-          const float S = (i == k) ? 0.f : fast_exp_neg(RS[wave * ldt + k]);
+          const float S = (i == k || !paper) ? 0.f : fast_exp_neg(RS[wave * ldt + k]);
           float R = (i == k) ? 1.f : 0.f;
-          R = R - (s_vec[k] * S) * si;
+          if (paper) R = R - (s_vec[k] * S) * si;
           out = lrelu(R, alpha);
           if (L0d) out += L0d[(int64_t)k * l0ld + i];
         }
@@ -431,6 +435,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     }
     int ta, tb;
     tile_range<NW>(2 * ntm, wave, ta, tb);
+    if (!paper && !RESLAP) tb = ta;      // (SGC_LL, reference mode: no gradient reaches the tile)
     for (int t = ta; t < tb; ++t) {
       const bool col = t >= ntm;
       const int ct = col ? t - ntm : t;
@@ -505,10 +510,10 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
           dlpk[cp] = dij[cp] * beta;      // dL_prev[i][j]: stored with everything else at the end (no store in front of a load)
         }
         const float sj = s_vec[j];
-        const float Sv = (i == j) ? 0.f : fast_exp_neg(RS[wave * ldt + j]);
+        const float Sv = (i == j || !paper) ? 0.f : fast_exp_neg(RS[wave * ldt + j]);
         const float dlt = (i == j) ? 1.f : 0.f;
-        Rij[cp] = dlt - (si * Sv) * sj;
-        Rji[cp] = dlt - (sj * Sv) * si;
+        Rij[cp] = paper ? dlt - (si * Sv) * sj : dlt;
+        Rji[cp] = paper ? dlt - (sj * Sv) * si : dlt;
         const float R1ij = Rij[cp] * scR, R1ji = Rji[cp] * scR;
         dalpha_part += dij[cp] * fminf(R1ij, 0.f);
         dij[cp] = dij[cp] * lrelu_grad(R1ij, alpha);          // dR1
@@ -528,7 +533,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
           dRij = clipR ? dij[cp] * invR - Rij[cp] * k3R : dij[cp];
           dRji = clipR ? dji[cp] * invR - Rji[cp] * k3R : dji[cp];
           const float sj = s_vec[j];
-          const float Sv = (i == j) ? 0.f : fast_exp_neg(RS[wave * ldt + j]);
+          const float Sv = (i == j || !paper) ? 0.f : fast_exp_neg(RS[wave * ldt + j]);
           dsum += (-dRij * Sv) * sj + (-dRji * Sv) * sj;         // P_ij s_j + P_ji s_j, P = dA . S, dA = -dR
         }
         DLr[wave * ldt + j] = dRij;
@@ -536,12 +541,12 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       }
     }
     dsum = wave_sum(dsum);
-    if (lane == 0 && iv) {
+    if (paper && lane == 0 && iv) {
       const float ddk = degree_grad(s_vec[i], dsum);   // dd_k = -1/2 s_k^3 ds_k
       ddv[i] = ddk;
       __hip_atomic_store(xch + i, coop_pack(ddk, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  } else
+  } else if (paper)
   {
     const int i = i0 + wave;
     float dsum = 0.f;
@@ -571,7 +576,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     }
   }
   // the other members' dd: poll their words until the flag is this backward's
-  if (tid < n && (tid < i0 || tid >= i0 + 16)) {
+  if (paper && tid < n && (tid < i0 || tid >= i0 + 16)) {
     bool got;
     const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, a.dev_status, a.coop_ticks, xch + tid, wants[tid >> 4], &got);
     ddv[tid] = got ? __uint_as_float((uint32_t)w) : __builtin_nanf("");   // (a wait that ran out is loud: NaN + status word)
@@ -580,7 +585,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   AGCN_STAMP(5, 6);
 
   // ---- M6: pass 2: c_ij = (dr_ij + dr_ji) / r_ij over the strip's rows, in place over the dL row strip; row sums -----
-  {
+  if (paper) {   // (uniform: launch argument)
     const int i = i0 + wave;
     float rsum = 0.f;
     if (i < n) {
@@ -621,7 +626,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 
   // ---- M7: dZ[I] = rowsum(c) Z[I] - c[I, :] Z  -> image + registers ------------------------------------------------
   f32x4 zacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (wave < NCB) {
+  if (paper && wave < NCB) {
     const int cb = wave;
     const float* Ap = DLr + r * ldt + q;
     const float* Bp = Zimg + q * LDX + cb * 16 + r;
@@ -655,6 +660,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     const int fcl = min(cb * 16 + r, FIN - 1);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     constexpr int NKBM = F4 / 16, CHM = 4;       // 16-k blocks over the input features (the copy is zero beyond FIN)
+    if (paper) {
 #pragma unroll
     for (int u0 = 0; u0 < NKBM; u0 += CHM) {
       f32x4 bf[CHM];
@@ -664,6 +670,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 #pragma unroll
       for (int uu = 0; uu < CHM; ++uu)
         if (u0 + uu < NKBM) acc = kb_mma(acc, Ap, u0 + uu, q, bf[uu]);
+    }
     }
     const int f = cb * 16 + r;
     if (f < FIN) {
@@ -675,7 +682,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
           if (a.feat_bf16) bf16_store(a.dX, (int64_t)(row0 + i) * a.lddx + f, dxacc[i4] + acc[i4]);
           else AGCN_ST(8, &dXg[(int64_t)i * a.lddx + f], dxacc[i4] + acc[i4]);
           if (tail) tail_store_f(a.ws_dZ + (int64_t)(row0 + i) * FIN + f, zacc[i4]);
-          else AGCN_ST(8, &a.ws_dZ[(int64_t)(row0 + i) * FIN + f], zacc[i4]);
+          else if (paper) AGCN_ST(8, &a.ws_dZ[(int64_t)(row0 + i) * FIN + f], zacc[i4]);
         }
       }
     }

@@ -339,7 +339,7 @@ def test_bf16_features_every_graph(amd, shape):
     gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(Xb, 0), sb["csr"], DEV)
     layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, mode, p, DEV)
     served = (amd._ffi.dispatch_info(layer, gb)[0] & 256) != 0
-    assert served == (shape != "hiv_beyond_reach" and not (shape == "hiv_within_reach" and mode == orc.REFERENCE))
+    assert served == (shape != "hiv_beyond_reach")
     Xt = gb.X.to(torch.bfloat16).requires_grad_(True)
     lib = amd._ffi.lib()
     lib.agcn_profile_enable(1)
@@ -759,9 +759,9 @@ def _hiv_batch_for_reach(reach, Fin, features):
 def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach):
     """BASELINE configs[4]'s batch shape (HIV-like sizes, mu = ln 23, up to 222 atoms): a 256-graph batch with a few
     molecules beyond the one-workgroup kernels' 96-node LDS plan.
-    within_members (largest molecule <= 128 atoms, paper mode): the specialised kernels take the batch, the oversized
-    molecules spread over member workgroups.  wide_members (129 .. 192 atoms, paper mode): the same, with the kernel
-    variant whose members cover three 64-column passes.  beyond_members (a 200-atom molecule; or reference mode): the whole
+    within_members (largest molecule <= 128 atoms): the specialised kernels take the batch, the oversized
+    molecules spread over member workgroups (reference mode: in the backward only those).  wide_members (129 .. 192 atoms): the
+    same, with the kernel variant whose members cover three 64-column passes.  beyond_members (a 200-atom molecule): the whole
     batch takes the slab kernels by default; with agcn_set_fused_mode(3) the oversized molecules take the slab kernels
     on the side stream beside the specialised kernels ("mixed" dispatch).  The launches must be exactly that, and
     EVERY graph and EVERY gradient must match the float64 oracle either way."""
@@ -775,7 +775,7 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach)
     G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
     caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, orc.SGC_LL, G, None, None)
     lib = amd._ffi.lib()
-    members_take_it = reach != "beyond_members" and mode == orc.PAPER
+    members_take_it = reach != "beyond_members"      # (reference mode: its backward spreads exactly the oversized molecules)
     for fused_mode in (1, 3):      # 1 (default); 3: mixed dispatch allowed
         lib.agcn_set_fused_mode(fused_mode)
         try:
@@ -799,9 +799,9 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach)
 def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode, reach):
     """The SGC_LL_Reslap twin of the test above (every convolution of ResAGCN.py:79-92 / DenseAGCN.py:112-146 is one): an
     HIV-shaped 256-graph batch, 64 -> 64, with a few molecules beyond the one-workgroup kernels' 96 nodes, a previous Laplacian
-    and a gradient arriving on L_sum.  within_members / wide_members (largest molecule <= 128 / <= 192 atoms, paper mode): the
+    and a gradient arriving on L_sum.  within_members / wide_members (largest molecule <= 128 / <= 192 atoms, both modes): the
     specialised kernels take the batch, the oversized molecules spread over member workgroups (which exchange the graph-wide
-    clip norms and inner products).  Beyond that (or reference mode: its backward has no members) SGC_LL_Reslap has no slab flavour: the oversized
+    clip norms and inner products).  Beyond that SGC_LL_Reslap has no slab flavour: the oversized
     molecules take the general per-graph kernels on the side stream, the rest of the batch the specialised kernels beside
     them ("mixed" dispatch, the default for SGC_LL_Reslap).  Whatever runs, EVERY graph's Y / res_W / res_L /
     L_sum and EVERY gradient (dX, dweight, dbias, dM_L, dalpha, dbeta, dL_prev) must match the float64 oracle; the kernels
@@ -833,7 +833,7 @@ def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode,
             seen[fused_mode] = st.kernel_names()
         finally:
             lib.agcn_set_fused_mode(1)
-    if reach != "beyond_members" and mode == orc.PAPER:
+    if reach != "beyond_members":
         assert seen[1][0] == "spec_forward_kernel" and seen[1][1] == "spec_backward_kernel", seen
     else:
         # mixed dispatch: the oversized molecules (no Reslap flavour of the members reaches beyond 128 nodes, the reference-mode

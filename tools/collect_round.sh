@@ -33,6 +33,6 @@ timeout 300 python tools/bench_shapes.py --mode reference --only tox21-l1,tox21-
 ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/netstats -- python3 $GRAFT_REPO_ROOT/tools/prof_network.py 10 > $O/netstats.log 2>&1 )
 cp $O/netstats/*/*kernel_stats.csv $O/${T}_network_kernel_stats.csv
 # HIV-shaped batches whose largest molecule is within / beyond the members' 128 nodes (wide members), SGC_LL_Reslap and SGC_LL
-for v in reslap sgc; do timeout 250 python tools/probe_reslap_reach.py $v 2>/dev/null | grep "^{" >> $O/${T}_member_reach.jsonl; done
+for m in paper reference; do for v in reslap sgc; do timeout 250 python tools/probe_reslap_reach.py $v $m 2>/dev/null | grep "^{" >> $O/${T}_member_reach.jsonl; done; done
 AGCN_CLOUD=0 timeout 200 python tools/bench_shapes.py --only modelnet-64-128 --modelnet-batch 32 --prof > $O/${T}_modelnet_general_slab_kernels.jsonl 2>/dev/null
 ls -la $O

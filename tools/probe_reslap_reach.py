@@ -2,7 +2,7 @@
 """SGC_LL_Reslap 64 -> 64 (with L_prev) or SGC_LL 64 -> 64 on HIV-shaped 256-graph batches: one whose largest molecule is within the
 cooperative members' reach (<= 128 atoms), one within the WIDE members' (129 .. 192) and one beyond both (that batch's largest
 molecule replaced by one of 200 atoms), per agcn_set_fused_mode setting -- what the dispatch costs when a batch leaves the
-specialised kernels.  usage: probe_reslap_reach.py reslap|sgc.  One JSON line per case: us per step (HIP-graph replay) + kernels."""
+specialised kernels.  usage: probe_reslap_reach.py reslap|sgc [paper|reference].  One JSON line per case: us per step (HIP-graph replay) + kernels."""
 import json
 import os
 import sys
@@ -19,6 +19,7 @@ from agcn_amd import synth           # noqa: E402
 dev = torch.device("cuda", 0)
 lib = amd._ffi.lib()
 variant = sys.argv[1] if len(sys.argv) > 1 else "reslap"
+lmode = sys.argv[2] if len(sys.argv) > 2 else "paper"      # laplacian_mode
 
 
 def pick(beyond):
@@ -57,12 +58,12 @@ for beyond in (False, True, None):
         lib.agcn_set_fused_mode(fm)
         try:
             if variant == "reslap":
-                layer = amd.SGC_LL_Reslap(64, 64, 256, K=2, laplacian_mode="paper", device=dev)
+                layer = amd.SGC_LL_Reslap(64, 64, 256, K=2, laplacian_mode=lmode, device=dev)
                 layer.load_vars(synth.glorot_params(np.random.RandomState(123), 64, 64, 2, reslap=True))
                 Lp = 0.1 * torch.randn(gb.plan.tile_elems, device=dev)
                 st = amd.SgcLLStep(layer, gb, L_prev=Lp, dY=torch.randn(gb.plan.rows, 64, device=dev))
             else:
-                layer = amd.SGC_LL(64, 64, 256, K=2, laplacian_mode="paper", device=dev)
+                layer = amd.SGC_LL(64, 64, 256, K=2, laplacian_mode=lmode, device=dev)
                 layer.load_vars(synth.glorot_params(np.random.RandomState(123), 64, 64, 2))
                 st = amd.SgcLLStep(layer, gb, dY=torch.randn(gb.plan.rows, 64, device=dev))
             names = st.kernel_names()
@@ -77,7 +78,7 @@ for beyond in (False, True, None):
             prof = amd._ffi.profile_collect()
             lib.agcn_profile_enable(0)
             kus = {k: round(1e3 * ms / c, 2) for k, (ms, c) in prof.items() if c > 0}
-            print(json.dumps({"variant": variant, "largest": nmax, "rows": int(gb.plan.rows), "fused_mode": fm,
+            print(json.dumps({"variant": variant, "laplacian_mode": lmode, "largest": nmax, "rows": int(gb.plan.rows), "fused_mode": fm,
                               "us_per_step": round(t * 1e6, 1), "kernels": names, "kernel_us": kus}), flush=True)
         finally:
             lib.agcn_set_fused_mode(1)
