@@ -333,16 +333,9 @@ def main():
             out["kernel_us"] = kernel_profile(amd, step, 10, dev)
         print(json.dumps(out), flush=True)
         # the same step (autograd forward + backward of the whole stack) captured into ONE HIP graph
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step()
+        # (amd.GraphedStep captures on the stream its warm-up ran on: the layers' reserves then come out of the lease pool; a capture
+        #  on another stream allocates them inside the graph, with four 64 KB header fills -- 20 us -- replayed every step)
+        g = amd.GraphedStep(step, dev)
         t = timed(g.replay, args.steps, args.warmup, dev)
         out = {"workload": "stack 75-64-128-128-64 + DenseMol 256 + GraphGather, one HIP graph",
                "mode": args.mode, "graphs": B, "us_per_step": round(t * 1e6, 2),
