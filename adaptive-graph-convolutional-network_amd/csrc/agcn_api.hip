@@ -191,8 +191,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
     // reference mode: members only for the graphs no single workgroup can hold (coop_reach: the fs.coop_forced leading ones)
     int s = 0;
     for (int k = 0; k < fs.coop_forced && k < B - 1; ++k) s += (host.n[host.order[k]] + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
-    if (fs.coop_forced > 0 && fs.coop_forced < B && s <= std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members()) &&
-        B + s - fs.coop_forced <= current_device_info().n_cus + current_device_info().n_cus / 2) {
+    if (fs.coop_forced > 0 && fs.coop_forced < B && s <= std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members())) {
       *graphs = fs.coop_forced; *slabs = s;
     }
     return;
@@ -220,6 +219,13 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
     // no members -- but from two rounds of workgroups per CU on, two small graphs per workgroup shorten the queue
     // (512 / 768 / 1000 graphs: 6.0 -> 6.2, 6.9 -> 7.1, 7.2 -> 7.7 M graphs/s; 400 graphs: 5.3 -> 5.0 M, not used)
     if (dual_on && B >= 2 * n_cus) *dual_graphs = (tiny / 2) * 2;
+    // ... except for the graphs only members can take (fs.coop_forced, coop_reach): the members are the first workgroups of
+    // the launch, so they are resident together however long the queue behind them is
+    if (fs.coop_forced > 0 && fs.coop_forced < B - *dual_graphs) {
+      int s = 0;
+      for (int k = 0; k < fs.coop_forced; ++k) s += (host.n[host.order[k]] + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
+      if (s <= member_budget) { *graphs = fs.coop_forced; *slabs = s; }
+    }
     return;
   }
   const int base_min = min_force >= 17 ? min_force : spec::COOP_MIN_N;

@@ -743,15 +743,43 @@ def _hiv_batch_for_reach(reach, Fin, features):
     sb = orc.synth_batch(seed, 256, Fin=Fin, mu=np.log(23.0), hi=222, features=features)
     assert np.array_equal(np.asarray(sb["ns"]), nsa)
     if reach == "beyond_members":
-        rs = np.random.RandomState(1000 + seed)
-        k, nb = int(np.argmax(nsa)), 200
-        adj = orc.synth_adj_lists(rs, nb)
-        x = orc.synth_atom_features(rs, nb) if (features == "atoms" and Fin == 75) else np.maximum(rs.randn(nb, Fin), 0).astype(np.float32)
-        indptr, indices, data, L = orc.graph_laplacian(adj)
-        sb["ns"] = np.asarray(sb["ns"]).copy()
-        sb["ns"][k] = nb
-        sb["X"][k], sb["adj"][k], sb["L0"][k], sb["csr"][k] = x, adj, L.astype(np.float32), (indptr, indices, data)
+        _replace_graph(sb, int(np.argmax(nsa)), 200, np.random.RandomState(1000 + seed), Fin, features)
     return seed, sb
+
+
+def _replace_graph(sb, k, nb, rs, Fin, features):
+    """Graph k of a synthetic batch replaced by a molecule of nb atoms."""
+    adj = orc.synth_adj_lists(rs, nb)
+    x = orc.synth_atom_features(rs, nb) if (features == "atoms" and Fin == 75) else np.maximum(rs.randn(nb, Fin), 0).astype(np.float32)
+    indptr, indices, data, L = orc.graph_laplacian(adj)
+    sb["ns"] = np.asarray(sb["ns"]).copy()
+    sb["ns"][k] = nb
+    sb["X"][k], sb["adj"][k], sb["L0"][k], sb["csr"][k] = x, adj, L.astype(np.float32), (indptr, indices, data)
+
+
+@pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
+def test_oversized_molecule_in_a_large_batch_every_graph(amd, mode):
+    """520 Tox21-shaped graphs -- two rounds of workgroups per CU, where the planner spreads no graph over members any more and
+    pairs the small ones instead -- with ONE molecule of 150 atoms: only the members can take it, so exactly that graph is spread
+    (forward and backward, both modes) and the batch stays on the specialised kernels.  Every graph and every gradient against
+    the float64 oracle."""
+    Fin, Fout, K, B = 75, 64, 2, 520
+    sb = orc.synth_batch(77, B)
+    _replace_graph(sb, 5, 150, np.random.RandomState(78), Fin, "atoms")
+    ns = [int(v) for v in sb["ns"]]
+    rs = np.random.RandomState(79)
+    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL)
+    p["alpha"] = np.array([0.8], np.float32)
+    G = [rs.randn(n, Fout).astype(np.float32) for n in ns]
+    out = run_packed(amd, DEV, ns, sb["X"], sb["csr"], p, G, Fin, Fout, K, mode, orc.SGC_LL, None, None)
+    caches, tot = oracle_run(sb["X"], sb["L0"], p, K, mode, orc.SGC_LL, G, None, None, Y_tie=np.concatenate(out["Y"]))
+    compare_with_oracle(out, caches, tot, orc.SGC_LL, mode, K, has_prev=False)
+    gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(sb["X"], 0), sb["csr"], DEV)
+    layer = make_layer(amd, orc.SGC_LL, Fout, Fin, B, K, mode, p, DEV)
+    info = amd._ffi.dispatch_info(layer, gb)
+    assert info[0] & 7 == 7 and info[2] == 1 and info[3] == 10 and info[5] == 1 and info[6] == 10, info
+    names = amd.SgcLLStep(layer, gb).kernel_names()
+    assert names[0] == "spec_forward_kernel" and names[1] == "spec_backward_kernel", names
 
 
 @pytest.mark.parametrize("reach", ["beyond_members", "wide_members", "within_members"])

@@ -264,6 +264,13 @@ def test_dispatch_table(amd):
     n[3] = 180      # (75 -> 64: the members' images of 180 rows x 80 features do not fit LDS; 64 -> 64 does)
     assert _dispatch(amd, n, 75, 64, 1)["path"] == 16
     assert _dispatch(amd, n, 64, 64, 1, variant=1)["path"] == 7
+    # ... also in a batch too large for members in general (two rounds of workgroups per CU): only that molecule is spread
+    nb = np.concatenate([n, n256]).astype(np.int32)
+    nb[3] = 150
+    d = _dispatch(amd, nb, 75, 64, 1)
+    assert d["path"] & 7 == 7 and d["f_graphs"] == 1 and d["f_members"] == 10 and d["b_graphs"] == 1 and d["b_members"] == 10
+    d = _dispatch(amd, nb, 75, 64, 0)
+    assert d["path"] & 7 == 7 and d["f_members"] == 10 and d["b_members"] == 10
     n[3] = 200      # SGC_LL_Reslap beyond every member: mixed dispatch (that molecule on the per-graph kernels, side stream)
     assert _dispatch(amd, n, 64, 64, 1, variant=1)["path"] == 8
     n[3] = 120
