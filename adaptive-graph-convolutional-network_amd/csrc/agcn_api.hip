@@ -179,7 +179,8 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
                int* slabs, int* dual_graphs) {
   *graphs = *slabs = *dual_graphs = 0;
   const int B = host.info.B;
-  // (reference mode: the backward has no n x n work to spread; the forward still has the similarity tile)
+  // (reference mode: the backward has no n x n work to spread -- members there only for the graphs no single workgroup can
+  //  hold, fs.coop_forced; the forward still has the similarity tile)
   // SGC_LL_Reslap: members in both directions too (they exchange the graph-wide clip norms / inner products as well)
   const bool reslap = d->variant == AGCN_SGC_LL_RESLAP;
   if (d->variant != AGCN_SGC_LL && !reslap) return;

@@ -38,7 +38,8 @@ constexpr int COOP_MAX_MEMBERS = 120;
 constexpr int DUAL_MAX_N = 16;         // graphs that may be packed two to a workgroup (8 waves each)
 // Largest graph the members can take: a member holds [n x F] images and 16-row strips, not n x n tiles, so it reaches
 // beyond the 96 nodes of the one-workgroup kernels (whose backward keeps two n x n tiles) as far as its LDS plan fits
-// (spec_coop_lds_bytes): lanes cover 128 columns, a wave 8 rows of an image, the epoch table 8 members.
+// (spec_coop_lds_bytes): lanes cover MAXN columns in MAXN / 64 passes, a wave owns MAXN / 16 rows of an image (register arrays),
+// the epoch table has MAXN / 16 entries -- the member code is templated on MAXN:
 constexpr int COOP_MAX_N = 128;
 // ... and the WIDE members (a kernel variant of their own, launched only for a batch with such a graph: spec_backward.hip):
 // three 64-column passes, 12 rows of an image per wave -- HIV-shaped batches: 5.6 % have a molecule beyond 128 atoms, none beyond 192
