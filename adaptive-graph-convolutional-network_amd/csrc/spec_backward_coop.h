@@ -104,8 +104,13 @@ __device__ __forceinline__ float coop_graph_sum(const SgcArgs& a, float part, fl
 
 struct CoopLds {
   int n4, ldt;
-  int o_s, o_dd, o_rs, o_lt, o_r, o_dlr, o_dlc, o_g0, o_g1, o_u, total;
+  int o_s, o_dd, o_rs, o_lt, o_r, o_dlr, o_dlc, o_g0, o_dz, o_g1, o_u, total;
 };
+// Regions with disjoint lifetimes share their floats (a barrier lies between the last read of the one and the first write of the
+// other): the dL COLUMN strip (written in M4) takes the place of the L^T strip (last read in M3); and where a strip row is at
+// least as long as an image row (n4 >= F4: the large graphs, the only ones whose plan is tight) the g_0 rows (M2 -> M3) live in
+// the dL row strip (written from M4 on) and the dZ rows (M7 -> M8) in the L^T / dL column strip (last read in M6).  That is what
+// lets a 128-node graph fit at 128 input features (159 KB), 176 nodes at 75 -> 64 and 160 at 64 -> 128.
 AGCN_HD inline CoopLds coop_lds(int n, int F4, int Fout) {
   CoopLds d;
   d.n4 = (n + 15) & ~15;
@@ -117,9 +122,16 @@ AGCN_HD inline CoopLds coop_lds(int n, int F4, int Fout) {
   d.o_lt = d.o_rs + 16;                  // [16][ldt]  L^T strip: LT[il][k] = L[k][i0 + il]
   d.o_r = d.o_lt + 16 * d.ldt;           // [16][ldt]  r rows of the strip
   d.o_dlr = d.o_r + 16 * d.ldt;          // [16][ldt]  dL[i0 + il][j]   -> c strip
-  d.o_dlc = d.o_dlr + 16 * d.ldt;        // [16][ldt]  dL[j][i0 + il]
-  d.o_g0 = d.o_dlc + 16 * d.ldt;         // [16][ldx]  g_0 rows of the strip, later the dZ rows
-  d.o_g1 = d.o_g0 + 16 * ldx;            // [n4][ldx]  g_1 (all rows), later Z (all rows)
+  d.o_dlc = d.o_lt;                      // [16][ldt]  dL[j][i0 + il]   (in place of the L^T strip)
+  int next = d.o_dlr + 16 * d.ldt;
+  if (d.n4 >= F4) {
+    d.o_g0 = d.o_dlr;                    // [16][ldx]  g_0 rows of the strip (until M3)
+    d.o_dz = d.o_lt;                     // [16][ldx]  dZ rows of the strip (from M7 on)
+  } else {
+    d.o_g0 = d.o_dz = next;              // [16][ldx]  g_0 rows of the strip, later the dZ rows
+    next += 16 * ldx;
+  }
+  d.o_g1 = next;                         // [n4][ldx]  g_1 (all rows), later Z (all rows)
   d.o_u = d.o_g1 + d.n4 * ldx;           // [n4][ldg]  Gp (all rows), later [n4][ldx] X_0 (all rows)
   const int gp = d.n4 * ldg, x = d.n4 * ldx;
   d.total = d.o_u + (gp > x ? gp : x);
@@ -172,7 +184,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   float* DLr = smem + d.o_dlr;
   float* DLc = smem + d.o_dlc;
   float* G0img = smem + d.o_g0;
-  float* DZimg = smem + d.o_g0;
+  float* DZimg = smem + d.o_dz;
   float* G1img = smem + d.o_g1;
   float* Zimg = smem + d.o_g1;
   float* GPimg = smem + d.o_u;

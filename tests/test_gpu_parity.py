@@ -822,6 +822,36 @@ def test_hiv_shaped_batch_with_oversized_molecules_every_graph(amd, mode, reach)
             assert ("spec_backward_kernel" in names[1]) == (fused_mode == 3), names
 
 
+@pytest.mark.parametrize("variant", [orc.SGC_LL, orc.SGC_LL_RESLAP], ids=["sgc_ll", "reslap"])
+@pytest.mark.parametrize("shape", [(75, 64, 176), (64, 128, 160), (128, 128, 128), (128, 64, 128), (64, 64, 192)],
+                         ids=lambda v: "%dto%d_n%d" % v)
+def test_members_at_the_edge_of_their_reach(amd, shape, variant):
+    """The largest graph the members' LDS plan holds at each covered layer shape (csrc/spec_backward_coop.h: coop_lds -- regions
+    with disjoint lifetimes share their floats; 129 nodes and up: the kernel variant with the wide members), one such graph and one
+    16 nodes smaller in a batch of small ones: specialised kernels asserted, every graph and gradient against the float64 oracle,
+    paper mode and (SGC_LL) reference mode."""
+    Fin, Fout, nmax = shape
+    ns = [nmax, 20, 7, nmax - 16, 33, 12, 50, 4, 64, 17, 96, 30]
+    K = 2
+    for mode in ((orc.PAPER, orc.REFERENCE) if variant == orc.SGC_LL else (orc.PAPER,)):
+        rs, X, L0, csr, p, G = synth_case(4000 + nmax, ns, Fin, Fout, K, variant, atoms=(Fin == 75))
+        Lp = dLs = None
+        if variant == orc.SGC_LL_RESLAP:
+            Lp = [(0.2 * rs.randn(n, n)).astype(np.float32) for n in ns]
+            dLs = [(0.3 * rs.randn(n, n)).astype(np.float32) for n in ns]
+        out = run_packed(amd, DEV, ns, X, csr, p, G, Fin, Fout, K, mode, variant, Lp, dLs)
+        caches, tot, tot32 = oracle_pair(X, L0, p, K, mode, variant, G, Lp, dLs, Y_got=np.concatenate(out["Y"]))
+        compare_with_oracle(out, caches, tot, variant, mode, K, has_prev=Lp is not None, tot32=tot32)
+        gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
+        layer = make_layer(amd, variant, Fout, Fin, len(ns), K, mode, p, DEV)
+        info = amd._ffi.dispatch_info(layer, gb)
+        assert info[0] & 7 == 7 and info[2] >= 2 and info[5] >= 2, info      # (both large graphs on members, forward and backward)
+        # one node more than the plan holds: the batch leaves the members (slab kernels / mixed dispatch)
+        gb1 = amd.GraphBatch.from_arrays(np.asarray([nmax + 1] + ns[1:], np.int32), np.zeros((sum(ns) + 1, Fin), np.float32),
+                                         [orc.graph_laplacian(orc.synth_adj_lists(np.random.RandomState(1), nmax + 1))[:3]] + csr[1:], DEV)
+        assert amd._ffi.dispatch_info(layer, gb1)[0] & 7 != 7
+
+
 @pytest.mark.parametrize("reach", ["beyond_members", "wide_members", "within_members"])
 @pytest.mark.parametrize("mode", [orc.REFERENCE, orc.PAPER], ids=["reference", "paper"])
 def test_hiv_shaped_reslap_batch_with_oversized_molecules_every_graph(amd, mode, reach):

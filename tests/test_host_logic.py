@@ -281,7 +281,11 @@ def test_dispatch_table(amd):
     amd._ffi.lib().agcn_set_spec_tail(0)
     assert _dispatch(amd, n256, 75, 64, 1)["path"] == 7
     amd._ffi.lib().agcn_set_spec_tail(prev_tail)
-    assert _dispatch(amd, n, 128, 128, 1)["path"] == 16        # (the members' LDS plan does not fit at this width)
+    d = _dispatch(amd, n, 128, 128, 1)                         # (128 input features: the members' plan holds a 128-node graph ...)
+    assert d["path"] & 7 == 7 and d["b_members"] == d["f_members"] >= 8
+    n[3] = 130
+    assert _dispatch(amd, n, 128, 128, 1)["path"] == 16        # (... and no larger one)
+    n[3] = 120
     assert _dispatch(amd, n256, 80, 64, 1)["path"] == 4
     # SGC_LL_Reslap at the specialised widths: the specialised kernels' Reslap flavour with the same layout as SGC_LL (the largest
     # graphs on members, small graphs paired to make room; reference mode: members in the forward only; a 120-node molecule
