@@ -489,12 +489,14 @@ void agcn_set_fused_global_b(int32_t mode);
  * bit-identical to each other. */
 int32_t agcn_get_param_grad_onepass(void);
 void agcn_set_param_grad_onepass(int32_t on);
-/* Shape-specialised fused kernels (csrc/spec_*.hip: SGC_LL, K = 2, layer widths 75->64, 64->128, 128->128, 128->64,
+/* Shape-specialised fused kernels (csrc/spec_*.hip: SGC_LL and SGC_LL_Reslap, K = 2, layer widths 75->64, 64->128, 128->128, 128->64,
  * 64->64; 1024-thread workgroups, feature widths compiled in).  A bit mask, default 7: bit 0 = forward, bit 1 =
  * backward (used wherever the fused path would be taken and the shape is covered; 0: always the general fused
  * kernels), bit 2 = the cooperative launch layout (csrc/spec_backward_coop.h): graphs of three 16-row tiles and up
- * (five, when the launch does not fit the chip any more; up to 128 nodes) spread over one workgroup per tile of the
- * same launch, the smallest graphs packed two to a workgroup to make room.  Same results within the last few ulps
+ * (five, when the launch does not fit the chip any more; up to 128 nodes, up to 192 in a kernel variant of its own as far
+ * as the members' LDS plan fits: 64->64 192, 75->64 176, 64->128 160, 128 input features 128) spread over one workgroup
+ * per tile of the same launch, the smallest graphs packed two to a workgroup to make room.  Graphs beyond the one-workgroup
+ * kernels' 96 nodes are spread whatever the batch size or Laplacian mode (only members can take them).  Same results within the last few ulps
  * (hardware sqrt / exp2 in the similarity phase; summation orders). */
 int32_t agcn_get_spec_mode(void);
 void agcn_set_spec_mode(int32_t mode);
