@@ -230,18 +230,22 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
     return;
   }
   const int base_min = min_force >= 17 ? min_force : spec::COOP_MIN_N;
-  int extra = 0;
-  for (int k = 0; k < B; ++k) {
-    const int n = host.n[host.order[k]];
-    if (n < base_min) break;
-    extra += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS - 1;
+  // The threshold: the smallest of base_min, base_min + 8, .. , COOP_MIN_N_FULL at which the launch still fits the chip -- after
+  // room has been made by packing the SMALLEST graphs (at most DUAL_MAX_N nodes: a suffix of the schedule) two to a workgroup
+  // (8 waves each, spec_forward.hip): a pair frees one CU.  (HIV-shaped batches have ~60 graphs of three tiles and up: the
+  // three- and four-tile ones cannot all be spread, the five-tile ones can once pairs make room: 57.3 -> 56.3 us per step
+  // against going straight to the last threshold without pairs; workgroups beyond the chip cost more than they save: 64 us.)
+  int min_n = std::max(base_min, spec::COOP_MIN_N_FULL), pairs = 0;
+  for (int t = base_min; t <= std::max(base_min, spec::COOP_MIN_N_FULL); t = (t < spec::COOP_MIN_N_FULL && t + 8 > spec::COOP_MIN_N_FULL) ? spec::COOP_MIN_N_FULL : t + 8) {
+    int extra = 0;
+    for (int k = 0; k < B; ++k) {
+      const int n = host.n[host.order[k]];
+      if (n < t) break;
+      extra += (n + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS - 1;
+    }
+    const int pr = (dual_on && B + extra > n_cus) ? std::min(tiny / 2, B + extra - n_cus) : 0;
+    if (B + extra - pr <= n_cus) { min_n = t; pairs = pr; break; }
   }
-  // When the launch would not fit the chip, room is made by packing the SMALLEST graphs (at most DUAL_MAX_N nodes: a
-  // suffix of the schedule) two to a workgroup (8 waves each, spec_forward.hip): a pair frees one CU.
-  int pairs = 0;
-  if (dual_on && B + extra > n_cus) pairs = std::min(tiny / 2, B + extra - n_cus);
-  const int min_n = B + extra - pairs <= n_cus ? base_min : std::max(base_min, spec::COOP_MIN_N_FULL);
-  if (min_n != base_min) pairs = 0;   // (no room to be made: nothing is paired)
   // (graphs only the members can take -- fs.coop_forced leading ones, n > 96 -- are above either threshold)
   *dual_graphs = 2 * pairs;
   int g = 0, s = 0;
