@@ -313,7 +313,8 @@ def test_bf16_feature_storage(amd):
     assert torch.equal(CastRowsFunction.apply(x.to(torch.bfloat16), torch.float32), x.to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("shape", ["tox21_b256", "hiv_within_reach", "hiv_wide_reach", "hiv_beyond_reach", "reference_mode"])
+@pytest.mark.parametrize("shape", ["tox21_b256", "hiv_within_reach", "hiv_wide_reach", "hiv_beyond_reach", "reference_mode",
+                                   "hiv_wide_reach_reference_mode"])
 def test_bf16_features_every_graph(amd, shape):
     """BASELINE config 4 ("bf16 features + fp32 Laplacian") at batch size, every graph: bf16 node features / upstream gradients
     in, bf16 activations / input gradients out, fp32 tiles, Laplacian and parameter gradients.  Where every graph of the batch
@@ -323,12 +324,12 @@ def test_bf16_features_every_graph(amd, shape):
     bf16-rounded inputs -- Y and dX to one bf16 rounding (2^-8 relative), res_W / res_L and every parameter gradient to the
     usual fp32 bars (their inputs are the same rounded values; nothing else is rounded)."""
     Fin, Fout, K = 75, 64, 2
-    mode = orc.REFERENCE if shape == "reference_mode" else orc.PAPER
+    mode = orc.REFERENCE if shape.endswith("reference_mode") else orc.PAPER
     if shape in ("tox21_b256", "reference_mode"):
         sb = orc.synth_batch(123, 256)
     else:   # (largest molecule <= 128 atoms: members; 129 .. 192: the wide members; a 200-atom molecule: beyond both)
         _, sb = _hiv_batch_for_reach({"hiv_within_reach": "within_members", "hiv_wide_reach": "wide_members",
-                                      "hiv_beyond_reach": "beyond_members"}[shape], Fin, "atoms")
+                                      "hiv_beyond_reach": "beyond_members", "hiv_wide_reach_reference_mode": "wide_members"}[shape], Fin, "atoms")
     ns = [int(v) for v in sb["ns"]]
     rs = np.random.RandomState(17)
     p = orc.init_params(rs, Fin, Fout, K)
