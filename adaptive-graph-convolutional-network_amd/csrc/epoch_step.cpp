@@ -17,7 +17,11 @@ extern "C" int agcn_epoch_step(const AgcnResidentStore* store, const int64_t* id
   if (desc->variant != AGCN_SGC_LL) return fail(AGCN_EINVAL, "%s: drives SGC_LL layers", who);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   hipEvent_t ev = static_cast<hipEvent_t>(slot_event);
+  // `needs` is an OUTPUT of this call only: an AGCN_ENOSPACE that leaves it zero is not a "grow the reserve" answer
+  needs->reserve_bytes = 0; needs->workspace_bytes = 0;
   if (restage) {
+    // a staging failure must not leave the previous batch's description behind for a retry with restage = 0
+    info->plan.rows = -1; info->plan.tile_elems = -1;
     // the copy that last read this pinned blob must have executed before the blob is rewritten
     if (ev != nullptr && hipEventSynchronize(ev) != hipSuccess) return fail(AGCN_EDEVICE, "%s: hipEventSynchronize failed", who);
     int rc = agcn_store_stage_batch(store, ids, B, buf->stage_host, buf->stage_dev, buf->stage_cap, buf->X, desc->Fin,
@@ -25,6 +29,7 @@ extern "C" int agcn_epoch_step(const AgcnResidentStore* store, const int64_t* id
     if (rc != AGCN_OK) return rc;
     if (ev != nullptr && hipEventRecord(ev, s) != hipSuccess) return fail(AGCN_EDEVICE, "%s: hipEventRecord failed", who);
   }
+  if (info->plan.rows < 0) return fail(AGCN_EINVAL, "%s: restage = 0 without a staged batch", who);
   if (info->plan.rows > buf->rows_cap || info->plan.tile_elems > buf->tiles_cap)
     return fail(AGCN_ENOSPACE, "%s: batch (rows %d, tile floats %lld) exceeds the output capacity (%lld, %lld)", who,
                 info->plan.rows, (long long)info->plan.tile_elems, (long long)buf->rows_cap, (long long)buf->tiles_cap);

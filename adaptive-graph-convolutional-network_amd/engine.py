@@ -401,6 +401,42 @@ def _overlapping_streams(device, k, candidates=12, spin=400000):
     return (chosen + [s for s in pool if s not in chosen])[:k]     # fewer independent queues than lanes
 
 
+class _MemberBudget(object):
+    """The process-wide member budget (include/agcn.h: agcn_set_coop_members) as lowered by the live SgcLLEpochLanes objects:
+    the knob is the minimum of the value found when the first override was taken and of every live override; it goes back
+    to that value when the last override is released -- whatever the order in which the objects close or are collected."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._live = {}
+        self._base = None
+        self._next = 0
+
+    def _apply(self):
+        _ffi.lib().agcn_set_coop_members(min([self._base] + list(self._live.values())))
+
+    def acquire(self, members):
+        with self._lock:
+            if not self._live:
+                self._base = _ffi.lib().agcn_get_coop_members()
+            self._next += 1
+            self._live[self._next] = int(members)
+            self._apply()
+            return self._next
+
+    def release(self, token):
+        with self._lock:
+            if self._live.pop(token, None) is None:
+                return
+            self._apply()
+            if not self._live:
+                self._base = None
+
+
+_member_budget = _MemberBudget()
+
+
 class SgcLLEpochLanes(object):
     """`lanes` independent `SgcLLEpochStep`s, each on its own stream with its own buffers, fed round-robin from a
     `ResidentStore`: consecutive batches overlap on the GPU.  A step of one 256-graph batch is as long as the dependent
@@ -429,10 +465,9 @@ class SgcLLEpochLanes(object):
         # (process-wide knob, include/agcn.h agcn_set_coop_members).
         # The knob is process-wide: the previous value comes back with close() / the end of a `with` block / the object's
         # death, so that step objects built later get the full budget again.
-        self._prev_members = None
-        if lanes > 2:
-            self._prev_members = _ffi.lib().agcn_get_coop_members()
-            _ffi.lib().agcn_set_coop_members(min(self._prev_members, 240 // lanes))
+        # Several lanes objects may be alive at once: the knob holds the MINIMUM over the live ones and the value found by the
+        # first comes back when the last one closes (_member_budget).
+        self._budget_token = _member_budget.acquire(240 // lanes) if lanes > 2 else None
         self.streams = _overlapping_streams(self.device, lanes)
         self._j = 0
         torch.cuda.synchronize(self.device)      # buffers, parameters and the store were filled on other streams
@@ -478,11 +513,11 @@ class SgcLLEpochLanes(object):
 
     def close(self):
         """Waits for the lanes and gives the cooperative-member budget back (only lanes > 2 lowered it)."""
-        if self._prev_members is not None:
+        if self._budget_token is not None:
             for s in self.streams:
                 s.synchronize()
-            _ffi.lib().agcn_set_coop_members(self._prev_members)
-            self._prev_members = None
+            _member_budget.release(self._budget_token)
+            self._budget_token = None
 
     def __enter__(self):
         return self
@@ -585,9 +620,32 @@ class GraphedStep(object):
         # captured on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were created
         # on, and one that outlives an iteration (a container or layer attribute that still references the last step's
         # graph) would otherwise meet the capture on a different stream -- a synchronisation inside the capture
-        with torch.cuda.graph(self.graph, stream=side):
+        # pooled reserve buffers the capture pins (functional._lease_reserve) belong to THIS object: they are freed
+        # with the graph (reset() / __del__), not to a process-wide list
+        from . import functional as _fn
+        self._scope = _fn.capture_scope()
+        with self._scope, torch.cuda.graph(self.graph, stream=side):
             self.outputs = fn()
 
     def replay(self):
         self.graph.replay()
         return self.outputs
+
+    @property
+    def pinned_reserve_bytes(self):
+        return self._scope.nbytes
+
+    def reset(self):
+        """Drops the captured graph and its outputs and frees the reserve buffers it pinned."""
+        if self.graph is not None:
+            torch.cuda.synchronize()
+            self.outputs = None
+            self.graph.reset()
+            self.graph = None
+            self._scope.release()
+
+    def __del__(self):
+        try:
+            self.reset()
+        except Exception:          # (interpreter shutdown)
+            pass

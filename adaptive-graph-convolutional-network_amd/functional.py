@@ -208,12 +208,73 @@ def check_device_status():
 # A reserve may serve any batch after any other (the header is self-maintaining: include/agcn.h), so a buffer that comes back
 # from the pool needs nothing.  A lease goes back when the autograd node that holds it dies (after backward(), or when the outputs
 # of a forward-only call are dropped).  Under stream capture: a pooled buffer (allocated eagerly, e.g. by the warm-up steps
-# GraphedStep runs on its capture stream) is used at its fixed address by every replay, so it is kept alive for good and never
-# handed out again; a buffer allocated INSIDE a capture belongs to the graph's own memory pool and never enters this one.
+# GraphedStep runs on its capture stream) is used at its fixed address by every replay, so it belongs to the CAPTURING OBJECT for
+# as long as its graph lives (capture_scope(): engine.GraphedStep owns the list and frees the buffers when it is
+# reset or deleted; a capture outside any scope pins its buffers in _unscoped_captures until release_reserve_pool(force=True));
+# a buffer allocated INSIDE a capture belongs to the graph's own memory pool and never enters this one.
 _reserve_pool = {}
 _reserve_pool_bytes = [0]
 _RESERVE_POOL_CAP = 2 << 30
-_captured_keepalive = []
+_unscoped_captures = []
+_capture_scopes = []
+
+
+def _size_class(rbytes):
+    """256 KB classes below 64 MB, 1/8-octave classes (at most +12.5 %) above: a point-cloud reserve of ~256 MB that grows by a
+    few KB with the batch finds the buffer of the previous batch instead of pinning a new one."""
+    if rbytes < (64 << 20):
+        return (rbytes + 262143) // 262144 * 262144
+    step = 1 << (int(rbytes - 1).bit_length() - 4)
+    return (rbytes + step - 1) // step * step
+
+
+def _pool_put(key, tensor):
+    if _reserve_pool_bytes[0] + tensor.numel() <= _RESERVE_POOL_CAP:
+        _reserve_pool.setdefault(key, []).append(tensor)
+        _reserve_pool_bytes[0] += tensor.numel()
+
+
+class capture_scope(object):
+    """Owner of the pooled reserves a stream capture pins.  `with capture_scope() as scope:` around the capture; the buffers
+    stay out of the pool until `scope.release()` (call it once the captured graph is gone)."""
+
+    def __init__(self):
+        self.held = []
+
+    def __enter__(self):
+        _capture_scopes.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _capture_scopes.remove(self)
+        return False
+
+    def release(self):
+        # (back to the torch caching allocator, not to the lease pool: the pool is keyed by stream, and the side stream of a
+        # GraphedStep that is gone may never ask again)
+        self.held = []
+
+    @property
+    def nbytes(self):
+        return sum(t.numel() for _, t in self.held)
+
+
+def reserve_pool_bytes():
+    """(bytes idle in the pool, bytes pinned by captures outside any capture_scope)."""
+    return _reserve_pool_bytes[0], sum(t.numel() for _, t in _unscoped_captures)
+
+
+def release_reserve_pool(force=False):
+    """Drops every idle reserve buffer of the pool (the torch caching allocator gets them back; torch.cuda.empty_cache() then
+    returns them to the device).  `force=True` also drops the buffers pinned by captures that ran outside a capture_scope --
+    only once those graphs are gone.  Returns the number of bytes dropped."""
+    n = _reserve_pool_bytes[0]
+    _reserve_pool.clear()
+    _reserve_pool_bytes[0] = 0
+    if force:
+        n += sum(t.numel() for _, t in _unscoped_captures)
+        del _unscoped_captures[:]
+    return n
 
 
 class _ReserveLease(object):
@@ -221,15 +282,14 @@ class _ReserveLease(object):
 
     def __del__(self):
         try:
-            if self.pooled and _reserve_pool_bytes[0] + self.tensor.numel() <= _RESERVE_POOL_CAP:
-                _reserve_pool.setdefault(self.key, []).append(self.tensor)
-                _reserve_pool_bytes[0] += self.tensor.numel()
+            if self.pooled:
+                _pool_put(self.key, self.tensor)
         except Exception:          # (interpreter shutdown)
             pass
 
 
 def _lease_reserve(dev, rbytes):
-    size = (rbytes + 262143) // 262144 * 262144 if rbytes < (64 << 20) else rbytes      # size classes of 256 KB
+    size = _size_class(rbytes)
     capturing = torch.cuda.is_current_stream_capturing()
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(dev).cuda_stream, size)
@@ -241,7 +301,7 @@ def _lease_reserve(dev, rbytes):
         _reserve_pool_bytes[0] -= lease.tensor.numel()
         lease.pooled = not capturing
         if capturing:
-            _captured_keepalive.append(lease.tensor)
+            (_capture_scopes[-1].held if _capture_scopes else _unscoped_captures).append((key, lease.tensor))
     else:
         lease.tensor = torch.empty(size, dtype=torch.uint8, device=dev)
         lease.tensor[:min(size, _ffi.RESERVE_HEADER_BYTES)].zero_()      # (must be zero when a reserve is first used)

@@ -46,7 +46,7 @@ def get_uid(prefix=""):
     return _UID_PREFIXES[prefix]
 
 
-# AGCN_DEBUG_CHECKS=1 / set_debug_checks(True): symmetry vouches are verified on every call, not only the first one per layer
+# AGCN_DEBUG_CHECKS=1 / set_debug_checks(True): symmetry vouches are verified on every call, not once per vouched object
 _DEBUG_CHECKS = [os.environ.get("AGCN_DEBUG_CHECKS", "0") not in ("", "0")]
 
 
@@ -175,7 +175,6 @@ class SGC_LL(Layer):
         self._device = device
         self._generator = generator
         self._built = False
-        self._vouch_checked = False     # _verify_vouches has run on this layer object
 
     def build(self, device=None):
         """Creates the parameters once (the reference re-creates them on every call,
@@ -262,18 +261,27 @@ class SGC_LL(Layer):
 
     def _verify_vouches(self, gb, L_prev, prev_sym):
         """A symmetry flag somebody VOUCHED for -- `GraphBatch(..., l0_dense=..., l0_symmetric=True)`, `TileViews(...,
-        symmetric=True)` / `x["res_lap_symmetric"]` -- is checked on the device the first time this layer object sees one
-        (agcn_tiles_asymmetry: one launch + one 4-byte read), and on every call under AGCN_DEBUG_CHECKS=1 /
-        `agcn_amd.set_debug_checks(True)`: the point-cloud kernels take La^T g_1 as La g_1 on the strength of those flags,
-        so a false vouch would be a silently wrong dX.  Flags this package computed itself are not re-checked."""
+        symmetric=True)` / `x["res_lap_symmetric"]` -- is checked on the device ONCE PER VOUCHED OBJECT
+        (agcn_tiles_asymmetry: one launch + one 4-byte read; the object then carries `_verified`, so a static batch replayed
+        step after step costs nothing after its first call and a NEW vouched batch / tile set is always checked), and on
+        every call under AGCN_DEBUG_CHECKS=1 / `agcn_amd.set_debug_checks(True)`: the point-cloud kernels take La^T g_1 as La g_1 on the strength of those flags,
+        so a false vouch would be a silently wrong dX.  Flags this package computed itself are not re-checked (outside the debug
+        mode); a vouch that comes as `x["res_lap_symmetric"]` beside a plain list of tiles has no object to remember the
+        verdict on and is checked on every call -- hand in a `TileViews`."""
         todo = []
         laps = getattr(self, "early_laps", None)
-        if prev_sym and L_prev is not None and not getattr(laps, "_verified", False):
+        dbg = _DEBUG_CHECKS[0]
+        if prev_sym and L_prev is not None and (dbg or not getattr(laps, "_verified", False)):
             todo.append(("the previous Laplacian (res_lap, vouched symmetric)", L_prev, 0, laps))
-        if gb.l0_symmetric and gb.l0_dense is not None and not gb._l0_verified:
+        if gb.l0_symmetric and gb.l0_dense is not None and (dbg or not gb._l0_verified):
             todo.append(("the dense original Laplacian (l0_symmetric=True)", gb.l0_dense, gb.l0_ld, gb))
-        if not todo or (self._vouch_checked and not _DEBUG_CHECKS[0]):
+        if not todo:
             return
+        if torch.cuda.is_current_stream_capturing():
+            from . import _ffi
+            raise _ffi.AgcnError("a vouched-symmetric object (%s) reached a layer for the first time inside a stream capture; "
+                                 "the check reads a word back from the device: run the step once before capturing it"
+                                 % todo[0][0])
         from . import _ffi
         from .functional import _stream
         dev = gb.plan.dev.device
@@ -291,7 +299,6 @@ class SGC_LL(Layer):
                 gb._l0_verified = True
             elif obj is not None and hasattr(obj, "_verified"):
                 obj._verified = True
-        self._vouch_checked = True
 
     def _bf16_served(self, gb, X, cfg):
         """True when the library's kernels for this batch read / write bf16 features themselves (dispatch bit 256: every graph

@@ -512,14 +512,15 @@ void agcn_set_spec_small(int32_t on);
  * to [0, 120].  Process-wide, like the other knobs. */
 int32_t agcn_get_coop_members(void);
 void agcn_set_coop_members(int32_t members);
+/* 0 (default; env AGCN_SPEC_TAIL=1 opts in): 1 makes a whole-backward call on a batch the specialised kernels take in ONE
+ * 16-wave launch (SGC_LL, paper mode) compute the parameter gradients in trailing workgroups of that launch -- dispatch bit
+ * 128 --; 0: always the separate parameter-gradient kernel (measured faster: profiles/EXPERIMENTS.md).  Both are
+ * bit-reproducible; they differ in summation order. */
+int32_t agcn_get_spec_tail(void);
+void agcn_set_spec_tail(int32_t on);
 /* Bound of a member's wait for a sibling's word, in ticks of the device's 100 MHz constant clock (default 1 000 000 = 10 ms:
  * three orders of magnitude beyond a step).  0 makes every wait that is not satisfied by its first poll run out -- the
  * deterministic way to exercise the reporting path (status words, NaN poisoning) in a test.  Process-wide. */
-/* 1 (default; env AGCN_SPEC_TAIL): a whole-backward call on a batch the specialised kernels take in ONE 16-wave launch
- * (SGC_LL, paper mode) computes the parameter gradients in trailing workgroups of that launch -- dispatch bit 128 --; 0: always
- * the separate parameter-gradient kernel.  Both are bit-reproducible; they differ in summation order. */
-int32_t agcn_get_spec_tail(void);
-void agcn_set_spec_tail(int32_t on);
 uint32_t agcn_get_coop_timeout_ticks(void);
 void agcn_set_coop_timeout_ticks(uint32_t ticks);
 

@@ -1467,16 +1467,25 @@ def test_false_symmetry_vouch_is_detected(amd):
     Lbad[0][5, 9] += 1e-3; Lbad[0][100, 2] += 1e-3
     with pytest.raises(amd.AgcnError, match="original Laplacian.*NOT symmetric: 2 element pair"):
         run(batch(Lbad), good, True)
-    # a layer object checks once; under set_debug_checks(True) every call does
+    # every NEWLY vouched object is checked once, whichever call of the layer it arrives in (the verdict is remembered on the
+    # object, not on the layer); an object that passed is not read again -- unless set_debug_checks(True)
     layer = make_layer(amd, orc.SGC_LL_RESLAP, Fout, Fin, len(sizes), K, orc.PAPER, p, DEV)
     gb = batch(Ls)
     tv = lambda Lp: amd.TileViews(torch.from_numpy(pack_tiles_np(Lp, plan)).to(DEV), plan, symmetric=True)  # noqa: E731
-    layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tv(good)})
-    layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tv(bad)})      # second call of the same layer: not re-checked
+    tgood = tv(good)
+    layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tgood})
+    assert tgood._verified and gb._l0_verified
+    with pytest.raises(amd.AgcnError, match="previous Laplacian.*NOT symmetric"):
+        layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tv(bad)})   # a later call of the same layer, a new object
+    with pytest.raises(amd.AgcnError, match="original Laplacian.*NOT symmetric"):
+        layer({"node_features": gb.X, "graph_batch": batch(Lbad), "res_lap": tgood})      # a new vouched batch
+    # a verified object that is then modified in place is caught under the debug mode only
+    tgood.data[int(plan.tile_off[1]) + 3 * sizes[1] + 17] += 1e-3
+    layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tgood})
     prev = amd.set_debug_checks(True)
     try:
         with pytest.raises(amd.AgcnError, match="NOT symmetric"):
-            layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tv(bad)})
+            layer({"node_features": gb.X, "graph_batch": gb, "res_lap": tgood})
     finally:
         amd.set_debug_checks(prev)
 
@@ -2266,6 +2275,50 @@ def test_autograd_reserves_are_leased_not_allocated(amd):
     del y
     gc.collect()
     assert pooled() == n1 + 1
+    torch.cuda.synchronize()
+    amd.functional.check_device_status()
+
+
+def test_captured_reserves_belong_to_the_graphed_step(amd):
+    """A pooled reserve that a stream capture pins is owned by the capturing GraphedStep (functional.capture_scope) and freed
+    with it -- not appended to a process-wide list for good; release_reserve_pool() empties the idle pool."""
+    import gc
+    from agcn_amd import functional as fn, synth
+    B, Fin, Fout, K = 32, 75, 64, 2
+    data = synth.tox21_batch(3, B, Fin)
+    gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], DEV)
+    layer = amd.SGC_LL(Fout, Fin, B, K=K, laplacian_mode="paper", device=DEV)
+    layer.load_vars(synth.glorot_params(np.random.RandomState(5), Fin, Fout, K))
+    G = torch.randn(gb.plan.rows, Fout, device=DEV)
+    X = gb.X.clone().requires_grad_(True)
+
+    def step():
+        X.grad = None
+        for v in layer.vars.values():
+            v.grad = None
+        nodes, _, _ = layer({"node_features": X, "graph_batch": gb})
+        (nodes.data * G).sum().backward()
+        return X.grad
+
+    gc.collect()
+    fn.release_reserve_pool(force=True)
+    assert fn.reserve_pool_bytes() == (0, 0)
+    gs = amd.GraphedStep(step, DEV)
+    pinned = gs.pinned_reserve_bytes
+    assert pinned > 0 and fn.reserve_pool_bytes() == (0, 0)       # the warm-up's buffer went into the graph, nowhere else
+    g1 = gs.replay().clone()
+    g2 = gs.replay().clone()
+    assert torch.equal(g1, g2) and bool(torch.isfinite(g1).all())
+    gs.reset()
+    assert gs.pinned_reserve_bytes == 0 and fn.reserve_pool_bytes() == (0, 0)
+    del gs
+    # a capture outside any scope is accounted for and can be dropped explicitly
+    eager = step().clone()
+    assert torch.equal(eager, g1)
+    gc.collect()
+    idle, _ = fn.reserve_pool_bytes()
+    assert idle > 0
+    assert fn.release_reserve_pool() == idle and fn.reserve_pool_bytes() == (0, 0)
     torch.cuda.synchronize()
     amd.functional.check_device_status()
 

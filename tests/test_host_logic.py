@@ -376,3 +376,48 @@ def test_hiv_epoch_plan_is_a_balanced_partition():
             assert max(sizes) <= 256 and max(sizes) == -(-sum(sizes) // world)      # (never more than the even share, rounded up)
             loads = np.array([cost[per_rank[r][j]].sum() for r in range(world)], dtype=np.float64)
             assert loads.max() / loads.mean() < 1.05
+
+
+def test_member_budget_overrides_are_reference_counted(amd):
+    """engine._member_budget (what SgcLLEpochLanes with more than two lanes lowers): the knob holds the minimum over the live
+    overrides and returns to the value the first one found when the LAST one is released, in whatever order they go."""
+    from agcn_amd import engine
+    lib = amd._ffi.lib()
+    old = lib.agcn_get_coop_members()
+    try:
+        lib.agcn_set_coop_members(120)
+        mb = engine._MemberBudget()
+        a = mb.acquire(80)
+        assert lib.agcn_get_coop_members() == 80
+        b = mb.acquire(60)
+        assert lib.agcn_get_coop_members() == 60
+        mb.release(a)                                   # the first object closes first: the second one's budget stays
+        assert lib.agcn_get_coop_members() == 60
+        c = mb.acquire(100)
+        assert lib.agcn_get_coop_members() == 60
+        mb.release(b)
+        assert lib.agcn_get_coop_members() == 100
+        mb.release(b)                                   # (a late finaliser releasing twice changes nothing)
+        assert lib.agcn_get_coop_members() == 100
+        mb.release(c)
+        assert lib.agcn_get_coop_members() == 120
+        lib.agcn_set_coop_members(90)                   # a new base is read when the next first override is taken
+        d = mb.acquire(200)
+        assert lib.agcn_get_coop_members() == 90
+        mb.release(d)
+        assert lib.agcn_get_coop_members() == 90
+    finally:
+        lib.agcn_set_coop_members(old)
+
+
+def test_reserve_size_classes(amd):
+    """functional._size_class: 256 KB classes below 64 MB, at most +12.5 % above (a reserve that grows by a few KB finds the
+    pooled buffer of the batch before it); monotone and never below the request."""
+    from agcn_amd import functional as fn
+    prev = 0
+    for r in [1, 65536, 262144, 262145, (64 << 20) - 1, 64 << 20, (64 << 20) + 1, 256 << 20, (256 << 20) + 4096, 1 << 30,
+              (1 << 30) + 1, 3 << 30]:
+        c = fn._size_class(r)
+        assert c >= r and c >= prev and c <= max(r + 262143, r * 1.125 + 1), (r, c)
+        prev = c
+    assert fn._size_class((256 << 20) + 4096) == fn._size_class((256 << 20) + 8192)
