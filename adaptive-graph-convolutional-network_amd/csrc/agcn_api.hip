@@ -486,6 +486,7 @@ using namespace agcn;
 // Which kernels a forward / backward call on this batch would launch (host logic only: nothing is launched, no device
 // pointer is dereferenced).  For tests and diagnostics.
 static bool cloud_shape(const AgcnLayerDesc* d);
+static bool split_images(const AgcnLayerDesc* d);
 static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi);
 
 // bf16 feature storage is served when every graph of the batch takes the specialised kernels in both directions (the general
@@ -591,6 +592,8 @@ extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const voi
 static bool cloud_shape(const AgcnLayerDesc* d) {
   return (d->variant == AGCN_SGC_LL || d->variant == AGCN_SGC_LL_RESLAP) && d->K == 2 && (d->Fin == 64 || d->Fin == 128);
 }
+// layer shapes whose packed-row products may run on the split-bf16 kernels (rows_split.hip): room for their parameter images
+static bool split_images(const AgcnLayerDesc* d) { return cloud_shape(d) && (d->Fout == 64 || d->Fout == 128); }
 // Batches the point-cloud kernels (cloud_kernels.hip) may take: what the slab kernels take (SGC_LL), and SGC_LL_Reslap with a
 // dense symmetric L_orig on packed rows (cloud_path() checks the rest: multiples of 64 nodes, alignment, Fin = 64)
 static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
@@ -625,10 +628,11 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   float *t, *b;
   global_scratch_floats(desc, host, false, &c, &t, &b);
   if (cloud_shape(desc)) c.take(cloud_dpart_floats(host.info.tile_elems));
+  if (split_images(desc)) c.take(rows_split_fwd_image_bytes(desc->Fin, desc->Fout) / 4);
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT, *MT, *spart; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT, *MT, *spart, *simg; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -661,6 +665,7 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
   w->n_glb = (int)global_scratch_floats(d, host, true, &c, &w->tile, &w->buf);
   w->WT = cloud_shape(d) ? c.take((size_t)d->K * d->Fout * d->Fin) : nullptr;   // cloud kernels: W^T for the filter adjoint
   w->MT = (cloud_shape(d) && d->Fin == 128 && paper) ? c.take((size_t)d->Fin * d->Fin) : nullptr;   // rows_wide.hip: M_L^T
+  w->simg = split_images(d) ? c.take(rows_split_bwd_image_bytes(d->Fin, d->Fout) / 4) : nullptr;    // rows_split.hip: images of W^T, M_L^T
   return c.off;
 }
 
@@ -717,6 +722,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   Carver c(workspace);
   const int n_glb = (int)global_scratch_floats(desc, host, false, &c, &a.ws_tile, &a.ws_buf);
   float* dpart = cloud_shape(desc) ? c.take(cloud_dpart_floats(host.info.tile_elems)) : nullptr;
+  float* simg = split_images(desc) ? c.take(rows_split_fwd_image_bytes(desc->Fin, desc->Fout) / 4) : nullptr;
   if (c.off > workspace_bytes || ((n_glb > 0 || dpart) && !workspace))
     return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, c.off);
 
@@ -831,8 +837,13 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     if (desc->Fin != 128) return launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
     // 128 input features: Z = X M_L and the filter product as packed-row launches around the strip kernels
     const bool rw = rows_wide_ok(host.info.rows, desc->Fin, desc->Fout, desc->K, desc->ldx, desc->ldy);
+    const bool rsp = simg && rows_split_ok(host.info.rows, desc->Fin, desc->Fout, desc->K, desc->ldx, desc->ldy);
     RowsGemmArgs g;
-    if (rw) {
+    if (rsp) {     // (rows_split.hip: bf16 matrix pipe at fp32 accuracy; one launch builds the images of M_L and W)
+      rc = launch_rows_split_fwd_images(params->M_L, params->weight, desc->Fin, desc->Fout, simg, hip_stream);
+      if (rc != AGCN_OK) return rc;
+      rc = launch_rows_split_project(batch->X, desc->ldx, a.sv_Z, desc->Fin, host.info.rows, simg, hip_stream);
+    } else if (rw) {
       rc = launch_rows_wide_project(batch->X, desc->ldx, params->M_L, a.sv_Z, host.info.rows, hip_stream);
     } else {
       fill_rows(g, desc, host, dev);
@@ -843,6 +854,9 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
     if (rc != AGCN_OK) return rc;
     rc = launch_cloud_forward(a, dpart, host.info.max_n, host.info.tile_elems, hip_stream);
     if (rc != AGCN_OK) return rc;
+    if (rsp)
+      return launch_rows_split_filter(batch->X, desc->ldx, a.sv_X, desc->Fin, params->bias, desc->activation == AGCN_ACT_RELU ? 1 : 0,
+                                      out->Y, desc->ldy, desc->Fin, desc->Fout, host.info.rows, simg, hip_stream);
     if (rw)
       return launch_rows_wide_filter(batch->X, desc->ldx, a.sv_X, params->weight, params->bias, desc->activation == AGCN_ACT_RELU ? 1 : 0,
                                      out->Y, desc->ldy, desc->Fout, host.info.rows, hip_stream);
@@ -1133,13 +1147,22 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     a.slab_quad = slab_quad_ok(host);
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd; a.ws_Gp = w.Gp;
+    a.rs_img = w.simg;
     // point clouds: either backward works behind either forward (both forwards leave Z, X_1, s and the r tiles)
     RowsGemmArgs g;
     if (cloud_res || cloud_bwd) {
       const bool wide = desc->Fin == 128;
       const bool rw = wide && w.WT != nullptr && (w.MT != nullptr || !paper) &&
                       rows_wide_ok(host.info.rows, desc->Fin, desc->Fout, desc->K, desc->ldx, desc->ldy);
-      if (rw) {      // (rows_wide.hip; the parameter gradients then take the row-chunk partials: no arrival counters to zero)
+      const bool rsp = rw && w.simg && rows_split_ok(host.info.rows, desc->Fin, desc->Fout, desc->K, desc->ldx, desc->ldy);
+      if (rsp) {     // (rows_split.hip: one launch builds the images of W^T and M_L^T -- no transposes)
+        rc = launch_rows_split_bwd_images(params->M_L, params->weight, desc->Fin, desc->Fout, paper, w.simg, hip_stream);
+        if (rc != AGCN_OK) return rc;
+        rc = launch_rows_split_filter_bwd(dY, fwd->Y, desc->ldy, desc->activation == AGCN_ACT_RELU ? 1 : 0, w.Gp, grads->dX, desc->ldx,
+                                          w.g, desc->Fin, desc->Fout, host.info.rows, w.simg, hip_stream);
+        if (rc != AGCN_OK) return rc;
+        filter_bwd_zeroed = false;
+      } else if (rw) {      // (rows_wide.hip; the parameter gradients then take the row-chunk partials: no arrival counters to zero)
         rc = launch_rows_wide_filter_bwd(dY, fwd->Y, desc->ldy, desc->activation == AGCN_ACT_RELU ? 1 : 0, params->weight, params->M_L,
                                          w.WT, w.MT, w.Gp, grads->dX, desc->ldx, w.g, desc->Fout, host.info.rows, hip_stream);
         if (rc != AGCN_OK) return rc;
@@ -1162,7 +1185,10 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         rc = launch_cloud_backward(a, fwd_cloud ? nullptr : w.WT, hip_stream);
       }
       if (rc != AGCN_OK) return rc;
-      if (rw && paper) {
+      if (rsp && paper) {
+        rc = launch_rows_split_project_bwd(w.dZ, grads->dX, desc->ldx, desc->Fin, desc->Fout, host.info.rows, w.simg, hip_stream);
+        if (rc != AGCN_OK) return rc;
+      } else if (rw && paper) {
         rc = launch_rows_wide_project_bwd(w.dZ, w.MT, grads->dX, desc->ldx, host.info.rows, hip_stream);
         if (rc != AGCN_OK) return rc;
       } else if (wide && paper) {   // dX += dZ . M_L^T

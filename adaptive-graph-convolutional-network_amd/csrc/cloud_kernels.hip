@@ -31,6 +31,7 @@
 //    halves is linear in the per-half products, so the second run adds to the first one's outputs.
 // Reductions are per-lane sequential + fixed shuffle trees: bit-reproducible.  No floating-point atomics.
 #include "agcn_device.h"
+#include "bf16_split.h"
 #include "sgc_kernels.h"
 
 #include <float.h>
@@ -728,48 +729,9 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_ref_kernel(SgcArgs a) {
 // everywhere in this file): 54 KB + the four L patches = 72 KB of LDS, two workgroups per CU.  B pieces are requested one
 // 6-MFMA block ahead.  History: on the f32 MFMA instruction 143-154 us; P alone on bf16 x 6 with 8-wave workgroups (110 KB:
 // ONE workgroup per CU, nothing to run behind its barriers) 211 us; this kernel 121 us.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int LDH = 72;                          // bf16 elements per image row (144 bytes)
 constexpr int PLANE_H = 64 * LDH;                // bf16 elements per plane
-// two floats -> their three bf16 pieces, packed (low half = x0)
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-  const bf16x2 hv = (bf16x2){(__bf16)x0, (__bf16)x1};
-  h = __builtin_bit_cast(uint32_t, hv);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  const bf16x2 mv = (bf16x2){(__bf16)r0, (__bf16)r1};
-  m = __builtin_bit_cast(uint32_t, mv);
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-  const bf16x2 lv = (bf16x2){(__bf16)s0, (__bf16)s1};
-  l = __builtin_bit_cast(uint32_t, lv);
-}
-struct Pieces { u32x4 h, m, l; };                // eight consecutive k of one row / column
-__device__ __forceinline__ Pieces split3x8(const f32x4& lo, const f32x4& hi) {
-  uint32_t h[4], m[4], l[4];
-  split3(lo.x, lo.y, h[0], m[0], l[0]);
-  split3(lo.z, lo.w, h[1], m[1], l[1]);
-  split3(hi.x, hi.y, h[2], m[2], l[2]);
-  split3(hi.z, hi.w, h[3], m[3], l[3]);
-  Pieces p;
-  p.h = (u32x4){h[0], h[1], h[2], h[3]}; p.m = (u32x4){m[0], m[1], m[2], m[3]}; p.l = (u32x4){l[0], l[1], l[2], l[3]};
-  return p;
-}
-__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma_x6(const Pieces& A, const Pieces& B, f32x4 acc) {
-  acc = mfma_bf(A.l, B.h, acc);
-  acc = mfma_bf(A.h, B.l, acc);
-  acc = mfma_bf(A.m, B.m, acc);
-  acc = mfma_bf(A.m, B.h, acc);
-  acc = mfma_bf(A.h, B.m, acc);
-  acc = mfma_bf(A.h, B.h, acc);
-  return acc;
-}
 // B pieces [k = 8q .. 8q + 7 of the block][column r]: rows of an image (the column index is the image ROW: 16-byte reads) ...
 __device__ __forceinline__ Pieces rows_B(const uint16_t* img, int off) {
   Pieces b;
@@ -1743,7 +1705,9 @@ int launch_cloud_param_partials(const ParamGradArgs& a0, void* stream) {
   a.n_chunks = std::max(1, std::min(a0.n_chunks, (a0.rows + chunk_target - 1) / chunk_target));
   a.chunk_rows = ((a0.rows + a.n_chunks - 1) / a.n_chunks + 63) / 64 * 64;
   const unsigned zm = a.paper ? 1u : 0u;   // the X^T dZ slice
-  int rc = a.Fin == 2 * FIN ? launch_rows_wide_param_partials(a, stream) : a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks, 2, 2 + zm), 256, 0, PK_PARAM_PARTIAL,
+  const bool split = (a0.rows & 31) == 0 && rows_split_ok(a0.rows, a0.Fin, a0.Fout, a0.K, a0.ldx, a0.Fout);
+  if (split) a = a0;                        // (rows_split.hip chooses its own chunks, at most the caller's count)
+  int rc = split ? launch_rows_split_param_partials(a, stream) : a.Fin == 2 * FIN ? launch_rows_wide_param_partials(a, stream) : a.Fout == 128 ? launch_cloud(cloud_param_partial_kernel<128>, dim3((unsigned)a.n_chunks, 2, 2 + zm), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a)
                        : launch_cloud(cloud_param_partial_kernel<64>, dim3((unsigned)a.n_chunks, 2, 1 + zm), 256, 0, PK_PARAM_PARTIAL,
                                       "cloud_param_partial", stream, a);
@@ -1751,6 +1715,28 @@ int launch_cloud_param_partials(const ParamGradArgs& a0, void* stream) {
   const int64_t total = (int64_t)a.K * a.Fin * a.Fout + a.Fout + (a.paper ? (int64_t)a.Fin * a.Fin : 0);
   return launch_cloud(cloud_param_reduce_kernel, dim3((unsigned)((total + 63) / 64)), 512, 0, PK_PARAM_REDUCE, "cloud_param_reduce",
                       stream, a);
+}
+
+// The packed filter adjoint of a 64-feature layer: Gp = dY act'(Y), g_0 = Gp W_0^T -> dX, g_1 = Gp W_1^T -> workspace.  On the bf16
+// matrix pipe at fp32 accuracy (rows_split.hip: one launch builds the image of [W_0^T | W_1^T]) where the caller gave the image
+// workspace, else cloud_filter_bwd_kernel behind the transposed copy of W (`WT`, or the one the cloud forward left in the reserve).
+static int packed_filter_bwd(const SgcArgs& a, float* WT, unsigned strips, void* stream) {
+  if (a.rs_img != nullptr && rows_split_ok(a.rows, a.Fin, a.Fout, a.K, a.ldx, a.ldy)) {
+    int rc = launch_rows_split_bwd_images(a.M_L, a.weight, a.Fin, a.Fout, false, a.rs_img, stream);
+    if (rc != AGCN_OK) return rc;
+    return launch_rows_split_filter_bwd(a.dY, a.Y, a.ldy, a.activation == AGCN_ACT_RELU ? 1 : 0, a.ws_Gp, a.dX, a.ldx, a.ws_g, a.Fin, a.Fout,
+                                        a.rows, a.rs_img, stream);
+  }
+  int rc = AGCN_OK;
+  if (WT != nullptr)
+    rc = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep", stream,
+                      a.weight, WT, a.Fout, 2);
+  else
+    WT = a.sv_WT;
+  if (rc != AGCN_OK) return rc;
+  return launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD, "cloud_filter_bwd",
+                      stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0, (const float*)WT, a.ws_Gp, a.dX,
+                      a.ldx, a.ws_g);
 }
 
 // Gp, g_0 -> dX, g_1 (the packed filter adjoint), then the strip kernels.  `WT`: K * Fout * 64 floats of workspace for W^T, or
@@ -1761,16 +1747,7 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   const unsigned strips = (unsigned)(a.n_slabs / 4);
   if (a.dL_sum != nullptr) return fail(AGCN_EINVAL, "cloud kernels: a gradient of L_sum is not supported");
   if (!wide) {
-    int rc0 = AGCN_OK;
-    if (WT != nullptr)
-      rc0 = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep",
-                         stream, a.weight, WT, a.Fout, 2);
-    else
-      WT = a.sv_WT;
-    if (rc0 != AGCN_OK) return rc0;
-    rc0 = launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD,
-                       "cloud_filter_bwd", stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0,
-                       (const float*)WT, a.ws_Gp, a.dX, a.ldx, a.ws_g);
+    int rc0 = packed_filter_bwd(a, WT, strips, stream);
     if (rc0 != AGCN_OK) return rc0;
   }
   const dim3 grid(xcd_grid((int)strips));
@@ -1805,15 +1782,7 @@ int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void
   const unsigned strips = (unsigned)(a.n_slabs / 4);
   int rc = AGCN_OK;
   if (!wide) {
-    if (WT != nullptr)
-      rc = launch_cloud(cloud_prep_kernel, dim3((unsigned)((2 * a.Fout * FIN + 255) / 256)), 256, 0, PK_FILTER_BWD, "cloud_prep", stream,
-                        a.weight, WT, a.Fout, 2);
-    else
-      WT = a.sv_WT;
-    if (rc != AGCN_OK) return rc;
-    rc = launch_cloud(cloud_filter_bwd_kernel, dim3(strips), 256, sizeof(float) * 4 * 16 * (a.Fout + 8), PK_FILTER_BWD, "cloud_filter_bwd",
-                      stream, a.dY, (const float*)a.Y, a.ldy, a.Fout, a.activation == AGCN_ACT_RELU ? 1 : 0, (const float*)WT, a.ws_Gp, a.dX,
-                      a.ldx, a.ws_g);
+    rc = packed_filter_bwd(a, WT, strips, stream);
     if (rc != AGCN_OK) return rc;
   }
   const dim3 grid(xcd_grid((int)strips));

@@ -22,7 +22,7 @@ const char* const kNames[PK_COUNT] = {
     "slab_bwd1_kernel", "slab_bwd2_kernel", "fused_forward_kernel", "fused_backward_kernel",
     "param_grad_onepass_kernel", "spec_forward_kernel", "spec_backward_kernel",
     "cloud_sim_kernel", "cloud_degree_kernel", "cloud_lap_kernel", "cloud_bwd1_kernel", "cloud_bwd2_kernel",
-    "cloud_rnorm_kernel", "cloud_rlap1_kernel", "cloud_rbwd_kernel<A>", "cloud_rbwd_kernel<B>", "cloud_rbwd_kernel<C>", "param_grad_tagged_kernel"};
+    "cloud_rnorm_kernel", "cloud_rlap1_kernel", "cloud_rbwd_kernel<A>", "cloud_rbwd_kernel<B>", "cloud_rbwd_kernel<C>", "param_grad_tagged_kernel", "rs_presplit_kernel"};
 
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }

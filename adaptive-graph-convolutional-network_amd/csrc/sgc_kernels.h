@@ -98,6 +98,8 @@ struct SgcArgs {
   // (`half_acc`: n x n outputs read-modify-write, per-graph sums and ds added to the first run's); `half_last` = this run
   // finishes the quantities that need both halves (dd).  64-feature layers: foff 0, fstride 64, half_acc 0, half_last 1.
   int32_t foff, fstride, half_acc, half_last;
+  // backward: workspace for the parameter images of the split-bf16 packed-row kernels (rows_split.hip), or nullptr
+  void* rs_img;
 };
 
 enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3, RG_DENSE = 4 };
@@ -158,7 +160,7 @@ struct ParamGradArgs {
 enum { PK_PROJECT = 0, PK_GRAPH_FWD, PK_FILTER, PK_FILTER_BWD, PK_GRAPH_BWD, PK_PROJECT_BWD, PK_PARAM_PARTIAL,
        PK_PARAM_REDUCE, PK_SLAB_SIM, PK_SLAB_LAP, PK_SLAB_BWD1, PK_SLAB_BWD2, PK_FUSED_FWD, PK_FUSED_BWD,
        PK_PARAM_ONEPASS, PK_SPEC_FWD, PK_SPEC_BWD, PK_CLOUD_SIM, PK_CLOUD_DEG, PK_CLOUD_LAP, PK_CLOUD_BWD1,
-       PK_CLOUD_BWD2, PK_CLOUD_RNORM, PK_CLOUD_RLAP1, PK_CLOUD_RBWD_A, PK_CLOUD_RBWD_B, PK_CLOUD_RBWD_C, PK_PARAM_TAGGED, PK_COUNT };
+       PK_CLOUD_BWD2, PK_CLOUD_RNORM, PK_CLOUD_RLAP1, PK_CLOUD_RBWD_A, PK_CLOUD_RBWD_B, PK_CLOUD_RBWD_C, PK_PARAM_TAGGED, PK_ROWS_PRESPLIT, PK_COUNT };
 // Raises a kernel's dynamic-LDS cap (hipFuncAttributeMaxDynamicSharedMemorySize) once per kernel and size: the
 // driver call is skipped when the cap already covers `bytes` (it costs several microseconds per launch otherwise).
 // Tracked per (device, kernel).  Returns hipSuccess (0) or the HIP error code.
@@ -213,6 +215,19 @@ int launch_rows_wide_filter_bwd(const float* dY, const float* Y, int ldy, int re
                                 float* Gp, float* dX, int ldx, float* g1, int Fout, int rows, void* stream);
 int launch_rows_wide_project_bwd(const float* dZ, const float* MT, float* dX, int ldx, int rows, void* stream);
 int launch_rows_wide_param_partials(const ParamGradArgs& a, void* stream);
+// the same products on the bf16 matrix pipe at fp32 accuracy (rows_split.hip): parameter images built once per call into workspace
+bool rows_split_ok(int rows, int Fin, int Fout, int K, int ldx, int ldy);
+size_t rows_split_fwd_image_bytes(int Fin, int Fout);
+size_t rows_split_bwd_image_bytes(int Fin, int Fout);
+int launch_rows_split_fwd_images(const float* M, const float* W, int Fin, int Fout, void* img, void* stream);
+int launch_rows_split_bwd_images(const float* M, const float* W, int Fin, int Fout, bool with_m, void* img, void* stream);
+int launch_rows_split_project(const float* X, int ldx, float* Z, int Fin, int rows, const void* img, void* stream);
+int launch_rows_split_filter(const float* X0, int ldx, const float* X1, int ldx1, const float* bias, int relu, float* Y, int ldy, int Fin,
+                             int Fout, int rows, const void* img, void* stream);
+int launch_rows_split_filter_bwd(const float* dY, const float* Y, int ldy, int relu, float* Gp, float* dX, int ldx, float* g1, int Fin,
+                                 int Fout, int rows, const void* img, void* stream);
+int launch_rows_split_project_bwd(const float* dZ, float* dX, int ldx, int Fin, int Fout, int rows, const void* img, void* stream);
+int launch_rows_split_param_partials(ParamGradArgs& a, void* stream);   // sets a.n_chunks / a.chunk_rows for the reduce
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper);
 // the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number
