@@ -94,7 +94,7 @@ SYMBOLS = [
     "agcn_plan_bytes", "agcn_plan_bytes_for", "agcn_plan_build", "agcn_plan_info",
     "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
     "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
-    "agcn_sgc_ll_dispatch_info", "agcn_sgc_ll_reserve_status", "agcn_set_device_status_word", "agcn_device_status", "agcn_get_coop_timeout_ticks", "agcn_set_coop_timeout_ticks", "agcn_tiles_asymmetry", "agcn_epoch_step", "agcn_get_spec_tail", "agcn_set_spec_tail",
+    "agcn_sgc_ll_dispatch_info", "agcn_sgc_ll_reserve_status", "agcn_set_device_status_word", "agcn_device_status", "agcn_get_coop_timeout_ticks", "agcn_set_coop_timeout_ticks", "agcn_tiles_asymmetry", "agcn_epoch_step", "agcn_get_spec_tail", "agcn_set_spec_tail", "agcn_get_rows_split", "agcn_set_rows_split",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
     "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
@@ -201,6 +201,10 @@ def _declare(lib):
     lib.agcn_get_spec_tail.argtypes = []
     lib.agcn_set_spec_tail.restype = None
     lib.agcn_set_spec_tail.argtypes = [I32]
+    lib.agcn_get_rows_split.restype = I32
+    lib.agcn_get_rows_split.argtypes = []
+    lib.agcn_set_rows_split.restype = None
+    lib.agcn_set_rows_split.argtypes = [I32]
     lib.agcn_get_coop_timeout_ticks.restype = C.c_uint32
     lib.agcn_get_coop_timeout_ticks.argtypes = []
     lib.agcn_set_coop_timeout_ticks.restype = None

@@ -82,6 +82,14 @@ std::atomic<int32_t> g_spec_tail{[] {
   const char* e = std::getenv("AGCN_SPEC_TAIL");
   return (e && e[0] == '1') ? 1 : 0;
 }()};
+// 1 (default; env AGCN_ROWS_SPLIT=0 turns it off): the packed-row products of point-cloud sized batches run on the bf16 matrix pipe
+// at fp32 accuracy (rows_split.hip); 0: the fp32-MFMA kernels of rows_wide.hip / cloud_kernels.hip
+std::atomic<int32_t> g_rows_split{[] {
+  const char* e = std::getenv("AGCN_ROWS_SPLIT");
+  return (e && e[0] == '0') ? 0 : 1;
+}()};
+extern "C" int32_t agcn_get_rows_split(void) { return g_rows_split.load(); }
+extern "C" void agcn_set_rows_split(int32_t on) { g_rows_split.store(on ? 1 : 0); }
 extern "C" int32_t agcn_get_spec_tail(void) { return g_spec_tail.load(); }
 extern "C" void agcn_set_spec_tail(int32_t on) { g_spec_tail.store(on ? 1 : 0); }
 extern "C" void agcn_set_spec_small(int32_t on) { g_spec_small.store(on < 0 ? 0 : (on > 2 ? 2 : on)); }

@@ -406,10 +406,7 @@ __global__ __launch_bounds__(PT) void rs_param_kernel(ParamGradArgs a) {
   else rs_param_body<FIN, FIN>(a, a.X, a.ldx, a.dZ, FIN, out + (int64_t)2 * FIN * FOUT + FOUT, FIN, 0, nullptr, lds);
 }
 
-bool rs_env() {
-  static const int off = [] { const char* e = std::getenv("AGCN_ROWS_SPLIT"); return (e && e[0] == '0') ? 1 : 0; }();
-  return !off;
-}
+bool rs_env() { return agcn_get_rows_split() != 0; }
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int KB, int NT, int NCB, int MODE>

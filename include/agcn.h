@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AGCN_VERSION 104 /* 0.1.4: AgcnLayerDesc.feat_dtype (bf16 features read / written by the specialised kernels) */
+#define AGCN_VERSION 105 /* 0.1.5: agcn_get / set_rows_split (packed-row products of point-cloud batches on the bf16 matrix pipe) */
 
 enum {
   AGCN_OK = 0,
@@ -523,6 +523,14 @@ void agcn_set_spec_tail(int32_t on);
  * deterministic way to exercise the reporting path (status words, NaN poisoning) in a test.  Process-wide. */
 uint32_t agcn_get_coop_timeout_ticks(void);
 void agcn_set_coop_timeout_ticks(uint32_t ticks);
+
+/* 1 (default; env AGCN_ROWS_SPLIT=0): the packed-row products of point-cloud sized batches (>= 1024 packed rows, 64 / 128 features,
+ * K = 2: Z = X M_L, the filter and its adjoint, dX += dZ M_L^T, the parameter-gradient partials) run on the bf16 matrix pipe at fp32
+ * accuracy -- every fp32 operand split exactly into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per 32 k (csrc/rows_split.hip);
+ * 0: the fp32-MFMA kernels (csrc/rows_wide.hip, csrc/cloud_kernels.hip).  Results differ by fp32 summation order only; both
+ * bit-reproducible.  Process-wide. */
+int32_t agcn_get_rows_split(void);
+void agcn_set_rows_split(int32_t on);
 
 /* Environment switches of the point-cloud kernels, read once per process (A/B measurements; results within the same
  * tolerances either way): AGCN_SLAB_SMALL=0 -- slab batches with Fin <= 4 and a dense L_orig take the general slab

@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(amd):
     for name in declared:
         assert hasattr(lib, name), "libagcn_hip.so does not export %s" % name
     assert sorted(amd._ffi.SYMBOLS) == declared
-    assert lib.agcn_version() == 104
+    assert lib.agcn_version() == 105
 
 
 def test_header_constants_match_the_c_header(amd):
@@ -147,7 +147,8 @@ def test_new_entry_points_validate_before_launching(amd):
                                    (lib.agcn_set_param_grad_onepass, lib.agcn_get_param_grad_onepass, (0, 1, 2)),
                                    (lib.agcn_set_fused_mode, lib.agcn_get_fused_mode, (0, 2, 3, 1)),
                                    (lib.agcn_set_spec_mode, lib.agcn_get_spec_mode, (0, 1, 2, 3, 7)),
-                                   (lib.agcn_set_spec_small, lib.agcn_get_spec_small, (0, 1, 2))):
+                                   (lib.agcn_set_spec_small, lib.agcn_get_spec_small, (0, 1, 2)),
+                                   (lib.agcn_set_rows_split, lib.agcn_get_rows_split, (0, 1))):
         for v in values:
             setter(v)
             assert getter() == v

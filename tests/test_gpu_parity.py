@@ -1297,6 +1297,61 @@ def _sym_prev(rs, n, scale=0.05):
 # case -> (variant, Fin, Fout, sizes, previous Laplacian: None | "symmetric" | "asymmetric", gradient on L_sum).  Every case is
 # spelt out and asserted inside the test: an id that is not in this table cannot run (round 3 had two ids that fell through to
 # the defaults and re-ran the first case).
+@pytest.mark.parametrize("Fin,Fout", [(64, 128), (128, 128), (128, 64)])
+def test_packed_row_products_on_the_bf16_pipe(amd, Fin, Fout):
+    """The packed-row products of a point-cloud layer (projection, filter, filter adjoint, projection adjoint, parameter-gradient
+    partials) on the bf16 matrix pipe at fp32 accuracy (csrc/rows_split.hip; agcn_set_rows_split, default on) against the
+    fp32-MFMA kernels they replace (knob off): the same results to 2 x the parity bars (two fp32 evaluations that differ in
+    summation order), the split kernels are the ones that ran (library profiler), and they are bit-reproducible run to run.
+    Rows = 1024 + 64: the last 128-row workgroup is partly empty.  (Both paths against the float64 oracle:
+    test_modelnet_hidden_layer_at_size, test_point_cloud_reslap_hidden_layer.)"""
+    sizes, K, mode = [1024, 64], 2, orc.PAPER
+    rs = np.random.RandomState(500 + Fin + Fout)
+    Xs, Ls, Gs = [], [], []
+    for n in sizes:
+        X, L, G = _cloud_case(rs, n, Fin, Fout, thresh=0.6)
+        Xs.append(X); Ls.append(L); Gs.append(G)
+    p = orc.init_params(rs, Fin, Fout, K, orc.SGC_LL)
+    p["bias"] = (0.1 * rs.randn(Fout)).astype(np.float32)
+    lib = amd._ffi.lib()
+    prev = lib.agcn_get_rows_split()
+
+    def run(split):
+        lib.agcn_set_rows_split(split)
+        lib.agcn_profile_enable(1)
+        try:
+            amd._ffi.profile_collect()
+            layer, gb, Xt, nodes, res_L, res_W = _run_dense_clouds(amd, sizes, Xs, Ls, Gs, p, Fin, Fout, K, mode)
+            torch.cuda.synchronize()
+            prof = {k: v[1] for k, v in amd._ffi.profile_collect().items() if v[1]}
+        finally:
+            lib.agcn_profile_enable(0)
+        out = {"Y": nodes.data.detach().clone(), "dX": Xt.grad.clone()}
+        for k in ("weight", "bias", "M_L", "alpha"):
+            out["d" + k] = layer.vars[k].grad.clone()
+        return out, prof
+
+    try:
+        a, prof_a = run(1)
+        a2, _ = run(1)
+        b, prof_b = run(0)
+    finally:
+        lib.agcn_set_rows_split(prev)
+    # forward: the 128-feature layers build the images of M_L and W (the 64-feature forward keeps its fused kernels); backward:
+    # the images of W^T (and M_L^T)
+    assert prof_a.get("rs_presplit_kernel", 0) == (2 if Fin == 128 else 1), prof_a
+    assert "rs_presplit_kernel" not in prof_b, prof_b
+    assert prof_a["cloud_sim_kernel"] == 1 and prof_b["cloud_sim_kernel"] == 1
+    for k in a:
+        assert torch.equal(a[k], a2[k]), k                       # bit-reproducible
+        rtol = FEATURE_RTOL if k == "Y" else GRAD_RTOL
+        if k == "dalpha":
+            from helpers import _scalar_close
+            _scalar_close(to_np(a[k]), to_np(b[k]).astype(np.float64), None, float(np.abs(to_np(b["dweight"])).max()), "dalpha")
+        else:
+            assert_close(to_np(a[k]), to_np(b[k]).astype(np.float64), 2 * rtol, "split vs fp32-MFMA " + k)
+
+
 _RESLAP_CLOUD_CASES = {
     # the first layer of a block: no previous Laplacian (graphconv_reslap.py:188-193, empty res_lap list)
     "first_layer_of_a_block": ("reslap", 64, 128, [1024, 64], None, False),
