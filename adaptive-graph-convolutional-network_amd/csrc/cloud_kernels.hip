@@ -970,8 +970,19 @@ __device__ __forceinline__ ResScal res_scalars(const SgcArgs& a, const float* sp
   return z;
 }
 
-template <int PASS, bool PAPER, int FS = 64, bool ACC = false>   // PASS 0 = A, 1 = B, 2 = C; FS / ACC: see cloud_bwd1_paper_kernel
+// BOTH (pass A of a 128-feature layer): both 64-column halves of the feature matrices in ONE run -- the only product of the pass,
+// g_1[I] X_0[J]^T, runs over all 128 features (four k-blocks; the second half's X_0 images take the LDS planes the pass has no g_1
+// images for), so L_pre / r / L_prev / dL_sum are read once instead of once per half (2 x 420 MB, 110 + 99 us before).
+// Pass C of a 128-feature layer in one run per PART: its two jobs share nothing but the L_pre tile, and together they would need the
+// g_1 AND X_0 images of both halves (12 planes: one workgroup per CU), so with BOTH they are two launches -- CPART 1: dX[I] += La[I, :] g_1
+// over all 128 features (g_1 images of both halves, two accumulator sets; + the graph's dalpha / dbeta), CPART 2 (only with a previous
+// Laplacian): dL_prev from D = g_1 X_0^T over four k-blocks, as pass A.  4 tile passes instead of 6, no read-modify-write of dL_prev.
+template <int PASS, bool PAPER, int FS = 64, bool ACC = false, bool BOTH = false, int CPART = 0>   // PASS 0 = A, 1 = B, 2 = C; FS / ACC: see cloud_bwd1_paper_kernel
 __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* spart) {
+  static_assert(!BOTH || (FS == 128 && !ACC && (PASS == 0 || (PASS == 2 && CPART != 0))), "both halves in one run: pass A, pass C by parts");
+  static_assert(CPART == 0 || (PASS == 2 && BOTH), "pass C by parts goes with BOTH");
+  constexpr bool DO_L = PASS == 2 && CPART != 2;      // the La g_1 product, dX, the graph's dalpha / dbeta
+  constexpr bool DO_D = PASS != 2 || CPART != 1;      // the D = g_1 X_0^T product and what hangs on it
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[4 * 8];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -983,9 +994,9 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   const int n = c.n;
   const bool has_prev = a.L_prev != nullptr, has_dls = a.dL_sum != nullptr && !ACC;
   constexpr bool NEED_X = true;                       // X_0 images: the B operand of g_1[I] X_0[J]^T
-  constexpr bool NEED_G = PASS != 0;                  // g_1 images: X_0[I] g_1[J]^T (B), La g_1 (C)
+  constexpr bool NEED_G = PASS != 0 || BOTH;          // g_1 images: X_0[I] g_1[J]^T (B), La g_1 (C); BOTH: the second half's rows
   // pass C without a previous Laplacian has no dL_prev to write: only the La g_1 product is left
-  const bool want_D = PASS != 2 || has_prev;
+  const bool want_D = DO_D && (PASS != 2 || has_prev);
   uint16_t* PX = reinterpret_cast<uint16_t*>(smem);   // [3][64][LDH]
   uint16_t* PG = PX + 3 * PLANE_H;
   float* Ls = smem + (6 * PLANE_H) / 2 + wave * (16 * LD);
@@ -1011,9 +1022,10 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   if constexpr (PASS != 0) z = res_scalars(a, spart, strip - (a.slab_row[4 * strip] >> 6), n >> 6, c.b, lane);
   const float beta = has_prev ? a.beta[0] : 0.f;
   // A pieces of the wave's own rows
-  Pieces Ag[2], Ax[2];
+  constexpr int NKB = BOTH ? 4 : 2;
+  Pieces Ag[NKB], Ax[2];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
+  for (int kb = 0; kb < NKB; ++kb) {
     const float* gp = g1 + (int64_t)(c.i0 + r) * FS + 32 * kb + 8 * q;
     Ag[kb] = split3x8(*reinterpret_cast<const f32x4*>(gp), *reinterpret_cast<const f32x4*>(gp + 4));
     if constexpr (PASS == 1) {
@@ -1025,8 +1037,12 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   struct Stage { f32x4 g[4], x[4]; };
   auto stage_load16 = [&](int c0) {
     Stage st;
-    const float* gp = g1 + (int64_t)(c0 + rho) * FS + 16 * sg;
-    const float* xp = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
+    // what the PX / PG planes hold: X_0 / g_1 of this run's half; BOTH, pass A and part 2 of C: X_0's two halves; part 1 of C:
+    // g_1's second / first half
+    const float* x0 = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
+    const float* g0 = g1 + (int64_t)(c0 + rho) * FS + 16 * sg;
+    const float* xp = (BOTH && CPART == 1) ? g0 + 64 : x0;
+    const float* gp = !BOTH ? g0 : (CPART == 1 ? g0 : x0 + 64);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (NEED_G) st.g[m] = *reinterpret_cast<const f32x4*>(gp + 4 * m);
@@ -1072,9 +1088,12 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
     }
     return g;
   };
-  f32x4 acc[4];          // pass C: dX[I], tile e <-> features 16 e + r
+  constexpr int NHC = BOTH ? 2 : 1;
+  f32x4 acc[NHC][4];     // pass C: dX[I], tile e of half h <-> features 64 h + 16 e + r
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < NHC; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dsum[4] = {0.f, 0.f, 0.f, 0.f};
   float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   Stage pre = stage_load16(0);
@@ -1099,21 +1118,24 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
       for (int t = 0; t < 4; ++t) {
         const bool diag = row == c0 + 4 * r + t;
         Sv[i][t] = (!PAPER || PASS == 2 || diag) ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);
-        if constexpr (PASS == 2) Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(Lp[i][t] * scL, alpha);      // La
+        if constexpr (DO_L) Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(Lp[i][t] * scL, alpha);      // La
       }
     }
     if (c0 + CC < n) cur = load_early(c0 + CC);
-    if constexpr (PASS == 2) __builtin_amdgcn_wave_barrier();
+    if constexpr (DO_L) __builtin_amdgcn_wave_barrier();
     // L product of pass C first (its A operand, the patch, is the only consumer of La)
-    if constexpr (PASS == 2) {
+    if constexpr (DO_L) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const float* lp = Ls + r * LD + 32 * kb + 8 * q;
         const Pieces Al = split3x8(*reinterpret_cast<const f32x4*>(lp), *reinterpret_cast<const f32x4*>(lp + 4));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = mfma_x6(Al, cols_B(PG, offT + 32 * kb * LDH + 16 * e), acc[e]);
+        for (int h = 0; h < NHC; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][e] = mfma_x6(Al, cols_B(h == 0 ? PG : PX, offT + 32 * kb * LDH + 16 * e), acc[h][e]);
       }
     }
+    if constexpr (!DO_D) continue;
     // tile by tile: the product(s), then the element-wise part behind them
     f32x4 outv[4];
 #pragma unroll
@@ -1121,8 +1143,8 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
       f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (want_D) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          pa = mfma_x6(Ag[kb], rows_B(PX, offB + 16 * t * LDH + 32 * kb), pa);
+        for (int kb = 0; kb < NKB; ++kb) {
+          pa = mfma_x6(Ag[kb], rows_B(kb < 2 ? PX : PG, offB + 16 * t * LDH + 32 * (kb & 1)), pa);
           if constexpr (PASS == 1) pb = mfma_x6(Ax[kb], rows_B(PG, offB + 16 * t * LDH + 32 * kb), pb);
         }
       }
@@ -1174,7 +1196,7 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = outv[i];
     }
-    if constexpr (PASS == 2) {
+    if constexpr (PASS == 2 && DO_D) {
       if (has_prev) {
         if (ACC) {
 #pragma unroll
@@ -1209,12 +1231,14 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
       }
     }
   }
-  if constexpr (PASS == 2) {
+  if constexpr (DO_L) {
     float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dXg[(int64_t)(4 * q + i) * a.ldx + 16 * e + r] += acc[e][i];
+      for (int h = 0; h < NHC; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dXg[(int64_t)(4 * q + i) * a.ldx + 64 * h + 16 * e + r] += acc[h][e][i];
     if (lane == 0) {   // the graph's dalpha / dbeta once, at its first slab
       const bool first = c.i0 == 0;
       a.ws_pg[2 * (a.pg_slab_base + slab) + 0] = first ? z.dalpha : 0.f;
@@ -1319,6 +1343,162 @@ __global__ __launch_bounds__(256) void cloud_bwd2_kernel(SgcArgs a) {
   if (NH != 1 || a.fstride != FIN) return;   // 128-feature layer: dX += dZ M_L^T is a packed-row launch behind it
   // dX[I] += dZ[I] M_L^T   (adjoint of graphconv.py:164): B[k][f] = M_L[f][k], the lane's M_L rows read along k; tile t
   // stands for the output columns 4r + t, so a lane's four results of a row are one 16-byte read-modify-write
+  float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
+  f32x4 d[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(Cs + r * LD + 16 * blk + 4 * q);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.M_L + (int64_t)(4 * r + t) * FIN + 16 * blk + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[t] = mfma4(av[j], bv[j], d[t]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4* p = reinterpret_cast<f32x4*>(dXg + (int64_t)(4 * q + i) * a.ldx + 4 * r);
+    f32x4 v = *p;
+    v.x += d[0][i]; v.y += d[1][i]; v.z += d[2][i]; v.w += d[3][i];
+    *p = v;
+  }
+}
+
+// backward 2 with the product c Z on the BF16 matrix pipe at fp32 accuracy (bf16_split.h; the construction of the L g_1 product of
+// cloud_bwd1_paper_kernel): the chunk's Z rows are staged as three bf16 piece images per feature half and read TRANSPOSED
+// (ds_read_b64_tr_b16: k = the image row = the chunk column of c), the wave's strip of c goes through its fp32 LDS patch and is
+// split per chunk.  48 MFMAs of 16 cycles per chunk and feature half instead of 64 of 32 (the f32 kernel's matrix pipe was busy
+// 34 % / 50 % of the time at 64 / 128 features: profiles/r05_modelnet*_counters.json).  Accumulator tile e <-> features 16 e + r.
+// Used for the 128-feature layers only (launch_bwd2).
+template <int NH = 1>
+__global__ __launch_bounds__(256, 2) void cloud_bwd2_bf_kernel(SgcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = xcd_strip(a.n_slabs >> 2);
+  if (strip < 0) return;
+  const WaveCtx c = wave_ctx(a, 4 * strip + wave);
+  const int n = c.n;
+  uint16_t* PZ = reinterpret_cast<uint16_t*>(smem);               // [NH][3][64][LDH]  bf16 pieces of the chunk's Z rows
+  float* Cs = smem + (NH * 3 * PLANE_H) / 2 + wave * (16 * LD);   // [16][LD]  this wave's strip of c (fp32)
+  const float* Zg = a.sv_Z + (int64_t)c.row0 * a.fstride + a.foff;
+  const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* sjp = a.sv_s + c.row0 + 4 * r;
+  const float* ddp = a.ws_dd + c.row0 + 4 * r;
+  float si[4], ddi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    si[i] = a.sv_s[c.row0 + c.i0 + 4 * q + i];
+    ddi[i] = a.ws_dd[c.row0 + c.i0 + 4 * q + i];
+  }
+  struct Tiles { f32x4 rv[4], qv[4], sj, ddj; };
+  auto load_tiles = [&](int c0) {
+    Tiles g;
+    g.sj = *reinterpret_cast<const f32x4*>(sjp + c0);
+    g.ddj = *reinterpret_cast<const f32x4*>(ddp + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.rv[i] = *reinterpret_cast<const f32x4*>(Rt + (int64_t)i * n + c0);
+      g.qv[i] = *reinterpret_cast<const f32x4*>(Qt + (int64_t)i * n + c0);
+    }
+    return g;
+  };
+  // staging: thread = (chunk row rho = tid / 4, features 16 (tid % 4) .. + 15 of each half); image row 16 (rho % 4) + rho / 4
+  const int rho = tid >> 2, sg = tid & 3, irow = 16 * (rho & 3) + (rho >> 2);
+  struct Stage { f32x4 z[NH][4]; };
+  auto stage_load16 = [&](int c0) {
+    Stage st;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float* zp = Zg + (int64_t)(c0 + rho) * a.fstride + 64 * h + 16 * sg;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) st.z[h][m] = *reinterpret_cast<const f32x4*>(zp + 4 * m);
+    }
+    return st;
+  };
+  auto stage_store16 = [&](const Stage& st) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const Pieces pz = split3x8(st.z[h][2 * hf], st.z[h][2 * hf + 1]);
+        uint16_t* o = PZ + h * 3 * PLANE_H + irow * LDH + 16 * sg + 8 * hf;
+        *reinterpret_cast<u32x4*>(o) = pz.h; *reinterpret_cast<u32x4*>(o + PLANE_H) = pz.m; *reinterpret_cast<u32x4*>(o + 2 * PLANE_H) = pz.l;
+      }
+  };
+  f32x4 acc[NH][4];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  Stage pre = stage_load16(0);
+  Tiles cur = load_tiles(0);
+  const int offT = (8 * q + (r >> 2)) * LDH + 4 * (r & 3);         // cols_B: row 32 kb + 8q + r / 4, columns 16 e + 4 (r % 4) ..
+#pragma unroll 1
+  for (int c0 = 0; c0 < n; c0 += CC) {
+    __syncthreads();
+    stage_store16(pre);
+    __syncthreads();
+    if (c0 + CC < n) pre = stage_load16(c0 + CC);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c.i0 + 4 * q + i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float rr = cur.rv[i][t];
+        const float S = __builtin_amdgcn_exp2f(rr * NLOG2E);      // cloud_sim's instruction
+        // dS_ij = dA_ij s_i s_j + dd_j, dr_ij = -S_ij dS_ij; the pair (i, j) contributes dr_ij + dr_ji
+        const float dr = -(S * __builtin_fmaf(cur.qv[i][t] * si[i], cur.sj[t], ddi[i] + cur.ddj[t]));
+        // r == 0 (coincident rows): the term is defined as 0; S == 0 (underflow): dr = 0, never inf * 0
+        const bool ok = row != c0 + 4 * r + t && rr > 0.f && S != 0.f;
+        const float cij = ok ? dr * __builtin_amdgcn_rcpf(rr) : 0.f;
+        cs[i] += cij;
+        Cs[(4 * q + i) * LD + 16 * t + r] = cij;
+      }
+    }
+    if (c0 + CC < n) cur = load_tiles(c0 + CC);   // (into the registers just consumed; in flight behind the product)
+    __builtin_amdgcn_wave_barrier();
+    // (c Z)[I] += c[I, chunk] Z[chunk]: A = the c patch (k = the patch column = the image row of the chunk's Z), split here
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const float* lp = Cs + r * LD + 32 * kb + 8 * q;
+      const Pieces Ac = split3x8(*reinterpret_cast<const f32x4*>(lp), *reinterpret_cast<const f32x4*>(lp + 4));
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const uint16_t* img = PZ + h * 3 * PLANE_H;
+        Pieces Tn = cols_B(img, offT + 32 * kb * LDH);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const Pieces Tc = Tn;
+          if (e < 3) Tn = cols_B(img, offT + 32 * kb * LDH + 16 * (e + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          acc[h][e] = mfma_x6(Ac, Tc, acc[h][e]);
+        }
+      }
+    }
+  }
+  // dZ_i = rowsum(c)_i Z_i - (c Z)_i -> workspace (for dM_L) and the A image of the product below
+  float* dZg = a.ws_dZ + (int64_t)(c.row0 + c.i0) * a.fstride + a.foff;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float csum = row16_sum(cs[i]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = 64 * h + 16 * e + r;
+        const float z = Zg[(int64_t)(c.i0 + 4 * q + i) * a.fstride + f];
+        const float v = csum * z - acc[h][e][i];
+        dZg[(int64_t)(4 * q + i) * a.fstride + f] = v;
+        if (NH == 1) Cs[(4 * q + i) * LD + 16 * e + r] = v;
+      }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (NH != 1 || a.fstride != FIN) return;   // 128-feature layer: dX += dZ M_L^T is a packed-row launch behind it
+  // dX[I] += dZ[I] M_L^T   (adjoint of graphconv.py:164), as in cloud_bwd2_kernel
   float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
   f32x4 d[4];
 #pragma unroll
@@ -1717,6 +1897,22 @@ int launch_cloud_param_partials(const ParamGradArgs& a0, void* stream) {
                       stream, a);
 }
 
+// backward 2: the product c Z on the bf16 matrix pipe at fp32 accuracy for the 128-feature layers (32 clouds x 1024 points:
+// 114 -> 105 us; at 64 features the piece images and the splits cost more than the shorter matrix work gains: 84 -> 96 us, so those
+// keep the fp32-MFMA kernel).  AGCN_CLOUD_BWD2_BF = 0: never, 2: always, for A/B runs.
+static int launch_bwd2(const SgcArgs& ah, bool wide, dim3 grid, void* stream) {
+  static const int bf = [] { const char* e = std::getenv("AGCN_CLOUD_BWD2_BF"); return e ? std::atoi(e) : 1; }();
+  const int nh = wide ? 2 : 1;
+  if (bf == 2 || (bf == 1 && wide)) {
+    const size_t lds = sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 3 * PLANE_H * nh;
+    return wide ? launch_cloud(cloud_bwd2_bf_kernel<2>, grid, 256, lds, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah)
+                : launch_cloud(cloud_bwd2_bf_kernel<1>, grid, 256, lds, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+  }
+  const size_t lds = sizeof(float) * (nh * CC * LD + 4 * 16 * LD);
+  return wide ? launch_cloud(cloud_bwd2_kernel<2>, grid, 256, lds, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah)
+              : launch_cloud(cloud_bwd2_kernel<1>, grid, 256, lds, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+}
+
 // The packed filter adjoint of a 64-feature layer: Gp = dY act'(Y), g_0 = Gp W_0^T -> dX, g_1 = Gp W_1^T -> workspace.  On the bf16
 // matrix pipe at fp32 accuracy (rows_split.hip: one launch builds the image of [W_0^T | W_1^T]) where the caller gave the image
 // workspace, else cloud_filter_bwd_kernel behind the transposed copy of W (`WT`, or the one the cloud forward left in the reserve).
@@ -1769,8 +1965,7 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   {   // (128 features: both halves in one run, the Q and r tiles read once)
     SgcArgs ah = a;
     ah.foff = 0;
-    rc = wide ? launch_cloud(cloud_bwd2_kernel<2>, grid, 256, lds_f32 + sizeof(float) * CC * LD, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah)
-              : launch_cloud(cloud_bwd2_kernel<1>, grid, 256, lds_f32, PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+    rc = launch_bwd2(ah, wide, grid, stream);
   }
   return rc;
 }
@@ -1800,18 +1995,32 @@ int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void
        : half == 0 ? launch_cloud(cloud_rbwd_kernel<PASS, PAPER, 128, false>, grid, 256, lds, ID, NAME, stream, ah, spart)         \
                    : launch_cloud(cloud_rbwd_kernel<PASS, PAPER, 128, true>, grid, 256, lds, ID, NAME, stream, ah, spart);          \
   }
-  if (paper) { AGCN_RBWD(0, true, PK_CLOUD_RBWD_A, "cloud_rbwdA") } else { AGCN_RBWD(0, false, PK_CLOUD_RBWD_A, "cloud_rbwdA") }
+  // pass A of a 128-feature layer: both feature halves in one run (AGCN_CLOUD_RBWD_BOTH=0: once per half, for A/B runs)
+  static const int both = [] { const char* e = std::getenv("AGCN_CLOUD_RBWD_BOTH"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (wide && both) {
+    SgcArgs ah = args(0);
+    ah.half_last = 1;
+    rc = paper ? launch_cloud(cloud_rbwd_kernel<0, true, 128, false, true>, grid, 256, lds, PK_CLOUD_RBWD_A, "cloud_rbwdA", stream, ah, spart)
+               : launch_cloud(cloud_rbwd_kernel<0, false, 128, false, true>, grid, 256, lds, PK_CLOUD_RBWD_A, "cloud_rbwdA", stream, ah, spart);
+  } else if (paper) { AGCN_RBWD(0, true, PK_CLOUD_RBWD_A, "cloud_rbwdA") } else { AGCN_RBWD(0, false, PK_CLOUD_RBWD_A, "cloud_rbwdA") }
   if (rc != AGCN_OK) return rc;
   if (paper) { AGCN_RBWD(1, true, PK_CLOUD_RBWD_B, "cloud_rbwdB") }
   if (rc != AGCN_OK) return rc;
-  if (paper) { AGCN_RBWD(2, true, PK_CLOUD_RBWD_C, "cloud_rbwdC") } else { AGCN_RBWD(2, false, PK_CLOUD_RBWD_C, "cloud_rbwdC") }
+  if (wide && both) {   // pass C by parts, both feature halves per run: dX += La g_1, then (with a previous Laplacian) dL_prev
+    SgcArgs ah = args(0);
+    ah.half_last = 1;
+    rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true, 128, false, true, 1>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart)
+               : launch_cloud(cloud_rbwd_kernel<2, false, 128, false, true, 1>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart);
+    if (rc == AGCN_OK && a.L_prev != nullptr)
+      rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart)
+                 : launch_cloud(cloud_rbwd_kernel<2, false, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart);
+  } else if (paper) { AGCN_RBWD(2, true, PK_CLOUD_RBWD_C, "cloud_rbwdC") } else { AGCN_RBWD(2, false, PK_CLOUD_RBWD_C, "cloud_rbwdC") }
 #undef AGCN_RBWD
   if (rc != AGCN_OK || !paper) return rc;
   {
     SgcArgs ah = a;
     ah.foff = 0;
-    rc = wide ? launch_cloud(cloud_bwd2_kernel<2>, grid, 256, sizeof(float) * (2 * CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, ah)
-              : launch_cloud(cloud_bwd2_kernel<1>, grid, 256, sizeof(float) * (CC * LD + 4 * 16 * LD), PK_CLOUD_BWD2, "cloud_bwd2", stream, ah);
+    rc = launch_bwd2(ah, wide, grid, stream);
   }
   return rc;
 }

@@ -1352,6 +1352,57 @@ def test_packed_row_products_on_the_bf16_pipe(amd, Fin, Fout):
             assert_close(to_np(a[k]), to_np(b[k]).astype(np.float64), 2 * rtol, "split vs fp32-MFMA " + k)
 
 
+def test_full_size_packed_row_products_exactness(amd):
+    """BASELINE config 3 at its FULL size (32 clouds x 1024 points = 32768 packed rows), the 128 -> 128 layer: size-independent
+    properties of the packed-row products on the bf16 matrix pipe (csrc/rows_split.hip), every one of the 32768 rows checked.
+      * M_L = I: a number's three bf16 pieces added smallest first give the number back exactly, so Z = X to the bit -- and res_W,
+        res_L are bit-identical to the fp32-MFMA path's (knob off), whose product with I is exact as well;
+      * W_0 = I, W_1 = 0, b = 0: Y = relu(X_0) = X_0 to the bit (features are >= 0);
+      * reference mode (no gradient through the Laplacian, g_1 = Gp W_1^T = 0): dX = Gp W_0^T = dY where Y > 0, to the bit;
+      * dbias / dweight = [X_0 | X_1]^T Gp against a float64 evaluation of the whole 32768-row sums (the parity bars)."""
+    from agcn_amd import synth
+    B, n, F, K = 32, 1024, 128, 2
+    X, L = synth.modelnet_clouds(31, B, n, F)
+    ds = np.stack([np.full(B, n), np.full(B, -1)], 1).astype(np.int32)
+    gb = amd.GraphBatch.from_padded(torch.from_numpy(X).to(DEV), torch.from_numpy(L).to(DEV), ds, DEV)
+    del L
+    rs = np.random.RandomState(77)
+    p = orc.init_params(rs, F, F, K, orc.SGC_LL)
+    p["M_L"] = np.eye(F, dtype=np.float32)
+    W = np.zeros((F * K, F), np.float32)
+    W[0::K] = np.eye(F, dtype=np.float32)                    # row f * K + 0 = term 0 of feature f (graphconv.py:243-244)
+    p["weight"], p["bias"] = W, np.zeros(F, np.float32)
+    G = torch.from_numpy(rs.randn(B * n, F).astype(np.float32)).to(DEV)
+    lib = amd._ffi.lib()
+    prev = lib.agcn_get_rows_split()
+
+    def run(split):
+        lib.agcn_set_rows_split(split)
+        layer = make_layer(amd, orc.SGC_LL, F, F, B, K, orc.REFERENCE, p, DEV)
+        Xt = gb.X.clone().requires_grad_(True)
+        nodes, res_L, res_W = layer({"node_features": Xt, "graph_batch": gb})
+        (nodes.data * G).sum().backward()
+        torch.cuda.synchronize()
+        return layer, Xt, nodes.data.detach(), res_L.data, res_W.data
+
+    try:
+        layer, Xt, Y, res_L, res_W = run(1)
+        assert amd._ffi.dispatch_info(layer, gb)[0] & 64, "the batch must take the point-cloud kernels"
+        _, _, Y0, res_L0, res_W0 = run(0)
+    finally:
+        lib.agcn_set_rows_split(prev)
+    Xd = gb.X.detach()
+    assert torch.equal(Y, Xd) and torch.equal(Y0, Xd)                              # Y = X_0 W_0 = X_0
+    assert torch.equal(res_W, res_W0) and torch.equal(res_L, res_L0)               # Z = X M_L = X on both pipes
+    Gp = torch.where(Y > 0, G, torch.zeros_like(G))
+    assert torch.equal(Xt.grad, Gp)                                                # dX = Gp W_0^T
+    # the 32768-row sums of the parameter gradients (X_1 = (I + L_orig) X_0 in reference mode is not needed: term 0 and the bias)
+    Xh, Gh = X.reshape(-1, F).astype(np.float64), to_np(Gp).astype(np.float64)
+    dW = to_np(layer.vars["weight"].grad)
+    assert_close(dW[0::K], Xh.T @ Gh, GRAD_RTOL, "dweight (term 0), 32768 rows", atol_ulps=GRAD_ULPS * 4)
+    assert_close(to_np(layer.vars["bias"].grad), Gh.sum(0), GRAD_RTOL, "dbias, 32768 rows", atol_ulps=GRAD_ULPS * 4)
+
+
 _RESLAP_CLOUD_CASES = {
     # the first layer of a block: no previous Laplacian (graphconv_reslap.py:188-193, empty res_lap list)
     "first_layer_of_a_block": ("reslap", 64, 128, [1024, 64], None, False),
