@@ -632,7 +632,7 @@ extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc,
   return c.off + 256;
 }
 
-struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT, *MT, *spart, *simg; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
+struct BwdWs { float *g, *dZ, *Gp, *pg, *part, *tile, *buf, *dA, *dAt, *dd, *WT, *MT, *spart, *simg, *P; int n_chunks; int64_t part_stride; int n_glb; size_t part_floats; };
 
 static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, BwdWs* w) {
   Carver c(ws);
@@ -656,6 +656,8 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
     }
     w->spart = c.take((size_t)8 * ((size_t)pi.n_slabs / 4 + 8));
   }
+  // ... 128 features: the P = g_1 X_0^T tile pass A leaves for the element-wise pass B / part 2 of pass C
+  w->P = (d->variant == AGCN_SGC_LL_RESLAP && cloud_shape(d) && d->Fin == 128) ? c.take((size_t)pi.tile_elems) : nullptr;
   w->n_chunks = n_chunks_for(pi.rows);
   w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
   w->part_stride = (w->part_stride + 3) / 4 * 4;
@@ -1148,6 +1150,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd; a.ws_Gp = w.Gp;
     a.rs_img = w.simg;
+    a.ws_P = w.P;
     // point clouds: either backward works behind either forward (both forwards leave Z, X_1, s and the r tiles)
     RowsGemmArgs g;
     if (cloud_res || cloud_bwd) {

@@ -977,10 +977,15 @@ __device__ __forceinline__ ResScal res_scalars(const SgcArgs& a, const float* sp
 // g_1 AND X_0 images of both halves (12 planes: one workgroup per CU), so with BOTH they are two launches -- CPART 1: dX[I] += La[I, :] g_1
 // over all 128 features (g_1 images of both halves, two accumulator sets; + the graph's dalpha / dbeta), CPART 2 (only with a previous
 // Laplacian): dL_prev from D = g_1 X_0^T over four k-blocks, as pass A.  4 tile passes instead of 6, no read-modify-write of dL_prev.
-template <int PASS, bool PAPER, int FS = 64, bool ACC = false, bool BOTH = false, int CPART = 0>   // PASS 0 = A, 1 = B, 2 = C; FS / ACC: see cloud_bwd1_paper_kernel
+// FROMP (pass B; with BOTH): the product P = g_1 X_0^T is not formed here but READ from the tile part 2 of pass C wrote (a.ws_P,
+// all 128 features; that part runs first then) -- and read again transposed for X_0 g_1^T = P^T: the pass is element-wise, no images,
+// no matrix instructions, one run.  (Pass B with the products: twice 256 registers' worth of operand pieces for both halves, or one
+// run per half = every tile read twice + the read-modify-write of Q: 2 x 135 us.)
+template <int PASS, bool PAPER, int FS = 64, bool ACC = false, bool BOTH = false, int CPART = 0, bool FROMP = false>   // PASS 0 = A, 1 = B, 2 = C; FS / ACC: see cloud_bwd1_paper_kernel
 __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* spart) {
-  static_assert(!BOTH || (FS == 128 && !ACC && (PASS == 0 || (PASS == 2 && CPART != 0))), "both halves in one run: pass A, pass C by parts");
+  static_assert(!BOTH || (FS == 128 && !ACC && (PASS == 0 || FROMP || (PASS == 2 && CPART != 0))), "both halves in one run: pass A, pass C by parts, passes from P");
   static_assert(CPART == 0 || (PASS == 2 && BOTH), "pass C by parts goes with BOTH");
+  static_assert(!FROMP || (BOTH && PASS == 1), "from the P tile: pass B");
   constexpr bool DO_L = PASS == 2 && CPART != 2;      // the La g_1 product, dX, the graph's dalpha / dbeta
   constexpr bool DO_D = PASS != 2 || CPART != 1;      // the D = g_1 X_0^T product and what hangs on it
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -993,10 +998,10 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   const WaveCtx c = wave_ctx(a, slab);
   const int n = c.n;
   const bool has_prev = a.L_prev != nullptr, has_dls = a.dL_sum != nullptr && !ACC;
-  constexpr bool NEED_X = true;                       // X_0 images: the B operand of g_1[I] X_0[J]^T
-  constexpr bool NEED_G = PASS != 0 || BOTH;          // g_1 images: X_0[I] g_1[J]^T (B), La g_1 (C); BOTH: the second half's rows
+  constexpr bool NEED_X = !FROMP;                     // X_0 images: the B operand of g_1[I] X_0[J]^T
+  constexpr bool NEED_G = !FROMP && (PASS != 0 || BOTH);   // g_1 images: X_0[I] g_1[J]^T (B), La g_1 (C); BOTH: the second half's rows
   // pass C without a previous Laplacian has no dL_prev to write: only the La g_1 product is left
-  const bool want_D = DO_D && (PASS != 2 || has_prev);
+  const bool want_D = DO_D && (PASS != 2 || has_prev || (CPART == 2 && a.ws_P != nullptr));
   uint16_t* PX = reinterpret_cast<uint16_t*>(smem);   // [3][64][LDH]
   uint16_t* PG = PX + 3 * PLANE_H;
   float* Ls = smem + (6 * PLANE_H) / 2 + wave * (16 * LD);
@@ -1077,13 +1082,20 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
     return g;
   };
   // ... and the ones only the epilogue needs (requested at the top of the chunk, in flight behind the products)
-  struct Late { f32x4 pv[4], ds[4], dt[4]; };
+  // part 2 of pass C (both halves) leaves P = g_1 X_0^T for the element-wise pass B behind it.  (Pass A forms the same product
+  // but has no register to spare: with the sixteen of a held-back tile it spilled 44, storing four bytes at a time 23 -- 115 -> 199 us.)
+  float* Pw = (PASS == 2 && CPART == 2 && !FROMP && a.ws_P != nullptr) ? a.ws_P + o0 : nullptr;
+  const float* Ppt = FROMP ? a.ws_P + o0 : nullptr;
+  const float* PpT = FROMP ? a.ws_P + c.toff + (int64_t)(4 * r) * n + c.i0 + 4 * q : nullptr;      // + (c0 + t) n: [t] over i
+  struct Late { f32x4 pv[4], ds[4], dt[4], pp[4], pt[4]; };
   auto load_late = [&](int c0) {
     Late g;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      g.pp[i] = FROMP ? *reinterpret_cast<const f32x4*>(Ppt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.pt[i] = (FROMP && PASS == 1) ? *reinterpret_cast<const f32x4*>(PpT + (int64_t)(c0 + i) * n) : (f32x4){0.f, 0.f, 0.f, 0.f};
       g.pv[i] = (PASS == 0 && has_prev) ? *reinterpret_cast<const f32x4*>(Pvt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      g.ds[i] = has_dls ? *reinterpret_cast<const f32x4*>(Dst + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.ds[i] = (has_dls && (PASS != 2 || has_prev)) ? *reinterpret_cast<const f32x4*>(Dst + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
       g.dt[i] = (PASS == 1 && has_dls) ? *reinterpret_cast<const f32x4*>(DsT + (int64_t)(c0 + i) * n) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     return g;
@@ -1102,10 +1114,12 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
   const int offT = (8 * q + (r >> 2)) * LDH + 4 * (r & 3);
 #pragma unroll 1
   for (int c0 = 0; c0 < n; c0 += CC) {
-    __syncthreads();
-    stage_store16(pre);
-    __syncthreads();
-    if (c0 + CC < n) pre = stage_load16(c0 + CC);
+    if constexpr (!FROMP) {
+      __syncthreads();
+      stage_store16(pre);
+      __syncthreads();
+      if (c0 + CC < n) pre = stage_load16(c0 + CC);
+    }
     const Late late = load_late(c0);
     // element-wise, before the products: S, R from r; Lc, La from L_pre
     f32x4 Sv[4], Lp[4];
@@ -1138,10 +1152,14 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
     if constexpr (!DO_D) continue;
     // tile by tile: the product(s), then the element-wise part behind them
     f32x4 outv[4];
+    f32x4 pout[(PASS == 2 && CPART == 2 && !FROMP) ? 4 : 1];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (want_D) {
+      if constexpr (FROMP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pa[i] = late.pp[i][t]; pb[i] = late.pt[t][i]; }
+      } else if (want_D) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
           pa = mfma_x6(Ag[kb], rows_B(kb < 2 ? PX : PG, offB + 16 * t * LDH + 32 * (kb & 1)), pa);
@@ -1183,6 +1201,7 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
           outv[i][t] = Q;
           dsum[i] = __builtin_fmaf(Q, Sv[i][t] * sj[t], dsum[i]);         // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
         } else {
+          if constexpr (CPART == 2 && !FROMP) pout[i][t] = pa[i];
           const float D = pa[i] + late.ds[i][t];
           outv[i][t] = ACC ? beta * ((z.aL * mL) * D) : beta * ((z.aL * mL) * D - z.bL * lpre);   // dL_prev = beta dLpre
         }
@@ -1195,6 +1214,12 @@ __global__ __launch_bounds__(256, 2) void cloud_rbwd_kernel(SgcArgs a, float* sp
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = outv[i];
+    }
+    if constexpr (PASS == 2 && CPART == 2 && !FROMP) {
+      if (Pw != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Pw + (int64_t)i * n + c0) = pout[i];
+      }
     }
     if constexpr (PASS == 2 && DO_D) {
       if (has_prev) {
@@ -2004,16 +2029,29 @@ int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void
                : launch_cloud(cloud_rbwd_kernel<0, false, 128, false, true>, grid, 256, lds, PK_CLOUD_RBWD_A, "cloud_rbwdA", stream, ah, spart);
   } else if (paper) { AGCN_RBWD(0, true, PK_CLOUD_RBWD_A, "cloud_rbwdA") } else { AGCN_RBWD(0, false, PK_CLOUD_RBWD_A, "cloud_rbwdA") }
   if (rc != AGCN_OK) return rc;
-  if (paper) { AGCN_RBWD(1, true, PK_CLOUD_RBWD_B, "cloud_rbwdB") }
+  // 128 features, paper mode: part 2 of pass C runs FIRST and leaves P = g_1 X_0^T (all 128 features) for pass B, which is then
+  // element-wise (P, P^T from the tile): one run instead of one per half
+  const bool from_p = wide && both && paper && a.ws_P != nullptr;
+  auto c_part2 = [&]() {
+    SgcArgs ah = args(0);
+    ah.half_last = 1;
+    return paper ? launch_cloud(cloud_rbwd_kernel<2, true, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart)
+                 : launch_cloud(cloud_rbwd_kernel<2, false, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart);
+  };
+  if (from_p) {
+    rc = c_part2();
+    if (rc != AGCN_OK) return rc;
+    SgcArgs ah = args(0);
+    ah.half_last = 1;
+    rc = launch_cloud(cloud_rbwd_kernel<1, true, 128, false, true, 0, true>, grid, 256, 0, PK_CLOUD_RBWD_B, "cloud_rbwdB", stream, ah, spart);
+  } else if (paper) { AGCN_RBWD(1, true, PK_CLOUD_RBWD_B, "cloud_rbwdB") }
   if (rc != AGCN_OK) return rc;
-  if (wide && both) {   // pass C by parts, both feature halves per run: dX += La g_1, then (with a previous Laplacian) dL_prev
+  if (wide && both) {   // pass C by parts, both feature halves per run: dX += La g_1, and (with a previous Laplacian) dL_prev
     SgcArgs ah = args(0);
     ah.half_last = 1;
     rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true, 128, false, true, 1>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart)
                : launch_cloud(cloud_rbwd_kernel<2, false, 128, false, true, 1>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart);
-    if (rc == AGCN_OK && a.L_prev != nullptr)
-      rc = paper ? launch_cloud(cloud_rbwd_kernel<2, true, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart)
-                 : launch_cloud(cloud_rbwd_kernel<2, false, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart);
+    if (rc == AGCN_OK && !from_p && a.L_prev != nullptr) rc = c_part2();
   } else if (paper) { AGCN_RBWD(2, true, PK_CLOUD_RBWD_C, "cloud_rbwdC") } else { AGCN_RBWD(2, false, PK_CLOUD_RBWD_C, "cloud_rbwdC") }
 #undef AGCN_RBWD
   if (rc != AGCN_OK || !paper) return rc;

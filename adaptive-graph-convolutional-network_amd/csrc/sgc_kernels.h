@@ -100,6 +100,9 @@ struct SgcArgs {
   int32_t foff, fstride, half_acc, half_last;
   // backward: workspace for the parameter images of the split-bf16 packed-row kernels (rows_split.hip), or nullptr
   void* rs_img;
+  // SGC_LL_Reslap, 128 features, point-cloud kernels: P = g_1 X_0^T [tile_elems] written by pass A (both halves in one run) for the
+  // element-wise pass B and part 2 of pass C, or nullptr (those passes then form the product themselves, once per half)
+  float* ws_P;
 };
 
 enum { RG_PROJECT = 0, RG_FILTER = 1, RG_FILTER_BWD = 2, RG_PROJECT_BWD = 3, RG_DENSE = 4 };

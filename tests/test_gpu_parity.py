@@ -1695,10 +1695,13 @@ def test_point_cloud_kernels_random_batches(amd, seed, mode):
         if mode == orc.PAPER:
             assert prof["slab_bwd1_kernel"][1] == 2, prof     # (pair kernel + its reduce)
     elif reslap:
-        nh = 2 if Fin == 128 else 1      # (128 features: every strip kernel behind the similarity once per 64-column half)
+        # (128 features, round 5: pass A takes both 64-column feature halves in one run, pass C runs by parts -- dX += La g_1, and
+        #  dL_prev which also leaves P = g_1 X_0^T -- and pass B is element-wise from that tile: ONE run each, no per-half repeats)
         assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_rlap1_kernel"][1] == 1, prof
+        assert prof["cloud_rbwd_kernel<A>"][1] == 1, prof
         if mode == orc.PAPER:
-            assert prof["cloud_rbwd_kernel<B>"][1] == nh, prof
+            assert prof["cloud_rbwd_kernel<B>"][1] == 1, prof
+            assert prof["cloud_rbwd_kernel<C>"][1] == (2 if Fin == 128 else 1), prof
     else:
         nh = 2 if Fin == 128 else 1
         assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_bwd1_kernel"][1] == nh, prof
