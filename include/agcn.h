@@ -536,7 +536,10 @@ void agcn_set_rows_split(int32_t on);
  * tolerances either way): AGCN_SLAB_SMALL=0 -- slab batches with Fin <= 4 and a dense L_orig take the general slab
  * kernels instead of the streaming small-feature ones (which keep nothing n x n for the backward: r, S, R and dA are
  * rebuilt from the Z / g_1 / X_0 rows); AGCN_ROWS_NARROW=0 -- the projection (Fin <= 4) and the filter adjoint
- * (K * Fin <= 8 columns) of >= 1024 packed rows take the 64-row MFMA workgroups instead of the streaming row kernels. */
+ * (K * Fin <= 8 columns) of >= 1024 packed rows take the 64-row MFMA workgroups instead of the streaming row kernels;
+ * AGCN_CLOUD_RBWD_BOTH=0 -- the backward passes of a 128-feature SGC_LL_Reslap layer run once per 64-column feature half, as before
+ * round 5, instead of pass A over both halves / pass C by parts / pass B element-wise from the P = g_1 X_0^T tile;
+ * AGCN_CLOUD_BWD2_BF = 0 | 2 -- backward 2's product c Z never | always on the bf16 matrix pipe (default 1: 128-feature layers only). */
 
 #ifdef __cplusplus
 }
