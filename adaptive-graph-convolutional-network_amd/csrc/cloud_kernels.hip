@@ -322,6 +322,158 @@ __global__ __launch_bounds__(256, NF == 64 ? 4 : 2) void cloud_sim_kernel(SgcArg
   }
 }
 
+// forward 1 at 128 features in TWO PASSES of 64 features per 16-row group, at the 64-feature kernel's register budget (four waves
+// per SIMD instead of the two of cloud_sim_kernel<.., 128>, whose lane keeps all 128 floats of its column's row): pass 0 leaves the
+// per-pair partial sums of squares over features 0..63 in the wave's LDS slots the pass-1 results will overwrite anyway (tS: the
+// mirrored-block patch, slot (lane, row % 16)), pass 1 adds features 64..127 and finishes the pair as before.  The lane's column row
+// is fetched twice per group (64 floats per pass: L1 / L2 hits), the task's rows twice (scalar cache).  Same tasks, slots and
+// stores as cloud_sim_kernel; the sum of squares of a pair is (first half) + (second half), each half four chains as before.
+template <bool PAPER, int RT>
+__global__ __launch_bounds__(256, 4) void cloud_sim2_kernel(SgcArgs a, float* dpart, int t_quota, int nquads, int qstride) {
+  constexpr int NF = 128;
+  constexpr int WSZ = PAPER ? 2560 : 1280;      // floats of LDS per wave: [4][64] S (, r) + [64][16] S^T (, r^T)
+  constexpr int NS = CS / RT;                   // partial-degree slots per row block
+  extern __shared__ __attribute__((aligned(16))) float trbuf[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* nS = trbuf + wave * WSZ;                // [4][64]
+  float* nR = nS + 256;
+  float* tS = nS + (PAPER ? 512 : 256);          // [64][16]
+  float* tR = tS + 1024;
+  const int fz = 4 * ((lane >> 1) & 3);
+  const int64_t total = (int64_t)a.B * t_quota * NS;
+  const int per_q = (int)((total + 7) >> 3);
+  const int xcd = (int)(blockIdx.x & 7);
+  const int wx = 4 * (int)(gridDim.x >> 3);      // waves per XCD
+#pragma unroll 1
+  for (int lid0 = 4 * (int)(blockIdx.x >> 3) + wave; lid0 < 4 * nquads; lid0 += wx) {
+  const int lid = 4 * (int)(((int64_t)(lid0 >> 2) * qstride) % nquads) + (lid0 & 3);
+  const int64_t id = (int64_t)xcd * per_q + lid;
+  if (lid >= per_q || id >= total) continue;
+  const int b = __builtin_amdgcn_readfirstlane((int)(id / (t_quota * NS)));
+  const int rem = __builtin_amdgcn_readfirstlane((int)(id - (int64_t)b * (t_quota * NS)));
+  const int n = __builtin_amdgcn_readfirstlane(a.n[b]), row0 = __builtin_amdgcn_readfirstlane(a.row_off[b]);
+  const int ncb = n >> 6;
+  if (rem >= ((ncb * (ncb + 1)) >> 1) * NS) continue;
+  int I = 0, J, h;
+  {
+    int left = rem, len = ncb;
+    while (left >= len * NS) { left -= len * NS; --len; ++I; }
+    h = left / len;
+    J = I + (left - h * len);
+  }
+  const int rb0 = 64 * I;
+  const bool diag = J == I;
+  const int r0 = rb0 + RT * h;                   // first row of the task
+  const int64_t toff_v = a.tile_off[b];
+  const int64_t toff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(toff_v >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)toff_v));
+  const float* Zg = a.sv_Z + (int64_t)row0 * NF;
+  const f32x4* zp = reinterpret_cast<const f32x4*>(Zg + (int64_t)(64 * J + lane) * NF);
+  const int dlane = diag ? lane - RT * h : -1;   // S_ii = 0 (graphconv.py:171-173): on the diagonal block only
+  float cs = 0.f;
+  float* dpI = dpart + (toff >> 6) * NS + (int64_t)(I * NS + h) * n;    // partial degrees [n / RT][n] per graph
+  float* dpJ = dpart + (toff >> 6) * NS + (int64_t)(J * NS) * n;
+#pragma unroll 1
+  for (int g16 = 0; g16 < RT; g16 += 16) {
+    float zj[64];
+    f32x16 A0, A1, B0, B1;
+#define AGCN_SIM16(SRC, BASE)                                                                                       \
+  _Pragma("unroll") for (int f = 0; f < 16; f += 4) {                                                             \
+    const float d0 = SRC[f] - zj[BASE + f], d1 = SRC[f + 1] - zj[BASE + f + 1];                                     \
+    const float d2 = SRC[f + 2] - zj[BASE + f + 2], d3 = SRC[f + 3] - zj[BASE + f + 3];                             \
+    c0 = __builtin_fmaf(d0, d0, c0); c1 = __builtin_fmaf(d1, d1, c1);                                               \
+    c2 = __builtin_fmaf(d2, d2, c2); c3 = __builtin_fmaf(d3, d3, c3);                                               \
+  }
+    // one row's 64 floats of this pass in two double-buffered rounds (as cloud_sim_kernel); rows are 128 floats apart
+#define AGCN_SIM_ROW(LAST)                                                                                          \
+    SWAIT2(A0, A1, cs);                                                                                             \
+    SLOAD16_BEFORE(B0, zrow, "0x80", A0);                                                                           \
+    SLOAD16_BEFORE(B1, zrow, "0xc0", A1);                                                                           \
+    AGCN_SIM16(A0, 0)                                                                                               \
+    AGCN_SIM16(A1, 16)                                                                                              \
+    SWAIT2(B0, B1, c3);                                                                                             \
+    zrow += (LAST) ? 0 : NF;                     /* (the last request re-reads the last row: never used) */        \
+    SLOAD16_BEFORE(A0, zrow, "0x0", B0);                                                                            \
+    SLOAD16_BEFORE(A1, zrow, "0x40", B1);                                                                           \
+    AGCN_SIM16(B0, 32)                                                                                              \
+    AGCN_SIM16(B1, 48)
+    // ---- pass 0: features 0 .. 63 -> partial sums into the tS slots
+    {
+#pragma unroll
+      for (int f4 = 0; f4 < 16; ++f4) {
+        const f32x4 t = zp[f4];
+        zj[4 * f4 + 0] = t.x; zj[4 * f4 + 1] = t.y; zj[4 * f4 + 2] = t.z; zj[4 * f4 + 3] = t.w;
+      }
+      const float* zrow = Zg + (int64_t)(r0 + g16) * NF;
+      SLOAD16(A0, zrow, "0x0");
+      SLOAD16(A1, zrow, "0x40");
+#pragma unroll 1
+      for (int rr16 = 0; rr16 < 16; ++rr16) {
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        AGCN_SIM_ROW(rr16 == 15)
+        tS[16 * lane + (rr16 ^ fz)] = (c0 + c1) + (c2 + c3);
+      }
+      SWAIT2(A0, A1, cs);
+    }
+    // ---- pass 1: features 64 .. 127, the pair finished
+    {
+#pragma unroll
+      for (int f4 = 0; f4 < 16; ++f4) {
+        const f32x4 t = zp[16 + f4];
+        zj[4 * f4 + 0] = t.x; zj[4 * f4 + 1] = t.y; zj[4 * f4 + 2] = t.z; zj[4 * f4 + 3] = t.w;
+      }
+      const float* zrow = Zg + (int64_t)(r0 + g16) * NF + 64;
+      SLOAD16(A0, zrow, "0x0");
+      SLOAD16(A1, zrow, "0x40");
+#pragma unroll 1
+      for (int i4 = 0; i4 < 16; i4 += 4) {
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+          const int ii = g16 + i4 + u;
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+          AGCN_SIM_ROW(i4 + u == 15)
+          const int tcol = 16 * lane + ((i4 + u) ^ fz);
+          const float rr = __builtin_amdgcn_sqrtf(tS[tcol] + ((c0 + c1) + (c2 + c3)));
+          const float S = (ii == dlane) ? 0.f : __builtin_amdgcn_exp2f(rr * NLOG2E);   // exp(-1 * norm) (:176-177)
+          nS[u * 64 + lane] = S;
+          tS[tcol] = S;
+          if (PAPER) { nR[u * 64 + lane] = rr; tR[tcol] = rr; }
+          cs += S;
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+          const int64_t o = toff + (int64_t)(r0 + g16 + i4 + (lane >> 4)) * n + 64 * J + 4 * (lane & 15);
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(nS + 4 * lane);
+          *reinterpret_cast<f32x4*>(a.res_W + o) = sv;
+          if (PAPER) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(nR + 4 * lane), reinterpret_cast<f32x4*>(a.sv_r + o));
+          if (!diag) {   // row sums of this block = column sums of the mirrored one
+            const float rs = row16_sum((sv.x + sv.y) + (sv.z + sv.w));
+            if ((lane & 15) == 0) dpJ[r0 + g16 + i4 + (lane >> 4)] = rs;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      SWAIT2(A0, A1, cs);
+    }
+#undef AGCN_SIM_ROW
+#undef AGCN_SIM16
+    if (!diag) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int j = (lane >> 2) + 16 * m;
+        const int src = 16 * j + 4 * ((lane & 3) ^ ((j >> 1) & 3));
+        const int64_t o = toff + (int64_t)(64 * J + j) * n + r0 + g16 + 4 * (lane & 3);
+        *reinterpret_cast<f32x4*>(a.res_W + o) = *reinterpret_cast<const f32x4*>(tS + src);
+        if (PAPER) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(tR + src), reinterpret_cast<f32x4*>(a.sv_r + o));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  dpI[64 * J + lane] = cs;
+  }
+}
+
 // forward 2: d_j = sum of the node's partial column sums in slot order + np.spacing(0) (graphconv.py:195-196), s = d^-1/2 (:197).
 // Slot (rb, h) of column j: h-th RT-row piece of row block rb for rb <= j / 64 (computed blocks), for rb > j / 64 the mirrored
 // block's sum in slot (rb, 0) alone.  One 64-thread workgroup per 64-row block.
@@ -1848,7 +2000,12 @@ int launch_cloud_forward(const SgcArgs& a, float* dpart, int32_t max_n, int64_t 
     // over resident waves: 75 against 79 us), beyond that the waves walk their lists
     const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>((int64_t)12 * n_cu, (tasks + 3) / 4 + 7) / 8 * 8);
     const size_t lds = sizeof(float) * 4 * (paper ? 2560 : 1280);
-    if (wide)
+    // 128 features: two passes of 64 at four waves per SIMD (AGCN_CLOUD_SIM2=0: all 128 in registers at two waves, for A/B runs)
+    static const int sim2 = [] { const char* e = std::getenv("AGCN_CLOUD_SIM2"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (wide && sim2)
+      rc = paper ? launch_cloud(cloud_sim2_kernel<true, SIM_RT>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride)
+                 : launch_cloud(cloud_sim2_kernel<false, SIM_RT>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride);
+    else if (wide)
       rc = paper ? launch_cloud(cloud_sim_kernel<true, SIM_RT, 128>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride)
                  : launch_cloud(cloud_sim_kernel<false, SIM_RT, 128>, dim3(wgs), 256, lds, PK_CLOUD_SIM, "cloud_sim", stream, a, dpart, t_quota, nquads, qstride);
     else
@@ -2035,6 +2192,7 @@ int launch_cloud_backward_reslap(const SgcArgs& a, float* WT, float* spart, void
   auto c_part2 = [&]() {
     SgcArgs ah = args(0);
     ah.half_last = 1;
+    if (!from_p) ah.ws_P = nullptr;      // (nobody reads P then: reference mode has no pass B)
     return paper ? launch_cloud(cloud_rbwd_kernel<2, true, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart)
                  : launch_cloud(cloud_rbwd_kernel<2, false, 128, false, true, 2>, grid, 256, lds, PK_CLOUD_RBWD_C, "cloud_rbwdC", stream, ah, spart);
   };
