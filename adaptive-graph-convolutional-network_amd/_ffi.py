@@ -97,7 +97,8 @@ SYMBOLS = [
     "agcn_sgc_ll_dispatch_info", "agcn_sgc_ll_reserve_status", "agcn_set_device_status_word", "agcn_device_status", "agcn_get_coop_timeout_ticks", "agcn_set_coop_timeout_ticks", "agcn_tiles_asymmetry", "agcn_epoch_step", "agcn_get_spec_tail", "agcn_set_spec_tail", "agcn_get_rows_split", "agcn_set_rows_split",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
-    "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward",
+    "agcn_rows_dense_scaled_forward", "agcn_rows_dense_scaled_backward", "agcn_rows_dense_forward_workspace_bytes",
+    "agcn_rows_dense_scaled_forward_ws",
     "agcn_multitask_ce_workspace_bytes", "agcn_multitask_ce_forward", "agcn_multitask_ce_backward",
     "agcn_graph_pool_forward", "agcn_graph_pool_backward",
     "agcn_store_batch_sizes", "agcn_store_pack_batch", "agcn_store_stage_bytes", "agcn_store_stage_batch",
@@ -146,6 +147,10 @@ def _declare(lib):
     lib.agcn_rows_dense_backward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P, P, P, SZ, P]
     lib.agcn_rows_dense_scaled_forward.restype = C.c_int
     lib.agcn_rows_dense_scaled_forward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P]
+    lib.agcn_rows_dense_forward_workspace_bytes.restype = SZ
+    lib.agcn_rows_dense_forward_workspace_bytes.argtypes = [C.POINTER(DenseDesc), P]
+    lib.agcn_rows_dense_scaled_forward_ws.restype = C.c_int
+    lib.agcn_rows_dense_scaled_forward_ws.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P, SZ, P]
     lib.agcn_rows_dense_scaled_backward.restype = C.c_int
     lib.agcn_rows_dense_scaled_backward.argtypes = [C.POINTER(DenseDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, P]
     lib.agcn_multitask_ce_workspace_bytes.restype = SZ

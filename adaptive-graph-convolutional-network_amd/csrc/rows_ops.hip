@@ -31,7 +31,11 @@ void fill_rows_dense(RowsGemmArgs& g, const AgcnDenseDesc* d, const PlanView& ho
   g.keep_pad = d->keep_pad_rows ? 1 : 0;
 }
 
-struct DenseWs { float *Gp, *part, *dbias; int n_chunks; int64_t part_stride; size_t part_floats; };
+struct DenseWs { float *Gp, *part, *dbias, *img; int n_chunks; int64_t part_stride; size_t part_floats; };
+// packed rows (no pad rows) at point-cloud row counts: the products may run on the split-bf16 row kernels (rows_split.hip)
+bool dense_split(const AgcnDenseDesc* d, const AgcnPlanInfo& pi) {
+  return pi.rows == pi.N1 && rows_split_dense_ok(pi.rows, d->Fin, d->Fout, d->ldx, d->ldy, d->ldadd);
+}
 size_t carve_dense(const AgcnDenseDesc* d, const AgcnPlanInfo& pi, void* ws, bool need_gp, DenseWs* w) {
   char* base = static_cast<char*>(ws);
   size_t off = 0;
@@ -46,6 +50,7 @@ size_t carve_dense(const AgcnDenseDesc* d, const AgcnPlanInfo& pi, void* ws, boo
   w->part_floats = std::max((size_t)c * w->part_stride, param_grad_onepass_floats(pi.rows, d->Fin, d->Fout, 1, 0));
   w->part = take(w->part_floats);
   w->dbias = take((size_t)d->Fout);
+  w->img = dense_split(d, pi) ? take(rows_split_dense_image_bytes(d->Fin, d->Fout) / 4) : nullptr;
   return off;
 }
 
@@ -156,6 +161,19 @@ extern "C" int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const v
                                               const void* plan_dev, const float* X, const float* W,
                                               const float* scale, const float* bias, const float* Add, float* Y,
                                               void* hip_stream) {
+  return agcn_rows_dense_scaled_forward_ws(desc, plan_host, plan_dev, X, W, scale, bias, Add, Y, nullptr, 0, hip_stream);
+}
+
+extern "C" size_t agcn_rows_dense_forward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host) {
+  AgcnPlanInfo pi;
+  if (check_dense(desc, "agcn_rows_dense_forward_workspace_bytes") != AGCN_OK || agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;
+  return dense_split(desc, pi) ? rows_split_dense_image_bytes(desc->Fin, desc->Fout) + 256 : 0;
+}
+
+extern "C" int agcn_rows_dense_scaled_forward_ws(const AgcnDenseDesc* desc, const void* plan_host,
+                                                 const void* plan_dev, const float* X, const float* W,
+                                                 const float* scale, const float* bias, const float* Add, float* Y,
+                                                 void* workspace, size_t workspace_bytes, void* hip_stream) {
   const char* who = "agcn_rows_dense_forward";
   int rc = check_dense(desc, who);
   if (rc != AGCN_OK) return rc;
@@ -165,6 +183,12 @@ extern "C" int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const v
   rc = plan_view(plan_host, plan_host, &host);
   if (rc != AGCN_OK) return rc;
   plan_view(plan_host, plan_dev, &dev);
+  // point-cloud row counts, packed rows, a workspace for the parameter image: the bf16 matrix pipe at fp32 accuracy (rows_split.hip)
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (workspace != nullptr && dense_split(desc, host.info) && workspace_bytes >= rows_split_dense_image_bytes(desc->Fin, desc->Fout) &&
+      al16(X) && al16(Y) && al16(workspace) && (!bias || al16(bias)) && (!Add || al16(Add)))
+    return launch_rows_split_dense_fwd(X, desc->ldx, W, scale, bias, Add, desc->ldadd, desc->activation == AGCN_ACT_RELU ? 1 : 0, Y, desc->ldy,
+                                       desc->Fin, desc->Fout, host.info.rows, workspace, hip_stream);
   RowsGemmArgs g;
   fill_rows_dense(g, desc, host, dev);
   g.Kd = desc->Fin; g.N = desc->Fout;
@@ -211,6 +235,8 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   if (!workspace || workspace_bytes < need) return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, need);
   float* Gp = dAdd ? dAdd : w.Gp;   // dAdd must be contiguous [rows, Fout]
 
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool split = w.img != nullptr && al16(dY) && al16(Y) && al16(Gp) && al16(dX);
   RowsGemmArgs g;
   fill_rows_dense(g, desc, host, dev);
   g.Kd = desc->Fout; g.N = desc->Fin;
@@ -219,10 +245,14 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   // the hand-off of the parameter-gradient kernel behind it: tagged granules cleared by this launch's workgroups (general
   // kernel only: the narrow kernels of few-column products keep the arrival counters), else arrival counters
   int32_t n16 = 0;
-  float* tags = (desc->Fin > 8) ? param_grad_tag_region(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &n16) : nullptr;
+  float* tags = (desc->Fin > 8 && !split) ? param_grad_tag_region(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &n16) : nullptr;
   if (tags != nullptr) { g.ztag_ptr = tags; g.ztag_count16 = n16; }
-  else g.zero_ptr = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &g.zero_count);
-  rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
+  else if (!split) g.zero_ptr = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &g.zero_count);
+  if (split)       // (rows_split.hip: Gp and dX = [scale] Gp W^T; the parameter-gradient kernel clears its own counters)
+    rc = launch_rows_split_dense_bwd(dY, Y, desc->ldy, desc->activation == AGCN_ACT_RELU ? 1 : 0, W, scale, Gp, dX, desc->ldx, desc->Fin,
+                                     desc->Fout, host.info.rows, w.img, hip_stream);
+  else
+    rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
   if (rc != AGCN_OK) return rc;
 
   ParamGradArgs pa;
@@ -232,7 +262,7 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = 0; pa.part_stride = w.part_stride;
   pa.X = X; pa.Gp = Gp; pa.part = w.part; pa.part_floats = w.part_floats;
-  pa.counters_zeroed = tags ? 0 : 1; pa.tags_zeroed = tags ? 1 : 0;
+  pa.counters_zeroed = (tags || split) ? 0 : 1; pa.tags_zeroed = tags ? 1 : 0;
   pa.dev_status = current_device_info().status_word; pa.ticks = agcn_get_coop_timeout_ticks();
   pa.dweight = dW; pa.dbias = dbias ? dbias : w.dbias;
   rc = launch_param_grads(pa, hip_stream);

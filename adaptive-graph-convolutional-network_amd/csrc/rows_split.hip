@@ -72,6 +72,8 @@ struct RsArgs {
   float* Out1; int32_t ldo1;          // output columns [n_split, N) (RS_FILTER_BWD: g_1)
   int32_t n_split;
   int32_t accumulate;                 // RS_PLAIN: Out0 += product (dX += dZ M_L^T)
+  const float* scale;                 // RS_FILTER / RS_FILTER_BWD: optional device scalar on the product (DenseBlockEnd's beta)
+  const float* Add; int32_t ldadd;    // RS_FILTER: optional addend [rows][ldadd] (the dense layers' running sum / residual)
   int32_t rows;
   const u32x4* Bimg; int32_t nt_total;   // image of the whole B: [KB][nt_total][3][64] u32x4
 };
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256) void rs_rows_kernel(RsArgs a) {
 
   f32x4 acc[2][NT];
   f32x4 old[2][NT / 4][4];
+  const float sc = (MODE != RS_PLAIN && a.scale != nullptr) ? a.scale[0] : 1.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int cb = c / KC, kc = c - cb * KC;
@@ -217,17 +220,23 @@ __global__ __launch_bounds__(256) void rs_rows_kernel(RsArgs a) {
       for (int g = 0; g < NT / 4; ++g) {
         const int col = cb * (16 * NT) + 64 * g + 4 * r;
         f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == RS_FILTER) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+        if constexpr (MODE == RS_FILTER) { if (a.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(a.bias + col); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int64_t row = row0 + 16 * rt + 4 * q + i;
           f32x4 v = (f32x4){acc[rt][4 * g][i], acc[rt][4 * g + 1][i], acc[rt][4 * g + 2][i], acc[rt][4 * g + 3][i]};
           if (row > last) continue;
           if constexpr (MODE == RS_FILTER) {
+            if (a.scale != nullptr) v = (f32x4){sc * v.x, sc * v.y, sc * v.z, sc * v.w};
             v = (f32x4){v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w};
+            if (a.Add != nullptr) {
+              const f32x4 ad = *reinterpret_cast<const f32x4*>(a.Add + row * a.ldadd + col);
+              v = (f32x4){v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w};
+            }
             if (a.relu) v = (f32x4){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
             *reinterpret_cast<f32x4*>(a.Out0 + row * a.ldo0 + col) = v;
           } else if constexpr (MODE == RS_FILTER_BWD) {
+            if (a.scale != nullptr) v = (f32x4){sc * v.x, sc * v.y, sc * v.z, sc * v.w};
             if (col < a.n_split) *reinterpret_cast<f32x4*>(a.Out0 + row * a.ldo0 + col) = v;
             else *reinterpret_cast<f32x4*>(a.Out1 + row * a.ldo1 + (col - a.n_split)) = v;
           } else {
@@ -518,6 +527,56 @@ int launch_rows_split_project_bwd(const float* dZ, float* dX, int ldx, int Fin, 
   a.Bimg = static_cast<const u32x4*>(img) + img_units(Fout, 2 * Fin); a.nt_total = Fin / 16;
   return Fin == 128 ? launch_rs<4, 8, 1, RS_PLAIN>(a, PK_PROJECT_BWD, "rs_project_bwd", stream)
                     : launch_rs<2, 4, 1, RS_PLAIN>(a, PK_PROJECT_BWD, "rs_project_bwd", stream);
+}
+
+// ---- the dense layers next to the convolutions (DenseMol, BlockEnd, the terms of DenseBlockEnd: rows_ops.hip) at point-cloud row counts:
+// Y = act([scale] A W [+ bias] [+ Add]) and the adjoint dX = [scale] (dY act'(Y)) W^T with Gp = dY act'(Y) stored for the parameter
+// gradients.  One parameter image per call (W, or W^T as strides of the split) in the caller's workspace.
+bool rows_split_dense_ok(int rows, int Fin, int Fout, int ldx, int ldy, int ldadd) {
+  auto w = [](int f) { return f == 64 || f == 128 || f == 256; };
+  return rs_env() && rows >= 8192 && w(Fin) && w(Fout) && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0;
+}
+size_t rows_split_dense_image_bytes(int Fin, int Fout) { return 16 * img_units(Fin, Fout); }
+
+namespace {
+template <int MODE>
+int launch_rs_kn(const RsArgs& a, int K, int N, int prof_id, const char* what, void* stream) {
+#define RS_KN(KB_, NT_, NCB_) return launch_rs<KB_, NT_, NCB_, MODE>(a, prof_id, what, stream)
+  if (K == 64) { if (N == 64) RS_KN(2, 4, 1); if (N == 128) RS_KN(2, 8, 1); if (N == 256) RS_KN(2, 8, 2); }
+  if (K == 128) { if (N == 64) RS_KN(4, 4, 1); if (N == 128) RS_KN(4, 8, 1); if (N == 256) RS_KN(4, 8, 2); }
+  if (K == 256) { if (N == 64) RS_KN(8, 4, 1); if (N == 128) RS_KN(8, 8, 1); if (N == 256) RS_KN(8, 8, 2); }
+#undef RS_KN
+  return fail(AGCN_EINVAL, "%s: unsupported shape %d x %d", what, K, N);
+}
+}  // namespace
+
+int launch_rows_split_dense_fwd(const float* A, int lda, const float* W, const float* scale, const float* bias, const float* Add, int ldadd,
+                                int relu, float* Y, int ldy, int Fin, int Fout, int rows, void* img, void* stream) {
+  if (!al16(A) || !al16(Y) || !al16(img) || (bias && !al16(bias)) || (Add && !al16(Add)))
+    return fail(AGCN_EINVAL, "rows_split_dense_fwd: unaligned buffer");
+  SplitJobs jobs;
+  jobs.j[0] = SplitJob{W, Fout, 1, Fin, Fout, 0u, Fout / 16, 0};
+  int rc = launch_presplit(jobs, 1, static_cast<u32x4*>(img), stream);
+  if (rc != AGCN_OK) return rc;
+  RsArgs a{};
+  a.A0 = A; a.lda0 = lda; a.kb_term = Fin / 32; a.relu = relu; a.bias = bias; a.scale = scale; a.Add = Add; a.ldadd = ldadd;
+  a.Out0 = Y; a.ldo0 = ldy; a.rows = rows;
+  a.Bimg = static_cast<const u32x4*>(img); a.nt_total = Fout / 16;
+  return launch_rs_kn<RS_FILTER>(a, Fin, Fout, PK_FILTER, "rs_dense_fwd", stream);
+}
+
+int launch_rows_split_dense_bwd(const float* dY, const float* Y, int ldy, int relu, const float* W, const float* scale, float* Gp, float* dX,
+                                int ldx, int Fin, int Fout, int rows, void* img, void* stream) {
+  if (!al16(dY) || !al16(Y) || !al16(Gp) || !al16(dX) || !al16(img)) return fail(AGCN_EINVAL, "rows_split_dense_bwd: unaligned buffer");
+  SplitJobs jobs;
+  jobs.j[0] = SplitJob{W, 1, Fout, Fout, Fin, 0u, Fin / 16, 0};       // B[k = c][column f] = W[f][c]
+  int rc = launch_presplit(jobs, 1, static_cast<u32x4*>(img), stream);
+  if (rc != AGCN_OK) return rc;
+  RsArgs a{};
+  a.A0 = dY; a.lda0 = ldy; a.Yact = Y; a.ldy = ldy; a.relu = relu; a.Gp = Gp; a.ldgp = Fout; a.scale = scale;
+  a.Out0 = dX; a.ldo0 = ldx; a.Out1 = dX; a.ldo1 = ldx; a.n_split = Fin; a.rows = rows;
+  a.Bimg = static_cast<const u32x4*>(img); a.nt_total = Fin / 16;
+  return launch_rs_kn<RS_FILTER_BWD>(a, Fout, Fin, PK_FILTER_BWD, "rs_dense_bwd", stream);
 }
 
 // Row-chunk partials of dweight / dbias / dM_L (the caller runs cloud_param_reduce_kernel behind it).  Sets a.n_chunks /

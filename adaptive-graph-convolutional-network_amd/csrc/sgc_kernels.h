@@ -231,6 +231,13 @@ int launch_rows_split_filter_bwd(const float* dY, const float* Y, int ldy, int r
                                  int Fout, int rows, const void* img, void* stream);
 int launch_rows_split_project_bwd(const float* dZ, float* dX, int ldx, int Fin, int Fout, int rows, const void* img, void* stream);
 int launch_rows_split_param_partials(ParamGradArgs& a, void* stream);   // sets a.n_chunks / a.chunk_rows for the reduce
+// ... and of the dense layers (rows_ops.hip) at >= 8192 packed rows, 64 / 128 / 256 features: one parameter image per call
+bool rows_split_dense_ok(int rows, int Fin, int Fout, int ldx, int ldy, int ldadd);
+size_t rows_split_dense_image_bytes(int Fin, int Fout);
+int launch_rows_split_dense_fwd(const float* A, int lda, const float* W, const float* scale, const float* bias, const float* Add, int ldadd,
+                                int relu, float* Y, int ldy, int Fin, int Fout, int rows, void* img, void* stream);
+int launch_rows_split_dense_bwd(const float* dY, const float* Y, int ldy, int relu, const float* W, const float* scale, float* Gp, float* dX,
+                                int ldx, int Fin, int Fout, int rows, void* img, void* stream);
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper);
 // the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number

@@ -470,9 +470,12 @@ class RowsDenseFunction(torch.autograd.Function):
                 raise ValueError("scale must hold one element")
         Y = torch.empty((plan.rows, Fout), dtype=torch.float32, device=A.device)
         desc = _ffi.DenseDesc(Fin, Fout, _ffi.ACT[activation], 1 if keep_pad_rows else 0, A.shape[1], Fout, Fout, 0)
-        _ffi.check(lib.agcn_rows_dense_scaled_forward(C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(),
-                                                      W.data_ptr(), _ptr(scale), _ptr(bias), _ptr(Add), Y.data_ptr(),
-                                                      _stream(A.device)))
+        # (point-cloud row counts: the product runs on the split-bf16 row kernels, which build a parameter image per call)
+        wbytes = lib.agcn_rows_dense_forward_workspace_bytes(C.byref(desc), plan.host_ptr)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=A.device) if wbytes else None
+        _ffi.check(lib.agcn_rows_dense_scaled_forward_ws(C.byref(desc), plan.host_ptr, plan.dev_ptr, A.data_ptr(),
+                                                         W.data_ptr(), _ptr(scale), _ptr(bias), _ptr(Add), Y.data_ptr(),
+                                                         _ptr(ws), wbytes, _stream(A.device)))
         ctx.batch, ctx.desc, ctx.has_bias, ctx.has_add = batch, desc, bias is not None, Add is not None
         ctx.has_scale = scale is not None
         if scale is not None:

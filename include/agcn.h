@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define AGCN_VERSION 105 /* 0.1.5: agcn_get / set_rows_split (packed-row products of point-cloud batches on the bf16 matrix pipe) */
+#define AGCN_VERSION 105 /* 0.1.5: agcn_get / set_rows_split (packed-row products of point-cloud batches on the bf16 matrix pipe), agcn_rows_dense_scaled_forward_ws */
 
 enum {
   AGCN_OK = 0,
@@ -309,6 +309,14 @@ int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* plan_host, c
 int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                                    const float* X, const float* W, const float* scale, const float* bias,
                                    const float* Add, float* Y, void* hip_stream);
+/* ... and with a WORKSPACE for the forward (ABI 105): at point-cloud row counts (>= 8192 packed rows without pad rows, 64 / 128 / 256
+ * features) the product runs on the bf16 matrix pipe at fp32 accuracy (csrc/rows_split.hip), which needs room for the parameter image
+ * it builds per call.  agcn_rows_dense_forward_workspace_bytes returns 0 when the batch / layer does not take that path (then
+ * workspace may be NULL and the call is exactly agcn_rows_dense_scaled_forward).  The backward's workspace covers its own image. */
+size_t agcn_rows_dense_forward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host);
+int agcn_rows_dense_scaled_forward_ws(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+                                      const float* X, const float* W, const float* scale, const float* bias,
+                                      const float* Add, float* Y, void* workspace, size_t workspace_bytes, void* hip_stream);
 int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                                     const float* X, const float* W, const float* scale, const float* Y,
                                     const float* dY, float* dX, float* dAdd, float* dW, float* dbias,

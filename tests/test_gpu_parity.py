@@ -1049,6 +1049,109 @@ def test_dense_block_end_packed_chain(amd):
     assert l1.vars["weight"].grad is not None and layer.vars["beta_inblock"].grad is not None
 
 
+def test_dense_layers_at_point_cloud_row_counts(amd):
+    """The layers next to the convolutions in the reference's point-cloud network (Point_AGCN.py:34-90: two DenseBlockEnd, DenseMol) at
+    the row counts of that network: 9 clouds x 1024 points = 9216 packed rows (>= 8192: their products take the split-bf16 row kernels,
+    csrc/rows_split.hip, through agcn_rows_dense_scaled_forward_ws and the backward's workspace), every shape the network has
+    (64 -> 128, 128 -> 128 | 128 -> 64, 64 -> 64, 128 -> 64 from the previous block | 64 -> 256), with the device scalars beta, the running
+    sum and the activation -- forward and every gradient against the float64 oracle of the whole row space, and the library's
+    profiler says which kernels ran (knob off: the general row kernels; same results to 2 x the bars)."""
+    B, n = 9, 1024
+    rows = B * n
+    rs = np.random.RandomState(99)
+    plan = amd.Plan([n] * B, 0, DEV)
+    gb = amd.GraphBatch(plan, torch.zeros(rows, 4, device=DEV))
+    f1, f2, f4, final = 64, 128, 64, 256
+    a1 = np.maximum(rs.randn(rows, f1), 0).astype(np.float32)      # in-block activations of block 2 (widths as block 1 / block 2 mixed:
+    a2 = np.maximum(rs.randn(rows, f2), 0).astype(np.float32)      #  every (Fin, Fout) pair of the network's six products occurs below)
+    o1 = np.maximum(rs.randn(rows, f2), 0).astype(np.float32)      # a previous block's output
+    x = (0.5 * rs.randn(rows, f4)).astype(np.float32)
+    Win = [orc.glorot_uniform(rs, (f1, f4)), orc.glorot_uniform(rs, (f2, f4))]
+    Wout = [orc.glorot_uniform(rs, (f2, f4))]
+    W12, W22 = orc.glorot_uniform(rs, (f1, f2)), orc.glorot_uniform(rs, (f2, f2))
+    Wd, bd = orc.glorot_uniform(rs, (f4, final)), (0.1 * rs.randn(final)).astype(np.float32)
+    b1, b2 = 0.6, 0.5
+    G = rs.randn(rows, f4).astype(np.float32)
+    Gd = rs.randn(rows, final).astype(np.float32)
+    G2 = rs.randn(rows, f2).astype(np.float32)
+    lib = amd._ffi.lib()
+    prev = lib.agcn_get_rows_split()
+
+    def run(split):
+        lib.agcn_set_rows_split(split)
+        lib.agcn_profile_enable(1)
+        try:
+            amd._ffi.profile_collect()
+            t = lambda v: torch.from_numpy(v).to(DEV).requires_grad_(True)      # noqa: E731
+            ta1, ta2, to1, tx = t(a1), t(a2), t(o1), t(x)
+            be = amd.DenseBlockEnd(1, [f1, f2], f4, "relu", max_atom=n, batch_size=B, device=DEV)
+            be.load_vars(Win, Wout, [b1], [b2])
+            rv = lambda v: amd.RowViews(v, plan, gb)                             # noqa: E731
+            out = be({"node_features": rv(tx), "graph_batch": gb, "inblock_activations": [rv(ta1), rv(ta2)],
+                      "inblock_activations_dim": [f1, f2], "block_outputs": [rv(to1)], "block_outputs_dim": [f2]})
+            (out.data * torch.from_numpy(G).to(DEV)).sum().backward()
+            # block 1's products (64 -> 128, 128 -> 128) and DenseMol (64 -> 256)
+            be1 = amd.DenseBlockEnd(0, [f1, f2], f2, "relu", max_atom=n, batch_size=B, device=DEV)
+            be1.load_vars([W12, W22], [], [0.7], [1.0])
+            tb1, tb2 = t(a1), t(a2)
+            out1 = be1({"node_features": rv(tb2), "graph_batch": gb, "inblock_activations": [rv(tb1), rv(tb2)],
+                        "inblock_activations_dim": [f1, f2], "block_outputs": [], "block_outputs_dim": []})
+            (out1.data * torch.from_numpy(G2).to(DEV)).sum().backward()
+            dm = amd.DenseMol(final, f4, activation="relu", device=DEV)
+            dm.load_vars(Wd, bd)
+            tdx = t(x)
+            outd = dm({"node_features": rv(tdx), "graph_batch": gb})
+            (outd.data * torch.from_numpy(Gd).to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            prof = {k: v[1] for k, v in amd._ffi.profile_collect().items() if v[1]}
+        finally:
+            lib.agcn_profile_enable(0)
+        res = {"out": out.data, "dx": tx.grad, "da1": ta1.grad, "da2": ta2.grad, "do1": to1.grad,
+               "out1": out1.data, "db1a": tb1.grad, "db1b": tb2.grad, "outd": outd.data, "ddx": tdx.grad}
+        for name, lay in (("be2", be), ("be1", be1), ("dm", dm)):
+            for i, v in enumerate(lay.parameters()):
+                res["grad_%s_%d" % (name, i)] = v.grad
+        return {k: to_np(v.detach()) for k, v in res.items() if v is not None}, prof
+
+    try:
+        got, prof = run(1)
+        got0, prof0 = run(0)
+    finally:
+        lib.agcn_set_rows_split(prev)
+    assert prof.get("rs_presplit_kernel", 0) == 12 and "rs_presplit_kernel" not in prof0, (prof, prof0)     # six products, both directions
+    f64 = lambda v: v.astype(np.float64)      # noqa: E731
+    y, pre = orc.dense_block_end_forward(f64(x), [f64(a1), f64(a2)], [f64(w) for w in Win], [f64(o1)], [f64(w) for w in Wout], b1, b2)
+    Gp, da, dWi, do, dWo, db1, db2 = orc.dense_block_end_backward([f64(a1), f64(a2)], [f64(w) for w in Win], [f64(o1)], [f64(w) for w in Wout],
+                                                                 b1, b2, pre, f64(G))
+    assert_close(got["out"], y, FEATURE_RTOL, "DenseBlockEnd out")
+    assert_close(got["dx"], Gp, GRAD_RTOL, "DenseBlockEnd dx")
+    assert_close(got["da1"], da[0], GRAD_RTOL, "da_1")
+    assert_close(got["da2"], da[1], GRAD_RTOL, "da_2")
+    assert_close(got["do1"], do[0], GRAD_RTOL, "do_1")
+    assert_close(got["grad_be2_0"], dWi[0], GRAD_RTOL, "dW_in[0] (64 x 64, 9216-row sums)", atol_ulps=GRAD_ULPS * 4)
+    assert_close(got["grad_be2_1"], dWi[1], GRAD_RTOL, "dW_in[1] (128 x 64)", atol_ulps=GRAD_ULPS * 4)
+    assert_close(got["grad_be2_2"], dWo[0], GRAD_RTOL, "dW_out[0] (128 x 64)", atol_ulps=GRAD_ULPS * 4)
+    assert abs(float(got["grad_be2_3"].reshape(-1)[0]) - db1) <= 4 * GRAD_RTOL * abs(db1) and \
+        abs(float(got["grad_be2_4"].reshape(-1)[0]) - db2) <= 4 * GRAD_RTOL * abs(db2)
+    y1, pre1 = orc.dense_block_end_forward(f64(a2), [f64(a1), f64(a2)], [f64(W12), f64(W22)], [], [], 0.7, 1.0)
+    assert_close(got["out1"], y1, FEATURE_RTOL, "block 1 end out")
+    Gp1, da1_, _, _, _, _, _ = orc.dense_block_end_backward([f64(a1), f64(a2)], [f64(W12), f64(W22)], [], [], 0.7, 1.0, pre1, f64(G2))
+    assert_close(got["db1a"], da1_[0], GRAD_RTOL, "block 1 end da_1")
+    assert_close(got["db1b"], Gp1 + da1_[1], GRAD_RTOL, "block 1 end dx + da_2")
+    yd = orc.dense_mol_forward(f64(x), f64(Wd), f64(bd))
+    assert_close(got["outd"], yd, FEATURE_RTOL, "DenseMol out")                  # (dense_layer.py:42-50: no activation applied)
+    dxd, dWd, dbd = orc.dense_mol_backward(f64(x), f64(Wd), f64(Gd))
+    assert_close(got["ddx"], dxd, GRAD_RTOL, "DenseMol dx")
+    assert_close(got["grad_dm_0"], dWd, GRAD_RTOL, "DenseMol dW (64 x 256)", atol_ulps=GRAD_ULPS * 4)
+    assert_close(got["grad_dm_1"], dbd, GRAD_RTOL, "DenseMol db", atol_ulps=GRAD_ULPS * 4)
+    # every tensor of the split path against the general kernels (two fp32 evaluations: 2 x the bars), parameter gradients included
+    for k in got:
+        if got[k].size == 1:
+            assert abs(float(got[k].reshape(-1)[0]) - float(got0[k].reshape(-1)[0])) <= 4 * GRAD_RTOL * max(1.0, abs(float(got0[k].reshape(-1)[0]))), k
+        else:
+            assert_close(got[k], f64(got0[k]), 2 * (FEATURE_RTOL if k.startswith("out") else GRAD_RTOL), "split vs general " + k)
+
+
 def test_multitask_head_golden(amd):
     """12-task-style classifier tail: logits, loss and every gradient against vectors produced by the
     reference's multitask_logits + add_training_loss('cross_entropy')."""
