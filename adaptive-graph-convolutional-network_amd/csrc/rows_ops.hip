@@ -247,10 +247,10 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   int32_t n16 = 0;
   float* tags = (desc->Fin > 8 && !split) ? param_grad_tag_region(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &n16) : nullptr;
   if (tags != nullptr) { g.ztag_ptr = tags; g.ztag_count16 = n16; }
-  else if (!split) g.zero_ptr = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &g.zero_count);
-  if (split)       // (rows_split.hip: Gp and dX = [scale] Gp W^T; the parameter-gradient kernel clears its own counters)
+  else g.zero_ptr = param_grad_counters(w.part, w.part_floats, host.info.rows, desc->Fin, desc->Fout, 1, 0, &g.zero_count);
+  if (split)       // (rows_split.hip: Gp and dX = [scale] Gp W^T; its first workgroup zeroes the parameter-gradient kernel's counters)
     rc = launch_rows_split_dense_bwd(dY, Y, desc->ldy, desc->activation == AGCN_ACT_RELU ? 1 : 0, W, scale, Gp, dX, desc->ldx, desc->Fin,
-                                     desc->Fout, host.info.rows, w.img, hip_stream);
+                                     desc->Fout, host.info.rows, w.img, g.zero_ptr, g.zero_count, hip_stream);
   else
     rc = launch_rows_gemm(g, RG_FILTER_BWD, hip_stream);
   if (rc != AGCN_OK) return rc;
@@ -262,7 +262,7 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
   pa.chunk_rows = ((host.info.rows + w.n_chunks - 1) / w.n_chunks + 15) / 16 * 16;
   pa.B = 0; pa.part_stride = w.part_stride;
   pa.X = X; pa.Gp = Gp; pa.part = w.part; pa.part_floats = w.part_floats;
-  pa.counters_zeroed = (tags || split) ? 0 : 1; pa.tags_zeroed = tags ? 1 : 0;
+  pa.counters_zeroed = tags ? 0 : 1; pa.tags_zeroed = tags ? 1 : 0;
   pa.dev_status = current_device_info().status_word; pa.ticks = agcn_get_coop_timeout_ticks();
   pa.dweight = dW; pa.dbias = dbias ? dbias : w.dbias;
   rc = launch_param_grads(pa, hip_stream);

@@ -74,6 +74,7 @@ struct RsArgs {
   int32_t accumulate;                 // RS_PLAIN: Out0 += product (dX += dZ M_L^T)
   const float* scale;                 // RS_FILTER / RS_FILTER_BWD: optional device scalar on the product (DenseBlockEnd's beta)
   const float* Add; int32_t ldadd;    // RS_FILTER: optional addend [rows][ldadd] (the dense layers' running sum / residual)
+  int32_t* zero_ptr; int32_t zero_count;   // RS_FILTER_BWD: arrival counters of the parameter-gradient kernel behind it, zeroed by workgroup 0
   int32_t rows;
   const u32x4* Bimg; int32_t nt_total;   // image of the whole B: [KB][nt_total][3][64] u32x4
 };
@@ -147,6 +148,8 @@ __global__ __launch_bounds__(256) void rs_rows_kernel(RsArgs a) {
   load_chunk(0);
 
   if constexpr (MODE == RS_FILTER_BWD) {   // the masked gradient rows for the parameter-gradient kernels
+    if (blockIdx.x == 0 && a.zero_ptr != nullptr)
+      for (int i = tid; i < a.zero_count; i += 256) a.zero_ptr[i] = 0;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -566,7 +569,7 @@ int launch_rows_split_dense_fwd(const float* A, int lda, const float* W, const f
 }
 
 int launch_rows_split_dense_bwd(const float* dY, const float* Y, int ldy, int relu, const float* W, const float* scale, float* Gp, float* dX,
-                                int ldx, int Fin, int Fout, int rows, void* img, void* stream) {
+                                int ldx, int Fin, int Fout, int rows, void* img, int32_t* zero_ptr, int32_t zero_count, void* stream) {
   if (!al16(dY) || !al16(Y) || !al16(Gp) || !al16(dX) || !al16(img)) return fail(AGCN_EINVAL, "rows_split_dense_bwd: unaligned buffer");
   SplitJobs jobs;
   jobs.j[0] = SplitJob{W, 1, Fout, Fout, Fin, 0u, Fin / 16, 0};       // B[k = c][column f] = W[f][c]
@@ -575,6 +578,7 @@ int launch_rows_split_dense_bwd(const float* dY, const float* Y, int ldy, int re
   RsArgs a{};
   a.A0 = dY; a.lda0 = ldy; a.Yact = Y; a.ldy = ldy; a.relu = relu; a.Gp = Gp; a.ldgp = Fout; a.scale = scale;
   a.Out0 = dX; a.ldo0 = ldx; a.Out1 = dX; a.ldo1 = ldx; a.n_split = Fin; a.rows = rows;
+  a.zero_ptr = zero_ptr; a.zero_count = zero_count;
   a.Bimg = static_cast<const u32x4*>(img); a.nt_total = Fin / 16;
   return launch_rs_kn<RS_FILTER_BWD>(a, Fout, Fin, PK_FILTER_BWD, "rs_dense_bwd", stream);
 }

@@ -237,7 +237,7 @@ size_t rows_split_dense_image_bytes(int Fin, int Fout);
 int launch_rows_split_dense_fwd(const float* A, int lda, const float* W, const float* scale, const float* bias, const float* Add, int ldadd,
                                 int relu, float* Y, int ldy, int Fin, int Fout, int rows, void* img, void* stream);
 int launch_rows_split_dense_bwd(const float* dY, const float* Y, int ldy, int relu, const float* W, const float* scale, float* Gp, float* dX,
-                                int ldx, int Fin, int Fout, int rows, void* img, void* stream);
+                                int ldx, int Fin, int Fout, int rows, void* img, int32_t* zero_ptr, int32_t zero_count, void* stream);
 int launch_param_grads(const ParamGradArgs& a, void* stream);
 size_t param_grad_onepass_floats(int32_t rows, int32_t Fin, int32_t Fout, int32_t K, int32_t paper);
 // the arrival counters inside `part` (nullptr when the one-pass kernel will not be used) and their number
