@@ -656,8 +656,8 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
     }
     w->spart = c.take((size_t)8 * ((size_t)pi.n_slabs / 4 + 8));
   }
-  // ... 128 features: the P = g_1 X_0^T tile pass A leaves for the element-wise pass B / part 2 of pass C
-  w->P = (d->variant == AGCN_SGC_LL_RESLAP && cloud_shape(d) && d->Fin == 128) ? c.take((size_t)pi.tile_elems) : nullptr;
+  // ... 128 features: the P = g_1 X_0^T tile for the element-wise passes behind its writer (Reslap: pass B; SGC_LL: backward 1 by parts)
+  w->P = (cloud_shape(d) && d->Fin == 128 && (d->variant == AGCN_SGC_LL_RESLAP || paper)) ? c.take((size_t)pi.tile_elems) : nullptr;
   w->n_chunks = n_chunks_for(pi.rows);
   w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
   w->part_stride = (w->part_stride + 3) / 4 * 4;

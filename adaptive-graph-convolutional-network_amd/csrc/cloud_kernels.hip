@@ -912,8 +912,19 @@ __device__ __forceinline__ Pieces cols_B(const uint16_t* img, int off) {
 
 // FS: row stride of the packed feature arrays (= Fin: 64, or 128 with the kernel run once per 64-column half); ACC: second half
 // (Q, ds and dalpha are linear in the per-half products: this run adds to the first one's)
-template <int FS, bool ACC>
+// PART (128-feature layers, both 64-column feature halves per run; the recipe of the SGC_LL_Reslap passes below):
+//   0  everything, one feature half per run (64-feature layers; the 128-feature layers until round 5: two runs, every tile read
+//      twice + the read-modify-write of Q: 124 + 149 us)
+//   1  P = g_1[I] X_0[J]^T over all 128 features (four k-blocks; X_0 images of both halves in the six planes) -> a.ws_P; no tile is read
+//   2  everything else, element-wise from that tile (P_sym = P + P^T: P_ji read as 16-byte pieces along i), the L g_1 product over
+//      both halves (g_1 images of both halves, two accumulator sets): r, L_orig, P, P^T in, Q out, one run
+template <int FS, bool ACC, int PART = 0>
 __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
+  static_assert(PART == 0 || (FS == 128 && !ACC), "by parts: 128 features, both halves per run");
+  constexpr bool DO_P = PART != 2;        // the P products are formed here
+  constexpr bool DO_REST = PART != 1;     // tiles, element-wise work, the L g_1 product
+  constexpr int NHX = PART == 2 ? 2 : 1;  // feature halves of the L g_1 product
+  constexpr int NKB = PART == 1 ? 4 : 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -922,29 +933,37 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
   const int slab = 4 * strip + wave;
   const WaveCtx c = wave_ctx(a, slab);
   const int n = c.n;
-  uint16_t* PX = reinterpret_cast<uint16_t*>(smem);   // [3][64][LDH]  bf16 pieces of the chunk's X_0 rows
-  uint16_t* PG = PX + 3 * PLANE_H;                     // [3][64][LDH]  ... of its g_1 rows
+  uint16_t* PX = reinterpret_cast<uint16_t*>(smem);   // [3][64][LDH]  bf16 pieces of the chunk's X_0 rows  (part 2: g_1, second half)
+  uint16_t* PG = PX + 3 * PLANE_H;                     // [3][64][LDH]  ... of its g_1 rows                (part 1: X_0, second half)
   float* Ls = smem + (6 * PLANE_H) / 2 + wave * (16 * LD);   // [16][LD] this wave's strip of L (fp32)
   const float alpha = a.alpha[0];
   const float* Xg = a.X + (int64_t)c.row0 * a.ldx + a.foff;
   const float* g1 = a.ws_g + (int64_t)c.row0 * FS + a.foff;   // adjoint of X_1 (K = 2: plane 0)
   int l0ld;
   const float* L0d = dense_l0(a, c, &l0ld);
-  const float* Rt = a.sv_r + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
-  float* Qt = a.ws_dA + c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const int64_t o0 = c.toff + (int64_t)(c.i0 + 4 * q) * n + 4 * r;
+  const float* Rt = a.sv_r + o0;
+  float* Qt = a.ws_dA + o0;
   const float* L0t = L0d + (int64_t)(c.i0 + 4 * q) * l0ld + 4 * r;
   const float* sjp = a.sv_s + c.row0 + 4 * r;
+  float* Pw = PART == 1 ? a.ws_P + o0 : nullptr;
+  const float* Ppt = PART == 2 ? a.ws_P + o0 : nullptr;
+  const float* PpT = PART == 2 ? a.ws_P + c.toff + (int64_t)(4 * r) * n + c.i0 + 4 * q : nullptr;      // + (c0 + t) n: [t] over i
   float si[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) si[i] = a.sv_s[c.row0 + c.i0 + 4 * q + i];
   // A pieces of the wave's own rows: lane (r, q) holds [row r][32 kb + 8q .. + 7]
-  Pieces Ag[2], Ax[2];
+  Pieces Ag[NKB], Ax[2];
+  if constexpr (DO_P) {
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const float* gp = g1 + (int64_t)(c.i0 + r) * FS + 32 * kb + 8 * q;
-    const float* xp = Xg + (int64_t)(c.i0 + r) * a.ldx + 32 * kb + 8 * q;
-    Ag[kb] = split3x8(*reinterpret_cast<const f32x4*>(gp), *reinterpret_cast<const f32x4*>(gp + 4));
-    Ax[kb] = split3x8(*reinterpret_cast<const f32x4*>(xp), *reinterpret_cast<const f32x4*>(xp + 4));
+    for (int kb = 0; kb < NKB; ++kb) {
+      const float* gp = g1 + (int64_t)(c.i0 + r) * FS + 32 * kb + 8 * q;
+      Ag[kb] = split3x8(*reinterpret_cast<const f32x4*>(gp), *reinterpret_cast<const f32x4*>(gp + 4));
+      if constexpr (PART == 0) {
+        const float* xp = Xg + (int64_t)(c.i0 + r) * a.ldx + 32 * kb + 8 * q;
+        Ax[kb] = split3x8(*reinterpret_cast<const f32x4*>(xp), *reinterpret_cast<const f32x4*>(xp + 4));
+      }
+    }
   }
   struct Tiles { f32x4 rv[4], l0[4], sj; };
   auto load_tiles = [&](int c0) {
@@ -957,37 +976,54 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
     }
     return g;
   };
-  // staging: thread = (chunk row rho = tid / 4, features 16 (tid % 4) .. + 15) of both matrices
+  // part 2: P_ij ([i][t]) and P_ji ([t][i]) of a chunk, requested at the top of the chunk (in flight behind the element-wise stage)
+  struct PTiles { f32x4 pp[4], pt[4]; };
+  auto load_p = [&](int c0) {
+    PTiles g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g.pp[i] = PART == 2 ? *reinterpret_cast<const f32x4*>(Ppt + (int64_t)i * n + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      g.pt[i] = PART == 2 ? *reinterpret_cast<const f32x4*>(PpT + (int64_t)(c0 + i) * n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return g;
+  };
+  // staging: thread = (chunk row rho = tid / 4, features 16 (tid % 4) .. + 15) of both matrices.  What the planes hold: PX <- X_0,
+  // PG <- g_1 of this run's half; part 1: X_0's two halves; part 2: g_1's second / first half.
   const int rho = tid >> 2, sg = tid & 3, irow = 16 * (rho & 3) + (rho >> 2);
   struct Stage { f32x4 g[4], x[4]; };
   auto stage_load16 = [&](int c0) {
-    Stage s;
-    const float* gp = g1 + (int64_t)(c0 + rho) * FS + 16 * sg;
-    const float* xp = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
+    Stage st;
+    const float* x0 = Xg + (int64_t)(c0 + rho) * a.ldx + 16 * sg;
+    const float* g0 = g1 + (int64_t)(c0 + rho) * FS + 16 * sg;
+    const float* xp = PART == 2 ? g0 + 64 : x0;
+    const float* gp = PART == 1 ? x0 + 64 : g0;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      s.g[m] = *reinterpret_cast<const f32x4*>(gp + 4 * m);
-      s.x[m] = *reinterpret_cast<const f32x4*>(xp + 4 * m);
+      st.g[m] = *reinterpret_cast<const f32x4*>(gp + 4 * m);
+      st.x[m] = *reinterpret_cast<const f32x4*>(xp + 4 * m);
     }
-    return s;
+    return st;
   };
-  auto stage_store16 = [&](const Stage& s) {
+  auto stage_store16 = [&](const Stage& st) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      const Pieces pg = split3x8(s.g[2 * hf], s.g[2 * hf + 1]), px = split3x8(s.x[2 * hf], s.x[2 * hf + 1]);
+      const Pieces pg = split3x8(st.g[2 * hf], st.g[2 * hf + 1]), px = split3x8(st.x[2 * hf], st.x[2 * hf + 1]);
       const int o = irow * LDH + 16 * sg + 8 * hf;
       *reinterpret_cast<u32x4*>(PG + o) = pg.h; *reinterpret_cast<u32x4*>(PG + PLANE_H + o) = pg.m; *reinterpret_cast<u32x4*>(PG + 2 * PLANE_H + o) = pg.l;
       *reinterpret_cast<u32x4*>(PX + o) = px.h; *reinterpret_cast<u32x4*>(PX + PLANE_H + o) = px.m; *reinterpret_cast<u32x4*>(PX + 2 * PLANE_H + o) = px.l;
     }
   };
 
-  f32x4 acc[4];          // dX[I]: tile e <-> features 16 e + r
+  f32x4 acc[NHX][4];     // dX[I]: tile e of half h <-> features 64 h + 16 e + r
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < NHX; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[h][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float ds[4] = {0.f, 0.f, 0.f, 0.f};
   float dalpha_part = 0.f;
   Stage pre = stage_load16(0);
-  Tiles cur = load_tiles(0);
+  Tiles cur;
+  if constexpr (DO_REST) cur = load_tiles(0);
   const int offB = r * LDH + 8 * q;                                // rows_B: image row 16 t + r, k 32 kb + 8q ..
   const int offT = (8 * q + (r >> 2)) * LDH + 4 * (r & 3);         // cols_B: row 32 kb + 8q + r / 4, columns 16 e + 4 (r % 4) ..
 #pragma unroll 1
@@ -997,63 +1033,89 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
     __syncthreads();
     if (c0 + CC < n) pre = stage_load16(c0 + CC);
     f32x4 Sv[4];          // [i][t]: S_ij
-    f32x4 sj = cur.sj;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = c.i0 + 4 * q + i;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bool diag = row == c0 + 4 * r + t;
-        Sv[i][t] = diag ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);          // cloud_sim's instruction
-        const float R = (diag ? 1.f : 0.f) - (si[i] * Sv[i][t]) * sj[t];                  // cloud_lap's instruction
-        Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(R, alpha) + cur.l0[i][t];
-      }
-    }
-    if (c0 + CC < n) cur = load_tiles(c0 + CC);
-    __builtin_amdgcn_wave_barrier();
-    // P[I, tile] = g_1[I] . X_0[tile]^T + X_0[I] . g_1[tile]^T (two accumulation chains), then the element-wise epilogue.
-    // Blocks (t, kb, which product) in a row, the next block's B pieces requested before this block's MFMAs.
-    f32x4 Qv[4];         // [i][t]
-    Pieces Bn = rows_B(PX, offB);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        Pieces Bc = Bn;
-        Bn = rows_B(PG, offB + 16 * t * LDH + 32 * kb);
-        __builtin_amdgcn_sched_barrier(0);
-        pa = mfma_x6(Ag[kb], Bc, pa);
-        Bc = Bn;
-        if (kb == 0) Bn = rows_B(PX, offB + 16 * t * LDH + 32);
-        else if (t < 3) Bn = rows_B(PX, offB + 16 * (t + 1) * LDH);
-        __builtin_amdgcn_sched_barrier(0);
-        pb = mfma_x6(Ax[kb], Bc, pb);
-      }
+    const PTiles pt_ = load_p(c0);
+    f32x4 sj = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (DO_REST) {
+      sj = cur.sj;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = c.i0 + 4 * q + i;
-        const bool diag = row == c0 + 4 * r + t;
-        const float R = (diag ? 1.f : 0.f) - (si[i] * Sv[i][t]) * sj[t];
-        const float P = pa[i] + pb[i];
-        dalpha_part = __builtin_fmaf(P, fminf(R, 0.f), dalpha_part);
-        const float Q = -(P * lrelu_grad(R, alpha));            // dA_ij + dA_ji, dA = -dR
-        Qv[i][t] = Q;
-        ds[i] = __builtin_fmaf(Q, Sv[i][t] * sj[t], ds[i]);      // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool diag = row == c0 + 4 * r + t;
+          Sv[i][t] = diag ? 0.f : __builtin_amdgcn_exp2f(cur.rv[i][t] * NLOG2E);          // cloud_sim's instruction
+          const float R = (diag ? 1.f : 0.f) - (si[i] * Sv[i][t]) * sj[t];                  // cloud_lap's instruction
+          Ls[(4 * q + i) * LD + 16 * t + r] = lrelu(R, alpha) + cur.l0[i][t];
+        }
       }
+      if (c0 + CC < n) cur = load_tiles(c0 + CC);
+      __builtin_amdgcn_wave_barrier();
+    }
+    // P[I, tile] = g_1[I] . X_0[tile]^T + X_0[I] . g_1[tile]^T (two accumulation chains), then the element-wise epilogue.
+    // Blocks (t, kb, which product) in a row, the next block's B pieces requested before this block's MFMAs.
+    f32x4 Qv[4];         // [i][t]  (part 1: P)
+    Pieces Bn;
+    if constexpr (PART == 0) Bn = rows_B(PX, offB);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (PART == 0) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          Pieces Bc = Bn;
+          Bn = rows_B(PG, offB + 16 * t * LDH + 32 * kb);
+          __builtin_amdgcn_sched_barrier(0);
+          pa = mfma_x6(Ag[kb], Bc, pa);
+          Bc = Bn;
+          if (kb == 0) Bn = rows_B(PX, offB + 16 * t * LDH + 32);
+          else if (t < 3) Bn = rows_B(PX, offB + 16 * (t + 1) * LDH);
+          __builtin_amdgcn_sched_barrier(0);
+          pb = mfma_x6(Ax[kb], Bc, pb);
+        }
+      } else if constexpr (PART == 1) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) pa = mfma_x6(Ag[kb], rows_B(kb < 2 ? PX : PG, offB + 16 * t * LDH + 32 * (kb & 1)), pa);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Qv[i][t] = pa[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pa[i] = pt_.pp[i][t]; pb[i] = pt_.pt[t][i]; }
+      }
+      if constexpr (DO_REST) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = c.i0 + 4 * q + i;
+          const bool diag = row == c0 + 4 * r + t;
+          const float R = (diag ? 1.f : 0.f) - (si[i] * Sv[i][t]) * sj[t];
+          const float P = pa[i] + pb[i];
+          dalpha_part = __builtin_fmaf(P, fminf(R, 0.f), dalpha_part);
+          const float Q = -(P * lrelu_grad(R, alpha));            // dA_ij + dA_ji, dA = -dR
+          Qv[i][t] = Q;
+          ds[i] = __builtin_fmaf(Q, Sv[i][t] * sj[t], ds[i]);      // ds_i = sum_j (dA_ij + dA_ji) S_ij s_j
+        }
+      }
+    }
+    if constexpr (PART == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Pw + (int64_t)i * n + c0) = Qv[i];
+      continue;
     }
     // dX[I] += L[I, chunk] g_1[chunk]: A = the L patch (k = the patch column = the image row of the chunk's g_1), split here
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const float* lp = Ls + r * LD + 32 * kb + 8 * q;
       const Pieces Al = split3x8(*reinterpret_cast<const f32x4*>(lp), *reinterpret_cast<const f32x4*>(lp + 4));
-      Pieces Tn = cols_B(PG, offT + 32 * kb * LDH);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const Pieces Tc = Tn;
-        if (e < 3) Tn = cols_B(PG, offT + 32 * kb * LDH + 16 * (e + 1));
-        __builtin_amdgcn_sched_barrier(0);
-        acc[e] = mfma_x6(Al, Tc, acc[e]);
+      for (int h = 0; h < NHX; ++h) {
+        const uint16_t* img = h == 0 ? PG : PX;
+        Pieces Tn = cols_B(img, offT + 32 * kb * LDH);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const Pieces Tc = Tn;
+          if (e < 3) Tn = cols_B(img, offT + 32 * kb * LDH + 16 * (e + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          acc[h][e] = mfma_x6(Al, Tc, acc[h][e]);
+        }
       }
     }
     if (ACC) {    // second feature half of a 128-feature layer: Q is linear in P
@@ -1063,12 +1125,15 @@ __global__ __launch_bounds__(256, 2) void cloud_bwd1_paper_kernel(SgcArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Qt + (int64_t)i * n + c0) = Qv[i];
   }
+  if constexpr (PART == 1) return;
   // dX rows of the strip (g_0 already there from the packed filter adjoint): lane (r, q) holds rows 4q + i, features 16 e + r
   float* dXg = a.dX + (int64_t)(c.row0 + c.i0) * a.ldx + a.foff;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dXg[(int64_t)(4 * q + i) * a.ldx + 16 * e + r] += acc[e][i];
+    for (int h = 0; h < NHX; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dXg[(int64_t)(4 * q + i) * a.ldx + 64 * h + 16 * e + r] += acc[h][e][i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float t = row16_sum(ds[i]);
@@ -2132,6 +2197,9 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
   const size_t lds_f32 = sizeof(float) * (CC * LD + 4 * 16 * LD);
   const size_t lds_bf = sizeof(float) * (4 * 16 * LD) + sizeof(uint16_t) * 6 * PLANE_H;
   int rc = AGCN_OK;
+  // 128 features, paper mode, a P tile in the workspace: backward 1 by parts (AGCN_CLOUD_BWD1_PARTS=0: once per half, for A/B runs)
+  static const int parts = [] { const char* e = std::getenv("AGCN_CLOUD_BWD1_PARTS"); return (e && e[0] == '0') ? 0 : 1; }();
+  const bool by_parts = wide && paper && parts && a.ws_P != nullptr;
   for (int half = 0; half < (wide ? 2 : 1) && rc == AGCN_OK; ++half) {
     SgcArgs ah = a;
     ah.foff = 64 * half; ah.half_acc = half; ah.half_last = (half == (wide ? 1 : 0)) ? 1 : 0;
@@ -2139,7 +2207,12 @@ int launch_cloud_backward(const SgcArgs& a, float* WT, void* stream) {
       rc = launch_cloud(cloud_bwd1_ref_kernel, grid, 256, lds_f32, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
     else if (!wide)
       rc = launch_cloud(cloud_bwd1_paper_kernel<64, false>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
-    else
+    else if (by_parts) {     // both feature halves per run: P = g_1 X_0^T -> a.ws_P, then everything else from that tile
+      if (half != 0) break;
+      ah.half_last = 1;
+      rc = launch_cloud(cloud_bwd1_paper_kernel<128, false, 1>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
+      if (rc == AGCN_OK) rc = launch_cloud(cloud_bwd1_paper_kernel<128, false, 2>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
+    } else
       rc = half == 0 ? launch_cloud(cloud_bwd1_paper_kernel<128, false>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah)
                      : launch_cloud(cloud_bwd1_paper_kernel<128, true>, grid, 256, lds_bf, PK_CLOUD_BWD1, "cloud_bwd1", stream, ah);
   }
