@@ -547,7 +547,10 @@ void agcn_set_rows_split(int32_t on);
  * (K * Fin <= 8 columns) of >= 1024 packed rows take the 64-row MFMA workgroups instead of the streaming row kernels;
  * AGCN_CLOUD_RBWD_BOTH=0 -- the backward passes of a 128-feature SGC_LL_Reslap layer run once per 64-column feature half, as before
  * round 5, instead of pass A over both halves / pass C by parts / pass B element-wise from the P = g_1 X_0^T tile;
- * AGCN_CLOUD_BWD2_BF = 0 | 2 -- backward 2's product c Z never | always on the bf16 matrix pipe (default 1: 128-feature layers only). */
+ * AGCN_CLOUD_BWD2_BF = 0 | 2 -- backward 2's product c Z never | always on the bf16 matrix pipe (default 1: 128-feature layers only);
+ * AGCN_CLOUD_BWD1_PARTS=0 -- backward 1 of a 128-feature SGC_LL layer once per feature half instead of by parts (P tile);
+ * AGCN_CLOUD_SIM2=0 -- the 128-feature similarity with all 128 features of a lane's column row in registers (two waves per SIMD)
+ * instead of two passes of 64 (four). */
 
 #ifdef __cplusplus
 }
