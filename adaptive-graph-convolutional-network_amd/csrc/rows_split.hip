@@ -66,7 +66,7 @@ struct RsArgs {
   const float* A1; int32_t lda1;      // rows of term 1 (RS_FILTER: X_1), k-blocks kb >= kb_term
   int32_t kb_term;                    // k-blocks per term
   const float* Yact; int32_t ldy; int32_t relu;   // RS_FILTER_BWD: A = A0 (dY) where Yact > 0 (relu) ; RS_FILTER: relu on the output
-  float* Gp; int32_t ldgp;            // RS_FILTER_BWD: the masked A rows, stored by column block 0
+  float* Gp; int32_t ldgp;            // RS_FILTER_BWD: the masked A rows, stored for the parameter-gradient kernels
   const float* bias;                  // RS_FILTER
   float* Out0; int32_t ldo0;          // output columns [0, n_split)
   float* Out1; int32_t ldo1;          // output columns [n_split, N) (RS_FILTER_BWD: g_1)
@@ -424,7 +424,8 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 template <int KB, int NT, int NCB, int MODE>
 int launch_rs(const RsArgs& a, int prof_id, const char* what, void* stream) {
   if (a.rows <= 0) return AGCN_OK;
-  const size_t lds = (size_t)2 * 16 * TILE16 * 16;         // two chunks of 16 tiles
+  constexpr int KBC = (16 / NT) < KB ? (16 / NT) : KB;
+  const size_t lds = (size_t)2 * KBC * NT * TILE16 * 16;   // two chunks (of at most 16 tiles: 48 KB each)
   const void* fn = reinterpret_cast<const void*>(&rs_rows_kernel<KB, NT, NCB, MODE>);
   if (int e = ensure_dynamic_lds(fn, lds)) return fail(AGCN_EDEVICE, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString((hipError_t)e));
   prof_begin(prof_id, stream);
