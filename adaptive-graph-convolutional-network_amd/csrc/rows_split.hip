@@ -538,7 +538,8 @@ int launch_rows_split_project_bwd(const float* dZ, float* dX, int ldx, int Fin, 
 // gradients.  One parameter image per call (W, or W^T as strides of the split) in the caller's workspace.
 bool rows_split_dense_ok(int rows, int Fin, int Fout, int ldx, int ldy, int ldadd) {
   auto w = [](int f) { return f == 64 || f == 128 || f == 256; };
-  return rs_env() && rows >= 8192 && w(Fin) && w(Fout) && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0;
+  static const int min_rows = [] { const char* e = std::getenv("AGCN_ROWS_SPLIT_DENSE_MIN"); return e ? std::atoi(e) : 8192; }();
+  return rs_env() && rows >= min_rows && w(Fin) && w(Fout) && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0;
 }
 size_t rows_split_dense_image_bytes(int Fin, int Fout) { return 16 * img_units(Fin, Fout); }
 
