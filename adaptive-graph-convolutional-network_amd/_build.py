@@ -11,8 +11,9 @@ ARCH = "gfx950"
 # -Wno-pass-failed: "loop not unrolled" remarks for unroll hints on runtime-bounded loops of the per-graph kernels
 # -fno-slp-vectorize: keeps adjacent scalar fp32 adds / fmas as v_add_f32 / v_fma_f32; the packed v_pk_*_f32 forms the
 # SLP vectoriser would build issue several times slower on gfx950 (measured in the pairwise-distance loop)
+# -fvisibility=hidden: the dynamic symbol table is the 66 functions of include/agcn.h (AGCN_API) and nothing else
 FLAGS = ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17", "-Wall",
-         "-Wno-unused-function", "-Wno-pass-failed"]
+         "-Wno-unused-function", "-Wno-pass-failed", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
 def sources():
@@ -21,7 +22,8 @@ def sources():
 
 def _deps():
     root = os.path.dirname(HERE)
-    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(root, "include", "agcn.h")]
+    return (sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(root, "include", "agcn.h"),
+                                                                os.path.join(CSRC, "exports.map")])
 
 
 def is_stale():
@@ -55,7 +57,8 @@ def build(force=False, verbose=False, jobs=None):
 
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         objs = list(pool.map(compile_one, sources()))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+           "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -26,7 +26,7 @@ class PlanInfo(C.Structure):
 class LayerDesc(C.Structure):
     _fields_ = [("Fin", C.c_int32), ("Fout", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32),
                 ("variant", C.c_int32), ("activation", C.c_int32), ("ldx", C.c_int32), ("ldy", C.c_int32),
-                ("feat_dtype", C.c_int32)]
+                ("feat_dtype", C.c_int32), ("flags", C.c_uint32)]
 
 
 class GraphBatch(C.Structure):
@@ -52,7 +52,7 @@ class Grads(C.Structure):
 
 class DenseDesc(C.Structure):
     _fields_ = [("Fin", C.c_int32), ("Fout", C.c_int32), ("activation", C.c_int32), ("keep_pad_rows", C.c_int32),
-                ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldadd", C.c_int32), ("reserved", C.c_int32)]
+                ("ldx", C.c_int32), ("ldy", C.c_int32), ("ldadd", C.c_int32), ("flags", C.c_uint32)]
 
 
 class GraphStoreC(C.Structure):
@@ -82,6 +82,27 @@ class EpochNeeds(C.Structure):
 class StagedBatch(C.Structure):
     _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("max_n", C.c_int32), ("symmetric", C.c_int32),
                 ("stage_bytes", C.c_int64), ("plan", PlanInfo)]
+
+
+# AgcnLayerDesc.flags / AgcnDenseDesc.flags (include/agcn.h, AGCN_FLAG_*): per-call dispatch overrides, field = value + 1
+_FLAG_FIELDS = {"spec_mode": (0, 15, 1, 0, 7), "fused_mode": (4, 7, 1, 0, 3), "pg_onepass": (7, 3, 1, 0, 2), "spec_small": (9, 3, 1, 0, 2),
+                "rows_split": (11, 3, 1, 0, 1), "slab_mode": (13, 3, 1, 0, 1), "fused_gb": (15, 3, 2, -1, 1), "spec_tail": (17, 3, 1, 0, 1),
+                "coop_members": (24, 255, 1, 0, 120)}
+
+
+def dispatch_flags(base=0, **knobs):
+    """The flags word that overrides the named dispatch knobs for one call (None = leave the field of `base` alone):
+    dispatch_flags(spec_mode=3) = every kernel path as usual but no member workgroups."""
+    f = int(base)
+    for name, v in knobs.items():
+        shift, mask, bias, lo, hi = _FLAG_FIELDS[name]
+        if v is None:
+            continue
+        v = int(v)
+        if not lo <= v <= hi:
+            raise ValueError("%s = %d outside %d..%d" % (name, v, lo, hi))
+        f = (f & ~(mask << shift)) | ((v + bias) << shift)
+    return f
 
 
 MODE = {"reference": 0, "paper": 1}

@@ -82,7 +82,7 @@ int count_global(const PlanView& host, int32_t Fin, bool bwd) {
 
 // Slab-parallel kernels (slab_kernels.hip): SGC_LL, K = 2, packed rows, symmetric L_orig (CSR or dense).
 bool use_slabs(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const AgcnPlanInfo& pi) {
-  if (agcn_get_slab_mode() == 0) return false;
+  if (knob_slab_mode() == 0) return false;
   return d->variant == AGCN_SGC_LL && d->K == 2 && pi.rows == pi.N1 &&
          (g->L0_rowptr != nullptr || g->L0_dense != nullptr) && g->L0_symmetric == 1 && slab_path_fits(d->Fin);
 }
@@ -114,7 +114,7 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
   f->spec_fwd = f->spec_bwd = f->spec_bwd_first = 0;
   f->spec_small_first = pi.B;
   if (f->mode != 1 || !spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
-  const int m = agcn_get_spec_mode();
+  const int m = knob_spec_mode();
   if ((m & 1) && spec_fwd_lds_bytes(pi.max_n, d->Fin, d->Fout, spec::NW_LARGE) <= lim) f->spec_fwd = 1;
   if ((m & 2) && f->spec_fwd) {   // (the specialised forward wrote the transposed parameter copies the backward reads)
     int first = 0;
@@ -127,7 +127,7 @@ void pick_spec(FusedSplit* f, const AgcnLayerDesc* d, const PlanView& host, size
   // (measured, Tox21-shaped batches, graphs/s with one launch | two launches side by side:
   //  512: 5.7 | 5.1 M;  768: 6.6 | 6.0 M;  1024: 7.2 | 7.4 M;  1280: 7.5 | 8.5 M;  2048: 8.0 | 10.6 M;  4096: 7.3 | 13.0 M)
   static const int min_b = [] { const char* e = std::getenv("AGCN_SMALL_MIN_B"); return e ? std::atoi(e) : 1024; }();
-  if ((f->spec_fwd || f->spec_bwd) && pi.B >= min_b && agcn_get_spec_small() != 0) {
+  if ((f->spec_fwd || f->spec_bwd) && pi.B >= min_b && knob_spec_small() != 0) {
     // the 8-wave launch's LDS per workgroup is that of its largest graph and its registers allow three workgroups per
     // CU: a lower cut keeps three of them resident (measured, 2048 graphs: cut at 40 / 32 / 24 nodes: 9.9 / 10.5 /
     // 10.6 M graphs/s; 4096 graphs: 12.7 / 13.0 / 12.2 M)
@@ -150,7 +150,7 @@ void mixed_spec(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   // stream BY DEFAULT (big_pg; AGCN_RESLAP_MIXED=0 disables)
   static const int res_mixed = [] { const char* e = std::getenv("AGCN_RESLAP_MIXED"); return e ? std::atoi(e) : 1; }();
   const bool reslap = d->variant == AGCN_SGC_LL_RESLAP;
-  if (agcn_get_fused_mode() < ((reslap && res_mixed) ? 1 : 3) || (agcn_get_spec_mode() & 3) != 3) return;
+  if (knob_fused_mode() < ((reslap && res_mixed) ? 1 : 3) || (knob_spec_mode() & 3) != 3) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || (!reslap && !use_slabs(d, g, pi))) return;
   if (reslap && g->L0_dense != nullptr) {   // (point clouds -- every graph a multiple of 64 nodes, dense L_orig -- stay with the cloud kernels)
@@ -186,13 +186,13 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   if (d->variant != AGCN_SGC_LL && !reslap) return;
   static const int res_coop = [] { const char* e = std::getenv("AGCN_RESLAP_COOP"); return e ? std::atoi(e) : 3; }();   // bit 0 forward, bit 1 backward
   if (reslap && !((res_coop >> (backward ? 1 : 0)) & 1)) return;
-  if (fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 || fs.spec_small_first < B || (agcn_get_spec_mode() & 4) == 0)
+  if (fs.mode != 1 || !fs.spec_fwd || !fs.spec_bwd || fs.spec_bwd_first != 0 || fs.spec_small_first < B || (knob_spec_mode() & 4) == 0)
     return;
   if (d->mode != AGCN_MODE_PAPER && backward) {
     // reference mode: members only for the graphs no single workgroup can hold (coop_reach: the fs.coop_forced leading ones)
     int s = 0;
     for (int k = 0; k < fs.coop_forced && k < B - 1; ++k) s += (host.n[host.order[k]] + AGCN_SLAB_ROWS - 1) / AGCN_SLAB_ROWS;
-    if (fs.coop_forced > 0 && fs.coop_forced < B && s <= std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members())) {
+    if (fs.coop_forced > 0 && fs.coop_forced < B && s <= std::min((int)spec::COOP_MAX_MEMBERS, (int)knob_coop_members())) {
       *graphs = fs.coop_forced; *slabs = s;
     }
     return;
@@ -205,7 +205,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
   static const int min_force = [] { const char* e = std::getenv("AGCN_COOP_MIN_N"); return e ? std::atoi(e) : 0; }();
   // CU count of the CURRENT device (the thresholds below rest on "members fit the chip")
   const int n_cus = current_device_info().n_cus;
-  const int member_budget = std::min((int)spec::COOP_MAX_MEMBERS, (int)agcn_get_coop_members());
+  const int member_budget = std::min((int)spec::COOP_MAX_MEMBERS, (int)knob_coop_members());
   // (with two and more rounds of workgroups per CU the tail graph matters less than the extra workgroups cost:
   //  512 graphs: 6.0 M graphs/s without, 5.7 M with members for its one 70-node graph)
   static const int dual_on = [] { const char* e = std::getenv("AGCN_DUAL"); return e ? std::atoi(e) : 1; }();
@@ -264,7 +264,7 @@ void coop_plan(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& f
 // (Reference mode: the backward spreads exactly these graphs -- its plain workgroups have no n x n work worth spreading.)
 void coop_reach(FusedSplit* f, const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host, size_t lim) {
   const AgcnPlanInfo& pi = host.info;
-  if (agcn_get_fused_mode() == 0 || (agcn_get_spec_mode() & 7) != 7 ||
+  if (knob_fused_mode() == 0 || (knob_spec_mode() & 7) != 7 ||
       (d->variant != AGCN_SGC_LL && d->variant != AGCN_SGC_LL_RESLAP)) return;
   if (!spec_supported(d->Fin, d->Fout, d->K, d->variant) || pi.tile_elems >= (1ll << 31)) return;
   if (pi.rows != pi.N1 || (g->L0_rowptr != nullptr) == (g->L0_dense != nullptr) || pi.B >= 1024 || pi.B < 2) return;
@@ -301,7 +301,7 @@ FusedSplit fused_split(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const Pl
 FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, const PlanView& host) {
   FusedSplit f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const AgcnPlanInfo& pi = host.info;
-  if (agcn_get_fused_mode() == 0) return f;
+  if (knob_fused_mode() == 0) return f;
   if (!(d->K == 2 && pi.rows == pi.N1 && (g->L0_rowptr != nullptr) != (g->L0_dense != nullptr))) return f;
   size_t lim = (size_t)agcn_get_lds_limit();
   if (lim > 160 * 1024) lim = 160 * 1024;
@@ -317,7 +317,7 @@ FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
     *slabs = ns;
     return nb;
   };
-  const int force_gb = agcn_get_fused_global_b();
+  const int force_gb = knob_fused_gb();
   int ns = 0;
   int nb = count_big(lim, &ns);
   const bool gb_fits = std::max(fused_lds_bytes_gb(pi.max_n, d->Fin, d->Fout, d->K),
@@ -347,11 +347,11 @@ FusedSplit fused_split_general(const AgcnLayerDesc* d, const AgcnGraphBatch* g, 
   // all-slab 117 us/step, mixed 144 us/step -- the side chain of four dependent launches is longer than
   // the fused kernel it runs beside, so mixed dispatch is opt-in (agcn_set_fused_mode(2)) and the whole
   // batch takes the slab path by default.
-  if (agcn_get_fused_mode() < 2) return f;
+  if (knob_fused_mode() < 2) return f;
   if (nb == pi.B) return f;
   // Big graphs whose tile still fits LDS run one workgroup each on the per-graph kernels (3 + 3 launches on the
   // side stream, any free CU); no co-residency with the fused workgroups is needed.
-  if (agcn_get_fused_mode() == 2) {
+  if (knob_fused_mode() == 2) {
     const int maxn = host.n[host.order[0]];
     if (std::max(sgc_lds_bytes(maxn, d->Fin), sgc_lds_bytes_bwd(maxn, d->Fin)) <= lim) {
       f.mode = 2; f.n_big = nb; f.n_big_slabs = 0; f.thr = host.n[host.order[nb]]; f.big_pg = 1;
@@ -500,7 +500,7 @@ static bool bf16_served(const AgcnLayerDesc* d, const PlanView& host, const Fuse
 // whole batch in ONE 16-wave launch (no general fused kernel in front, no 8-wave launch beside it), units within the header.
 // agcn_set_spec_tail(0) / AGCN_SPEC_TAIL=0 keeps the separate parameter-gradient kernel (A/B measurements).
 static bool spec_tail_ok(const AgcnLayerDesc* d, const PlanView& host, const FusedSplit& fs, int coop_graphs, int coop_slabs) {
-  if (!agcn_get_spec_tail() || fs.mode != 1 || !fs.spec_bwd || d->variant != AGCN_SGC_LL || d->mode != AGCN_MODE_PAPER || d->K != 2) return false;
+  if (!knob_spec_tail() || fs.mode != 1 || !fs.spec_bwd || d->variant != AGCN_SGC_LL || d->mode != AGCN_MODE_PAPER || d->K != 2) return false;
   const int B = host.info.B;
   if (fs.spec_bwd_first != 0 || std::max(fs.spec_bwd_first, fs.spec_small_first) < B) return false;
   return coop_slabs + (B - coop_graphs) <= spec::TAIL_MAX_UNITS &&
@@ -515,6 +515,7 @@ static int spec_tail_ksteps(const PlanView& host, int coop_graphs, int coop_slab
 }
 
 extern "C" int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   const char* who = "agcn_sgc_ll_dispatch_info";
   int rc = check_desc(desc, who);
   if (rc != AGCN_OK) return rc;
@@ -583,6 +584,7 @@ extern "C" int agcn_device_status(int32_t device, void* hip_stream, int32_t* tim
 }
 
 extern "C" size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   AgcnPlanInfo pi;
   if (check_desc(desc, "agcn_sgc_ll_reserve_bytes") != AGCN_OK || agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;
   return reserve_layout(desc, pi).total + 256;
@@ -600,10 +602,10 @@ static bool cloud_candidate(const AgcnLayerDesc* d, const AgcnGraphBatch* g, con
   if (d->variant == AGCN_SGC_LL && use_slabs(d, g, pi)) return true;
   // (the general slab kernels' LDS plan may not fit a 128-feature layer: the point-cloud kernels do not depend on it)
   if (d->variant == AGCN_SGC_LL)
-    return agcn_get_slab_mode() != 0 && d->K == 2 && pi.rows == pi.N1 && g->L0_dense != nullptr && g->L0_rowptr == nullptr &&
+    return knob_slab_mode() != 0 && d->K == 2 && pi.rows == pi.N1 && g->L0_dense != nullptr && g->L0_rowptr == nullptr &&
            g->L0_symmetric == 1;
   // (the Reslap kernels add a graph's per-strip partial sums with one lane per 64-row strip: graphs of up to 4096 nodes)
-  return agcn_get_slab_mode() != 0 && d->variant == AGCN_SGC_LL_RESLAP && d->K == 2 && pi.rows == pi.N1 && pi.max_n <= 4096 &&
+  return knob_slab_mode() != 0 && d->variant == AGCN_SGC_LL_RESLAP && d->K == 2 && pi.rows == pi.N1 && pi.max_n <= 4096 &&
          g->L0_dense != nullptr && g->L0_rowptr == nullptr && g->L0_symmetric == 1 &&
          (g->L_prev == nullptr || g->L_prev_symmetric == 1);
 }
@@ -621,6 +623,7 @@ static size_t global_scratch_floats(const AgcnLayerDesc* d, const PlanView& host
 }
 
 extern "C" size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   PlanView host;
   if (check_desc(desc, "agcn_sgc_ll_forward_workspace_bytes") != AGCN_OK ||
       plan_view(plan_host, plan_host, &host) != AGCN_OK) return 0;
@@ -657,7 +660,8 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
     w->spart = c.take((size_t)8 * ((size_t)pi.n_slabs / 4 + 8));
   }
   // ... 128 features: the P = g_1 X_0^T tile for the element-wise passes behind its writer (Reslap: pass B; SGC_LL: backward 1 by parts)
-  w->P = (cloud_shape(d) && d->Fin == 128 && (d->variant == AGCN_SGC_LL_RESLAP || paper)) ? c.take((size_t)pi.tile_elems) : nullptr;
+  // (paper mode only: in reference mode no pass reads it -- the launchers pass ws_P = nullptr there)
+  w->P = (cloud_shape(d) && d->Fin == 128 && paper) ? c.take((size_t)pi.tile_elems) : nullptr;
   w->n_chunks = n_chunks_for(pi.rows);
   w->part_stride = (int64_t)d->K * d->Fin * d->Fout + d->Fout + (paper ? (int64_t)d->Fin * d->Fin : 0);
   w->part_stride = (w->part_stride + 3) / 4 * 4;
@@ -672,6 +676,7 @@ static size_t carve_bwd(const AgcnLayerDesc* d, const PlanView& host, void* ws, 
 }
 
 extern "C" size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   PlanView host;
   if (check_desc(desc, "agcn_sgc_ll_backward_workspace_bytes") != AGCN_OK ||
       plan_view(plan_host, plan_host, &host) != AGCN_OK) return 0;
@@ -683,6 +688,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
                                    const AgcnParams* params, const AgcnOutputs* out, void* reserve,
                                    size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                                    void* hip_stream) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   const char* who = "agcn_sgc_ll_forward";
   int rc = check_desc(desc, who);
   if (rc != AGCN_OK) return rc;
@@ -740,7 +746,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
       // chip idle behind its longest graph, so it goes to a side stream and the two launches overlap (they touch
       // disjoint graphs; the transposed parameter copies are written by the block of the last graph only).
       const int B = host.info.B, ss = fs.spec_small_first;
-      const bool two = ss > 0 && ss < B, conc = two && agcn_get_spec_small() >= 2;
+      const bool two = ss > 0 && ss < B, conc = two && knob_spec_small() >= 2;
       hipStream_t main_s = static_cast<hipStream_t>(hip_stream);
       SideStream* side = nullptr;
       std::unique_lock<std::mutex> side_lock;
@@ -1078,7 +1084,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
                                    fs.gb_bwd_w != 0, fs.gb_bwd_m != 0, hip_stream);
       if (rc != AGCN_OK) return rc;
       const int ss = std::max(sf, fs.spec_small_first);
-      const bool two = ss > sf && ss < B, conc = two && sf == 0 && agcn_get_spec_small() >= 2 && fs.mode == 1;
+      const bool two = ss > sf && ss < B, conc = two && sf == 0 && knob_spec_small() >= 2 && fs.mode == 1;
       // one launch for every graph: the largest graphs are spread over one workgroup per 16-row tile (members: the
       // leading slabs of the slab table, which is in the same largest-first order), spec_backward_coop.h
       const int first_plain = coop_graphs;
@@ -1266,6 +1272,7 @@ extern "C" int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBa
                                     const float* dL_sum, const AgcnGrads* grads, const void* reserve,
                                     size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                                     void* hip_stream) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
                        workspace_bytes, hip_stream, 3, "agcn_sgc_ll_backward");
 }
@@ -1275,6 +1282,7 @@ extern "C" int agcn_sgc_ll_backward_nodes(const AgcnLayerDesc* desc, const AgcnG
                                           const float* dL_sum, const AgcnGrads* grads, const void* reserve,
                                           size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                                           void* hip_stream) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
                        workspace_bytes, hip_stream, 1, "agcn_sgc_ll_backward_nodes");
 }
@@ -1284,6 +1292,7 @@ extern "C" int agcn_sgc_ll_backward_params(const AgcnLayerDesc* desc, const Agcn
                                            const float* dL_sum, const AgcnGrads* grads, const void* reserve,
                                            size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                                            void* hip_stream) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
                        workspace_bytes, hip_stream, 2, "agcn_sgc_ll_backward_params");
 }

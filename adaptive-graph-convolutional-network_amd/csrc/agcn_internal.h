@@ -20,6 +20,27 @@ namespace agcn {
 
 int fail(int code, const char* fmt, ...);
 
+// Dispatch knobs as THIS call sees them: the per-call flags of its descriptor (AgcnLayerDesc.flags / AgcnDenseDesc.flags) where a
+// field is set, the process default (environment / agcn_set_*) otherwise.  A KnobScope lives on the stack of every entry point
+// that takes a descriptor; the override is thread-local, so concurrent calls with different flags do not see each other.
+struct KnobScope {
+  explicit KnobScope(uint32_t flags);
+  ~KnobScope();
+  KnobScope(const KnobScope&) = delete;
+  KnobScope& operator=(const KnobScope&) = delete;
+ private:
+  uint32_t prev_;
+};
+int32_t knob_spec_mode();
+int32_t knob_fused_mode();
+int32_t knob_pg_onepass();
+int32_t knob_spec_small();
+int32_t knob_rows_split();
+int32_t knob_slab_mode();
+int32_t knob_fused_gb();
+int32_t knob_spec_tail();
+int32_t knob_coop_members();
+
 // Leading dimensions of on-chip images, chosen so that MFMA fragment reads are LDS
 // bank-conflict free:
 //  * an image read as the A operand (lane (r, q) reads [row0 + r][k0 + q]) -- or, transposed,

@@ -19,6 +19,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // two floats -> their three bf16 pieces, packed (low half = x0)
+// Non-finite and near-maximum inputs (documented in include/agcn.h, agcn_set_rows_split): h = bf16(x) rounds to infinity for |x| within
+// half a bf16 ulp of the bf16 maximum, x - h is then -inf (NaN for x = inf), and the products of that row come out NaN where the
+// fp32-MFMA kernels would propagate the infinity.  Guarding it (r = isfinite(h) ? x - h : 0) costs two vector instructions per pair
+// on the critical path of every split; finite results are identical either way, so the kernels do not pay for it.
 __device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
   const bf16x2 hv = (bf16x2){(__bf16)x0, (__bf16)x1};
   h = __builtin_bit_cast(uint32_t, hv);

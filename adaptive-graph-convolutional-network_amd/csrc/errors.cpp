@@ -103,6 +103,23 @@ extern "C" void agcn_set_lds_limit(int32_t bytes) {
 }
 
 namespace agcn {
+namespace {
+thread_local uint32_t t_flags = 0;   // the flags of the call this thread is inside (0: none / nothing overridden)
+inline int32_t field(int shift, uint32_t mask) { return (int32_t)((t_flags >> shift) & mask); }
+}  // namespace
+KnobScope::KnobScope(uint32_t flags) : prev_(t_flags) { t_flags = flags; }
+KnobScope::~KnobScope() { t_flags = prev_; }
+static inline int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+int32_t knob_spec_mode() { const int32_t f = field(0, 15u); return f ? clampi(f - 1, 0, 7) : g_spec_mode.load(); }
+int32_t knob_fused_mode() { const int32_t f = field(4, 7u); return f ? clampi(f - 1, 0, 3) : g_fused_mode.load(); }
+int32_t knob_pg_onepass() { const int32_t f = field(7, 3u); return f ? clampi(f - 1, 0, 2) : g_pg_onepass.load(); }
+int32_t knob_spec_small() { const int32_t f = field(9, 3u); return f ? clampi(f - 1, 0, 2) : g_spec_small.load(); }
+int32_t knob_rows_split() { const int32_t f = field(11, 3u); return f ? clampi(f - 1, 0, 1) : g_rows_split.load(); }
+int32_t knob_slab_mode() { const int32_t f = field(13, 3u); return f ? clampi(f - 1, 0, 1) : g_slab_mode.load(); }
+int32_t knob_fused_gb() { const int32_t f = field(15, 3u); return f ? clampi(f - 2, -1, 1) : g_fused_gb.load(); }
+int32_t knob_spec_tail() { const int32_t f = field(17, 3u); return f ? clampi(f - 1, 0, 1) : g_spec_tail.load(); }
+int32_t knob_coop_members() { const int32_t f = field(24, 255u); return f ? clampi(f - 1, 0, 120) : g_coop_members.load(); }
+
 // One workgroup per graph: with few graphs per CU, 16 waves per graph hide the memory latency of
 // the bulk loads and spread the MFMA tiles; with many graphs per CU the CU is full anyway.
 int graph_threads(int32_t n_graphs) {

@@ -468,7 +468,7 @@ void pg_split(int rows, int nt, int* rows_per_wave, int* S) {
   *rows_per_wave = rpw;
   *S = std::max(1, (rows + 16 * rpw - 1) / (16 * rpw));
 }
-int pg_mode() { return agcn_get_param_grad_onepass(); }
+int pg_mode() { return knob_pg_onepass(); }
 }  // namespace
 
 // the tagged hand-off serves the batches below 8k rows: 16-row tiles, eight or sixteen row splits (split % 8 = its XCD) of 16 waves

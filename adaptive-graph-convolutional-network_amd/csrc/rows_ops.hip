@@ -33,8 +33,9 @@ void fill_rows_dense(RowsGemmArgs& g, const AgcnDenseDesc* d, const PlanView& ho
 
 struct DenseWs { float *Gp, *part, *dbias, *img; int n_chunks; int64_t part_stride; size_t part_floats; };
 // packed rows (no pad rows) at point-cloud row counts: the products may run on the split-bf16 row kernels (rows_split.hip)
+// (the addend's stride is tested by the forward itself, and only when the call HAS an addend)
 bool dense_split(const AgcnDenseDesc* d, const AgcnPlanInfo& pi) {
-  return pi.rows == pi.N1 && rows_split_dense_ok(pi.rows, d->Fin, d->Fout, d->ldx, d->ldy, d->ldadd);
+  return pi.rows == pi.N1 && rows_split_dense_ok(pi.rows, d->Fin, d->Fout, d->ldx, d->ldy, 0);
 }
 size_t carve_dense(const AgcnDenseDesc* d, const AgcnPlanInfo& pi, void* ws, bool need_gp, DenseWs* w) {
   char* base = static_cast<char*>(ws);
@@ -165,6 +166,7 @@ extern "C" int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const v
 }
 
 extern "C" size_t agcn_rows_dense_forward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   AgcnPlanInfo pi;
   if (check_dense(desc, "agcn_rows_dense_forward_workspace_bytes") != AGCN_OK || agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;
   return dense_split(desc, pi) ? rows_split_dense_image_bytes(desc->Fin, desc->Fout) + 256 : 0;
@@ -174,6 +176,7 @@ extern "C" int agcn_rows_dense_scaled_forward_ws(const AgcnDenseDesc* desc, cons
                                                  const void* plan_dev, const float* X, const float* W,
                                                  const float* scale, const float* bias, const float* Add, float* Y,
                                                  void* workspace, size_t workspace_bytes, void* hip_stream) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   const char* who = "agcn_rows_dense_forward";
   int rc = check_dense(desc, who);
   if (rc != AGCN_OK) return rc;
@@ -186,7 +189,7 @@ extern "C" int agcn_rows_dense_scaled_forward_ws(const AgcnDenseDesc* desc, cons
   // point-cloud row counts, packed rows, a workspace for the parameter image: the bf16 matrix pipe at fp32 accuracy (rows_split.hip)
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (workspace != nullptr && dense_split(desc, host.info) && workspace_bytes >= rows_split_dense_image_bytes(desc->Fin, desc->Fout) &&
-      al16(X) && al16(Y) && al16(workspace) && (!bias || al16(bias)) && (!Add || al16(Add)))
+      al16(X) && al16(Y) && al16(workspace) && (!bias || al16(bias)) && (!Add || (al16(Add) && (desc->ldadd & 3) == 0)))
     return launch_rows_split_dense_fwd(X, desc->ldx, W, scale, bias, Add, desc->ldadd, desc->activation == AGCN_ACT_RELU ? 1 : 0, Y, desc->ldy,
                                        desc->Fin, desc->Fout, host.info.rows, workspace, hip_stream);
   RowsGemmArgs g;
@@ -198,6 +201,7 @@ extern "C" int agcn_rows_dense_scaled_forward_ws(const AgcnDenseDesc* desc, cons
 }
 
 extern "C" size_t agcn_rows_dense_backward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   AgcnPlanInfo pi;
   if (check_dense(desc, "agcn_rows_dense_backward_workspace_bytes") != AGCN_OK ||
       agcn_plan_info(plan_host, &pi) != AGCN_OK) return 0;
@@ -220,6 +224,7 @@ extern "C" int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const 
                                                const float* scale, const float* Y, const float* dY, float* dX,
                                                float* dAdd, float* dW, float* dbias, float* dscale,
                                                void* workspace, size_t workspace_bytes, void* hip_stream) {
+  KnobScope knobs(desc ? desc->flags : 0u);
   const char* who = "agcn_rows_dense_backward";
   if ((scale == nullptr) != (dscale == nullptr))
     return fail(AGCN_EINVAL, "%s: scale and dscale go together", who);

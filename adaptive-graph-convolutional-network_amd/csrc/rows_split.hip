@@ -418,7 +418,7 @@ __global__ __launch_bounds__(PT) void rs_param_kernel(ParamGradArgs a) {
   else rs_param_body<FIN, FIN>(a, a.X, a.ldx, a.dZ, FIN, out + (int64_t)2 * FIN * FOUT + FOUT, FIN, 0, nullptr, lds);
 }
 
-bool rs_env() { return agcn_get_rows_split() != 0; }
+bool rs_env() { return knob_rows_split() != 0; }
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int KB, int NT, int NCB, int MODE>
@@ -536,9 +536,19 @@ int launch_rows_split_project_bwd(const float* dZ, float* dX, int ldx, int Fin, 
 // ---- the dense layers next to the convolutions (DenseMol, BlockEnd, the terms of DenseBlockEnd: rows_ops.hip) at point-cloud row counts:
 // Y = act([scale] A W [+ bias] [+ Add]) and the adjoint dX = [scale] (dY act'(Y)) W^T with Gp = dY act'(Y) stored for the parameter
 // gradients.  One parameter image per call (W, or W^T as strides of the split) in the caller's workspace.
+// (ldadd: the addend's row stride, or 0 when the call has no addend -- an unused stride must not cost the fast path)
 bool rows_split_dense_ok(int rows, int Fin, int Fout, int ldx, int ldy, int ldadd) {
   auto w = [](int f) { return f == 64 || f == 128 || f == 256; };
-  static const int min_rows = [] { const char* e = std::getenv("AGCN_ROWS_SPLIT_DENSE_MIN"); return e ? std::atoi(e) : 8192; }();
+  // AGCN_ROWS_SPLIT_DENSE_MIN (include/agcn.h, environment section): fewest packed rows at which the dense layers take these
+  // kernels; a workgroup owns 128 rows, so anything below 128 (or unparsable) is clamped to 128
+  static const int min_rows = [] {
+    const char* e = std::getenv("AGCN_ROWS_SPLIT_DENSE_MIN");
+    if (!e) return 8192;
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    if (end == e || v < 128) return 128;
+    return v > (1 << 30) ? (1 << 30) : (int)v;
+  }();
   return rs_env() && rows >= min_rows && w(Fin) && w(Fout) && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldadd & 3) == 0;
 }
 size_t rows_split_dense_image_bytes(int Fin, int Fout) { return 16 * img_units(Fin, Fout); }

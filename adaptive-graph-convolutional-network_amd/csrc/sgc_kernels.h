@@ -100,8 +100,9 @@ struct SgcArgs {
   int32_t foff, fstride, half_acc, half_last;
   // backward: workspace for the parameter images of the split-bf16 packed-row kernels (rows_split.hip), or nullptr
   void* rs_img;
-  // SGC_LL_Reslap, 128 features, point-cloud kernels: P = g_1 X_0^T [tile_elems] written by pass A (both halves in one run) for the
-  // element-wise pass B and part 2 of pass C, or nullptr (those passes then form the product themselves, once per half)
+  // 128 features, point-cloud kernels, paper mode: P = g_1 X_0^T [tile_elems] over all 128 features -- SGC_LL_Reslap: written by
+  // part 2 of pass C (which runs first), read element-wise by pass B; SGC_LL: written by part 1 of backward 1, read by its part 2 --
+  // or nullptr (those passes then form the product themselves, once per 64-column half)
   float* ws_P;
 };
 

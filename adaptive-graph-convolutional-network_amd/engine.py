@@ -12,11 +12,29 @@ import numpy as np
 import torch
 
 from . import _ffi
+from . import functional as _fn
 from .functional import _Cfg, _desc, _gbatch, _ptr
 
 
+def _reserve_timeouts(lib, reserve, nbytes, stream, device):
+    """(count, message) of agcn_sgc_ll_reserve_status: waits for `stream`; count = cooperative waits that ran out."""
+    n = C.c_int32(0)
+    with torch.cuda.device(device):
+        rc = lib.agcn_sgc_ll_reserve_status(reserve.data_ptr(), int(nbytes), stream, C.byref(n))
+    if rc != 0 and n.value == 0:
+        _ffi.check(rc)
+    return n.value, (lib.agcn_last_error().decode() if rc != 0 else "")
+
+
+def _no_member_desc(d):
+    return _ffi.LayerDesc(d.Fin, d.Fout, d.K, d.mode, d.variant, d.activation, d.ldx, d.ldy, d.feat_dtype,
+                          _fn.no_member_flags(d.flags))
+
+
 class SgcLLStep(object):
-    def __init__(self, layer, batch, X=None, L_prev=None, dY=None, dL_sum=None, L_prev_symmetric=False):
+    def __init__(self, layer, batch, X=None, L_prev=None, dY=None, dL_sum=None, L_prev_symmetric=False, flags=None):
+        """`flags`: per-call dispatch flags of every call of this step (default: the constructing thread's current ones,
+        `agcn_amd.dispatch`)."""
         lib = _ffi.lib()
         self.lib, self.layer, self.batch = lib, layer, batch
         plan = batch.plan
@@ -39,7 +57,8 @@ class SgcLLStep(object):
         # Every buffer of the step is carved out of ONE allocation (256-byte aligned pieces): the kernels then touch
         # a handful of contiguous 2 MB pages instead of a dozen scattered ones (address-translation misses at the
         # start of each kernel were a measurable part of its first load phase)
-        self.desc = _desc(cfg, ldx, ldy)
+        self.desc = _desc(cfg, ldx, ldy, flags)
+        self.recovered = 0
         self.rbytes = lib.agcn_sgc_ll_reserve_bytes(C.byref(self.desc), plan.host_ptr)
         self.wf = lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
         self.wb = lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(self.desc), plan.host_ptr)
@@ -157,11 +176,42 @@ class SgcLLStep(object):
     def replay(self):
         self._graph.replay()
 
-    def check(self):
-        """Waits for the current stream and raises AgcnError if a wait between the workgroups that share a large graph ran
-        out in any step of this object (include/agcn.h: agcn_sgc_ll_reserve_status).  Call it where the host synchronises
-        anyway."""
-        return _ffi.reserve_status(self.reserve)
+    def check(self, recover=False):
+        """Waits for the current stream.  If a wait between the workgroups that share a large graph ran out in any step of this
+        object since the last check (include/agcn.h: agcn_sgc_ll_reserve_status; the step's results are NaN): raises AgcnError,
+        or -- `recover=True` -- RE-ISSUES the step on the non-member dispatch (fresh launches of the kernels in which no
+        workgroup waits for another, per-call flags; same inputs, same output buffers), counts it in `self.recovered` /
+        `agcn_amd.recovered_calls` and returns the number of waits that had run out.  Returns 0 when nothing happened.
+        Call it where the host synchronises anyway."""
+        n, msg = _reserve_timeouts(self.lib, self.reserve, self.rbytes, self._stream(), self.device)
+        if n == 0:
+            return 0
+        self.reserve[:_ffi.RESERVE_HEADER_BYTES].zero_()     # re-arms the header (exchange words + the sticky count)
+        if not recover:
+            raise _ffi.AgcnError("agcn error -3: %s" % msg)
+        self._rerun_without_members()
+        return n
+
+    def _rerun_without_members(self):
+        lib, plan = self.lib, self.batch.plan
+        desc = _no_member_desc(self.desc)
+        rb = lib.agcn_sgc_ll_reserve_bytes(C.byref(desc), plan.host_ptr)
+        wb = max(lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(desc), plan.host_ptr),
+                 lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(desc), plan.host_ptr))
+        with torch.cuda.device(self.device):
+            reserve = torch.zeros(int(rb), dtype=torch.uint8, device=self.device)
+            ws = torch.empty(int(wb), dtype=torch.uint8, device=self.device)
+            st = self._stream()
+            _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(self.gb), C.byref(self.pr), C.byref(self.out),
+                                               reserve.data_ptr(), rb, ws.data_ptr(), wb, st))
+            _ffi.check(lib.agcn_sgc_ll_backward(C.byref(desc), C.byref(self.gb), C.byref(self.pr), C.byref(self.out),
+                                                self.dY.data_ptr(), _ptr(self.dL_sum), C.byref(self.gr), reserve.data_ptr(), rb,
+                                                ws.data_ptr(), wb, st))
+            n, msg = _reserve_timeouts(lib, reserve, rb, st, self.device)
+        if n:
+            raise _ffi.AgcnError("a cooperative wait ran out on the non-member dispatch (which has none): %s" % msg)
+        self.recovered += 1
+        _fn.recovered_calls[0] += 1
 
 
 class SgcLLEpochStep(object):
@@ -177,7 +227,7 @@ class SgcLLEpochStep(object):
             ep.step(gb, dY=None)           # dY: [rows, Fout] upstream gradient (default: the static ones-filled one)
     """
 
-    def __init__(self, layer, rows_cap, tiles_cap, batch_cap, device=None):
+    def __init__(self, layer, rows_cap, tiles_cap, batch_cap, device=None, flags=None):
         lib = _ffi.lib()
         self.lib, self.layer = lib, layer
         dev = torch.device(device if device is not None else layer._device)
@@ -206,7 +256,9 @@ class SgcLLEpochStep(object):
         for k, n in sizes:
             self.grads[k] = self.bucket[o:o + n].view(v[k].shape)
             o += n
-        self.desc = _desc(cfg, cfg.Fin, cfg.Fout)
+        self.desc = _desc(cfg, cfg.Fin, cfg.Fout, flags)
+        self.recovered = 0
+        self._last_ids = None
         self.pr = _ffi.Params(v["weight"].data_ptr(), v["bias"].data_ptr(), v["M_L"].data_ptr(),
                               v["alpha"].data_ptr(), None)
         self.out = _ffi.Outputs(self._Y.data_ptr(), self._res_L.data_ptr(), self._res_W.data_ptr(), None)
@@ -261,6 +313,7 @@ class SgcLLEpochStep(object):
         self.plan, self.batch = plan, batch       # (keeps the batch's device tensors alive until the next step)
         self._rows, self._tile_elems = plan.rows, plan.tile_elems
         self._stream = stream
+        self._last = ("batch", batch, dY)
         return self
 
     def step_ids(self, rstore, graph_ids, lane=0, dY=None, stream=None):
@@ -316,6 +369,7 @@ class SgcLLEpochStep(object):
         self._rows, self._tile_elems = int(info.plan.rows), int(info.plan.tile_elems)
         self.plan = self.batch = None
         self._stream = st
+        self._last = ("ids", rstore, ids, lane, dY, sl, ev)
         return self
 
     def _retry_ids(self, rstore, ids, lane, dY, sl, ev, st):
@@ -331,16 +385,67 @@ class SgcLLEpochStep(object):
         self._rows, self._tile_elems = int(self._einfo.plan.rows), int(self._einfo.plan.tile_elems)
         self.plan = self.batch = None
         self._stream = st
+        self._last = ("ids", rstore, ids, lane, dY, sl, ev)
         return self
 
-    def check(self):
-        """Waits for the stream of the last step and raises AgcnError if a cooperative wait ran out in any step since the
-        reserve was (re)allocated (include/agcn.h: agcn_sgc_ll_reserve_status)."""
-        n = C.c_int32(0)
+    def check(self, recover=False):
+        """Waits for the stream of the last step.  If a cooperative wait ran out in any step since the last check (include/agcn.h:
+        agcn_sgc_ll_reserve_status): raises AgcnError, or -- `recover=True` -- re-issues THE LAST batch on the non-member dispatch
+        (its inputs are still staged; fresh launches, per-call flags), counts it (`self.recovered`, `agcn_amd.recovered_calls`)
+        and returns the number of waits that had run out.  Batches before the last one cannot be re-run from here: check after
+        every batch whose results matter.  Returns 0 when nothing happened."""
+        st = getattr(self, "_stream", None) or torch.cuda.current_stream(self.device).cuda_stream
+        n, msg = _reserve_timeouts(self.lib, self._reserve, self._reserve.numel(), st, self.device)
+        if n == 0:
+            return 0
+        self._reserve[:_ffi.RESERVE_HEADER_BYTES].zero_()     # re-arms the header (exchange words + the sticky count)
+        if not recover or getattr(self, "_last", None) is None:
+            raise _ffi.AgcnError("agcn error -3: %s" % msg)
+        self._rerun_without_members(st)
+        return n
+
+    def _rerun_without_members(self, st):
+        lib, desc = self.lib, _no_member_desc(self.desc)
+        last = self._last
         with torch.cuda.device(self.device):
-            st = getattr(self, "_stream", None) or torch.cuda.current_stream(self.device).cuda_stream
-            _ffi.check(self.lib.agcn_sgc_ll_reserve_status(self._reserve.data_ptr(), self._reserve.numel(), st, C.byref(n)))
-        return n.value
+            if last[0] == "batch":
+                _, batch, dY = last
+                hp = batch.plan.host_ptr
+                rb = lib.agcn_sgc_ll_reserve_bytes(C.byref(desc), hp)
+                wb = max(lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(desc), hp),
+                         lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(desc), hp))
+                reserve = torch.zeros(int(rb), dtype=torch.uint8, device=self.device)
+                ws = torch.empty(int(wb), dtype=torch.uint8, device=self.device)
+                gb = _gbatch(batch, batch.X, None)
+                d, p, o = C.byref(desc), C.byref(self.pr), C.byref(self.out)
+                _ffi.check(lib.agcn_sgc_ll_forward(d, C.byref(gb), p, o, reserve.data_ptr(), rb, ws.data_ptr(), wb, st))
+                _ffi.check(lib.agcn_sgc_ll_backward(d, C.byref(gb), p, o, (self._dY if dY is None else dY).data_ptr(), None,
+                                                    C.byref(self.gr), reserve.data_ptr(), rb, ws.data_ptr(), wb, st))
+            else:
+                _, rstore, ids, lane, dY, sl, ev = last
+                ln, g = rstore.lanes[lane], self.grads
+                reserve, ws = self._reserve, self._ws
+                for _ in range(2):       # (second round: the non-member kernels asked for more room)
+                    buf = _ffi.EpochBuffers(
+                        sl["ptr"], ln["stage"].data_ptr(), rstore.stage_cap, ln["X"].data_ptr(), ln["rowptr"].data_ptr(),
+                        ln["col"].data_ptr(), ln["val"].data_ptr(), rstore.rows_cap, rstore.nnz_cap, self.tiles_cap,
+                        self._Y.data_ptr(), self._res_L.data_ptr(), self._res_W.data_ptr(),
+                        (self._dY if dY is None else dY).data_ptr(), self._dX.data_ptr(), g["weight"].data_ptr(),
+                        g["bias"].data_ptr(), _ptr(g.get("M_L")), g["alpha"].data_ptr(),
+                        reserve.data_ptr(), reserve.numel(), ws.data_ptr(), ws.numel())
+                    rc = lib.agcn_epoch_step(C.byref(rstore._c), ids.ctypes.data, int(ids.size), C.byref(desc), C.byref(self.pr),
+                                             C.byref(buf), 0, C.byref(self._einfo), C.byref(self._eneeds), ev, st)
+                    if rc == -2 and self._eneeds.reserve_bytes:
+                        reserve = torch.zeros(int(self._eneeds.reserve_bytes), dtype=torch.uint8, device=self.device)
+                        ws = torch.zeros(max(int(self._eneeds.workspace_bytes), 256), dtype=torch.uint8, device=self.device)
+                        continue
+                    _ffi.check(rc)
+                    break
+            n, msg = _reserve_timeouts(lib, reserve, reserve.numel(), st, self.device)
+        if n:
+            raise _ffi.AgcnError("a cooperative wait ran out on the non-member dispatch (which has none): %s" % msg)
+        self.recovered += 1
+        _fn.recovered_calls[0] += 1
 
     # views of the current batch's results
     @property
@@ -401,42 +506,6 @@ def _overlapping_streams(device, k, candidates=12, spin=400000):
     return (chosen + [s for s in pool if s not in chosen])[:k]     # fewer independent queues than lanes
 
 
-class _MemberBudget(object):
-    """The process-wide member budget (include/agcn.h: agcn_set_coop_members) as lowered by the live SgcLLEpochLanes objects:
-    the knob is the minimum of the value found when the first override was taken and of every live override; it goes back
-    to that value when the last override is released -- whatever the order in which the objects close or are collected."""
-
-    def __init__(self):
-        import threading
-        self._lock = threading.Lock()
-        self._live = {}
-        self._base = None
-        self._next = 0
-
-    def _apply(self):
-        _ffi.lib().agcn_set_coop_members(min([self._base] + list(self._live.values())))
-
-    def acquire(self, members):
-        with self._lock:
-            if not self._live:
-                self._base = _ffi.lib().agcn_get_coop_members()
-            self._next += 1
-            self._live[self._next] = int(members)
-            self._apply()
-            return self._next
-
-    def release(self, token):
-        with self._lock:
-            if self._live.pop(token, None) is None:
-                return
-            self._apply()
-            if not self._live:
-                self._base = None
-
-
-_member_budget = _MemberBudget()
-
-
 class SgcLLEpochLanes(object):
     """`lanes` independent `SgcLLEpochStep`s, each on its own stream with its own buffers, fed round-robin from a
     `ResidentStore`: consecutive batches overlap on the GPU.  A step of one 256-graph batch is as long as the dependent
@@ -458,16 +527,17 @@ class SgcLLEpochLanes(object):
         if len(rstore.lanes) < lanes:
             raise ValueError("the resident store was built with %d lane(s)" % len(rstore.lanes))
         self.rstore, self.device = rstore, rstore.device
-        self.steps = [SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device)
-                      for _ in range(lanes)]
         # All member workgroups of the launches in flight must be resident together (csrc/spec_backward_coop.h): the
-        # library's budget of 120 per launch is sized for two concurrent launches; with more lanes it is divided
-        # (process-wide knob, include/agcn.h agcn_set_coop_members).
-        # The knob is process-wide: the previous value comes back with close() / the end of a `with` block / the object's
-        # death, so that step objects built later get the full budget again.
-        # Several lanes objects may be alive at once: the knob holds the MINIMUM over the live ones and the value found by the
-        # first comes back when the last one closes (_member_budget).
-        self._budget_token = _member_budget.acquire(240 // lanes) if lanes > 2 else None
+        # library's budget of 120 per launch is sized for two concurrent launches; with more lanes it is divided -- a PER-CALL
+        # flag of these lanes' calls (AGCN_FLAG_COOP_MEMBERS): nothing process-wide changes, step objects built elsewhere
+        # keep the full budget
+        flags = _fn.current_flags()
+        if lanes > 2:
+            have = ((flags >> 24) & 255) - 1 if (flags >> 24) & 255 else _ffi.lib().agcn_get_coop_members()
+            flags = _ffi.dispatch_flags(flags, coop_members=min(have, 240 // lanes))
+        self.member_budget = ((flags >> 24) & 255) - 1 if (flags >> 24) & 255 else None
+        self.steps = [SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device, flags=flags)
+                      for _ in range(lanes)]
         self.streams = _overlapping_streams(self.device, lanes)
         self._j = 0
         torch.cuda.synchronize(self.device)      # buffers, parameters and the store were filled on other streams
@@ -512,12 +582,9 @@ class SgcLLEpochLanes(object):
             raise errs[0]
 
     def close(self):
-        """Waits for the lanes and gives the cooperative-member budget back (only lanes > 2 lowered it)."""
-        if self._budget_token is not None:
-            for s in self.streams:
-                s.synchronize()
-            _member_budget.release(self._budget_token)
-            self._budget_token = None
+        """Waits for the lanes (kept for `with` blocks; there is no process-wide state to give back any more)."""
+        for s in self.streams:
+            s.synchronize()
 
     def __enter__(self):
         return self
@@ -532,13 +599,14 @@ class SgcLLEpochLanes(object):
         except Exception:
             pass
 
-    def synchronize(self, check=True):
-        """Waits for every lane and (check=True) raises AgcnError if a cooperative wait ran out on any of them."""
+    def synchronize(self, check=True, recover=False):
+        """Waits for every lane and (check=True) raises AgcnError if a cooperative wait ran out on any of them (recover=True:
+        each lane re-issues its LAST batch on the non-member dispatch instead, SgcLLEpochStep.check)."""
         for s in self.streams:
             s.synchronize()
         if check:
             for st in self.steps:
-                st.check()
+                st.check(recover=recover)
 
 
 class SgcLLEpochPipeline(object):

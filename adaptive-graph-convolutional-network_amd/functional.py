@@ -3,6 +3,7 @@ whole batch.  PyTorch is used for device memory, streams and autograd bookkeepin
 all arithmetic happens in the HIP library (there is no eager fallback)."""
 import ctypes as C
 import functools
+import threading
 
 import torch
 
@@ -133,9 +134,52 @@ class _Cfg(object):
         self.lsum = bool(lsum) or variant == "SGC_LL_Reslap"
 
 
-def _desc(cfg, ldx, ldy):
+# Per-call dispatch flags (include/agcn.h: AgcnLayerDesc.flags): which of the equivalent kernel paths serves the calls THIS
+# thread issues inside a `with dispatch(...)` block.  Nothing process-wide is touched; other threads keep their own flags.
+_tls = threading.local()
+
+
+def current_flags():
+    return getattr(_tls, "flags", 0)
+
+
+class dispatch(object):
+    """`with agcn_amd.dispatch(spec_mode=3):` -- the layer calls issued by this thread inside the block carry these per-call
+    dispatch overrides (names and values as the agcn_set_* functions of include/agcn.h: spec_mode, fused_mode, pg_onepass,
+    spec_small, rows_split, slab_mode, fused_gb, spec_tail, coop_members).  The backward of an autograd call uses the flags
+    its forward ran with, whichever thread runs it.  Step objects (SgcLLStep, ...) take the flags current at construction."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        self.prev = current_flags()
+        _tls.flags = _ffi.dispatch_flags(self.prev, **self.knobs)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.flags = self.prev
+        return False
+
+
+def no_member_flags(base=None):
+    """`base` (default: this thread's current flags) with the member workgroups switched off: every graph then runs in one
+    workgroup (or on the slab kernels) and no launch waits for another workgroup -- the dispatch a call is re-issued on
+    when a cooperative wait ran out."""
+    base = current_flags() if base is None else int(base)
+    sm = (base & 15) - 1 if (base & 15) else _ffi.lib().agcn_get_spec_mode()
+    return _ffi.dispatch_flags(base, spec_mode=sm & 3)
+
+
+# how many calls were re-issued on the non-member dispatch after a cooperative wait ran out (engine.*.check(recover=True),
+# functional.run_checked)
+recovered_calls = [0]
+
+
+def _desc(cfg, ldx, ldy, flags=None):
     return _ffi.LayerDesc(cfg.Fin, cfg.Fout, cfg.K, _ffi.MODE[cfg.mode], _ffi.VARIANT[cfg.variant],
-                          _ffi.ACT[cfg.activation], int(ldx), int(ldy), 1 if getattr(cfg, "bf16", False) else 0)
+                          _ffi.ACT[cfg.activation], int(ldx), int(ldy), 1 if getattr(cfg, "bf16", False) else 0,
+                          current_flags() if flags is None else int(flags))
 
 
 def _gbatch(batch, X, L_prev, prev_symmetric=False):
@@ -146,20 +190,22 @@ def _gbatch(batch, X, L_prev, prev_symmetric=False):
                            1 if (prev_symmetric and L_prev is not None) else 0, 0)
 
 
-def _sizes(plan, cfg, ldx, ldy):
+def _sizes(plan, cfg, ldx, ldy, flags=None):
     """(desc, reserve bytes, forward workspace bytes, backward workspace bytes) of a layer on a plan: three host-side
     FFI calls, cached on the plan (a plan is immutable)."""
     lib = _ffi.lib()
-    # the library's process-wide dispatch knobs change which kernels (and so which workspaces) a call takes
-    knobs = (lib.agcn_get_lds_limit(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(),
+    flags = current_flags() if flags is None else int(flags)
+    # the per-call flags and, where they leave a field alone, the process defaults change which kernels (and so which
+    # workspaces) a call takes
+    knobs = (flags, lib.agcn_get_lds_limit(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(),
              lib.agcn_get_fused_global_b(), lib.agcn_get_param_grad_onepass(), lib.agcn_get_spec_mode(),
-             lib.agcn_get_spec_small(), lib.agcn_get_spec_tail())
+             lib.agcn_get_spec_small(), lib.agcn_get_spec_tail(), lib.agcn_get_rows_split(), lib.agcn_get_coop_members())
     key = (cfg.Fin, cfg.Fout, cfg.K, cfg.mode, cfg.variant, cfg.activation, int(ldx), int(ldy), bool(cfg.bf16)) + knobs
     cache = plan.__dict__.setdefault("_size_cache", {})
     hit = cache.get(key)
     if hit is None:
         lib = _ffi.lib()
-        desc = _desc(cfg, ldx, ldy)
+        desc = _desc(cfg, ldx, ldy, flags)
         hit = (desc, lib.agcn_sgc_ll_reserve_bytes(C.byref(desc), plan.host_ptr),
                lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(desc), plan.host_ptr),
                lib.agcn_sgc_ll_backward_workspace_bytes(C.byref(desc), plan.host_ptr))
@@ -182,6 +228,38 @@ def _status_word(device):
         _ffi.check(_ffi.lib().agcn_set_device_status_word(idx, w.data_ptr()))
         _status_words[idx] = w
     return w
+
+
+def device_timeouts(clear=True):
+    """Synchronises the devices that ran SGC_LL autograd calls; returns how many cooperative waits ran out since the words
+    were last cleared (0: every result is good) and, by default, clears them."""
+    total = 0
+    for idx, w in list(_status_words.items()):
+        with torch.cuda.device(idx):
+            t = C.c_int32(0)
+            _ffi.lib().agcn_device_status(idx, torch.cuda.current_stream(idx).cuda_stream, C.byref(t))
+            if t.value and clear:
+                w.zero_()
+            total += int(t.value)
+    return total
+
+
+def run_checked(fn):
+    """A step that cannot be lost: runs `fn()` (the calls of one training / evaluation step on this thread: forward, loss,
+    backward -- it must be re-runnable: same inputs, gradients zeroed or overwritten inside), synchronises, and if a wait between
+    the workgroups that share a large graph ran out anywhere in it -- results NaN, include/agcn.h: agcn_device_status --
+    RE-ISSUES the same calls on the non-member dispatch (fresh launches, per-call flags: no workgroup of those kernels waits
+    for another) and returns that run's result.  `recovered_calls[0]` counts such re-runs."""
+    device_timeouts()           # (whatever an earlier, unchecked step left behind is not this step's)
+    out = fn()
+    if device_timeouts() == 0:
+        return out
+    with dispatch(spec_mode=(no_member_flags() & 15) - 1):
+        out = fn()
+    recovered_calls[0] += 1
+    if device_timeouts() != 0:
+        raise _ffi.AgcnError("a cooperative wait ran out on the non-member dispatch (which has none): device fault")
+    return out
 
 
 def check_device_status():
@@ -346,7 +424,8 @@ class SgcLLFunction(torch.autograd.Function):
         res_L = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         res_W = torch.empty(plan.tile_elems, dtype=torch.float32, device=dev)
         L_sum = torch.empty(plan.tile_elems if cfg.lsum else 0, dtype=torch.float32, device=dev)
-        desc, rbytes, wbytes, _ = _sizes(plan, cfg, ldx, ldy)
+        flags = current_flags()
+        desc, rbytes, wbytes, _ = _sizes(plan, cfg, ldx, ldy, flags)
         # (the reserve starts with the exchange header of the cooperative kernels, which must be zero when a reserve is FIRST
         # used -- include/agcn.h: AGCN_RESERVE_HEADER_BYTES; only that: at point-cloud sizes the reserve holds n x n tiles, and
         # zero-filling all of it was 75 us per layer call -- and only then: see _lease_reserve)
@@ -359,7 +438,7 @@ class SgcLLFunction(torch.autograd.Function):
         _ffi.check(lib.agcn_sgc_ll_forward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(out),
                                            reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, _stream(dev)))
         ctx.batch, ctx.cfg, ctx.has_prev, ctx.has_beta = batch, cfg, (reslap and L_prev is not None), beta is not None
-        ctx.reserve_lease = lease
+        ctx.reserve_lease, ctx.flags = lease, flags
         ctx.save_for_backward(X, weight, bias, M_L, alpha, beta, L_prev if reslap else None,
                               Y, res_L, res_W, L_sum)
         ctx.mark_non_differentiable(res_L, res_W)
@@ -385,7 +464,7 @@ class SgcLLFunction(torch.autograd.Function):
         if dL_sum is not None:
             dL_sum = _f32c(dL_sum, "dL_sum")
         ldx, ldy = X.shape[1], cfg.Fout
-        desc, _, _, wbytes = _sizes(plan, cfg, ldx, ldy)
+        desc, _, _, wbytes = _sizes(plan, cfg, ldx, ldy, ctx.flags)     # (the forward's flags: autograd runs this on its own thread)
         dX = torch.empty_like(X)
         if ldx > cfg.Fin:
             dX.zero_()
@@ -469,7 +548,7 @@ class RowsDenseFunction(torch.autograd.Function):
             if scale.numel() != 1:
                 raise ValueError("scale must hold one element")
         Y = torch.empty((plan.rows, Fout), dtype=torch.float32, device=A.device)
-        desc = _ffi.DenseDesc(Fin, Fout, _ffi.ACT[activation], 1 if keep_pad_rows else 0, A.shape[1], Fout, Fout, 0)
+        desc = _ffi.DenseDesc(Fin, Fout, _ffi.ACT[activation], 1 if keep_pad_rows else 0, A.shape[1], Fout, Fout, current_flags())
         # (point-cloud row counts: the product runs on the split-bf16 row kernels, which build a parameter image per call)
         wbytes = lib.agcn_rows_dense_forward_workspace_bytes(C.byref(desc), plan.host_ptr)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=A.device) if wbytes else None

@@ -306,10 +306,10 @@ class SGC_LL(Layer):
         if self._variant != "SGC_LL" or not X.is_cuda or X.shape[1] != cfg.Fin:
             return False
         from . import _ffi
-        from .functional import _desc, _gbatch
+        from .functional import _desc, _gbatch, current_flags
         lib = _ffi.lib()
         key = ("bf16_served", cfg.Fin, cfg.Fout, cfg.K, cfg.mode, lib.agcn_get_lds_limit(), lib.agcn_get_fused_mode(),
-               lib.agcn_get_spec_mode(), lib.agcn_get_slab_mode())
+               lib.agcn_get_spec_mode(), lib.agcn_get_slab_mode(), current_flags())
         cache = gb.plan.__dict__.setdefault("_size_cache", {})
         hit = cache.get(key)
         if hit is None:

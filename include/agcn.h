@@ -8,13 +8,14 @@
  * never synchronises, and enqueues all work on the stream it is given.
  *
  * Threading.  Calls are re-entrant across threads (one stream per thread, disjoint
- * buffers; tests/test_gpu_parity.py runs two threads concurrently); the error string
- * is thread-local.  What IS process-wide, by design: the dispatch knobs of the
- * last section (agcn_set_* / the AGCN_* environment variables: they select
- * between kernel paths that give the same results, set them before the first
- * call or while no call is in flight), a per-(device, kernel) cache of the
- * dynamic-LDS caps already raised, and -- only with the opt-in mixed dispatch,
- * agcn_set_fused_mode(2 | 3) -- one internal side stream + event pair per device;
+ * buffers; tests/test_gpu_parity.py runs two threads concurrently, each with its own
+ * dispatch flags); the error string is thread-local.  Which of the equivalent kernel
+ * paths serves a call is a PER-CALL argument (AgcnLayerDesc.flags / AgcnDenseDesc.flags,
+ * ABI 106); a field left 0 takes the process default, which comes from the AGCN_*
+ * environment variables and -- for diagnostics and A/B measurements -- the agcn_set_*
+ * functions of the last section.  What else is process-wide, by design: a per-(device,
+ * kernel) cache of the dynamic-LDS caps already raised, and -- only with the opt-in mixed
+ * dispatch, fused mode 2 | 3 -- one internal side stream + event pair per device;
  * a mixed-dispatch call holds that device's lock while it enqueues.  The launch
  * profiler (agcn_profile_*) is a single-threaded debug facility.
  *
@@ -43,7 +44,15 @@
 extern "C" {
 #endif
 
-#define AGCN_VERSION 105 /* 0.1.5: agcn_get / set_rows_split (packed-row products of point-cloud batches on the bf16 matrix pipe), agcn_rows_dense_scaled_forward_ws */
+/* The library is built with -fvisibility=hidden: the 66 functions declared here are its whole dynamic symbol table
+ * (tests/test_abi.py compares `nm -D` with this header). */
+#if defined(__GNUC__)
+#define AGCN_API __attribute__((visibility("default")))
+#else
+#define AGCN_API
+#endif
+
+#define AGCN_VERSION 106 /* 0.1.6: per-call dispatch flags (AgcnLayerDesc.flags, AgcnDenseDesc.flags); hidden visibility */
 
 enum {
   AGCN_OK = 0,
@@ -116,18 +125,18 @@ typedef struct AgcnGraphDesc {
 #define AGCN_SLAB_ROWS 16
 
 /* Bytes needed for a plan: worst case for B graphs / exact for the given node counts. */
-size_t agcn_plan_bytes(int32_t B);
-size_t agcn_plan_bytes_for(const int32_t* n, int32_t B, int32_t row_stride);
+AGCN_API size_t agcn_plan_bytes(int32_t B);
+AGCN_API size_t agcn_plan_bytes_for(const int32_t* n, int32_t B, int32_t row_stride);
 
 /* Build a plan from host arrays.  n[B] = node counts (data_slice[:,0] /
  * lap_slice[:,0], graph_topology.py:90,98).  row_stride = 0 -> packed rows,
  * otherwise every graph owns row_stride rows (the reference's max_atom).
  * Fails with AGCN_EINVAL if any n[b] < 1, n[b] > row_stride (padded mode) or
  * the batch does not fit 32-bit row indexing. */
-int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, void* plan_host, size_t plan_bytes);
+AGCN_API int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, void* plan_host, size_t plan_bytes);
 
 /* Read the header back (validates the magic). */
-int agcn_plan_info(const void* plan_host, AgcnPlanInfo* info);
+AGCN_API int agcn_plan_info(const void* plan_host, AgcnPlanInfo* info);
 
 /* ------------------------------------------------------------------------ */
 typedef struct AgcnLayerDesc {
@@ -143,7 +152,22 @@ typedef struct AgcnLayerDesc {
                        * "bf16 features + fp32 Laplacian": widened exactly on load, rounded to nearest even on store, every
                        * tile, product and parameter gradient in fp32.  Served by the specialised kernels only (dispatch bits
                        * 1 | 2 of agcn_sgc_ll_dispatch_info); other batches: AGCN_EINVAL (convert with agcn_cast_rows) */
+  uint32_t flags;     /* per-CALL dispatch overrides (ABI 106), 0 = the process defaults (AGCN_* environment / agcn_set_*): which of
+                       * the equivalent kernel paths serves THIS call, for this thread only -- AGCN_FLAG_* below.  The size queries
+                       * (reserve / workspace bytes, dispatch_info) and the forward / backward calls of one step take the same flags */
 } AgcnLayerDesc;
+
+/* AgcnLayerDesc.flags / AgcnDenseDesc.flags: each field holds (value + 1), 0 = "not overridden"; values as the setter of the
+ * same name documents them (last section of this header). */
+#define AGCN_FLAG_SPEC_MODE(v)     (((uint32_t)(v) + 1u) & 15u)            /* agcn_set_spec_mode: 0..7 (bit 2 off = no member workgroups) */
+#define AGCN_FLAG_FUSED_MODE(v)    ((((uint32_t)(v) + 1u) & 7u) << 4)      /* agcn_set_fused_mode: 0..3 */
+#define AGCN_FLAG_PG_ONEPASS(v)    ((((uint32_t)(v) + 1u) & 3u) << 7)      /* agcn_set_param_grad_onepass: 0..2 */
+#define AGCN_FLAG_SPEC_SMALL(v)    ((((uint32_t)(v) + 1u) & 3u) << 9)      /* agcn_set_spec_small: 0..2 */
+#define AGCN_FLAG_ROWS_SPLIT(v)    ((((uint32_t)(v) + 1u) & 3u) << 11)     /* agcn_set_rows_split: 0..1 */
+#define AGCN_FLAG_SLAB_MODE(v)     ((((uint32_t)(v) + 1u) & 3u) << 13)     /* agcn_set_slab_mode: 0..1 */
+#define AGCN_FLAG_FUSED_GB(v)      ((((uint32_t)((v) + 2)) & 3u) << 15)    /* agcn_set_fused_global_b: -1..1 */
+#define AGCN_FLAG_SPEC_TAIL(v)     ((((uint32_t)(v) + 1u) & 3u) << 17)     /* agcn_set_spec_tail: 0..1 */
+#define AGCN_FLAG_COOP_MEMBERS(v)  ((((uint32_t)(v) + 1u) & 255u) << 24)   /* agcn_set_coop_members: 0..120 */
 
 /* Device pointers unless stated otherwise. */
 typedef struct AgcnGraphBatch {
@@ -205,7 +229,7 @@ typedef struct AgcnGrads {
  * the buffer is reused for other batches.  (It holds the words through which the workgroups that share one large
  * graph exchange a vector inside a launch; csrc/spec_backward_coop.h.) */
 #define AGCN_RESERVE_HEADER_BYTES 65536
-size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host);
+AGCN_API size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 /* Device-side status of the calls that used `reserve`.  The workgroups that share one large graph wait for each other's
  * words inside a launch; such a wait is bounded (10 ms of wall time) and can only run out when the members are not
  * co-resident -- more concurrent launches with members than the chip holds (see agcn_set_coop_members), or other work
@@ -214,16 +238,16 @@ size_t agcn_sgc_ll_reserve_bytes(const AgcnLayerDesc* desc, const void* plan_hos
  * where the host synchronises anyway -- reading a loss, the end of an epoch); *timeouts = the count.  Returns AGCN_OK
  * when it is 0, AGCN_EDEVICE otherwise (every result computed with this reserve since the header was last zeroed is
  * suspect; zero the header to re-arm). */
-int agcn_sgc_ll_reserve_status(const void* reserve, size_t reserve_bytes, void* hip_stream, int32_t* timeouts);
+AGCN_API int agcn_sgc_ll_reserve_status(const void* reserve, size_t reserve_bytes, void* hip_stream, int32_t* timeouts);
 /* The same count, kept where it outlives the reserve.  A caller whose reserves are short-lived (an autograd graph frees
  * them as soon as backward has run) registers ONE 4-byte device word per device -- caller-owned, zeroed by the caller, alive
  * until it is unregistered with NULL --; every wait that runs out in a later call ON THAT DEVICE counts itself there too.
  * agcn_device_status copies the word to the host on `hip_stream` and waits for it, like agcn_sgc_ll_reserve_status:
  * AGCN_OK when 0 (or when nothing is registered), AGCN_EDEVICE otherwise.  The library never clears the word. */
-int agcn_set_device_status_word(int32_t device, void* word);
-int agcn_device_status(int32_t device, void* hip_stream, int32_t* timeouts);
-size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
-size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
+AGCN_API int agcn_set_device_status_word(int32_t device, void* word);
+AGCN_API int agcn_device_status(int32_t device, void* hip_stream, int32_t* timeouts);
+AGCN_API size_t agcn_sgc_ll_forward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
+AGCN_API size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const void* plan_host);
 
 /* Which kernels a forward / backward call on this batch would launch: host logic only (nothing is launched, device
  * pointers of `batch` are only tested for NULL).  out[0] = path: 4 fused one-launch-per-direction kernels (| 1 / | 2:
@@ -233,16 +257,16 @@ size_t agcn_sgc_ll_backward_workspace_bytes(const AgcnLayerDesc* desc, const voi
  * the first graph of the 8-wave launch (== B: none); out[2..4] = forward: graphs spread over member workgroups,
  * members, graphs packed two to a workgroup; out[5..7] = the same for the backward. */
 #define AGCN_DISPATCH_INFO_INTS 8
-int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out);
+AGCN_API int agcn_sgc_ll_dispatch_info(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, int32_t* out, int32_t n_out);
 
-int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+AGCN_API int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
                         const AgcnOutputs* out, void* reserve, size_t reserve_bytes,
                         void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* `fwd` are the tensors the forward produced (read only here).  dY [rows, ldy]
  * is the gradient w.r.t. Y; dL_sum (tiles, nullable) is the gradient arriving
  * on the L_sum output from a later Reslap layer's dL_prev. */
-int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+AGCN_API int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
                          const AgcnOutputs* fwd, const float* dY, const float* dL_sum,
                          const AgcnGrads* grads, const void* reserve, size_t reserve_bytes,
                          void* workspace, size_t workspace_bytes, void* hip_stream);
@@ -251,19 +275,19 @@ int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
  * _nodes  = everything local to a graph: dX, dL_prev, and the per-graph partials in workspace;
  * _params = the reductions over the batch: dweight, dbias, dM_L, dalpha, dbeta.
  * _params must follow _nodes on the same stream with the same workspace. */
-int agcn_sgc_ll_backward_nodes(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+AGCN_API int agcn_sgc_ll_backward_nodes(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
                                const AgcnOutputs* fwd, const float* dY, const float* dL_sum,
                                const AgcnGrads* grads, const void* reserve, size_t reserve_bytes,
                                void* workspace, size_t workspace_bytes, void* hip_stream);
-int agcn_sgc_ll_backward_params(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+AGCN_API int agcn_sgc_ll_backward_params(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
                                 const AgcnOutputs* fwd, const float* dY, const float* dL_sum,
                                 const AgcnGrads* grads, const void* reserve, size_t reserve_bytes,
                                 void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* GraphGatherMol (graphgather.py:40-77): out[b, :] = act(sum of graph b's real rows). */
-int agcn_graph_gather_forward(const void* plan_host, const void* plan_dev, const float* X, int32_t F,
+AGCN_API int agcn_graph_gather_forward(const void* plan_host, const void* plan_dev, const float* X, int32_t F,
                               int32_t ldx, int32_t activation, float* out /* [B, F] */, void* hip_stream);
-int agcn_graph_gather_backward(const void* plan_host, const void* plan_dev, const float* out,
+AGCN_API int agcn_graph_gather_backward(const void* plan_host, const void* plan_dev, const float* out,
                                const float* dOut, int32_t F, int32_t ldx, int32_t activation,
                                float* dX /* [rows, ldx], pad rows zeroed */, void* hip_stream);
 
@@ -273,7 +297,7 @@ int agcn_graph_gather_backward(const void* plan_host, const void* plan_dev, cons
  * (ld = max_atom: graph b at b * ld * ld).  Asynchronous on `hip_stream`; reading the count is the caller's synchronisation.
  * The point-cloud kernels take La^T g_1 as La g_1 on the strength of those flags: a false vouch is a silently wrong dX, so the
  * Python layers run this once per layer object (and on every call under AGCN_DEBUG_CHECKS=1) and raise on a non-zero count. */
-int agcn_tiles_asymmetry(const void* plan_host, const void* plan_dev, const float* tiles, int32_t ld,
+AGCN_API int agcn_tiles_asymmetry(const void* plan_host, const void* plan_dev, const float* tiles, int32_t ld,
                          int32_t* count_dev, void* hip_stream);
 
 /* ---- "next" rows: the layers around the SGC stack --------------------------------
@@ -289,13 +313,13 @@ typedef struct AgcnDenseDesc {
   int32_t activation;    /* AGCN_ACT_LINEAR | AGCN_ACT_RELU */
   int32_t keep_pad_rows; /* 1: pad rows are ordinary rows */
   int32_t ldx, ldy, ldadd;
-  int32_t reserved;
+  uint32_t flags;        /* per-call dispatch overrides (AGCN_FLAG_ROWS_SPLIT, AGCN_FLAG_PG_ONEPASS), 0 = process defaults */
 } AgcnDenseDesc;
-int agcn_rows_dense_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+AGCN_API int agcn_rows_dense_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                             const float* X, const float* W, const float* bias, const float* Add, float* Y,
                             void* hip_stream);
-size_t agcn_rows_dense_backward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host);
-int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+AGCN_API size_t agcn_rows_dense_backward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host);
+AGCN_API int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                              const float* X, const float* W, const float* Y, const float* dY, float* dX,
                              float* dAdd, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                              void* hip_stream);
@@ -306,18 +330,18 @@ int agcn_rows_dense_backward(const AgcnDenseDesc* desc, const void* plan_host, c
  *   adding onto the previous sum (Add), the last one carrying the activation (:92) and zeroing pad rows (:126).
  * Backward additionally returns dscale[0] = <W, A^T Gp>; dX and dW carry the factor scale[0].
  * scale == NULL (and dscale == NULL) is exactly agcn_rows_dense_forward / _backward. */
-int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+AGCN_API int agcn_rows_dense_scaled_forward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                                    const float* X, const float* W, const float* scale, const float* bias,
                                    const float* Add, float* Y, void* hip_stream);
 /* ... and with a WORKSPACE for the forward (ABI 105): at point-cloud row counts (>= 8192 packed rows without pad rows, 64 / 128 / 256
  * features) the product runs on the bf16 matrix pipe at fp32 accuracy (csrc/rows_split.hip), which needs room for the parameter image
  * it builds per call.  agcn_rows_dense_forward_workspace_bytes returns 0 when the batch / layer does not take that path (then
  * workspace may be NULL and the call is exactly agcn_rows_dense_scaled_forward).  The backward's workspace covers its own image. */
-size_t agcn_rows_dense_forward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host);
-int agcn_rows_dense_scaled_forward_ws(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+AGCN_API size_t agcn_rows_dense_forward_workspace_bytes(const AgcnDenseDesc* desc, const void* plan_host);
+AGCN_API int agcn_rows_dense_scaled_forward_ws(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                                       const float* X, const float* W, const float* scale, const float* bias,
                                       const float* Add, float* Y, void* workspace, size_t workspace_bytes, void* hip_stream);
-int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
+AGCN_API int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const void* plan_host, const void* plan_dev,
                                     const float* X, const float* W, const float* scale, const float* Y,
                                     const float* dY, float* dX, float* dAdd, float* dW, float* dbias,
                                     float* dscale, void* workspace, size_t workspace_bytes, void* hip_stream);
@@ -333,12 +357,12 @@ int agcn_rows_dense_scaled_backward(const AgcnDenseDesc* desc, const void* plan_
  * logits [T][B][2], loss [1].  workspace: agcn_multitask_ce_workspace_bytes(B, F, T).
  * Backward: dloss is a DEVICE scalar (the upstream gradient of the loss); writes dfeat [B, ldf] (columns < F),
  * dW [T][F][2], dbias [T][2].  Reductions run in a fixed order (no atomics). */
-size_t agcn_multitask_ce_workspace_bytes(int32_t B, int32_t F, int32_t T);
-int agcn_multitask_ce_forward(int32_t B, int32_t F, int32_t T, const float* feat, int32_t ldf, const float* W,
+AGCN_API size_t agcn_multitask_ce_workspace_bytes(int32_t B, int32_t F, int32_t T);
+AGCN_API int agcn_multitask_ce_forward(int32_t B, int32_t F, int32_t T, const float* feat, int32_t ldf, const float* W,
                               const float* bias, const float* labels, const float* weights, float inv_batch,
                               float* logits, float* loss, void* workspace, size_t workspace_bytes,
                               void* hip_stream);
-int agcn_multitask_ce_backward(int32_t B, int32_t F, int32_t T, const float* feat, int32_t ldf, const float* W,
+AGCN_API int agcn_multitask_ce_backward(int32_t B, int32_t F, int32_t T, const float* feat, int32_t ldf, const float* W,
                                const float* logits, const float* labels, const float* weights, float inv_batch,
                                const float* dloss, float* dfeat, float* dW, float* dbias, void* workspace,
                                size_t workspace_bytes, void* hip_stream);
@@ -347,10 +371,10 @@ int agcn_multitask_ce_backward(int32_t B, int32_t F, int32_t T, const float* fea
  * is empty), pad rows 0.  `lap`: only the L0_* members are read.  argmax [rows, F] int32 is optional.
  * The reference passes NO gradient through this layer (py_func); agcn_graph_pool_backward is the
  * arg-max-routing extension and needs a symmetric pattern. */
-int agcn_graph_pool_forward(const void* plan_host, const void* plan_dev, const AgcnGraphBatch* lap,
+AGCN_API int agcn_graph_pool_forward(const void* plan_host, const void* plan_dev, const AgcnGraphBatch* lap,
                             const float* X, int32_t F, int32_t ldx, float* out, int32_t* argmax,
                             void* hip_stream);
-int agcn_graph_pool_backward(const void* plan_host, const void* plan_dev, const AgcnGraphBatch* lap,
+AGCN_API int agcn_graph_pool_backward(const void* plan_host, const void* plan_dev, const AgcnGraphBatch* lap,
                              const int32_t* argmax, const float* dOut, int32_t F, int32_t ldx, float* dX,
                              void* hip_stream);
 
@@ -359,7 +383,7 @@ int agcn_graph_pool_backward(const void* plan_host, const void* plan_dev, const 
  * every kernel of the path computes in fp32.  f32 -> bf16 rounds to nearest even. */
 #define AGCN_DTYPE_F32 0
 #define AGCN_DTYPE_BF16 1
-int agcn_cast_rows(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t rows, int32_t cols,
+AGCN_API int agcn_cast_rows(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t rows, int32_t cols,
                    int32_t ld_src, int32_t ld_dst, void* hip_stream);
 
 /* Row layout conversion between the reference's padded feed and packed rows.  The reference hands every layer
@@ -368,9 +392,9 @@ int agcn_cast_rows(const void* src, int32_t src_dtype, void* dst, int32_t dst_dt
  * runs on packed rows, and a padded copy is produced only if the caller looks at per-graph outputs
  * (agcn_rows_unpack; pad rows = 0, or pad_fill[F] for DenseMol whose bias also lands on pad rows,
  * dense_layer.py:42-50).  `plan` must be a packed plan (row_stride 0) of the same node counts. */
-int agcn_rows_pack(const void* plan_host, const void* plan_dev, const float* padded, int32_t stride_rows, int32_t F,
+AGCN_API int agcn_rows_pack(const void* plan_host, const void* plan_dev, const float* padded, int32_t stride_rows, int32_t F,
                    int32_t ld_padded, float* packed, int32_t ld_packed, void* hip_stream);
-int agcn_rows_unpack(const void* plan_host, const void* plan_dev, const float* packed, int32_t F, int32_t ld_packed,
+AGCN_API int agcn_rows_unpack(const void* plan_host, const void* plan_dev, const float* packed, int32_t F, int32_t ld_packed,
                      float* padded, int32_t stride_rows, int32_t ld_padded, const float* pad_fill, void* hip_stream);
 
 /* ---- packed-batch ingest: the step before the path, host only -------------------
@@ -391,11 +415,11 @@ typedef struct AgcnGraphStore {   /* all HOST pointers, owned by the caller */
   const uint8_t* symmetric;  /* [G] 1 = L_orig == L_orig^T bit for bit (NULL = unknown: batches report 0) */
 } AgcnGraphStore;
 /* rows / nnz (and the largest graph) of the batch `ids` [B]: sizes of the staging buffers */
-int agcn_store_batch_sizes(const AgcnGraphStore* store, const int64_t* ids, int32_t B, int64_t* rows,
+AGCN_API int agcn_store_batch_sizes(const AgcnGraphStore* store, const int64_t* ids, int32_t B, int64_t* rows,
                            int64_t* nnz, int32_t* max_n);
 /* n_out [B]; X_out [rows][ldx_out]; rowptr_out [rows+1] (batch-global offsets, as AgcnGraphBatch wants);
  * col_out / val_out [nnz]; symmetric_out = AND of the graphs' flags.  n_threads <= 1: single thread. */
-int agcn_store_pack_batch(const AgcnGraphStore* store, const int64_t* ids, int32_t B, int32_t* n_out,
+AGCN_API int agcn_store_pack_batch(const AgcnGraphStore* store, const int64_t* ids, int32_t B, int32_t* n_out,
                           float* X_out, int32_t ldx_out, int32_t* rowptr_out, int32_t* col_out, float* val_out,
                           int32_t* symmetric_out, int32_t n_threads);
 
@@ -424,8 +448,8 @@ typedef struct AgcnStagedBatch {
   AgcnPlanInfo plan;         /* what agcn_plan_info would return for the staged plan */
 } AgcnStagedBatch;
 /* upper bound of the blob size for a batch of B graphs with `rows` rows in total */
-size_t agcn_store_stage_bytes(int32_t B, int64_t rows);
-int agcn_store_stage_batch(const AgcnResidentStore* store, const int64_t* ids, int32_t B, void* stage_host,
+AGCN_API size_t agcn_store_stage_bytes(int32_t B, int64_t rows);
+AGCN_API int agcn_store_stage_batch(const AgcnResidentStore* store, const int64_t* ids, int32_t B, void* stage_host,
                            void* stage_dev, size_t stage_cap, float* X_out, int32_t ldx_out, int64_t rows_cap,
                            int32_t* rowptr_out, int32_t* col_out, float* val_out, int64_t nnz_cap,
                            AgcnStagedBatch* info, void* hip_stream);
@@ -454,7 +478,7 @@ typedef struct AgcnEpochBuffers {
   void* workspace; size_t workspace_bytes;
 } AgcnEpochBuffers;
 typedef struct AgcnEpochNeeds { size_t reserve_bytes, workspace_bytes; } AgcnEpochNeeds;
-int agcn_epoch_step(const AgcnResidentStore* store, const int64_t* ids, int32_t B, const AgcnLayerDesc* desc,
+AGCN_API int agcn_epoch_step(const AgcnResidentStore* store, const int64_t* ids, int32_t B, const AgcnLayerDesc* desc,
                     const AgcnParams* params, const AgcnEpochBuffers* buf, int32_t restage, AgcnStagedBatch* info,
                     AgcnEpochNeeds* needs, void* slot_event, void* hip_stream);
 
@@ -462,41 +486,41 @@ int agcn_epoch_step(const AgcnResidentStore* store, const int64_t* ids, int32_t 
  * the path).  Off by default.  agcn_profile_collect waits for the events recorded since the last
  * collect and returns, per kernel id < agcn_profile_kernels(), the total milliseconds and the
  * number of launches.  Debug facility: not thread safe, not capturable into a HIP graph. */
-void agcn_profile_enable(int on);
-int32_t agcn_profile_kernels(void);
-const char* agcn_profile_kernel_name(int32_t id);
-int agcn_profile_collect(double* total_ms, int64_t* calls);
+AGCN_API void agcn_profile_enable(int on);
+AGCN_API int32_t agcn_profile_kernels(void);
+AGCN_API const char* agcn_profile_kernel_name(int32_t id);
+AGCN_API int agcn_profile_collect(double* total_ms, int64_t* calls);
 
-int32_t agcn_version(void);
-const char* agcn_last_error(void);
+AGCN_API int32_t agcn_version(void);
+AGCN_API const char* agcn_last_error(void);
 /* LDS bytes per workgroup above which a graph is processed with its tile in
  * global memory instead of LDS (default 160 KiB; settable for tests). */
-int32_t agcn_get_lds_limit(void);
-void agcn_set_lds_limit(int32_t bytes);
+AGCN_API int32_t agcn_get_lds_limit(void);
+AGCN_API void agcn_set_lds_limit(int32_t bytes);
 /* 1 (default): SGC_LL with K = 2 on packed rows with a symmetric CSR L_orig runs on the
  * slab-parallel kernels (16-row strips of every graph's tile, balanced over the CUs);
  * 0: always one workgroup per graph.  Same results either way (tested). */
-int32_t agcn_get_slab_mode(void);
-void agcn_set_slab_mode(int32_t mode);
+AGCN_API int32_t agcn_get_slab_mode(void);
+AGCN_API void agcn_set_slab_mode(int32_t mode);
 /* 1 (default): batches of small graphs (the largest graph's X, M_L, W, n x n tile and Z^T fit
  * LDS) run SGC_LL K = 2 on the fused one-launch-per-direction kernels; 0: never; 2 / 3: additionally,
  * when only a few graphs are too large, run those on a side stream next to the fused kernels ("mixed"
  * dispatch): 2 = on the per-graph LDS-tile kernels when their tile fits LDS (else as 3), 3 = on the slab
  * kernels. */
-int32_t agcn_get_fused_mode(void);
-void agcn_set_fused_mode(int32_t mode);
+AGCN_API int32_t agcn_get_fused_mode(void);
+AGCN_API void agcn_set_fused_mode(int32_t mode);
 /* Flavour of the fused kernels: -1 (default) the library picks per direction from measurements;
  * 0: always stage M_L / W as LDS images; 1: always read them from global memory inside the k-loops (whenever the
  * graph's own working set fits LDS).  Same results to the last few ulps (different summation grouping). */
-int32_t agcn_get_fused_global_b(void);
-void agcn_set_fused_global_b(int32_t mode);
+AGCN_API int32_t agcn_get_fused_global_b(void);
+AGCN_API void agcn_set_fused_global_b(int32_t mode);
 /* 2 (default): parameter gradients in one launch, the row splits' partial tiles handed to the workgroup of the tile's last
  * split as tagged 8-byte granules (where the per-graph kernel of the same call can clear them: whole backward calls on the
  * shape-specialised kernels, batches below 8192 rows; elsewhere as 1); 1: one launch, arrival counters (the last workgroup
  * to arrive adds the splits); 0: partial + reduce launches.  All three add in fixed order: bit-reproducible, and 1 and 2
  * bit-identical to each other. */
-int32_t agcn_get_param_grad_onepass(void);
-void agcn_set_param_grad_onepass(int32_t on);
+AGCN_API int32_t agcn_get_param_grad_onepass(void);
+AGCN_API void agcn_set_param_grad_onepass(int32_t on);
 /* Shape-specialised fused kernels (csrc/spec_*.hip: SGC_LL and SGC_LL_Reslap, K = 2, layer widths 75->64, 64->128, 128->128, 128->64,
  * 64->64; 1024-thread workgroups, feature widths compiled in).  A bit mask, default 7: bit 0 = forward, bit 1 =
  * backward (used wherever the fused path would be taken and the shape is covered; 0: always the general fused
@@ -506,39 +530,46 @@ void agcn_set_param_grad_onepass(int32_t on);
  * per tile of the same launch, the smallest graphs packed two to a workgroup to make room.  Graphs beyond the one-workgroup
  * kernels' 96 nodes are spread whatever the batch size or Laplacian mode (only members can take them).  Same results within the last few ulps
  * (hardware sqrt / exp2 in the similarity phase; summation orders). */
-int32_t agcn_get_spec_mode(void);
-void agcn_set_spec_mode(int32_t mode);
+AGCN_API int32_t agcn_get_spec_mode(void);
+AGCN_API void agcn_set_spec_mode(int32_t mode);
 /* In batches of >= 1024 graphs the graphs of at most 24 nodes (32 from 3072 graphs on) take an 8-wave flavour of the
  * specialised kernels in a launch of their own (three such workgroups share a CU).  2 (default): the launch of the few larger
  * graphs runs beside it on the library's per-device side stream (fork / join with events, capturable into a HIP
  * graph); 1: before it on the caller's stream; 0: one launch for all graphs. */
-int32_t agcn_get_spec_small(void);
-void agcn_set_spec_small(int32_t on);
+AGCN_API int32_t agcn_get_spec_small(void);
+AGCN_API void agcn_set_spec_small(int32_t on);
 /* Member workgroups per launch of the cooperative layout (spec_mode bit 2): all members of a graph must be RESIDENT
  * together, so concurrent member launches on one device have to fit the chip.  Default 120 (two concurrent launches on
  * 256 CUs: two epoch lanes, or two ranks sharing a GPU); with L launches in flight set 240 / L (0: no members).  Clamped
  * to [0, 120].  Process-wide, like the other knobs. */
-int32_t agcn_get_coop_members(void);
-void agcn_set_coop_members(int32_t members);
+AGCN_API int32_t agcn_get_coop_members(void);
+AGCN_API void agcn_set_coop_members(int32_t members);
 /* 0 (default; env AGCN_SPEC_TAIL=1 opts in): 1 makes a whole-backward call on a batch the specialised kernels take in ONE
  * 16-wave launch (SGC_LL, paper mode) compute the parameter gradients in trailing workgroups of that launch -- dispatch bit
  * 128 --; 0: always the separate parameter-gradient kernel (measured faster: profiles/EXPERIMENTS.md).  Both are
  * bit-reproducible; they differ in summation order. */
-int32_t agcn_get_spec_tail(void);
-void agcn_set_spec_tail(int32_t on);
+AGCN_API int32_t agcn_get_spec_tail(void);
+AGCN_API void agcn_set_spec_tail(int32_t on);
 /* Bound of a member's wait for a sibling's word, in ticks of the device's 100 MHz constant clock (default 1 000 000 = 10 ms:
  * three orders of magnitude beyond a step).  0 makes every wait that is not satisfied by its first poll run out -- the
  * deterministic way to exercise the reporting path (status words, NaN poisoning) in a test.  Process-wide. */
-uint32_t agcn_get_coop_timeout_ticks(void);
-void agcn_set_coop_timeout_ticks(uint32_t ticks);
+AGCN_API uint32_t agcn_get_coop_timeout_ticks(void);
+AGCN_API void agcn_set_coop_timeout_ticks(uint32_t ticks);
 
-/* 1 (default; env AGCN_ROWS_SPLIT=0): the packed-row products of point-cloud sized batches (>= 1024 packed rows, 64 / 128 features,
- * K = 2: Z = X M_L, the filter and its adjoint, dX += dZ M_L^T, the parameter-gradient partials) run on the bf16 matrix pipe at fp32
- * accuracy -- every fp32 operand split exactly into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per 32 k (csrc/rows_split.hip);
- * 0: the fp32-MFMA kernels (csrc/rows_wide.hip, csrc/cloud_kernels.hip).  Results differ by fp32 summation order only; both
- * bit-reproducible.  Process-wide. */
-int32_t agcn_get_rows_split(void);
-void agcn_set_rows_split(int32_t on);
+/* 1 (default; env AGCN_ROWS_SPLIT=0; per call: AGCN_FLAG_ROWS_SPLIT): packed-row products of point-cloud sized batches (>= 1024
+ * packed rows, K = 2) run on the bf16 matrix pipe at fp32 accuracy -- every fp32 operand split exactly into three bf16 pieces, six
+ * v_mfma_f32_16x16x32_bf16 per 32 k (csrc/rows_split.hip).  WHICH products, exactly as the dispatch has it:
+ *   Fin = 128 (forward: rows a multiple of 64; backward: rows a multiple of 128): Z = X M_L, the filter, its adjoint,
+ *              dX += dZ M_L^T and the parameter-gradient partials;
+ *   Fin = 64:  the forward stays on the fused point-cloud kernels (cloud_lap computes the filter itself); the backward takes the
+ *              filter adjoint and the parameter-gradient partials;
+ *   dense layers (agcn_rows_dense_*): >= AGCN_ROWS_SPLIT_DENSE_MIN packed rows (default 8192), 64 / 128 / 256 features.
+ * 0: the fp32-MFMA kernels (csrc/rows_wide.hip, csrc/cloud_kernels.hip, csrc/rows_gemm.hip).  Results differ by fp32 summation order
+ * only; both bit-reproducible.  A non-finite or near-FLT_MAX operand (|x| within half a bf16 ulp of the bf16 maximum, 3.39e38)
+ * turns its row of the product into NaN on the split kernels (the high piece rounds to infinity, inf - inf), where the fp32-MFMA
+ * kernels would propagate the infinity: overflow diagnostics differ between the two settings, finite results do not. */
+AGCN_API int32_t agcn_get_rows_split(void);
+AGCN_API void agcn_set_rows_split(int32_t on);
 
 /* Environment switches of the point-cloud kernels, read once per process (A/B measurements; results within the same
  * tolerances either way): AGCN_SLAB_SMALL=0 -- slab batches with Fin <= 4 and a dense L_orig take the general slab
@@ -550,7 +581,9 @@ void agcn_set_rows_split(int32_t on);
  * AGCN_CLOUD_BWD2_BF = 0 | 2 -- backward 2's product c Z never | always on the bf16 matrix pipe (default 1: 128-feature layers only);
  * AGCN_CLOUD_BWD1_PARTS=0 -- backward 1 of a 128-feature SGC_LL layer once per feature half instead of by parts (P tile);
  * AGCN_CLOUD_SIM2=0 -- the 128-feature similarity with all 128 features of a lane's column row in registers (two waves per SIMD)
- * instead of two passes of 64 (four). */
+ * instead of two passes of 64 (four);
+ * AGCN_ROWS_SPLIT_DENSE_MIN=<rows> -- fewest packed rows at which the dense layers (agcn_rows_dense_*) take the split-bf16 row
+ * kernels (default 8192; values below 128 -- one workgroup's rows -- or unparsable ones are clamped to 128). */
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,23 @@ def test_exports_every_declared_symbol(amd):
     for name in declared:
         assert hasattr(lib, name), "libagcn_hip.so does not export %s" % name
     assert sorted(amd._ffi.SYMBOLS) == declared
-    assert lib.agcn_version() == 105
+    assert lib.agcn_version() == 106
+
+
+def test_dynamic_symbol_table_is_the_header_and_nothing_else(amd):
+    """the boundary is the C functions of include/agcn.h.  The library is built with -fvisibility=hidden and
+    every declaration carries AGCN_API, so `nm -D --defined-only` lists exactly those names: no mangled C++ symbol, no kernel
+    stub, no global."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "agcn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(agcn_[a-z_0-9]+)\s*\(", hdr)))
+    out = subprocess.run(["nm", "-D", "--defined-only", amd._build.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    extra = [e for e in exported if e not in declared]
+    assert not extra, "symbols exported beyond include/agcn.h: %s" % extra[:10]
+    assert exported == declared
+    assert all(re.search(r"AGCN_API [^;]*\b%s\(" % n, hdr) for n in declared), "a declaration without AGCN_API"
 
 
 def test_header_constants_match_the_c_header(amd):
@@ -78,7 +94,7 @@ def test_plan_rejects_bad_input(amd):
 def test_size_queries_and_validation(amd):
     lib = amd._ffi.lib()
     p = amd.Plan([18, 48, 7, 23])
-    d = amd._ffi.LayerDesc(75, 64, 2, 1, 0, 1, 75, 64)
+    d = amd._ffi.LayerDesc(75, 64, 2, 1, 0, 1, 75, 64, 0, 0)
     r = lib.agcn_sgc_ll_reserve_bytes(C.byref(d), p.host_ptr)
     assert r >= 4 * (p.rows + 4 * p.B + p.rows * 75)
     assert lib.agcn_sgc_ll_forward_workspace_bytes(C.byref(d), p.host_ptr) >= 256
@@ -91,7 +107,7 @@ def test_size_queries_and_validation(amd):
     finally:
         lib.agcn_set_lds_limit(160 * 1024)
     assert lib.agcn_get_lds_limit() == 160 * 1024
-    bad = amd._ffi.LayerDesc(75, 64, 0, 1, 0, 1, 75, 64)     # K = 0
+    bad = amd._ffi.LayerDesc(75, 64, 0, 1, 0, 1, 75, 64, 0, 0)     # K = 0
     assert lib.agcn_sgc_ll_reserve_bytes(C.byref(bad), p.host_ptr) == 0
     assert b"K must be" in lib.agcn_last_error()
     # argument validation happens before any device work

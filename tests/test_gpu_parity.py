@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI) against golden vectors made from the reference's
 own layer code and against the oracle.  Needs a real MI355X: run with `-m gpu`."""
+import ctypes as C
 import glob
 import os
 
@@ -10,7 +11,7 @@ import torch
 import agcn_oracle as orc
 from conftest import GOLDEN
 from helpers import (oracle_pair, FEATURE_RTOL, FEATURE_ULPS, GRAD_RTOL, GRAD_ULPS, assert_close, compare_with_oracle, golden_params, load_golden,
-                     make_layer, oracle_run, pack_tiles_np, run_packed, synth_case, to_np, unpack_tiles_np)
+                     make_layer, oracle_run, size_factor, pack_tiles_np, run_packed, synth_case, to_np, unpack_tiles_np)
 
 pytestmark = pytest.mark.gpu
 
@@ -1305,7 +1306,7 @@ def test_modelnet_shaped_dense_adjacency(amd, symmetric):
     # column max, helpers.assert_close) is scaled by sqrt(n / 64): every output here is, or depends on, sums over
     # n = 1024 nodes (X_1 = L X_0, the degree, dM_L = X^T dZ), and the rounding error of an n-term fp32 sum grows like
     # sqrt(n) eps; 64 nodes is the size the default allowance was calibrated on.
-    k = float(np.sqrt(n / 64.0))
+    k = size_factor(n)
     assert_close(to_np(nodes.data), c["Y"], FEATURE_RTOL, "Y n=1024", atol_ulps=FEATURE_ULPS * k)
     w = to_np(res_W[0])
     assert_close(w, c["S"], FEATURE_RTOL, "res_W n=1024", atol_ulps=0)
@@ -1388,7 +1389,7 @@ def test_modelnet_hidden_layer_at_size(amd, mode):
     assert (amd._ffi.dispatch_info(layer, gb)[0] & 16) != 0, "n = 1024 must take the slab-parallel kernels"
     caches, tot = oracle_run([X], [L], p, K, mode, orc.SGC_LL, [G], Y_tie=to_np(nodes.data))
     tot32 = oracle_run([X], [L], p, K, mode, orc.SGC_LL, [G], dtype=np.float32, Y_tie=to_np(nodes.data))[1]
-    k = float(np.sqrt(n / 64.0))                              # n-term sums: see test_modelnet_shaped_dense_adjacency
+    k = size_factor(n)                              # n-term sums: see test_modelnet_shaped_dense_adjacency
     _check_dense_clouds([n], caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k, tot32)
 
 
@@ -1611,7 +1612,7 @@ def test_point_cloud_reslap_hidden_layer(amd, mode, case):
         if vname == "reslap":
             assert prof["cloud_rlap1_kernel"][1] == 1, prof
     caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, Y_tie=to_np(nodes.data))
-    k = float(np.sqrt(max(sizes) / 64.0))
+    k = size_factor(max(sizes))
     Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
     for b, n in enumerate(sizes):
         c = caches[b]
@@ -1810,7 +1811,7 @@ def test_point_cloud_kernels_random_batches(amd, seed, mode):
         assert prof["cloud_sim_kernel"][1] == 1 and prof["cloud_bwd1_kernel"][1] == nh, prof
     caches, tot = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, Y_tie=to_np(nodes.data))
     tot32 = oracle_run(Xs, Ls, p, K, mode, variant, Gs, Lp, dLs, dtype=np.float32, Y_tie=to_np(nodes.data))[1]
-    k = float(np.sqrt(max(sizes) / 64.0))
+    k = size_factor(max(sizes))
     Y, dX, r0 = to_np(nodes.data), to_np(Xt.grad), 0
     for b, n in enumerate(sizes):
         c = caches[b]
@@ -1854,7 +1855,7 @@ def test_point_cloud_batch_hidden_features(amd, mode, sizes):
     layer, gb, Xt, nodes, res_L, res_W = _run_dense_clouds(amd, sizes, Xs, Ls, Gs, p, Fin, Fout, K, mode)
     caches, tot = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL, Gs, Y_tie=to_np(nodes.data))
     tot32 = oracle_run(Xs, Ls, p, K, mode, orc.SGC_LL, Gs, dtype=np.float32, Y_tie=to_np(nodes.data))[1]
-    k = float(np.sqrt(max(sizes) / 64.0))
+    k = size_factor(max(sizes))
     _check_dense_clouds(sizes, caches, tot, layer, Xt, nodes, res_L, res_W, mode, k, k, tot32)
 
 
@@ -1894,7 +1895,7 @@ def test_point_cloud_batch_streaming_kernels(amd, mode, Fin, Fout):
     # absolute allowance scaled by sqrt(n / 64) as in test_modelnet_shaped_dense_adjacency; the gradients of the
     # degenerate one-feature case ((z_i - z_j) / r_ij = +-1: dZ and dX are sums of signed terms that cancel) get the
     # allowance fp32 arithmetic itself needs there (helpers.py: 120 ulp on dX against 5 in the other cases)
-    k = float(np.sqrt(max(sizes) / 64.0))
+    k = size_factor(max(sizes))
     kg = k * (4.0 if Fin == 1 else 1.0)
     Y = to_np(nodes.data)
     dX = to_np(Xt.grad)
@@ -1915,27 +1916,44 @@ def test_point_cloud_batch_streaming_kernels(amd, mode, Fin, Fout):
 
 
 def test_two_threads_call_the_library_concurrently(amd):
-    """include/agcn.h "Threading": calls are re-entrant across threads.  Two threads, each with its own stream, batch
-    and buffers, run forward + backward steps at the same time (ctypes drops the GIL inside the library); every
-    result must be bit-identical to the same step run alone."""
+    """include/agcn.h "Threading": calls are re-entrant across threads, and the kernel path of a call is a PER-CALL argument
+    (AgcnLayerDesc.flags).  Four threads, each with its own stream, batch and buffers, run forward + backward steps at the
+    same time (ctypes drops the GIL inside the library) -- each with DIFFERENT dispatch flags: the default (specialised
+    kernels with members and pairs), specialised kernels without members, the general fused kernels, the per-graph split
+    kernels.  Every thread's results must be bit-identical to the same step run alone with the same flags, the kernels that
+    ran must be the ones its flags ask for, and nothing process-wide may have moved."""
     import threading
+    from agcn_amd import synth
     Fin, Fout, K = 75, 64, 2
+    lib, ffi = amd._ffi.lib(), amd._ffi
+    knobs0 = (lib.agcn_get_spec_mode(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(), lib.agcn_get_coop_members())
+    data = synth.tox21_batch(123, 256, Fin)
+    p = synth.glorot_params(np.random.RandomState(123), Fin, Fout, K)
+    settings = [("default", 0, 7), ("no members", ffi.dispatch_flags(spec_mode=3), 7),
+                ("general fused kernels", ffi.dispatch_flags(spec_mode=0), 4),
+                ("per-graph split kernels", ffi.dispatch_flags(fused_mode=0, slab_mode=0), 32)]
     steps = []
-    for seed, ns in ((41, [18, 7, 33, 12, 25, 9]), (42, [40, 5, 11, 22])):
-        rs, X, L0, csr, p, G = synth_case(seed, ns, Fin, Fout, K, orc.SGC_LL, atoms=True)
-        gb = amd.GraphBatch.from_arrays(np.asarray(ns, np.int32), np.concatenate(X, 0), csr, DEV)
-        layer = make_layer(amd, orc.SGC_LL, Fout, Fin, len(ns), K, orc.PAPER, p, DEV)
-        st = amd.SgcLLStep(layer, gb, dY=torch.from_numpy(np.concatenate(G, 0)).to(DEV))
+    for k, (name, flags, path) in enumerate(settings):
+        sel = np.arange(k, 256, 4)          # 64 graphs each, the large ones spread over the four
+        gb = amd.GraphBatch.from_arrays(data["n"][sel], np.concatenate([data["X"][i] for i in sel], 0), [data["csr"][i] for i in sel], DEV)
+        layer = amd.SGC_LL(Fout, Fin, len(sel), K=K, laplacian_mode="paper", device=DEV)
+        layer.load_vars(p)
+        st = amd.SgcLLStep(layer, gb, dY=torch.randn(gb.plan.rows, Fout, device=DEV), flags=flags)
+        out = (C.c_int32 * 8)()
+        amd._ffi.check(lib.agcn_sgc_ll_dispatch_info(C.byref(st.desc), C.byref(st.gb), out, 8))
+        assert out[0] & ~(128 | 256) == path, (name, list(out))
+        assert (out[3] > 0) == (name == "default"), (name, list(out))     # member workgroups only with the default flags
         st.step()
         torch.cuda.synchronize()
         steps.append((st, [t.clone() for t in (st.Y, st.res_W, st.res_L, st.dX, st.bucket)]))
+    # the four dispatches agree with each other to the comparison tolerance of two fp32 runs (same math, other kernels)
     errors = []
 
     def worker(st):
         try:
             stream = torch.cuda.Stream(DEV)
             with torch.cuda.stream(stream):
-                for _ in range(200):
+                for _ in range(100):
                     st.step()
             stream.synchronize()
         except Exception as e:      # noqa: BLE001
@@ -1948,9 +1966,83 @@ def test_two_threads_call_the_library_concurrently(amd):
         t.join()
     torch.cuda.synchronize()
     assert not errors, errors
-    for st, want in steps:
+    for (st, want), (name, _, _) in zip(steps, settings):
+        assert st.check() == 0
+        for got, w in zip((st.Y, st.res_W, st.res_L, st.dX, st.bucket), want):
+            assert torch.equal(got, w), name
+    assert knobs0 == (lib.agcn_get_spec_mode(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(), lib.agcn_get_coop_members())
+
+
+def test_members_cannot_lose_a_call(amd):
+    """A wait between the workgroups that share a large graph is bounded; when it runs out the step's results are NaN and the
+    status word counts it (test_cooperative_waits_are_never_silent).  That call is not lost: `check(recover=True)` (step
+    objects) and `agcn_amd.run_checked` (autograd calls) RE-ISSUE it on the non-member dispatch -- fresh launches of kernels in
+    which no workgroup waits for another, selected by per-call flags -- and count the recovery.  Forced here with a wait bound
+    of one tick (10 ns): results must EQUAL the run that never used members, bit for bit (the same kernels), and the counters
+    must have moved."""
+    from agcn_amd import synth
+    Fin, Fout, K = 75, 64, 2
+    lib, ffi = amd._ffi.lib(), amd._ffi
+    data = synth.tox21_batch(123, 256, Fin)
+    p = synth.glorot_params(np.random.RandomState(123), Fin, Fout, K)
+    gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], DEV)
+    layer = amd.SGC_LL(Fout, Fin, 256, K=K, laplacian_mode="paper", device=DEV)
+    layer.load_vars(p)
+    dY = torch.randn(gb.plan.rows, Fout, device=DEV)
+    assert amd._ffi.dispatch_info(layer, gb)[3] > 0, "the batch must use member workgroups"
+    ref = amd.SgcLLStep(layer, gb, dY=dY, flags=ffi.dispatch_flags(spec_mode=3))        # never any member
+    ref.step()
+    torch.cuda.synchronize()
+    assert ref.check() == 0
+    want = [t.clone() for t in (ref.Y, ref.res_W, ref.res_L, ref.dX, ref.bucket)]
+    count0 = amd.recovered_calls[0]
+    ticks0 = lib.agcn_get_coop_timeout_ticks()
+    lib.agcn_set_coop_timeout_ticks(1)
+    try:
+        # (1) the static-buffer step, eager and as a replayed HIP graph
+        st = amd.SgcLLStep(layer, gb, dY=dY)
+        st.step()
+        n = st.check(recover=True)
+        assert n > 0 and st.recovered == 1 and amd.recovered_calls[0] == count0 + 1
         for got, w in zip((st.Y, st.res_W, st.res_L, st.dX, st.bucket), want):
             assert torch.equal(got, w)
+        st.capture()
+        st.replay()
+        assert st.check(recover=True) > 0 and st.recovered == 2
+        for got, w in zip((st.Y, st.res_W, st.res_L, st.dX, st.bucket), want):
+            assert torch.equal(got, w)
+        with pytest.raises(amd.AgcnError, match="ran out"):        # without recover the failure stays loud
+            st.replay()
+            st.check()
+        # (2) the autograd path
+        amd.device_timeouts()
+        X = gb.X.clone().requires_grad_(True)
+
+        def step():
+            X.grad = None
+            for v in layer.vars.values():
+                v.grad = None
+            nodes, res_L, res_W = layer({"node_features": X, "graph_batch": gb})
+            nodes.data.backward(dY)
+            return nodes.data.detach().clone()
+
+        Y = amd.run_checked(step)
+        assert amd.recovered_calls[0] == count0 + 3
+        assert torch.equal(Y, want[0]) and torch.equal(X.grad, want[3])
+        assert torch.equal(layer.vars["weight"].grad.reshape(-1), want[4][:Fin * K * Fout])
+        assert amd.device_timeouts() == 0
+        # (3) a batch of an epoch, staged from the resident store: the LAST batch is re-issued from its staged inputs
+        store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
+        rs = store.to_device(DEV, 256)
+        ep = amd.SgcLLEpochStep(layer, rs.rows_cap, rs.tiles_cap, 256, device=DEV)
+        ep.step_ids(rs, np.arange(256), dY=dY)
+        assert ep.check(recover=True) > 0 and ep.recovered == 1
+        assert torch.equal(ep.Y, want[0]) and torch.equal(ep.dX, want[3]) and torch.equal(ep.bucket, want[4])
+    finally:
+        lib.agcn_set_coop_timeout_ticks(ticks0)
+    # with the bound back at 10 ms the member dispatch runs clean again on the same objects
+    st.step()
+    assert st.check() == 0 and bool(torch.isfinite(st.dX).all())
 
 
 @pytest.mark.parametrize("path", ["auto", "fused_general", "slab", "pergraph"])

@@ -191,7 +191,7 @@ def test_stage_blob_bound_covers_every_split_of_the_rows(amd):
     assert lib.agcn_store_stage_bytes(0, 10) == 0 and lib.agcn_store_stage_bytes(4, 3) == 0
 
 
-def _dispatch(amd, n, Fin, Fout, mode, variant=0, K=2, symmetric=1, csr=True):
+def _dispatch(amd, n, Fin, Fout, mode, variant=0, K=2, symmetric=1, csr=True, flags=0):
     """agcn_sgc_ll_dispatch_info on a packed plan of the node counts `n` (host logic: no GPU needed)."""
     import ctypes as C
     lib = amd._ffi.lib()
@@ -199,7 +199,7 @@ def _dispatch(amd, n, Fin, Fout, mode, variant=0, K=2, symmetric=1, csr=True):
     nbytes = lib.agcn_plan_bytes_for(n.ctypes.data, n.size, 0)
     plan = np.zeros(nbytes, np.uint8)
     assert lib.agcn_plan_build(n.ctypes.data, n.size, 0, plan.ctypes.data, nbytes) == 0
-    desc = amd._ffi.LayerDesc(Fin, Fout, K, mode, variant, 1, Fin, Fout)
+    desc = amd._ffi.LayerDesc(Fin, Fout, K, mode, variant, 1, Fin, Fout, 0, flags)
     one = 1   # any non-NULL "device" pointer: the call only tests them for NULL
     gb = amd._ffi.GraphBatch(plan.ctypes.data, one, one, None, 0, symmetric, one if csr else None, one if csr else None,
                              one if csr else None, None)
@@ -378,36 +378,63 @@ def test_hiv_epoch_plan_is_a_balanced_partition():
             assert loads.max() / loads.mean() < 1.05
 
 
-def test_member_budget_overrides_are_reference_counted(amd):
-    """engine._member_budget (what SgcLLEpochLanes with more than two lanes lowers): the knob holds the minimum over the live
-    overrides and returns to the value the first one found when the LAST one is released, in whatever order they go."""
-    from agcn_amd import engine
-    lib = amd._ffi.lib()
-    old = lib.agcn_get_coop_members()
-    try:
-        lib.agcn_set_coop_members(120)
-        mb = engine._MemberBudget()
-        a = mb.acquire(80)
-        assert lib.agcn_get_coop_members() == 80
-        b = mb.acquire(60)
-        assert lib.agcn_get_coop_members() == 60
-        mb.release(a)                                   # the first object closes first: the second one's budget stays
-        assert lib.agcn_get_coop_members() == 60
-        c = mb.acquire(100)
-        assert lib.agcn_get_coop_members() == 60
-        mb.release(b)
-        assert lib.agcn_get_coop_members() == 100
-        mb.release(b)                                   # (a late finaliser releasing twice changes nothing)
-        assert lib.agcn_get_coop_members() == 100
-        mb.release(c)
-        assert lib.agcn_get_coop_members() == 120
-        lib.agcn_set_coop_members(90)                   # a new base is read when the next first override is taken
-        d = mb.acquire(200)
-        assert lib.agcn_get_coop_members() == 90
-        mb.release(d)
-        assert lib.agcn_get_coop_members() == 90
-    finally:
-        lib.agcn_set_coop_members(old)
+def test_dispatch_flags_are_per_call_and_per_thread(amd):
+    """AgcnLayerDesc.flags (ABI 106): the kernel-selecting knobs as a per-call argument.  A field that is set overrides the
+    process default for THAT call only -- the process-wide value (agcn_get_*) never moves -- and two threads calling at the
+    same time with different flags each get their own dispatch (the override is thread-local inside the library).  Host
+    logic only (agcn_sgc_ll_dispatch_info)."""
+    import threading
+    from agcn_amd import synth
+    lib, ffi = amd._ffi.lib(), amd._ffi
+    n256 = synth.node_counts(np.random.RandomState(123), 256)
+    base = _dispatch(amd, n256, 75, 64, 1)
+    assert base["path"] & ~128 == 7 and base["f_members"] > 40
+    assert lib.agcn_get_coop_members() == 120 and lib.agcn_get_spec_mode() == 7 and lib.agcn_get_fused_mode() == 1
+    # member budget, members off, specialised kernels off, fused kernels off: each for one call
+    d = _dispatch(amd, n256, 75, 64, 1, flags=ffi.dispatch_flags(coop_members=40))
+    assert d["path"] & ~128 == 7 and 0 < d["f_members"] <= 40 and d["b_members"] <= 40
+    d = _dispatch(amd, n256, 75, 64, 1, flags=ffi.dispatch_flags(coop_members=0))
+    assert d["f_members"] == 0 and d["b_members"] == 0
+    d = _dispatch(amd, n256, 75, 64, 1, flags=ffi.dispatch_flags(spec_mode=3))
+    assert d["path"] & ~128 == 7 and d["f_members"] == 0 and d["b_members"] == 0 and d["f_paired"] == 0
+    assert _dispatch(amd, n256, 75, 64, 1, flags=ffi.dispatch_flags(spec_mode=0))["path"] == 4
+    assert _dispatch(amd, n256, 75, 64, 1, flags=ffi.dispatch_flags(fused_mode=0))["path"] in (16, 32)
+    assert _dispatch(amd, n256, 75, 64, 1, flags=ffi.dispatch_flags(fused_mode=0, slab_mode=0))["path"] == 32
+    # nothing process-wide moved, and a call without flags is the default dispatch again
+    assert lib.agcn_get_coop_members() == 120 and lib.agcn_get_spec_mode() == 7 and lib.agcn_get_fused_mode() == 1
+    assert lib.agcn_get_slab_mode() == 1
+    assert _dispatch(amd, n256, 75, 64, 1) == base
+    # the encoding: (value + 1) per field, 0 = not overridden; out-of-range values are refused on the Python side
+    assert ffi.dispatch_flags() == 0 and ffi.dispatch_flags(spec_mode=0) == 1 and ffi.dispatch_flags(fused_gb=-1) == 1 << 15
+    assert ffi.dispatch_flags(ffi.dispatch_flags(spec_mode=7), spec_mode=3) == 4
+    with pytest.raises(ValueError):
+        ffi.dispatch_flags(coop_members=121)
+    # two threads, different flags, many calls each, at the same time
+    want = {0: base["f_members"], 1: 0}
+    flags = {0: 0, 1: ffi.dispatch_flags(spec_mode=3)}
+    bad = []
+
+    def worker(k):
+        for _ in range(200):
+            got = _dispatch(amd, n256, 75, 64, 1, flags=flags[k])["f_members"]
+            if got != want[k]:
+                bad.append((k, got))
+    th = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad[:5]
+    # the Python context manager carries the flags into the descriptors this thread builds, and only inside the block
+    from agcn_amd import functional as fn
+    assert fn.current_flags() == 0
+    with amd.dispatch(spec_mode=3, coop_members=10):
+        assert fn.current_flags() == ffi.dispatch_flags(spec_mode=3, coop_members=10)
+        with amd.dispatch(spec_mode=7):
+            assert fn.current_flags() == ffi.dispatch_flags(spec_mode=7, coop_members=10)
+        assert fn.no_member_flags() & 15 == 4            # spec_mode 3 (+ 1)
+    assert fn.current_flags() == 0
+    assert fn.no_member_flags() & 15 == 4                # process default 7 -> 3
 
 
 def test_reserve_size_classes(amd):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Diagnostic: builds lib/libagcn_hip_stamps.so with -DAGCN_STAMPS (per-workgroup wall-clock stamps
+"""Diagnostic: builds tools/build/libagcn_hip_stamps.so (on demand: `--build`; not shipped in lib/) with -DAGCN_STAMPS (per-workgroup wall-clock stamps
 at phase boundaries), runs a few benchmark steps and prints, per kernel, the phase breakdown.
 Never used by the product, tests or bench.py."""
 import ctypes as C
@@ -11,11 +11,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "adaptive-graph-convolutional-network_amd")
-LIB = os.path.join(PKG, "lib", "libagcn_hip_stamps.so")
+LIB = os.path.join(ROOT, "tools", "build", "libagcn_hip_stamps.so")
 
 
 def build():
     src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.cpp")))
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17",
            "-DAGCN_STAMPS", "-fgpu-rdc", "-o", LIB] + src
     subprocess.check_call(cmd)
