@@ -63,7 +63,7 @@ class GraphStoreC(C.Structure):
 
 class ResidentStoreC(C.Structure):
     _fields_ = [("host", GraphStoreC), ("X_dev", C.c_void_p), ("rowptr_dev", C.c_void_p), ("col_dev", C.c_void_p),
-                ("val_dev", C.c_void_p), ("x_bf16", C.c_int32), ("reserved", C.c_int32)]
+                ("val_dev", C.c_void_p), ("x_bf16", C.c_int32), ("stage_bf16", C.c_int32)]
 
 
 class EpochBuffers(C.Structure):

@@ -30,14 +30,19 @@ struct GatherArgs {
   const int64_t* rowptr;
   const int32_t* col;
   const float* val;
-  float* X_out;
+  void* X_out;              // float rows, or bf16 rows (out_bf16)
   int32_t* rowptr_out;
   int32_t* col_out;
   float* val_out;
-  int32_t F, ldx_out, x_bf16;
+  int32_t F, ldx_out, x_bf16, out_bf16;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float v) {      // round to nearest even, NaN stays NaN (as spec_kernels.h: bf16_store)
+  uint32_t u = __float_as_uint(v);
+  u = ((u & 0x7fffffffu) > 0x7f800000u) ? (u | 0x00400000u) : u + 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
 
 // one workgroup per graph: contiguous segments in, contiguous segments out
 __global__ __launch_bounds__(256) void store_gather_kernel(GatherArgs a) {
@@ -53,13 +58,25 @@ __global__ __launch_bounds__(256) void store_gather_kernel(GatherArgs a) {
   const float* xs = static_cast<const float*>(a.X) + rc.src_row * F;
   const uint16_t* xh = static_cast<const uint16_t*>(a.X) + rc.src_row * F;
   const bool h = a.x_bf16 != 0;   // (uniform)
-  if (a.ldx_out == F) {
-    float* xd = a.X_out + (int64_t)r0 * F;
+  if (a.out_bf16) {               // (uniform) the staged rows stay bf16: the layer's kernels read them themselves (feat_dtype = bf16)
+    uint16_t* xo = static_cast<uint16_t*>(a.X_out);
+    if (a.ldx_out == F) {
+      uint16_t* xd = xo + (int64_t)r0 * F;
+      for (int i = tid; i < n * F; i += 256) xd[i] = h ? xh[i] : f32_to_bf16(xs[i]);
+    } else {
+      for (int i = tid; i < n * F; i += 256) {
+        const int r = i / F, f = i - r * F;
+        xo[(int64_t)(r0 + r) * a.ldx_out + f] = h ? xh[i] : f32_to_bf16(xs[i]);
+      }
+    }
+  } else if (a.ldx_out == F) {
+    float* xd = static_cast<float*>(a.X_out) + (int64_t)r0 * F;
     for (int i = tid; i < n * F; i += 256) xd[i] = h ? bf16_to_f32(xh[i]) : xs[i];
   } else {
+    float* xo = static_cast<float*>(a.X_out);
     for (int i = tid; i < n * F; i += 256) {
       const int r = i / F, f = i - r * F;
-      a.X_out[(int64_t)(r0 + r) * a.ldx_out + f] = h ? bf16_to_f32(xh[i]) : xs[i];
+      xo[(int64_t)(r0 + r) * a.ldx_out + f] = h ? bf16_to_f32(xh[i]) : xs[i];
     }
   }
   const int64_t shift = (int64_t)rc.dst_nnz - rc.src_nnz;
@@ -90,7 +107,7 @@ extern "C" size_t agcn_store_stage_bytes(int32_t B, int64_t rows) {
 }
 
 extern "C" int agcn_store_stage_batch(const AgcnResidentStore* st, const int64_t* ids, int32_t B, void* stage_host,
-                                      void* stage_dev, size_t stage_cap, float* X_out, int32_t ldx_out,
+                                      void* stage_dev, size_t stage_cap, void* X_out, int32_t ldx_out,
                                       int64_t rows_cap, int32_t* rowptr_out, int32_t* col_out, float* val_out,
                                       int64_t nnz_cap, AgcnStagedBatch* info, void* hip_stream) {
   using agcn::fail;
@@ -168,7 +185,7 @@ extern "C" int agcn_store_stage_batch(const AgcnResidentStore* st, const int64_t
   a.rec = reinterpret_cast<const agcn::GatherRec*>(d + tab_off);
   a.X = st->X_dev; a.rowptr = st->rowptr_dev; a.col = st->col_dev; a.val = st->val_dev;
   a.X_out = X_out; a.rowptr_out = rowptr_out; a.col_out = col_out; a.val_out = val_out;
-  a.F = h.F; a.ldx_out = ldx_out; a.x_bf16 = st->x_bf16 != 0 ? 1 : 0;
+  a.F = h.F; a.ldx_out = ldx_out; a.x_bf16 = st->x_bf16 != 0 ? 1 : 0; a.out_bf16 = st->stage_bf16 != 0 ? 1 : 0;
   hipLaunchKernelGGL(agcn::store_gather_kernel, dim3((unsigned)B), dim3(256), 0, s, a);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(AGCN_EDEVICE, "%s: gather launch: %s", who, hipGetErrorString(e));

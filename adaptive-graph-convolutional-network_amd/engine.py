@@ -227,25 +227,32 @@ class SgcLLEpochStep(object):
             ep.step(gb, dY=None)           # dY: [rows, Fout] upstream gradient (default: the static ones-filled one)
     """
 
-    def __init__(self, layer, rows_cap, tiles_cap, batch_cap, device=None, flags=None):
+    def __init__(self, layer, rows_cap, tiles_cap, batch_cap, device=None, flags=None, feat_dtype=torch.float32):
+        """`feat_dtype=torch.bfloat16`: X (the staged rows), Y, dY and dX are bf16 tensors read and written by the kernels
+        themselves (AgcnLayerDesc.feat_dtype; tiles, Laplacian, products and parameter gradients fp32) -- BASELINE.json's
+        "bf16 features + fp32 Laplacian"; the resident store must stage bf16 (`to_device(..., stage_dtype=torch.bfloat16)`)."""
         lib = _ffi.lib()
         self.lib, self.layer = lib, layer
         dev = torch.device(device if device is not None else layer._device)
         layer.build(dev)
         self.device = dev
         cfg = _Cfg(layer.n_atom_feature, layer.nb_filter, layer.K, layer.laplacian_mode, layer._variant,
-                   "relu" if layer.activation == "relu" else "linear")
+                   "relu" if layer.activation == "relu" else "linear", bf16=(feat_dtype == torch.bfloat16))
+        if feat_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("features are float32 or bfloat16")
+        self.feat_dtype = feat_dtype
         if cfg.variant != "SGC_LL":
             raise ValueError("SgcLLEpochStep drives SGC_LL layers")
         self.cfg = cfg
         self.paper = cfg.mode == "paper"
         self.rows_cap, self.tiles_cap, self.batch_cap = int(rows_cap), int(tiles_cap), int(batch_cap)
         f32 = dict(dtype=torch.float32, device=dev)
-        self._Y = torch.zeros((self.rows_cap, cfg.Fout), **f32)
+        fdt = dict(dtype=feat_dtype, device=dev)
+        self._Y = torch.zeros((self.rows_cap, cfg.Fout), **fdt)
         self._res_L = torch.zeros(self.tiles_cap, **f32)
         self._res_W = torch.zeros(self.tiles_cap, **f32)
-        self._dX = torch.zeros((self.rows_cap, cfg.Fin), **f32)
-        self._dY = torch.ones((self.rows_cap, cfg.Fout), **f32)
+        self._dX = torch.zeros((self.rows_cap, cfg.Fin), **fdt)
+        self._dY = torch.ones((self.rows_cap, cfg.Fout), **fdt)
         v = layer.vars
         sizes = [("weight", cfg.Fin * cfg.K * cfg.Fout), ("bias", cfg.Fout)]
         if self.paper:
@@ -295,11 +302,14 @@ class SgcLLEpochStep(object):
         """Forward + backward of `batch` on `stream` (a torch stream; default: the current one)."""
         plan = batch.plan
         X = batch.X
-        if (X.dtype != torch.float32 or not X.is_contiguous() or X.dim() != 2 or X.shape[1] != self.cfg.Fin
+        if (X.dtype != self.feat_dtype or not X.is_contiguous() or X.dim() != 2 or X.shape[1] != self.cfg.Fin
                 or X.shape[0] < plan.rows):
-            raise ValueError("node features must be contiguous fp32 [>= %d rows, Fin]" % plan.rows)
+            raise ValueError("node features must be contiguous %s [>= %d rows, Fin]" % (self.feat_dtype, plan.rows))
+        if self.feat_dtype == torch.bfloat16 and not (self._dispatch(batch)[0] & 256):
+            raise _ffi.AgcnError("this batch is not served with bf16 features by the specialised kernels (a molecule beyond the "
+                                 "members' reach): run it through step_ids (which converts inside the call) or in float32")
         rb = self._fit(plan)
-        if dY is not None and (dY.dtype != torch.float32 or not dY.is_contiguous() or dY.dim() != 2
+        if dY is not None and (dY.dtype != self.feat_dtype or not dY.is_contiguous() or dY.dim() != 2
                                or dY.shape[1] != self.cfg.Fout or dY.shape[0] < plan.rows):
             raise ValueError("dY must be contiguous fp32 [>= %d rows, Fout]" % plan.rows)
         gb = _gbatch(batch, X, None)
@@ -316,6 +326,11 @@ class SgcLLEpochStep(object):
         self._last = ("batch", batch, dY)
         return self
 
+    def _dispatch(self, batch):
+        out = (C.c_int32 * 8)()
+        _ffi.check(self.lib.agcn_sgc_ll_dispatch_info(C.byref(self.desc), C.byref(_gbatch(batch, batch.X, None)), out, 8))
+        return list(out)
+
     def step_ids(self, rstore, graph_ids, lane=0, dY=None, stream=None):
         """Stage the batch `graph_ids` out of the resident store `rstore` (lane `lane`'s buffers) and run forward + backward on
         it in ONE C-ABI call (include/agcn.h: agcn_epoch_step) -- no plan object, no size queries, no per-batch structs on
@@ -324,6 +339,8 @@ class SgcLLEpochStep(object):
         B = int(ids.size)
         if B > min(self.batch_cap, rstore.batch_cap):
             raise ValueError("batch of %d graphs exceeds the capacity" % B)
+        if rstore.stage_dtype != self.feat_dtype:
+            raise ValueError("the resident store stages %s rows, this step runs %s features" % (rstore.stage_dtype, self.feat_dtype))
         # (the pinned blobs of lane k: slots k, k + lanes, ... -- every lane rotates through its own, so that lanes driven from
         #  different host threads share nothing)
         nl = len(rstore.lanes)
@@ -536,8 +553,8 @@ class SgcLLEpochLanes(object):
             have = ((flags >> 24) & 255) - 1 if (flags >> 24) & 255 else _ffi.lib().agcn_get_coop_members()
             flags = _ffi.dispatch_flags(flags, coop_members=min(have, 240 // lanes))
         self.member_budget = ((flags >> 24) & 255) - 1 if (flags >> 24) & 255 else None
-        self.steps = [SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device, flags=flags)
-                      for _ in range(lanes)]
+        self.steps = [SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device, flags=flags,
+                                     feat_dtype=rstore.stage_dtype) for _ in range(lanes)]
         self.streams = _overlapping_streams(self.device, lanes)
         self._j = 0
         torch.cuda.synchronize(self.device)      # buffers, parameters and the store were filled on other streams
@@ -626,7 +643,8 @@ class SgcLLEpochPipeline(object):
         if len(rstore.lanes) < 2:
             raise ValueError("the pipeline needs a resident store with lanes >= 2 (two buffer sets)")
         self.rstore, self.device = rstore, rstore.device
-        self.step_obj = SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device)
+        self.step_obj = SgcLLEpochStep(layer, rstore.rows_cap, rstore.tiles_cap, rstore.batch_cap, device=self.device,
+                                       feat_dtype=rstore.stage_dtype)
         self.side = _overlapping_streams(self.device, 2)[1]
         self._staged = [torch.cuda.Event(), torch.cuda.Event()]     # staging of buffer set b has executed
         self._freed = [None, None]                                  # last compute that read buffer set b has executed

@@ -163,12 +163,14 @@ class dispatch(object):
 
 
 def no_member_flags(base=None):
-    """`base` (default: this thread's current flags) with the member workgroups switched off: every graph then runs in one
-    workgroup (or on the slab kernels) and no launch waits for another workgroup -- the dispatch a call is re-issued on
-    when a cooperative wait ran out."""
+    """`base` (default: this thread's current flags) with everything switched off in which one workgroup WAITS for another
+    inside a launch: the member workgroups that share a large graph (every graph then runs in one workgroup, or on the slab
+    kernels) and the tagged hand-off of the parameter-gradient kernel (the arrival-counter kernel instead: its last arriver
+    adds the partials, nobody polls) -- the dispatch a call is re-issued on when a bounded wait ran out."""
     base = current_flags() if base is None else int(base)
     sm = (base & 15) - 1 if (base & 15) else _ffi.lib().agcn_get_spec_mode()
-    return _ffi.dispatch_flags(base, spec_mode=sm & 3)
+    pg = ((base >> 7) & 3) - 1 if ((base >> 7) & 3) else _ffi.lib().agcn_get_param_grad_onepass()
+    return _ffi.dispatch_flags(base, spec_mode=sm & 3, pg_onepass=min(pg, 1))
 
 
 # how many calls were re-issued on the non-member dispatch after a cooperative wait ran out (engine.*.check(recover=True),
@@ -254,7 +256,8 @@ def run_checked(fn):
     out = fn()
     if device_timeouts() == 0:
         return out
-    with dispatch(spec_mode=(no_member_flags() & 15) - 1):
+    nm = no_member_flags()
+    with dispatch(spec_mode=(nm & 15) - 1, pg_onepass=((nm >> 7) & 3) - 1):
         out = fn()
     recovered_calls[0] += 1
     if device_timeouts() != 0:

@@ -137,10 +137,11 @@ class GraphStore(object):
         dev = torch.device(device)
         return self._upload(self._pack(graph_ids, slot, dev.type == "cuda", n_threads), dev)
 
-    def to_device(self, device, batch_cap, slots=4, lanes=1, dtype=torch.float32):
+    def to_device(self, device, batch_cap, slots=4, lanes=1, dtype=torch.float32, stage_dtype=torch.float32):
         """The store resident in HBM (`ResidentStore`): arrays uploaded once, batches gathered on the device.
-        dtype=torch.bfloat16 keeps the node features in bf16 at rest (rounded once, nearest-even)."""
-        return ResidentStore(self, device, batch_cap, slots, lanes, dtype)
+        dtype=torch.bfloat16 keeps the node features in bf16 at rest (rounded once, nearest-even); stage_dtype=torch.bfloat16
+        also hands them to the layer in bf16 (its kernels read and write bf16 rows themselves)."""
+        return ResidentStore(self, device, batch_cap, slots, lanes, dtype, stage_dtype)
 
     def _selections(self, batch_size, deterministic, rng):
         N = len(self)
@@ -217,9 +218,12 @@ class ResidentStore(object):
     order) and until `slots` further batches on the host side.  `lanes` > 1 keeps that many independent sets of
     capacity buffers, so that batches staged on different streams can be in flight together (`SgcLLEpochLanes`)."""
 
-    def __init__(self, store, device, batch_cap, slots=4, lanes=1, dtype=torch.float32):
+    def __init__(self, store, device, batch_cap, slots=4, lanes=1, dtype=torch.float32, stage_dtype=torch.float32):
+        """`dtype`: the features at rest in HBM; `stage_dtype`: what a staged batch holds -- float32 (bf16 at rest is widened by
+        the gather, the layer runs with fp32 features) or bfloat16 (the rows stay bf16, half the gather's bytes in and out: for
+        layer calls with bf16 features, `SgcLLEpochStep(..., feat_dtype=torch.bfloat16)` / an SGC_LL called on a bf16 tensor)."""
         dev = torch.device(device)
-        if dtype not in (torch.float32, torch.bfloat16):
+        if dtype not in (torch.float32, torch.bfloat16) or stage_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("node features are kept in float32 or bfloat16")
         if dev.type != "cuda":
             raise _ffi.AgcnError("a resident store lives on the GPU: there is no CPU fallback")
@@ -230,7 +234,7 @@ class ResidentStore(object):
         # bf16 at rest ("bf16 features + fp32 Laplacian"): rounded once here, widened by the gather;
         # every batch then carries float32(bf16(x)) and the layer computes in fp32
         self.X, self.rowptr = up(store.X).to(dtype), up(store.rowptr)
-        self.dtype = dtype
+        self.dtype, self.stage_dtype = dtype, stage_dtype
         self.col = up(store.col if store.col.size else np.zeros(1, np.int32))
         self.val = up(store.val if store.val.size else np.zeros(1, np.float32))
         # capacity of any batch of <= batch_cap graphs: the batch_cap largest graphs / Laplacians of the store
@@ -244,7 +248,7 @@ class ResidentStore(object):
         i32 = dict(dtype=torch.int32, device=dev)
         self.lanes = []
         for _ in range(max(1, int(lanes))):
-            ln = {"X": torch.zeros((self.rows_cap, self.F), dtype=torch.float32, device=dev),
+            ln = {"X": torch.zeros((self.rows_cap, self.F), dtype=stage_dtype, device=dev),
                   "rowptr": torch.zeros(self.rows_cap + 1, **i32), "col": torch.zeros(self.nnz_cap, **i32),
                   "val": torch.zeros(self.nnz_cap, dtype=torch.float32, device=dev),
                   "stage": torch.zeros(self.stage_cap, dtype=torch.uint8, device=dev)}
@@ -259,7 +263,8 @@ class ResidentStore(object):
         self._lane_k = [0] * len(self.lanes)      # (engine.SgcLLEpochStep.step_ids: every lane rotates through its own blobs)
         h = store._c
         self._c = _ffi.ResidentStoreC(h, self.X.data_ptr(), self.rowptr.data_ptr(), self.col.data_ptr(),
-                                      self.val.data_ptr(), 1 if dtype == torch.bfloat16 else 0, 0)
+                                      self.val.data_ptr(), 1 if dtype == torch.bfloat16 else 0,
+                                      1 if stage_dtype == torch.bfloat16 else 0)
         self._info = _ffi.StagedBatch()
 
     def __len__(self):

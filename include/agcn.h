@@ -437,9 +437,11 @@ typedef struct AgcnResidentStore {
   const int64_t* rowptr_dev; /* [R+1]   device copies of the CSR arrays */
   const int32_t* col_dev;
   const float* val_dev;
-  int32_t x_bf16;            /* 1: X_dev holds bfloat16 (features at rest in bf16, "bf16 features + fp32 Laplacian");
-                              * the gather widens them, X_out is always float32 */
-  int32_t reserved;
+  int32_t x_bf16;            /* 1: X_dev holds bfloat16 (features at rest in bf16, "bf16 features + fp32 Laplacian") */
+  int32_t stage_bf16;        /* 0: the gather writes float32 rows (bf16 at rest is widened: the layer then runs with fp32 features);
+                              * 1 (ABI 106): X_out is a BFLOAT16 buffer ([rows][ldx_out] elements) -- bf16 rows are copied as they
+                              * are (half the bytes in AND out), float32 rows are rounded to nearest even -- for a layer call with
+                              * AgcnLayerDesc.feat_dtype = AGCN_DTYPE_BF16 */
 } AgcnResidentStore;
 typedef struct AgcnStagedBatch {
   int64_t rows, nnz;
@@ -450,7 +452,7 @@ typedef struct AgcnStagedBatch {
 /* upper bound of the blob size for a batch of B graphs with `rows` rows in total */
 AGCN_API size_t agcn_store_stage_bytes(int32_t B, int64_t rows);
 AGCN_API int agcn_store_stage_batch(const AgcnResidentStore* store, const int64_t* ids, int32_t B, void* stage_host,
-                           void* stage_dev, size_t stage_cap, float* X_out, int32_t ldx_out, int64_t rows_cap,
+                           void* stage_dev, size_t stage_cap, void* X_out, int32_t ldx_out, int64_t rows_cap,
                            int32_t* rowptr_out, int32_t* col_out, float* val_out, int64_t nnz_cap,
                            AgcnStagedBatch* info, void* hip_stream);
 
@@ -469,6 +471,10 @@ typedef struct AgcnEpochBuffers {
   void* stage_host;          /* PINNED host blob (agcn_store_stage_bytes) */
   void* stage_dev;           /* its device twin */
   size_t stage_cap;
+  /* X, Y, dY, dX: float32, or BFLOAT16 buffers of the same shapes when desc->feat_dtype == AGCN_DTYPE_BF16 (the store must then
+   * stage bf16: AgcnResidentStore.stage_bf16 = 1; ABI 106).  A bf16 batch the specialised kernels do not serve (dispatch bit 256
+   * unset: a molecule beyond the members' reach) is converted inside the call -- four agcn_cast_rows launches around the fp32 layer
+   * kernels, scratch from `workspace` (counted in needs->workspace_bytes) --, the results are the same bf16 tensors */
   float* X; int32_t* rowptr; int32_t* col; float* val;   /* the staged batch: [rows_cap][Fin], [rows_cap + 1], [nnz_cap] x 2 */
   int64_t rows_cap, nnz_cap, tiles_cap;
   float *Y, *res_L, *res_W;  /* [rows_cap][Fout], [tiles_cap] x 2 */

@@ -31,7 +31,8 @@ def pytest_sessionfinish(session, exitstatus):
         return
     import json
     recs = [{"test": k[0], "tensor": k[1], "rtol": k[2], "ulps": k[3], "worst_over_bound": round(v["worst"], 4), "calls": v["calls"],
-             "fp32_oracle_over_bound": None if v["k32"] is None else round(v["k32"], 4), "calibration": round(v["calibration"], 3)}
+             "fp32_oracle_over_bound": None if v["k32"] is None else round(v["k32"], 4), "calibration": round(v["calibration"], 3),
+             "ulps_needed": None if v["ulps_needed"] is None else round(v["ulps_needed"], 3)}
             for k, v in sorted(helpers.MARGINS.items(), key=lambda kv: -kv[1]["worst"])]
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)

@@ -119,9 +119,10 @@ def capture_main(out):
     warm = torch.ones(4, device=dev)
     dist.all_reduce(warm)                                  # communicator set-up outside the capture
     torch.cuda.synchronize(dev)
-    st.capture(extra=lambda: dist.all_reduce(st.bucket, op=dist.ReduceOp.SUM), steps=2)
-    ok = True
-    for _ in range(3):
+    # TEN steps -- kernels and collective -- per graph launch, as bench.py's default for N > 1 captures them; ten replays
+    st.capture(extra=lambda: dist.all_reduce(st.bucket, op=dist.ReduceOp.SUM), steps=10)
+    ok = st.steps_per_replay == 10
+    for _ in range(10):
         st.bucket.zero_()
         st.replay()
         torch.cuda.synchronize(dev)

@@ -87,8 +87,9 @@ def test_dp_multilayer_step_one_bucket(flavour, tmp_path):
 
 
 def test_allreduce_captured_into_the_step_graph(tmp_path):
-    """`bench.py --graph-allreduce` on one GPU: a one-rank RCCL group, the bucket all-reduce captured into the HIP graph
-    behind the step (tests/dist_worker.py capture_main), three replays bit-identical to the eager bucket."""
+    """bench.py's default for N > 1 (`--graph-allreduce auto`) on one GPU: a one-rank RCCL group, the bucket all-reduce captured
+    into the HIP graph behind the step, TEN steps (kernels + collective) per graph launch (tests/dist_worker.py capture_main),
+    ten replays bit-identical to the eager bucket."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     out = str(tmp_path / "capture.npz")
@@ -114,6 +115,12 @@ def test_bench_launches_its_own_ranks():
     assert res.returncode == 0
     line = json.loads(res.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["value"] > 0
+    # the line says which collective library moved the bucket: "RCCL" only when the backend is nccl (two GPUs), never for the
+    # gloo self-test on a shared GPU
+    rccl = torch.cuda.device_count() >= 2
+    assert line["config"]["backend"] == ("nccl" if rccl else "gloo")
+    assert ("RCCL grad all-reduce" in line["config"]["workload"]) == rccl and ("gloo" in line["config"]["workload"]) == (not rccl)
+    assert line["config"]["allreduce"] in ("in_graph", "same stream, after the replay")
 
 
 @pytest.mark.parametrize("gpus,dtype", [(1, "f32"), (2, "bf16")])

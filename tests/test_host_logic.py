@@ -434,7 +434,7 @@ def test_dispatch_flags_are_per_call_and_per_thread(amd):
             assert fn.current_flags() == ffi.dispatch_flags(spec_mode=7, coop_members=10)
         assert fn.no_member_flags() & 15 == 4            # spec_mode 3 (+ 1)
     assert fn.current_flags() == 0
-    assert fn.no_member_flags() & 15 == 4                # process default 7 -> 3
+    assert fn.no_member_flags() == ffi.dispatch_flags(spec_mode=3, pg_onepass=1)     # process defaults 7 / 2 -> 3 / 1
 
 
 def test_reserve_size_classes(amd):
