@@ -396,7 +396,7 @@ SideStream& side_stream() {
   return ss;
 }
 
-struct ReserveLayout { size_t Z, s, scal, X, X0, Lpre, r, MT, WT, xch, total; };
+struct ReserveLayout { size_t Z, s, scal, X, X0, Lpre, r, MT, WT, WTI, xch, total; };
 ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   Carver c(nullptr);
   ReserveLayout r;
@@ -420,6 +420,10 @@ ReserveLayout reserve_layout(const AgcnLayerDesc* d, const AgcnPlanInfo& pi) {
   // transposed parameter copies (specialised kernels)
   r.MT = c.off; c.take((size_t)((d->Fin + 15) & ~15) * d->Fin);      // k-blocked: [F4 / 4][Fin][4], zero beyond Fin
   r.WT = c.off; c.take((size_t)d->K * d->Fout * d->Fin);
+  // bf16 features (spec_bfpipe.h): W^T as a three-piece image in MFMA operand order for the backward's filter adjoint
+  r.WTI = c.off;
+  if (d->K == 2 && d->Fout == 64)
+    c.take((size_t)d->K * (d->Fout / 32) * (((d->Fin + 15) & ~15) / 16) * 768);
   r.total = c.off;
   return r;
 }
@@ -715,6 +719,8 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
+  a.sv_WTI = (desc->K == 2 && desc->Fout == 64 && (knob_bfpipe() & (a.feat_bf16 ? 4 : 8)) &&
+              (reinterpret_cast<uintptr_t>(params->weight) & 15) == 0) ? static_cast<void*>(rb + rl.WTI) : nullptr;
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
   a.dev_status = current_device_info().status_word;
   a.coop_ticks = agcn_get_coop_timeout_ticks();
@@ -765,6 +771,17 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
         a.tp_first = std::max(cg, B - 32);   // (cg < B: the last graph of the schedule is never spread over members)
         size_t lds = spec_fwd_lds_bytes(host.n[host.order[cg]], desc->Fin, desc->Fout, spec::NW_LARGE);
         if (cs > 0) lds = std::max(lds, spec_coop_fwd_lds_bytes(host.n[host.order[0]], desc->Fin));
+        // bf16 pipe (spec_bfpipe.h): room for the piece planes + parameter image of the largest member graph that fits with them
+        // (a member decides for itself against the launch's LDS size: larger graphs keep the fp32 matrix instruction)
+        // (off by default, errors.cpp knob_bfpipe: the phase gains what the image build and the larger launch LDS cost)
+        a.bfp_fwd = (knob_bfpipe() & (a.feat_bf16 ? 1 : 2)) != 0 ? 1 : 0;
+        if (a.bfp_fwd && cs > 0) {
+          const size_t lim = (size_t)agcn_get_lds_limit();
+          for (int g = 0; g < cg; ++g) {
+            const size_t want = spec_coop_fwd_lds_bytes_bfp(host.n[host.order[g]], desc->Fin, a.feat_bf16 ? 1 : 3);
+            if (want <= lim) { lds = std::max(lds, want); break; }     // (largest first)
+          }
+        }
         if (dg > 0) {   // the dg smallest graphs, two to a workgroup
           const size_t half = spec_fwd_lds_bytes(host.n[host.order[B - dg]], desc->Fin, desc->Fout, spec::NW_SMALL);
           a.dual_pairs = dg / 2;
@@ -953,6 +970,8 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   a.sv_Lpre = reslap ? reinterpret_cast<float*>(rb + rl.Lpre) : nullptr;
   a.sv_MT = reinterpret_cast<float*>(rb + rl.MT);
   a.sv_WT = reinterpret_cast<float*>(rb + rl.WT);
+  a.sv_WTI = (desc->K == 2 && desc->Fout == 64 && (knob_bfpipe() & (a.feat_bf16 ? 4 : 8)) &&
+              (reinterpret_cast<uintptr_t>(params->weight) & 15) == 0) ? static_cast<void*>(rb + rl.WTI) : nullptr;
   a.sv_xch = reinterpret_cast<uint64_t*>(rb + rl.xch);
   a.dev_status = current_device_info().status_word;
   a.coop_ticks = agcn_get_coop_timeout_ticks();
@@ -1121,13 +1140,20 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
       }
       {
         const int f0 = std::max(sf, first_plain);
-        size_t lds = f0 < B ? spec_bwd_lds_bytes(host.n[host.order[f0]], desc->Fin, desc->Fout, spec::NW_LARGE) : 0;
-        if (coop_slabs > 0) lds = std::max(lds, spec_coop_lds_bytes(host.n[host.order[0]], desc->Fin, desc->Fout));
-        if (dual_graphs > 0) {
-          const size_t half = spec_bwd_lds_bytes(host.n[host.order[B - dual_graphs]], desc->Fin, desc->Fout, spec::NW_SMALL);
-          a.dual_pairs = dual_graphs / 2;
-          a.dual_stride = (int32_t)(half / sizeof(float));
-          lds = std::max(lds, 2 * half);
+        // phase G on the bf16 pipe (spec_bfpipe.h) where the forward left the W^T piece image: bf16 features one piece plane in
+        // the place of the fp32 image; fp32 features THREE planes -- more LDS: only when every body of this launch still fits
+        size_t lds = 0;
+        for (int gnp = a.sv_WTI ? (a.feat_bf16 ? 1 : 3) : 0;; gnp = 0) {
+          lds = f0 < B ? spec_bwd_lds_bytes(host.n[host.order[f0]], desc->Fin, desc->Fout, spec::NW_LARGE, gnp) : 0;
+          if (coop_slabs > 0) lds = std::max(lds, spec_coop_lds_bytes(host.n[host.order[0]], desc->Fin, desc->Fout, gnp));
+          if (dual_graphs > 0) {
+            const size_t half = spec_bwd_lds_bytes(host.n[host.order[B - dual_graphs]], desc->Fin, desc->Fout, spec::NW_SMALL, gnp);
+            a.dual_pairs = dual_graphs / 2;
+            a.dual_stride = (int32_t)(half / sizeof(float));
+            lds = std::max(lds, 2 * half);
+          }
+          a.g_np = gnp;
+          if (gnp == 0 || lds <= (size_t)agcn_get_lds_limit()) break;
         }
         rc = launch_spec_backward(a, f0, ss - f0 - dual_graphs, lds, spec::NW_LARGE, conc ? side->s : main_s);
       }

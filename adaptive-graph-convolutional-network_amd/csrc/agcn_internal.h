@@ -40,6 +40,7 @@ int32_t knob_slab_mode();
 int32_t knob_fused_gb();
 int32_t knob_spec_tail();
 int32_t knob_coop_members();
+int32_t knob_bfpipe();
 
 // Leading dimensions of on-chip images, chosen so that MFMA fragment reads are LDS
 // bank-conflict free:

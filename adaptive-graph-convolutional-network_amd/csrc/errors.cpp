@@ -118,6 +118,22 @@ int32_t knob_rows_split() { const int32_t f = field(11, 3u); return f ? clampi(f
 int32_t knob_slab_mode() { const int32_t f = field(13, 3u); return f ? clampi(f - 1, 0, 1) : g_slab_mode.load(); }
 int32_t knob_fused_gb() { const int32_t f = field(15, 3u); return f ? clampi(f - 2, -1, 1) : g_fused_gb.load(); }
 int32_t knob_spec_tail() { const int32_t f = field(17, 3u); return f ? clampi(f - 1, 0, 1) : g_spec_tail.load(); }
+// AGCN_BFPIPE (environment, read once; A/B measurements): bit mask of the per-graph kernels' feature contractions that run on the
+// bf16 matrix pipe at fp32 accuracy (csrc/spec_bfpipe.h).
+//   bit 2 (value 4, DEFAULT): the filter adjoint [g_0 | g_1] = Gp W^T of the backward for calls with bf16 features -- Gp is one
+//          bf16 piece, W^T a three-piece image in MFMA operand order that the forward's last blocks leave in the reserve: three
+//          v_mfma_f32_16x16x32_bf16 per 32 k.  Measured (HIV-shaped 256-molecule step, profiles/EXPERIMENTS.md round 6): the phase
+//          2.04 -> 0.49 us in the one-workgroup bodies, 2.98 -> 1.48 us in the members; the bf16 step 69.9 -> 67.5 us.
+//   bit 3 (value 8, DEFAULT): the same phase for calls with fp32 features: Gp split exactly into three bf16 piece planes in LDS (six
+//          instructions per 32 k), where the launch's bodies still fit their LDS with the planes.
+//   bit 0 (value 1): Z = X M_L of the member workgroups' forward for calls with bf16 features, parameter image built in LDS by each
+//          member.  Off: the phase itself goes 3.5 -> 1.8 us, but the image costs 1.0-1.5 us of LDS stores per member and the
+//          launch's larger dynamic LDS (up to 140 KB for every workgroup) keeps two small graphs from sharing a CU: step + 1 us.
+//   bit 1 (value 2): the same for fp32 features (three piece planes): level with the fp32 instruction.  Off.
+int32_t knob_bfpipe() {
+  static const int32_t v = [] { const char* e = std::getenv("AGCN_BFPIPE"); return e ? (int32_t)std::atoi(e) : 12; }();
+  return v;
+}
 int32_t knob_coop_members() { const int32_t f = field(24, 255u); return f ? clampi(f - 1, 0, 120) : g_coop_members.load(); }
 
 // One workgroup per graph: with few graphs per CU, 16 waves per graph hide the memory latency of

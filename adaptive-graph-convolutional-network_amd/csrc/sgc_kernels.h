@@ -63,6 +63,16 @@ struct SgcArgs {
   int32_t plain_count;  // the next plain_count one graph each, the rest TWO small graphs each (spec_forward.hip)
   int32_t dual_stride;  // floats of LDS between the two halves of such a workgroup
   int32_t dual_pairs;   // number of such workgroups (set by the caller; plain_count is set by the launcher)
+  // feature contractions of the specialised kernels on the bf16 matrix pipe at fp32 accuracy (spec_bfpipe.h): bit 0 = Z = X M_L of
+  // the forward; a workgroup takes it where its piece planes + parameter image fit `lds_bytes` (the launch's dynamic LDS)
+  int32_t bfp_fwd;
+  int32_t lds_bytes;
+  // bf16 features: the adjoint of the filter, [g_0 | g_1] = Gp W^T, on the bf16 pipe -- Gp = dY act'(Y) is ONE bf16 piece per
+  // element there, W^T comes as a three-piece image in MFMA operand order that the forward's last blocks leave in the reserve
+  // beside the fp32 copies: tiles [K][Fout / 32][F4 / 16] x (3 pieces x 64 lanes x 16 bytes); nullptr: fp32 matrix instruction
+  void* sv_WTI;
+  int32_t g_np;       // backward: 0 = that phase on the fp32 instruction; 1 = bf16 features (Gp one piece); 3 = fp32 features (Gp split
+                      // into three piece planes: more LDS, decided per launch by the host)
   // global-tile mode scratch
   float* ws_tile;  // [wtile_off[B]]
   float* ws_buf;   // per-graph image scratch, see graph_scratch_floats()

@@ -41,10 +41,17 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   const GraphRec g = load_graph(a.graph_desc + gpos);
   const int n = g.n, row0 = g.row0;
   const uint32_t toff = g.toff;
-  const BwdLds d = bwd_lds(n, F4, FOUT, NW);
+  // phase G on the bf16 pipe (spec_bfpipe.h; a.g_np: 1 = bf16 features, Gp is one piece; 3 = fp32 features, three piece planes)
+  // -- FOUT = 64: 48 registers of image pieces in flight; not in the 8-wave launch of its own (batches of >= 1024 graphs), which
+  // is held to 80 registers
+  const int gnp = (FOUT == 64 && (NW == NW_LARGE || DUAL)) ? a.g_np : 0;      // (launch argument: uniform)
+  const BwdLds d = bwd_lds(n, F4, FOUT, NW, gnp);
   const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
   const bool paper = a.mode == AGCN_MODE_PAPER;
   const bool relu = a.activation == AGCN_ACT_RELU;
+  const bool gbf = gnp != 0;
+  constexpr int SGP = bfp_stride(FOUT);                 // row stride of the Gp plane, dwords
+  constexpr int KBW = FOUT / 32;
   float* red = smem;
   float* s_vec = smem + d.o_s;
   float* ddv = smem + d.o_dd;
@@ -118,7 +125,19 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       }
     }
   });
-  if (t1a < t1b) load_wc(wb0, t1a, 0, 0);
+  u32x4 bpa[KBW][3], bpb[KBW][3];          // (gbf) the three pieces of the KBW k-blocks of one (tile, Chebyshev term), two buffers
+  auto load_bp = [&](u32x4 (&bp)[KBW][3], int t, int kk) {
+    const u32x4* img = static_cast<const u32x4*>(a.sv_WTI);
+#pragma unroll
+    for (int kb = 0; kb < KBW; ++kb) {
+      const u32x4* bt = img + (size_t)((kk * KBW + kb) * NCB + t % NCB) * 192 + lane;
+      bp[kb][0] = bt[0]; bp[kb][1] = bt[64]; bp[kb][2] = bt[128];
+    }
+  };
+  if (t1a < t1b) {
+    if (gbf) load_bp(bpa, t1a, 0);
+    else load_wc(wb0, t1a, 0, 0);
+  }
   // r tile rows (the forward stored r_ij for i < j)
   float rr[RPW][2];
 #pragma unroll
@@ -166,7 +185,11 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         yy[u][cp] = bf16_widen(yy[u][cp]);
       }
   }
+  uint32_t* GPpl = reinterpret_cast<uint32_t*>(GPimg);
+  const int gplane = n4 * SGP;
   // Gp = dY . act'(Y) -> image (A operand of phase G); kept in registers for the hand-off store at the end
+  // bf16 features + the W^T piece image of the forward (a.sv_WTI): Gp is bf16 data, ONE piece -- phase G runs on the bf16 pipe
+  // (spec_bfpipe.h) and the image is a plane of bf16 rows (in the place of the fp32 image: smaller)
   float gpv[RPW][CPO];
 #pragma unroll
   for (int u = 0; u < RPW; ++u) {
@@ -176,7 +199,16 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       const int c = lane + 64 * cp;
       const float v = (i < n && c < FOUT && (!relu || yy[u][cp] > 0.f)) ? gy[u][cp] : 0.f;
       gpv[u][cp] = v;
-      if (i < n4 && c < FOUT) GPimg[i * LDG + c] = v;
+      if (!gbf && i < n4 && c < FOUT) GPimg[i * LDG + c] = v;
+    }
+    if (gbf) {   // (uniform) two adjacent columns per lane, one 4-byte store
+      float lo, hi;
+      int col;
+      bfp_pair_columns<(CPO > 1)>(gpv[u][0], gpv[u][CPO > 1 ? 1 : 0], lane, lo, hi, col);
+      if (i < n4 && col >= 0 && col < FOUT) {
+        if (gnp == 3) bfp_store_pair<3>(GPpl, gplane, i * SGP + (col >> 1), lo, hi);
+        else bfp_store_pair<1>(GPpl, 0, i * SGP + (col >> 1), lo, hi);
+      }
     }
   }
   // r tile: mirrored, diagonal 0
@@ -255,6 +287,32 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       for (int u = 0; u < CHW; ++u) acc = kb_mma(acc, Ap, CHW * ch + u, q, wf[u]);
       return acc;
     };
+    if (gbf) {   // (uniform) bf16 pipe: three products per 32 k against the image's pieces (16-byte loads, one (tile, term) ahead)
+      auto mma_bp = [&](f32x4 acc, const u32x4 (&bp)[KBW][3], const uint32_t* arow) {
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) acc = bfp_mma_regs(acc, arow, gplane, gnp, kb, q, bp[kb]);
+        return acc;
+      };
+#pragma unroll
+      for (int sl = 0; sl < MAXTB; ++sl) {
+        const int t = t1a + sl;
+        if (t < t1b) {
+          const int rt = t / NCB, cb = t - rt * NCB;
+          const uint32_t* arow = GPpl + (rt * 16 + r) * SGP;
+          // step 2 sl (term 0) reads buffer a, step 2 sl + 1 (term 1) buffer b; each requests the next step's pieces first
+          load_bp(bpb, t, 1);
+          const f32x4 a0 = mma_bp((f32x4){0.f, 0.f, 0.f, 0.f}, bpa, arow);
+          if (t + 1 < t1b) load_bp(bpa, t + 1, 0);
+          const f32x4 a1 = mma_bp((f32x4){0.f, 0.f, 0.f, 0.f}, bpb, arow);
+          dxacc[sl] = a0;
+          const int f = cb * 16 + r;
+          float* dst = G1img + (rt * 16 + 4 * q) * LDX + f;
+          const bool fv = f < FIN;
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? a1[i4] : 0.f;
+        }
+      }
+    } else
 #pragma unroll
     for (int sl = 0; sl < MAXTB; ++sl) {
       const int t = t1a + sl;
@@ -733,17 +791,17 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
 
 // LDS bytes of the backward kernel for a largest graph of n nodes; SIZE_MAX when a wave would own more tiles (or
 // node-feature rows) than its register arrays hold
-size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw) {
+size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw, int32_t gnp) {
   const int F4 = (Fin + 15) & ~15, ntm = (n + 15) / 16;
   const int lim = spec::MAXTB * nw;
   if (ntm * (F4 / 16) > lim || ntm * ntm > lim || ntm * 16 > (nw == spec::NW_SMALL ? 6 : 8) * nw) return ~(size_t)0;
   if (nw == spec::NW_SMALL && n > spec::SMALL_N) return ~(size_t)0;
-  return sizeof(float) * (size_t)spec::bwd_lds(n, F4, Fout, nw).total;
+  return sizeof(float) * (size_t)spec::bwd_lds(n, F4, Fout, nw, gnp).total;
 }
 
 // LDS bytes of a member of the cooperative backward for a graph of n nodes
-size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout) {
-  return sizeof(float) * (size_t)spec::coop_lds(n, (Fin + 15) & ~15, Fout).total;
+size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t gnp) {
+  return sizeof(float) * (size_t)spec::coop_lds(n, (Fin + 15) & ~15, Fout, gnp).total;
 }
 
 template <int FIN, int FOUT, int NW>

@@ -25,6 +25,7 @@
 #include <float.h>
 
 #include "spec_kernels.h"
+#include "spec_bfpipe.h"
 
 namespace agcn {
 namespace spec {
@@ -111,7 +112,7 @@ struct CoopLds {
 // least as long as an image row (n4 >= F4: the large graphs, the only ones whose plan is tight) the g_0 rows (M2 -> M3) live in
 // the dL row strip (written from M4 on) and the dZ rows (M7 -> M8) in the L^T / dL column strip (last read in M6).  That is what
 // lets a 128-node graph fit at 128 input features (159 KB), 176 nodes at 75 -> 64 and 160 at 64 -> 128.
-AGCN_HD inline CoopLds coop_lds(int n, int F4, int Fout) {
+AGCN_HD inline CoopLds coop_lds(int n, int F4, int Fout, int gnp = 0) {
   CoopLds d;
   d.n4 = (n + 15) & ~15;
   d.ldt = d.n4 + 2;
@@ -132,8 +133,8 @@ AGCN_HD inline CoopLds coop_lds(int n, int F4, int Fout) {
     next += 16 * ldx;
   }
   d.o_g1 = next;                         // [n4][ldx]  g_1 (all rows), later Z (all rows)
-  d.o_u = d.o_g1 + d.n4 * ldx;           // [n4][ldg]  Gp (all rows), later [n4][ldx] X_0 (all rows)
-  const int gp = d.n4 * ldg, x = d.n4 * ldx;
+  d.o_u = d.o_g1 + d.n4 * ldx;           // [n4][ldg]  Gp (all rows; gnp = 3: three bf16 piece planes), later [n4][ldx] X_0 (all rows)
+  const int gp = gnp == 3 ? 3 * d.n4 * bfp_stride(Fout) : d.n4 * ldg, x = d.n4 * ldx;
   d.total = d.o_u + (gp > x ? gp : x);
   return d;
 }
@@ -164,7 +165,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const int b = uni(a.slab_graph[sl]), i0 = uni(a.slab_row[sl]);
   const int n = uni(a.n[b]), row0 = uni(a.row_off[b]);
   const uint32_t toff = (uint32_t)a.tile_off[b];
-  const CoopLds d = coop_lds(n, F4, FOUT);
+  const CoopLds d = coop_lds(n, F4, FOUT, a.g_np);
   const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
   const int me = i0 >> 4;                      // member index == this strip's row tile
   const bool relu = a.activation == AGCN_ACT_RELU;
@@ -275,15 +276,33 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   float gpown[CPO];   // Gp row i0 + wave (this wave loaded it: rows wave, wave + 16, ..), for the hand-off store
 #pragma unroll
   for (int cp = 0; cp < CPO; ++cp) gpown[cp] = 0.f;
+  // bf16 features + the W^T piece image of the forward: Gp is ONE bf16 piece, phase M2 runs on the bf16 pipe (spec_bfpipe.h) and
+  // the image is a plane of bf16 rows in the place of the fp32 one
+  const int gnp = FOUT == 64 ? a.g_np : 0;              // (launch argument: uniform) 0: fp32 instruction; 1 | 3 piece planes
+  const bool gbf = gnp != 0;
+  constexpr int SGP = bfp_stride(FOUT), KBW = FOUT / 32;
+  uint32_t* GPpl = reinterpret_cast<uint32_t*>(GPimg);
+  const int gplane = n4 * SGP;
 #pragma unroll
   for (int u = 0; u < RPW; ++u) {
     const int i = wave + NW * u;
+    float vv[CPO];
 #pragma unroll
     for (int cp = 0; cp < CPO; ++cp) {
       const int c = lane + 64 * cp;
       const float v = (i < n && c < FOUT && (!relu || yy[u][cp] > 0.f)) ? gy[u][cp] : 0.f;
+      vv[cp] = v;
       if (u == me) gpown[cp] = v;
-      if (i < n4 && c < FOUT) GPimg[i * LDG + c] = v;
+      if (!gbf && i < n4 && c < FOUT) GPimg[i * LDG + c] = v;
+    }
+    if (gbf) {
+      float lo, hi;
+      int col;
+      bfp_pair_columns<(CPO > 1)>(vv[0], vv[CPO > 1 ? 1 : 0], lane, lo, hi, col);
+      if (i < n4 && col >= 0 && col < FOUT) {
+        if (gnp == 3) bfp_store_pair<3>(GPpl, gplane, i * SGP + (col >> 1), lo, hi);
+        else bfp_store_pair<1>(GPpl, 0, i * SGP + (col >> 1), lo, hi);
+      }
     }
   }
   {
@@ -347,6 +366,41 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     constexpr int CHW = 4, NCHW = NKW / (4 * CHW);   // 16-k blocks per chunk (spec_kernels.h: kb_frag / kb_mma)
     int ta, tb;
     tile_range<NW>((ntm + 1) * NCB, wave, ta, tb);
+    if (gbf) {   // (uniform) three products per 32 k against the image's pieces, the next tile's pieces requested first
+      const u32x4* img = static_cast<const u32x4*>(a.sv_WTI);
+      u32x4 bpa[KBW][3], bpb[KBW][3];
+      auto load_bp = [&](u32x4 (&bp)[KBW][3], int t) {
+        const bool own = t >= ntm * NCB;
+        const int cb = own ? t - ntm * NCB : t % NCB, kk = own ? 0 : 1;
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) {
+          const u32x4* bt = img + (size_t)((kk * KBW + kb) * NCB + cb) * 192 + lane;
+          bp[kb][0] = bt[0]; bp[kb][1] = bt[64]; bp[kb][2] = bt[128];
+        }
+      };
+      auto tile = [&](const u32x4 (&bp)[KBW][3], int t) {
+        const bool own = t >= ntm * NCB;
+        const int rt = own ? me : t / NCB, cb = own ? t - ntm * NCB : t - rt * NCB;
+        const uint32_t* arow = GPpl + (rt * 16 + r) * SGP;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBW; ++kb) acc = bfp_mma_regs(acc, arow, gplane, gnp, kb, q, bp[kb]);
+        const int f = cb * 16 + r;
+        const bool fv = f < FIN;
+        float* dst = own ? G0img + (4 * q) * LDX + f : G1img + (rt * 16 + 4 * q) * LDX + f;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) dst[i4 * LDX] = fv ? acc[i4] : 0.f;
+      };
+      if (ta < tb) load_bp(bpa, ta);
+      for (int t = ta; t < tb; t += 2) {
+        if (t + 1 < tb) load_bp(bpb, t + 1);
+        tile(bpa, t);
+        if (t + 1 < tb) {
+          if (t + 2 < tb) load_bp(bpa, t + 2);
+          tile(bpb, t + 1);
+        }
+      }
+    } else
     for (int t = ta; t < tb; ++t) {
       const bool own = t >= ntm * NCB;            // a g_0 tile of the strip
       const int rt = own ? me : t / NCB, cb = own ? t - ntm * NCB : t - rt * NCB;
@@ -751,8 +805,11 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 struct CoopFwdLds {
   int n4, ldt, ldz;
   int o_s, o_st, o_x, o_z, o_x1, total;
+  int o_xp, o_mi, xp_plane;   // np > 0 (spec_bfpipe.h): the bf16 piece planes of X [np][n4][S] and the operand-order image of M_L (dwords)
 };
-AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4) {
+// np = 0: Z = X M_L on the fp32 matrix instruction (parameter fragments from global memory); np = 1 | 3: on the bf16 pipe
+// (spec_bfpipe.h), X as np piece planes (1: bf16 features, 3: fp32 features split exactly) + the M_L image, both in LDS
+AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4, int np = 0) {
   CoopFwdLds d;
   d.n4 = (n + 15) & ~15;
   d.ldt = d.n4 + 2;
@@ -764,6 +821,15 @@ AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4) {
   d.o_z = d.o_x + d.n4 * ldx;         // [F4][ldz]  Z^T (all rows)
   d.o_x1 = d.o_z + F4 * d.ldz;        // [16][ldx]  X_1 rows of the strip
   d.total = d.o_x1 + 16 * ldx;
+  d.o_xp = d.o_mi = d.xp_plane = 0;
+  if (np > 0) {
+    const int KP = bfp_kp(F4);
+    d.total = (d.total + 3) & ~3;       // (16-byte aligned: the planes and the image are read with ds_read_b128)
+    d.xp_plane = d.n4 * bfp_stride(KP);
+    d.o_xp = d.total;
+    d.o_mi = d.o_xp + np * d.xp_plane;
+    d.total = d.o_mi + bfp_image_dwords(KP, F4);
+  }
   return d;
 }
 
@@ -788,11 +854,18 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   const int b = uni(a.slab_graph[sl]), i0 = uni(a.slab_row[sl]);
   const int n = uni(a.n[b]), row0 = uni(a.row_off[b]);
   const uint32_t toff = (uint32_t)a.tile_off[b];
-  const CoopFwdLds d = coop_fwd_lds(n, F4);
+  // Z = X M_L on the bf16 pipe (spec_bfpipe.h) where this graph's planes + the M_L image fit the launch's LDS
+  constexpr int KP = bfp_kp(F4), SXP = bfp_stride(KP);
+  int np = a.bfp_fwd ? (a.feat_bf16 ? 1 : 3) : 0;
+  if (np > 0 && (size_t)coop_fwd_lds(n, F4, np).total * sizeof(float) > (size_t)a.lds_bytes) np = 0;
+  np = uni(np);
+  const CoopFwdLds d = coop_fwd_lds(n, F4, np);
   const int n4 = d.n4, ldt = d.ldt, ldz = d.ldz, ntm = n4 >> 4;
   const int me = i0 >> 4;
   const bool relu = a.activation == AGCN_ACT_RELU;
   const bool paper = a.mode == AGCN_MODE_PAPER;   // (reference mode: R = I, nothing to exchange)
+  uint16_t* XPh = reinterpret_cast<uint16_t*>(smem + d.o_xp);
+  u32x4* MI = reinterpret_cast<u32x4*>(smem + d.o_mi);
   float* s_vec = smem + d.o_s;
   float* St = smem + d.o_st;
   float* Ximg = smem + d.o_x;
@@ -814,6 +887,10 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     csr_p0 = a.L0_rowptr[row0 + i0 + tid];
     csr_p1 = a.L0_rowptr[row0 + i0 + tid + 1];
   }
+  // (bf16 pipe) this thread's eight values of the M_L image, requested with the first round of loads
+  constexpr int MI_THREADS = (KP / 32) * (F4 / 16) * 64;
+  float mlv[8];
+  if (np > 0) bfp_load_param<FIN, FIN, KP, F4>(mlv, a.M_L, FIN, 1, tid);      // (uniform branch; every thread loads, clamped)
   for (int ib = wave; ib < n4; ib += 4 * NW) {
     float xr[4][CP];
     by_dtype(a.feat_bf16 != 0, [&](auto BF) {
@@ -837,9 +914,22 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
           const int c = lane + 64 * cp;
           if (c < F4) Ximg[i * LDX + c] = (i < n && c < FIN) ? xr[u][cp] : 0.f;
         }
+        if (np > 0) {   // (uniform) the same rows as bf16 piece planes, zero beyond the last feature / the last node
+          const float v0 = (i < n && lane < FIN) ? xr[u][0] : 0.f;
+          const float v1 = (CP > 1 && i < n && lane + 64 < FIN) ? xr[u][CP > 1 ? 1 : 0] : 0.f;
+          float lo, hi;
+          int col;
+          bfp_pair_columns<(CP > 1)>(v0, v1, lane, lo, hi, col);
+          if (col >= 0 && col < KP) {
+            uint32_t* XPw = reinterpret_cast<uint32_t*>(XPh);
+            if (np == 1) bfp_store_pair<1>(XPw, d.xp_plane, i * SXP + (col >> 1), lo, hi);
+            else bfp_store_pair<3>(XPw, d.xp_plane, i * SXP + (col >> 1), lo, hi);
+          }
+        }
       }
     }
   }
+  if (np > 0 && tid < MI_THREADS) bfp_store_param<FIN, FIN, KP, F4>(MI, mlv, tid);
   // Reslap: the strip's rows of L_prev (wave il = row i0 + il), requested with the first round of loads
   float lprv[NCP] = {};
   if constexpr (RESLAP) {
@@ -870,14 +960,23 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     tile_range<NW>(ntm * NCB, wave, ta, tb);
     for (int t = ta; t < tb; ++t) {
       const int rt = t / NCB, cb = t - rt * NCB;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (np > 0) {   // (uniform) bf16 pipe: A pieces from the planes, B pieces from the image, both 16-byte LDS reads
+        const uint32_t* arow = reinterpret_cast<const uint32_t*>(XPh) + (rt * 16 + r) * SXP;
+#pragma unroll
+        for (int kb = 0; kb < KP / 32; ++kb) {
+          const u32x4* bt = MI + (size_t)(kb * NCB + cb) * 192;
+          acc = np == 1 ? bfp_mma<1>(acc, arow, d.xp_plane, kb, q, bt, lane) : bfp_mma<3>(acc, arow, d.xp_plane, kb, q, bt, lane);
+        }
+      } else {
       const float* p = mq + min(cb * 16 + r, FIN - 1);
       float bf[NKS];
 #pragma unroll
       for (int u = 0; u < NKS; ++u) bf[u] = (4 * u + 3 < FIN) ? p[4 * u * FIN] : p[(min(4 * u + q, FIN - 1) - q) * FIN];
       const float* Ap = Ximg + (rt * 16 + r) * LDX + q;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
+      }
       const int c = cb * 16 + r, ib = rt * 16 + 4 * q;
       if (c < FIN) {
         *reinterpret_cast<f32x4*>(Zt + c * ldz + ib) = acc;

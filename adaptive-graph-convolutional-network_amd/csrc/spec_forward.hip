@@ -492,6 +492,25 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         const int f = rem2 >> 2, c = 4 * cg + (rem2 & 3);
         a.sv_WT[e] = a.weight[(f * 2 + kk) * FOUT + c];
       }
+      // bf16 features: W^T once more as a THREE-PIECE image in MFMA operand order for the backward's filter adjoint on the bf16
+      // pipe (spec_bfpipe.h): tile (kk, kb, ct), lane (r, q) holds B[k = 32 kb + 8 q + j][f = 16 ct + r] = W[f K + kk][k], j = 0 .. 7
+      // -- eight consecutive floats of one row of W (two 16-byte loads); zero rows for f >= FIN
+      if (a.sv_WTI != nullptr) {
+        if constexpr ((FOUT & 31) == 0) {
+          constexpr int KBW = FOUT / 32;
+          u32x4* img = static_cast<u32x4*>(a.sv_WTI);
+          for (int e = me * 512 + tid; e < 2 * KBW * NCB * 64; e += nsh * 512) {
+            const int ln = e & 63, tile = e >> 6, ct = tile % NCB, kb = (tile / NCB) % KBW, kk = tile / (NCB * KBW);
+            const int f = 16 * ct + (ln & 15), k0 = 32 * kb + 8 * (ln >> 4);
+            const float* src = a.weight + (size_t)(min(f, FIN - 1) * 2 + kk) * FOUT + k0;
+            f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            if (f >= FIN) { lo = (f32x4){0.f, 0.f, 0.f, 0.f}; hi = lo; }
+            const Pieces P = split3x8(lo, hi);
+            u32x4* dst = img + (size_t)tile * 192 + ln;
+            dst[0] = P.h; dst[64] = P.m; dst[128] = P.l;
+          }
+        }
+      }
     }
   }
   AGCN_STAMP(1, 8);
@@ -560,12 +579,17 @@ size_t spec_coop_fwd_lds_bytes(int32_t n, int32_t Fin) {
   return sizeof(float) * (size_t)spec::coop_fwd_lds(n, (Fin + 15) & ~15).total;
 }
 
+size_t spec_coop_fwd_lds_bytes_bfp(int32_t n, int32_t Fin, int32_t np) {
+  return sizeof(float) * (size_t)spec::coop_fwd_lds(n, (Fin + 15) & ~15, np).total;
+}
+
 template <int FIN, int FOUT, int NW>
 static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, hipStream_t s) {
   if (a.variant == AGCN_SGC_LL_RESLAP) {
     if ((a.dual_pairs > 0 || a.coop_slabs > 0) && NW != spec::NW_LARGE) return fail(AGCN_EINVAL, "spec_forward: members / paired graphs need the 16-wave launch");
     SgcArgs aa = a;
     aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
+    aa.lds_bytes = (int32_t)lds_bytes;
     auto kern = &spec::spec_forward_kernel<FIN, FOUT, NW, 0, true>;
     if constexpr (NW == spec::NW_LARGE) {
       if (a.coop_wide && a.coop_slabs > 0) kern = &spec::spec_forward_kernel<FIN, FOUT, NW, 2, true>;
@@ -594,6 +618,7 @@ static int launch_spec_forward_t(const SgcArgs& a, int32_t first, int32_t count,
   const unsigned members = NW == spec::NW_LARGE ? (unsigned)(a.coop_slabs + a.dual_pairs) : 0u;
   SgcArgs aa = a;
   aa.plain_count = count;   // one-graph workgroups; behind them a.dual_pairs workgroups of two small graphs each
+  aa.lds_bytes = (int32_t)lds_bytes;
   // count = plain workgroups + workgroups of two small graphs each (a.plain_count is set by the caller for the 16-wave
   // launch; the 8-wave launch has one graph per workgroup throughout)
   hipLaunchKernelGGL(kern, dim3(members + count), dim3(64 * NW), lds_bytes, s, aa, first);

@@ -94,7 +94,9 @@ struct BwdLds {
   int n4, ldt;
   int o_s, o_dd, o_rs, o_colp, o_tile, o_rt, o_g1, o_u, total;
 };
-AGCN_HD inline BwdLds bwd_lds(int n, int F4, int Fout, int NW) {
+// gnp = 3: the Gp image as THREE bf16 piece planes of [n4][bfp_stride(Fout)] dwords (spec_bfpipe.h: fp32 features, phase G on the
+// bf16 pipe); 0 | 1: the fp32 image, or one plane in its place (smaller)
+AGCN_HD inline BwdLds bwd_lds(int n, int F4, int Fout, int NW, int gnp = 0) {
   BwdLds d;
   d.n4 = (n + 15) & ~15;
   d.ldt = d.n4 + 2;
@@ -107,7 +109,7 @@ AGCN_HD inline BwdLds bwd_lds(int n, int F4, int Fout, int NW) {
   d.o_rt = d.o_tile + d.n4 * d.ldt;         // r_ij
   d.o_g1 = d.o_rt + d.n4 * d.ldt;           // g_1 image, later the Z image
   d.o_u = d.o_g1 + d.n4 * ldx;              // Gp image, later the X_0 image, later the dZ image
-  const int gp = d.n4 * ldg, x = d.n4 * ldx;
+  const int gp = gnp == 3 ? 3 * d.n4 * (((Fout / 2 - 8 + 15) / 16) * 16 + 8) : d.n4 * ldg, x = d.n4 * ldx;
   d.total = d.o_u + (gp > x ? gp : x);
   return d;
 }
@@ -267,9 +269,11 @@ __device__ __forceinline__ void tile_range(int T, int w, int& t0, int& t1) {
 bool spec_supported(int32_t Fin, int32_t Fout, int32_t K, int32_t variant);
 // nw = waves per workgroup: spec::NW_LARGE (16) or spec::NW_SMALL (8, graphs of at most spec::SMALL_N nodes)
 size_t spec_fwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw);
-size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw);
-size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout);
+size_t spec_bwd_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t nw, int32_t gnp = 0);
+size_t spec_coop_lds_bytes(int32_t n, int32_t Fin, int32_t Fout, int32_t gnp = 0);
 size_t spec_coop_fwd_lds_bytes(int32_t n, int32_t Fin);
+// ... with Z = X M_L on the bf16 pipe (spec_bfpipe.h): np piece planes of X (1: bf16 features, 3: fp32) + the M_L image
+size_t spec_coop_fwd_lds_bytes_bfp(int32_t n, int32_t Fin, int32_t np);
 int launch_spec_forward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream);
 int launch_spec_backward(const SgcArgs& a, int32_t first, int32_t count, size_t lds_bytes, int32_t nw, void* stream);
 
