@@ -11,7 +11,7 @@ ARCH = "gfx950"
 # -Wno-pass-failed: "loop not unrolled" remarks for unroll hints on runtime-bounded loops of the per-graph kernels
 # -fno-slp-vectorize: keeps adjacent scalar fp32 adds / fmas as v_add_f32 / v_fma_f32; the packed v_pk_*_f32 forms the
 # SLP vectoriser would build issue several times slower on gfx950 (measured in the pairwise-distance loop)
-# -fvisibility=hidden: the dynamic symbol table is the 66 functions of include/agcn.h (AGCN_API) and nothing else
+# -fvisibility=hidden: the dynamic symbol table is the functions of include/agcn.h (AGCN_API) and nothing else
 FLAGS = ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-Wno-pass-failed", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 

@@ -114,7 +114,7 @@ RESERVE_HEADER_BYTES = 65536      # include/agcn.h: AGCN_RESERVE_HEADER_BYTES (w
 SYMBOLS = [
     "agcn_plan_bytes", "agcn_plan_bytes_for", "agcn_plan_build", "agcn_plan_info",
     "agcn_sgc_ll_reserve_bytes", "agcn_sgc_ll_forward_workspace_bytes", "agcn_sgc_ll_backward_workspace_bytes",
-    "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params",
+    "agcn_sgc_ll_forward", "agcn_sgc_ll_backward", "agcn_sgc_ll_backward_nodes", "agcn_sgc_ll_backward_params", "agcn_sgc_ll_backward_forked",
     "agcn_sgc_ll_dispatch_info", "agcn_sgc_ll_reserve_status", "agcn_set_device_status_word", "agcn_device_status", "agcn_get_coop_timeout_ticks", "agcn_set_coop_timeout_ticks", "agcn_tiles_asymmetry", "agcn_epoch_step", "agcn_get_spec_tail", "agcn_set_spec_tail", "agcn_get_rows_split", "agcn_set_rows_split",
     "agcn_graph_gather_forward", "agcn_graph_gather_backward",
     "agcn_rows_dense_forward", "agcn_rows_dense_backward_workspace_bytes", "agcn_rows_dense_backward",
@@ -156,6 +156,9 @@ def _declare(lib):
         f.restype = C.c_int
         f.argtypes = [C.POINTER(LayerDesc), C.POINTER(GraphBatch), C.POINTER(Params),
                       C.POINTER(Outputs), P, P, C.POINTER(Grads), P, SZ, P, SZ, P]
+    lib.agcn_sgc_ll_backward_forked.restype = C.c_int
+    lib.agcn_sgc_ll_backward_forked.argtypes = [C.POINTER(LayerDesc), C.POINTER(GraphBatch), C.POINTER(Params),
+                                                C.POINTER(Outputs), P, P, C.POINTER(Grads), P, SZ, P, SZ, P, P, P]
     lib.agcn_graph_gather_forward.restype = C.c_int
     lib.agcn_graph_gather_forward.argtypes = [P, P, P, I32, I32, I32, P, P]
     lib.agcn_graph_gather_backward.restype = C.c_int

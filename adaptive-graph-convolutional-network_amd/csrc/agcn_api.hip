@@ -934,7 +934,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
                          const AgcnParams* params, const AgcnOutputs* fwd, const float* dY,
                          const float* dL_sum, const AgcnGrads* grads, const void* reserve,
                          size_t reserve_bytes, void* workspace, size_t workspace_bytes,
-                         void* hip_stream, int stages, const char* who) {
+                         void* hip_stream, int stages, const char* who, void* param_stream = nullptr, void* fork_event = nullptr) {
   int rc = check_desc(desc, who);
   if (rc != AGCN_OK) return rc;
   rc = check_batch(desc, batch, params, who);
@@ -1269,6 +1269,17 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
     }
   }
   if (!(stages & 2) || tail_done) return AGCN_OK;
+  // agcn_sgc_ll_backward_forked: the parameter gradients go to `param_stream`, behind everything this call has enqueued on
+  // `hip_stream` so far (one event record + one wait: graph edges under stream capture) -- the caller's stream is free for the
+  // next layer's backward while they run; the caller joins the two streams once, at the end of its step
+  if (param_stream != nullptr && param_stream != hip_stream) {
+    hipEvent_t ev = static_cast<hipEvent_t>(fork_event);
+    if (ev == nullptr) return fail(AGCN_EINVAL, "%s: param_stream without a fork event", who);
+    if (hipEventRecord(ev, static_cast<hipStream_t>(hip_stream)) != hipSuccess ||
+        hipStreamWaitEvent(static_cast<hipStream_t>(param_stream), ev, 0) != hipSuccess)
+      return fail(AGCN_EDEVICE, "%s: stream fork failed", who);
+    hip_stream = param_stream;
+  }
 
   ParamGradArgs pa;
   std::memset(&pa, 0, sizeof(pa));
@@ -1301,6 +1312,16 @@ extern "C" int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBa
   KnobScope knobs(desc ? desc->flags : 0u);
   return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
                        workspace_bytes, hip_stream, 3, "agcn_sgc_ll_backward");
+}
+
+extern "C" int agcn_sgc_ll_backward_forked(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
+                                           const AgcnParams* params, const AgcnOutputs* fwd, const float* dY,
+                                           const float* dL_sum, const AgcnGrads* grads, const void* reserve,
+                                           size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                           void* hip_stream, void* param_stream, void* fork_event) {
+  KnobScope knobs(desc ? desc->flags : 0u);
+  return backward_impl(desc, batch, params, fwd, dY, dL_sum, grads, reserve, reserve_bytes, workspace,
+                       workspace_bytes, hip_stream, 3, "agcn_sgc_ll_backward_forked", param_stream, fork_event);
 }
 
 extern "C" int agcn_sgc_ll_backward_nodes(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,

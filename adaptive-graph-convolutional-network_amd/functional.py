@@ -173,6 +173,48 @@ def no_member_flags(base=None):
     return _ffi.dispatch_flags(base, spec_mode=sm & 3, pg_onepass=min(pg, 1))
 
 
+# Parameter gradients beside the backward chain (include/agcn.h: agcn_sgc_ll_backward_forked).  In a multi-layer step the
+# parameter-gradient kernel of layer l depends on that layer's per-graph backward kernel only; nothing downstream of it is needed by
+# the backward of layer l - 1.  Inside `with param_grad_fork(device):` every SGC layer's backward enqueues its parameter gradients
+# on ONE side stream (an event edge per layer), the main stream goes straight on to the previous layer, and the two streams are
+# joined once when the block ends.  Process-wide per device (autograd runs backward() on its own thread), so one training step at
+# a time per device.  Parameters' .grad must be None (or untouched) until the block ends: the gradient tensors are filled on the
+# side stream -- autograd only STORES them (no kernel) when .grad is None.
+_forks = {}
+
+
+class param_grad_fork(object):
+    def __init__(self, device):
+        dev = torch.device(device)
+        self.idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        st = _forks.get(self.idx)
+        if st is None:
+            st = _forks[self.idx] = {"stream": torch.cuda.Stream(torch.device("cuda", self.idx)), "keep": [], "active": False}
+        self.st = st
+
+    def __enter__(self):
+        self.st["active"] = True
+        self.st["used"] = False
+        return self
+
+    def __exit__(self, *exc):
+        st = self.st
+        st["active"] = False
+        if st["used"]:
+            torch.cuda.current_stream(torch.device("cuda", self.idx)).wait_stream(st["stream"])      # the ONE join of the step
+        if torch.cuda.is_current_stream_capturing():
+            # a captured graph replays on these buffers: they belong to the capturing object (engine.GraphedStep's capture_scope)
+            # for as long as its graph lives, like the pooled reserves a capture pins
+            (_capture_scopes[-1].held if _capture_scopes else _unscoped_captures).extend((None, k) for k in st["keep"])
+        del st["keep"][:]
+        return False
+
+
+def _active_fork(dev):
+    st = _forks.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    return st if (st is not None and st["active"]) else None
+
+
 # how many calls were re-issued on the non-member dispatch after a cooperative wait ran out (engine.*.check(recover=True),
 # functional.run_checked)
 recovered_calls = [0]
@@ -337,12 +379,12 @@ class capture_scope(object):
 
     @property
     def nbytes(self):
-        return sum(t.numel() for _, t in self.held)
+        return sum(t.numel() for _, t in self.held if torch.is_tensor(t))
 
 
 def reserve_pool_bytes():
     """(bytes idle in the pool, bytes pinned by captures outside any capture_scope)."""
-    return _reserve_pool_bytes[0], sum(t.numel() for _, t in _unscoped_captures)
+    return _reserve_pool_bytes[0], sum(t.numel() for _, t in _unscoped_captures if torch.is_tensor(t))
 
 
 def release_reserve_pool(force=False):
@@ -353,7 +395,7 @@ def release_reserve_pool(force=False):
     _reserve_pool.clear()
     _reserve_pool_bytes[0] = 0
     if force:
-        n += sum(t.numel() for _, t in _unscoped_captures)
+        n += sum(t.numel() for _, t in _unscoped_captures if torch.is_tensor(t))
         del _unscoped_captures[:]
     return n
 
@@ -483,9 +525,23 @@ class SgcLLFunction(torch.autograd.Function):
         fw = _ffi.Outputs(Y.data_ptr(), res_L.data_ptr(), res_W.data_ptr(), L_sum.data_ptr() if cfg.lsum else None)
         gr = _ffi.Grads(dX.data_ptr(), dweight.data_ptr(), dbias.data_ptr(), _ptr(dM), dalpha.data_ptr(),
                         _ptr(dbeta), _ptr(dLp))
-        _ffi.check(lib.agcn_sgc_ll_backward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(fw),
-                                            dY.data_ptr(), _ptr(dL_sum), C.byref(gr), reserve.data_ptr(),
-                                            reserve.numel(), ws.data_ptr(), wbytes, _stream(dev)))
+        fk = _active_fork(dev)
+        if fk is not None:
+            main = torch.cuda.current_stream(dev)
+            ev = torch.cuda.Event()
+            ev.record(main)                                   # (creates the handle; the library records it again where it forks)
+            _ffi.check(lib.agcn_sgc_ll_backward_forked(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(fw),
+                                                       dY.data_ptr(), _ptr(dL_sum), C.byref(gr), reserve.data_ptr(),
+                                                       reserve.numel(), ws.data_ptr(), wbytes, main.cuda_stream,
+                                                       fk["stream"].cuda_stream, int(ev.cuda_event)))
+            # what the side stream still reads when this function returns: alive until the join (NOT the gradient tensors: a
+            # second reference would make autograd copy them -- on the main stream, before they are written)
+            fk["keep"].append((ws, ev, ctx.reserve_lease, X, Y, dY))
+            fk["used"] = True
+        else:
+            _ffi.check(lib.agcn_sgc_ll_backward(C.byref(desc), C.byref(gb), C.byref(pr), C.byref(fw),
+                                                dY.data_ptr(), _ptr(dL_sum), C.byref(gr), reserve.data_ptr(),
+                                                reserve.numel(), ws.data_ptr(), wbytes, _stream(dev)))
         if ctx.has_beta and dbeta is None:
             dbeta = None   # beta unused (no L_prev): TF reports no gradient either
         return dX, dweight, dbias, dM, dalpha, dbeta, dLp, None, None

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-/* The library is built with -fvisibility=hidden: the 66 functions declared here are its whole dynamic symbol table
+/* The library is built with -fvisibility=hidden: the functions declared here are its whole dynamic symbol table
  * (tests/test_abi.py compares `nm -D` with this header). */
 #if defined(__GNUC__)
 #define AGCN_API __attribute__((visibility("default")))
@@ -275,6 +275,17 @@ AGCN_API int agcn_sgc_ll_backward(const AgcnLayerDesc* desc, const AgcnGraphBatc
  * _nodes  = everything local to a graph: dX, dL_prev, and the per-graph partials in workspace;
  * _params = the reductions over the batch: dweight, dbias, dM_L, dalpha, dbeta.
  * _params must follow _nodes on the same stream with the same workspace. */
+/* The whole backward with its PARAMETER GRADIENTS ON A SECOND STREAM (ABI 106).  dX (and dL_prev) are complete on `hip_stream` when the
+ * call's launches there are; dweight / dbias / dM_L / dalpha / dbeta are computed on `param_stream`, behind the per-graph kernels of
+ * this call: the library records `fork_event` (a hipEvent_t the caller owns) on hip_stream and makes param_stream wait for it -- graph
+ * edges under stream capture, no host synchronisation.  In a multi-layer step the caller's stream goes straight on to the previous
+ * layer's backward while this layer's parameter gradients run beside it; the caller JOINS the streams once, at the end of the step
+ * (record on param_stream, wait on hip_stream), and keeps reserve and workspace untouched until then.  Same kernels, same bits as
+ * agcn_sgc_ll_backward. */
+AGCN_API int agcn_sgc_ll_backward_forked(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
+                                const AgcnOutputs* fwd, const float* dY, const float* dL_sum, const AgcnGrads* grads,
+                                const void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                void* hip_stream, void* param_stream, void* fork_event);
 AGCN_API int agcn_sgc_ll_backward_nodes(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch, const AgcnParams* params,
                                const AgcnOutputs* fwd, const float* dY, const float* dL_sum,
                                const AgcnGrads* grads, const void* reserve, size_t reserve_bytes,

@@ -2089,6 +2089,62 @@ def test_two_threads_call_the_library_concurrently(amd):
     assert knobs0 == (lib.agcn_get_spec_mode(), lib.agcn_get_fused_mode(), lib.agcn_get_slab_mode(), lib.agcn_get_coop_members())
 
 
+def test_parameter_gradients_beside_the_backward_chain(amd):
+    """`with agcn_amd.param_grad_fork(dev):` around a multi-layer backward (include/agcn.h: agcn_sgc_ll_backward_forked): every
+    SGC layer's parameter-gradient kernel runs on ONE side stream behind its own layer's per-graph kernel, the main stream goes
+    straight on to the previous layer's backward, one join at the end.  The 4-layer SimpleAGCN-shaped stack + DenseMol +
+    GraphGatherMol, eager and as one HIP graph: every gradient must be BIT-IDENTICAL to the serial step (the same kernels on the
+    same inputs; only their order in time changes), replay after replay."""
+    from agcn_amd import synth
+    K = 2
+    data = synth.tox21_batch(123, 256, 75)
+    gb = amd.GraphBatch.from_arrays(data["n"], np.concatenate(data["X"], 0), data["csr"], DEV)
+    rs = np.random.RandomState(5)
+    layers, fin = [], 75
+    for w in (64, 128, 128, 64):
+        lay = amd.SGC_LL(w, fin, 256, K=K, laplacian_mode="paper", device=DEV)
+        lay.load_vars(synth.glorot_params(rs, fin, w, K))
+        layers.append(lay)
+        fin = w
+    dense = amd.DenseMol(256, fin, device=DEV)
+    dense.build(DEV)
+    gather = amd.GraphGatherMol(256, activation="tanh")
+    G = torch.from_numpy(rs.randn(256, 256).astype(np.float32)).to(DEV)
+    X = gb.X.clone().requires_grad_(True)
+    params = [v for lay in layers for v in lay.vars.values()] + dense.parameters() + [X]
+
+    def step(fork):
+        for q in params:
+            q.grad = None
+        h = X
+        for lay in layers:
+            h, _, _ = lay({"node_features": h, "graph_batch": gb})
+        h = dense({"node_features": h, "graph_batch": gb})
+        out = gather({"node_features": h, "graph_batch": gb})
+        if fork:
+            with amd.param_grad_fork(DEV):
+                out.backward(G)
+        else:
+            out.backward(G)
+        return [q.grad for q in params]
+
+    want = [g.clone() for g in step(False)]
+    torch.cuda.synchronize()
+    got = step(True)
+    torch.cuda.synchronize()
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+    gs = amd.GraphedStep(lambda: step(True), DEV)
+    for _ in range(5):
+        grads = gs.replay()
+        torch.cuda.synchronize()
+        for a_, b_ in zip(grads, want):
+            assert torch.equal(a_, b_)
+    assert gs.pinned_reserve_bytes > 0
+    del gs
+    assert amd.check_device_status() >= 1
+
+
 def test_members_cannot_lose_a_call(amd):
     """A wait between the workgroups that share a large graph is bounded; when it runs out the step's results are NaN and the
     status word counts it (test_cooperative_waits_are_never_silent).  That call is not lost: `check(recover=True)` (step
