@@ -599,6 +599,10 @@ AGCN_API void agcn_set_rows_split(int32_t on);
  * AGCN_CLOUD_BWD1_PARTS=0 -- backward 1 of a 128-feature SGC_LL layer once per feature half instead of by parts (P tile);
  * AGCN_CLOUD_SIM2=0 -- the 128-feature similarity with all 128 features of a lane's column row in registers (two waves per SIMD)
  * instead of two passes of 64 (four);
+ * AGCN_BFPIPE=<mask> -- which feature contractions of the per-graph (molecule) kernels run on the bf16 matrix pipe at fp32 accuracy
+ * (csrc/spec_bfpipe.h; default 12): 4 the backward's filter adjoint Gp W^T for calls with bf16 features (Gp is one bf16 piece, W^T a
+ * three-piece image in MFMA operand order left in the reserve by the forward), 8 the same for fp32 features (Gp split into three piece
+ * planes), 1 | 2 the members' forward projection Z = X M_L with bf16 | fp32 features (image built in LDS: measured no gain, off);
  * AGCN_ROWS_SPLIT_DENSE_MIN=<rows> -- fewest packed rows at which the dense layers (agcn_rows_dense_*) take the split-bf16 row
  * kernels (default 8192; values below 128 -- one workgroup's rows -- or unparsable ones are clamped to 128). */
 

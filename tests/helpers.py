@@ -25,8 +25,14 @@ from conftest import GOLDEN
 MAX_TIES = 4
 FEATURE_RTOL = 1e-5
 GRAD_RTOL = 2e-5
-FEATURE_ULPS = 16
-GRAD_ULPS = 32
+# The absolute allowances, in ulps of the row / column maximum: TWICE the worst need observed over the whole GPU suite on MI355X
+# (profiles/r06_parity_margins.json, `ulps_needed`: the suite records it per comparison): features 3.6 -> 8; dX / dweight / dbias /
+# dL_prev 5.5 -> 12; dM_L (a sum over every PAIR of every graph) 19.2 -> 40, flat in the graph size.  Rounds 1-5 ran with 16 / 32 and
+# a sqrt(n / 64) size factor that allowed 64 ulps where 7.9 were needed.
+FEATURE_ULPS = 8
+GRAD_ULPS = 12
+DML_ULPS = 40
+SCALAR_RTOL = 5e-6       # dalpha / dbeta: observed at most 0.1 x GRAD_RTOL of the weight-gradient scale
 EPS32 = float(np.finfo(np.float32).eps)
 TINY32 = float(np.finfo(np.float32).tiny)
 
@@ -54,8 +60,9 @@ MARGINS = {}
 
 def size_factor(n):
     """Factor on the absolute (ulp) allowance for outputs that are, or depend on, sums over the n nodes of a large graph
-    (rounding grows like sqrt(n) eps; 64 nodes is the size the default allowance was calibrated on)."""
-    return float(np.sqrt(max(float(n), 64.0) / 64.0))
+    (64 nodes is the size the default allowance was calibrated on; observed need at n = 1024: 7.9 ulps on features against 3.6 at
+    molecule sizes -- the fourth root, (n / 64)^(1/4) = 2 at n = 1024, covers it twice)."""
+    return float((max(float(n), 64.0) / 64.0) ** 0.25)
 
 
 def _record_margin(what, rtol, ulps, ratio, k32=None, factor=1.0, ulps_needed=None):
@@ -89,6 +96,8 @@ def assert_close(a, b, rtol, what, atol_ulps=None, ref32=None):
     assert np.all(np.isfinite(b)), "%s: non-finite values in the expected tensor" % what
     if b.size == 0:
         return
+    if "dm_l" in what.lower() and rtol > FEATURE_RTOL:
+        atol_ulps = DML_ULPS * max(1.0, rtol / GRAD_RTOL)      # (whatever the caller scaled for the graph size: flat, see DML_ULPS)
     if atol_ulps is None:
         atol_ulps = FEATURE_ULPS if rtol <= FEATURE_RTOL else GRAD_ULPS * max(1.0, rtol / GRAD_RTOL)
     a64, b64 = a.astype(np.float64), b.astype(np.float64)
@@ -278,14 +287,14 @@ def _scalar_close(got, want, want32, scale, what):
     """Scalar gradients (dalpha, dbeta: sums over every pair of every graph): GRAD_RTOL of the weight-gradient scale, or
     twice the error the fp32 oracle itself makes on this case, whichever is larger (printed)."""
     got, want = float(np.asarray(got).reshape(-1)[0]), float(np.asarray(want).reshape(-1)[0])
-    bar = GRAD_RTOL * max(abs(want), scale)
+    bar = SCALAR_RTOL * max(abs(want), scale)
     e32 = abs(float(np.asarray(want32).reshape(-1)[0]) - want) if want32 is not None else None
     print("%-12s fp32 oracle %s, HIP %.2f x the bar (%.1e of the gradient scale)"
-          % (what, "n/a" if e32 is None else "%.2f x the bar" % (e32 / bar), abs(got - want) / bar, GRAD_RTOL))
+          % (what, "n/a" if e32 is None else "%.2f x the bar" % (e32 / bar), abs(got - want) / bar, SCALAR_RTOL))
     if e32 is not None:
         assert e32 <= K32_CAP / 2.0 * bar, "%s: the fp32 oracle is %.1f x the bar away from the float64 one: ill-conditioned case" % (what, e32 / bar)
-    allowed = min(max(bar, 2.0 * e32), K32_CAP * bar) if e32 is not None else 2.0 * bar
-    _record_margin(what, GRAD_RTOL, None, abs(got - want) / bar, None if e32 is None else e32 / bar, allowed / bar)
+    allowed = min(max(bar, 2.0 * e32), K32_CAP * bar) if e32 is not None else bar
+    _record_margin(what, SCALAR_RTOL, None, abs(got - want) / bar, None if e32 is None else e32 / bar, allowed / bar)
     assert abs(got - want) <= allowed, "%s %r vs %r (allowed %.3e)" % (what, got, want, allowed)
 
 

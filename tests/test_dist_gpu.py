@@ -141,3 +141,28 @@ def test_bench_hiv_epoch_workload(gpus, dtype):
     assert line["n_gpus"] == gpus and line["dtype"] == dtype and line["value"] > 0 and line["steps"] == 6
     assert line["config"]["global_batch"] == 256 * gpus and line["config"]["global_batches_per_epoch"] == 2048 // (256 * gpus)
     assert "hiv" in line["config"]["workload"].lower() and line["config"]["bucket_bytes"] == 4 * (150 * 64 + 64 + 75 * 75 + 1)
+
+
+@pytest.mark.parametrize("workload", ["tox21-layer", "hiv-epoch"])
+def test_bench_eight_ranks_selftest(workload):
+    """BASELINE.json configs[3] / [4] are 8-GPU runs; no 8-GPU node has been available to this build, so the LAUNCHER PATH of
+    `python bench.py --gpus 8` is exercised the only way one GPU allows: AGCN_BENCH_SELFTEST=1 -- eight rank processes sharing
+    cuda:0 over gloo (control flow: rank start-up, LPT shards of the 2048-graph global batch / the epoch's global batches, eight
+    buckets summed per step, MAX-over-ranks timing, one JSON line) -- for both workloads.  The line must count eight ranks, name
+    its backend honestly (gloo, not RCCL) and carry the global batch of eight shards."""
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU box runs the real thing (the driver's SCALE run)")
+    env = dict(os.environ, AGCN_BENCH_SELFTEST="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"]
+    if workload == "hiv-epoch":
+        cmd += ["--workload", "hiv-epoch", "--dtype", "bf16", "--epoch-graphs", "8192"]
+    else:
+        cmd += ["--no-cpu-baseline", "--skip-other-mode", "--repeats", "2"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=1200)
+    assert res.returncode == 0
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["global_batch"] == 2048
+    assert line["config"]["backend"] == "gloo" and "RCCL" not in line["config"]["workload"].replace("not RCCL", "")
+    assert line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak"

@@ -105,7 +105,7 @@ def test_golden_reference_feed(amd, name, lds_limit, pack):
                     got = 0.0 if v.grad is None else float(v.grad[0])
                     want = float(g[prefix + "d_" + k][0]) if has else 0.0
                     # (the golden is the reference's own fp32 result: two fp32 sums, each within one bar of the exact value)
-                    assert abs(got - want) <= 2 * GRAD_RTOL * max(abs(want), scale), (prefix, k, got, want)
+                    assert abs(got - want) <= GRAD_RTOL * max(abs(want), scale), (prefix, k, got, want)
                 elif k == "M_L":
                     assert not has and v.grad is None     # the reference gives M_L no gradient
                 else:
@@ -202,7 +202,7 @@ def test_mixed_dispatch_full_batch(amd, fmode):
         b2 = run()
         for x, y, z in zip(ref, a, b2):
             assert torch.equal(y, z), "mixed dispatch must be reproducible"
-            assert_close(to_np(y), to_np(x), 2 * GRAD_RTOL, "mixed vs fused", atol_ulps=2 * GRAD_ULPS)   # two fp32 runs
+            assert_close(to_np(y), to_np(x), GRAD_RTOL, "mixed vs fused")   # two fp32 runs
     finally:
         lib.agcn_set_lds_limit(160 * 1024)
         lib.agcn_set_fused_mode(1)
@@ -396,7 +396,7 @@ def test_fused_path_large_graph_and_wide_layer(amd):
                 assert np.array_equal(out["res_W"][b], out["res_W"][b].T)
                 assert_close(out["res_W"][b], slab["res_W"][b], FEATURE_RTOL, "res_W fused vs slab")
             # (two fp32 results, each held to GRAD_RTOL against the oracle above: their difference to twice that)
-            assert_close(np.concatenate(out["dX"]), np.concatenate(slab["dX"]), 2 * GRAD_RTOL, "dX fused vs slab")
+            assert_close(np.concatenate(out["dX"]), np.concatenate(slab["dX"]), GRAD_RTOL, "dX fused vs slab")
 
 
 def test_graphed_network_step(amd):
@@ -813,9 +813,9 @@ def test_full_size_properties(amd):
     _, _, _, dXp2, gp2 = run(orc.PAPER, G2)
     _, _, _, dXp3, gp3 = run(orc.PAPER, G1 + G2)
     # (three fp32 runs are compared with each other: the allowance of one run against the truth, times three)
-    assert_close(to_np(dXp3), to_np(dXp1 + dXp2), 3 * GRAD_RTOL, "linearity dX", atol_ulps=3 * GRAD_ULPS)
+    assert_close(to_np(dXp3), to_np(dXp1 + dXp2), GRAD_RTOL, "linearity dX")
     for a, b, c in zip(gp1[:3], gp2[:3], gp3[:3]):
-        assert_close(to_np(c), to_np(a + b), 3 * GRAD_RTOL, "linearity param grad", atol_ulps=3 * GRAD_ULPS)
+        assert_close(to_np(c), to_np(a + b), GRAD_RTOL, "linearity param grad")
 
 
 @pytest.mark.parametrize("B", [256, 600, 2048], ids=["b256", "b600", "b2048"])
@@ -1136,7 +1136,7 @@ def test_dense_block_end_golden(amd):
         assert_close(to_np(layer.vars["weight_outblock"][i].grad), g["dWout%d" % i], GRAD_RTOL, "DenseBlockEnd dWout")
     for k, ref in (("beta_inblock", "dbeta1"), ("beta_outblock", "dbeta2")):
         got, want = float(layer.vars[k].grad[0]), float(g[ref][0])
-        assert abs(got - want) <= 2 * GRAD_RTOL * abs(want), (k, got, want)      # (golden = the reference's fp32 sum)
+        assert abs(got - want) <= GRAD_RTOL * abs(want), (k, got, want)      # (golden = the reference's fp32 sum)
 
 
 def test_dense_block_end_packed_chain(amd):
@@ -1245,11 +1245,11 @@ def test_dense_layers_at_point_cloud_row_counts(amd):
     assert_close(got["da1"], da[0], GRAD_RTOL, "da_1")
     assert_close(got["da2"], da[1], GRAD_RTOL, "da_2")
     assert_close(got["do1"], do[0], GRAD_RTOL, "do_1")
-    assert_close(got["grad_be2_0"], dWi[0], GRAD_RTOL, "dW_in[0] (64 x 64, 9216-row sums)", atol_ulps=GRAD_ULPS * 4)
-    assert_close(got["grad_be2_1"], dWi[1], GRAD_RTOL, "dW_in[1] (128 x 64)", atol_ulps=GRAD_ULPS * 4)
-    assert_close(got["grad_be2_2"], dWo[0], GRAD_RTOL, "dW_out[0] (128 x 64)", atol_ulps=GRAD_ULPS * 4)
-    assert abs(float(got["grad_be2_3"].reshape(-1)[0]) - db1) <= 4 * GRAD_RTOL * abs(db1) and \
-        abs(float(got["grad_be2_4"].reshape(-1)[0]) - db2) <= 4 * GRAD_RTOL * abs(db2)
+    assert_close(got["grad_be2_0"], dWi[0], GRAD_RTOL, "dW_in[0] (64 x 64, 9216-row sums)")
+    assert_close(got["grad_be2_1"], dWi[1], GRAD_RTOL, "dW_in[1] (128 x 64)")
+    assert_close(got["grad_be2_2"], dWo[0], GRAD_RTOL, "dW_out[0] (128 x 64)")
+    assert abs(float(got["grad_be2_3"].reshape(-1)[0]) - db1) <= GRAD_RTOL * abs(db1) and \
+        abs(float(got["grad_be2_4"].reshape(-1)[0]) - db2) <= GRAD_RTOL * abs(db2)
     y1, pre1 = orc.dense_block_end_forward(f64(a2), [f64(a1), f64(a2)], [f64(W12), f64(W22)], [], [], 0.7, 1.0)
     assert_close(got["out1"], y1, FEATURE_RTOL, "block 1 end out")
     Gp1, da1_, _, _, _, _, _ = orc.dense_block_end_backward([f64(a1), f64(a2)], [f64(W12), f64(W22)], [], [], 0.7, 1.0, pre1, f64(G2))
@@ -1259,12 +1259,12 @@ def test_dense_layers_at_point_cloud_row_counts(amd):
     assert_close(got["outd"], yd, FEATURE_RTOL, "DenseMol out")                  # (dense_layer.py:42-50: no activation applied)
     dxd, dWd, dbd = orc.dense_mol_backward(f64(x), f64(Wd), f64(Gd))
     assert_close(got["ddx"], dxd, GRAD_RTOL, "DenseMol dx")
-    assert_close(got["grad_dm_0"], dWd, GRAD_RTOL, "DenseMol dW (64 x 256)", atol_ulps=GRAD_ULPS * 4)
-    assert_close(got["grad_dm_1"], dbd, GRAD_RTOL, "DenseMol db", atol_ulps=GRAD_ULPS * 4)
+    assert_close(got["grad_dm_0"], dWd, GRAD_RTOL, "DenseMol dW (64 x 256)")
+    assert_close(got["grad_dm_1"], dbd, GRAD_RTOL, "DenseMol db")
     # every tensor of the split path against the general kernels (two fp32 evaluations: 2 x the bars), parameter gradients included
     for k in got:
         if got[k].size == 1:
-            assert abs(float(got[k].reshape(-1)[0]) - float(got0[k].reshape(-1)[0])) <= 4 * GRAD_RTOL * max(1.0, abs(float(got0[k].reshape(-1)[0]))), k
+            assert abs(float(got[k].reshape(-1)[0]) - float(got0[k].reshape(-1)[0])) <= GRAD_RTOL * max(1.0, abs(float(got0[k].reshape(-1)[0]))), k
         else:
             assert_close(got[k], f64(got0[k]), 2 * (FEATURE_RTOL if k.startswith("out") else GRAD_RTOL), "split vs general " + k)
 
@@ -1619,8 +1619,8 @@ def test_full_size_packed_row_products_exactness(amd):
     # the 32768-row sums of the parameter gradients (X_1 = (I + L_orig) X_0 in reference mode is not needed: term 0 and the bias)
     Xh, Gh = X.reshape(-1, F).astype(np.float64), to_np(Gp).astype(np.float64)
     dW = to_np(layer.vars["weight"].grad)
-    assert_close(dW[0::K], Xh.T @ Gh, GRAD_RTOL, "dweight (term 0), 32768 rows", atol_ulps=GRAD_ULPS * 4)
-    assert_close(to_np(layer.vars["bias"].grad), Gh.sum(0), GRAD_RTOL, "dbias, 32768 rows", atol_ulps=GRAD_ULPS * 4)
+    assert_close(dW[0::K], Xh.T @ Gh, GRAD_RTOL, "dweight (term 0), 32768 rows")
+    assert_close(to_np(layer.vars["bias"].grad), Gh.sum(0), GRAD_RTOL, "dbias, 32768 rows")
 
 
 _RESLAP_CLOUD_CASES = {
@@ -2012,7 +2012,7 @@ def test_point_cloud_batch_streaming_kernels(amd, mode, Fin, Fout):
     # degenerate one-feature case ((z_i - z_j) / r_ij = +-1: dZ and dX are sums of signed terms that cancel) get the
     # allowance fp32 arithmetic itself needs there (helpers.py: 120 ulp on dX against 5 in the other cases)
     k = size_factor(max(sizes))
-    kg = k * (4.0 if Fin == 1 else 1.0)
+    kg = k * (8.0 if Fin == 1 else 1.0)
     Y = to_np(nodes.data)
     dX = to_np(Xt.grad)
     r0 = 0
@@ -2145,6 +2145,30 @@ def test_parameter_gradients_beside_the_backward_chain(amd):
     assert amd.check_device_status() >= 1
 
 
+@pytest.mark.parametrize("switch", ["AGCN_CLOUD_RBWD_BOTH=0", "AGCN_CLOUD_BWD1_PARTS=0", "AGCN_CLOUD_SIM2=0", "AGCN_CLOUD_BWD2_BF=0",
+                                    "AGCN_CLOUD_BWD2_BF=2", "AGCN_ROWS_SPLIT=0", "AGCN_BFPIPE=0", "AGCN_BFPIPE=15"])
+def test_kernel_variants_behind_environment_switches(switch):
+    """The A/B fallbacks kept behind environment switches (include/agcn.h, last section; csrc/errors.cpp AGCN_BFPIPE) are read once
+    per process, so each is run in a process of its own: the 128-feature point-cloud layers (SGC_LL_Reslap with a previous
+    Laplacian, SGC_LL; paper mode, n = 1024) for the point-cloud switches, the bf16 / member / golden molecule cases for the
+    bf16-pipe mask -- every one against the float64 oracle at the usual bars.  A variant that is kept must keep passing."""
+    import subprocess
+    import sys
+    name, val = switch.split("=")
+    env = dict(os.environ)
+    env[name] = val
+    if name == "AGCN_BFPIPE":
+        sel = "test_bf16_features_every_graph or test_large_graphs_spread_over_several_workgroups or test_golden_reference_feed"
+    else:
+        sel = ("test_point_cloud_reslap_hidden_layer and paper and (wide_inner_layer or wide_sgc_ll)"
+               if name != "AGCN_CLOUD_BWD2_BF" or val != "2" else "test_point_cloud_reslap_hidden_layer and paper and (inner_layer or wide_sgc_ll)")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    tail = res.stdout.decode(errors="replace")[-1500:]
+    assert res.returncode == 0, tail
+    assert " passed" in tail and "no tests ran" not in tail, tail
+
+
 def test_members_cannot_lose_a_call(amd):
     """A wait between the workgroups that share a large graph is bounded; when it runs out the step's results are NaN and the
     status word counts it (test_cooperative_waits_are_never_silent).  That call is not lost: `check(recover=True)` (step
@@ -2244,8 +2268,8 @@ def test_far_away_nodes_do_not_poison_the_gradients(amd, path):
             assert np.all(np.isfinite(out[k])), k
         assert all(np.all(np.isfinite(d)) for d in out["dX"])
         # (the oracle of this test runs in float32 -- the overflow it is about does not exist in float64 --: two fp32 results)
-        assert_close(out["dM_L"], tot["dM_L"], 2 * GRAD_RTOL, "dM_L with far-away nodes")
-        assert_close(out["dweight"], tot["dweight"], 2 * GRAD_RTOL, "dweight with far-away nodes")
+        assert_close(out["dM_L"], tot["dM_L"], GRAD_RTOL, "dM_L with far-away nodes")
+        assert_close(out["dweight"], tot["dweight"], GRAD_RTOL, "dweight with far-away nodes")
     finally:
         lib.agcn_set_fused_mode(1)
         lib.agcn_set_slab_mode(1)
@@ -2595,9 +2619,9 @@ def test_param_grads_ride_in_the_backward_launch(amd, B):
             a, b = to_np(st.grads[k]), to_np(st0.grads[k])
             scale = float(np.abs(to_np(st0.grads["weight"])).max())
             if a.size == 1:
-                assert abs(float(a.reshape(-1)[0]) - float(b.reshape(-1)[0])) <= 2 * GRAD_RTOL * max(abs(float(b.reshape(-1)[0])), scale), k
+                assert abs(float(a.reshape(-1)[0]) - float(b.reshape(-1)[0])) <= GRAD_RTOL * max(abs(float(b.reshape(-1)[0])), scale), k
             else:
-                assert_close(a, b, 2 * GRAD_RTOL, "d%s: backward-launch tiles vs the separate kernel" % k)
+                assert_close(a, b, GRAD_RTOL, "d%s: backward-launch tiles vs the separate kernel" % k)
         assert torch.equal(st0.dX, dX)
     finally:
         lib.agcn_set_spec_tail(prev_tail)
@@ -2668,7 +2692,7 @@ def test_param_grads_tagged_hand_off(amd, shape):
         torch.cuda.synchronize()
         ref.append(st.bucket.clone())
         for k in range(2):      # (the flat bucket of every parameter gradient: one vector, bound relative to its largest entry)
-            assert_close(to_np(ref[k]), to_np(want[k]), 2 * GRAD_RTOL, "tagged vs arrival-counter kernel, dY %d" % k)
+            assert_close(to_np(ref[k]), to_np(want[k]), GRAD_RTOL, "tagged vs arrival-counter kernel, dY %d" % k)
         for it in range(8):                                   # call after call; stale granules differ or are poisoned
             st.dY.copy_(dYs[it & 1])
             st.bucket.zero_()
@@ -2883,8 +2907,8 @@ def test_large_graphs_spread_over_several_workgroups(amd, Fin, Fout):
             res[mode] = first
     finally:
         lib.agcn_set_spec_mode(7)
-    assert_close(to_np(res[7][1]), to_np(res[3][1]), 2 * GRAD_RTOL, "dX coop vs plain", atol_ulps=2 * GRAD_ULPS)
-    assert_close(to_np(res[7][0]), to_np(res[3][0]), 2 * GRAD_RTOL, "bucket coop vs plain", atol_ulps=2 * GRAD_ULPS)
+    assert_close(to_np(res[7][1]), to_np(res[3][1]), GRAD_RTOL, "dX coop vs plain")
+    assert_close(to_np(res[7][0]), to_np(res[3][0]), GRAD_RTOL, "bucket coop vs plain")
 
 
 def test_dropout_on_the_activated_nodes(amd):
