@@ -32,7 +32,7 @@ def main():
     import agcn_amd
     from agcn_amd import synth
     mode = "paper" if "--reference" not in sys.argv else "reference"
-    B = 256
+    B = int(os.environ.get("AGCN_STAMP_B", 256))
     data = synth.tox21_batch(123, B)
     if os.environ.get("AGCN_STAMP_SHARD_OF"):      # shard 0 of an emulated N-GPU run (holds the largest graph)
         N = int(os.environ["AGCN_STAMP_SHARD_OF"])
@@ -78,6 +78,12 @@ def main():
         print("   stamp idx      :", cols)
         print("   median (us)    :", np.round(np.median(rel, 0), 2))
         print("   max    (us)    :", np.round(rel.max(0), 2))
+        if os.environ.get("AGCN_STAMP_ROUNDS"):      # phase durations of the workgroups that start first vs those that start late
+            start = blk[used][:, cols[0]] - t0
+            dur = np.diff(blk[used][:, cols], axis=1) / 100.0
+            early, late = start <= np.percentile(start, 25), start >= np.percentile(start, 75)
+            print("   phase durations, earliest quarter (start <= %.1f us):" % (np.percentile(start, 25) / 100.0), np.round(np.median(dur[early], 0), 2))
+            print("   phase durations, latest quarter   (start >= %.1f us):" % (np.percentile(start, 75) / 100.0), np.round(np.median(dur[late], 0), 2))
         # the block that ends last
         w = np.argmax(blk[used, last])
         print("   slowest block  :", np.round(rel[w], 2), "(block %d)" % np.nonzero(used)[0][w])
