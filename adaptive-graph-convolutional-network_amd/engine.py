@@ -695,6 +695,7 @@ class GraphedStep(object):
 
     def __init__(self, fn, device, warmup=3):
         dev = torch.device(device)
+        self.fn, self.recovered = fn, 0
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -717,6 +718,24 @@ class GraphedStep(object):
         self.graph.replay()
         return self.outputs
 
+    def replay_checked(self):
+        """A replay that cannot be lost: replays, synchronises, and if a wait between the workgroups that share a large graph ran
+        out anywhere in it (results NaN; include/agcn.h: agcn_device_status) RE-ISSUES the step -- `fn()` eagerly, fresh launches
+        on the dispatch in which no workgroup waits for another (per-call flags) -- and returns THAT run's outputs (new tensors;
+        parameter gradients in the `.grad` fields as `fn` leaves them).  Counted in `self.recovered` / `agcn_amd.recovered_calls`."""
+        _fn.device_timeouts()
+        out = self.replay()
+        if _fn.device_timeouts() == 0:
+            return out
+        nm = _fn.no_member_flags()
+        with _fn.dispatch(spec_mode=(nm & 15) - 1, pg_onepass=((nm >> 7) & 3) - 1):
+            out = self.fn()
+        if _fn.device_timeouts() != 0:
+            raise _ffi.AgcnError("a cooperative wait ran out on the non-member dispatch (which has none): device fault")
+        self.recovered += 1
+        _fn.recovered_calls[0] += 1
+        return out
+
     @property
     def pinned_reserve_bytes(self):
         return self._scope.nbytes
@@ -725,7 +744,7 @@ class GraphedStep(object):
         """Drops the captured graph and its outputs and frees the reserve buffers it pinned."""
         if self.graph is not None:
             torch.cuda.synchronize()
-            self.outputs = None
+            self.outputs = self.fn = None
             self.graph.reset()
             self.graph = None
             self._scope.release()

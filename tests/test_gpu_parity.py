@@ -2228,12 +2228,19 @@ def test_members_cannot_lose_a_call(amd):
         assert torch.equal(Y, want[0]) and torch.equal(X.grad, want[3])
         assert torch.equal(layer.vars["weight"].grad.reshape(-1), want[4][:Fin * K * Fout])
         assert amd.device_timeouts() == 0
+        # ... and the same step captured into one HIP graph: the replay's kernels time out, the step is re-issued eagerly
+        gs = amd.GraphedStep(step, DEV)
+        amd.device_timeouts()
+        Y = gs.replay_checked()
+        assert gs.recovered == 1 and amd.recovered_calls[0] == count0 + 4
+        assert torch.equal(Y, want[0]) and torch.equal(X.grad, want[3])
+        del gs
         # (3) a batch of an epoch, staged from the resident store: the LAST batch is re-issued from its staged inputs
         store = amd.GraphStore.from_arrays(data["n"], data["X"], data["csr"])
         rs = store.to_device(DEV, 256)
         ep = amd.SgcLLEpochStep(layer, rs.rows_cap, rs.tiles_cap, 256, device=DEV)
         ep.step_ids(rs, np.arange(256), dY=dY)
-        assert ep.check(recover=True) > 0 and ep.recovered == 1
+        assert ep.check(recover=True) > 0 and ep.recovered == 1 and amd.recovered_calls[0] == count0 + 5
         assert torch.equal(ep.Y, want[0]) and torch.equal(ep.dX, want[3]) and torch.equal(ep.bucket, want[4])
     finally:
         lib.agcn_set_coop_timeout_ticks(ticks0)
