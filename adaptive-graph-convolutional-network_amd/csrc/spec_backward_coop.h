@@ -1058,6 +1058,31 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     }
   }
   if (tid < n4 && (!paper || tid >= n)) s_vec[tid] = 0.f;
+  // While the first waves (tid < n: at most three) wait for the siblings' words -- one hand-off latency, ~2.5 us -- the LAST NOB
+  // waves, which never poll, do the part of the filter that depends on nothing but this strip's X rows: they request both terms'
+  // W fragments and run T_0 = X_0[I] W_0; P5 then only adds X_1[I] W_1 onto the same accumulator (the same instruction sequence as
+  // before, split in time: the same bits).  Before: the fragments' round trip and 19 of the 38 chained MFMAs sat in P5.
+  // (layers of up to 80 input features: at 128 the 32 fragment registers held across two phases spill)
+  constexpr bool EARLY = FIN <= 80;
+  constexpr int P5W0 = NW - NOB;          // first wave of the filter tiles (tile ob = wave - P5W0)
+  float w1[NKS];
+  f32x4 yacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ybias = 0.f;
+  if (EARLY && wave >= P5W0) {
+    const int ob = wave - P5W0;
+    const float* wq = a.weight + q * 2 * FOUT + r + ob * 16;
+    float w0[NKS];
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      const int off = (4 * u + 3 < FIN) ? 4 * u * 2 * FOUT : (min(4 * u + q, FIN - 1) - q) * 2 * FOUT;
+      w0[u] = wq[off];
+      w1[u] = wq[off + FOUT];
+    }
+    ybias = a.bias[ob * 16 + r];
+    const float* A0 = Ximg + (me * 16 + r) * LDX + q;
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) yacc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], w0[u], yacc, 0, 0, 0);
+  }
   if (paper && tid < n && (tid < i0 || tid >= i0 + 16)) {
     bool got;
     const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, a.dev_status, a.coop_ticks, xch + tid, wants[tid >> 4], &got);
@@ -1220,22 +1245,25 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
 
   AGCN_STAMP(0, 5);
   // ---- P5: Y[I] = act(X_0[I] W_0 + X_1[I] W_1 + b), then the stores -------------------------------------------------
-  if (wave < NOB) {
-    const int ob = wave;
-    const float* wq = a.weight + q * 2 * FOUT + r + ob * 16;
-    float w0[NKS], w1[NKS];
-#pragma unroll
-    for (int u = 0; u < NKS; ++u) {
-      const int off = (4 * u + 3 < FIN) ? 4 * u * 2 * FOUT : (min(4 * u + q, FIN - 1) - q) * 2 * FOUT;
-      w0[u] = wq[off];
-      w1[u] = wq[off + FOUT];
-    }
-    const float bias = a.bias[ob * 16 + r];
-    const float* A0 = Ximg + (me * 16 + r) * LDX + q;
+  if (wave >= P5W0) {      // (EARLY: T_0 and the W_1 fragments come from the exchange's waiting time, above)
+    const int ob = wave - P5W0;
+    float bias = ybias;
     const float* A1 = X1s + r * LDX + q;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = yacc;
+    if constexpr (!EARLY) {
+      const float* wq = a.weight + q * 2 * FOUT + r + ob * 16;
+      float w0[NKS];
 #pragma unroll
-    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], w0[u], acc, 0, 0, 0);
+      for (int u = 0; u < NKS; ++u) {
+        const int off = (4 * u + 3 < FIN) ? 4 * u * 2 * FOUT : (min(4 * u + q, FIN - 1) - q) * 2 * FOUT;
+        w0[u] = wq[off];
+        w1[u] = wq[off + FOUT];
+      }
+      bias = a.bias[ob * 16 + r];
+      const float* A0 = Ximg + (me * 16 + r) * LDX + q;
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], w0[u], acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * u], w1[u], acc, 0, 0, 0);
     float* Yg = a.Y + (int64_t)row0 * a.ldy;
