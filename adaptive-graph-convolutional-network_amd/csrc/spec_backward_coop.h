@@ -802,6 +802,48 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+// Sum over the 64 lanes with DPP row operations (lane ^ 1, lane ^ 2, the mirrored half row, the mirrored row: every lane then holds
+// its 16-lane row's sum, the same bits in all of them) and four lane reads; every lane returns the total.  EXEC must be all ones.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1, 0, 3, 2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2, 3, 0, 1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+// Squared distances of the row pair (zr[0], zr[1]) against this lane's column(s) over FIN features, Z^T rows LDZ floats apart
+// (LDZ = 0: the run-time stride ldz).  TWO: columns (zc[0], zc[1]) -> accA = row 0, accB = row 1; else one column -> .x of each.
+template <int FIN, int LDZ, bool TWO>
+__device__ __forceinline__ void coop_pair_dist(const float* zr, const float* zc, f32x2& accA, f32x2& accB, int ldz = 0) {
+  const int st = LDZ > 0 ? LDZ : ldz;
+  if constexpr (TWO) {
+#pragma unroll 5
+    for (int f = 0; f < FIN; ++f) {
+      const f32x2 u = *reinterpret_cast<const f32x2*>(zr + f * st);
+      const f32x2 v = *reinterpret_cast<const f32x2*>(zc + f * st);
+      const f32x2 dA = (f32x2){u.x, u.x} - v, dB = (f32x2){u.y, u.y} - v;
+      accA = __builtin_elementwise_fma(dA, dA, accA);
+      accB = __builtin_elementwise_fma(dB, dB, accB);
+    }
+  } else {
+    f32x2 acc = {0.f, 0.f};                               // (row 0, row 1) against the one column
+#pragma unroll 5
+    for (int f = 0; f < FIN; ++f) {
+      const f32x2 u = *reinterpret_cast<const f32x2*>(zr + f * st);
+      const float v = zc[f * st];
+      const f32x2 dd = u - (f32x2){v, v};
+      acc = __builtin_elementwise_fma(dd, dd, acc);
+    }
+    accA.x = acc.x; accB.x = acc.y;
+  }
+}
+#endif
+
 struct CoopFwdLds {
   int n4, ldt, ldz;
   int o_s, o_st, o_x, o_z, o_x1, total;
@@ -993,6 +1035,77 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   AGCN_STAMP(0, 2);
   // ---- P2: S[I, :], r[I, :], degree of the strip's rows (wave il = row i0 + il) -> s published -----------------------
   float rkeep[NCP] = {}, skeep[NCP] = {}, sd_keep = 0.f;
+  // members of up to 128 nodes: TWO rows per wave (waves 0 .. 7: rows ia, ia + 1) against all columns, two columns per lane beyond
+  // 64 nodes: the row pair's Z values come as ONE 8-byte broadcast read, the columns' as one read for both rows -- two LDS reads and
+  // four packed instructions per feature for 256 pairs, with the Z^T row stride a compile-time constant per 16-node size class
+  // (immediate offsets: no address arithmetic in the loop).  Before: one row per wave, three 4-byte reads (half the LDS rate),
+  // four scalar instructions and two address adds per feature for 128 pairs.  Per pair still ONE fma chain over the features in
+  // index order: S stays bit-symmetric across members.  The two degrees are summed with DPP row operations + four lane reads
+  // (a __shfl_down tree is six dependent LDS permutes per sum) and inverted by lanes 0 and 1 side by side.
+  constexpr bool ROWPAIR = NCP <= 2;
+  f32x2 rk2[2] = {{0.f, 0.f}, {0.f, 0.f}}, sk2[2] = {{0.f, 0.f}, {0.f, 0.f}};      // [row of the pair](columns c0, c0 + 1 | c0)
+  float sdk = 0.f;                                            // lane 0 | 1: s of row ia | ia + 1
+  const bool two = n > 64;                                    // (uniform) two columns per lane: 2 lane, 2 lane + 1
+  const int ia = i0 + 2 * wave, c0 = two ? 2 * lane : lane;
+  if constexpr (ROWPAIR) {
+    if (wave < 8) {
+      float ds[2] = {0.f, 0.f};
+      if (ia < n) {   // (uniform)
+        f32x2 accA = {0.f, 0.f}, accB = {0.f, 0.f};           // row ia, row ia + 1 against columns (c0, c0 + 1)  [one column: .x]
+        const float* zr = Zt + ia;                            // (8-byte aligned: ia, ldz, the region's offset are even)
+        const float* zc = Zt + (two ? min(c0, n4 - 2) : min(c0, n4 - 1));
+        switch (n4) {   // (uniform)
+          case 48: coop_pair_dist<FIN, 52, false>(zr, zc, accA, accB); break;
+          case 64: coop_pair_dist<FIN, 68, false>(zr, zc, accA, accB); break;
+          case 80: coop_pair_dist<FIN, 84, true>(zr, zc, accA, accB); break;
+          case 96: coop_pair_dist<FIN, 100, true>(zr, zc, accA, accB); break;
+          case 112: coop_pair_dist<FIN, 116, true>(zr, zc, accA, accB); break;
+          case 128: coop_pair_dist<FIN, 132, true>(zr, zc, accA, accB); break;
+          default:   // (no other size class reaches a member kernel of up to 128 nodes; kept for safety: run-time stride)
+            if (two) coop_pair_dist<FIN, 0, true>(zr, zc, accA, accB, ldz);
+            else coop_pair_dist<FIN, 0, false>(zr, zc, accA, accB, ldz);
+        }
+        AGCN_STAMP(0, 10);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int i = ia + rr;
+          const f32x2 acc = rr ? accB : accA;
+          float sv[2] = {0.f, 0.f}, rv[2] = {0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const int j = c0 + cc;
+            if (i < n && j < n && (cc == 0 || two)) {
+              rv[cc] = (i == j) ? 0.f : fast_sqrt(cc ? acc.y : acc.x);
+              sv[cc] = (i == j) ? 0.f : fast_exp_neg(rv[cc]);
+            }
+          }
+          rk2[rr] = (f32x2){rv[0], rv[1]};
+          sk2[rr] = (f32x2){sv[0], sv[1]};
+          ds[rr] = sv[0] + sv[1];
+        }
+      }
+      // S rows of the pair -> strip image (zero beyond the last node / the last row)
+      if (two) {
+        if (c0 < n4) {
+          *reinterpret_cast<f32x2*>(St + (2 * wave) * ldt + c0) = sk2[0];
+          *reinterpret_cast<f32x2*>(St + (2 * wave + 1) * ldt + c0) = sk2[1];
+        }
+      } else if (c0 < n4) {
+        St[(2 * wave) * ldt + c0] = sk2[0].x;
+        St[(2 * wave + 1) * ldt + c0] = sk2[1].x;
+      }
+      AGCN_STAMP(0, 12);
+      const float da = wave_sum_dpp(ds[0]), db = wave_sum_dpp(ds[1]);      // (every lane holds both)
+      AGCN_STAMP(0, 13);
+      if (paper && lane < 2 && ia + lane < n) {
+        // (published before any other store of this phase: the siblings' polls -- and this workgroup's own, which queue
+        // behind its stores in the one in-order memory counter -- then see it a store round trip earlier)
+        sdk = 1.0f / sqrtf((lane ? db : da) + FLT_TRUE_MIN);
+        s_vec[ia + lane] = sdk;
+        __hip_atomic_store(xch + ia + lane, coop_pack(sdk, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else
   {
     const int i = i0 + wave;
     float dsum = 0.f;
@@ -1057,6 +1170,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       __hip_atomic_store(xch + i, coop_pack(sd, wants[me]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  AGCN_STAMP(0, 7);
   if (tid < n4 && (!paper || tid >= n)) s_vec[tid] = 0.f;
   // While the first waves (tid < n: at most three) wait for the siblings' words -- one hand-off latency, ~2.5 us -- the LAST NOB
   // waves, which never poll, do the part of the filter that depends on nothing but this strip's X rows: they request both terms'
@@ -1088,7 +1202,27 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     const uint64_t w = coop_wait_word(a.sv_xch + COOP_STATUS_WORD, a.dev_status, a.coop_ticks, xch + tid, wants[tid >> 4], &got);
     s_vec[tid] = got ? __uint_as_float((uint32_t)w) : __builtin_nanf("");
   }
-  {   // the strip's rows of res_W and r, and s: out behind the exchange
+  AGCN_STAMP(0, 8);
+  if constexpr (ROWPAIR) {   // the strip's rows of res_W and r, and s: out behind the exchange
+    if (wave < 8) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int i = ia + rr;
+        if (i < n) {
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const int j = c0 + cc;
+            if (j < n && (cc == 0 || two)) {
+              const uint32_t o = toff + (uint32_t)(i * n + j);
+              AGCN_ST(1, &a.res_W[o], cc ? sk2[rr].y : sk2[rr].x);
+              if (paper) AGCN_ST(2, &a.sv_r[o], cc ? rk2[rr].y : rk2[rr].x);
+            }
+          }
+        }
+      }
+      if (lane < 2 && ia + lane < n) a.sv_s[row0 + ia + lane] = paper ? sdk : 0.f;
+    }
+  } else {
     const int i = i0 + wave;
     if (i < n) {
 #pragma unroll
@@ -1103,6 +1237,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       if (lane == 0) a.sv_s[row0 + i] = paper ? sd_keep : 0.f;
     }
   }
+  AGCN_STAMP(0, 9);
   lds_barrier();
 
   AGCN_STAMP(0, 3);

@@ -209,6 +209,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
           acc1 = __builtin_elementwise_fma(d1, d1, acc1);
         }
       }
+      AGCN_STAMP(1, 10);
       float a00 = acc0.x, a01 = acc0.y, a10 = acc1.x, a11 = acc1.y;
       for (int o = 1; o < fs; o <<= 1) {
         a00 += __shfl_xor(a00, o, 64);
@@ -216,6 +217,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         a10 += __shfl_xor(a10, o, 64);
         a11 += __shfl_xor(a11, o, 64);
       }
+      AGCN_STAMP(1, 11);
       // every lane of the group now holds the four sums; lane `part` finishes element e0 + part, so that the
       // sqrt / exp / store sequence is issued once per `step` elements instead of once per element
       for (int e0 = 0; e0 < 4; e0 += step) {
@@ -235,6 +237,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         }
       }
     }
+    AGCN_STAMP(1, 12);
   }
   lds_barrier();
   AGCN_STAMP(1, 3);
