@@ -41,10 +41,25 @@ struct FastDiv {
 __host__ __device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
 
 
+// the value of another lane by a DPP control word (0xB1: lane ^ 1, 0x4E: lane ^ 2 inside quads; 0x141: the mirrored half row
+// (lane 7 - l of every 8); 0x140: the mirrored row (15 - l of every 16)): a register move, not an LDS permute.  EXEC all ones.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// Sum over the 64 lanes: DPP row operations (lane ^ 1, lane ^ 2, the mirrored half row, the mirrored row: every lane then holds its
+// 16-lane row's sum, the same bits in all of them) and four lane reads; EVERY lane returns the total.  Fixed order: bit-reproducible.
+// (Until round 6 a __shfl_down tree: six dependent ds_bpermute round trips, ~0.15 us per sum on a phase's critical path.)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;  // lane 0 holds the total
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // Sum over the B per-graph (or per-slab) scalar partials pg[2 b + which] by ONE wave, in a fixed order: 16 loads in flight per

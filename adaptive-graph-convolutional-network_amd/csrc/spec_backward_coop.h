@@ -803,19 +803,6 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
 
 // ---- forward -------------------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
-// Sum over the 64 lanes with DPP row operations (lane ^ 1, lane ^ 2, the mirrored half row, the mirrored row: every lane then holds
-// its 16-lane row's sum, the same bits in all of them) and four lane reads; every lane returns the total.  EXEC must be all ones.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1, 0, 3, 2]
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2, 3, 0, 1]
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-  return (r0 + r1) + (r2 + r3);
-}
 // Squared distances of the row pair (zr[0], zr[1]) against this lane's column(s) over FIN features, Z^T rows LDZ floats apart
 // (LDZ = 0: the run-time stride ldz).  TWO: columns (zc[0], zc[1]) -> accA = row 0, accB = row 1; else one column -> .x of each.
 template <int FIN, int LDZ, bool TWO>
@@ -1095,7 +1082,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
         St[(2 * wave + 1) * ldt + c0] = sk2[1].x;
       }
       AGCN_STAMP(0, 12);
-      const float da = wave_sum_dpp(ds[0]), db = wave_sum_dpp(ds[1]);      // (every lane holds both)
+      const float da = wave_sum(ds[0]), db = wave_sum(ds[1]);      // (every lane holds both)
       AGCN_STAMP(0, 13);
       if (paper && lane < 2 && ia + lane < n) {
         // (published before any other store of this phase: the siblings' polls -- and this workgroup's own, which queue

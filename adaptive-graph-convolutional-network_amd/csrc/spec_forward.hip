@@ -200,23 +200,56 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       // packed fp32: a v_pk_add_f32 / v_pk_fma_f32 takes one issue slot like its scalar form and does two pairs
       f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
       if (live) {
-#pragma unroll 5
-        for (int f = part; f < FIN; f += fs) {
-          const f32x2 u = *reinterpret_cast<const f32x2*>(zi + f * ldz);
-          const f32x2 v = *reinterpret_cast<const f32x2*>(zj + f * ldz);
-          const f32x2 d0 = (f32x2){u.x, u.x} - v, d1 = (f32x2){u.y, u.y} - v;
-          acc0 = __builtin_elementwise_fma(d0, d0, acc0);
-          acc1 = __builtin_elementwise_fma(d1, d1, acc1);
+        // five features' operands requested before the first is used (a run-time stride keeps the compiler from hoisting the reads
+        // over the fma chain by itself: it waited out one LDS round trip per feature), one running pointer per operand
+        constexpr int DEPTH = (NW == NW_LARGE || DUAL) ? 5 : 3;     // (the standalone 8-wave kernels live within 80 registers)
+        const int fstep = fs * ldz;
+        const float* pi = zi + part * ldz;
+        const float* pj = zj + part * ldz;
+        int f = part;
+        for (; f + (DEPTH - 1) * fs < FIN; f += DEPTH * fs) {
+          f32x2 u[DEPTH], v[DEPTH];
+#pragma unroll
+          for (int k = 0; k < DEPTH; ++k) {
+            u[k] = *reinterpret_cast<const f32x2*>(pi + k * fstep);
+            v[k] = *reinterpret_cast<const f32x2*>(pj + k * fstep);
+          }
+          pi += DEPTH * fstep; pj += DEPTH * fstep;
+#pragma unroll
+          for (int k = 0; k < DEPTH; ++k) {
+            const f32x2 d0 = (f32x2){u[k].x, u[k].x} - v[k], d1 = (f32x2){u[k].y, u[k].y} - v[k];
+            acc0 = __builtin_elementwise_fma(d0, d0, acc0);
+            acc1 = __builtin_elementwise_fma(d1, d1, acc1);
+          }
+        }
+        {   // the last (up to DEPTH - 1) features of this lane: requested together as well (addresses clamped, sums under the test)
+          f32x2 u[DEPTH - 1], v[DEPTH - 1];
+#pragma unroll
+          for (int k = 0; k < DEPTH - 1; ++k) {
+            const bool on = f + k * fs < FIN;
+            u[k] = *reinterpret_cast<const f32x2*>(on ? pi + k * fstep : zi);
+            v[k] = *reinterpret_cast<const f32x2*>(on ? pj + k * fstep : zi);
+          }
+#pragma unroll
+          for (int k = 0; k < DEPTH - 1; ++k) {
+            if (f + k * fs < FIN) {
+              const f32x2 d0 = (f32x2){u[k].x, u[k].x} - v[k], d1 = (f32x2){u[k].y, u[k].y} - v[k];
+              acc0 = __builtin_elementwise_fma(d0, d0, acc0);
+              acc1 = __builtin_elementwise_fma(d1, d1, acc1);
+            }
+          }
         }
       }
       AGCN_STAMP(1, 10);
       float a00 = acc0.x, a01 = acc0.y, a10 = acc1.x, a11 = acc1.y;
-      for (int o = 1; o < fs; o <<= 1) {
-        a00 += __shfl_xor(a00, o, 64);
-        a01 += __shfl_xor(a01, o, 64);
-        a10 += __shfl_xor(a10, o, 64);
-        a11 += __shfl_xor(a11, o, 64);
-      }
+      // sum over the fs lanes of a block (fs = 1 .. 16, a power of two): lane ^ 1, lane ^ 2 as DPP quad permutations, then the
+      // mirrored half row and the mirrored row -- after the first two steps every lane of a quad holds the same bits, so the
+      // mirrored partner stands for lane ^ 4 / lane ^ 8: the same sums, bit for bit, as the __shfl_xor butterfly this replaces
+      // (a run-time xor distance made each of its steps an LDS permute: 0.46 us for eight of them)
+      if (fs >= 2) { a00 += dpp_mov<0xB1>(a00); a01 += dpp_mov<0xB1>(a01); a10 += dpp_mov<0xB1>(a10); a11 += dpp_mov<0xB1>(a11); }
+      if (fs >= 4) { a00 += dpp_mov<0x4E>(a00); a01 += dpp_mov<0x4E>(a01); a10 += dpp_mov<0x4E>(a10); a11 += dpp_mov<0x4E>(a11); }
+      if (fs >= 8) { a00 += dpp_mov<0x141>(a00); a01 += dpp_mov<0x141>(a01); a10 += dpp_mov<0x141>(a10); a11 += dpp_mov<0x141>(a11); }
+      if (fs >= 16) { a00 += dpp_mov<0x140>(a00); a01 += dpp_mov<0x140>(a01); a10 += dpp_mov<0x140>(a10); a11 += dpp_mov<0x140>(a11); }
       AGCN_STAMP(1, 11);
       // every lane of the group now holds the four sums; lane `part` finishes element e0 + part, so that the
       // sqrt / exp / store sequence is issued once per `step` elements instead of once per element
@@ -245,7 +278,22 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
   if (tid < n) {
     float dsum = 0.f;
     const float* col = tile + tid;
-    for (int i = 0; i < n; ++i) dsum += col[i * ldt];
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {      // (eight reads in flight; the adds stay in row order)
+      float c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = col[(i + k) * ldt];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dsum += c[k];
+    }
+    {
+      float c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = col[min(i + k, n - 1) * ldt];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i + k < n) dsum += c[k];
+    }
     dsum += FLT_TRUE_MIN;
     const float sd = 1.0f / sqrtf(dsum);
     s_vec[tid] = sd;
@@ -386,7 +434,15 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
 
   AGCN_STAMP(1, 5);
   // ---- F4: X_1 = L X_0 -> X_1 image (over Z^T) -------------------------------------------------------------
-  if (t5a < t5b) load_w(bA, t5a, 0);   // first W fragment of F5: its round trip overlaps F4
+  // first W fragments of F5 (both terms): their round trip overlaps F4.  (Before: the W_1 fragment was requested at the start of F5
+  // and waited for on the spot -- one L2 round trip of the phase's 1.4 us.)
+  // (the standalone 8-wave kernels live within 80 registers: there the second fragment is requested in F5 as before)
+  constexpr bool ROOMY = NW == NW_LARGE || DUAL;
+  float bW1[ROOMY ? NKS : 1];
+  if (t5a < t5b) {
+    load_w(bA, t5a, 0);
+    if constexpr (ROOMY) load_w(bW1, t5a, 1);
+  }
   {
     int t4a, t4b;
     tile_range<NW>(ntm * NCB, wave, t4a, t4b);
@@ -422,7 +478,12 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
     const int t = t5a + sl;
     if (t < t5b) {
       const int rt = t / NOB, ob = t - rt * NOB;
-      load_w(bB, t, 1);
+      if (ROOMY && sl == 0) {
+#pragma unroll
+        for (int u = 0; u < NKS; ++u) bB[u] = bW1[ROOMY ? u : 0];
+      } else {
+        load_w(bB, t, 1);
+      }
       ybias[sl] = a.bias[ob * 16 + r];
       const float* A0 = Ximg + (rt * 16 + r) * LDX + q;
       const float* A1 = X1img + (rt * 16 + r) * LDX + q;

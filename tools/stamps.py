@@ -56,13 +56,18 @@ def main():
     buf = np.zeros(8 * 1024 * 16, dtype=np.uint64)
     lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
     seq = os.environ.get("AGCN_STAMP_SEQ", "")     # e.g. "ff": two forwards in a row, "bf": backward then forward
-    if seq:
-        for ch in seq:
-            st.forward() if ch == "f" else st.backward()
-    else:
-        st.step()
-    lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
-    s = buf.reshape(8, 1024, 16).astype(np.int64)
+    reps = int(os.environ.get("AGCN_STAMP_REPS", 1))   # > 1: the sequence is repeated, medians over the repetitions are printed
+
+    def one():
+        if seq:
+            for ch in seq:
+                st.forward() if ch == "f" else st.backward()
+        else:
+            st.step()
+        lib.agcn_debug_read_stamps(buf.ctypes.data, buf.size, 1)
+        return buf.reshape(8, 1024, 16).astype(np.int64).copy()
+    runs = [one() for _ in range(reps)]
+    s = runs[0]
     names = ["PROJECT", "graph_fwd/slab_sim", "FILTER", "FILTER_BWD", "graph_bwd", "PROJECT_BWD", "slab_lap/DENSE", "param_grad"]
     for k, nm in enumerate(names):
         blk = s[k]
@@ -87,6 +92,16 @@ def main():
         # the block that ends last
         w = np.argmax(blk[used, last])
         print("   slowest block  :", np.round(rel[w], 2), "(block %d)" % np.nonzero(used)[0][w])
+        if reps > 1:
+            meds, maxs = [], []
+            for r in runs:
+                b = r[k]
+                u = b[:, 0] > 0
+                rr = (b[u][:, cols] - b[u, 0].min()) / 100.0
+                meds.append(np.median(rr, 0)); maxs.append(rr.max(0))
+            np.set_printoptions(linewidth=250)
+            print("   over %d repetitions: median of medians:" % reps, np.round(np.median(meds, 0), 2))
+            print("   over %d repetitions: median of maxima :" % reps, np.round(np.median(maxs, 0), 2))
 
 
 if __name__ == "__main__":
