@@ -41,6 +41,12 @@ struct FastDiv {
 __host__ __device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
 
 
+// x += v on an LDS cell as ONE ds_add_f32 without a return value: a handful of them issue back to back, where `cell += v` is a read, a
+// wait for it and a write per term (the CSR scatters of L_orig: six dependent LDS round trips per row).  Same single fp32 addition
+// per term, terms of one lane applied in program order: the same bits.
+__device__ __forceinline__ void lds_add(float* cell, float v) {
+  __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // the value of another lane by a DPP control word (0xB1: lane ^ 1, 0x4E: lane ^ 2 inside quads; 0x141: the mirrored half row
 // (lane 7 - l of every 8); 0x140: the mirrored row (15 - l of every 16)): a register move, not an LDS permute.  EXEC all ones.
 template <int CTRL>

@@ -176,6 +176,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       csr_v[u] = a.L0_val[pp];
     }
   }
+  AGCN_STAMP(4, 10);
   if (a.feat_bf16) {     // (widened HERE, behind every load of the round: spec_kernels.h, bf16_load_raw)
 #pragma unroll
     for (int u = 0; u < RPW; ++u)
@@ -211,6 +212,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       }
     }
   }
+  AGCN_STAMP(4, 11);
   // r tile: mirrored, diagonal 0
   if (paper) {
 #pragma unroll
@@ -231,6 +233,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }
   }
   if (tid < n) s_vec[tid] = paper ? s_own : 0.f;
+  AGCN_STAMP(4, 12);
   lds_barrier();
 
   AGCN_STAMP(4, 1);
@@ -273,8 +276,8 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
   if (!RESLAP && a.L0_rowptr && tid < n) {
 #pragma unroll
     for (int u = 0; u < 6; ++u)
-      if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
-    for (int p = csr_p0 + 6; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+      if (csr_p0 + u < csr_p1) lds_add(&tile[tid * ldt + csr_c[u]], csr_v[u]);
+    for (int p = csr_p0 + 6; p < csr_p1; ++p) lds_add(&tile[tid * ldt + a.L0_col[p]], a.L0_val[p]);
   }
 
   AGCN_STAMP(4, 2);
@@ -679,6 +682,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       }
     }
     // (no load is issued past this point)
+    AGCN_STAMP(4, 13);
 #pragma unroll
     for (int sl = 0; sl < MAXTB; ++sl) {
       const int t = t1a + sl;
@@ -713,8 +717,10 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }
     }
   }
+  AGCN_STAMP(4, 14);
   const float da = body_sum<NW>(dalpha_part, red, tid);
   const float db = RESLAP ? body_sum<NW>(dbeta_part, red, tid) : 0.f;
+  AGCN_STAMP(4, 15);
   if (tid == 0) {
     if (tail) {
       tail_store_f(a.ws_pg + 2 * g.b + 0, da);

@@ -353,10 +353,10 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   if (!RESLAP && a.L0_rowptr && tid < n) {      // CSR row tid: its entries in the columns of the strip
 #pragma unroll
     for (int u = 0; u < 6; ++u)
-      if (csr_p0 + u < csr_p1 && csr_c[u] >= i0 && csr_c[u] < i0 + 16) LT[(csr_c[u] - i0) * ldt + tid] += csr_v[u];
+      if (csr_p0 + u < csr_p1 && csr_c[u] >= i0 && csr_c[u] < i0 + 16) lds_add(&LT[(csr_c[u] - i0) * ldt + tid], csr_v[u]);
     for (int p = csr_p0 + 6; p < csr_p1; ++p) {
       const int c = a.L0_col[p];
-      if (c >= i0 && c < i0 + 16) LT[(c - i0) * ldt + tid] += a.L0_val[p];
+      if (c >= i0 && c < i0 + 16) lds_add(&LT[(c - i0) * ldt + tid], a.L0_val[p]);
     }
   }
 
@@ -1275,8 +1275,8 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       if (a.L0_rowptr && tid < 16 && i0 + tid < n) {
 #pragma unroll
         for (int u = 0; u < 6; ++u)
-          if (csr_p0 + u < csr_p1) St[tid * ldt + csr_c[u]] += csr_v[u];
-        for (int p = csr_p0 + 6; p < csr_p1; ++p) St[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+          if (csr_p0 + u < csr_p1) lds_add(&St[tid * ldt + csr_c[u]], csr_v[u]);
+        for (int p = csr_p0 + 6; p < csr_p1; ++p) lds_add(&St[tid * ldt + a.L0_col[p]], a.L0_val[p]);
       }
       lds_barrier();
       // ||L_pre||_F^2 of the whole graph -> scL; second clip + leaky-ReLU (:194-198): L_pre out (reserve), La -> strip + 4th output
@@ -1331,8 +1331,8 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   if (a.L0_rowptr && tid < 16 && i0 + tid < n) {
 #pragma unroll
     for (int u = 0; u < 6; ++u)
-      if (csr_p0 + u < csr_p1) St[tid * ldt + csr_c[u]] += csr_v[u];
-    for (int p = csr_p0 + 6; p < csr_p1; ++p) St[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+      if (csr_p0 + u < csr_p1) lds_add(&St[tid * ldt + csr_c[u]], csr_v[u]);
+    for (int p = csr_p0 + 6; p < csr_p1; ++p) lds_add(&St[tid * ldt + a.L0_col[p]], a.L0_val[p]);
   }
   lds_barrier();
   if (a.L_sum) {

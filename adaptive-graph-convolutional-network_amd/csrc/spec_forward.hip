@@ -421,8 +421,8 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       if (a.L0_rowptr && tid < n) {
 #pragma unroll
         for (int u = 0; u < 6; ++u)
-          if (csr_p0 + u < csr_p1) tile[tid * ldt + csr_c[u]] += csr_v[u];
-        for (int p = csr_p0 + 6; p < csr_p1; ++p) tile[tid * ldt + a.L0_col[p]] += a.L0_val[p];
+          if (csr_p0 + u < csr_p1) lds_add(&tile[tid * ldt + csr_c[u]], csr_v[u]);
+        for (int p = csr_p0 + 6; p < csr_p1; ++p) lds_add(&tile[tid * ldt + a.L0_col[p]], a.L0_val[p]);
       }
       lds_barrier();
       if (a.L_sum) {   // SGC_LL with the combined Laplacian requested
