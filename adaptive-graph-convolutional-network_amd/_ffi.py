@@ -20,7 +20,7 @@ class PlanInfo(C.Structure):
                 ("off_order", C.c_int64), ("off_wtile_off", C.c_int64),
                 ("n_slabs", C.c_int32), ("reserved1", C.c_int32),
                 ("off_slab_graph", C.c_int64), ("off_slab_row", C.c_int64), ("off_row_graph", C.c_int64),
-                ("off_graph_desc", C.c_int64)]
+                ("off_graph_desc", C.c_int64), ("off_slab_desc", C.c_int64)]
 
 
 class LayerDesc(C.Structure):

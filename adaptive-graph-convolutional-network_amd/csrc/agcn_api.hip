@@ -740,7 +740,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
   if (c.off > workspace_bytes || ((n_glb > 0 || dpart) && !workspace))
     return fail(AGCN_ENOSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, c.off);
 
-  a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+  a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.slab_desc = dev.slab_desc; a.n_slabs = host.info.n_slabs;
     a.slab_quad = slab_quad_ok(host);
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
   const FusedSplit fs = fused_split(desc, batch, host);
@@ -901,7 +901,7 @@ extern "C" int agcn_sgc_ll_forward(const AgcnLayerDesc* desc, const AgcnGraphBat
 
   // 2. graph-local stages (similarity tile, learned Laplacian, Chebyshev terms)
   const int B = host.info.B;
-  a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+  a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.slab_desc = dev.slab_desc; a.n_slabs = host.info.n_slabs;
     a.slab_quad = slab_quad_ok(host);
   a.sv_r = reinterpret_cast<float*>(rb + rl.r);
   if (use_slabs(desc, batch, host.info)) {
@@ -1047,7 +1047,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
   int coop_graphs = 0, coop_slabs = 0, dual_graphs = 0;
   coop_plan(desc, host, fs, true, &coop_graphs, &coop_slabs, &dual_graphs);
   if ((stages & 1) && fused) {
-    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.slab_desc = dev.slab_desc; a.n_slabs = host.info.n_slabs;
     a.slab_quad = slab_quad_ok(host);
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_Gp = w.Gp;
@@ -1177,7 +1177,7 @@ static int backward_impl(const AgcnLayerDesc* desc, const AgcnGraphBatch* batch,
         return fail(AGCN_EDEVICE, "%s: stream join failed", who);
     }
   } else if (stages & 1) {
-    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.n_slabs = host.info.n_slabs;
+    a.slab_graph = dev.slab_graph; a.slab_row = dev.slab_row; a.slab_desc = dev.slab_desc; a.n_slabs = host.info.n_slabs;
     a.slab_quad = slab_quad_ok(host);
     a.sv_r = reinterpret_cast<float*>(rb + rl.r);
     a.ws_dA = w.dA; a.ws_dAt = w.dAt; a.ws_dd = w.dd; a.ws_Gp = w.Gp;

@@ -74,6 +74,7 @@ struct PlanView {
   const int32_t* slab_row;
   const int32_t* row_graph;
   const AgcnGraphDesc* graph_desc;
+  const AgcnSlabDesc* slab_desc;
 };
 
 // Validates the HOST blob and returns views whose pointers point into `base`
@@ -91,6 +92,7 @@ inline int plan_view(const void* plan_host, const void* base, PlanView* v) {
   v->slab_row = reinterpret_cast<const int32_t*>(p + v->info.off_slab_row);
   v->row_graph = reinterpret_cast<const int32_t*>(p + v->info.off_row_graph);
   v->graph_desc = reinterpret_cast<const AgcnGraphDesc*>(p + v->info.off_graph_desc);
+  v->slab_desc = reinterpret_cast<const AgcnSlabDesc*>(p + v->info.off_slab_desc);
   return AGCN_OK;
 }
 

@@ -17,7 +17,7 @@ inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
   int64_t off_n, off_row_off, off_tile_off, off_order, off_wtile_off, off_slab_graph, off_slab_row, off_row_graph,
-      off_graph_desc, total;
+      off_graph_desc, off_slab_desc, total;
 };
 
 // max_slabs: upper bound used for sizing (sum of ceil(n/16) <= N1/16 + B, but N1 is unknown when
@@ -37,6 +37,7 @@ Layout layout_for(int32_t B, int64_t n_slabs, int64_t rows) {
   l.off_slab_row = o;    o = align_up(o + 4ll * n_slabs, 16);
   l.off_row_graph = o;   o = align_up(o + 4ll * rows, 16);
   l.off_graph_desc = o;  o = align_up(o + (int64_t)sizeof(AgcnGraphDesc) * B, 16);
+  l.off_slab_desc = o;   o = align_up(o + (int64_t)sizeof(AgcnSlabDesc) * n_slabs, 16);
   l.total = o;
   return l;
 }
@@ -131,6 +132,16 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
     }
   }
 
+  // ... and one per slab, for the workgroups that own a single slab of a graph
+  {
+    AgcnSlabDesc* sd = reinterpret_cast<AgcnSlabDesc*>(base + l.off_slab_desc);
+    for (int64_t s = 0; s < n_slabs; ++s) {
+      const int32_t g = slab_graph[s];
+      sd[s].graph = g; sd[s].row = slab_row[s]; sd[s].n = pn[g]; sd[s].row0 = row_off[g];
+      sd[s].tile_off = tile_off[g]; sd[s].tile_end = tile_off[g + 1];
+    }
+  }
+
   AgcnPlanInfo info;
   std::memset(&info, 0, sizeof(info));
   info.B = B;
@@ -150,6 +161,7 @@ extern "C" int agcn_plan_build(const int32_t* n, int32_t B, int32_t row_stride, 
   info.off_slab_row = l.off_slab_row;
   info.off_row_graph = l.off_row_graph;
   info.off_graph_desc = l.off_graph_desc;
+  info.off_slab_desc = l.off_slab_desc;
   std::memcpy(base, &kMagic, sizeof(kMagic));
   std::memcpy(base + sizeof(kMagic), &info, sizeof(info));
   return AGCN_OK;

@@ -87,6 +87,7 @@ struct SgcArgs {
   // slab-parallel path (slab_kernels.hip)
   const int32_t* slab_graph;
   const int32_t* slab_row;
+  const AgcnSlabDesc* slab_desc;     // [n_slabs]: one 32-byte load per member workgroup (spec_backward_coop.h)
   int32_t n_slabs;
   float* sv_r;     // [tile_elems]  r_ij = ||Z_i - Z_j||  (paper mode, forward -> backward)
   float* ws_dA;    // [tile_elems]  dA = -dR               (paper mode, bwd1 -> bwd2)

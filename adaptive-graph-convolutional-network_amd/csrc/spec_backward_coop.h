@@ -162,9 +162,9 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int b = uni(a.slab_graph[sl]), i0 = uni(a.slab_row[sl]);
-  const int n = uni(a.n[b]), row0 = uni(a.row_off[b]);
-  const uint32_t toff = (uint32_t)a.tile_off[b];
+  const SlabRec srec = load_slab(a.slab_desc + sl);
+  const int b = srec.b, i0 = srec.i0, n = srec.n, row0 = srec.row0;
+  const uint32_t toff = srec.toff;
   const CoopLds d = coop_lds(n, F4, FOUT, a.g_np);
   const int n4 = d.n4, ldt = d.ldt, ntm = n4 >> 4, rpw = n4 / NW;
   const int me = i0 >> 4;                      // member index == this strip's row tile
@@ -202,8 +202,11 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   // members of its graph before it publishes anything and bumps its own when it is done -- by then it holds every
   // sibling's words, so every sibling has read the epochs.
   uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [<= 16] in the (otherwise unused) tail of the `red` area
-  if (tid < ntm)
-    wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  // (requested by the first wave under a UNIFORM branch and stored behind the first round of loads: as `wants[tid] = load + 1`
+  //  under `tid < ntm` the first wave sat out a whole agent-scope round trip -- 0.7 us -- before it issued any of its loads, and the
+  //  first barrier waited for it)
+  uint64_t epw = 0;
+  if (wave == 0) epw = __hip_atomic_load(xep + min(lane, ntm - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   AGCN_STAMP(5, 0);
   // ---- M0: one round of loads ---------------------------------------------------------------------------------
@@ -314,6 +317,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
     }
   }
   if (tid < n4) s_vec[tid] = tid < n ? s_own : 0.f;
+  if (tid < ntm) wants[tid] = (uint32_t)epw + 1u;
   lds_barrier();
   AGCN_STAMP(5, 1);
 
@@ -769,7 +773,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
         for (int cp = 0; cp < NCP; ++cp)
           if (lane + 64 * cp < n) a.dL_prev[toff + (uint32_t)(i * n + lane + 64 * cp)] = dlpk[cp];
       }
-      if (i0 == 0 && tid < (int)((uint32_t)(a.tile_off[b + 1] - a.tile_off[b]) - (uint32_t)(n * n)))
+      if (i0 == 0 && tid < (int)srec.npad)
         a.dL_prev[toff + (uint32_t)(n * n) + tid] = 0.f;   // alignment floats behind the tile
     }
   }
@@ -880,9 +884,10 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int b = uni(a.slab_graph[sl]), i0 = uni(a.slab_row[sl]);
-  const int n = uni(a.n[b]), row0 = uni(a.row_off[b]);
-  const uint32_t toff = (uint32_t)a.tile_off[b];
+  AGCN_STAMP(0, 14);
+  const SlabRec srec = load_slab(a.slab_desc + sl);
+  const int b = srec.b, i0 = srec.i0, n = srec.n, row0 = srec.row0;
+  const uint32_t toff = srec.toff;
   // Z = X M_L on the bf16 pipe (spec_bfpipe.h) where this graph's planes + the M_L image fit the launch's LDS
   constexpr int KP = bfp_kp(F4), SXP = bfp_stride(KP);
   int np = a.bfp_fwd ? (a.feat_bf16 ? 1 : 3) : 0;
@@ -905,8 +910,8 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   uint64_t* xch = a.sv_xch + COOP_DIR_WORDS + (sl - me) * 16;                     // direction 1
   uint64_t* xep = a.sv_xch + COOP_DIR_WORDS + COOP_MAX_MEMBERS * 16 + (sl - me);
   uint32_t* wants = reinterpret_cast<uint32_t*>(smem + 16);   // [<= 16], see coop_backward_member
-  if ((paper || RESLAP) && tid < ntm)
-    wants[tid] = (uint32_t)__hip_atomic_load(xep + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  uint64_t epw = 0;      // (stored behind the first round of loads, see coop_backward_member)
+  if ((paper || RESLAP) && wave == 0) epw = __hip_atomic_load(xep + min(lane, ntm - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint64_t* xsc = a.sv_xch + COOP_SCAL_WORD + 2 * COOP_MAX_MEMBERS + (sl - me);      // direction 1, kind 0; kind 1 COOP_MAX_MEMBERS on
 
   AGCN_STAMP(0, 0);
@@ -978,6 +983,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       csr_v[u] = a.L0_val[pp];
     }
   }
+  if ((paper || RESLAP) && tid < ntm) wants[tid] = (uint32_t)epw + 1u;
   lds_barrier();
 
   AGCN_STAMP(0, 1);
@@ -1418,7 +1424,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     }
   }
   if (i0 == 0) {
-    const uint32_t npad = (uint32_t)(a.tile_off[b + 1] - a.tile_off[b]) - (uint32_t)(n * n);
+    const uint32_t npad = srec.npad;
     if (tid < (int)npad) {   // alignment floats behind the tile
       a.res_W[toff + (uint32_t)(n * n) + tid] = 0.f;
       a.res_L[toff + (uint32_t)(n * n) + tid] = 0.f;

@@ -164,9 +164,16 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       }
     }
   }
-  // W fragments of this wave's F5 tiles
+  // W fragments of this wave's F5 tiles.  (ROOMY: 16-wave launches) the tiles go to the LAST waves -- the ones the pair phase F2 leaves
+  // idle (its 2 x 2 blocks fill the first waves) -- and their first term T_0 = X_0 W_0, which depends on nothing but the X image,
+  // runs THERE, beside F2; F5 then only adds X_1 W_1 onto the same accumulators (the same instruction sequence per accumulator,
+  // split in time: the same bits).  F5 is bound by the fp32 matrix pipe (two-tile graph: 8 tiles x 38 chained MFMAs = 1.0 us of
+  // pipe time): half of it moves into a phase that does not use the pipe.  (The standalone 8-wave kernels live within 80 registers:
+  // there both terms stay in F5.)
+  constexpr bool ROOMY = NW == NW_LARGE || DUAL;
+  constexpr bool EARLYF = ROOMY && FIN <= 80 && !RESLAP;     // (Reslap holds 16 registers of L_prev across F0 .. F3: it would spill)
   int t5a, t5b;
-  tile_range<NW>(ntm * NOB, wave, t5a, t5b);
+  tile_range<NW>(ntm * NOB, EARLYF ? NW - 1 - wave : wave, t5a, t5b);
   const float* wq = a.weight + q * 2 * FOUT + r;
   auto load_w = [&](float (&bf)[NKS], int t, int h) {
     const int ob = t % NOB;
@@ -177,6 +184,12 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       else bf[u] = p[(min(4 * u + q, FIN - 1) - q) * 2 * FOUT];
     }
   };
+  f32x4 yacc[MAXT];
+  float ybias[MAXT];
+  float bW1[ROOMY ? NKS : 1];
+  if constexpr (EARLYF) {
+    if (t5a < t5b) load_w(bA, t5a, 0);      // (its round trip overlaps the barrier and the pair loop)
+  }
   lds_barrier();
 
   AGCN_STAMP(1, 2);
@@ -271,6 +284,29 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       }
     }
     AGCN_STAMP(1, 12);
+  }
+  if constexpr (EARLYF) {   // T_0 = X_0 W_0 of this wave's F5 tiles (two fragment buffers: the next tile's is in flight)
+#pragma unroll
+    for (int sl = 0; sl < MAXT; ++sl) {
+      const int t = t5a + sl;
+      if (t < t5b) {
+        const int rt = t / NOB, ob = t - rt * NOB;
+        ybias[sl] = a.bias[ob * 16 + r];
+        const float* A0 = Ximg + (rt * 16 + r) * LDX + q;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((sl & 1) == 0) {
+          if (t + 1 < t5b) load_w(bB, t + 1, 0);
+#pragma unroll
+          for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bA[u], acc, 0, 0, 0);
+        } else {
+          if (t + 1 < t5b) load_w(bA, t + 1, 0);
+#pragma unroll
+          for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bB[u], acc, 0, 0, 0);
+        }
+        yacc[sl] = acc;
+      }
+    }
+    if (t5a < t5b) load_w(bW1, t5a, 1);     // first W_1 fragment: consumed in F5
   }
   lds_barrier();
   AGCN_STAMP(1, 3);
@@ -437,11 +473,11 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
   // first W fragments of F5 (both terms): their round trip overlaps F4.  (Before: the W_1 fragment was requested at the start of F5
   // and waited for on the spot -- one L2 round trip of the phase's 1.4 us.)
   // (the standalone 8-wave kernels live within 80 registers: there the second fragment is requested in F5 as before)
-  constexpr bool ROOMY = NW == NW_LARGE || DUAL;
-  float bW1[ROOMY ? NKS : 1];
-  if (t5a < t5b) {
-    load_w(bA, t5a, 0);
-    if constexpr (ROOMY) load_w(bW1, t5a, 1);
+  if constexpr (!EARLYF) {
+    if (t5a < t5b) {
+      load_w(bA, t5a, 0);
+      if constexpr (ROOMY) load_w(bW1, t5a, 1);
+    }
   }
   {
     int t4a, t4b;
@@ -471,8 +507,6 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
 
   AGCN_STAMP(1, 6);
   // ---- F5: Y = act(X_0 W_0 + X_1 W_1 + b); accumulators held until every W fragment has been requested -----
-  f32x4 yacc[MAXT];
-  float ybias[MAXT];
 #pragma unroll
   for (int sl = 0; sl < MAXT; ++sl) {
     const int t = t5a + sl;
@@ -484,13 +518,17 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       } else {
         load_w(bB, t, 1);
       }
-      ybias[sl] = a.bias[ob * 16 + r];
-      const float* A0 = Ximg + (rt * 16 + r) * LDX + q;
       const float* A1 = X1img + (rt * 16 + r) * LDX + q;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (EARLYF) {
+        acc = yacc[sl];
+      } else {
+        ybias[sl] = a.bias[ob * 16 + r];
+        const float* A0 = Ximg + (rt * 16 + r) * LDX + q;
 #pragma unroll
-      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bA[u], acc, 0, 0, 0);
-      if (t + 1 < t5b) load_w(bA, t + 1, 0);
+        for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bA[u], acc, 0, 0, 0);
+        if (t + 1 < t5b) load_w(bA, t + 1, 0);
+      }
 #pragma unroll
       for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * u], bB[u], acc, 0, 0, 0);
       yacc[sl] = acc;

@@ -201,6 +201,25 @@ struct TriFold19 {
 };
 
 // deterministic sum over the NW waves of one body (block_sum of agcn_device.h for a body that may be half a workgroup);
+// the member workgroups' counterpart: slab record `sl` of the plan (AgcnSlabDesc, one s_load_dwordx8; before: slab_graph / slab_row, then
+// n / row_off / tile_off of that graph -- two dependent round trips, 0.7 us between a member's first instruction and its first load)
+struct SlabRec { int b, i0, n, row0; uint32_t toff, npad; };
+__device__ __forceinline__ SlabRec load_slab(const AgcnSlabDesc* sd) {
+  const uint64_t ga = reinterpret_cast<uint64_t>(sd);
+  const uint64_t gs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ga >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ga);
+  i32x8 rec;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(gs) : "memory");
+  SlabRec g;
+  g.b = rec[0];
+  g.i0 = rec[1];
+  g.n = rec[2];
+  g.row0 = rec[3];
+  g.toff = (uint32_t)rec[4];
+  g.npad = (uint32_t)rec[6] - g.toff - (uint32_t)(g.n * g.n);
+  return g;
+}
+
 // red: 32 floats of the body's LDS; contains barriers: uniform control flow only
 template <int NW>
 __device__ __forceinline__ float body_sum(float v, float* red, int tid) {

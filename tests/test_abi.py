@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(amd):
     for name in declared:
         assert hasattr(lib, name), "libagcn_hip.so does not export %s" % name
     assert sorted(amd._ffi.SYMBOLS) == declared
-    assert lib.agcn_version() == 106
+    assert lib.agcn_version() == 107
 
 
 def test_dynamic_symbol_table_is_the_header_and_nothing_else(amd):

@@ -5,7 +5,7 @@ O=gpurun_out/p1; mkdir -p $O
 if [ "$FULL" = 1 ]; then timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > $O/tests.log
 else timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "bf16 or full_size or members or spread or packed_vs_oracle or golden or tagged or bit_rep or epoch or reslap" 2>&1 | tail -4 > $O/tests.log; fi
 tail -4 $O/tests.log
-AGCN_STAMP_REPS=9 AGCN_STAMP_SEQ=fbfbfbfb timeout 200 python tools/stamps.py 2>&1 | grep -A1 "blocks\|over 9" | grep -v "^--\|stamp idx\|median of medians" > $O/stamps.txt; cat $O/stamps.txt
+AGCN_STAMP_REPS=9 AGCN_STAMP_SEQ=fbfbfbfb timeout 200 python tools/stamps.py 2>&1 | grep -A1 "blocks\|over 9\|launch " | grep -v "^--\|stamp idx\|median of medians" > $O/stamps.txt; cat $O/stamps.txt
 for rep in 1 2 3; do
 for v in base new; do
   L=adaptive-graph-convolutional-network_amd/lib/libagcn_hip.so; [ $v = base ] && L=tools/build/libagcn_base.so

@@ -77,8 +77,8 @@ def main():
         t0 = blk[used, 0].min()
         cols = [c for c in range(16) if (blk[used, c] > 0).any()]
         cols = sorted(cols, key=lambda c: np.median(blk[used, c]))
-        last = max(cols)
-        print("%-12s blocks %4d  span %.2f us (first start -> last end)" % (nm, used.sum(), (blk[used, last].max() - t0) / 100.0))
+        print("%-12s blocks %4d  span %.2f us (first start -> last end)" % (nm, used.sum(), (blk[used].max() - t0) / 100.0))
+        last = cols[-1]
         rel = (blk[used][:, cols] - t0) / 100.0
         print("   stamp idx      :", cols)
         print("   median (us)    :", np.round(np.median(rel, 0), 2))
@@ -102,6 +102,28 @@ def main():
             np.set_printoptions(linewidth=250)
             print("   over %d repetitions: median of medians:" % reps, np.round(np.median(meds, 0), 2))
             print("   over %d repetitions: median of maxima :" % reps, np.round(np.median(maxs, 0), 2))
+
+
+    # whole launches: the forward = members (slot 0) + one-workgroup bodies (slot 1), the backward = slots 5 + 4
+    for nm, slots in (("forward launch", (0, 1)), ("backward launch", (5, 4)), ("param-grad launch", (7,))):
+        spans, per = [], {k: ([], []) for k in slots}
+        for r in runs:
+            v = np.concatenate([r[k][r[k][:, 0] > 0] for k in slots])
+            if len(v) == 0:
+                continue
+            t0 = np.where(v > 0, v, np.iinfo(np.int64).max).min()
+            spans.append((v.max() - t0) / 100.0)
+            for k in slots:
+                b = r[k][r[k][:, 0] > 0]
+                if len(b):
+                    st0 = np.where(b > 0, b, np.iinfo(np.int64).max).min(1)
+                    per[k][0].append((st0.max() - t0) / 100.0)
+                    per[k][1].append((b.max() - t0) / 100.0)
+        if spans:
+            print("%-18s first start -> last stamp, median over %d repetitions: %.2f us" % (nm, len(spans), np.median(spans)))
+            for k in slots:
+                if per[k][0]:
+                    print("    %-20s last workgroup starts at %.2f, last one ends at %.2f us of the launch" % (names[k], np.median(per[k][0]), np.median(per[k][1])))
 
 
 if __name__ == "__main__":
