@@ -134,10 +134,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       bp[kb][0] = bt[0]; bp[kb][1] = bt[64]; bp[kb][2] = bt[128];
     }
   };
-  if (t1a < t1b) {
-    if (gbf) load_bp(bpa, t1a, 0);
-    else load_wc(wb0, t1a, 0, 0);
-  }
   // r tile rows (the forward stored r_ij for i < j)
   float rr[RPW][2];
 #pragma unroll
@@ -175,6 +171,12 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       csr_c[u] = a.L0_col[pp];
       csr_v[u] = a.L0_val[pp];
     }
+  }
+  // first parameter fragments of phase G: requested LAST (loads return in order: in front of the r / s / CSR requests their 4-6 KB per
+  // wave held up everything this phase stores to LDS; they are consumed two barriers further on)
+  if (t1a < t1b) {
+    if (gbf) load_bp(bpa, t1a, 0);
+    else load_wc(wb0, t1a, 0, 0);
   }
   AGCN_STAMP(4, 10);
   if (a.feat_bf16) {     // (widened HERE, behind every load of the round: spec_kernels.h, bf16_load_raw)
