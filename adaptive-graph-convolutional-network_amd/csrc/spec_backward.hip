@@ -178,7 +178,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     if (gbf) load_bp(bpa, t1a, 0);
     else load_wc(wb0, t1a, 0, 0);
   }
-  AGCN_STAMP(4, 10);
   if (a.feat_bf16) {     // (widened HERE, behind every load of the round: spec_kernels.h, bf16_load_raw)
 #pragma unroll
     for (int u = 0; u < RPW; ++u)
@@ -214,7 +213,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       }
     }
   }
-  AGCN_STAMP(4, 11);
   // r tile: mirrored, diagonal 0
   if (paper) {
 #pragma unroll
@@ -235,7 +233,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }
   }
   if (tid < n) s_vec[tid] = paper ? s_own : 0.f;
-  AGCN_STAMP(4, 12);
   lds_barrier();
 
   AGCN_STAMP(4, 1);
@@ -346,11 +343,9 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       }
     }
   }
-  lds_barrier();
-
-  AGCN_STAMP(4, 3);
-  // ---- B1: dX += L^T g_1 --------------------------------------------------------------------------------------
-  // (paper) the X_0 rows B2 needs are requested now; their round trip overlaps the matrix work
+  // (paper) the X_0 rows B2 needs are requested HERE, behind phase G's products (its fragment registers are free again) and in front
+  // of its closing barrier: the round trip overlaps the barrier and B1's matrix work (requested at the start of B1 it outlasted
+  // that work by most of a microsecond)
   float xzr[RPW][CP];
   if (paper || RESLAP) {
 #pragma unroll
@@ -363,6 +358,10 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       }
     }
   }
+  lds_barrier();
+
+  AGCN_STAMP(4, 3);
+  // ---- B1: dX += L^T g_1 --------------------------------------------------------------------------------------
 #pragma unroll
   for (int sl = 0; sl < MAXTB; ++sl) {
     const int t = t1a + sl;
@@ -558,6 +557,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       rsum = wave_sum(rsum);
       if (lane == 0) rsv[i] = rsum;
     }
+    AGCN_STAMP(4, 10);
     lds_barrier();
     if (tid < n) {
       float cs = 0.f;
@@ -565,6 +565,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       for (int w = 0; w < NW; ++w) cs += colp[w * n4 + tid];
       ddv[tid] = degree_grad(s_vec[tid], rsv[tid] + cs);   // dd_k = -1/2 s_k^3 ds_k
     }
+    AGCN_STAMP(4, 11);
     lds_barrier();
     AGCN_STAMP(4, 6);
     // pass 2: c_ij = (dr_ij + dr_ji) / r_ij for i < j, dr_ij = -S_ij (dA_ij s_i s_j + dd_j) (0 where S or r is 0),
@@ -592,6 +593,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         }
       }
     }
+    AGCN_STAMP(4, 12);
     lds_barrier();
     for (int i = wave; i < n; i += NW) {
       float rsum = 0.f;
