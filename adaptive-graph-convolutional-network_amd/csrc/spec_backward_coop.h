@@ -837,11 +837,14 @@ __device__ __forceinline__ void coop_pair_dist(const float* zr, const float* zc,
 
 struct CoopFwdLds {
   int n4, ldt, ldz;
-  int o_s, o_st, o_x, o_z, o_x1, total;
+  int o_s, o_st, o_x, o_z, o_x1, o_ml, total;
   int o_xp, o_mi, xp_plane;   // np > 0 (spec_bfpipe.h): the bf16 piece planes of X [np][n4][S] and the operand-order image of M_L (dwords)
 };
 // np = 0: Z = X M_L on the fp32 matrix instruction (parameter fragments from global memory); np = 1 | 3: on the bf16 pipe
 // (spec_bfpipe.h), X as np piece planes (1: bf16 features, 3: fp32 features split exactly) + the M_L image, both in LDS
+// row stride of the staged M_L: == 16 (mod 64) floats, so that the four k rows of a fragment read fall into four different
+// 16-bank groups (lane (r, q) reads row 4 u + q, column 16 cb + r)
+AGCN_HD constexpr int coop_ml_stride(int F4) { return ((F4 + 47) / 64) * 64 + 16; }
 AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4, int np = 0) {
   CoopFwdLds d;
   d.n4 = (n + 15) & ~15;
@@ -855,6 +858,15 @@ AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4, int np = 0) {
   d.o_x1 = d.o_z + F4 * d.ldz;        // [16][ldx]  X_1 rows of the strip
   d.total = d.o_x1 + 16 * ldx;
   d.o_xp = d.o_mi = d.xp_plane = 0;
+  // M_L itself, staged ONCE per workgroup ([F4][coop_ml_stride(F4)], zero beyond the last feature): the fragments of Z = X M_L are
+  // LDS reads then -- from global memory every row tile re-read the whole matrix with 64-byte pieces (n / 16 x 24 KB through the
+  // CU's address path), a fragment round trip in front of every tile.  Layers of up to 80 input features, graphs of up to
+  // COOP_MAX_N nodes (beyond, the plan is tight), fp32 matrix path only.
+  d.o_ml = 0;
+  if (np == 0 && F4 <= 80 && n <= COOP_MAX_N) {
+    d.o_ml = d.total;
+    d.total += F4 * coop_ml_stride(F4);
+  }
   if (np > 0) {
     const int KP = bfp_kp(F4);
     d.total = (d.total + 3) & ~3;       // (16-byte aligned: the planes and the image are read with ds_read_b128)
@@ -921,6 +933,20 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     csr_p0 = a.L0_rowptr[row0 + i0 + tid];
     csr_p1 = a.L0_rowptr[row0 + i0 + tid + 1];
   }
+  // M_L for the LDS copy (coop_fwd_lds): coalesced rows, requested with the first round of loads
+  float* MLs = smem + d.o_ml;
+  constexpr int SML = coop_ml_stride(F4);
+  const bool ml_staged = d.o_ml > 0;      // (uniform)
+  constexpr int PER = (F4 * F4 + 64 * NW - 1) / (64 * NW);
+  float mv[PER];
+  if (ml_staged) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int idx = min(tid + 64 * NW * e, F4 * F4 - 1);
+      const int k = idx / F4, c = idx - k * F4;
+      mv[e] = a.M_L[min(k, FIN - 1) * FIN + min(c, FIN - 1)];
+    }
+  }
   // (bf16 pipe) this thread's eight values of the M_L image, requested with the first round of loads
   constexpr int MI_THREADS = (KP / 32) * (F4 / 16) * 64;
   float mlv[8];
@@ -964,6 +990,15 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     }
   }
   if (np > 0 && tid < MI_THREADS) bfp_store_param<FIN, FIN, KP, F4>(MI, mlv, tid);
+  // M_L -> LDS (zero beyond the last feature)
+  if (ml_staged) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int idx = tid + 64 * NW * e;
+      const int k = idx / F4, c = idx - k * F4;
+      if (idx < F4 * F4) MLs[k * SML + c] = (k < FIN && c < FIN) ? mv[e] : 0.f;
+    }
+  }
   // Reslap: the strip's rows of L_prev (wave il = row i0 + il), requested with the first round of loads
   float lprv[NCP] = {};
   if constexpr (RESLAP) {
@@ -1003,6 +1038,11 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
           const u32x4* bt = MI + (size_t)(kb * NCB + cb) * 192;
           acc = np == 1 ? bfp_mma<1>(acc, arow, d.xp_plane, kb, q, bt, lane) : bfp_mma<3>(acc, arow, d.xp_plane, kb, q, bt, lane);
         }
+      } else if (ml_staged) {   // (uniform) fragments from the staged matrix: rows 4 u + q (zero from row FIN on, as the A image's columns)
+      const float* p = MLs + q * SML + cb * 16 + r;
+      const float* Ap = Ximg + (rt * 16 + r) * LDX + q;
+#pragma unroll
+      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], p[4 * u * SML], acc, 0, 0, 0);
       } else {
       const float* p = mq + min(cb * 16 + r, FIN - 1);
       float bf[NKS];
