@@ -20,8 +20,15 @@ extern __device__ unsigned long long g_agcn_stamps[];
     if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0)                               \
       g_agcn_stamps[((kernel_slot) * 1024 + blockIdx.x) * 16 + (i)] = wall_clock64();           \
   } while (0)
+// ... the same from thread `t` of the block (e.g. the first lane of the last wave: how far behind wave 0 it runs)
+#define AGCN_STAMP_T(kernel_slot, i, t)                                                         \
+  do {                                                                                          \
+    if ((int)threadIdx.x == (t) && blockIdx.x < 1024 && blockIdx.y == 0)                        \
+      g_agcn_stamps[((kernel_slot) * 1024 + blockIdx.x) * 16 + (i)] = wall_clock64();           \
+  } while (0)
 #else
 #define AGCN_STAMP(kernel_slot, i) do {} while (0)
+#define AGCN_STAMP_T(kernel_slot, i, t) do {} while (0)
 #endif
 
 namespace agcn {

@@ -173,11 +173,14 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }
   }
   // first parameter fragments of phase G: requested LAST (loads return in order: in front of the r / s / CSR requests their 4-6 KB per
-  // wave held up everything this phase stores to LDS; they are consumed two barriers further on)
+  // wave held up everything this phase stores to LDS; they are consumed two barriers further on).  (Requested behind B0's barrier
+  // instead -- B0 is bound by the CU's vector-memory path, its last wave issues its loads 2 us into the phase -- B0 ends 0.4 us
+  // earlier and B0b / G pay it back: kernel 16.95 -> 17.12 us, measured.)
   if (t1a < t1b) {
     if (gbf) load_bp(bpa, t1a, 0);
     else load_wc(wb0, t1a, 0, 0);
   }
+  AGCN_STAMP_T(4, 10, 64 * NW - 64);
   if (a.feat_bf16) {     // (widened HERE, behind every load of the round: spec_kernels.h, bf16_load_raw)
 #pragma unroll
     for (int u = 0; u < RPW; ++u)
@@ -213,6 +216,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       }
     }
   }
+  AGCN_STAMP_T(4, 11, 64 * NW - 64);
   // r tile: mirrored, diagonal 0
   if (paper) {
 #pragma unroll
@@ -233,6 +237,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
     }
   }
   if (tid < n) s_vec[tid] = paper ? s_own : 0.f;
+  AGCN_STAMP_T(4, 12, 64 * NW - 64);
   lds_barrier();
 
   AGCN_STAMP(4, 1);
@@ -557,7 +562,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       rsum = wave_sum(rsum);
       if (lane == 0) rsv[i] = rsum;
     }
-    AGCN_STAMP(4, 10);
     lds_barrier();
     if (tid < n) {
       float cs = 0.f;
@@ -565,7 +569,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
       for (int w = 0; w < NW; ++w) cs += colp[w * n4 + tid];
       ddv[tid] = degree_grad(s_vec[tid], rsv[tid] + cs);   // dd_k = -1/2 s_k^3 ds_k
     }
-    AGCN_STAMP(4, 11);
     lds_barrier();
     AGCN_STAMP(4, 6);
     // pass 2: c_ij = (dr_ij + dr_ji) / r_ij for i < j, dr_ij = -S_ij (dA_ij s_i s_j + dd_j) (0 where S or r is 0),
@@ -593,7 +596,6 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         }
       }
     }
-    AGCN_STAMP(4, 12);
     lds_barrier();
     for (int i = wave; i < n; i += NW) {
       float rsum = 0.f;
