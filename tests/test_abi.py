@@ -133,6 +133,28 @@ def test_graph_descriptor_table(amd):
     assert list(n[p.order]) == sorted(n, reverse=True)
 
 
+def test_slab_descriptor_table(amd):
+    """AgcnSlabDesc records (ABI 107), in slab order, agree with slab_graph / slab_row and the per-graph plan arrays; the table lies
+    inside the blob agcn_plan_bytes_for sized."""
+    n = np.array([5, 33, 9, 64, 17, 1, 130], dtype=np.int32)
+    p = amd.Plan(n)
+    rec = np.dtype([("graph", "<i4"), ("row", "<i4"), ("n", "<i4"), ("row0", "<i4"), ("tile_off", "<i8"), ("tile_end", "<i8")])
+    assert rec.itemsize == 32
+    off = p.info.off_slab_desc
+    assert off > 0 and off % 16 == 0 and off + 32 * p.n_slabs <= p.info.plan_bytes <= len(p.host)
+    sd = p.host[off:off + 32 * p.n_slabs].view(rec)
+    assert p.n_slabs == int(((n + 15) // 16).sum())
+    np.testing.assert_array_equal(sd["graph"], p.slab_graph)
+    np.testing.assert_array_equal(sd["row"], p.slab_row)
+    np.testing.assert_array_equal(sd["n"], n[p.slab_graph])
+    np.testing.assert_array_equal(sd["row0"], p.row_off[p.slab_graph])
+    np.testing.assert_array_equal(sd["tile_off"], p.tile_off[p.slab_graph])
+    np.testing.assert_array_equal(sd["tile_end"], p.tile_off[p.slab_graph + 1])
+    # slabs of one graph are consecutive, rows 0, 16, ..; graphs in schedule order (largest first)
+    assert list(sd["row"][sd["graph"] == 6]) == list(range(0, 130, 16))
+    assert sd["graph"][0] == 6 and sd["graph"][-1] == 5
+
+
 def test_new_entry_points_validate_before_launching(amd):
     """Host-side argument checks of the tail / ingest / layout entry points (no kernel is launched on an error)."""
     lib = amd._ffi.lib()
