@@ -27,18 +27,20 @@ constexpr int MAXTB = 3;   // most MFMA tiles of one phase a wave may own
 // The body for ONE graph; DUAL as in spec_forward.hip.  RESLAP: SGC_LL_Reslap (graphconv_reslap.py:184-198 under autodiff):
 // L is the saved, twice clipped L_sum; between dL = g_1 X_0^T and the pair passes sit the adjoints of the two
 // clip_by_norm + leaky-ReLU stages (two graph-wide inner products), dbeta and dL_prev.
-template <int FIN, int FOUT, int NW, bool DUAL, bool RESLAP>
-__device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int gpos, float* smem_) {
+// RPWC > 0: the body for graphs whose waves own at most RPWC rows of a node-feature matrix (n4 <= RPWC NW) -- the unrolled
+// per-row loops of the load / store phases then have RPWC iterations instead of 6 | 8: a two-tile graph on sixteen waves owns TWO
+// rows per wave, and the dead iterations (predicated off, but issued) were most of the instructions of its first phase.
+template <int FIN, int FOUT, int NW, bool DUAL, bool RESLAP, int RPWC = 0>
+__device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int gpos, float* smem_, const GraphRec& g) {
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
   constexpr int F4 = FT::F4, LDX = FT::LDX, NCB = FT::NCB, NKS = FT::NKS, CP = FT::CP;
   constexpr int LDG = FOUT + 2, CPO = (FOUT + 63) / 64;
-  constexpr int RPW = NW == NW_SMALL ? 6 : 8;   // rows of a node-feature matrix one wave may own (n4 <= 48 | 128)
+  constexpr int RPW = RPWC > 0 ? RPWC : (NW == NW_SMALL ? 6 : 8);   // rows of a node-feature matrix one wave may own (n4 <= 48 | 128)
   const int tid = DUAL ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;
   float* smem = smem_ + ((DUAL && (int)threadIdx.x >= NT) ? a.dual_stride : 0);
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const GraphRec g = load_graph(a.graph_desc + gpos);
   const int n = g.n, row0 = g.row0;
   const uint32_t toff = g.toff;
   // phase G on the bf16 pipe (spec_bfpipe.h; a.g_np: 1 = bf16 features, Gp is one piece; 3 = fp32 features, three piece planes)
@@ -755,6 +757,9 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
 template <int FIN, int FOUT, int NW, int FULL, bool RESLAP = false>
 __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMALL_OCC) : 4) void spec_backward_kernel(SgcArgs a, int first) {
   constexpr int MAXN = FULL == 2 ? COOP_MAX_N_WIDE : COOP_MAX_N;
+  // paired small graphs have at most DUAL_MAX_N nodes: n4 = 16, two rows of a node-feature matrix per wave of their eight
+  static_assert(DUAL_MAX_N <= 16, "the paired bodies' row loops are sized for one 16-row tile");
+  constexpr int DUAL_RPW = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if constexpr (RESLAP) {   // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
     int blk = (int)blockIdx.x;
@@ -765,11 +770,16 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
       }
       blk -= a.coop_slabs;
       if (blk >= a.plain_count) {
-        spec_backward_body<FIN, FOUT, NW_SMALL, true, true>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
+        const int gp = first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9);
+        spec_backward_body<FIN, FOUT, NW_SMALL, true, true, DUAL_RPW>(a, gp, smem, load_graph(a.graph_desc + gp));
         return;
       }
     }
-    spec_backward_body<FIN, FOUT, NW, false, true>(a, first + blk, smem);
+    {
+      const GraphRec g = load_graph(a.graph_desc + first + blk);
+      if (NW == NW_LARGE && g.n <= 2 * NW) spec_backward_body<FIN, FOUT, NW, false, true, NW == NW_LARGE ? 2 : 0>(a, first + blk, smem, g);
+      else spec_backward_body<FIN, FOUT, NW, false, true>(a, first + blk, smem, g);
+    }
   } else if constexpr (FULL) {
     // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
     //       [parameter-gradient tiles: tail_tiles (spec_tail.h)]
@@ -784,10 +794,15 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     }
     blk -= a.coop_slabs;
     if (blk >= a.plain_count) {
-      spec_backward_body<FIN, FOUT, NW_SMALL, true, false>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
+      const int gp = first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9);
+      spec_backward_body<FIN, FOUT, NW_SMALL, true, false, DUAL_RPW>(a, gp, smem, load_graph(a.graph_desc + gp));
       return;
     }
-    spec_backward_body<FIN, FOUT, NW_LARGE, false, false>(a, first + blk, smem);
+    {
+      const GraphRec g = load_graph(a.graph_desc + first + blk);
+      if (g.n <= 2 * NW_LARGE) spec_backward_body<FIN, FOUT, NW_LARGE, false, false, 2>(a, first + blk, smem, g);     // (uniform)
+      else spec_backward_body<FIN, FOUT, NW_LARGE, false, false>(a, first + blk, smem, g);
+    }
   } else {
     if constexpr (NW == NW_LARGE) {
       if (a.tail_tiles > 0 && (int)blockIdx.x >= (int)gridDim.x - a.tail_tiles) {
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
         return;
       }
     }
-    spec_backward_body<FIN, FOUT, NW, false, false>(a, first + (int)blockIdx.x, smem);
+    spec_backward_body<FIN, FOUT, NW, false, false>(a, first + (int)blockIdx.x, smem, load_graph(a.graph_desc + first + (int)blockIdx.x));
   }
 }
 
