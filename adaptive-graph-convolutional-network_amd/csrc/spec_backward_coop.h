@@ -42,6 +42,10 @@ constexpr int DUAL_MAX_N = 16;         // graphs that may be packed two to a wor
 // (spec_coop_lds_bytes): lanes cover MAXN columns in MAXN / 64 passes, a wave owns MAXN / 16 rows of an image (register arrays),
 // the epoch table has MAXN / 16 entries -- the member code is templated on MAXN:
 constexpr int COOP_MAX_N = 128;
+// ... and a variant for graphs of up to 64 nodes (one column pass, four rows of an image per wave): the unrolled per-row / per-pass loops
+// of the 128-node code run eight / two iterations whatever the graph -- dead ones are predicated off but issued (the headline batch's
+// members all have 33-59 nodes)
+constexpr int COOP_SMALL_N = 64;
 // ... and the WIDE members (a kernel variant of their own, launched only for a batch with such a graph: spec_backward.hip):
 // three 64-column passes, 12 rows of an image per wave -- HIV-shaped batches: 5.6 % have a molecule beyond 128 atoms, none beyond 192
 constexpr int COOP_MAX_N_WIDE = 192;
@@ -151,7 +155,7 @@ __device__ __forceinline__ uint64_t coop_pack(float v, uint32_t flag) {
 // evaluated for (i, j) AND (j, i) by the thread that owns (row i of the strip, column j): the row strips of L_pre / L_prev /
 // dL_sum arrive as coalesced loads, the column strips as gathers, all in that thread's registers.
 template <int FIN, int FOUT, bool RESLAP = false, int MAXN = COOP_MAX_N>
-__device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int sl, float* smem) {
+__device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int sl, float* smem, const SlabRec& srec) {
   __shared__ float coop_gs[MAXN / 16];
   constexpr int NCP = MAXN / 64;               // 64-column passes of a strip row (lanes cover MAXN columns)
   constexpr int NW = 16, NT = 1024;
@@ -162,7 +166,6 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const SlabRec srec = load_slab(a.slab_desc + sl);
   const int b = srec.b, i0 = srec.i0, n = srec.n, row0 = srec.row0;
   const uint32_t toff = srec.toff;
   const CoopLds d = coop_lds(n, F4, FOUT, a.g_np);
@@ -886,7 +889,7 @@ AGCN_HD inline CoopFwdLds coop_fwd_lds(int n, int F4, int np = 0) {
 // RESLAP (SGC_LL_Reslap, graphconv_reslap.py:184-198): the two clip_by_norm stages need ||R||_F and ||L_pre||_F of the WHOLE graph:
 // two more exchanges (coop_graph_sum), the same sums in the same order in every member.
 template <int FIN, int FOUT, bool RESLAP = false, int MAXN = COOP_MAX_N>
-__device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int sl, float* smem) {
+__device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int sl, float* smem, const SlabRec& srec) {
   __shared__ float coop_gs[MAXN / 16];
   constexpr int NCP = MAXN / 64;               // 64-column passes of a strip row (lanes cover MAXN columns)
   constexpr int NW = 16;
@@ -897,7 +900,6 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
   const int lane = tid & 63, wave = uni(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   AGCN_STAMP(0, 14);
-  const SlabRec srec = load_slab(a.slab_desc + sl);
   const int b = srec.b, i0 = srec.i0, n = srec.n, row0 = srec.row0;
   const uint32_t toff = srec.toff;
   // Z = X M_L on the bf16 pipe (spec_bfpipe.h) where this graph's planes + the M_L image fit the launch's LDS

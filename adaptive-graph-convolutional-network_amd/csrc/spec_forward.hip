@@ -631,7 +631,11 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     int blk = (int)blockIdx.x;
     if constexpr (NW == NW_LARGE) {
       if (blk < a.coop_slabs) {
-        coop_forward_member<FIN, FOUT, true, MAXN>(a, blk, smem);
+        {
+          const SlabRec srec = load_slab(a.slab_desc + blk);
+          if (MAXN == COOP_MAX_N && srec.n <= COOP_SMALL_N) coop_forward_member<FIN, FOUT, true, MAXN == COOP_MAX_N ? COOP_SMALL_N : MAXN>(a, blk, smem, srec);     // (uniform)
+          else coop_forward_member<FIN, FOUT, true, MAXN>(a, blk, smem, srec);
+        }
         return;
       }
       blk -= a.coop_slabs;
@@ -645,7 +649,11 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     // grid: [members of the cooperative graphs][one workgroup per graph: plain_count][two small graphs per workgroup]
     int blk = (int)blockIdx.x;
     if (blk < a.coop_slabs) {   // (spec_backward_coop.h)
-      coop_forward_member<FIN, FOUT, false, MAXN>(a, blk, smem);
+      {
+          const SlabRec srec = load_slab(a.slab_desc + blk);
+          if (MAXN == COOP_MAX_N && srec.n <= COOP_SMALL_N) coop_forward_member<FIN, FOUT, false, MAXN == COOP_MAX_N ? COOP_SMALL_N : MAXN>(a, blk, smem, srec);     // (uniform)
+          else coop_forward_member<FIN, FOUT, false, MAXN>(a, blk, smem, srec);
+        }
       return;
     }
     blk -= a.coop_slabs;
