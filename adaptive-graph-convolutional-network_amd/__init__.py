@@ -14,7 +14,7 @@ from .graphs import (SequentialGraphMol, ResidualGraphMol, ResidualGraphMolResLa
 from .store import GraphStore, ResidentStore  # noqa: F401
 from .engine import GraphedStep, SgcLLEpochLanes, SgcLLEpochPipeline, SgcLLEpochStep, SgcLLStep  # noqa: F401
 from .functional import (check_device_status, capture_scope, release_reserve_pool, reserve_pool_bytes,  # noqa: F401
-                         dispatch, run_checked, device_timeouts, recovered_calls, param_grad_fork)
+                         dispatch, run_checked, device_timeouts, recovered_calls, param_grad_fork, no_member_flags)
 from . import dist  # noqa: F401
 
 __version__ = "0.1.0"

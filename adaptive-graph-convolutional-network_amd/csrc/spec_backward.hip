@@ -782,6 +782,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     {
       const GraphRec g = load_graph(a.graph_desc + first + blk);
       if (NW == NW_LARGE && g.n <= 2 * NW) spec_backward_body<FIN, FOUT, NW, false, true, NW == NW_LARGE ? 2 : 0>(a, first + blk, smem, g);
+      else if (NW == NW_LARGE && g.n <= 4 * NW) spec_backward_body<FIN, FOUT, NW, false, true, NW == NW_LARGE ? 4 : 0>(a, first + blk, smem, g);
       else spec_backward_body<FIN, FOUT, NW, false, true>(a, first + blk, smem, g);
     }
   } else if constexpr (FULL) {
@@ -809,6 +810,7 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
     {
       const GraphRec g = load_graph(a.graph_desc + first + blk);
       if (g.n <= 2 * NW_LARGE) spec_backward_body<FIN, FOUT, NW_LARGE, false, false, 2>(a, first + blk, smem, g);     // (uniform)
+      else if (g.n <= 4 * NW_LARGE) spec_backward_body<FIN, FOUT, NW_LARGE, false, false, 4>(a, first + blk, smem, g);
       else spec_backward_body<FIN, FOUT, NW_LARGE, false, false>(a, first + blk, smem, g);
     }
   } else {

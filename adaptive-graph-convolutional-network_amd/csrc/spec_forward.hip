@@ -33,7 +33,9 @@ constexpr int MAXT = 3;   // most MFMA tiles of one phase a wave may own (accumu
 // sequence of them (every barrier of the body is in control flow that depends on the launch arguments only).
 // RESLAP: SGC_LL_Reslap (graphconv_reslap.py:184-198): clip_by_norm on R and on the combined Laplacian (two graph-wide
 // Frobenius norms), + beta L_prev, the pre-clip Laplacian kept for the backward, L_sum = the 4th output.
-template <int FIN, int FOUT, int NW, bool DUAL, bool RESLAP = false>
+// RPWC > 0 (Reslap): the body for graphs whose waves own at most RPWC rows of the tile (n4 <= RPWC NW): the unrolled per-row loops over
+// this thread's L_prev elements then have RPWC iterations instead of 6 | 8 (spec_backward.hip: the dead ones are issued all the same)
+template <int FIN, int FOUT, int NW, bool DUAL, bool RESLAP = false, int RPWC = 0>
 __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gpos, float* smem_) {
   constexpr int NT = 64 * NW;
   using FT = Feat<FIN>;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
   }
   // Reslap: this thread's elements of L_prev (rows wave + NW u, columns lane + 64 cp), requested with the first round of
   // loads: in F3 they would sit behind the res_W / res_L stores (one in-order counter for loads and stores)
-  constexpr int RPWF = NW == NW_SMALL ? 6 : 8;
+  constexpr int RPWF = RPWC > 0 ? RPWC : (NW == NW_SMALL ? 6 : 8);
   float lprv[RESLAP ? RPWF : 1][2];
   if constexpr (RESLAP) {
 #pragma unroll
@@ -640,9 +642,15 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
       }
       blk -= a.coop_slabs;
       if (blk >= a.plain_count) {
-        spec_forward_body<FIN, FOUT, NW_SMALL, true, true>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
+        // (paired graphs have at most DUAL_MAX_N = 16 nodes: two tile rows per wave of their eight)
+        spec_forward_body<FIN, FOUT, NW_SMALL, true, true, 2>(a, first + a.plain_count + 2 * (blk - a.plain_count) + (int)(threadIdx.x >> 9), smem);
         return;
       }
+    }
+    if constexpr (NW == NW_LARGE) {
+      const int npk = load_graph(a.graph_desc + first + blk).n;      // (uniform; the body reads the record again: scalar cache)
+      if (npk <= 2 * NW_LARGE) { spec_forward_body<FIN, FOUT, NW_LARGE, false, true, 2>(a, first + blk, smem); return; }
+      if (npk <= 4 * NW_LARGE) { spec_forward_body<FIN, FOUT, NW_LARGE, false, true, 4>(a, first + blk, smem); return; }
     }
     spec_forward_body<FIN, FOUT, NW, false, true>(a, first + blk, smem);
   } else if constexpr (FULL) {
