@@ -820,7 +820,13 @@ __global__ __launch_bounds__(64 * NW, NW == NW_SMALL ? (FIN > 80 ? 4 : AGCN_SMAL
         return;
       }
     }
-    spec_backward_body<FIN, FOUT, NW, false, false>(a, first + (int)blockIdx.x, smem, load_graph(a.graph_desc + first + (int)blockIdx.x));
+    {
+      const GraphRec g = load_graph(a.graph_desc + first + (int)blockIdx.x);
+      // (the launches without members or pairs -- batches of 1024 graphs and up on eight waves, or sixteen -- by the rows a wave owns)
+      if (g.n <= 2 * NW) spec_backward_body<FIN, FOUT, NW, false, false, 2>(a, first + (int)blockIdx.x, smem, g);     // (uniform)
+      else if (g.n <= 4 * NW) spec_backward_body<FIN, FOUT, NW, false, false, 4>(a, first + (int)blockIdx.x, smem, g);
+      else spec_backward_body<FIN, FOUT, NW, false, false>(a, first + (int)blockIdx.x, smem, g);
+    }
   }
 }
 
