@@ -124,6 +124,22 @@ def main():
             for k in slots:
                 if per[k][0]:
                     print("    %-20s last workgroup starts at %.2f, last one ends at %.2f us of the launch" % (names[k], np.median(per[k][0]), np.median(per[k][1])))
+    # launch boundaries inside the last step of the sequence (absolute 100 MHz clocks): last stamp of one launch -> first stamp of the next
+    if seq.endswith("fb") or not seq:
+        def ends(r, slots):
+            v = np.concatenate([r[k][r[k][:, 0] > 0] for k in slots])
+            return np.where(v > 0, v, np.iinfo(np.int64).max).min(), v.max()
+        gaps = {"forward -> backward": [], "backward -> param-grad": []}
+        for r in runs:
+            try:
+                f0, f1 = ends(r, (0, 1)); b0, b1 = ends(r, (5, 4)); p0, p1 = ends(r, (7,))
+            except ValueError:
+                continue
+            gaps["forward -> backward"].append((b0 - f1) / 100.0)
+            gaps["backward -> param-grad"].append((p0 - b1) / 100.0)
+        for k, v in gaps.items():
+            if v:
+                print("boundary %-24s last stamp -> first stamp of the next launch: median %.2f us" % (k, np.median(v)))
 
 
 if __name__ == "__main__":
