@@ -962,8 +962,11 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
           const int c = min(lane + 64 * cp, FIN - 1);
-          if constexpr (decltype(BF)::value) xr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
-          else xr[u][cp] = Xg[ro + c];
+          xr[u][cp] = 0.f;
+          if (ib + NW * u < n4) {      // (uniform: rows beyond the image are not requested)
+            if constexpr (decltype(BF)::value) xr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
+            else xr[u][cp] = Xg[ro + c];
+          }
         }
       }
     });

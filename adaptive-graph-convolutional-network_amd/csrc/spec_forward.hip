@@ -95,8 +95,13 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
           const int c = min(lane + 64 * cp, FIN - 1);
-          if constexpr (decltype(BF)::value) xr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
-          else xr[u][cp] = Xg[ro + c];
+          xr[u][cp] = 0.f;
+          // (a UNIFORM bound: rows beyond the image are not requested at all -- a two-tile graph on sixteen waves has two of these
+          //  four rows, and the clamped requests of the other two were half of the phase's bytes through the CU's address path)
+          if (i0 + NW * u < n4) {
+            if constexpr (decltype(BF)::value) xr[u][cp] = bf16_load(a.X, (int64_t)row0 * a.ldx + ro + c);
+            else xr[u][cp] = Xg[ro + c];
+          }
         }
       }
     });
