@@ -210,6 +210,9 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
     const int fs = 1 << fs_log;
     const int part = tid & (fs - 1);
     const int step = fs >= 4 ? 4 : fs;        // results of a block handled per lane group pass
+    // (a wave whose threads all lie beyond the loop's cnt * fs work items skips it -- a uniform branch: walking through its index
+    //  arithmetic and reductions at the lowest issue priority took the idle waves 1.3 us, and they carry the T_0 work below)
+    if (64 * wave < cnt * fs)
     for (int tb = 0; tb < cnt * fs; tb += NT) {
       const int t = (tb + tid) >> fs_log;
       int bi = 0, bj = 0;
@@ -292,6 +295,11 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
     }
     AGCN_STAMP(1, 12);
   }
+  lds_barrier();
+  AGCN_STAMP(1, 3);
+  AGCN_STAMP_T(1, 13, 64 * NW - 64);
+  // (beside the DEGREE phase, where one wave sums the columns and fifteen wait: beside the pair loop F2 the wave that has both a share
+  //  of the pairs and a tile was the last one at F2's barrier by 1.1 us)
   if constexpr (EARLYF) {   // T_0 = X_0 W_0 of this wave's F5 tiles (two fragment buffers: the next tile's is in flight)
 #pragma unroll
     for (int sl = 0; sl < MAXT; ++sl) {
@@ -313,10 +321,11 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         yacc[sl] = acc;
       }
     }
+    AGCN_STAMP_T(1, 14, 64 * NW - 64);
     if (t5a < t5b) load_w(bW1, t5a, 1);     // first W_1 fragment: consumed in F5
   }
-  lds_barrier();
-  AGCN_STAMP(1, 3);
+  AGCN_STAMP_T(1, 15, 64 * NW - 64);
+
   // degree: column sums in row order (numpy's axis-0 order), s = d^-1/2   graphconv.py:195-197
   if (tid < n) {
     float dsum = 0.f;
