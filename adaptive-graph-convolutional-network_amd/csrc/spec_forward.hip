@@ -171,10 +171,11 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       }
     }
   }
-  // W fragments of this wave's F5 tiles.  (ROOMY: 16-wave launches) the tiles go to the LAST waves -- the ones the pair phase F2 leaves
-  // idle (its 2 x 2 blocks fill the first waves) -- and their first term T_0 = X_0 W_0, which depends on nothing but the X image,
-  // runs THERE, beside F2; F5 then only adds X_1 W_1 onto the same accumulators (the same instruction sequence per accumulator,
-  // split in time: the same bits).  F5 is bound by the fp32 matrix pipe (two-tile graph: 8 tiles x 38 chained MFMAs = 1.0 us of
+  // W fragments of this wave's F5 tiles.  (ROOMY: 16-wave launches) the tiles go to the LAST waves -- away from wave 0, which sums the
+  // degree's columns alone -- and their first term T_0 = X_0 W_0, which depends on nothing but the X image, runs beside that DEGREE
+  // phase (fifteen waves wait there); F5 then only adds X_1 W_1 onto the same accumulators (the same instruction sequence per
+  // accumulator, split in time: the same bits).  (First placed beside the pair loop F2: the one wave with both a share of the pairs
+  // and a tile was then the last one at F2's barrier.)  F5 is bound by the fp32 matrix pipe (two-tile graph: 8 tiles x 38 chained MFMAs = 1.0 us of
   // pipe time): half of it moves into a phase that does not use the pipe.  (The standalone 8-wave kernels live within 80 registers:
   // there both terms stay in F5.)
   constexpr bool ROOMY = NW == NW_LARGE || DUAL;
