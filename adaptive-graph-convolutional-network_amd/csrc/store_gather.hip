@@ -101,8 +101,8 @@ extern "C" size_t agcn_store_stage_bytes(int32_t B, int64_t rows) {
   std::vector<int32_t> n((size_t)B, (int32_t)(rows / B));
   n[0] += (int32_t)(rows - (rows / B) * B);
   size_t plan = agcn_plan_bytes_for(n.data(), B, 0);
-  // slab tables: 8 bytes per slab; uneven graphs have at most B more slabs than the even split
-  plan += 8 * (size_t)B + 64;
+  // slab tables: 8 bytes (slab_graph, slab_row) + one AgcnSlabDesc per slab; uneven graphs have at most B more slabs than the even split
+  plan += (8 + sizeof(AgcnSlabDesc)) * (size_t)B + 64;
   return agcn::align16(plan) + sizeof(agcn::GatherRec) * (size_t)B;
 }
 

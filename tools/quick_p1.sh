@@ -1,6 +1,6 @@
 # same-box A/B of two builds of the library through AGCN_HIP_LIB: tools/build/libagcn_base.so (a copy of an EARLIER build -- check that
 # revision out, `python -c "import __graft_entry__ as g; g.build()"`, `cp adaptive-graph-convolutional-network_amd/lib/libagcn_hip.so
-# tools/build/libagcn_base.so`; same ABI version, or the Python side refuses it) against the in-tree one, three alternations of the
+# tools/build/libagcn_base.so`; an older ABI works as long as its structures only GREW since) against the in-tree one, three alternations of the
 # headline bench; before it (FULL=1: the whole GPU suite, else) the parity tests that exercise the members, and the phase stamps of a
 # steady-state launch sequence (tools/stamps.py --build first: the stamps library is a build of its own)
 cd $GRAFT_REPO_ROOT
