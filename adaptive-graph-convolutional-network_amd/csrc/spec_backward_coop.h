@@ -1046,16 +1046,14 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       } else if (ml_staged) {   // (uniform) fragments from the staged matrix: rows 4 u + q (zero from row FIN on, as the A image's columns)
       const float* p = MLs + q * SML + cb * 16 + r;
       const float* Ap = Ximg + (rt * 16 + r) * LDX + q;
-#pragma unroll
-      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], p[4 * u * SML], acc, 0, 0, 0);
+      acc = mfma_chain2<NKS>(Ap, p, 4 * SML, acc);
       } else {
       const float* p = mq + min(cb * 16 + r, FIN - 1);
       float bf[NKS];
 #pragma unroll
       for (int u = 0; u < NKS; ++u) bf[u] = (4 * u + 3 < FIN) ? p[4 * u * FIN] : p[(min(4 * u + q, FIN - 1) - q) * FIN];
       const float* Ap = Ximg + (rt * 16 + r) * LDX + q;
-#pragma unroll
-      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
+      acc = mfma_chain<NKS>(Ap, bf, acc);
       }
       const int c = cb * 16 + r, ib = rt * 16 + 4 * q;
       if (c < FIN) {
@@ -1232,8 +1230,7 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
     }
     ybias = a.bias[ob * 16 + r];
     const float* A0 = Ximg + (me * 16 + r) * LDX + q;
-#pragma unroll
-    for (int u = 0; u < NKS; ++u) yacc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], w0[u], yacc, 0, 0, 0);
+    yacc = mfma_chain<NKS>(A0, w0, yacc);
   }
   if (paper && tid < n && (tid < i0 || tid >= i0 + 16)) {
     bool got;
@@ -1434,11 +1431,9 @@ __device__ __forceinline__ void coop_forward_member(const SgcArgs& a, const int 
       }
       bias = a.bias[ob * 16 + r];
       const float* A0 = Ximg + (me * 16 + r) * LDX + q;
-#pragma unroll
-      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], w0[u], acc, 0, 0, 0);
+      acc = mfma_chain<NKS>(A0, w0, acc);
     }
-#pragma unroll
-    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * u], w1[u], acc, 0, 0, 0);
+    acc = mfma_chain<NKS>(A1, w1, acc);
     float* Yg = a.Y + (int64_t)row0 * a.ldy;
     const int c = ob * 16 + r;
 #pragma unroll

@@ -152,8 +152,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       const int rt = t / NCB, cb = t - rt * NCB;
       const float* Ap = Ximg + (rt * 16 + r) * LDX + q;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], bf[u], acc, 0, 0, 0);
+      acc = mfma_chain<NKS>(Ap, bf, acc);
       const int c = cb * 16 + r, i0 = rt * 16 + 4 * q;
       if (c < FIN) {
         *reinterpret_cast<f32x4*>(Zt + c * ldz + i0) = acc;   // rows >= n come out 0 (zero rows of the X image)
@@ -162,6 +161,7 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
           if (i0 + i4 < n) AGCN_ST(2, &Zg[(i0 + i4) * FIN + c], acc[i4]);
       }
     };
+    AGCN_STAMP_T(1, 13, 64 * 9);      // (wave 9: the last wave with an F1 tile of a two-tile graph)
     for (int t = t1a; t < t1b; t += 2) {
       if (t + 1 < t1b) load_m(bB, t + 1);
       tile_f1(bA, t);
@@ -195,9 +195,11 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
   f32x4 yacc[MAXT];
   float ybias[MAXT];
   float bW1[ROOMY ? NKS : 1];
+  AGCN_STAMP_T(1, 14, 64 * 9);
   if constexpr (EARLYF) {
     if (t5a < t5b) load_w(bA, t5a, 0);      // (its round trip overlaps the barrier and the pair loop)
   }
+  AGCN_STAMP_T(1, 15, 64 * 9);
   lds_barrier();
 
   AGCN_STAMP(1, 2);
@@ -298,7 +300,6 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
   }
   lds_barrier();
   AGCN_STAMP(1, 3);
-  AGCN_STAMP_T(1, 13, 64 * NW - 64);
   // (beside the DEGREE phase, where one wave sums the columns and fifteen wait: beside the pair loop F2 the wave that has both a share
   //  of the pairs and a tile was the last one at F2's barrier by 1.1 us)
   if constexpr (EARLYF) {   // T_0 = X_0 W_0 of this wave's F5 tiles (two fragment buffers: the next tile's is in flight)
@@ -312,20 +313,16 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if ((sl & 1) == 0) {
           if (t + 1 < t5b) load_w(bB, t + 1, 0);
-#pragma unroll
-          for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bA[u], acc, 0, 0, 0);
+          acc = mfma_chain<NKS>(A0, bA, acc);
         } else {
           if (t + 1 < t5b) load_w(bA, t + 1, 0);
-#pragma unroll
-          for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bB[u], acc, 0, 0, 0);
+          acc = mfma_chain<NKS>(A0, bB, acc);
         }
         yacc[sl] = acc;
       }
     }
-    AGCN_STAMP_T(1, 14, 64 * NW - 64);
     if (t5a < t5b) load_w(bW1, t5a, 1);     // first W_1 fragment: consumed in F5
   }
-  AGCN_STAMP_T(1, 15, 64 * NW - 64);
 
   // degree: column sums in row order (numpy's axis-0 order), s = d^-1/2   graphconv.py:195-197
   if (tid < n) {
@@ -542,12 +539,10 @@ __device__ __forceinline__ void spec_forward_body(const SgcArgs& a, const int gp
       } else {
         ybias[sl] = a.bias[ob * 16 + r];
         const float* A0 = Ximg + (rt * 16 + r) * LDX + q;
-#pragma unroll
-        for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[4 * u], bA[u], acc, 0, 0, 0);
+        acc = mfma_chain<NKS>(A0, bA, acc);
         if (t + 1 < t5b) load_w(bA, t + 1, 0);
       }
-#pragma unroll
-      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * u], bB[u], acc, 0, 0, 0);
+      acc = mfma_chain<NKS>(A1, bB, acc);
       yacc[sl] = acc;
     }
   }

@@ -220,6 +220,44 @@ __device__ __forceinline__ SlabRec load_slab(const AgcnSlabDesc* sd) {
   return g;
 }
 
+// acc += sum_u A[4 u] b[u] over NKS k-steps of v_mfma_f32_16x16x4_f32, A an LDS image row (this lane's k column: stride 4 floats): ALL the
+// A operands are read before the first matrix instruction.  Left to itself the compiler reads a pair into ONE register pair, waits for
+// it, issues two instructions and reads the next pair -- an LDS round trip per two links: ~1750 cycles for a 19-link chain that takes
+// 19 x 40 when its operands are there (tools/stamps.py: 1.36 us for the one F1 tile of a wave).  The scheduling barrier keeps the reads in
+// front of the instructions (an empty asm with a memory clobber did not: the reads were sunk back to their uses).  Same instructions in the same order per accumulator: same bits.
+// (Chains of more than 20 links -- 128 input features -- keep the plain loop: 32 more live registers would spill.)
+template <int NKS>
+__device__ __forceinline__ f32x4 mfma_chain(const float* Ap, const float (&b)[NKS], f32x4 acc) {
+  if constexpr (NKS <= 20) {
+    float av[NKS];
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) av[u] = Ap[4 * u];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], b[u], acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], b[u], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// ... both operands LDS image rows (B: this lane's column, `bs` floats between k rows 4 u and 4 u + 4)
+template <int NKS>
+__device__ __forceinline__ f32x4 mfma_chain2(const float* Ap, const float* Bp, int bs, f32x4 acc) {
+  if constexpr (NKS <= 20) {
+    float av[NKS], bv[NKS];
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) { av[u] = Ap[4 * u]; bv[u] = Bp[u * bs]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], Bp[u * bs], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 // red: 32 floats of the body's LDS; contains barriers: uniform control flow only
 template <int NW>
 __device__ __forceinline__ float body_sum(float v, float* red, int tid) {
