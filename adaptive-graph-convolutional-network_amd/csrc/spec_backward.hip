@@ -426,8 +426,7 @@ __device__ __forceinline__ void spec_backward_body(const SgcArgs& a, const int g
         const float* Ap = G1img + (rt * 16 + r) * LDX + q;
         const float* Bp = X0img + (ct * 16 + r) * LDX + q;   // B[k][j] = X_0[j][k]
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], Bp[4 * u], acc, 0, 0, 0);
+        acc = mfma_chain2<NKS>(Ap, Bp, 4, acc);
         const int j = ct * 16 + r, i0 = rt * 16 + 4 * q;
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {

@@ -516,8 +516,7 @@ __device__ __forceinline__ void coop_backward_member(const SgcArgs& a, const int
       const float* Ap = (col ? X0img : G1img) + (me * 16 + r) * LDX + q;
       const float* Bp = (col ? G1img : X0img) + (ct * 16 + r) * LDX + q;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < NKS; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[4 * u], Bp[4 * u], acc, 0, 0, 0);
+      acc = mfma_chain2<NKS>(Ap, Bp, 4, acc);
       float* dst = (col ? DLc : DLr) + (4 * q) * ldt + ct * 16 + r;
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) dst[i4 * ldt] = acc[i4];
